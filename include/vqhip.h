@@ -1,0 +1,118 @@
+/*
+ * vqhip.h -- C ABI of libvqhip.so, the MI355X (gfx950 / CDNA4) vector-quantization hot path.
+ *
+ * The reference (lucidrains/vector-quantize-pytorch v1.31.0) is pure Python and has no FFI; its
+ * seam is `VectorQuantize._codebook(x, ...) -> (quantize, embed_ind, dist)`
+ * (vector_quantize_pytorch.py:1176, class Codebook :349-791).  Each entry point below replaces the
+ * ATen op sequence of one stretch of that class; the reference lines are cited per function
+ * ("vqp.py" = vector_quantize_pytorch/vector_quantize_pytorch.py, "rvq.py" = residual_vq.py).
+ *
+ * Conventions
+ *  - plain pointers + sizes, no framework types.  Every pointer is a DEVICE pointer.
+ *  - the caller owns every buffer, including workspaces; the library never allocates, frees or
+ *    synchronises.  All work is enqueued on `stream` (a hipStream_t passed as void*).
+ *  - return value: 0 on success, a negative VQHIP_E* code on argument errors, or a positive
+ *    hipError_t from the launch.  vqhip_last_error() returns a thread-local message.
+ *  - dtype codes: VQHIP_F32 = 0, VQHIP_BF16 = 1.  metric: 0 = euclidean, 1 = cosine.
+ *  - supported shapes: 1 <= D <= 512, C >= 1, N >= 0; rows addressed as base + n * ld (elements).
+ */
+#ifndef VQHIP_H
+#define VQHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VQHIP_F32  0
+#define VQHIP_BF16 1
+
+#define VQHIP_EUCLID 0
+#define VQHIP_COSINE 1
+
+#define VQHIP_EINVAL   (-1)   /* bad argument (null pointer, negative size, unknown dtype) */
+#define VQHIP_EDIM     (-2)   /* D outside the supported range                              */
+#define VQHIP_EALIGN   (-3)   /* pointer / stride alignment requirement violated            */
+
+#define VQHIP_ASSIGN_ROWS_PER_BLOCK 128  /* rows one workgroup of vqhip_assign owns */
+#define VQHIP_STATS_DSLICE 32            /* feature columns one workgroup of vqhip_ema_accumulate owns */
+#define VQHIP_STATS_CCHUNK 1024          /* codes one workgroup of vqhip_ema_accumulate owns */
+
+const char *vqhip_version(void);
+const char *vqhip_last_error(void);
+
+/* ---- codebook preparation -------------------------------------------------------------------
+ * Re-tiles the fp32 codebook `embed` [C, D] into the MFMA A-operand order the assign kernel
+ * streams through LDS, and appends ||c||^2 per code summed in ATen's CPU order (the `y2` term
+ * of cdist, vqp.py:60).  Must be re-run whenever `embed` changes.
+ * packed: caller buffer of vqhip_packed_bytes(C, D) bytes, 16-byte aligned. */
+size_t vqhip_packed_bytes(int C, int D);
+int vqhip_pack_codebook(const float *embed, int C, int D, float *packed, void *stream);
+
+/* ---- nearest-code assignment + gather + commitment-loss partials ------------------------------
+ * Replaces: cdist (vqp.py:58-62) / cosine einsum (:741), the negate + argmax of gumbel_sample's
+ * deterministic branch (:134-145), the one-hot gather (:766, :779-781), l2norm of the input for
+ * the cosine metric (:37-38 applied at :1159) and the squared-error sum of F.mse_loss (:1327).
+ *
+ *  x          [N, D] rows at stride ldx (elements), dtype x_dtype.
+ *  packed     output of vqhip_pack_codebook for the SAME embed.
+ *  embed      [C, D] fp32 (rows are copied verbatim into q_out).
+ *  idx_out    [N] int64: index of the first code attaining the minimum distance (maximum
+ *             similarity for cosine) -- ties resolve to the lowest index like ATen argmax.
+ *  q_out      nullable; [N, D] rows at stride ldq, dtype q_dtype: embed[idx] (rounded RNE for bf16).
+ *  best_out   nullable; [N] fp32: the winning distance (euclid) or similarity (cosine).
+ *  rnorm_out  nullable; [N] fp32: euclid -> ||x||^2 in ATen order; cosine -> max(||x||, 1e-6).
+ *  sqerr_partial  nullable; [vqhip_assign_blocks(N)] doubles: per-workgroup sum over its rows of
+ *             sum_d (q - x)^2 (x = l2-normalised x for cosine), rows with row_mask == 0 excluded.
+ *  row_mask   nullable; [N] bytes (vqp.py:599-600, 1317-1325 semantics: 0 = padding row).
+ */
+int64_t vqhip_assign_blocks(int64_t N);
+int vqhip_assign(const void *x, int x_dtype, int64_t N, int D, int64_t ldx,
+                 const float *packed, const float *embed, int C, int metric,
+                 int64_t *idx_out, void *q_out, int q_dtype, int64_t ldq,
+                 float *best_out, float *rnorm_out, double *sqerr_partial,
+                 const uint8_t *row_mask, void *stream);
+
+/* sum of `n` doubles times `scale` -> one fp32 (commit loss = scale * sum of partials). */
+int vqhip_reduce_partials(const double *partials, int64_t n, double scale, float *out, void *stream);
+
+/* ---- EMA sufficient statistics ----------------------------------------------------------------
+ * Replaces embed_onehot.sum(1) and einsum('h n d, h n c -> h c d') (vqp.py:602, 605).
+ * count [C] and embed_sum [C, D] fp32 are ACCUMULATED INTO (zero them first, e.g. hipMemsetAsync).
+ * Rows with idx < 0 or row_mask == 0 are skipped.  For metric == cosine the rows are divided by
+ * rnorm[n] (the value vqhip_assign wrote) before accumulation, i.e. the l2-normalised input.
+ * Implementation: per-workgroup LDS-privatised [1024 codes x 32 columns] fp32 accumulators
+ * (ds_add_f32), flushed with global fp32 atomics. */
+int vqhip_ema_accumulate(const void *x, int x_dtype, int64_t N, int D, int64_t ldx,
+                         const int64_t *idx, int64_t idx_stride, const float *rnorm, int metric,
+                         const uint8_t *row_mask, int C,
+                         float *count, float *embed_sum, void *stream);
+
+/* ---- EMA fold + codebook renormalisation ------------------------------------------------------
+ * Replaces ema_inplace x2 (vqp.py:76-97, ATen lerp_ semantics), laplace_smoothing + update_ema
+ * (:152-154, :576-584).  In place on cluster_size [C], embed_avg [C, D], embed [C, D].
+ *   do_lerp        fold count / embed_sum into cluster_size / embed_avg with weight
+ *                  w = (1 - decay) * (weight ? weight[c] : 1).
+ *   do_update_ema  embed = embed_avg / ((cs + eps) / (sum cs + C eps) * sum cs) [, l2norm if cosine].
+ * denom_ws: caller workspace of C floats. */
+int vqhip_ema_finalize(float *cluster_size, float *embed_avg, float *embed,
+                       const float *count, const float *embed_sum, const float *weight,
+                       int C, int D, float one_minus_decay, float eps, int cosine,
+                       int do_lerp, int do_update_ema, float *denom_ws, void *stream);
+
+/* ---- decode -----------------------------------------------------------------------------------
+ * Replaces codebook[indices] (vqp.py:1003) and get_at('q [c] d, b n q -> q b n d') + sum over q
+ * (rvq.py:341-381).  out[n, :] = sum_q embed_q[idx[n, q], :], idx < 0 contributing zero.
+ * embed: Q codebooks [C, D] each at stride embed_qstride floats (0 => shared codebook). */
+int vqhip_decode_sum(const int64_t *idx, int64_t N, int Q, const float *embed, int64_t embed_qstride,
+                     int C, int D, void *out, int out_dtype, int64_t ldo, void *stream);
+
+/* ---- ATen-order row sum of squares (vqp.py:59) -- exposed for tests / odd D -------------------- */
+int vqhip_row_sumsq(const void *x, int x_dtype, int64_t N, int D, int64_t ldx, float *out, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VQHIP_H */

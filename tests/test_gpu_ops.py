@@ -1,0 +1,183 @@
+"""GPU parity tests of the C-ABI entry points against the oracle (oracle/vq_oracle.{c,py}).
+
+Bars: indices bit-exact vs the deterministic ("chain") oracle; the winning distance bit-exact too
+(which pins the MFMA k-order, the ATen-order norms, the association and the sqrt rounding);
+floating-point statistics within 1e-5 relative (fp32) as BASELINE.json's north_star states.
+"""
+import pytest
+import torch
+
+from oracle import vq_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _mk(N, C, D, dtype=torch.float32, unit=False, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(N, D, generator=g)
+    if unit:
+        e = torch.randn(C, D, generator=g)
+    else:  # kaiming-uniform-like tiny codebook: the worst case for near-ties (SURVEY §7 hard part 1)
+        bound = (6.0 / (C * D)) ** 0.5
+        e = (torch.rand(C, D, generator=g) * 2 - 1) * bound
+    x = x.to(dtype)
+    return x, e
+
+
+@pytest.mark.parametrize("N,D", [(1000, 256), (777, 100), (64, 8), (333, 512), (5, 2), (4096, 128), (130, 40)])
+def test_row_sumsq_matches_aten_order(dev, N, D):
+    from vector_quantize_pytorch_amd import _lib as L
+    x, _ = _mk(N, 4, D)
+    got = L.row_sumsq(x.to(dev)).cpu()
+    want = (x ** 2).sum(-1)                      # live ATen on this host
+    want_c = O.c_row_sumsq(x)                    # C restatement
+    assert torch.equal(want, want_c)
+    assert torch.equal(got, want_c)
+
+
+@pytest.mark.parametrize("N,C,D,dtype,unit", [
+    (1024, 512, 256, torch.float32, False),      # BASELINE cfg 1 shape
+    (1024, 512, 256, torch.float32, True),
+    (4099, 1024, 256, torch.bfloat16, False),    # cfg 2 dtype, ragged N
+    (2048, 1024, 256, torch.float32, False),
+    (513, 100, 64, torch.float32, True),         # C not a multiple of 32
+    (300, 37, 100, torch.float32, True),         # odd D -> pre-pass norms + scalar loads
+    (257, 5, 2, torch.float32, True),            # test_tiger-like tiny dims (rvq.py codebook sizes (5,128,256), dim 2)
+    (1000, 4096, 128, torch.float32, False),     # cfg 5 per-group shape
+    (640, 2048, 512, torch.float32, False),      # cfg 4 dim
+    (1, 16, 32, torch.float32, True),
+])
+def test_assign_euclid_bitexact(dev, N, C, D, dtype, unit):
+    from vector_quantize_pytorch_amd import _lib as L
+    x, e = _mk(N, C, D, dtype, unit)
+    xd, ed = x.to(dev), e.to(dev)
+    packed = L.pack_codebook(ed)
+    r = L.assign(xd, packed, ed, want_q=True, want_sqerr=True, want_best=True, want_rnorm=True)
+    idx_o, best_o = O.c_assign(x.float(), e)
+    idx = r["idx"].cpu()
+    mism = (idx != idx_o).sum().item()
+    assert mism == 0, f"{mism}/{N} index mismatches vs chain oracle"
+    assert torch.equal(r["best"].cpu(), best_o), "winning distance differs bitwise"
+    assert torch.equal(r["rnorm"].cpu(), O.c_row_sumsq(x.float()))
+    q = r["q"].cpu()
+    want_q = e[idx_o].to(dtype)
+    assert torch.equal(q, want_q)
+    sq = r["sqerr_partials"][: r["nblk"]].sum().item()
+    want_sq = ((want_q.double() - x.double()) ** 2).sum().item()
+    assert abs(sq - want_sq) <= 1e-5 * max(want_sq, 1e-12)
+
+
+@pytest.mark.parametrize("N,C,D,dtype", [(1024, 512, 256, torch.float32), (999, 1000, 512, torch.float32),
+                                         (2048, 1024, 256, torch.bfloat16), (300, 37, 100, torch.float32)])
+def test_assign_cosine_bitexact(dev, N, C, D, dtype):
+    from vector_quantize_pytorch_amd import _lib as L
+    x, e = _mk(N, C, D, dtype, unit=True)
+    e = O.l2norm(e)
+    xd, ed = x.to(dev), e.to(dev)
+    packed = L.pack_codebook(ed)
+    r = L.assign(xd, packed, ed, cosine=True, want_q=True, want_sqerr=True, want_best=True, want_rnorm=True)
+    xn = O.c_l2norm(x.float())
+    if dtype == torch.bfloat16:   # the reference normalises bf16 inputs in bf16 (vqp.py:1159 before :692)
+        nrm = O.c_row_sumsq(x.float()).sqrt().bfloat16().float().clamp(min=1e-6)
+        xn = (x.float() / nrm[:, None]).bfloat16().float()
+    idx_o, best_o = O.c_assign(xn, e, cosine=True)
+    assert (r["idx"].cpu() != idx_o).sum().item() == 0
+    assert torch.equal(r["best"].cpu(), best_o)
+    want_q = e[idx_o].to(dtype)
+    assert torch.equal(r["q"].cpu(), want_q)
+    sq = r["sqerr_partials"][: r["nblk"]].sum().item()
+    want_sq = ((want_q.double() - xn.double()) ** 2).sum().item()
+    assert abs(sq - want_sq) <= 1e-5 * max(want_sq, 1e-12)
+
+
+def test_assign_ties_lowest_index(dev):
+    """duplicate codes: the first copy must win (ATen argmax first-occurrence, vqp.py:140)."""
+    from vector_quantize_pytorch_amd import _lib as L
+    x, e = _mk(512, 96, 64, unit=True)
+    e = torch.cat([e, e, e[:7]], 0)              # every code appears twice (or three times)
+    ed = e.to(dev)
+    r = L.assign(x.to(dev), L.pack_codebook(ed), ed)
+    idx = r["idx"].cpu()
+    assert int(idx.max()) < 96
+    assert torch.equal(idx, O.c_assign(x, e)[0])
+
+
+def test_assign_masked_rows_excluded_from_sqerr(dev):
+    from vector_quantize_pytorch_amd import _lib as L
+    x, e = _mk(700, 64, 32, unit=True)
+    m = torch.rand(700) < 0.5
+    ed = e.to(dev)
+    r = L.assign(x.to(dev), L.pack_codebook(ed), ed, want_sqerr=True, row_mask=m.to(dev))
+    idx = r["idx"].cpu()
+    want = (((e[idx] - x) ** 2).sum(-1).double() * m).sum().item()
+    assert abs(r["sqerr_partials"][: r["nblk"]].sum().item() - want) <= 1e-5 * want
+
+
+def test_assign_strided_rows(dev):
+    """feature-chunk views (GroupedResidualVQ's x.chunk(groups, -1), rvq.py:690) need no copy."""
+    from vector_quantize_pytorch_amd import _lib as L
+    x, e = _mk(600, 128, 64, unit=True)
+    big = torch.randn(600, 256)
+    big[:, 64:128] = x
+    xd = big.to(dev)[:, 64:128]
+    ed = e.to(dev)
+    r = L.assign(xd, L.pack_codebook(ed), ed)
+    assert torch.equal(r["idx"].cpu(), O.c_assign(x, e)[0])
+
+
+@pytest.mark.parametrize("N,C,D,dtype,cos", [(5000, 1024, 256, torch.float32, False), (3000, 100, 40, torch.float32, False),
+                                             (4096, 2500, 128, torch.bfloat16, False), (2000, 512, 256, torch.float32, True)])
+def test_ema_accumulate(dev, N, C, D, dtype, cos):
+    from vector_quantize_pytorch_amd import _lib as L
+    x, _ = _mk(N, C, D, dtype, unit=True)
+    idx = torch.randint(0, C, (N,))
+    idx[::17] = -1                                # masked / dropped rows are skipped
+    rn = None
+    xf = x.float()
+    if cos:
+        rn = O.c_row_sumsq(xf).sqrt().clamp(min=1e-6)
+        xf = xf / rn[:, None]
+    cnt, es = L.ema_accumulate(x.to(dev), idx.to(dev), C, cosine=cos, rnorm=None if rn is None else rn.to(dev))
+    cnt_o, es_o = O.c_ema_stats(xf, idx, C)
+    assert torch.equal(cnt.cpu(), cnt_o)
+    scale = es_o.abs().max().item()
+    assert (es.cpu() - es_o).abs().max().item() <= 1e-5 * scale
+
+
+@pytest.mark.parametrize("C,D,cos", [(512, 256, False), (1024, 256, False), (1000, 100, False), (4096, 128, True), (37, 2, False)])
+def test_ema_finalize(dev, C, D, cos):
+    from vector_quantize_pytorch_amd import _lib as L
+    g = torch.Generator().manual_seed(1)
+    cfg = O.VQConfig(dim=D, codebook_size=C, use_cosine_sim=cos)
+    st = O.VQState(embed=torch.randn(1, C, D, generator=g), embed_avg=torch.randn(1, C, D, generator=g),
+                   cluster_size=torch.rand(1, C, generator=g) * 5)
+    count = torch.randint(0, 9, (1, C), generator=g).float()
+    esum = torch.randn(1, C, D, generator=g) * 3
+    d = {k: v.clone().to(dev) for k, v in dict(cs=st.cluster_size[0], ea=st.embed_avg[0], e=st.embed[0]).items()}
+    L.ema_finalize(d["cs"], d["ea"], d["e"], count[0].to(dev), esum[0].to(dev), decay=cfg.decay, eps=cfg.eps, cosine=cos)
+    O.lerp_inplace(st.cluster_size, count, cfg.decay)
+    O.lerp_inplace(st.embed_avg, esum, cfg.decay)
+    O.update_ema(st, cfg)
+    assert torch.equal(d["cs"].cpu(), st.cluster_size[0])          # ATen lerp_ restated exactly
+    assert torch.equal(d["ea"].cpu(), st.embed_avg[0])
+    if cos:
+        assert (d["e"].cpu() - st.embed[0]).abs().max().item() <= 1e-6
+    else:
+        assert torch.equal(d["e"].cpu(), st.embed[0])              # incl. ATen-order sum of cluster_size
+
+
+def test_decode_sum(dev):
+    from vector_quantize_pytorch_amd import _lib as L
+    g = torch.Generator().manual_seed(2)
+    Q, C, D = 4, 50, 96
+    cb = torch.randn(Q, C, D, generator=g)
+    idx = torch.randint(0, C, (3, 70, Q), generator=g)
+    idx[0, :5, 2:] = -1
+    out = L.decode_sum(idx.to(dev), cb.to(dev)).cpu()
+    want = torch.zeros(3, 70, D)
+    for q in range(Q):
+        want = want + O.decode(cb[q], idx[..., q])
+    assert torch.equal(out, want)
+    out1 = L.decode_sum(idx.to(dev), cb[0].contiguous().to(dev)).cpu()
+    want1 = sum(O.decode(cb[0], idx[..., q]) for q in range(Q))
+    assert (out1 - want1).abs().max().item() <= 1e-6

@@ -1,0 +1,234 @@
+"""ctypes binding of csrc/libvqhip.so (C ABI: include/vqhip.h).
+
+PyTorch is plumbing here: it owns device memory and the stream; every kernel on the hot path is in
+the HIP library.  There is NO fallback: if the library is missing or the tensor is not on a GPU the
+call raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "csrc", "libvqhip.so")
+
+F32, BF16 = 0, 1
+EUCLID, COSINE = 0, 1
+ASSIGN_ROWS_PER_BLOCK = 128
+
+_lib = None
+
+
+class VQHipError(RuntimeError):
+    pass
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(SO_PATH):
+        raise VQHipError(
+            f"{SO_PATH} not found: build it with `make -C {os.path.dirname(SO_PATH)}` "
+            "(or `python -c 'import __graft_entry__ as g; g.build()'`). "
+            "vector_quantize_pytorch_amd has no non-HIP fallback.")
+    L = ctypes.CDLL(SO_PATH)
+    vp, i64, i32, f32, f64 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_float, ctypes.c_double
+    L.vqhip_version.restype = ctypes.c_char_p
+    L.vqhip_last_error.restype = ctypes.c_char_p
+    L.vqhip_packed_bytes.restype = ctypes.c_size_t
+    L.vqhip_packed_bytes.argtypes = [i32, i32]
+    L.vqhip_assign_blocks.restype = i64
+    L.vqhip_assign_blocks.argtypes = [i64]
+    L.vqhip_pack_codebook.argtypes = [vp, i32, i32, vp, vp]
+    L.vqhip_assign.argtypes = [vp, i32, i64, i32, i64, vp, vp, i32, i32, vp, vp, i32, i64, vp, vp, vp, vp, vp]
+    L.vqhip_reduce_partials.argtypes = [vp, i64, f64, vp, vp]
+    L.vqhip_ema_accumulate.argtypes = [vp, i32, i64, i32, i64, vp, i64, vp, i32, vp, i32, vp, vp, vp]
+    L.vqhip_ema_finalize.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, f32, f32, i32, i32, i32, vp, vp]
+    L.vqhip_decode_sum.argtypes = [vp, i64, i32, vp, i64, i32, i32, vp, i32, i64, vp]
+    L.vqhip_row_sumsq.argtypes = [vp, i32, i64, i32, i64, vp, vp]
+    for name in ("vqhip_pack_codebook", "vqhip_assign", "vqhip_reduce_partials", "vqhip_ema_accumulate",
+                 "vqhip_ema_finalize", "vqhip_decode_sum", "vqhip_row_sumsq"):
+        getattr(L, name).restype = i32
+    _lib = L
+    return L
+
+
+EXPORTS = ("vqhip_version", "vqhip_last_error", "vqhip_packed_bytes", "vqhip_pack_codebook",
+           "vqhip_assign_blocks", "vqhip_assign", "vqhip_reduce_partials", "vqhip_ema_accumulate",
+           "vqhip_ema_finalize", "vqhip_decode_sum", "vqhip_row_sumsq")
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise VQHipError(f"{what} failed (rc={rc}): {lib().vqhip_last_error().decode()}")
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _dtype_code(t: torch.Tensor) -> int:
+    if t.dtype == torch.float32:
+        return F32
+    if t.dtype == torch.bfloat16:
+        return BF16
+    raise VQHipError(f"unsupported dtype {t.dtype}: the HIP path takes float32 or bfloat16")
+
+
+def _need_gpu(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise VQHipError("vector_quantize_pytorch_amd runs on MI355X only: got a CPU tensor "
+                             "(there is no CPU fallback; move the module and input to 'cuda')")
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def as_rows(x: torch.Tensor):
+    """View `x` [..., D] as N rows of D elements at a uniform element stride, without copying when
+    the layout allows it (contiguous, or a last-dim slice of a contiguous tensor as produced by
+    `x.chunk(groups, -1)`).  Returns (tensor_keeping_memory_alive, N, D, ld)."""
+    D = x.shape[-1]
+    N = x.numel() // D if D else 0
+    if x.is_contiguous():
+        return x, N, D, D
+    if x.stride(-1) == 1 or D == 1:
+        lead = [(s, st) for s, st in zip(x.shape[:-1], x.stride()[:-1]) if s != 1]
+        if not lead:
+            return x, N, D, D
+        ld = lead[-1][1]
+        ok = ld >= D
+        for (s0, st0), (s1, st1) in zip(lead[:-1], lead[1:]):
+            ok = ok and (st0 == st1 * s1)
+        if ok:
+            return x, N, D, ld
+    xc = x.contiguous()
+    return xc, N, D, D
+
+
+# ------------------------------------------------------------------------------------------------
+# thin wrappers (allocation is done here, in torch; the library never allocates)
+# ------------------------------------------------------------------------------------------------
+def pack_codebook(embed2d: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
+    _need_gpu(embed2d)
+    assert embed2d.dtype == torch.float32 and embed2d.is_contiguous() and embed2d.ndim == 2
+    C, D = embed2d.shape
+    nbytes = lib().vqhip_packed_bytes(C, D)
+    if nbytes == 0:
+        raise VQHipError(f"codebook [{C}, {D}] unsupported: the HIP path handles 1 <= dim <= 512")
+    if out is None or out.numel() * 4 != nbytes:
+        out = torch.empty(nbytes // 4, dtype=torch.float32, device=embed2d.device)
+    _check(lib().vqhip_pack_codebook(_ptr(embed2d), C, D, _ptr(out), _stream()), "vqhip_pack_codebook")
+    return out
+
+
+def assign(x: torch.Tensor, packed: torch.Tensor, embed2d: torch.Tensor, *, cosine=False,
+           want_q=True, want_sqerr=False, want_best=False, want_rnorm=False, row_mask=None, q_out=None):
+    """x [..., D] -> dict(idx [...], q [..., D] | None, sqerr_partials | None, best, rnorm)."""
+    _need_gpu(x, packed, embed2d, row_mask)
+    xk, N, D, ldx = as_rows(x)
+    C = embed2d.shape[0]
+    assert embed2d.shape[1] == D and embed2d.is_contiguous() and embed2d.dtype == torch.float32
+    dev = x.device
+    lead = x.shape[:-1]
+    idx = torch.empty(lead, dtype=torch.int64, device=dev)
+    q = None
+    ldq = D
+    if want_q:
+        q = q_out if q_out is not None else torch.empty(*lead, D, dtype=x.dtype, device=dev)
+        assert q.is_contiguous() and q.dtype == x.dtype
+    need_rn = want_rnorm or cosine or (D % 32 != 0)
+    rnorm = torch.empty(lead, dtype=torch.float32, device=dev) if need_rn else None
+    best = torch.empty(lead, dtype=torch.float32, device=dev) if want_best else None
+    nblk = lib().vqhip_assign_blocks(N)
+    partials = torch.empty(max(nblk, 1), dtype=torch.float64, device=dev) if want_sqerr else None
+    if row_mask is not None:
+        row_mask = row_mask.reshape(-1).to(torch.uint8).contiguous()
+        assert row_mask.numel() == N
+    if N > 0:
+        _check(lib().vqhip_assign(_ptr(xk), _dtype_code(xk), N, D, ldx, _ptr(packed), _ptr(embed2d), C,
+                                  COSINE if cosine else EUCLID, _ptr(idx), _ptr(q), _dtype_code(x), ldq,
+                                  _ptr(best), _ptr(rnorm), _ptr(partials), _ptr(row_mask), _stream()),
+               "vqhip_assign")
+    elif partials is not None:
+        partials.zero_()
+    return dict(idx=idx, q=q, sqerr_partials=partials, best=best, rnorm=rnorm, nblk=nblk)
+
+
+def reduce_partials(partials: torch.Tensor, n: int, scale: float, out: torch.Tensor | None = None) -> torch.Tensor:
+    _need_gpu(partials)
+    if out is None:
+        out = torch.empty((), dtype=torch.float32, device=partials.device)
+    _check(lib().vqhip_reduce_partials(_ptr(partials), n, float(scale), _ptr(out), _stream()), "vqhip_reduce_partials")
+    return out
+
+
+def ema_accumulate(x: torch.Tensor, idx: torch.Tensor, C: int, *, cosine=False, rnorm=None, row_mask=None,
+                   count=None, embed_sum=None, idx_stride=1):
+    """Accumulates into (count [C], embed_sum [C, D]); allocates zeroed ones if not given."""
+    _need_gpu(x, idx, rnorm, row_mask)
+    xk, N, D, ldx = as_rows(x)
+    dev = x.device
+    if count is None:
+        count = torch.zeros(C, dtype=torch.float32, device=dev)
+    if embed_sum is None:
+        embed_sum = torch.zeros(C, D, dtype=torch.float32, device=dev)
+    assert idx.dtype == torch.int64
+    if row_mask is not None:
+        row_mask = row_mask.reshape(-1).to(torch.uint8).contiguous()
+    if N > 0:
+        _check(lib().vqhip_ema_accumulate(_ptr(xk), _dtype_code(xk), N, D, ldx, _ptr(idx), idx_stride, _ptr(rnorm),
+                                          COSINE if cosine else EUCLID, _ptr(row_mask), C, _ptr(count),
+                                          _ptr(embed_sum), _stream()), "vqhip_ema_accumulate")
+    return count, embed_sum
+
+
+def ema_finalize(cluster_size, embed_avg, embed, count, embed_sum, *, decay, eps, cosine=False, weight=None,
+                 do_lerp=True, do_update_ema=True, denom_ws=None):
+    """In place on cluster_size [C], embed_avg [C, D], embed [C, D] (2-D views of the module buffers)."""
+    _need_gpu(cluster_size, embed_avg, embed)
+    C, D = embed.shape
+    for t in (cluster_size, embed_avg, embed):
+        assert t.is_contiguous() and t.dtype == torch.float32
+    if denom_ws is None and do_update_ema:
+        denom_ws = torch.empty(C, dtype=torch.float32, device=embed.device)
+    # (1 - decay) is formed in Python double and handed to ATen as a scalar, which casts to fp32
+    omd = float(torch.tensor(1.0 - decay, dtype=torch.float64).to(torch.float32))
+    _check(lib().vqhip_ema_finalize(_ptr(cluster_size), _ptr(embed_avg), _ptr(embed), _ptr(count), _ptr(embed_sum),
+                                    _ptr(weight), C, D, omd, float(eps), int(cosine), int(do_lerp),
+                                    int(do_update_ema), _ptr(denom_ws), _stream()), "vqhip_ema_finalize")
+
+
+def decode_sum(idx: torch.Tensor, embed: torch.Tensor, out_dtype=torch.float32) -> torch.Tensor:
+    """idx [..., Q] int64, embed [Q, C, D] or [C, D] (shared by all Q) -> [..., D] = sum_q embed_q[idx_q]."""
+    _need_gpu(idx, embed)
+    assert idx.dtype == torch.int64 and embed.dtype == torch.float32 and embed.is_contiguous()
+    idx = idx.contiguous()
+    Q = idx.shape[-1]
+    if embed.ndim == 2:
+        C, D = embed.shape
+        qstride = 0
+    else:
+        assert embed.shape[0] == Q
+        _, C, D = embed.shape
+        qstride = C * D
+    N = idx.numel() // Q
+    out = torch.empty(*idx.shape[:-1], D, dtype=out_dtype, device=idx.device)
+    if N > 0:
+        _check(lib().vqhip_decode_sum(_ptr(idx), N, Q, _ptr(embed), qstride, C, D, _ptr(out),
+                                      F32 if out_dtype == torch.float32 else BF16, D, _stream()), "vqhip_decode_sum")
+    return out
+
+
+def row_sumsq(x: torch.Tensor) -> torch.Tensor:
+    _need_gpu(x)
+    xk, N, D, ldx = as_rows(x)
+    out = torch.empty(x.shape[:-1], dtype=torch.float32, device=x.device)
+    if N > 0:
+        _check(lib().vqhip_row_sumsq(_ptr(xk), _dtype_code(xk), N, D, ldx, _ptr(out), _stream()), "vqhip_row_sumsq")
+    return out

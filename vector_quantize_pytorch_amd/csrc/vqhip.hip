@@ -1,0 +1,901 @@
+// vqhip.hip -- hand-written CDNA4 (gfx950, MI355X) kernels behind the C ABI of include/vqhip.h.
+//
+// Hot path of lucidrains/vector-quantize-pytorch's Codebook.forward (vqp.py:673-791), re-designed
+// for wave64 + fp32 MFMA instead of translated from the reference's ATen op sequence:
+//
+//   vq_pack_kernel      codebook -> MFMA A-operand tiles (+ ||c||^2 in ATen's summation order)
+//   vq_assign_kernel    x rows stay resident in VGPRs as the MFMA B operand for the whole codebook
+//                       sweep; codebook tiles are streamed L2 -> LDS by LDS-DMA (global_load_lds),
+//                       double buffered; v_mfma_f32_32x32x2_f32 computes code x row score tiles with
+//                       the CODE index on the accumulator-register axis, so the per-row argmin is
+//                       lane-local (no cross-lane reduce inside the sweep) and the N x C distance
+//                       matrix is never written; gather + squared-error partials in the epilogue.
+//   vq_stats_kernel     EMA sufficient statistics via LDS-privatised fp32 accumulators + global atomics
+//   vq_ema_*_kernel     lerp fold, Laplace smoothing, codebook renormalisation
+//   vq_decode_kernel    indices -> (summed) codes
+//
+// Numerics contract (see DESIGN.md "bit-exact indices"): every fp32 rounding after the dot product
+// follows the reference's CPU arithmetic; the dot product itself is ONE fp32 FMA chain in ascending
+// k (what the f32 MFMA computes), which oracle/vq_oracle.c restates.  BUILD WITH -ffp-contract=off.
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <math.h>
+
+#include "../../include/vqhip.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+#define AS1 __attribute__((address_space(1)))
+#define AS3 __attribute__((address_space(3)))
+
+static thread_local char g_err[256] = "";
+#define VQ_FAIL(code, ...)                           \
+    do {                                             \
+        snprintf(g_err, sizeof g_err, __VA_ARGS__);  \
+        return (code);                               \
+    } while (0)
+
+extern "C" const char *vqhip_last_error(void) { return g_err; }
+extern "C" const char *vqhip_version(void) { return "vqhip 0.1 (gfx950)"; }
+
+static inline int launch_status(const char *what)
+{
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        snprintf(g_err, sizeof g_err, "%s: %s", what, hipGetErrorString(e));
+        return (int)e;
+    }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// small device helpers
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float bf16_bits_to_f32(unsigned short b) { return __uint_as_float(((unsigned)b) << 16); }
+
+__device__ __forceinline__ unsigned short f32_to_bf16_rne(float f)
+{
+    unsigned u = __float_as_uint(f);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+
+__device__ __forceinline__ float round_to_bf16(float f) { return bf16_bits_to_f32(f32_to_bf16_rne(f)); }
+
+template <bool BF16>
+__device__ __forceinline__ float load_elem(const void *base, int64_t off)
+{
+    if (BF16) return bf16_bits_to_f32(((const unsigned short *)base)[off]);
+    return ((const float *)base)[off];
+}
+
+// ATen CPU order of sum(x*x) over one contiguous row of D <= 512 floats (vqp.py:59-60).
+// 32 interleaved chains (8 SIMD lanes x 4 ILP accumulators), leftovers and tail as in
+// oracle/vq_oracle.c::aten_sumsq_row.  Sequential, one thread per row: only used for the codebook
+// and for odd D; the assign kernel has an in-register version for D % 32 == 0.
+template <typename F>
+__device__ float aten_sumsq_seq(F ld, int D)
+{
+    const int V = D >> 3;
+    const int size = V >> 2;
+    float acc[32];
+#pragma unroll
+    for (int c = 0; c < 32; ++c) acc[c] = 0.f;
+    for (int i = 0; i < size; ++i) {
+#pragma unroll
+        for (int c = 0; c < 32; ++c) {
+            float v = ld(32 * i + c);
+            acc[c] += v * v;
+        }
+    }
+    for (int v = size * 4; v < V; ++v) {
+#pragma unroll
+        for (int l = 0; l < 8; ++l) {
+            float t = ld(v * 8 + l);
+            acc[l] += t * t;
+        }
+    }
+    float fin = 0.f;
+    for (int e = V * 8; e < D; ++e) {
+        float t = ld(e);
+        fin += t * t;
+    }
+#pragma unroll
+    for (int l = 0; l < 8; ++l) {
+        float p = ((acc[l] + acc[8 + l]) + acc[16 + l]) + acc[24 + l];
+        fin += p;
+    }
+    return fin;
+}
+
+// ------------------------------------------------------------------------------------------------
+// codebook packing.  Tile t (32 codes) = 32*DT floats in A-operand order + 256 floats of which the
+// first 32 are ||c||^2 (+inf for padding codes):
+//   tile[((t4*2 + hi)*32 + i)*4 + jj] = embed[t*32 + i][8*t4 + 2*jj + hi]
+// so that lane (i, hi) fetches the A values of MFMA k-steps 4*t4 .. 4*t4+3 with one ds_read_b128
+// and a whole wave reads 1 KiB contiguous (conflict-free).
+// ------------------------------------------------------------------------------------------------
+static inline int pick_dt(int D)
+{
+    if (D <= 32) return 32;
+    if (D <= 64) return 64;
+    if (D <= 128) return 128;
+    if (D <= 256) return 256;
+    if (D <= 512) return 512;
+    return 0;
+}
+
+extern "C" size_t vqhip_packed_bytes(int C, int D)
+{
+    const int DT = pick_dt(D);
+    if (DT == 0 || C <= 0) return 0;
+    const size_t tiles = ((size_t)C + 31) / 32;
+    return tiles * ((size_t)32 * DT + 256) * sizeof(float);
+}
+
+__global__ void __launch_bounds__(256) vq_pack_kernel(const float *__restrict__ embed, int C, int D, int DT,
+                                                      float *__restrict__ packed)
+{
+    const int t = blockIdx.x;
+    const int tile_f = 32 * DT + 256;
+    float *out = packed + (size_t)t * tile_f;
+    for (int p = threadIdx.x; p < 32 * DT; p += 256) {
+        const int jj = p & 3;
+        const int i = (p >> 2) & 31;
+        const int hi = (p >> 7) & 1;
+        const int t4 = p >> 8;
+        const int code = t * 32 + i;
+        const int k = 8 * t4 + 2 * jj + hi;
+        out[p] = (code < C && k < D) ? embed[(size_t)code * D + k] : 0.f;
+    }
+    if (threadIdx.x < 256) {
+        const int i = threadIdx.x;
+        float v = 0.f;
+        if (i < 32) {
+            const int code = t * 32 + i;
+            if (code < C) {
+                const float *r = embed + (size_t)code * D;
+                v = aten_sumsq_seq([&](int e) { return r[e]; }, D);
+            } else {
+                v = INFINITY;
+            }
+        }
+        out[32 * DT + i] = v;
+    }
+}
+
+extern "C" int vqhip_pack_codebook(const float *embed, int C, int D, float *packed, void *stream)
+{
+    if (!embed || !packed || C <= 0) VQ_FAIL(VQHIP_EINVAL, "pack_codebook: null pointer or C <= 0");
+    const int DT = pick_dt(D);
+    if (D < 1 || DT == 0) VQ_FAIL(VQHIP_EDIM, "pack_codebook: D=%d unsupported (1..512)", D);
+    if (((uintptr_t)packed) & 15) VQ_FAIL(VQHIP_EALIGN, "pack_codebook: packed must be 16-byte aligned");
+    const int tiles = (C + 31) / 32;
+    hipLaunchKernelGGL(vq_pack_kernel, dim3(tiles), dim3(256), 0, (hipStream_t)stream, embed, C, D, DT, packed);
+    return launch_status("vq_pack_kernel");
+}
+
+// ------------------------------------------------------------------------------------------------
+// assignment
+// ------------------------------------------------------------------------------------------------
+struct AssignArgs {
+    const void *x;
+    int64_t N;
+    int D;
+    int64_t ldx;
+    const float *packed;
+    const float *embed;
+    int C;
+    int n_tiles;
+    int64_t *idx_out;
+    void *q_out;
+    int q_bf16;
+    int64_t ldq;
+    float *best_out;
+    float *rnorm_out;
+    double *sqerr_partial;
+    const uint8_t *row_mask;
+    int x_vec;  // 1: D == DT and x rows are vector-load aligned
+    int q_vec;  // 1: D == DT and q rows are vector-store aligned
+};
+
+__device__ __forceinline__ void swap32(float &a, float &b)
+{
+    // v_permlane32_swap: lanes 32..63 of `a` <-> lanes 0..31 of `b`
+    u32x2 r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    a = __uint_as_float(r[0]);
+    b = __uint_as_float(r[1]);
+}
+
+template <int DT, bool XBF16, int METRIC>
+__global__ void __launch_bounds__(256, (DT <= 256 ? 2 : 1)) vq_assign_kernel(const AssignArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int TILE_F = 32 * DT + 256;
+    constexpr int TILE_B = TILE_F * 4;
+    constexpr int NCHUNK = TILE_B / 1024;  // 1 KiB LDS-DMA pieces per tile
+    constexpr int NG = DT / 8;             // groups of 8 consecutive features
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 31;   // row within the wave's 32-row block  (MFMA N index)
+    const int hi = lane >> 5;  // which of the 2 k's of an MFMA step this lane feeds
+    const int64_t row = (int64_t)blockIdx.x * VQHIP_ASSIGN_ROWS_PER_BLOCK + wave * 32 + j;
+    const bool row_ok = row < a.N;
+    const int64_t rowc = row_ok ? row : (a.N - 1);
+
+    // ---- kick off the DMA of codebook tile 0 while x is being loaded -----------------------------
+    auto issue_tile = [&](int ct, int buf) {
+        const char *g = (const char *)a.packed + (size_t)ct * TILE_B + lane * 16;
+        char *l = smem + buf * TILE_B;
+        for (int c = wave; c < NCHUNK; c += 4)
+            __builtin_amdgcn_global_load_lds((const AS1 void *)(g + c * 1024), (AS3 void *)(l + c * 1024), 16, 0, 0);
+    };
+    issue_tile(0, 0);
+
+    // ---- x rows -> registers.  xr[4m + r] = x[row][8m + 4hi + r]  ("load layout") ----------------
+    float xr[DT / 2];
+    if (a.x_vec) {
+        if (XBF16) {
+            const uint2 *p = (const uint2 *)((const unsigned short *)a.x + rowc * a.ldx + 4 * hi);
+#pragma unroll
+            for (int m = 0; m < NG; ++m) {
+                const uint2 w = p[m * 2];
+                xr[4 * m + 0] = __uint_as_float(w.x << 16);
+                xr[4 * m + 1] = __uint_as_float(w.x & 0xffff0000u);
+                xr[4 * m + 2] = __uint_as_float(w.y << 16);
+                xr[4 * m + 3] = __uint_as_float(w.y & 0xffff0000u);
+            }
+        } else {
+            const f32x4 *p = (const f32x4 *)((const float *)a.x + rowc * a.ldx + 4 * hi);
+#pragma unroll
+            for (int m = 0; m < NG; ++m) {
+                const f32x4 w = p[m * 2];
+                xr[4 * m + 0] = w.x;
+                xr[4 * m + 1] = w.y;
+                xr[4 * m + 2] = w.z;
+                xr[4 * m + 3] = w.w;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int m = 0; m < NG; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int k = 8 * m + 4 * hi + r;
+                xr[4 * m + r] = (k < a.D) ? load_elem<XBF16>(a.x, rowc * a.ldx + k) : 0.f;
+            }
+    }
+
+    // ---- ||x||^2 in ATen's order (vqp.py:59): chain (e % 32) over e ascending, then lane-wise
+    //      ((a0+a1)+a2)+a3 over the ILP accumulators, then the 8 SIMD lanes left to right.
+    //      In the load layout element e = 8m + 4hi + r sits in chain [m & 3][4hi + r].
+    //      Zero padding (D < DT) only adds +0 to non-negative chains.  Rows whose D is not a
+    //      multiple of 32 take x2 from a pre-pass (a.rnorm_out pre-filled) -- see host wrapper. ----
+    float x2;
+    {
+        float ch[4][4];
+#pragma unroll
+        for (int mm = 0; mm < 4; ++mm)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ch[mm][r] = 0.f;
+#pragma unroll
+        for (int m = 0; m < NG; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float v = xr[4 * m + r];
+                ch[m & 3][r] += v * v;
+            }
+        float p[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) p[r] = ((ch[0][r] + ch[1][r]) + ch[2][r]) + ch[3][r];
+        const float f_lo = ((p[0] + p[1]) + p[2]) + p[3];          // SIMD lanes 0..3 (hi == 0 half)
+        const float f_from_lo = __shfl(f_lo, j, 64);               // value of the hi == 0 partner
+        const float f_hi = (((f_from_lo + p[0]) + p[1]) + p[2]) + p[3];  // continue with lanes 4..7
+        x2 = __shfl(f_hi, j + 32, 64);
+    }
+    if (a.D & 31) x2 = a.rnorm_out[rowc];  // exact ATen order for odd D was precomputed
+
+    float nrm = 0.f;
+    if (METRIC == 1) {
+        // l2norm (vqp.py:37-38): x / max(||x||, 1e-6); for bf16 inputs the reference normalises in
+        // bf16 (norm and quotient both rounded to bf16) before Codebook.forward casts to fp32.
+        nrm = sqrtf(x2);
+        if (XBF16) nrm = round_to_bf16(nrm);
+        nrm = fmaxf(nrm, XBF16 ? round_to_bf16(1e-6f) : 1e-6f);
+#pragma unroll
+        for (int q = 0; q < DT / 2; ++q) {
+            float v = xr[q] / nrm;
+            xr[q] = XBF16 ? round_to_bf16(v) : v;
+        }
+    }
+
+    // ---- load layout -> MFMA B-operand layout: after the swaps register 4m+{0,2,1,3} holds
+    //      x[row][8m + 2*jj + hi] for jj = 0..3, i.e. the k = 2t + hi element of k-step t = 4m + jj.
+#pragma unroll
+    for (int m = 0; m < NG; ++m) {
+        swap32(xr[4 * m + 0], xr[4 * m + 1]);
+        swap32(xr[4 * m + 2], xr[4 * m + 3]);
+    }
+
+    // ---- sweep the codebook ----------------------------------------------------------------------
+    float bd = (METRIC == 0) ? INFINITY : -INFINITY;  // best distance / similarity so far
+    float bs = INFINITY;                              // its pre-sqrt value (euclid only)
+    int bi = 0;
+
+    const int nt = a.n_tiles;
+    for (int ct = 0; ct < nt; ++ct) {
+        const int buf = ct & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();  // tile ct has landed for every wave; everyone is done with the other buffer
+        if (ct + 1 < nt) issue_tile(ct + 1, buf ^ 1);
+
+        const char *tile = smem + buf * TILE_B;
+        const f32x4 *ap = (const f32x4 *)tile + (hi * 32 + j);
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int t4 = 0; t4 < NG; ++t4) {
+            const f32x4 av = ap[t4 * 64];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, xr[4 * t4 + 0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, xr[4 * t4 + 2], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, xr[4 * t4 + 1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, xr[4 * t4 + 3], acc, 0, 0, 0);
+        }
+
+        // acc[4q + r] = <code ct*32 + 8q + 4hi + r , row j>.  Codes ascend with (ct, q, r), so a
+        // strict comparison keeps the lowest index among equal distances (ATen argmax semantics).
+        const float *y2s = (const float *)tile + 32 * DT;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 yv = *(const f32x4 *)(y2s + 8 * q + 4 * hi);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int code = ct * 32 + 8 * q + 4 * hi + r;
+                const float v = acc[4 * q + r];
+                if (METRIC == 0) {
+                    // vqp.py:62  (x2 + y2) + (-2 xy), clamp(min=1e-8), sqrt -- one rounding each
+                    const float t = x2 + yv[r];
+                    float s = __builtin_fmaf(-2.0f, v, t);
+                    s = fmaxf(s, 1e-8f);
+                    const bool cand = s < bs;  // s >= bs implies sqrt(s) >= bd: cannot win
+                    if (__any(cand)) {
+                        const float d = sqrtf(s);
+                        const bool win = cand && (d < bd);
+                        bd = win ? d : bd;
+                        bs = win ? s : bs;
+                        bi = win ? code : bi;
+                    }
+                } else {
+                    const bool win = (v > bd) && (code < a.C);
+                    bd = win ? v : bd;
+                    bi = win ? code : bi;
+                }
+            }
+        }
+    }
+
+    // ---- merge the two half-waves (same row, disjoint code subsets) ------------------------------
+    {
+        const float od = __shfl_xor(bd, 32, 64);
+        const int oi = __shfl_xor(bi, 32, 64);
+        const bool take = (METRIC == 0) ? ((od < bd) || (od == bd && oi < bi)) : ((od > bd) || (od == bd && oi < bi));
+        bd = take ? od : bd;
+        bi = take ? oi : bi;
+    }
+
+    if (row_ok && hi == 0) {
+        a.idx_out[row] = (int64_t)bi;
+        if (a.best_out) a.best_out[row] = bd;
+        if (a.rnorm_out) a.rnorm_out[row] = (METRIC == 0) ? x2 : nrm;
+    }
+
+    // ---- gather the winning code row, write q, accumulate sum (q - x)^2 --------------------------
+    if (a.q_out || a.sqerr_partial) {
+        // back to the load layout (the swap is an involution)
+#pragma unroll
+        for (int m = 0; m < NG; ++m) {
+            swap32(xr[4 * m + 0], xr[4 * m + 1]);
+            swap32(xr[4 * m + 2], xr[4 * m + 3]);
+        }
+        const float *er = a.embed + (size_t)bi * a.D;
+        const bool qb = a.q_bf16 != 0;
+        float lsum = 0.f;
+#pragma unroll
+        for (int m = 0; m < NG; ++m) {
+            const int k0 = 8 * m + 4 * hi;
+            float g[4];
+            if (a.x_vec) {  // D == DT: embed rows are 16-byte aligned whenever embed is
+                const f32x4 w = *(const f32x4 *)(er + k0);
+                g[0] = w.x; g[1] = w.y; g[2] = w.z; g[3] = w.w;
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) g[r] = (k0 + r < a.D) ? er[k0 + r] : 0.f;
+            }
+            if (qb) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) g[r] = round_to_bf16(g[r]);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float df = g[r] - xr[4 * m + r];
+                lsum += df * df;
+            }
+            if (a.q_out && row_ok) {
+                if (qb) {
+                    unsigned short *qp = (unsigned short *)a.q_out + row * a.ldq + k0;
+                    if (a.q_vec) {
+                        uint2 w;
+                        w.x = (__float_as_uint(g[0]) >> 16) | (__float_as_uint(g[1]) & 0xffff0000u);
+                        w.y = (__float_as_uint(g[2]) >> 16) | (__float_as_uint(g[3]) & 0xffff0000u);
+                        *(uint2 *)qp = w;
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (k0 + r < a.D) qp[r] = (unsigned short)(__float_as_uint(g[r]) >> 16);
+                    }
+                } else {
+                    float *qp = (float *)a.q_out + row * a.ldq + k0;
+                    if (a.q_vec) {
+                        f32x4 w = {g[0], g[1], g[2], g[3]};
+                        *(f32x4 *)qp = w;
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (k0 + r < a.D) qp[r] = g[r];
+                    }
+                }
+            }
+        }
+        if (a.sqerr_partial) {
+            const bool counted = row_ok && (!a.row_mask || a.row_mask[row] != 0);
+            double ds = counted ? (double)lsum : 0.0;
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) ds += __shfl_xor(ds, o, 64);
+            // all DMA traffic has drained (last loop iteration waited); reuse LDS for the 4 partials
+            __syncthreads();
+            double *red = (double *)smem;
+            if (lane == 0) red[wave] = ds;
+            __syncthreads();
+            if (tid == 0) a.sqerr_partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+        }
+    }
+}
+
+extern "C" int64_t vqhip_assign_blocks(int64_t N)
+{
+    return N <= 0 ? 0 : (N + VQHIP_ASSIGN_ROWS_PER_BLOCK - 1) / VQHIP_ASSIGN_ROWS_PER_BLOCK;
+}
+
+template <int DT, bool XBF16, int METRIC>
+static int launch_assign(const AssignArgs &a, hipStream_t st)
+{
+    constexpr int TILE_B = (32 * DT + 256) * 4;
+    constexpr int SMEM = 2 * TILE_B;
+    static bool attr_done = false;  // per instantiation
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void *)vq_assign_kernel<DT, XBF16, METRIC>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+        if (e != hipSuccess) VQ_FAIL((int)e, "hipFuncSetAttribute(assign<%d>): %s", DT, hipGetErrorString(e));
+        attr_done = true;
+    }
+    const int64_t blocks = vqhip_assign_blocks(a.N);
+    hipLaunchKernelGGL((vq_assign_kernel<DT, XBF16, METRIC>), dim3((unsigned)blocks), dim3(256), SMEM, st, a);
+    return launch_status("vq_assign_kernel");
+}
+
+template <int DT>
+static int dispatch_assign(const AssignArgs &a, int x_dtype, int metric, hipStream_t st)
+{
+    if (x_dtype == VQHIP_BF16)
+        return metric ? launch_assign<DT, true, 1>(a, st) : launch_assign<DT, true, 0>(a, st);
+    return metric ? launch_assign<DT, false, 1>(a, st) : launch_assign<DT, false, 0>(a, st);
+}
+
+// thread-per-row exact ATen-order sum of squares (any D <= 512)
+template <bool XBF16>
+__global__ void __launch_bounds__(256) vq_row_sumsq_kernel(const void *x, int64_t N, int D, int64_t ldx, float *out)
+{
+    const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    out[n] = aten_sumsq_seq([&](int e) { return load_elem<XBF16>(x, n * ldx + e); }, D);
+}
+
+extern "C" int vqhip_row_sumsq(const void *x, int x_dtype, int64_t N, int D, int64_t ldx, float *out, void *stream)
+{
+    if (!x || !out || N < 0) VQ_FAIL(VQHIP_EINVAL, "row_sumsq: bad argument");
+    if (D < 1 || D > 512) VQ_FAIL(VQHIP_EDIM, "row_sumsq: D=%d unsupported (1..512)", D);
+    if (N == 0) return 0;
+    const unsigned blocks = (unsigned)((N + 255) / 256);
+    if (x_dtype == VQHIP_BF16)
+        hipLaunchKernelGGL(vq_row_sumsq_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, N, D, ldx, out);
+    else if (x_dtype == VQHIP_F32)
+        hipLaunchKernelGGL(vq_row_sumsq_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, N, D, ldx, out);
+    else
+        VQ_FAIL(VQHIP_EINVAL, "row_sumsq: unknown dtype %d", x_dtype);
+    return launch_status("vq_row_sumsq_kernel");
+}
+
+extern "C" int vqhip_assign(const void *x, int x_dtype, int64_t N, int D, int64_t ldx,
+                            const float *packed, const float *embed, int C, int metric,
+                            int64_t *idx_out, void *q_out, int q_dtype, int64_t ldq,
+                            float *best_out, float *rnorm_out, double *sqerr_partial,
+                            const uint8_t *row_mask, void *stream)
+{
+    if (N < 0 || C <= 0) VQ_FAIL(VQHIP_EINVAL, "assign: N < 0 or C <= 0");
+    if (N == 0) return 0;
+    if (!x || !packed || !embed || !idx_out) VQ_FAIL(VQHIP_EINVAL, "assign: null pointer");
+    if (x_dtype != VQHIP_F32 && x_dtype != VQHIP_BF16) VQ_FAIL(VQHIP_EINVAL, "assign: unknown x dtype %d", x_dtype);
+    if (q_out && q_dtype != VQHIP_F32 && q_dtype != VQHIP_BF16) VQ_FAIL(VQHIP_EINVAL, "assign: unknown q dtype %d", q_dtype);
+    if (metric != 0 && metric != 1) VQ_FAIL(VQHIP_EINVAL, "assign: unknown metric %d", metric);
+    const int DT = pick_dt(D);
+    if (D < 1 || DT == 0) VQ_FAIL(VQHIP_EDIM, "assign: D=%d unsupported (1..512)", D);
+    if (ldx < D || (q_out && ldq < D)) VQ_FAIL(VQHIP_EINVAL, "assign: row stride smaller than D");
+    if (((uintptr_t)packed) & 15) VQ_FAIL(VQHIP_EALIGN, "assign: packed must be 16-byte aligned");
+    if ((D & 31) && !rnorm_out) VQ_FAIL(VQHIP_EINVAL, "assign: D %% 32 != 0 needs rnorm_out (scratch for the exact ||x||^2 pre-pass)");
+
+    hipStream_t st = (hipStream_t)stream;
+    if (D & 31) {  // exact ATen-order ||x||^2 for odd D: pre-pass into rnorm_out, the kernel reads it back
+        int rc = vqhip_row_sumsq(x, x_dtype, N, D, ldx, rnorm_out, stream);
+        if (rc) return rc;
+    }
+
+    AssignArgs a;
+    a.x = x; a.N = N; a.D = D; a.ldx = ldx; a.packed = packed; a.embed = embed; a.C = C;
+    a.n_tiles = (C + 31) / 32;
+    a.idx_out = idx_out; a.q_out = q_out; a.q_bf16 = (q_dtype == VQHIP_BF16); a.ldq = ldq;
+    a.best_out = best_out; a.rnorm_out = rnorm_out; a.sqerr_partial = sqerr_partial; a.row_mask = row_mask;
+    const int xes = (x_dtype == VQHIP_BF16) ? 2 : 4;
+    a.x_vec = (D == DT) && (((uintptr_t)x) % (4 * xes) == 0) && ((ldx * xes) % (4 * xes) == 0) && ((((uintptr_t)embed) & 15) == 0);
+    if (q_out) {
+        const int qes = a.q_bf16 ? 2 : 4;
+        a.q_vec = (D == DT) && (((uintptr_t)q_out) % (4 * qes) == 0) && ((ldq * qes) % (4 * qes) == 0);
+    } else {
+        a.q_vec = 0;
+    }
+
+    switch (DT) {
+        case 32: return dispatch_assign<32>(a, x_dtype, metric, st);
+        case 64: return dispatch_assign<64>(a, x_dtype, metric, st);
+        case 128: return dispatch_assign<128>(a, x_dtype, metric, st);
+        case 256: return dispatch_assign<256>(a, x_dtype, metric, st);
+        default: return dispatch_assign<512>(a, x_dtype, metric, st);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// partial reduction (commit loss)
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) vq_reduce_kernel(const double *__restrict__ p, int64_t n, double scale, float *out)
+{
+    __shared__ double red[256];
+    double s = 0.0;
+    for (int64_t i = threadIdx.x; i < n; i += 256) s += p[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o >= 1; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *out = (float)(red[0] * scale);
+}
+
+extern "C" int vqhip_reduce_partials(const double *partials, int64_t n, double scale, float *out, void *stream)
+{
+    if (!out || n < 0 || (n > 0 && !partials)) VQ_FAIL(VQHIP_EINVAL, "reduce_partials: bad argument");
+    hipLaunchKernelGGL(vq_reduce_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partials, n, scale, out);
+    return launch_status("vq_reduce_kernel");
+}
+
+// ------------------------------------------------------------------------------------------------
+// EMA sufficient statistics
+// ------------------------------------------------------------------------------------------------
+struct StatsArgs {
+    const void *x;
+    int64_t N;
+    int D;
+    int64_t ldx;
+    const int64_t *idx;
+    int64_t idx_stride;
+    const float *rnorm;
+    int cosine;
+    const uint8_t *row_mask;
+    int C;
+    float *count;
+    float *embed_sum;
+    int64_t rows_per_block;
+};
+
+template <bool XBF16>
+__global__ void __launch_bounds__(256) vq_stats_kernel(const StatsArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int d0 = blockIdx.x * VQHIP_STATS_DSLICE;
+    const int c0 = blockIdx.y * VQHIP_STATS_CCHUNK;
+    const int CC = min(VQHIP_STATS_CCHUNK, a.C - c0);
+    float *acc = (float *)smem;            // [CC][32]
+    int *cnt = (int *)(acc + CC * 32);     // [CC]
+    const int tid = threadIdx.x;
+    for (int e = tid; e < CC * 33; e += 256) acc[e] = 0.f;  // zero bits == int 0 too
+    __syncthreads();
+
+    const int dd = tid & 31;
+    const int rr = tid >> 5;
+    const bool col_ok = (d0 + dd) < a.D;
+    const bool do_cnt = (blockIdx.x == 0) && (dd == 0);
+    const int64_t r_begin = (int64_t)blockIdx.z * a.rows_per_block;
+    const int64_t r_end = min(a.N, r_begin + a.rows_per_block);
+
+    constexpr int U = 4;
+    for (int64_t base = r_begin + rr; base < r_end; base += 8 * U) {
+        int cc[U];
+        float v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t row = base + 8 * u;
+            int c = -1;
+            if (row < r_end) {
+                const int64_t ci = a.idx[row * a.idx_stride];
+                const bool keep = (!a.row_mask || a.row_mask[row] != 0) && ci >= c0 && ci < c0 + CC;
+                c = keep ? (int)(ci - c0) : -1;
+            }
+            cc[u] = c;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t row = base + 8 * u;
+            v[u] = 0.f;
+            if (cc[u] >= 0 && col_ok) {
+                float t = load_elem<XBF16>(a.x, row * a.ldx + d0 + dd);
+                if (a.cosine) {
+                    t = t / a.rnorm[row];
+                    if (XBF16) t = round_to_bf16(t);
+                }
+                v[u] = t;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (cc[u] >= 0) {
+                if (col_ok) atomicAdd(&acc[cc[u] * 32 + dd], v[u]);  // ds_add_f32
+                if (do_cnt) atomicAdd(&cnt[cc[u]], 1);
+            }
+        }
+    }
+    __syncthreads();
+
+    for (int e = tid; e < CC * 32; e += 256) {
+        const float s = acc[e];
+        const int d = d0 + (e & 31);
+        if (s != 0.f && d < a.D) unsafeAtomicAdd(&a.embed_sum[(size_t)(c0 + (e >> 5)) * a.D + d], s);
+    }
+    if (blockIdx.x == 0)
+        for (int c = tid; c < CC; c += 256)
+            if (cnt[c]) unsafeAtomicAdd(&a.count[c0 + c], (float)cnt[c]);
+}
+
+extern "C" int vqhip_ema_accumulate(const void *x, int x_dtype, int64_t N, int D, int64_t ldx,
+                                    const int64_t *idx, int64_t idx_stride, const float *rnorm, int metric,
+                                    const uint8_t *row_mask, int C,
+                                    float *count, float *embed_sum, void *stream)
+{
+    if (N < 0 || C <= 0 || D < 1) VQ_FAIL(VQHIP_EINVAL, "ema_accumulate: bad size");
+    if (N == 0) return 0;
+    if (!x || !idx || !count || !embed_sum) VQ_FAIL(VQHIP_EINVAL, "ema_accumulate: null pointer");
+    if (metric == VQHIP_COSINE && !rnorm) VQ_FAIL(VQHIP_EINVAL, "ema_accumulate: cosine needs rnorm");
+    if (x_dtype != VQHIP_F32 && x_dtype != VQHIP_BF16) VQ_FAIL(VQHIP_EINVAL, "ema_accumulate: unknown dtype");
+
+    StatsArgs a;
+    a.x = x; a.N = N; a.D = D; a.ldx = ldx; a.idx = idx; a.idx_stride = idx_stride; a.rnorm = rnorm;
+    a.cosine = (metric == VQHIP_COSINE); a.row_mask = row_mask; a.C = C; a.count = count; a.embed_sum = embed_sum;
+
+    const int nx = (D + VQHIP_STATS_DSLICE - 1) / VQHIP_STATS_DSLICE;
+    const int ny = (C + VQHIP_STATS_CCHUNK - 1) / VQHIP_STATS_CCHUNK;
+    // ~2 workgroups per CU overall; at least 2048 rows per workgroup so the flush amortises
+    int64_t nz = (512 + (int64_t)nx * ny - 1) / ((int64_t)nx * ny);
+    const int64_t max_nz = (N + 2047) / 2048;
+    if (nz > max_nz) nz = max_nz;
+    if (nz < 1) nz = 1;
+    if (nz > 65535) nz = 65535;
+    a.rows_per_block = (N + nz - 1) / nz;
+    a.rows_per_block = (a.rows_per_block + 7) / 8 * 8;
+    nz = (N + a.rows_per_block - 1) / a.rows_per_block;
+
+    const int CCmax = C < VQHIP_STATS_CCHUNK ? C : VQHIP_STATS_CCHUNK;
+    const int smem = CCmax * 33 * 4;
+    static bool attr_done[2] = {false, false};
+    const int which = (x_dtype == VQHIP_BF16);
+    if (!attr_done[which]) {
+        hipError_t e = which ? hipFuncSetAttribute((const void *)vq_stats_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, VQHIP_STATS_CCHUNK * 33 * 4)
+                             : hipFuncSetAttribute((const void *)vq_stats_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, VQHIP_STATS_CCHUNK * 33 * 4);
+        if (e != hipSuccess) VQ_FAIL((int)e, "hipFuncSetAttribute(stats): %s", hipGetErrorString(e));
+        attr_done[which] = true;
+    }
+    dim3 grid(nx, ny, (unsigned)nz);
+    if (which)
+        hipLaunchKernelGGL(vq_stats_kernel<true>, grid, dim3(256), smem, (hipStream_t)stream, a);
+    else
+        hipLaunchKernelGGL(vq_stats_kernel<false>, grid, dim3(256), smem, (hipStream_t)stream, a);
+    return launch_status("vq_stats_kernel");
+}
+
+// ------------------------------------------------------------------------------------------------
+// EMA fold + codebook renormalisation
+// ------------------------------------------------------------------------------------------------
+// ATen CPU lerp (vectorised form): |w| < 0.5 ? fma(w, end - start, start) : fma(w - 1, end - start, end)
+__device__ __forceinline__ float aten_lerp(float start, float end, float w)
+{
+    const float diff = end - start;
+    return (fabsf(w) < 0.5f) ? __builtin_fmaf(w, diff, start) : __builtin_fmaf(w - 1.0f, diff, end);
+}
+
+__global__ void __launch_bounds__(256) vq_ema_cs_lerp_kernel(float *cs, const float *count, const float *weight, int C, float omd)
+{
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const float w = weight ? omd * weight[c] : omd;
+    cs[c] = aten_lerp(cs[c], count[c], w);
+}
+
+// total = cluster_size.sum() in ATen's cascade order (8 lanes x 4 ILP chains, 4 cascade levels);
+// denom[c] = (cs + eps) / (total + C eps) * total        (vqp.py:152-154, 577)
+__global__ void __launch_bounds__(256) vq_ema_denom_kernel(const float *cs, int C, float eps, float ceps, float *denom)
+{
+    __shared__ float part[32];
+    __shared__ float total_s;
+    const int tid = threadIdx.x;
+    if (tid < 32) {
+        const int V = C >> 3;
+        const int size = V >> 2;
+        int cl2 = 0;
+        while ((1 << cl2) < size) cl2++;
+        int lp = cl2 / 4;
+        if (lp < 4) lp = 4;
+        const int step = 1 << lp;
+        const int lmask = step - 1;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        int i = 0;
+        for (; i + step <= size;) {
+            for (int jj = 0; jj < step; ++jj, ++i) a0 += cs[32 * i + tid];
+            a1 += a0; a0 = 0.f;
+            if ((i & (lmask << lp)) == 0) {
+                a2 += a1; a1 = 0.f;
+                if ((i & (lmask << (2 * lp))) == 0) { a3 += a2; a2 = 0.f; }
+            }
+        }
+        for (; i < size; ++i) a0 += cs[32 * i + tid];
+        a0 += a1; a0 += a2; a0 += a3;
+        if (tid < 8)
+            for (int v = size * 4; v < V; ++v) a0 += cs[v * 8 + tid];
+        part[tid] = a0;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        float fin = 0.f;
+        for (int e = (C >> 3) << 3; e < C; ++e) fin += cs[e];
+        for (int l = 0; l < 8; ++l) fin += ((part[l] + part[8 + l]) + part[16 + l]) + part[24 + l];
+        total_s = fin;
+    }
+    __syncthreads();
+    const float total = total_s;
+    const float den = total + ceps;
+    for (int c = tid; c < C; c += 256) denom[c] = ((cs[c] + eps) / den) * total;
+}
+
+// one wave per code row
+__global__ void __launch_bounds__(256) vq_ema_embed_kernel(float *embed_avg, float *embed, const float *embed_sum,
+                                                           const float *weight, const float *denom, int C, int D,
+                                                           float omd, int cosine, int do_lerp, int do_update)
+{
+    const int lane = threadIdx.x & 63;
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (c >= C) return;
+    const float w = weight ? omd * weight[c] : omd;
+    const float den = do_update ? denom[c] : 1.f;
+    float e[8];
+    float ss = 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int d = lane + 64 * q;
+        e[q] = 0.f;
+        if (d < D) {
+            const size_t o = (size_t)c * D + d;
+            float ea = embed_avg[o];
+            if (do_lerp) {
+                ea = aten_lerp(ea, embed_sum[o], w);
+                embed_avg[o] = ea;
+            }
+            if (do_update) {
+                e[q] = ea / den;
+                ss += e[q] * e[q];
+            }
+        }
+    }
+    if (!do_update) return;
+    float inv = 1.f;
+    if (cosine) {
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) ss += __shfl_xor(ss, o, 64);
+        inv = fmaxf(sqrtf(ss), 1e-6f);
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int d = lane + 64 * q;
+        if (d < D) embed[(size_t)c * D + d] = cosine ? (e[q] / inv) : e[q];
+    }
+}
+
+extern "C" int vqhip_ema_finalize(float *cluster_size, float *embed_avg, float *embed,
+                                  const float *count, const float *embed_sum, const float *weight,
+                                  int C, int D, float one_minus_decay, float eps, int cosine,
+                                  int do_lerp, int do_update_ema, float *denom_ws, void *stream)
+{
+    if (!cluster_size || !embed_avg || !embed || C <= 0) VQ_FAIL(VQHIP_EINVAL, "ema_finalize: null pointer or C <= 0");
+    if (D < 1 || D > 512) VQ_FAIL(VQHIP_EDIM, "ema_finalize: D=%d unsupported (1..512)", D);
+    if (do_lerp && (!count || !embed_sum)) VQ_FAIL(VQHIP_EINVAL, "ema_finalize: do_lerp needs count and embed_sum");
+    if (do_update_ema && !denom_ws) VQ_FAIL(VQHIP_EINVAL, "ema_finalize: do_update_ema needs denom_ws");
+    hipStream_t st = (hipStream_t)stream;
+    if (do_lerp)
+        hipLaunchKernelGGL(vq_ema_cs_lerp_kernel, dim3((C + 255) / 256), dim3(256), 0, st, cluster_size, count, weight, C, one_minus_decay);
+    if (do_update_ema) {
+        const float ceps = (float)((double)C * (double)eps);
+        hipLaunchKernelGGL(vq_ema_denom_kernel, dim3(1), dim3(256), 0, st, cluster_size, C, eps, ceps, denom_ws);
+    }
+    if (do_lerp || do_update_ema)
+        hipLaunchKernelGGL(vq_ema_embed_kernel, dim3((C + 3) / 4), dim3(256), 0, st, embed_avg, embed, embed_sum, weight,
+                           denom_ws, C, D, one_minus_decay, cosine, do_lerp, do_update_ema);
+    return launch_status("vq_ema_finalize");
+}
+
+// ------------------------------------------------------------------------------------------------
+// decode: out[n,:] = sum_q embed_q[idx[n,q],:]   (sequential in q, like the reference's running sum)
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) vq_decode_kernel(const int64_t *__restrict__ idx, int64_t N, int Q,
+                                                        const float *__restrict__ embed, int64_t qstride, int C, int D,
+                                                        void *out, int out_bf16, int64_t ldo)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t n = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= N) return;
+    float s[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s[u] = 0.f;
+    for (int q = 0; q < Q; ++q) {
+        const int64_t c = idx[n * Q + q];
+        if (c < 0 || c >= C) continue;
+        const float *r = embed + (size_t)q * qstride + (size_t)c * D;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int d = lane + 64 * u;
+            if (d < D) s[u] += r[d];
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int d = lane + 64 * u;
+        if (d < D) {
+            if (out_bf16) ((unsigned short *)out)[n * ldo + d] = f32_to_bf16_rne(s[u]);
+            else ((float *)out)[n * ldo + d] = s[u];
+        }
+    }
+}
+
+extern "C" int vqhip_decode_sum(const int64_t *idx, int64_t N, int Q, const float *embed, int64_t embed_qstride,
+                                int C, int D, void *out, int out_dtype, int64_t ldo, void *stream)
+{
+    if (N < 0 || Q < 1 || C <= 0) VQ_FAIL(VQHIP_EINVAL, "decode_sum: bad size");
+    if (N == 0) return 0;
+    if (!idx || !embed || !out) VQ_FAIL(VQHIP_EINVAL, "decode_sum: null pointer");
+    if (D < 1 || D > 512) VQ_FAIL(VQHIP_EDIM, "decode_sum: D=%d unsupported (1..512)", D);
+    if (out_dtype != VQHIP_F32 && out_dtype != VQHIP_BF16) VQ_FAIL(VQHIP_EINVAL, "decode_sum: unknown dtype");
+    hipLaunchKernelGGL(vq_decode_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, (hipStream_t)stream, idx, N, Q, embed,
+                       embed_qstride, C, D, out, out_dtype == VQHIP_BF16, ldo);
+    return launch_status("vq_decode_kernel");
+}
