@@ -1,0 +1,154 @@
+#!/usr/bin/env python
+"""bench.py -- BASELINE.json's headline metric on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is one training forward of the hot path (codebook pack + fused fp32-MFMA assign/gather/loss +
+EMA statistics + EMA fold) over one synthetic batch already resident in HBM.  At N = 1 the workload is
+BASELINE config[1]: VectorQuantize(dim=256, codebook_size=1024), x = (64, 16384, 256) bf16 (2^20
+vectors).  For N > 1 (launched by torch.distributed.run, one rank per GPU, RCCL) every rank owns its
+own batch of that shape (weak scaling) and the EMA statistics are summed with ONE all-reduce per step,
+which is the reference's data-parallel scheme (vqp.py:603, 607).  value = all ranks' vectors / max time.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch
+import torch.distributed as dist
+
+B, S, D, C = 64, 16384, 256, 1024
+PEAK_FP32_MFMA_TFLOPS = 157.3        # /opt/skills/guides/MI355X_MICROARCH.md, v_mfma_f32_32x32x2_f32 dense peak
+
+
+def cpu_baseline(nthreads):
+    """The reference's CPU op sequence (oracle mode="aten": 3 N*C*D contractions + the N*C temporaries,
+    bit-identical to the live reference) on the host cores, bounded sample of the same workload."""
+    from oracle import vq_oracle as O
+    # torch's own default thread count is what the reference would run with on this host
+    rows_b, rows_s = 8, 16384                       # 131072 of the 2^20 vectors per timed forward
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(rows_b, rows_s, D, generator=g).bfloat16()
+    bound = (6.0 / (C * D)) ** 0.5
+    e = (torch.rand(1, C, D, generator=g) * 2 - 1) * bound
+    st = O.VQState(embed=e.clone(), embed_avg=e.clone(), cluster_size=torch.ones(1, C))
+    cfg = O.VQConfig(dim=D, codebook_size=C)
+    with torch.no_grad():
+        O.vq_forward(st, cfg, x)                    # warm-up
+        ts = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            O.vq_forward(st, cfg, x)
+            ts.append(time.perf_counter() - t0)
+    t = sorted(ts)[1]
+    return dict(value=rows_b * rows_s / t, unit="vectors/s", cores=nthreads, kind="port",
+                sample=f"oracle mode=aten (reference op sequence) x=({rows_b},{rows_s},{D}) bf16, C={C}, train step, median of 3 after 1 warm-up, {t:.3f} s/forward")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    from vector_quantize_pytorch_amd import VectorQuantize, _lib
+
+    torch.manual_seed(0)
+    vq = VectorQuantize(dim=D, codebook_size=C, sync_codebook=(world > 1)).to(dev).train()
+    g = torch.Generator().manual_seed(rank)
+    x = torch.randn(B, S, D, generator=g).bfloat16().to(dev)       # resident in HBM before timing
+
+    # per-launch timing of the dominant kernel (vq_assign_kernel) with events on the launch stream
+    ev = []
+    orig_assign = _lib.assign
+
+    def timed_assign(*a, **k):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        r = orig_assign(*a, **k)
+        e1.record()
+        ev.append((e0, e1))
+        return r
+
+    import vector_quantize_pytorch_amd.codebook as cbmod
+    cbmod.L.assign = timed_assign
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            vq(x)
+        sync()
+        ev.clear()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            q, idx, loss = vq(x)
+        sync()
+        dt = time.perf_counter() - t0
+
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+
+    if rank == 0:
+        n_vec = B * S
+        k_ms = sum(a.elapsed_time(b) for a, b in ev) / max(len(ev), 1)
+        flops = 2.0 * n_vec * C * D                                  # 2*C*D per vector
+        achieved = flops / (k_ms * 1e-3) / 1e12
+        traffic = None
+        tp = os.path.join(ROOT, "profiles", "traffic.json")          # HBM bytes per launch from rocprofv3 PMC passes
+        if os.path.exists(tp):
+            try:
+                traffic = json.load(open(tp)).get("vq_assign_kernel_cfg2_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "vectors quantized/sec (VectorQuantize train forward, dim=256 cb=1024)",
+            "value": world * n_vec * args.steps / dt,
+            "unit": "vectors/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"VectorQuantize(dim={D}, codebook_size={C}) train forward + EMA update, x=({B},{S},{D}) bf16 per GPU",
+                       "vectors_per_gpu": n_vec, "parallelism": f"dp{world} (rows sharded, one all-reduce of EMA statistics per step)" if world > 1 else "single GPU",
+                       "loss": float(loss.item())},
+            "roofline": {"bound": "mfma", "kernel": "vq_assign_kernel<256,bf16,euclid>", "achieved": achieved,
+                         "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
+                         "traffic": traffic, "kernel_ms": k_ms, "algorithmic_flops_per_launch": flops,
+                         "algorithmic_bytes_per_launch": n_vec * 1032 + C * D * 4},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(torch.get_num_threads())
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

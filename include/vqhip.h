@@ -13,7 +13,7 @@
  *    synchronises.  All work is enqueued on `stream` (a hipStream_t passed as void*).
  *  - return value: 0 on success, a negative VQHIP_E* code on argument errors, or a positive
  *    hipError_t from the launch.  vqhip_last_error() returns a thread-local message.
- *  - dtype codes: VQHIP_F32 = 0, VQHIP_BF16 = 1.  metric: 0 = euclidean, 1 = cosine.
+ *  - dtype codes: VQHIP_F32 = 0, VQHIP_BF16 = 1.  metric: VQHIP_EUCLID / VQHIP_COSINE / VQHIP_COSINE_PRENORM.
  *  - supported shapes: 1 <= D <= 512, C >= 1, N >= 0; rows addressed as base + n * ld (elements).
  */
 #ifndef VQHIP_H
@@ -30,7 +30,8 @@ extern "C" {
 #define VQHIP_BF16 1
 
 #define VQHIP_EUCLID 0
-#define VQHIP_COSINE 1
+#define VQHIP_COSINE 1          /* l2-normalise the rows in the kernel prologue, then max dot product */
+#define VQHIP_COSINE_PRENORM 2  /* rows are already unit-norm: max dot product only                    */
 
 #define VQHIP_EINVAL   (-1)   /* bad argument (null pointer, negative size, unknown dtype) */
 #define VQHIP_EDIM     (-2)   /* D outside the supported range                              */

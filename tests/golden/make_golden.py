@@ -1,0 +1,148 @@
+"""Generates tests/golden/*.npz from the LIVE reference (lucidrains/vector-quantize-pytorch v1.31.0,
+mounted read-only at /root/reference in the build container; it does not exist on the GPU box).
+
+    python tests/golden/make_golden.py
+
+The reference hard-imports `einx`, which is not installed; oracle/refshim/einx provides the handful of
+patterns the VQ / RVQ path uses (see its docstring).  Each fixture stores: constructor kwargs, the
+state_dict before, the inputs, the reference outputs (indices always; quantized as a sha1 + float64
+sum because it is exactly embed_before[indices]) and the state after.  RNG-dependent steps (k-means
+seeding, dead-code replacement) are made deterministic through the reference's own seams
+`Codebook.sample_fn` / `.replace_sample_fn` (vqp.py:408-410): "take the first `num` rows".
+"""
+import hashlib
+import json
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, os.path.join(ROOT, "oracle", "refshim"))
+sys.path.insert(0, "/root/reference")
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+from vector_quantize_pytorch import GroupedResidualVQ, ResidualVQ, VectorQuantize  # the live reference
+
+
+def first_rows(samples, num):           # deterministic stand-in for batched_sample_vectors (vqp.py:165)
+    n = samples.shape[1]
+    if n >= num:
+        return samples[:, :num].clone()
+    reps = -(-num // n)
+    return samples.repeat(1, reps, 1)[:, :num].clone()
+
+
+def sha(t):
+    return hashlib.sha1(to_np(t.detach().contiguous()).tobytes()).hexdigest()
+
+
+def to_np(t):
+    t = t.detach().cpu().clone()          # clone: state_dict tensors alias live buffers that the forward mutates
+    if t.dtype == torch.bfloat16:
+        return t.view(torch.int16).numpy()          # raw bits; loader views them back
+    return t.numpy()
+
+
+def inject(mod):
+    for m in mod.modules():
+        if hasattr(m, "sample_fn"):
+            m.sample_fn = first_rows
+            m.replace_sample_fn = first_rows
+
+
+def run_case(name, cls, kwargs, xs, *, train=True, fwd_kwargs=None, grad=False, unit_codebook=False, deterministic_sampling=False):
+    torch.manual_seed(1234)
+    mod = cls(**kwargs)
+    if unit_codebook:
+        for m in mod.modules():
+            if hasattr(m, "embed"):
+                e = torch.randn_like(m.embed)
+                if getattr(m, "use_cosine_sim", False):
+                    e = torch.nn.functional.normalize(e, dim=-1)
+                m.embed.copy_(e)
+                m.embed_avg.copy_(e)
+    if deterministic_sampling:
+        inject(mod)
+    mod.train(train)
+    out = {"meta": dict(name=name, cls=cls.__name__, kwargs={k: (list(v) if isinstance(v, tuple) else v) for k, v in kwargs.items()},
+                        train=train, steps=len(xs), grad=grad, fwd_kwargs=fwd_kwargs or {},
+                        deterministic_sampling=deterministic_sampling, bf16=bool(xs[0].dtype == torch.bfloat16))}
+    arrays = {}
+    shared = bool(kwargs.get("shared_codebook", False))
+
+    def aliased(k):     # shared_codebook: layers.{i>0} alias layers.0 (rvq.py:302-306); store once
+        return shared and k.startswith("layers.") and not k.startswith("layers.0.")
+
+    for k, v in mod.state_dict().items():
+        if aliased(k):
+            continue
+        if k.endswith("embed_avg") and torch.equal(v, mod.state_dict()[k[:-4]]):
+            continue                                 # loader: missing embed_avg == embed
+        arrays["before/" + k] = to_np(v)
+    fk = dict(fwd_kwargs or {})
+    if "lens" in fk:
+        fk["lens"] = torch.tensor(fk["lens"])
+    for s, x in enumerate(xs):
+        x = x.clone()
+        if grad:
+            x.requires_grad_(True)
+        res = mod(x, **fk)
+        q, idx, loss = res[0], res[1], res[2]
+        arrays[f"x{s}"] = to_np(x)
+        arrays[f"idx{s}"] = to_np(idx)
+        arrays[f"loss{s}"] = to_np(loss.float())
+        arrays[f"qsum{s}"] = np.float64(q.double().sum().item())
+        out["meta"][f"qsha{s}"] = sha(q)
+        if grad or q.dtype != torch.float32 or "lens" in fk or cls is not VectorQuantize:
+            arrays[f"q{s}"] = to_np(q)          # not reconstructible as embed[idx]: store it
+        if grad:
+            g = torch.Generator().manual_seed(77 + s)
+            w = torch.randn(q.shape, generator=g).to(q.dtype)
+            (loss.sum() * 3.0 + (q * w).sum()).backward()
+            arrays[f"gw{s}"] = to_np(w)
+            arrays[f"gx{s}"] = to_np(x.grad)
+    if train:
+        for k, v in mod.state_dict().items():
+            if not aliased(k):
+                arrays["after/" + k] = to_np(v)
+    arrays["meta"] = np.frombuffer(json.dumps(out["meta"]).encode(), dtype=np.uint8)
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **arrays)
+    print(f"{name}: {os.path.getsize(path) / 1e6:.2f} MB  loss0={float(arrays['loss0'].reshape(-1)[0]):.6f}")
+
+
+def randn(*shape, seed=0, dtype=torch.float32):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g).to(dtype)
+
+
+if __name__ == "__main__":
+    torch.set_num_threads(8)
+    # BASELINE cfg 1: README smoke test shape, default (tiny, tie-prone) kaiming codebook
+    run_case("vq_cfg1_train", VectorQuantize, dict(dim=256, codebook_size=512), [randn(1, 1024, 256, seed=1)])
+    run_case("vq_cfg1_eval", VectorQuantize, dict(dim=256, codebook_size=512), [randn(1, 1024, 256, seed=2)], train=False)
+    run_case("vq_unit_2step", VectorQuantize, dict(dim=128, codebook_size=256), [randn(2, 300, 128, seed=3), randn(2, 300, 128, seed=4)], unit_codebook=True)
+    run_case("vq_cosine", VectorQuantize, dict(dim=128, codebook_size=256, use_cosine_sim=True), [randn(1, 512, 128, seed=5), randn(1, 512, 128, seed=6)])
+    # cfg 2 dtype (bf16 in), scaled down
+    run_case("vq_bf16", VectorQuantize, dict(dim=256, codebook_size=1024), [randn(2, 512, 256, seed=7, dtype=torch.bfloat16)])
+    run_case("vq_lens", VectorQuantize, dict(dim=64, codebook_size=128), [randn(3, 200, 64, seed=8)], fwd_kwargs=dict(lens=[200, 57, 1]), unit_codebook=True)
+    run_case("vq_grad_rot", VectorQuantize, dict(dim=64, codebook_size=128), [randn(2, 128, 64, seed=9)], grad=True, unit_codebook=True)
+    run_case("vq_grad_ste", VectorQuantize, dict(dim=64, codebook_size=128, rotation_trick=False), [randn(2, 128, 64, seed=10)], grad=True, unit_codebook=True)
+    run_case("vq_grad_cos", VectorQuantize, dict(dim=64, codebook_size=128, use_cosine_sim=True), [randn(2, 128, 64, seed=11)], grad=True)
+    run_case("vq_kmeans", VectorQuantize, dict(dim=32, codebook_size=64, kmeans_init=True, kmeans_iters=4), [randn(1, 2048, 32, seed=12)], deterministic_sampling=True)
+    run_case("vq_expire", VectorQuantize, dict(dim=32, codebook_size=128, threshold_ema_dead_code=2), [randn(1, 256, 32, seed=13), randn(1, 256, 32, seed=14)],
+             unit_codebook=True, deterministic_sampling=True)
+    run_case("vq_fmap", VectorQuantize, dict(dim=32, codebook_size=64, accept_image_fmap=True), [randn(2, 32, 8, 8, seed=15)], unit_codebook=True)
+    run_case("vq_proj", VectorQuantize, dict(dim=48, codebook_size=64, codebook_dim=16), [randn(2, 50, 48, seed=16)], unit_codebook=True)
+    # cfg 3: ResidualVQ shared codebook, scaled down
+    run_case("rvq_shared", ResidualVQ, dict(dim=256, num_quantizers=8, codebook_size=256, shared_codebook=True), [randn(2, 128, 256, seed=17), randn(2, 128, 256, seed=18)])
+    run_case("rvq_separate", ResidualVQ, dict(dim=64, num_quantizers=4, codebook_size=128), [randn(2, 200, 64, seed=19)], unit_codebook=True)
+    run_case("rvq_tiger", ResidualVQ, dict(dim=2, codebook_size=(5, 128, 256)), [randn(2, 32, 2, seed=20)], unit_codebook=True)
+    run_case("rvq_cosine_eval", ResidualVQ, dict(dim=64, num_quantizers=3, codebook_size=64, use_cosine_sim=True), [randn(1, 256, 64, seed=21)], train=False)
+    # cfg 5: grouped RVQ, scaled down (k-means through the deterministic sampler)
+    run_case("grvq", GroupedResidualVQ, dict(dim=128, groups=2, num_quantizers=3, codebook_size=64), [randn(2, 100, 128, seed=22)], unit_codebook=True)
+    run_case("grvq_kmeans", GroupedResidualVQ, dict(dim=64, groups=2, num_quantizers=2, codebook_size=32, kmeans_init=True, kmeans_iters=3),
+             [randn(1, 1024, 64, seed=23)], deterministic_sampling=True)

@@ -1,0 +1,263 @@
+"""GPU: the drop-in nn.Modules (vector_quantize_pytorch_amd) against (1) the golden vectors produced
+by the live reference and (2) the oracle at larger sizes, plus size-independent properties at
+BASELINE.json's full sizes.  Tests read like the reference's tests/test_readme.py / test_beam.py.
+
+Tolerances (BASELINE.json north_star): indices bit-exact; quantized / commit_loss / state within 1e-5
+(fp32) and 1e-2 (bf16), relative to the tensor's scale.
+"""
+import pytest
+import torch
+
+import golden_util as G
+from oracle import vq_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _close(a, b, tol, what):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    assert a.shape == b.shape, f"{what}: shape {tuple(a.shape)} vs {tuple(b.shape)}"
+    scale = max(b.abs().max().item(), 1e-12)
+    err = (a - b).abs().max().item()
+    assert err <= tol * scale, f"{what}: max err {err:.3e} vs scale {scale:.3e}"
+
+
+def _build(fx, dev):
+    import vector_quantize_pytorch_amd as A
+    mod = getattr(A, fx.meta["cls"])(**fx.kwargs)
+    missing, unexpected = mod.load_state_dict(fx.state("before"), strict=True)
+    mod = mod.to(dev)
+    if fx.meta["deterministic_sampling"]:
+        for m in mod.modules():
+            if hasattr(m, "sample_fn"):
+                m.sample_fn = G.first_rows
+                m.replace_sample_fn = G.first_rows
+    mod.train(fx.meta["train"])
+    return mod
+
+
+@pytest.mark.parametrize("name", G.names())
+def test_module_matches_reference_golden(dev, name):
+    fx = G.Fixture(name)
+    mod = _build(fx, dev)
+    tol = 1e-2 if fx.bf16 else 1e-5
+    for s in range(fx.meta["steps"]):
+        x = fx.t(f"x{s}").to(dev)
+        if fx.meta["grad"]:
+            x.requires_grad_(True)
+        q, idx, loss = mod(x, **fx.fwd_kwargs(dev))[:3]
+        want_idx = fx.t(f"idx{s}")
+        assert idx.dtype == torch.int64 and q.dtype == x.dtype and loss.dtype == torch.float32
+        nm = (idx.cpu() != want_idx).sum().item()
+        assert nm == 0, f"step {s}: {nm} index mismatches vs the reference"
+        _close(loss.reshape(-1), fx.t(f"loss{s}").reshape(-1), tol, f"loss step {s}")
+        if fx.has(f"q{s}"):
+            _close(q.float(), fx.t(f"q{s}").float(), tol, f"quantized step {s}")
+        elif s == 0 and not fx.meta["kwargs"].get("kmeans_init") and "codebook_dim" not in fx.meta["kwargs"]:
+            # no-grad fp32, first step: quantized is an exact copy of rows of the (identical) codebook -> bitwise (sha1)
+            import hashlib
+            assert hashlib.sha1(q.detach().cpu().contiguous().numpy().tobytes()).hexdigest() == fx.meta[f"qsha{s}"]
+        else:   # rows of a codebook that already went through fp32 k-means / EMA arithmetic, or a projection
+            want = float(fx.arr[f"qsum{s}"])
+            assert abs(q.double().sum().item() - want) <= 1e-4 * max(1.0, abs(want))
+        if fx.meta["grad"]:
+            (loss.sum() * 3.0 + (q * fx.t(f"gw{s}").to(dev)).sum()).backward()
+            _close(x.grad.float(), fx.t(f"gx{s}").float(), tol, f"grad_x step {s}")
+    if fx.meta["train"]:
+        after = fx.state("after")
+        mine = mod.state_dict()
+        assert set(mine.keys()) == set(after.keys())
+        for k, v in after.items():
+            if k.endswith("initted"):
+                assert bool(mine[k]) == bool(v)
+            else:
+                _close(mine[k].float(), v.float(), tol, k)
+
+
+# ---- reference tests/test_readme.py style self-consistency tests -----------------------------------
+@pytest.mark.parametrize("use_cosine_sim", (True, False))
+@pytest.mark.parametrize("rotation_trick", (True, False))
+@pytest.mark.parametrize("input_requires_grad", (True, False))
+def test_vq(dev, use_cosine_sim, rotation_trick, input_requires_grad):       # tests/test_readme.py:7-31
+    from vector_quantize_pytorch_amd import VectorQuantize
+    vq = VectorQuantize(dim=256, codebook_size=512, decay=0.8, commitment_weight=1., use_cosine_sim=use_cosine_sim,
+                        rotation_trick=rotation_trick).to(dev)
+    x = torch.randn(1, 1024, 256, device=dev)
+    if input_requires_grad:
+        x.requires_grad_()
+    quantized, indices, commit_loss = vq(x)
+    assert quantized.shape == x.shape and indices.shape == (1, 1024) and commit_loss.ndim == 0
+    if input_requires_grad:
+        (quantized.sum() + commit_loss).backward()
+        assert x.grad is not None and torch.isfinite(x.grad).all()
+
+
+def test_vq_eval(dev):                                                        # tests/test_readme.py:33-47
+    from vector_quantize_pytorch_amd import VectorQuantize
+    vq = VectorQuantize(dim=256, codebook_size=512).to(dev).eval()
+    x = torch.randn(1, 1024, 256, device=dev)
+    quantized, indices, commit_loss = vq(x)
+    assert torch.allclose(quantized, vq.get_output_from_indices(indices))
+    assert commit_loss.item() == 0.
+
+
+def test_vq_mask(dev):                                                        # tests/test_readme.py:49-72
+    from vector_quantize_pytorch_amd import VectorQuantize
+    vq = VectorQuantize(dim=256, codebook_size=512).to(dev).eval()
+    x = torch.randn(1, 1024, 256, device=dev)
+    lens = torch.full((1,), 512, device=dev)
+    vq.train()
+    sd = {k: v.clone() for k, v in vq.state_dict().items()}
+    quantized, indices, commit_loss = vq(x[:, :512])
+    vq.load_state_dict(sd)
+    mquantized, mindices, mcommit_loss = vq(x, lens=lens)
+    assert torch.allclose(commit_loss, mcommit_loss)
+    assert torch.allclose(quantized, mquantized[:, :512])
+    assert torch.equal(indices, mindices[:, :512])
+    assert (mquantized[:, 512:] == 0.).all() and (mindices[:, 512:] == -1).all()
+
+
+@pytest.mark.parametrize("shared_codebook", (True, False))
+@pytest.mark.parametrize("use_cosine_sim", (True, False))
+@pytest.mark.parametrize("train", (True, False))
+def test_residual_vq(dev, shared_codebook, use_cosine_sim, train):            # tests/test_readme.py:74-103
+    from vector_quantize_pytorch_amd import ResidualVQ
+    rvq = ResidualVQ(dim=256, num_quantizers=8, codebook_size=1024, shared_codebook=shared_codebook,
+                     use_cosine_sim=use_cosine_sim).to(dev)
+    x = torch.randn(1, 256, 256, device=dev)
+    rvq.train(train)
+    quantized, indices, commit_loss = rvq(x, freeze_codebook=train)
+    out = rvq.get_output_from_indices(indices)
+    assert torch.allclose(quantized, out, atol=1e-5)
+    assert indices.shape == (1, 256, 8) and commit_loss.shape == (8,)
+
+
+def test_grouped_residual_vq(dev):                                            # tests/test_readme.py:120-132
+    from vector_quantize_pytorch_amd import GroupedResidualVQ
+    rvq = GroupedResidualVQ(dim=256, num_quantizers=8, groups=2, codebook_size=1024).to(dev)
+    x = torch.randn(1, 1024, 256, device=dev)
+    quantized, indices, commit_loss = rvq(x)
+    assert quantized.shape == x.shape and indices.shape == (2, 1, 1024, 8) and commit_loss.shape == (2, 8)
+
+
+def test_accum_ema_update(dev):                                               # tests/test_readme.py:467-492
+    from vector_quantize_pytorch_amd import VectorQuantize
+    vq = VectorQuantize(dim=64, codebook_size=128).to(dev)
+    before = vq.codebook.clone()
+    x = torch.randn(2, 256, 64, device=dev)
+    vq(x, accum_ema_update=True)
+    vq(x, accum_ema_update=True)
+    assert torch.equal(before, vq.codebook)
+    vq(x)
+    assert not torch.allclose(before, vq.codebook)
+
+
+def test_custom_ema_update_weighting(dev):                                    # tests/test_readme.py:434-465
+    from vector_quantize_pytorch_amd import VectorQuantize
+    vq = VectorQuantize(dim=64, codebook_size=128).to(dev)
+    x = torch.randn(16, 256, 64, device=dev)
+    w = torch.zeros(128, device=dev); w[64:] = 1.
+    before = vq.codebook.clone()
+    vq(x, ema_update_weight=w)
+    after = vq.codebook
+    assert torch.allclose(before[:64], after[:64], atol=1e-6)
+    assert (before[64:] != after[64:]).any(-1).all()
+
+
+def test_update_ema_indices_matches_forward(dev):                             # tests/test_beam.py:7-47
+    from vector_quantize_pytorch_amd import VectorQuantize
+    vq1 = VectorQuantize(dim=64, codebook_size=128).to(dev)
+    vq2 = VectorQuantize(dim=64, codebook_size=128, manual_ema_update=False).to(dev)
+    vq2.load_state_dict(vq1.state_dict())
+    x = torch.randn(2, 300, 64, device=dev)
+    _, idx, _ = vq1(x)
+    vq2.update_ema_indices(x, idx)
+    for k in ("cluster_size", "embed_avg", "embed"):
+        a, b = getattr(vq1._codebook, k), getattr(vq2._codebook, k)
+        assert torch.allclose(a, b, rtol=1e-5, atol=1e-6), k
+
+
+# ---- larger-than-fixture parity vs the oracle, and full-size properties ---------------------------
+def test_vq_vs_oracle_multi_step_64k(dev):
+    """N = 65536 rows, C = 1024, D = 256, default tiny codebook, 3 EMA steps from a common state:
+    indices bit-exact vs the chain oracle at every step as long as the codebooks agree to fp32
+    round-off; any disagreement is audited by the fp32 gap in the oracle's own score row."""
+    from vector_quantize_pytorch_amd import VectorQuantize
+    torch.manual_seed(0)
+    vq = VectorQuantize(dim=256, codebook_size=1024)
+    sd = {k: v.clone() for k, v in vq.state_dict().items()}
+    st = O.VQState.from_state_dict(sd)
+    cfg = O.VQConfig(dim=256, codebook_size=1024)
+    vq = vq.to(dev)
+    g = torch.Generator().manual_seed(5)
+    for step in range(3):
+        x = torch.randn(8, 8192, 256, generator=g)
+        e_before = st.embed[0].clone()
+        q, idx, loss = vq(x.to(dev))
+        q2, idx2, loss2 = O.vq_forward(st, cfg, x, assign_mode="chain", stats_mode="double")
+        idx, idx2 = idx.cpu().reshape(-1), idx2.reshape(-1)
+        audit = G.classify_mismatches(x.reshape(-1, 256), e_before, idx, idx2)
+        if step == 0:
+            assert len(audit) == 0, audit[:5]
+        assert all(gap <= 4.0 for *_, gap in audit), audit[:5]       # only near-ties once codebooks differ by round-off
+        assert len(audit) <= 16
+        _close(loss, loss2, 1e-5, f"loss step {step}")
+        _close(vq._codebook.embed.cpu(), st.embed, 1e-5, f"embed step {step}")
+        _close(vq._codebook.cluster_size.cpu(), st.cluster_size, 1e-5, f"cluster_size step {step}")
+
+
+def test_cfg2_full_size_properties(dev):
+    """BASELINE cfg 2 at full size: x = (64, 16384, 256) bf16, C = 1024.  The oracle cannot run 1M rows in
+    seconds, so check (a) a 32768-row slice bit-exactly against the chain oracle, (b) quantized == codebook
+    rows of the returned indices everywhere, (c) the commit loss equals the mean squared error recomputed
+    from (x, quantized), (d) cluster_size follows the EMA of the index histogram exactly."""
+    from vector_quantize_pytorch_amd import VectorQuantize
+    torch.manual_seed(0)
+    vq = VectorQuantize(dim=256, codebook_size=1024).to(dev)
+    e0 = vq.codebook.clone()
+    x = torch.randn(64, 16384, 256, device=dev, dtype=torch.bfloat16)
+    q, idx, loss = vq(x)
+    assert q.dtype == torch.bfloat16 and idx.shape == (64, 16384)
+    sl = x[3, :].float().cpu()
+    idx_o, _ = O.c_assign(sl, e0.cpu())
+    assert torch.equal(idx[3].cpu(), idx_o)
+    assert torch.equal(q, e0[idx].to(torch.bfloat16))
+    mse = ((q.float() - x.float()) ** 2).mean()
+    assert abs(loss.item() - mse.item()) <= 1e-3 * mse.item()
+    hist = torch.bincount(idx.reshape(-1), minlength=1024).float()
+    want_cs = torch.lerp(torch.ones(1024, device=dev), hist, 0.2)
+    _close(vq._codebook.cluster_size[0], want_cs, 1e-6, "cluster_size")
+    assert hist.sum().item() == 64 * 16384
+
+
+def test_cfg3_rvq_shared_vs_oracle(dev):
+    """BASELINE cfg 3 shape scaled to 16384 rows: ResidualVQ Q = 8, C = 1024, shared codebook."""
+    from vector_quantize_pytorch_amd import ResidualVQ
+    torch.manual_seed(1)
+    rvq = ResidualVQ(dim=256, num_quantizers=8, codebook_size=1024, shared_codebook=True)
+    sd = {k: v.clone() for k, v in rvq.state_dict().items()}
+    st = O.VQState.from_state_dict(sd, "layers.0._codebook.")
+    cfg = O.VQConfig(dim=256, codebook_size=1024, manual_ema_update=True)
+    rvq = rvq.to(dev)
+    x = torch.randn(2, 8192, 256, generator=torch.Generator().manual_seed(2))
+    q, idx, loss = rvq(x.to(dev))
+    q2, idx2, loss2 = O.rvq_forward([st] * 8, cfg, x, shared_codebook=True, assign_mode="chain", stats_mode="double")
+    assert torch.equal(idx.cpu(), idx2)
+    _close(q, q2, 1e-5, "quantized_out")
+    _close(loss, loss2, 1e-5, "losses")
+    _close(rvq.layers[0]._codebook.embed.cpu(), st.embed, 1e-5, "embed after")
+
+
+def test_errors_are_loud(dev):
+    from vector_quantize_pytorch_amd import VectorQuantize
+    from vector_quantize_pytorch_amd._lib import VQHipError
+    vq = VectorQuantize(dim=64, codebook_size=32)
+    with pytest.raises(VQHipError):
+        vq(torch.randn(1, 8, 64))                      # CPU tensor: no fallback
+    with pytest.raises(NotImplementedError):
+        VectorQuantize(dim=64, codebook_size=32, stochastic_sample_codes=True)
+    with pytest.raises(NotImplementedError):
+        VectorQuantize(dim=1024, codebook_size=32)
+    vq = vq.to(dev)
+    q, idx, loss = vq(torch.randn(0, 8, 64, device=dev))   # empty batch
+    assert q.shape == (0, 8, 64) and idx.shape == (0, 8)

@@ -1,0 +1,73 @@
+"""CPU: pins the oracle (oracle/vq_oracle.{c,py}) to the golden vectors produced by the live reference.
+
+ * mode="aten"  (the reference's own ATen/MKL op sequence restated) must reproduce every fixture:
+   indices identical, floats to 1e-6 (bit-identical on the host that generated them).
+ * mode="chain" (the deterministic C restatement the HIP kernels are compared with bit-for-bit) must
+   give identical indices on every fixture and floats within the north-star tolerance (1e-5).
+"""
+import pytest
+import torch
+
+import golden_util as G
+from oracle import vq_oracle as O
+
+
+def _close(a, b, tol, what):
+    a, b = a.double(), b.double()
+    scale = max(b.abs().max().item(), 1e-12)
+    err = (a - b).abs().max().item()
+    assert err <= tol * scale, f"{what}: max err {err:.3e} vs scale {scale:.3e}"
+
+
+@pytest.mark.parametrize("name", [n for n in G.names() if n not in ("vq_fmap", "vq_proj")])
+@pytest.mark.parametrize("mode", ["aten", "chain"])
+def test_oracle_reproduces_reference(name, mode):
+    fx = G.Fixture(name)
+    outs, final = G.run_oracle(fx, mode)
+    tol = 1e-6 if mode == "aten" else 1e-5
+    if fx.bf16:
+        tol = 1e-2
+    for s, o in enumerate(outs):
+        want_idx = fx.t(f"idx{s}")
+        assert torch.equal(o["idx"], want_idx), f"step {s}: {(o['idx'] != want_idx).sum().item()} index mismatches"
+        _close(o["loss"].reshape(-1), fx.t(f"loss{s}").reshape(-1), tol, f"loss step {s}")
+        if fx.has(f"q{s}"):
+            _close(o["q"].float(), fx.t(f"q{s}").float(), tol, f"quantized step {s}")
+        else:
+            assert abs(o["q"].double().sum().item() - float(fx.arr[f"qsum{s}"])) <= 1e-6 * max(1.0, abs(float(fx.arr[f"qsum{s}"])))
+        if "gx" in o:
+            _close(o["gx"].float(), fx.t(f"gx{s}").float(), tol if mode == "chain" else 1e-5, f"grad_x step {s}")
+    if fx.meta["train"]:
+        after = fx.state("after")
+        for k, v in final.items():
+            if k.endswith("initted"):
+                continue
+            _close(v.float(), after[k].float(), tol, k)
+
+
+@pytest.mark.parametrize("D", [2, 8, 20, 32, 40, 64, 100, 128, 256, 384, 512])
+def test_c_sumsq_is_aten_order(D):
+    x = torch.randn(2000, D, generator=torch.Generator().manual_seed(D))
+    assert torch.equal(O.c_row_sumsq(x), (x ** 2).sum(-1))
+
+
+def test_chain_vs_aten_index_agreement_audit():
+    """default (tiny, tie-prone) codebook, N = 16384: the FMA-chain dot product may only disagree with
+    MKL's on rows whose two best scores are within a couple of ulps -- classify every mismatch."""
+    g = torch.Generator().manual_seed(0)
+    N, C, D = 16384, 1024, 256
+    x = torch.randn(N, D, generator=g)
+    e = (torch.rand(C, D, generator=g) * 2 - 1) * (6.0 / (C * D)) ** 0.5
+    ia = O.neg_cdist(x[None], e[None]).argmax(-1)[0]
+    ic, _ = O.c_assign(x, e)
+    audit = G.classify_mismatches(x, e, ia, ic)
+    assert len(audit) <= N * 1e-3
+    assert all(gap <= 2.0 for *_, gap in audit), audit
+
+
+def test_oracle_first_occurrence_on_ties():
+    x = torch.randn(100, 32, generator=torch.Generator().manual_seed(3))
+    e = torch.randn(40, 32, generator=torch.Generator().manual_seed(4))
+    e2 = torch.cat([e, e])
+    assert int(O.c_assign(x, e2)[0].max()) < 40
+    assert torch.equal(O.c_assign(x, e2)[0], O.neg_cdist(x[None], e2[None]).argmax(-1)[0])

@@ -1,0 +1,8 @@
+"""vector_quantize_pytorch_amd -- MI355X-native drop-in for the VectorQuantize / ResidualVQ forward
+path of lucidrains/vector-quantize-pytorch.  HIP kernels: csrc/vqhip.hip, C ABI:
+include/vqhip.h."""
+from .codebook import Codebook
+from .vector_quantize import VectorQuantize, LossBreakdown
+from .residual_vq import ResidualVQ, GroupedResidualVQ
+
+__all__ = ["VectorQuantize", "ResidualVQ", "GroupedResidualVQ", "Codebook", "LossBreakdown"]

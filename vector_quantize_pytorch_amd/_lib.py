@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_HERE, "csrc", "libvqhip.so")
 
 F32, BF16 = 0, 1
-EUCLID, COSINE = 0, 1
+EUCLID, COSINE, COSINE_PRENORM = 0, 1, 2
 ASSIGN_ROWS_PER_BLOCK = 128
 
 _lib = None
@@ -128,7 +128,8 @@ def pack_codebook(embed2d: torch.Tensor, out: torch.Tensor | None = None) -> tor
 
 
 def assign(x: torch.Tensor, packed: torch.Tensor, embed2d: torch.Tensor, *, cosine=False,
-           want_q=True, want_sqerr=False, want_best=False, want_rnorm=False, row_mask=None, q_out=None):
+           want_q=True, want_sqerr=False, want_best=False, want_rnorm=False, row_mask=None, q_out=None,
+           skip_l2norm=False):
     """x [..., D] -> dict(idx [...], q [..., D] | None, sqerr_partials | None, best, rnorm)."""
     _need_gpu(x, packed, embed2d, row_mask)
     xk, N, D, ldx = as_rows(x)
@@ -152,7 +153,8 @@ def assign(x: torch.Tensor, packed: torch.Tensor, embed2d: torch.Tensor, *, cosi
         assert row_mask.numel() == N
     if N > 0:
         _check(lib().vqhip_assign(_ptr(xk), _dtype_code(xk), N, D, ldx, _ptr(packed), _ptr(embed2d), C,
-                                  COSINE if cosine else EUCLID, _ptr(idx), _ptr(q), _dtype_code(x), ldq,
+                                  (COSINE_PRENORM if skip_l2norm else COSINE) if cosine else EUCLID, _ptr(idx), _ptr(q),
+                                  _dtype_code(x), ldq,
                                   _ptr(best), _ptr(rnorm), _ptr(partials), _ptr(row_mask), _stream()),
                "vqhip_assign")
     elif partials is not None:

@@ -1,0 +1,352 @@
+"""MI355X codebook: the object `VectorQuantize._codebook` holds.
+
+Mirrors the interface of the reference's `Codebook` (vector_quantize_pytorch.py:349-791): same
+constructor keywords, same buffers / state_dict keys (`initted`, `cluster_size`, `embed_avg`,
+`embed`, :415-423), same public methods other code touches (`transform_input`, `update_ema`,
+`expire_codes_`, `update_indices`, `forward`).  Everything beneath is libvqhip.so (csrc/vqhip.hip):
+the N x C distance / one-hot tensors the reference materialises never exist here.
+"""
+from __future__ import annotations
+
+from typing import Callable, Optional
+
+import torch
+import torch.distributed as dist
+import torch.nn.functional as F
+from torch import Tensor, nn
+
+from . import _lib as L
+
+
+def _l2norm(t, eps=1e-6):
+    return F.normalize(t, p=2, dim=-1, eps=eps)
+
+
+def _kaiming_uniform(*shape):
+    t = torch.empty(shape)
+    nn.init.kaiming_uniform_(t)
+    return t
+
+
+def sample_rows(samples: Tensor, num: int) -> Tensor:
+    """`num` rows of `samples` [n, d]; RNG consumption identical to the reference's sample_vectors
+    (vqp.py:156-163) so that a shared seed gives the same draw on the same device."""
+    n = samples.shape[0]
+    if n >= num:
+        pick = torch.randperm(n, device=samples.device)[:num]
+    else:
+        pick = torch.randint(0, n, (num,), device=samples.device)
+    return samples[pick]
+
+
+def batched_sample_rows(samples: Tensor, num: int) -> Tensor:
+    return torch.stack([sample_rows(s, num) for s in samples.unbind(0)], 0)
+
+
+def _all_gather_sizes(n: int, device) -> list:
+    size = torch.tensor(n, dtype=torch.long, device=device)
+    sizes = [torch.empty_like(size) for _ in range(dist.get_world_size())]
+    dist.all_gather(sizes, size)
+    return [int(s) for s in sizes]
+
+
+def sample_rows_distributed(samples: Tensor, num: int) -> Tensor:
+    """Cross-rank sampling for k-means seeding / dead-code replacement (vqp.py:211-229 semantics:
+    a multinomial split of `num` over ranks proportional to their row counts, local draws, then an
+    all-gather).  samples [1, n, d] -> [1, num, d]."""
+    local = samples[0]
+    rank, world = dist.get_rank(), dist.get_world_size()
+    sizes = _all_gather_sizes(local.shape[0], local.device)
+    split = torch.empty(world, dtype=torch.long, device=local.device)
+    if rank == 0:
+        probs = torch.tensor(sizes, dtype=torch.float32)
+        probs = probs / probs.sum()
+        left, rem = num, 1.0
+        for i in range(world):
+            if i == world - 1:
+                k = left
+            else:
+                k = int(torch.binomial(torch.tensor(float(left)), (probs[i] / rem).clamp(0, 1)).item())
+            split[i] = k
+            left -= k
+            rem -= float(probs[i])
+    dist.broadcast(split, src=0)
+    counts = split.tolist()
+    mine = sample_rows(local, counts[rank])
+    # one padded all-gather instead of `world` variably-sized broadcasts
+    width = max(max(counts), 1)
+    pad = torch.zeros(width, local.shape[-1], dtype=local.dtype, device=local.device)
+    pad[: mine.shape[0]] = mine
+    gathered = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(gathered, pad)
+    out = torch.cat([g[:c] for g, c in zip(gathered, counts)], 0)
+    return out[None]
+
+
+class Codebook(nn.Module):
+    def __init__(
+        self,
+        dim,
+        codebook_size,
+        num_codebooks=1,
+        kmeans_init=False,
+        kmeans_iters=10,
+        sync_kmeans=True,
+        decay=0.8,
+        eps=1e-5,
+        threshold_ema_dead_code=2,
+        reset_cluster_size=None,
+        use_ddp=False,
+        learnable_codebook=False,
+        gumbel_sample=None,
+        sample_codebook_temp=1.,
+        ema_update=True,
+        manual_ema_update=False,
+        affine_param=False,
+        sync_affine_param=False,
+        affine_param_batch_decay=0.99,
+        affine_param_codebook_decay=0.9,
+        use_cosine_sim=False,
+        vq_bridge: Optional[nn.Module] = None,
+    ):
+        super().__init__()
+        if learnable_codebook or affine_param or vq_bridge is not None:
+            raise NotImplementedError(
+                "learnable_codebook / affine_param / vq_bridge are outside the MI355X hot path (SURVEY.md §2.1, "
+                "§8f) and are not implemented in vector_quantize_pytorch_amd")
+        if not (1 <= dim <= 512):
+            raise NotImplementedError(f"codebook dim {dim}: the HIP path supports 1 <= dim <= 512")
+
+        self.dim = dim
+        self.codebook_size = codebook_size
+        self.num_codebooks = num_codebooks
+        self.use_cosine_sim = use_cosine_sim
+        self.transform_input = _l2norm if use_cosine_sim else (lambda t: t)
+
+        self.decay = decay
+        self.eps = eps
+        self.ema_update = ema_update
+        self.manual_ema_update = manual_ema_update
+        self.kmeans_iters = kmeans_iters
+        self.threshold_ema_dead_code = threshold_ema_dead_code
+        self.has_dead_code_replacement = threshold_ema_dead_code > 0
+        self.reset_cluster_size = threshold_ema_dead_code if reset_cluster_size is None else reset_cluster_size
+        self.sample_codebook_temp = sample_codebook_temp
+        self.learnable_codebook = False
+        self.affine_param = False
+        self.vq_bridge = None
+
+        self.use_ddp = use_ddp
+        assert not (use_ddp and num_codebooks > 1 and kmeans_init), \
+            'kmeans init is not compatible with multiple codebooks in distributed environment for now'
+        sync_sampling = use_ddp and sync_kmeans
+        self.sample_fn = sample_rows_distributed if sync_sampling else batched_sample_rows
+        self.replace_sample_fn = sample_rows_distributed if sync_sampling else batched_sample_rows
+        self.sync_kmeans_stats = sync_sampling
+
+        if kmeans_init:
+            embed = torch.zeros(num_codebooks, codebook_size, dim)
+        else:
+            embed = _kaiming_uniform(num_codebooks, codebook_size, dim)     # vqp.py:385
+            if use_cosine_sim:
+                embed = _l2norm(embed)
+
+        self.register_buffer('initted', torch.tensor(not kmeans_init))
+        self.register_buffer('cluster_size', torch.ones(num_codebooks, codebook_size))
+        self.register_buffer('embed_avg', embed.clone())
+        self.register_buffer('embed', embed)
+
+        self._initted_known = not kmeans_init     # python-side cache: no host sync per forward
+
+    # ---- state handling --------------------------------------------------------------------------
+    def _load_from_state_dict(self, *args, **kwargs):
+        super()._load_from_state_dict(*args, **kwargs)
+        self._initted_known = None                # re-read `initted` lazily after a checkpoint load
+
+    def _is_initted(self) -> bool:
+        if self._initted_known is None:
+            self._initted_known = bool(self.initted.item())
+        return self._initted_known
+
+    def _views(self, h: int):
+        return self.cluster_size[h], self.embed_avg[h], self.embed[h]
+
+    # ---- k-means initialisation (vqp.py:238-278, 450-473) -----------------------------------------
+    @torch.no_grad()
+    def init_embed_(self, flat: Tensor, mask: Optional[Tensor] = None):
+        """flat [H, n, d] (already l2-normalised when cosine)."""
+        if self._is_initted():
+            return
+        H, C, D = self.num_codebooks, self.codebook_size, self.dim
+        data = flat.float()
+        if mask is not None:
+            data = data[mask].reshape(H, -1, D)
+        means = self.sample_fn(data, C).contiguous()
+        bins = None
+        for _ in range(self.kmeans_iters):
+            new_means, bins = [], []
+            for h in range(H):
+                m = means[h].contiguous()
+                # means may be zero rows when cosine; the kernel's metric handles both
+                r = L.assign(data[h], L.pack_codebook(m), m, cosine=self.use_cosine_sim, want_q=False,
+                             skip_l2norm=True)
+                cnt, esum = L.ema_accumulate(data[h], r["idx"], C)
+                if self.sync_kmeans_stats:
+                    dist.all_reduce(cnt)
+                    # the reference divides by the all-reduced bins *before* all-reducing the means
+                    # (vqp.py:258-267); keep that order
+                zero = cnt == 0
+                nm = esum / cnt.masked_fill(zero, 1.)[:, None]
+                if self.sync_kmeans_stats:
+                    dist.all_reduce(nm)
+                if self.use_cosine_sim:
+                    nm = _l2norm(nm)
+                new_means.append(torch.where(zero[:, None], m, nm))
+                bins.append(cnt)
+            means = torch.stack(new_means)
+            bins = torch.stack(bins)
+        self.embed_avg.copy_(means * bins[..., None])
+        self.cluster_size.copy_(bins)
+        self.update_ema()
+        self.initted.fill_(True)
+        self._initted_known = True
+
+    # ---- EMA pieces -------------------------------------------------------------------------------
+    @torch.no_grad()
+    def update_ema(self):
+        """embed <- embed_avg / laplace-smoothed cluster size (vqp.py:576-584)."""
+        for h in range(self.num_codebooks):
+            cs, ea, e = self._views(h)
+            L.ema_finalize(cs, ea, e, None, None, decay=self.decay, eps=self.eps, cosine=self.use_cosine_sim,
+                           do_lerp=False, do_update_ema=True)
+
+    @torch.no_grad()
+    def replace(self, batch_samples: Tensor, batch_mask: Tensor, seq_mask: Optional[Tensor] = None):
+        """vqp.py:544-562: overwrite expired codes with sampled batch rows."""
+        if self.use_cosine_sim:
+            batch_samples = _l2norm(batch_samples)
+        for h in range(batch_samples.shape[0]):
+            samples, m = batch_samples[h], batch_mask[h]
+            if seq_mask is not None:
+                samples = samples[seq_mask[h]]
+            if samples.numel() == 0:
+                continue
+            picked = self.replace_sample_fn(samples[None], int(m.sum().item()))[0].to(self.embed.dtype)
+            self.embed[h][m] = picked
+            self.cluster_size[h][m] = self.reset_cluster_size
+            self.embed_avg[h][m] = picked * self.reset_cluster_size
+
+    @torch.no_grad()
+    def expire_codes_(self, batch_samples: Tensor, seq_mask: Optional[Tensor] = None):
+        """vqp.py:564-574.  The `any()` below is the only host sync and only exists when
+        threshold_ema_dead_code > 0 (0 is VectorQuantize's default, vqp.py:818)."""
+        if not self.has_dead_code_replacement or not self.training:
+            return
+        expired = self.cluster_size < self.threshold_ema_dead_code
+        if not bool(expired.any()):
+            return
+        H = batch_samples.shape[0]
+        self.replace(batch_samples.reshape(H, -1, batch_samples.shape[-1]).float(), expired, seq_mask)
+
+    def _fold_stats(self, h, count, esum, ema_update_weight, accum_ema_update, ema_update):
+        cs, ea, e = self._views(h)
+        w = ema_update_weight
+        if callable(w):
+            w = w(esum[None], count[None])
+        if torch.is_tensor(w):
+            w = w.reshape(-1, self.codebook_size)[h if w.numel() > self.codebook_size else 0]
+            w = w.to(torch.float32).contiguous()
+        elif w is not None:
+            raise NotImplementedError("ema_update_weight must be a tensor [codebook_size], a callable or None")
+        if accum_ema_update:                       # vqp.py:612-614: park the statistics for a later fold
+            for buf, new in ((self.cluster_size, count), (self.embed_avg, esum)):
+                if buf.grad is None:
+                    buf.grad = torch.zeros_like(buf)
+                buf.grad[h] += new
+            return
+        if self.cluster_size.grad is not None:      # vqp.py:80-82: fold parked statistics first
+            count = count + self.cluster_size.grad[h]
+            esum = esum + self.embed_avg.grad[h]
+        L.ema_finalize(cs, ea, e, count, esum, decay=self.decay, eps=self.eps, cosine=self.use_cosine_sim, weight=w,
+                       do_lerp=True, do_update_ema=bool(ema_update and not self.manual_ema_update))
+
+    # ---- the hot path -----------------------------------------------------------------------------
+    @torch.no_grad()
+    def quantize(self, x: Tensor, *, mask: Optional[Tensor] = None, freeze_codebook=False,
+                 ema_update_weight=None, accum_ema_update=False, ema_update=None, update_usage=True,
+                 want_sqerr=False, input_normalized=False, q_out=None):
+        """x [b, n, d] (or [h, b, n, d] when num_codebooks > 1), float32 / bfloat16, RAW input: for the
+        cosine metric the l2norm of vqp.py:1159 is fused into the kernel (pass input_normalized=True
+        when x is already unit-norm).  Returns dict(q, idx, sqerr_partials, nblk, rnorm)."""
+        ema_update = self.ema_update if ema_update is None else ema_update
+        H, C = self.num_codebooks, self.codebook_size
+        xs = x if x.ndim == 4 else x[None]
+        assert xs.shape[0] == H and xs.shape[-1] == self.dim
+        rmask = None if mask is None else mask.reshape(-1)      # same rows for every codebook
+
+        if not self._is_initted():
+            flat = xs.reshape(H, -1, self.dim).float()
+            if self.use_cosine_sim and not input_normalized:
+                flat = _l2norm(flat)
+            self.init_embed_(flat, None if rmask is None else rmask[None].expand(H, -1))
+
+        do_update = (self.training and update_usage and not freeze_codebook
+                     and (ema_update or self.has_dead_code_replacement))
+        outs = []
+        for h in range(H):
+            e = self.embed[h]
+            packed = L.pack_codebook(e)
+            r = L.assign(xs[h], packed, e, cosine=self.use_cosine_sim, want_q=True, want_sqerr=want_sqerr,
+                         row_mask=rmask, skip_l2norm=input_normalized, want_rnorm=self.use_cosine_sim,
+                         q_out=q_out if H == 1 else None)
+            if do_update:
+                buf = torch.zeros(C * self.dim + C, dtype=torch.float32, device=x.device)
+                esum, count = buf[: C * self.dim].view(C, self.dim), buf[C * self.dim:]
+                L.ema_accumulate(xs[h], r["idx"].reshape(-1), C, cosine=self.use_cosine_sim and not input_normalized,
+                                 rnorm=r["rnorm"], row_mask=rmask, count=count, embed_sum=esum)
+                if self.use_ddp:
+                    dist.all_reduce(buf)          # ONE collective for count || embed_sum (RCCL over xGMI)
+                self._fold_stats(h, count, esum, ema_update_weight, accum_ema_update, ema_update)
+            outs.append(r)
+        if do_update and not accum_ema_update:
+            self.expire_codes_(xs.reshape(H, -1, self.dim), seq_mask=None if rmask is None else rmask[None].expand(H, -1).bool())
+        if H == 1:
+            return outs[0]
+        return dict(q=torch.stack([o["q"] for o in outs]), idx=torch.stack([o["idx"] for o in outs]),
+                    sqerr_partials=None if not want_sqerr else torch.cat([o["sqerr_partials"][: o["nblk"]] for o in outs]),
+                    nblk=sum(o["nblk"] for o in outs), rnorm=None)
+
+    @torch.no_grad()
+    def update_indices(self, x: Tensor, embed_ind: Tensor, mask: Optional[Tensor] = None,
+                       ema_update_weight=None, accum_ema_update=False, ema_update=None):
+        """EMA update from externally supplied indices (vqp.py:643-671); -1 is treated as code 0 like
+        the reference's masked_fill (:665).  x is the already-transformed input [b, n, d]."""
+        ema_update = self.ema_update if ema_update is None else ema_update
+        if not ema_update and not self.has_dead_code_replacement:
+            return
+        H, C = self.num_codebooks, self.codebook_size
+        xs = x if x.ndim == 4 else x[None]
+        ind = embed_ind if embed_ind.ndim == xs.ndim - 1 else embed_ind[None]
+        ind = ind.masked_fill(ind == -1, 0).reshape(H, -1).contiguous()
+        rmask = None if mask is None else mask.reshape(-1)
+        for h in range(H):
+            count, esum = L.ema_accumulate(xs[h], ind[h], C, row_mask=rmask)
+            if self.use_ddp:
+                dist.all_reduce(count)
+                dist.all_reduce(esum)
+            self._fold_stats(h, count, esum, ema_update_weight, accum_ema_update, ema_update)
+        if not accum_ema_update:
+            self.expire_codes_(xs.reshape(H, -1, self.dim), seq_mask=None if rmask is None else rmask[None].expand(H, -1).bool())
+
+    update_ema_indices = update_indices
+
+    def forward(self, x, sample_codebook_temp=None, mask=None, freeze_codebook=False, codebook_transform_fn=None,
+                ema_update_weight=None, accum_ema_update=False, ema_update=None, topk=None, update_usage=True):
+        """Reference call shape (vqp.py:673-686): x is the *transformed* input; returns
+        (quantize fp32, embed_ind, None) -- the N x C `dist` tensor is never produced."""
+        if codebook_transform_fn is not None or topk is not None:
+            raise NotImplementedError("codebook_transform_fn / topk are not on the MI355X hot path (SURVEY.md §8f)")
+        r = self.quantize(x.float(), mask=mask, freeze_codebook=freeze_codebook, ema_update_weight=ema_update_weight,
+                          accum_ema_update=accum_ema_update, ema_update=ema_update, update_usage=update_usage,
+                          input_normalized=True)
+        return r["q"], r["idx"], None

@@ -202,6 +202,7 @@ struct AssignArgs {
     const uint8_t *row_mask;
     int x_vec;  // 1: D == DT and x rows are vector-load aligned
     int q_vec;  // 1: D == DT and q rows are vector-store aligned
+    int skip_norm;  // cosine: rows are already unit-norm
 };
 
 __device__ __forceinline__ void swap32(float &a, float &b)
@@ -303,7 +304,8 @@ __global__ void __launch_bounds__(256, (DT <= 256 ? 2 : 1)) vq_assign_kernel(con
     if (a.D & 31) x2 = a.rnorm_out[rowc];  // exact ATen order for odd D was precomputed
 
     float nrm = 0.f;
-    if (METRIC == 1) {
+    if (METRIC == 1 && a.skip_norm) nrm = 1.f;
+    if (METRIC == 1 && !a.skip_norm) {
         // l2norm (vqp.py:37-38): x / max(||x||, 1e-6); for bf16 inputs the reference normalises in
         // bf16 (norm and quotient both rounded to bf16) before Codebook.forward casts to fp32.
         nrm = sqrtf(x2);
@@ -534,7 +536,7 @@ extern "C" int vqhip_assign(const void *x, int x_dtype, int64_t N, int D, int64_
     if (!x || !packed || !embed || !idx_out) VQ_FAIL(VQHIP_EINVAL, "assign: null pointer");
     if (x_dtype != VQHIP_F32 && x_dtype != VQHIP_BF16) VQ_FAIL(VQHIP_EINVAL, "assign: unknown x dtype %d", x_dtype);
     if (q_out && q_dtype != VQHIP_F32 && q_dtype != VQHIP_BF16) VQ_FAIL(VQHIP_EINVAL, "assign: unknown q dtype %d", q_dtype);
-    if (metric != 0 && metric != 1) VQ_FAIL(VQHIP_EINVAL, "assign: unknown metric %d", metric);
+    if (metric < 0 || metric > 2) VQ_FAIL(VQHIP_EINVAL, "assign: unknown metric %d", metric);
     const int DT = pick_dt(D);
     if (D < 1 || DT == 0) VQ_FAIL(VQHIP_EDIM, "assign: D=%d unsupported (1..512)", D);
     if (ldx < D || (q_out && ldq < D)) VQ_FAIL(VQHIP_EINVAL, "assign: row stride smaller than D");
@@ -551,6 +553,7 @@ extern "C" int vqhip_assign(const void *x, int x_dtype, int64_t N, int D, int64_
     a.x = x; a.N = N; a.D = D; a.ldx = ldx; a.packed = packed; a.embed = embed; a.C = C;
     a.n_tiles = (C + 31) / 32;
     a.idx_out = idx_out; a.q_out = q_out; a.q_bf16 = (q_dtype == VQHIP_BF16); a.ldq = ldq;
+    a.skip_norm = (metric == VQHIP_COSINE_PRENORM);
     a.best_out = best_out; a.rnorm_out = rnorm_out; a.sqerr_partial = sqerr_partial; a.row_mask = row_mask;
     const int xes = (x_dtype == VQHIP_BF16) ? 2 : 4;
     a.x_vec = (D == DT) && (((uintptr_t)x) % (4 * xes) == 0) && ((ldx * xes) % (4 * xes) == 0) && ((((uintptr_t)embed) & 15) == 0);
@@ -566,7 +569,7 @@ extern "C" int vqhip_assign(const void *x, int x_dtype, int64_t N, int D, int64_
         case 64: return dispatch_assign<64>(a, x_dtype, metric, st);
         case 128: return dispatch_assign<128>(a, x_dtype, metric, st);
         case 256: return dispatch_assign<256>(a, x_dtype, metric, st);
-        default: return dispatch_assign<512>(a, x_dtype, metric, st);
+        default: return dispatch_assign<512>(a, x_dtype, metric, st);  // metric != 0 -> cosine family
     }
 }
 

@@ -1,0 +1,245 @@
+"""`ResidualVQ` / `GroupedResidualVQ` for MI355X (reference: residual_vq.py:166-724).
+
+Same constructor / forward keywords and outputs `(quantized_out, indices [b, n, Q], losses [Q])`,
+same state_dict keys (`layers.{i}._codebook.*`, aliased under shared_codebook).  The per-quantizer
+loop stays on the device: no host synchronisation happens between stages (the only `.item()` of the
+reference -- the quantize-dropout seed, rvq.py:96-102 -- is taken only when quantize_dropout is on).
+"""
+from __future__ import annotations
+
+import random
+from math import ceil
+from typing import Optional
+
+import torch
+import torch.distributed as dist
+from torch import Tensor, nn
+
+from . import _lib as L
+from .vector_quantize import VectorQuantize
+
+
+def _round_up(n, m):
+    return ceil(n / m) * m
+
+
+def _draw_seed(device, need_value: bool, max_size=10_000):
+    """Consumes the device RNG exactly like get_maybe_sync_seed (rvq.py:96-102); syncs only if asked."""
+    r = torch.randint(0, max_size, (), device=device)
+    if not need_value:
+        return None
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(r)
+    return int(r.item())
+
+
+class ResidualVQ(nn.Module):
+    def __init__(
+        self,
+        *,
+        dim,
+        num_quantizers: Optional[int] = None,
+        codebook_size,
+        codebook_dim=None,
+        shared_codebook=False,
+        diveq=False,
+        heads=1,
+        quantize_dropout=False,
+        quantize_dropout_cutoff_index=0,
+        quantize_dropout_multiple_of=1,
+        accept_image_fmap=False,
+        implicit_neural_codebook=False,
+        mlp_kwargs: dict = dict(),
+        beam_size=None,
+        eval_beam_size=None,
+        beam_score_quantizer_weights=None,
+        quant_grad_frac=0.,
+        **vq_kwargs,
+    ):
+        super().__init__()
+        assert heads == 1, 'residual vq is not compatible with multi-headed codes'
+        assert num_quantizers is not None or isinstance(codebook_size, tuple)
+        if diveq or implicit_neural_codebook or (beam_size or 0) > 1 or (eval_beam_size or 0) > 1:
+            raise NotImplementedError("diveq / implicit_neural_codebook (QINCo) / beam search are outside the MI355X hot "
+                                      "path (SURVEY.md §2.1, §8f); no fallback is provided")
+
+        codebook_dim = dim if codebook_dim is None else codebook_dim
+        self.codebook_dim = codebook_dim
+        requires_projection = codebook_dim != dim
+        self.project_in = nn.Linear(dim, codebook_dim) if requires_projection else nn.Identity()
+        self.project_out = nn.Linear(codebook_dim, dim) if requires_projection else nn.Identity()
+        self.has_projections = requires_projection
+        self.accept_image_fmap = accept_image_fmap
+        self.implicit_neural_codebook = False
+        self.diveq = False
+
+        if shared_codebook:                                   # rvq.py:213-217
+            vq_kwargs.update(manual_ema_update=True, manual_in_place_optimizer_update=True)
+
+        sizes = codebook_size if isinstance(codebook_size, tuple) else (codebook_size,) * num_quantizers
+        num_quantizers = len(sizes) if num_quantizers is None else num_quantizers
+        assert len(sizes) == num_quantizers
+        self.num_quantizers = num_quantizers
+        self.codebook_sizes = sizes
+        self.uniform_codebook_size = len(set(sizes)) == 1
+
+        self.layers = nn.ModuleList([
+            VectorQuantize(dim=codebook_dim, codebook_size=c, codebook_dim=codebook_dim,
+                           accept_image_fmap=accept_image_fmap, **vq_kwargs) for c in sizes])
+        assert all(not vq.has_projections for vq in self.layers)
+
+        self.quantize_dropout = quantize_dropout and num_quantizers > 1
+        assert quantize_dropout_cutoff_index >= 0
+        self.quantize_dropout_cutoff_index = quantize_dropout_cutoff_index
+        self.quantize_dropout_multiple_of = quantize_dropout_multiple_of
+        self.vq_is_ema_updating = self.layers[0].ema_update
+        self.quant_grad_frac = quant_grad_frac
+        self.beam_size = None
+        self.eval_beam_size = None
+        self.mlps = (None,) * (num_quantizers - 1)
+
+        self.shared_codebook = shared_codebook
+        if shared_codebook:                                   # rvq.py:300-306: every layer aliases layer 0's codebook
+            assert self.uniform_codebook_size
+            first = self.layers[0]._codebook
+            for vq in self.layers[1:]:
+                vq._codebook = first
+
+    @property
+    def codebook_size(self):
+        return self.layers[0].codebook_size
+
+    @property
+    def codebooks(self):
+        cbs = tuple(layer._codebook.embed[0] for layer in self.layers)
+        return torch.stack(cbs) if self.uniform_codebook_size else cbs
+
+    def get_codes_from_indices(self, indices):
+        """[b, ..., q] -> [q, b, ..., d]; -1 (dropped-out quantizer) decodes to zeros (rvq.py:324-377)."""
+        qdim = indices.shape[-1]
+        if qdim < self.num_quantizers:
+            assert self.quantize_dropout > 0., 'quantize dropout must be greater than 0 if you wish to reconstruct from a signal with less fine quantizations'
+            indices = torch.nn.functional.pad(indices, (0, self.num_quantizers - qdim), value=-1)
+        cbs = self.codebooks
+        out = [L.decode_sum(indices[..., q:q + 1].contiguous(), cbs[q].contiguous()) for q in range(self.num_quantizers)]
+        return torch.stack(out)
+
+    def get_output_from_indices(self, indices):
+        qdim = indices.shape[-1]
+        if qdim < self.num_quantizers:
+            assert self.quantize_dropout > 0., 'quantize dropout must be greater than 0 if you wish to reconstruct from a signal with less fine quantizations'
+            indices = torch.nn.functional.pad(indices, (0, self.num_quantizers - qdim), value=-1)
+        if self.uniform_codebook_size:
+            cb = self.layers[0]._codebook.embed[0] if self.shared_codebook else self.codebooks.contiguous()
+            summed = L.decode_sum(indices.contiguous(), cb.contiguous())           # one fused gather + sum over q
+        else:
+            summed = self.get_codes_from_indices(indices).sum(0)
+        return self.project_out(summed)
+
+    def forward(
+        self,
+        x,
+        mask=None,
+        indices=None,
+        return_all_codes=False,
+        sample_codebook_temp=None,
+        freeze_codebook=False,
+        beam_size=None,
+        rand_quantize_dropout_fixed_seed=None,
+    ):
+        if indices is not None or (beam_size or 0) > 1:
+            raise NotImplementedError("forward(indices=) / beam search are not on the MI355X hot path (SURVEY.md §8f)")
+        L._need_gpu(x)
+        Q = self.num_quantizers
+        x = self.project_in(x)
+
+        drop_at = None
+        if self.training and self.quantize_dropout:                # rvq.py:423-439
+            seed = rand_quantize_dropout_fixed_seed
+            if seed is None:
+                seed = _draw_seed(x.device, need_value=True)
+            drop_at = random.Random(seed).randrange(self.quantize_dropout_cutoff_index, Q)
+            if self.quantize_dropout_multiple_of != 1:
+                drop_at = _round_up(drop_at + 1, self.quantize_dropout_multiple_of) - 1
+
+        quantized_out = torch.zeros_like(x)
+        residual = x
+        all_idx, all_loss, stage_inputs = [], [], []
+        idx_shape = x.shape[:-1] if not self.accept_image_fmap else (x.shape[0], *x.shape[2:])
+
+        for qi, vq in enumerate(self.layers):                      # rvq.py:469-568
+            if drop_at is not None and qi > drop_at:
+                all_idx.append(torch.full(idx_shape, -1, device=x.device, dtype=torch.long))
+                all_loss.append(torch.zeros((), device=x.device, dtype=torch.float32))
+                continue
+            if self.shared_codebook and self.training:
+                stage_inputs.append(residual.detach())
+            quantized, ind, loss = vq(residual, mask=mask, sample_codebook_temp=sample_codebook_temp,
+                                      freeze_codebook=freeze_codebook)
+            step = quantized.detach() if self.quant_grad_frac <= 0 else (
+                self.quant_grad_frac * quantized + (1. - self.quant_grad_frac) * quantized.detach())
+            residual = residual - step
+            quantized_out = quantized_out + quantized
+            all_idx.append(ind)
+            all_loss.append(loss)
+
+        if self.training and self.shared_codebook:                 # rvq.py:593-601
+            shared = self.layers[0]
+            if self.vq_is_ema_updating:
+                shared._codebook.update_ema()
+            if shared._codebook.has_dead_code_replacement:
+                stacked = torch.stack(stage_inputs, -2)
+                if self.accept_image_fmap:
+                    stacked = torch.stack([s.flatten(2).transpose(1, 2) for s in stage_inputs], -2)
+                shared.expire_codes_(stacked.reshape(stacked.shape[0], -1, stacked.shape[-1]))
+
+        quantized_out = self.project_out(quantized_out)
+        ret = (quantized_out, torch.stack(all_idx, -1), torch.stack(all_loss))
+        if return_all_codes:
+            ret = (*ret, self.get_codes_from_indices(ret[1]))
+        return ret
+
+
+class GroupedResidualVQ(nn.Module):
+    """G independent ResidualVQs on feature chunks (rvq.py:634-724).  Chunks are passed to the kernels as
+    strided row views -- no per-group copy of the input."""
+
+    def __init__(self, *, dim, groups=1, accept_image_fmap=False, **kwargs):
+        super().__init__()
+        self.dim = dim
+        self.groups = groups
+        assert dim % groups == 0
+        self.accept_image_fmap = accept_image_fmap
+        self.rvqs = nn.ModuleList([ResidualVQ(dim=dim // groups, accept_image_fmap=accept_image_fmap, **kwargs)
+                                   for _ in range(groups)])
+
+    @property
+    def codebooks(self):
+        return torch.stack(tuple(r.codebooks for r in self.rvqs))
+
+    @property
+    def split_dim(self):
+        return 1 if self.accept_image_fmap else -1
+
+    def get_codes_from_indices(self, indices):
+        return torch.stack(tuple(r.get_codes_from_indices(i) for r, i in zip(self.rvqs, indices)))
+
+    def get_output_from_indices(self, indices):
+        return torch.cat(tuple(r.get_output_from_indices(i) for r, i in zip(self.rvqs, indices)), dim=self.split_dim)
+
+    def forward(self, x, indices=None, return_all_codes=False, sample_codebook_temp=None, freeze_codebook=False, mask=None):
+        if indices is not None and len(indices) > 0:
+            raise NotImplementedError("forward(indices=) is not on the MI355X hot path (SURVEY.md §8f)")
+        assert x.shape[self.split_dim] == self.dim
+        chunks = x.chunk(self.groups, dim=self.split_dim)
+        seed = None
+        if self.training:   # same RNG consumption as rvq.py:701; the value (host sync) only if dropout needs it
+            seed = _draw_seed(x.device, need_value=any(r.quantize_dropout for r in self.rvqs))
+        outs = [r(c, return_all_codes=return_all_codes, sample_codebook_temp=sample_codebook_temp, mask=mask,
+                  freeze_codebook=freeze_codebook, rand_quantize_dropout_fixed_seed=seed)
+                for r, c in zip(self.rvqs, chunks)]
+        quantized, all_idx, losses, *codes = zip(*outs)
+        ret = (torch.cat(quantized, dim=self.split_dim), torch.stack(all_idx), torch.stack(losses))
+        if codes:
+            ret = (*ret, torch.stack(codes[0]))
+        return ret

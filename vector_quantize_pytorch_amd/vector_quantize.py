@@ -1,0 +1,414 @@
+"""`VectorQuantize` for MI355X: the reference's nn.Module API (vector_quantize_pytorch.py:802-1403)
+over the HIP hot path.
+
+Same constructor keywords (vqp.py:803-849), same forward keywords (:1093-1107), same outputs
+`(quantized, indices, commit_loss[, LossBreakdown])`, same state_dict keys.  Options that are not
+on the north-star hot path (SURVEY.md §2.1 "delegated", §8f) raise NotImplementedError at
+construction / call time -- there is no silent fallback and nothing here runs on the CPU.
+"""
+from __future__ import annotations
+
+from collections import namedtuple
+from functools import cache
+from typing import Callable, Optional
+
+import torch
+import torch.distributed as dist
+import torch.nn.functional as F
+from torch import Tensor, nn
+
+from . import _lib as L
+from .codebook import Codebook
+
+LossBreakdown = namedtuple('LossBreakdown', ['commitment', 'codebook_diversity', 'orthogonal_reg', 'inplace_optimize'])
+
+
+@cache
+def _is_distributed():
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
+def _rot_fwd(x, q):
+    """Forward value of the rotation trick (vqp.py:287-318, arXiv:2410.06424 §4.2), rows independent:
+    out = s (e - 2 (e.w) w + 2 (e.u) qh),  u = e/|e|, qh = q/|q|, w = l2norm(u + qh), s = |q|/|e|."""
+    e = x.float()
+    qf = q.float()
+    ne = e.norm(dim=-1, keepdim=True).clamp(min=1e-6)
+    nq = qf.norm(dim=-1, keepdim=True)
+    u = e / ne
+    qh = qf / nq.clamp(min=1e-6)
+    w = F.normalize(u + qh, p=2, dim=-1, eps=1e-6)
+    out = e - 2 * (e * w).sum(-1, keepdim=True) * w + 2 * (e * u).sum(-1, keepdim=True) * qh
+    return out * (nq / ne), (u, qh, w, nq / ne)
+
+
+class _QuantizeFn(torch.autograd.Function):
+    """Forward = HIP assign/gather/EMA; backward = closed-form gradients of the reference's graph:
+      commit loss   mean((q.detach() - x)^2)              -> 2 (x - q) / count        (vqp.py:1327)
+      straight-through x + (q - x).detach()               -> g                        (vqp.py:282-283)
+      rotation trick (all of u, qh, w, s detached)        -> s (g - 2 (g.w) w + 2 (g.qh) u)   (vqp.py:287-318)
+    """
+
+    @staticmethod
+    def forward(ctx, x, vq, mask, kw):
+        cb = vq._codebook
+        N_rows = x.numel() // x.shape[-1]
+        r = cb.quantize(x, mask=mask, want_sqerr=vq.training and vq.has_commitment_loss, **kw)
+        q, idx = r["q"], r["idx"]
+        loss_sum = None
+        if vq.training and vq.has_commitment_loss:
+            loss_sum = L.reduce_partials(r["sqerr_partials"], r["nblk"], 1.0)
+        out = q
+        mode = 0
+        saved = []
+        if vq.training and x.requires_grad and vq.route_gradients_to_input:
+            if vq.rotation_trick:
+                mode = 2
+                out32, (u, qh, w, s) = _rot_fwd(x, q)
+                out = out32.to(x.dtype)
+                saved = [u, qh, w, s]
+            else:
+                mode = 1
+                out = x + (q - x)
+        ctx.mode = mode
+        ctx.has_mask = mask is not None
+        ctx.save_for_backward(x, q, *( [mask] if mask is not None else []), *saved)
+        ctx.mark_non_differentiable(idx)
+        if loss_sum is None:
+            loss_sum = torch.zeros((), dtype=torch.float32, device=x.device)
+        return out, idx, loss_sum
+
+    @staticmethod
+    def backward(ctx, g_out, g_idx, g_loss):
+        tensors = list(ctx.saved_tensors)
+        x, q = tensors[0], tensors[1]
+        pos = 2
+        mask = None
+        if ctx.has_mask:
+            mask = tensors[pos]
+            pos += 1
+        gx = None
+        if ctx.mode == 1 and g_out is not None:
+            gx = g_out.float()
+        elif ctx.mode == 2 and g_out is not None:
+            u, qh, w, s = tensors[pos:pos + 4]
+            g = g_out.float()
+            gx = s * (g - 2 * (g * w).sum(-1, keepdim=True) * w + 2 * (g * qh).sum(-1, keepdim=True) * u)
+        if g_loss is not None:
+            gl = (2.0 * g_loss) * (x.float() - q.float())      # d/dx sum (q - x)^2 ; the caller divides by the count
+            if mask is not None:
+                gl = gl * mask[..., None]
+            gx = gl if gx is None else gx + gl
+        return (None if gx is None else gx.to(x.dtype)), None, None, None
+
+
+class VectorQuantize(nn.Module):
+    def __init__(
+        self,
+        dim,
+        codebook_size,
+        codebook_dim=None,
+        heads=1,
+        separate_codebook_per_head=False,
+        decay=0.8,
+        eps=1e-5,
+        freeze_codebook=False,
+        kmeans_init=False,
+        kmeans_iters=10,
+        sync_kmeans=True,
+        use_cosine_sim=False,
+        layernorm_after_project_in=False,
+        threshold_ema_dead_code=0,
+        channel_last=True,
+        accept_image_fmap=False,
+        accept_3d_fmap=False,
+        commitment_weight=1.,
+        commitment_use_cross_entropy_loss=False,
+        orthogonal_reg_weight=0.,
+        orthogonal_reg_active_codes_only=False,
+        orthogonal_reg_max_codes=None,
+        codebook_diversity_loss_weight=0.,
+        codebook_diversity_temperature=100.,
+        stochastic_sample_codes=False,
+        sample_codebook_temp=1.,
+        straight_through=False,
+        rotation_trick=None,
+        directional_reparam=False,
+        directional_reparam_variance=5e-3,
+        sync_codebook=None,
+        sync_affine_param=False,
+        ema_update=None,
+        vq_bridge: Optional[nn.Module] = None,
+        manual_ema_update=False,
+        learnable_codebook=None,
+        in_place_codebook_optimizer: Optional[Callable] = None,
+        manual_in_place_optimizer_update=False,
+        affine_param=False,
+        affine_param_batch_decay=0.99,
+        affine_param_codebook_decay=0.9,
+        sync_update_v=0.,
+        return_zeros_for_masked_padding=True,
+        route_gradients_to_input=True,
+    ):
+        super().__init__()
+
+        # derived defaults, as vqp.py:854-856
+        ema_update = (not directional_reparam and vq_bridge is None) if ema_update is None else ema_update
+        learnable_codebook = (directional_reparam or vq_bridge is not None) if learnable_codebook is None else learnable_codebook
+        rotation_trick = (not directional_reparam and dim > 1) if rotation_trick is None else rotation_trick
+
+        unsupported = dict(
+            commitment_use_cross_entropy_loss=commitment_use_cross_entropy_loss,
+            orthogonal_reg_weight=orthogonal_reg_weight > 0., codebook_diversity_loss_weight=codebook_diversity_loss_weight > 0.,
+            stochastic_sample_codes=stochastic_sample_codes, straight_through=straight_through,
+            directional_reparam=directional_reparam, vq_bridge=vq_bridge is not None, learnable_codebook=learnable_codebook,
+            in_place_codebook_optimizer=in_place_codebook_optimizer is not None, affine_param=affine_param,
+            sync_update_v=sync_update_v > 0.)
+        bad = [k for k, v in unsupported.items() if v]
+        if bad:
+            raise NotImplementedError(
+                f"VectorQuantize options {bad} need the full N x C distance matrix, an RNG inside the kernel or a "
+                "learnable codebook; they are outside the MI355X hot path (SURVEY.md §2.1 / §8f) and are not "
+                "implemented. There is deliberately no fallback.")
+
+        # the reference's own cross-flag checks (vqp.py:884, 898-913), for identical error behaviour
+        assert not (use_cosine_sim and learnable_codebook), 'cosine sim distance codebook not compatible with learnable codebook yet'
+        assert sum(map(int, (straight_through, rotation_trick, directional_reparam))) <= 1
+        assert 0 <= sync_update_v <= 1.
+
+        self.dim = dim
+        self.heads = heads
+        self.separate_codebook_per_head = separate_codebook_per_head
+        codebook_dim = dim if codebook_dim is None else codebook_dim
+        codebook_input_dim = codebook_dim * heads
+        requires_projection = codebook_input_dim != dim
+
+        if requires_projection:
+            proj = [nn.Linear(dim, codebook_input_dim)]
+            if layernorm_after_project_in:
+                proj.append(nn.LayerNorm(codebook_input_dim))
+            self.project_in = proj[0] if len(proj) == 1 else nn.Sequential(*proj)
+            self.project_out = nn.Linear(codebook_input_dim, dim)
+        else:
+            self.project_in = nn.Identity()
+            self.project_out = nn.Identity()
+        self.has_projections = requires_projection
+
+        self.eps = eps
+        self.has_commitment_loss = commitment_weight > 0.
+        self.commitment_weight = commitment_weight
+        self.learnable_codebook = False
+        self.rotation_trick = rotation_trick
+        self.route_gradients_to_input = route_gradients_to_input
+        self.use_cosine_sim = use_cosine_sim
+        self.codebook_size = codebook_size
+        self.accept_image_fmap = accept_image_fmap
+        self.accept_3d_fmap = accept_3d_fmap
+        self.channel_last = channel_last
+        self.return_zeros_for_masked_padding = return_zeros_for_masked_padding
+        self.freeze_codebook = freeze_codebook
+
+        if sync_codebook is None:
+            sync_codebook = _is_distributed()
+
+        self._codebook = Codebook(
+            dim=codebook_dim,
+            num_codebooks=heads if separate_codebook_per_head else 1,
+            codebook_size=codebook_size,
+            kmeans_init=kmeans_init,
+            kmeans_iters=kmeans_iters,
+            sync_kmeans=sync_kmeans,
+            decay=decay,
+            eps=eps,
+            threshold_ema_dead_code=threshold_ema_dead_code,
+            use_ddp=sync_codebook,
+            sample_codebook_temp=sample_codebook_temp,
+            ema_update=ema_update,
+            manual_ema_update=manual_ema_update,
+            use_cosine_sim=use_cosine_sim,
+        )
+        self.in_place_codebook_optimizer = None
+        self.register_buffer('zero', torch.tensor(0.), persistent=False)
+
+    # ---- reference-compatible accessors (vqp.py:978-1022) -----------------------------------------
+    @property
+    def ema_update(self):
+        return self._codebook.ema_update
+
+    @property
+    def codebook(self):
+        cb = self._codebook.embed
+        return cb if self.separate_codebook_per_head else cb[0]
+
+    @codebook.setter
+    def codebook(self, codes):
+        if not self.separate_codebook_per_head:
+            codes = codes[None]
+        self._codebook.embed.copy_(codes)
+
+    def _from_rows_layout(self, t):
+        if not self.channel_last or self.accept_image_fmap or self.accept_3d_fmap:
+            t = t.movedim(-1, 1)
+        return t
+
+    def get_codes_from_indices(self, indices):
+        cb = self.codebook
+        if cb.ndim == 2:
+            codes = L.decode_sum(indices[..., None], cb.contiguous())
+        else:   # separate codebook per head: indices [b, ..., h]
+            parts = [L.decode_sum(indices[..., h:h + 1].contiguous(), cb[h].contiguous()) for h in range(cb.shape[0])]
+            codes = torch.cat(parts, -1)
+        return self._from_rows_layout(codes)
+
+    def get_output_from_indices(self, indices):
+        codes = self.get_codes_from_indices(indices)
+        if isinstance(self.project_out, nn.Identity):
+            return codes
+        if not self.channel_last or self.accept_image_fmap or self.accept_3d_fmap:
+            return self.project_out(codes.movedim(1, -1)).movedim(-1, 1)
+        return self.project_out(codes)
+
+    def update_in_place_optimizer(self):
+        return  # no learnable codebook on this path
+
+    def _split_heads(self, x):
+        if self.heads == 1:
+            return x
+        b, n, _ = x.shape
+        xh = x.reshape(b, n, self.heads, -1)
+        if self.separate_codebook_per_head:
+            return xh.permute(2, 0, 1, 3).contiguous()                   # h b n d
+        return xh.permute(0, 2, 1, 3).reshape(b * self.heads, n, -1)    # (b h) n d
+
+    def expire_codes_(self, x):
+        x = self._codebook.transform_input(x)
+        x = self._split_heads(x)
+        self._codebook.expire_codes_(x if x.ndim == 4 else x[None])
+
+    def update_indices(self, x, indices, mask=None):
+        x = self._to_rows_layout(x, check_mask=mask)
+        x = self.project_in(x)
+        x = self._split_heads(x)
+        x = self._codebook.transform_input(x)
+        if self.heads > 1:
+            b = indices.shape[0]
+            if self.separate_codebook_per_head:
+                indices = indices.reshape(b, -1, self.heads).permute(2, 0, 1)
+            else:
+                indices = indices.reshape(b, -1, self.heads).permute(0, 2, 1).reshape(b * self.heads, -1)
+        else:
+            indices = indices.reshape(x.shape[0], -1)
+        self._codebook.update_indices(x, indices, mask=mask)
+
+    update_ema_indices = update_indices
+
+    def _to_rows_layout(self, x, check_mask=None):
+        if self.accept_image_fmap or self.accept_3d_fmap:
+            assert check_mask is None
+            return x.flatten(2).transpose(1, 2)
+        if not self.channel_last:
+            return x.transpose(1, 2)
+        return x
+
+    # ---- forward ----------------------------------------------------------------------------------
+    def forward(
+        self,
+        x,
+        indices=None,
+        mask=None,
+        lens=None,
+        topk=None,
+        sample_codebook_temp=None,
+        freeze_codebook=None,
+        return_loss_breakdown=False,
+        codebook_transform_fn: Optional[Callable] = None,
+        ema_update_weight=None,
+        accum_ema_update=False,
+        ema_update=None,
+    ):
+        if indices is not None or topk is not None or codebook_transform_fn is not None:
+            raise NotImplementedError("forward(indices= / topk= / codebook_transform_fn=) read the full distance matrix; "
+                                      "not on the MI355X hot path (SURVEY.md §8f)")
+        L._need_gpu(x)
+        orig_input = x
+        freeze_codebook = self.freeze_codebook if freeze_codebook is None else freeze_codebook
+
+        assert not (mask is not None and lens is not None)
+        if lens is not None:                                                   # vqp.py:108-110
+            mask = torch.arange(x.shape[1], device=x.device)[None, :] < lens[:, None]
+
+        only_one = x.ndim == 2
+        if only_one:
+            assert mask is None
+            x = x[:, None, :]
+
+        spatial = x.shape[2:] if (self.accept_image_fmap or self.accept_3d_fmap) else None
+        x = self._to_rows_layout(x, check_mask=mask)
+        x = self.project_in(x)
+        b, n = x.shape[0], x.shape[1]
+        xs = self._split_heads(x)                                             # [b,n,d] | [(b h),n,d] | [h,b,n,d]
+        if not xs.is_contiguous() and xs.stride(-1) != 1:
+            xs = xs.contiguous()
+
+        rmask = mask
+        if mask is not None and self.heads > 1:
+            rmask = mask if self.separate_codebook_per_head else mask[:, None, :].expand(b, self.heads, n).reshape(b * self.heads, n)
+
+        # cosine: gradients must flow through the l2norm (vqp.py:1159), so when the input needs grad the
+        # normalisation stays an autograd op and the kernel is told the rows are already unit-norm.
+        pre_normalized = False
+        needs_grad = self.training and xs.requires_grad and torch.is_grad_enabled()
+        if self.use_cosine_sim and (needs_grad or (mask is not None and self.training)):
+            xs = F.normalize(xs, p=2, dim=-1, eps=1e-6)
+            pre_normalized = True
+
+        kw = dict(freeze_codebook=freeze_codebook, ema_update_weight=ema_update_weight,
+                  accum_ema_update=accum_ema_update, ema_update=ema_update, input_normalized=pre_normalized)
+        quantize, embed_ind, sq_sum = _QuantizeFn.apply(xs, self, rmask, kw)
+
+        # ---- loss (vqp.py:1282-1329) --------------------------------------------------------------
+        loss = torch.zeros((), device=x.device, dtype=torch.float32, requires_grad=self.training)
+        commit_loss = self.zero
+        if self.training and self.has_commitment_loss:
+            d = xs.shape[-1]
+            if mask is None:
+                commit_loss = sq_sum / float(xs.numel())
+            elif not self.use_cosine_sim:
+                denom = (rmask.sum() * d).to(torch.float32) * (xs.shape[0] if xs.ndim == 4 else 1)
+                commit_loss = sq_sum / denom
+            else:
+                # reference quirk (vqp.py:1319): the masked loss compares against the ORIGINAL (un-normalised) input
+                diff = (quantize.detach().float() - orig_input.float()) ** 2
+                commit_loss = diff[mask].mean()
+            loss = loss + commit_loss * self.commitment_weight
+
+        # ---- indices / quantized back to the caller's layout (vqp.py:1265-1396) -------------------
+        if self.heads > 1:
+            if self.separate_codebook_per_head:
+                embed_ind = embed_ind.permute(1, 2, 0)
+                quantize = quantize.permute(1, 2, 0, 3).reshape(b, n, -1)
+            else:
+                embed_ind = embed_ind.reshape(b, self.heads, n).permute(0, 2, 1)
+                quantize = quantize.reshape(b, self.heads, n, -1).permute(0, 2, 1, 3).reshape(b, n, -1)
+        if spatial is not None:
+            embed_ind = embed_ind.reshape(b, *spatial, *embed_ind.shape[2:])
+        if only_one:
+            embed_ind = embed_ind[:, 0]
+
+        quantize = self.project_out(quantize)
+        if spatial is not None:
+            quantize = quantize.transpose(1, 2).reshape(b, -1, *spatial)
+        elif not self.channel_last:
+            quantize = quantize.transpose(1, 2)
+        if only_one:
+            quantize = quantize[:, 0]
+
+        if mask is not None:
+            fill = torch.zeros_like(orig_input) if self.return_zeros_for_masked_padding else orig_input
+            quantize = torch.where(mask[..., None], quantize, fill)
+            m = mask if embed_ind.ndim == mask.ndim else mask[..., None]
+            embed_ind = torch.where(m, embed_ind, torch.full_like(embed_ind, -1))
+
+        if not return_loss_breakdown:
+            return quantize, embed_ind, loss
+        return quantize, embed_ind, loss, LossBreakdown(commit_loss, self.zero, self.zero, self.zero)
