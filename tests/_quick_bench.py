@@ -3,30 +3,30 @@ import sys, time, torch
 sys.path.insert(0, '.')
 from vector_quantize_pytorch_amd import _lib as L
 dev = torch.device('cuda:0')
-def run(N, C, D, dtype, train=True, iters=5):
+
+def tm(fn, n=5):
+    fn(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n
+
+N, D = 1 << 20, 256
+for dtype in (torch.bfloat16, torch.float32):
     x = torch.randn(N, D, device=dev).to(dtype)
-    e = torch.randn(C, D, device=dev) * 0.005
-    cs = torch.ones(C, device=dev); ea = e.clone()
-    for it in range(iters + 2):
-        if it == 2:
-            torch.cuda.synchronize(); t0 = time.time()
+    for C in (32, 64, 256, 1024, 2048):
+        e = torch.randn(C, D, device=dev) * 0.005
         packed = L.pack_codebook(e)
-        r = L.assign(x, packed, e, want_q=True, want_sqerr=True)
-        if train:
-            cnt, es = L.ema_accumulate(x, r['idx'], C)
-            L.ema_finalize(cs, ea, e, cnt, es, decay=0.8, eps=1e-5)
-        loss = L.reduce_partials(r['sqerr_partials'], r['nblk'], 1.0 / (N * D))
-    torch.cuda.synchronize(); dt = (time.time() - t0) / iters
-    fl = 2.0 * N * C * D
-    print(f"N={N} C={C} D={D} {dtype} train={train}: {dt*1e3:.3f} ms/step  {N/dt:.3e} vec/s  {fl/dt/1e12:.1f} TF/s ({fl/dt/157.3e12*100:.1f}% of fp32 MFMA peak) loss={loss.item():.5f}")
-    # per-kernel
-    for name, fn in [("pack", lambda: L.pack_codebook(e)), ("assign", lambda: L.assign(x, packed, e, want_q=True, want_sqerr=True)),
-                     ("stats", lambda: L.ema_accumulate(x, r['idx'], C))]:
-        torch.cuda.synchronize(); t0 = time.time()
-        for _ in range(3): fn()
-        torch.cuda.synchronize(); print(f"   {name}: {(time.time()-t0)/3*1e3:.3f} ms")
-run(1 << 20, 1024, 256, torch.bfloat16)
-run(1 << 20, 1024, 256, torch.float32)
-run(1 << 18, 1024, 256, torch.float32, train=False)
-run(1 << 16, 4096, 128, torch.float32)
-run(1 << 15, 8192, 512, torch.float32)
+        t_full = tm(lambda: L.assign(x, packed, e, want_q=True, want_sqerr=True))
+        t_idx = tm(lambda: L.assign(x, packed, e, want_q=False, want_sqerr=False))
+        print(f"assign {dtype} C={C}: full {t_full:.3f} ms  idx-only {t_idx:.3f} ms   per-tile {(t_full)/(C/32)*1e3:.1f} us")
+    e = torch.randn(1024, D, device=dev) * 0.005
+    r = L.assign(x, L.pack_codebook(e), e)
+    print(f"stats {dtype}: {tm(lambda: L.ema_accumulate(x, r['idx'].reshape(-1), 1024)):.3f} ms")
+    idx_same = torch.zeros(N, dtype=torch.int64, device=dev)
+    print(f"stats {dtype} (all rows -> code 0, worst-case contention): {tm(lambda: L.ema_accumulate(x, idx_same, 1024)):.3f} ms")
+x = torch.randn(1 << 18, 128, device=dev)
+e = torch.randn(4096, 128, device=dev)
+r = L.assign(x, L.pack_codebook(e), e)
+print(f"stats f32 N=2^18 D=128 C=4096: {tm(lambda: L.ema_accumulate(x, r['idx'].reshape(-1), 4096)):.3f} ms; assign {tm(lambda: L.assign(x, L.pack_codebook(e), e)):.3f} ms")

@@ -12,7 +12,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "csrc", "libvqhip.so")
+SO_PATH = os.environ.get("VQHIP_SO", os.path.join(_HERE, "csrc", "libvqhip.so"))   # VQHIP_SO: A/B experiments only
 
 F32, BF16 = 0, 1
 EUCLID, COSINE, COSINE_PRENORM = 0, 1, 2

@@ -399,8 +399,63 @@ __global__ void __launch_bounds__(256, (DT <= 256 ? 2 : 1)) vq_assign_kernel(con
         if (a.rnorm_out) a.rnorm_out[row] = (METRIC == 0) ? x2 : nrm;
     }
 
-    // ---- gather the winning code row, write q, accumulate sum (q - x)^2 --------------------------
-    if (a.q_out || a.sqerr_partial) {
+    // ---- q = embed[idx]: row-cooperative copy.  For each of the wave's 32 rows all 64 lanes move the
+    //      winning code row L2 -> HBM as whole contiguous rows (per-lane-row stores of 8..16 bytes were
+    //      measured at 1.7x write amplification: profiles/r1_first).  8 rows in flight per wave. ------
+    if (a.q_out) {
+        const int64_t wrow0 = (int64_t)blockIdx.x * VQHIP_ASSIGN_ROWS_PER_BLOCK + wave * 32;
+        const bool qb = a.q_bf16 != 0;
+        if (a.q_vec && a.x_vec) {
+#pragma unroll
+            for (int r0 = 0; r0 < 32; r0 += 8) {
+                f32x4 g[8][(DT + 255) / 256];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int c = __builtin_amdgcn_readlane(bi, r0 + u);
+                    const float *er = a.embed + (size_t)c * DT;
+#pragma unroll
+                    for (int h = 0; h < (DT + 255) / 256; ++h) {
+                        const int d = h * 256 + lane * 4;
+                        if (d < DT) g[u][h] = *(const f32x4 *)(er + d);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int64_t rr = wrow0 + r0 + u;
+                    if (rr < a.N) {
+#pragma unroll
+                        for (int h = 0; h < (DT + 255) / 256; ++h) {
+                            const int d = h * 256 + lane * 4;
+                            if (d < DT) {
+                                if (qb) {
+                                    uint2 w;
+                                    w.x = (unsigned)f32_to_bf16_rne(g[u][h].x) | ((unsigned)f32_to_bf16_rne(g[u][h].y) << 16);
+                                    w.y = (unsigned)f32_to_bf16_rne(g[u][h].z) | ((unsigned)f32_to_bf16_rne(g[u][h].w) << 16);
+                                    *(uint2 *)((unsigned short *)a.q_out + rr * a.ldq + d) = w;
+                                } else {
+                                    *(f32x4 *)((float *)a.q_out + rr * a.ldq + d) = g[u][h];
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+        } else {
+            for (int r = 0; r < 32; ++r) {
+                const int64_t rr = wrow0 + r;
+                if (rr >= a.N) break;
+                const int c = __builtin_amdgcn_readlane(bi, r);
+                const float *er = a.embed + (size_t)c * a.D;
+                for (int d = lane; d < a.D; d += 64) {
+                    if (qb) ((unsigned short *)a.q_out)[rr * a.ldq + d] = f32_to_bf16_rne(er[d]);
+                    else ((float *)a.q_out)[rr * a.ldq + d] = er[d];
+                }
+            }
+        }
+    }
+
+    // ---- commitment-loss partial: sum over the wave's rows of sum_d (q - x)^2, x still in registers ----
+    if (a.sqerr_partial) {
         // back to the load layout (the swap is an involution)
 #pragma unroll
         for (int m = 0; m < NG; ++m) {
@@ -430,44 +485,17 @@ __global__ void __launch_bounds__(256, (DT <= 256 ? 2 : 1)) vq_assign_kernel(con
                 const float df = g[r] - xr[4 * m + r];
                 lsum += df * df;
             }
-            if (a.q_out && row_ok) {
-                if (qb) {
-                    unsigned short *qp = (unsigned short *)a.q_out + row * a.ldq + k0;
-                    if (a.q_vec) {
-                        uint2 w;
-                        w.x = (__float_as_uint(g[0]) >> 16) | (__float_as_uint(g[1]) & 0xffff0000u);
-                        w.y = (__float_as_uint(g[2]) >> 16) | (__float_as_uint(g[3]) & 0xffff0000u);
-                        *(uint2 *)qp = w;
-                    } else {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r)
-                            if (k0 + r < a.D) qp[r] = (unsigned short)(__float_as_uint(g[r]) >> 16);
-                    }
-                } else {
-                    float *qp = (float *)a.q_out + row * a.ldq + k0;
-                    if (a.q_vec) {
-                        f32x4 w = {g[0], g[1], g[2], g[3]};
-                        *(f32x4 *)qp = w;
-                    } else {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r)
-                            if (k0 + r < a.D) qp[r] = g[r];
-                    }
-                }
-            }
         }
-        if (a.sqerr_partial) {
-            const bool counted = row_ok && (!a.row_mask || a.row_mask[row] != 0);
-            double ds = counted ? (double)lsum : 0.0;
+        const bool counted = row_ok && (!a.row_mask || a.row_mask[row] != 0);
+        double ds = counted ? (double)lsum : 0.0;
 #pragma unroll
-            for (int o = 32; o >= 1; o >>= 1) ds += __shfl_xor(ds, o, 64);
-            // all DMA traffic has drained (last loop iteration waited); reuse LDS for the 4 partials
-            __syncthreads();
-            double *red = (double *)smem;
-            if (lane == 0) red[wave] = ds;
-            __syncthreads();
-            if (tid == 0) a.sqerr_partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
-        }
+        for (int o = 32; o >= 1; o >>= 1) ds += __shfl_xor(ds, o, 64);
+        // all DMA traffic has drained (last loop iteration waited); reuse LDS for the 4 partials
+        __syncthreads();
+        double *red = (double *)smem;
+        if (lane == 0) red[wave] = ds;
+        __syncthreads();
+        if (tid == 0) a.sqerr_partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
     }
 }
 
@@ -614,60 +642,109 @@ struct StatsArgs {
     float *count;
     float *embed_sum;
     int64_t rows_per_block;
+    int x_vec;  // rows are 16-byte aligned and D % 8 == 0: 16-byte loads
 };
 
-template <bool XBF16>
+// One workgroup owns a [CC <= 1024 codes] x [32 feature columns] tile of embed_sum, privatised in LDS
+// (128 KiB fp32 + 4 KiB counters), and streams its share of the rows: 4 lanes per row, each lane 8
+// consecutive columns loaded with ONE 16-byte load (bf16) or two (fp32), U rows per lane in flight
+// (~32 KiB of HBM loads per CU).  ds_add_f32 into acc[c][(col + c) & 31]: rotating the column by the
+// code spreads the 4-lanes-per-row access pattern over all 32 LDS banks (un-rotated, every row would
+// hit the same 4 banks: 16-way conflict).  Flush with global fp32 atomics (non-zero entries only).
+template <bool XBF16, bool HAS_MASK, bool VEC>
 __global__ void __launch_bounds__(256) vq_stats_kernel(const StatsArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int d0 = blockIdx.x * VQHIP_STATS_DSLICE;
     const int c0 = blockIdx.y * VQHIP_STATS_CCHUNK;
     const int CC = min(VQHIP_STATS_CCHUNK, a.C - c0);
-    float *acc = (float *)smem;            // [CC][32]
+    float *acc = (float *)smem;            // [CC][32], column rotated by the code
     int *cnt = (int *)(acc + CC * 32);     // [CC]
     const int tid = threadIdx.x;
     for (int e = tid; e < CC * 33; e += 256) acc[e] = 0.f;  // zero bits == int 0 too
     __syncthreads();
 
-    const int dd = tid & 31;
-    const int rr = tid >> 5;
-    const bool col_ok = (d0 + dd) < a.D;
-    const bool do_cnt = (blockIdx.x == 0) && (dd == 0);
+    const int l4 = tid & 3;       // which 8-column group of the 32-column slice
+    const int slot = tid >> 2;    // 64 rows per pass
+    const int dcol = d0 + 8 * l4;
+    const bool do_cnt = (blockIdx.x == 0) && (l4 == 0);
     const int64_t r_begin = (int64_t)blockIdx.z * a.rows_per_block;
     const int64_t r_end = min(a.N, r_begin + a.rows_per_block);
+    const bool col_ok = VEC ? (dcol + 8 <= a.D) : (dcol < a.D);
 
-    constexpr int U = 4;
-    for (int64_t base = r_begin + rr; base < r_end; base += 8 * U) {
-        int cc[U];
-        float v[U];
+    // Every load below is UNCONDITIONAL (clamped / redirected to a safe address) so that the U loads
+    // of a phase are independent and stay in flight together; a guarded load makes hipcc wait
+    // vmcnt(0) per element and the loop becomes latency-bound (measured: 3.3 ms -> see DESIGN.md).
+    constexpr int U = XBF16 ? 8 : 4;
+    for (int64_t base = r_begin + slot; base < r_end; base += 64 * U) {
+        int64_t ci[U];
+        unsigned char mk[U];
+        float rn[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int64_t row = base + 8 * u;
-            int c = -1;
-            if (row < r_end) {
-                const int64_t ci = a.idx[row * a.idx_stride];
-                const bool keep = (!a.row_mask || a.row_mask[row] != 0) && ci >= c0 && ci < c0 + CC;
-                c = keep ? (int)(ci - c0) : -1;
-            }
-            cc[u] = c;
+            const int64_t rowc = min(base + 64 * u, r_end - 1);
+            ci[u] = a.idx[rowc * a.idx_stride];
+            mk[u] = HAS_MASK ? a.row_mask[rowc] : (unsigned char)1;
+            rn[u] = a.cosine ? a.rnorm[rowc] : 1.f;
         }
+        int cc[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int64_t row = base + 8 * u;
-            v[u] = 0.f;
-            if (cc[u] >= 0 && col_ok) {
-                float t = load_elem<XBF16>(a.x, row * a.ldx + d0 + dd);
-                if (a.cosine) {
-                    t = t / a.rnorm[row];
-                    if (XBF16) t = round_to_bf16(t);
+            const bool keep = (base + 64 * u < r_end) & (mk[u] != 0) & (ci[u] >= c0) & (ci[u] < c0 + CC) & col_ok;
+            cc[u] = keep ? (int)(ci[u] - c0) : -1;
+        }
+        float v[U][8];
+        if (VEC) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                // rows this lane does not own are redirected to the workgroup's first row (a valid, cached line)
+                const int64_t row = (cc[u] >= 0) ? (base + 64 * u) : r_begin;
+                const int64_t off = row * a.ldx + ((cc[u] >= 0) ? dcol : 0);
+                if (XBF16) {
+                    const uint4 w = *(const uint4 *)((const unsigned short *)a.x + off);
+                    v[u][0] = __uint_as_float(w.x << 16); v[u][1] = __uint_as_float(w.x & 0xffff0000u);
+                    v[u][2] = __uint_as_float(w.y << 16); v[u][3] = __uint_as_float(w.y & 0xffff0000u);
+                    v[u][4] = __uint_as_float(w.z << 16); v[u][5] = __uint_as_float(w.z & 0xffff0000u);
+                    v[u][6] = __uint_as_float(w.w << 16); v[u][7] = __uint_as_float(w.w & 0xffff0000u);
+                } else {
+                    const f32x4 *p = (const f32x4 *)((const float *)a.x + off);
+                    const f32x4 w0 = p[0], w1 = p[1];
+                    v[u][0] = w0.x; v[u][1] = w0.y; v[u][2] = w0.z; v[u][3] = w0.w;
+                    v[u][4] = w1.x; v[u][5] = w1.y; v[u][6] = w1.z; v[u][7] = w1.w;
                 }
-                v[u] = t;
             }
+        } else {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int64_t row = (cc[u] >= 0) ? (base + 64 * u) : r_begin;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int d = (cc[u] >= 0 && dcol + k < a.D) ? (dcol + k) : 0;
+                    v[u][k] = load_elem<XBF16>(a.x, row * a.ldx + d);
+                }
+            }
+        }
+        if (a.cosine) {
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const float t = v[u][k] / rn[u];
+                    v[u][k] = XBF16 ? round_to_bf16(t) : t;
+                }
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             if (cc[u] >= 0) {
-                if (col_ok) atomicAdd(&acc[cc[u] * 32 + dd], v[u]);  // ds_add_f32
+                float *rowacc = acc + cc[u] * 32;
+                const int rot = cc[u] + 8 * l4;
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+#ifdef VQ_EXPERIMENT_RACY_STATS
+                    if (VEC || dcol + k < a.D) rowacc[(rot + k) & 31] += v[u][k];   // timing experiment only (wrong results)
+#else
+                    if (VEC || dcol + k < a.D) atomicAdd(&rowacc[(rot + k) & 31], v[u][k]);  // ds_add_f32
+#endif
                 if (do_cnt) atomicAdd(&cnt[cc[u]], 1);
             }
         }
@@ -676,12 +753,27 @@ __global__ void __launch_bounds__(256) vq_stats_kernel(const StatsArgs a)
 
     for (int e = tid; e < CC * 32; e += 256) {
         const float s = acc[e];
-        const int d = d0 + (e & 31);
-        if (s != 0.f && d < a.D) unsafeAtomicAdd(&a.embed_sum[(size_t)(c0 + (e >> 5)) * a.D + d], s);
+        const int c = e >> 5;
+        const int d = d0 + (((e & 31) - c) & 31);
+        if (s != 0.f && d < a.D) unsafeAtomicAdd(&a.embed_sum[(size_t)(c0 + c) * a.D + d], s);
     }
     if (blockIdx.x == 0)
         for (int c = tid; c < CC; c += 256)
             if (cnt[c]) unsafeAtomicAdd(&a.count[c0 + c], (float)cnt[c]);
+}
+
+template <bool XBF16, bool HAS_MASK, bool VEC>
+static int launch_stats(const StatsArgs &a, dim3 grid, int smem, hipStream_t st)
+{
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void *)vq_stats_kernel<XBF16, HAS_MASK, VEC>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, VQHIP_STATS_CCHUNK * 33 * 4);
+        if (e != hipSuccess) VQ_FAIL((int)e, "hipFuncSetAttribute(stats): %s", hipGetErrorString(e));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((vq_stats_kernel<XBF16, HAS_MASK, VEC>), grid, dim3(256), smem, st, a);
+    return launch_status("vq_stats_kernel");
 }
 
 extern "C" int vqhip_ema_accumulate(const void *x, int x_dtype, int64_t N, int D, int64_t ldx,
@@ -701,32 +793,36 @@ extern "C" int vqhip_ema_accumulate(const void *x, int x_dtype, int64_t N, int D
 
     const int nx = (D + VQHIP_STATS_DSLICE - 1) / VQHIP_STATS_DSLICE;
     const int ny = (C + VQHIP_STATS_CCHUNK - 1) / VQHIP_STATS_CCHUNK;
-    // ~2 workgroups per CU overall; at least 2048 rows per workgroup so the flush amortises
-    int64_t nz = (512 + (int64_t)nx * ny - 1) / ((int64_t)nx * ny);
+    // one workgroup per CU (the LDS tile is 132 KiB); at least 2048 rows per workgroup so the flush amortises
+    int64_t nz = (256 + (int64_t)nx * ny - 1) / ((int64_t)nx * ny);
     const int64_t max_nz = (N + 2047) / 2048;
     if (nz > max_nz) nz = max_nz;
     if (nz < 1) nz = 1;
     if (nz > 65535) nz = 65535;
     a.rows_per_block = (N + nz - 1) / nz;
-    a.rows_per_block = (a.rows_per_block + 7) / 8 * 8;
+    a.rows_per_block = (a.rows_per_block + 63) / 64 * 64;
+    {
+        const int es = (x_dtype == VQHIP_BF16) ? 2 : 4;
+        a.x_vec = (D % 8 == 0) && (((uintptr_t)x) % 16 == 0) && ((ldx * es) % 16 == 0);
+    }
     nz = (N + a.rows_per_block - 1) / a.rows_per_block;
 
     const int CCmax = C < VQHIP_STATS_CCHUNK ? C : VQHIP_STATS_CCHUNK;
     const int smem = CCmax * 33 * 4;
-    static bool attr_done[2] = {false, false};
-    const int which = (x_dtype == VQHIP_BF16);
-    if (!attr_done[which]) {
-        hipError_t e = which ? hipFuncSetAttribute((const void *)vq_stats_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, VQHIP_STATS_CCHUNK * 33 * 4)
-                             : hipFuncSetAttribute((const void *)vq_stats_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, VQHIP_STATS_CCHUNK * 33 * 4);
-        if (e != hipSuccess) VQ_FAIL((int)e, "hipFuncSetAttribute(stats): %s", hipGetErrorString(e));
-        attr_done[which] = true;
-    }
     dim3 grid(nx, ny, (unsigned)nz);
-    if (which)
-        hipLaunchKernelGGL(vq_stats_kernel<true>, grid, dim3(256), smem, (hipStream_t)stream, a);
-    else
-        hipLaunchKernelGGL(vq_stats_kernel<false>, grid, dim3(256), smem, (hipStream_t)stream, a);
-    return launch_status("vq_stats_kernel");
+    hipStream_t st = (hipStream_t)stream;
+    const bool bf = (x_dtype == VQHIP_BF16), hm = (row_mask != nullptr), vec = (a.x_vec != 0);
+#define VQ_STATS_CASE(B, M, V) if (bf == B && hm == M && vec == V) return launch_stats<B, M, V>(a, grid, smem, st)
+    VQ_STATS_CASE(true, true, true);
+    VQ_STATS_CASE(true, true, false);
+    VQ_STATS_CASE(true, false, true);
+    VQ_STATS_CASE(true, false, false);
+    VQ_STATS_CASE(false, true, true);
+    VQ_STATS_CASE(false, true, false);
+    VQ_STATS_CASE(false, false, true);
+    VQ_STATS_CASE(false, false, false);
+#undef VQ_STATS_CASE
+    return 0;
 }
 
 // ------------------------------------------------------------------------------------------------
