@@ -1,0 +1,144 @@
+"""CPU (no GPU): the C-ABI library loads and exports every symbol include/vqhip.h declares, argument
+validation happens before any HIP call, the host-side mirror keeps the reference's constructor / state_dict
+contract, and the product refuses to run without the GPU."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+import golden_util as G
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    src = open(os.path.join(ROOT, "include", "vqhip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(vqhip_\w+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    from vector_quantize_pytorch_amd import _lib
+    L = _lib.lib()
+    names = _declared()
+    assert len(names) >= 10
+    for n in names:
+        assert hasattr(L, n), f"{n} declared in include/vqhip.h but not exported"
+    assert set(names) == set(_lib.EXPORTS)
+    assert b"gfx950" in L.vqhip_version()
+
+
+def test_host_only_entry_points():
+    from vector_quantize_pytorch_amd import _lib
+    L = _lib.lib()
+    assert L.vqhip_packed_bytes(1024, 256) == 32 * (32 * 256 + 256) * 4
+    assert L.vqhip_packed_bytes(33, 100) == 2 * (32 * 128 + 256) * 4      # D padded to 128, C to 64
+    assert L.vqhip_packed_bytes(16, 513) == 0                              # unsupported D
+    assert L.vqhip_assign_blocks(0) == 0 and L.vqhip_assign_blocks(1) == 1 and L.vqhip_assign_blocks(129) == 2
+
+
+def test_argument_validation_precedes_any_gpu_work():
+    from vector_quantize_pytorch_amd import _lib
+    L = _lib.lib()
+    null = ctypes.c_void_p(0)
+    rc = L.vqhip_assign(null, 0, 16, 64, 64, null, null, 8, 0, null, null, 0, 64, null, null, null, null, null)
+    assert rc == -1 and b"null" in L.vqhip_last_error()
+    buf = (ctypes.c_float * 64)()
+    p = ctypes.cast(buf, ctypes.c_void_p)
+    assert L.vqhip_assign(p, 0, 16, 1024, 1024, p, p, 8, 0, p, null, 0, 64, null, null, null, null, null) == -2   # D too large
+    assert L.vqhip_assign(p, 7, 16, 64, 64, p, p, 8, 0, p, null, 0, 64, null, null, null, null, null) == -1      # dtype
+    assert L.vqhip_assign(p, 0, 0, 64, 64, p, p, 8, 0, p, null, 0, 64, null, null, null, null, null) == 0        # N == 0: no-op
+    assert L.vqhip_pack_codebook(null, 8, 64, null, null) == -1
+    assert L.vqhip_ema_finalize(p, p, p, null, null, null, 8, 64, 0.2, 1e-5, 0, 1, 1, null, null) == -1          # do_lerp w/o stats
+    assert L.vqhip_decode_sum(null, 4, 1, null, 0, 8, 64, null, 0, 64, null) == -1
+
+
+@pytest.mark.parametrize("name", ["vq_cfg1_train", "rvq_shared", "rvq_tiger", "grvq", "vq_proj"])
+def test_state_dict_contract_matches_reference(name):
+    import vector_quantize_pytorch_amd as A
+    fx = G.Fixture(name)
+    mod = getattr(A, fx.meta["cls"])(**fx.kwargs)
+    ref = fx.state("before")
+    mine = mod.state_dict()
+    assert list(mine.keys()) == list(ref.keys()) or set(mine.keys()) == set(ref.keys())
+    for k in ref:
+        assert mine[k].shape == ref[k].shape and mine[k].dtype == ref[k].dtype, k
+    mod.load_state_dict(ref, strict=True)
+
+
+def test_default_init_matches_reference_statistics():
+    from vector_quantize_pytorch_amd import VectorQuantize
+    vq = VectorQuantize(dim=256, codebook_size=512)
+    e = vq._codebook.embed
+    assert e.shape == (1, 512, 256) and e.abs().max().item() <= (6.0 / (512 * 256)) ** 0.5 + 1e-7   # kaiming-uniform bound (vqp.py:112-115)
+    assert torch.equal(vq._codebook.cluster_size, torch.ones(1, 512)) and bool(vq._codebook.initted)
+    vc = VectorQuantize(dim=64, codebook_size=32, use_cosine_sim=True)
+    assert torch.allclose(vc._codebook.embed.norm(dim=-1), torch.ones(1, 32), atol=1e-6)
+    vk = VectorQuantize(dim=64, codebook_size=32, kmeans_init=True)
+    assert not bool(vk._codebook.initted) and vk._codebook.embed.abs().sum().item() == 0
+    # VectorQuantize default threshold is 0 while Codebook's is 2 (vqp.py:818 vs :360)
+    assert vq._codebook.threshold_ema_dead_code == 0
+
+
+def test_unsupported_options_fail_loudly_and_cpu_is_refused():
+    from vector_quantize_pytorch_amd import ResidualVQ, VectorQuantize
+    from vector_quantize_pytorch_amd._lib import VQHipError
+    for kw in (dict(stochastic_sample_codes=True), dict(learnable_codebook=True, ema_update=False), dict(affine_param=True),
+               dict(orthogonal_reg_weight=1.), dict(codebook_diversity_loss_weight=1.), dict(directional_reparam=True, threshold_ema_dead_code=2)):
+        with pytest.raises(NotImplementedError):
+            VectorQuantize(dim=32, codebook_size=16, **kw)
+    with pytest.raises(NotImplementedError):
+        ResidualVQ(dim=32, num_quantizers=2, codebook_size=16, implicit_neural_codebook=True)
+    with pytest.raises(AssertionError):
+        ResidualVQ(dim=32, num_quantizers=2, codebook_size=16, heads=2)
+    vq = VectorQuantize(dim=32, codebook_size=16)
+    with pytest.raises(VQHipError, match="no CPU fallback"):
+        vq(torch.randn(1, 4, 32))
+    with pytest.raises(NotImplementedError):
+        vq(torch.randn(1, 4, 32), topk=2)
+
+
+def test_product_never_imports_the_oracle():
+    """only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline may touch oracle/ (comments may cite it)"""
+    pkg = os.path.join(ROOT, "vector_quantize_pytorch_amd")
+    bad = re.compile(r"^\s*(from\s+oracle|import\s+oracle|#\s*include.*oracle)|libvqoracle|CDLL\(.*oracle", re.M)
+    for dp, _, fs in os.walk(pkg):
+        for f in fs:
+            if f.endswith((".py", ".hip", ".h")):
+                assert not bad.search(open(os.path.join(dp, f)).read()), f
+
+
+def test_as_rows_views():
+    from vector_quantize_pytorch_amd._lib import as_rows
+    x = torch.randn(4, 10, 64)
+    t, N, D, ld = as_rows(x)
+    assert (N, D, ld) == (40, 64, 64) and t.data_ptr() == x.data_ptr()
+    c = x.chunk(4, -1)[1]
+    t, N, D, ld = as_rows(c)
+    assert (N, D, ld) == (40, 16, 64) and t.data_ptr() == c.data_ptr()         # no copy for feature chunks
+    tr = x.transpose(1, 2)
+    t, N, D, ld = as_rows(tr)
+    assert (N, D, ld) == (4 * 64, 10, 10) and t.is_contiguous()                  # copied
+    t, N, D, ld = as_rows(x[:, ::2])
+    assert (N, ld) == (20, 128) and t.data_ptr() == x.data_ptr()                 # uniform row stride 128: still no copy
+    t, N, D, ld = as_rows(x[:, :3])
+    assert (N, ld) == (12, 64) and t.is_contiguous() and t.data_ptr() != x.data_ptr()   # ragged leading stride -> copy
+
+
+def test_key_packing_orders_like_argmax():
+    from vector_quantize_pytorch_amd.parallel import pack_score_index, unpack_score_index
+    g = torch.Generator().manual_seed(0)
+    s = torch.randn(4096, generator=g)
+    s[::7] = s[3]                       # force ties
+    s[5] = float("-inf"); s[6] = 0.0; s[8] = -0.0
+    idx = torch.randperm(4096, generator=g)
+    key = pack_score_index(s, idx)
+    s2, i2 = unpack_score_index(key)
+    assert torch.equal(s2.view(torch.int32), s.view(torch.int32)) and torch.equal(i2, idx)
+    order = torch.argsort(key, descending=True)
+    ss, ii = s[order], idx[order]
+    assert (ss[:-1] >= ss[1:]).all()
+    same = ss[:-1] == ss[1:]
+    assert (ii[:-1][same] < ii[1:][same]).all()     # among equal scores the lowest index has the largest key
