@@ -38,8 +38,6 @@ extern "C" {
 #define VQHIP_EALIGN   (-3)   /* pointer / stride alignment requirement violated            */
 
 #define VQHIP_ASSIGN_ROWS_PER_BLOCK 128  /* rows one workgroup of vqhip_assign owns */
-#define VQHIP_STATS_DSLICE 32            /* feature columns one workgroup of vqhip_ema_accumulate owns */
-#define VQHIP_STATS_CCHUNK 1024          /* codes one workgroup of vqhip_ema_accumulate owns */
 
 const char *vqhip_version(void);
 const char *vqhip_last_error(void);
@@ -82,14 +80,17 @@ int vqhip_reduce_partials(const double *partials, int64_t n, double scale, float
 /* ---- EMA sufficient statistics ----------------------------------------------------------------
  * Replaces embed_onehot.sum(1) and einsum('h n d, h n c -> h c d') (vqp.py:602, 605).
  * count [C] and embed_sum [C, D] fp32 are ACCUMULATED INTO (zero them first, e.g. hipMemsetAsync).
- * Rows with idx < 0 or row_mask == 0 are skipped.  For metric == cosine the rows are divided by
- * rnorm[n] (the value vqhip_assign wrote) before accumulation, i.e. the l2-normalised input.
- * Implementation: per-workgroup LDS-privatised [1024 codes x 32 columns] fp32 accumulators
- * (ds_add_f32), flushed with global fp32 atomics. */
+ * Rows with idx outside [0, C) or row_mask == 0 are skipped.  For metric == VQHIP_COSINE the rows are
+ * divided by rnorm[n] (the value vqhip_assign wrote) before accumulation, i.e. the l2-normalised input.
+ * Implementation: counting sort of the row ids by code (LDS integer histograms + one global atomic per
+ * workgroup and code), then one wave per (code, <=256-row chunk) streams whole rows and adds its partial
+ * sum with global fp32 atomics.  workspace: vqhip_ema_workspace_bytes(N, C) bytes, 256-byte aligned. */
+size_t vqhip_ema_workspace_bytes(int64_t N, int C);
 int vqhip_ema_accumulate(const void *x, int x_dtype, int64_t N, int D, int64_t ldx,
                          const int64_t *idx, int64_t idx_stride, const float *rnorm, int metric,
                          const uint8_t *row_mask, int C,
-                         float *count, float *embed_sum, void *stream);
+                         float *count, float *embed_sum, void *workspace, size_t workspace_bytes,
+                         void *stream);
 
 /* ---- EMA fold + codebook renormalisation ------------------------------------------------------
  * Replaces ema_inplace x2 (vqp.py:76-97, ATen lerp_ semantics), laplace_smoothing + update_ema

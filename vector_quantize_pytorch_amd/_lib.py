@@ -45,7 +45,9 @@ def lib():
     L.vqhip_pack_codebook.argtypes = [vp, i32, i32, vp, vp]
     L.vqhip_assign.argtypes = [vp, i32, i64, i32, i64, vp, vp, i32, i32, vp, vp, i32, i64, vp, vp, vp, vp, vp]
     L.vqhip_reduce_partials.argtypes = [vp, i64, f64, vp, vp]
-    L.vqhip_ema_accumulate.argtypes = [vp, i32, i64, i32, i64, vp, i64, vp, i32, vp, i32, vp, vp, vp]
+    L.vqhip_ema_workspace_bytes.restype = ctypes.c_size_t
+    L.vqhip_ema_workspace_bytes.argtypes = [i64, i32]
+    L.vqhip_ema_accumulate.argtypes = [vp, i32, i64, i32, i64, vp, i64, vp, i32, vp, i32, vp, vp, vp, ctypes.c_size_t, vp]
     L.vqhip_ema_finalize.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, f32, f32, i32, i32, i32, vp, vp]
     L.vqhip_decode_sum.argtypes = [vp, i64, i32, vp, i64, i32, i32, vp, i32, i64, vp]
     L.vqhip_row_sumsq.argtypes = [vp, i32, i64, i32, i64, vp, vp]
@@ -57,7 +59,7 @@ def lib():
 
 
 EXPORTS = ("vqhip_version", "vqhip_last_error", "vqhip_packed_bytes", "vqhip_pack_codebook",
-           "vqhip_assign_blocks", "vqhip_assign", "vqhip_reduce_partials", "vqhip_ema_accumulate",
+           "vqhip_assign_blocks", "vqhip_assign", "vqhip_reduce_partials", "vqhip_ema_workspace_bytes", "vqhip_ema_accumulate",
            "vqhip_ema_finalize", "vqhip_decode_sum", "vqhip_row_sumsq")
 
 
@@ -184,9 +186,11 @@ def ema_accumulate(x: torch.Tensor, idx: torch.Tensor, C: int, *, cosine=False, 
     if row_mask is not None:
         row_mask = row_mask.reshape(-1).to(torch.uint8).contiguous()
     if N > 0:
+        nbytes = lib().vqhip_ema_workspace_bytes(N, C)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)     # caching allocator: 512-byte aligned
         _check(lib().vqhip_ema_accumulate(_ptr(xk), _dtype_code(xk), N, D, ldx, _ptr(idx), idx_stride, _ptr(rnorm),
                                           COSINE if cosine else EUCLID, _ptr(row_mask), C, _ptr(count),
-                                          _ptr(embed_sum), _stream()), "vqhip_ema_accumulate")
+                                          _ptr(embed_sum), _ptr(ws), nbytes, _stream()), "vqhip_ema_accumulate")
     return count, embed_sum
 
 

@@ -626,203 +626,303 @@ extern "C" int vqhip_reduce_partials(const double *partials, int64_t n, double s
 }
 
 // ------------------------------------------------------------------------------------------------
-// EMA sufficient statistics
+// EMA sufficient statistics: counting sort of the rows by code, then full-row segmented sums.
+//
+//   vq_hist_kernel     count[c]           LDS integer histogram per workgroup -> global int atomics
+//   vq_scan_kernel     segment offsets, chunk offsets (<= VQ_SEG_CH rows per work item), cursors
+//   vq_scatter_kernel  perm[] = row ids grouped by code: LDS returning int atomics give the rank inside
+//                      the workgroup, ONE global atomic per (workgroup, code) reserves the slots
+//                      (cursors padded to one 64-byte line each so they spread over the L2 channels)
+//   vq_segsum_kernel   one wave per (code, chunk): streams whole rows (512 B .. 2 KiB contiguous) with
+//                      16 rows in flight, sums in registers, one global fp32 atomic per column
+//
+// Why not LDS-privatised fp32 accumulators (the first implementation): ds_add_f32 retires ~1 lane per
+// 3 clocks on gfx950 -- measured 1.36 ms vs 0.36 ms for the same kernel with plain racy adds at
+// N = 2^20, C = 1024, D = 256 (profiles/README.md).  Integer LDS atomics are only used for counting.
 // ------------------------------------------------------------------------------------------------
-struct StatsArgs {
-    const void *x;
-    int64_t N;
-    int D;
-    int64_t ldx;
+#define VQ_SEG_CH 256          // rows per segmented-sum work item
+#define VQ_HIST_LDS_MAX 16384  // codes whose histogram fits the LDS path (64 KiB)
+#define VQ_SORT_ROWS_PER_BLOCK 4096
+
+struct SortArgs {
     const int64_t *idx;
     int64_t idx_stride;
-    const float *rnorm;
-    int cosine;
     const uint8_t *row_mask;
+    int64_t N;
     int C;
-    float *count;
-    float *embed_sum;
-    int64_t rows_per_block;
-    int x_vec;  // rows are 16-byte aligned and D % 8 == 0: 16-byte loads
+    int *hist;     // [C]
+    int *cursor;   // [C * 16]
+    int *seg_off;  // [C + 1]
+    int *chunk_off;  // [C + 1]
+    int *perm;     // [N]
+    float *count;  // [C] fp32, accumulated into
 };
 
-// One workgroup owns a [CC <= 1024 codes] x [32 feature columns] tile of embed_sum, privatised in LDS
-// (128 KiB fp32 + 4 KiB counters), and streams its share of the rows: 4 lanes per row, each lane 8
-// consecutive columns loaded with ONE 16-byte load (bf16) or two (fp32), U rows per lane in flight
-// (~32 KiB of HBM loads per CU).  ds_add_f32 into acc[c][(col + c) & 31]: rotating the column by the
-// code spreads the 4-lanes-per-row access pattern over all 32 LDS banks (un-rotated, every row would
-// hit the same 4 banks: 16-way conflict).  Flush with global fp32 atomics (non-zero entries only).
-template <bool XBF16, bool HAS_MASK, bool VEC>
-__global__ void __launch_bounds__(256) vq_stats_kernel(const StatsArgs a)
+__device__ __forceinline__ int sort_code(const SortArgs &a, int64_t row)
+{
+    const int64_t ci = a.idx[row * a.idx_stride];
+    const bool ok = (ci >= 0) & (ci < a.C) & (!a.row_mask || a.row_mask[row] != 0);
+    return ok ? (int)ci : -1;
+}
+
+__global__ void __launch_bounds__(256) vq_hist_kernel(const SortArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int d0 = blockIdx.x * VQHIP_STATS_DSLICE;
-    const int c0 = blockIdx.y * VQHIP_STATS_CCHUNK;
-    const int CC = min(VQHIP_STATS_CCHUNK, a.C - c0);
-    float *acc = (float *)smem;            // [CC][32], column rotated by the code
-    int *cnt = (int *)(acc + CC * 32);     // [CC]
+    int *lh = (int *)smem;
+    const bool use_lds = a.C <= VQ_HIST_LDS_MAX;
     const int tid = threadIdx.x;
-    for (int e = tid; e < CC * 33; e += 256) acc[e] = 0.f;  // zero bits == int 0 too
+    if (use_lds) {
+        for (int c = tid; c < a.C; c += 256) lh[c] = 0;
+        __syncthreads();
+    }
+    const int64_t r0 = (int64_t)blockIdx.x * VQ_SORT_ROWS_PER_BLOCK;
+    const int64_t r1 = min(a.N, r0 + VQ_SORT_ROWS_PER_BLOCK);
+    for (int64_t row = r0 + tid; row < r1; row += 256) {
+        const int c = sort_code(a, row);
+        if (c >= 0) {
+            if (use_lds) atomicAdd(&lh[c], 1);
+            else atomicAdd(&a.hist[c], 1);
+        }
+    }
+    if (use_lds) {
+        __syncthreads();
+        for (int c = tid; c < a.C; c += 256)
+            if (lh[c]) atomicAdd(&a.hist[c], lh[c]);
+    }
+}
+
+__global__ void __launch_bounds__(1024) vq_scan_kernel(const SortArgs a)
+{
+    __shared__ int s_cnt[1024];
+    __shared__ int s_chk[1024];
+    const int tid = threadIdx.x;
+    const int per = (a.C + 1023) / 1024;
+    const int c_lo = min(a.C, tid * per), c_hi = min(a.C, c_lo + per);
+    int sc = 0, sk = 0;
+    for (int c = c_lo; c < c_hi; ++c) {
+        const int n = a.hist[c];
+        sc += n;
+        sk += (n + VQ_SEG_CH - 1) / VQ_SEG_CH;
+    }
+    s_cnt[tid] = sc;
+    s_chk[tid] = sk;
     __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {  // inclusive Hillis-Steele scan
+        int vc = 0, vk = 0;
+        if (tid >= o) { vc = s_cnt[tid - o]; vk = s_chk[tid - o]; }
+        __syncthreads();
+        s_cnt[tid] += vc;
+        s_chk[tid] += vk;
+        __syncthreads();
+    }
+    int oc = s_cnt[tid] - sc, ok = s_chk[tid] - sk;  // exclusive prefix of this thread's range
+    for (int c = c_lo; c < c_hi; ++c) {
+        const int n = a.hist[c];
+        a.seg_off[c] = oc;
+        a.chunk_off[c] = ok;
+        a.cursor[c * 16] = oc;
+        if (n) a.count[c] += (float)n;
+        oc += n;
+        ok += (n + VQ_SEG_CH - 1) / VQ_SEG_CH;
+    }
+    if (tid == 1023) {
+        a.seg_off[a.C] = s_cnt[1023];
+        a.chunk_off[a.C] = s_chk[1023];
+    }
+}
 
-    const int l4 = tid & 3;       // which 8-column group of the 32-column slice
-    const int slot = tid >> 2;    // 64 rows per pass
-    const int dcol = d0 + 8 * l4;
-    const bool do_cnt = (blockIdx.x == 0) && (l4 == 0);
-    const int64_t r_begin = (int64_t)blockIdx.z * a.rows_per_block;
-    const int64_t r_end = min(a.N, r_begin + a.rows_per_block);
-    const bool col_ok = VEC ? (dcol + 8 <= a.D) : (dcol < a.D);
+__global__ void __launch_bounds__(256) vq_scatter_kernel(const SortArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int *lc = (int *)smem;
+    const bool use_lds = a.C <= VQ_HIST_LDS_MAX;
+    const int tid = threadIdx.x;
+    const int64_t r0 = (int64_t)blockIdx.x * VQ_SORT_ROWS_PER_BLOCK;
+    const int64_t r1 = min(a.N, r0 + VQ_SORT_ROWS_PER_BLOCK);
+    constexpr int RPT = VQ_SORT_ROWS_PER_BLOCK / 256;
+    if (!use_lds) {
+        for (int64_t row = r0 + tid; row < r1; row += 256) {
+            const int c = sort_code(a, row);
+            if (c >= 0) a.perm[atomicAdd(&a.cursor[c * 16], 1)] = (int)row;
+        }
+        return;
+    }
+    for (int c = tid; c < a.C; c += 256) lc[c] = 0;
+    __syncthreads();
+    int code[RPT], rank[RPT];
+#pragma unroll
+    for (int u = 0; u < RPT; ++u) {
+        const int64_t row = r0 + tid + 256 * u;
+        code[u] = (row < r1) ? sort_code(a, row) : -1;
+    }
+#pragma unroll
+    for (int u = 0; u < RPT; ++u) rank[u] = (code[u] >= 0) ? atomicAdd(&lc[code[u]], 1) : 0;
+    __syncthreads();
+    for (int c = tid; c < a.C; c += 256) {
+        const int n = lc[c];
+        if (n) lc[c] = atomicAdd(&a.cursor[c * 16], n);  // reserve n slots; lc[c] becomes the base
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < RPT; ++u)
+        if (code[u] >= 0) a.perm[lc[code[u]] + rank[u]] = (int)(r0 + tid + 256 * u);
+}
 
-    // Every load below is UNCONDITIONAL (clamped / redirected to a safe address) so that the U loads
-    // of a phase are independent and stay in flight together; a guarded load makes hipcc wait
-    // vmcnt(0) per element and the loop becomes latency-bound (measured: 3.3 ms -> see DESIGN.md).
-    constexpr int U = XBF16 ? 8 : 4;
-    for (int64_t base = r_begin + slot; base < r_end; base += 64 * U) {
-        int64_t ci[U];
-        unsigned char mk[U];
+struct SegArgs {
+    const void *x;
+    int D;
+    int64_t ldx;
+    const float *rnorm;
+    int cosine;
+    int C;
+    const int *seg_off;
+    const int *chunk_off;
+    const int *perm;
+    float *embed_sum;
+};
+
+// EPL = elements per lane (vector path: D == 64 * EPL * nvec ... handled by the h loop)
+template <bool XBF16, bool VEC>
+__global__ void __launch_bounds__(256) vq_segsum_kernel(const SegArgs a)
+{
+    const int lane = threadIdx.x & 63;
+    const int w = blockIdx.x * 4 + (threadIdx.x >> 6);   // work item = (code, chunk)
+    const int total = a.chunk_off[a.C];
+    if (w >= total) return;
+    // binary search: largest c with chunk_off[c] <= w   (chunk_off is non-decreasing)
+    int lo = 0, hi = a.C;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (a.chunk_off[mid] <= w) lo = mid; else hi = mid;
+    }
+    const int c = __builtin_amdgcn_readfirstlane(lo);
+    const int j = w - a.chunk_off[c];
+    const int beg = a.seg_off[c] + j * VQ_SEG_CH;
+    const int end = min(a.seg_off[c + 1], beg + VQ_SEG_CH);
+
+    constexpr int NH = 2;          // up to 512 columns: 2 x (64 lanes x 4)
+    float acc[NH][4];
+#pragma unroll
+    for (int h = 0; h < NH; ++h)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[h][e] = 0.f;
+
+    constexpr int U = 8;
+    for (int r = beg; r < end; r += U) {
+        int rows[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) rows[u] = a.perm[min(r + u, end - 1)];   // wave-uniform
+        float v[U][NH][4];
         float rn[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int64_t rowc = min(base + 64 * u, r_end - 1);
-            ci[u] = a.idx[rowc * a.idx_stride];
-            mk[u] = HAS_MASK ? a.row_mask[rowc] : (unsigned char)1;
-            rn[u] = a.cosine ? a.rnorm[rowc] : 1.f;
-        }
-        int cc[U];
+            rn[u] = a.cosine ? a.rnorm[rows[u]] : 1.f;
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const bool keep = (base + 64 * u < r_end) & (mk[u] != 0) & (ci[u] >= c0) & (ci[u] < c0 + CC) & col_ok;
-            cc[u] = keep ? (int)(ci[u] - c0) : -1;
-        }
-        float v[U][8];
-        if (VEC) {
+            for (int h = 0; h < NH; ++h) {
+                const int d = h * 256 + lane * 4;
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                // rows this lane does not own are redirected to the workgroup's first row (a valid, cached line)
-                const int64_t row = (cc[u] >= 0) ? (base + 64 * u) : r_begin;
-                const int64_t off = row * a.ldx + ((cc[u] >= 0) ? dcol : 0);
-                if (XBF16) {
-                    const uint4 w = *(const uint4 *)((const unsigned short *)a.x + off);
-                    v[u][0] = __uint_as_float(w.x << 16); v[u][1] = __uint_as_float(w.x & 0xffff0000u);
-                    v[u][2] = __uint_as_float(w.y << 16); v[u][3] = __uint_as_float(w.y & 0xffff0000u);
-                    v[u][4] = __uint_as_float(w.z << 16); v[u][5] = __uint_as_float(w.z & 0xffff0000u);
-                    v[u][6] = __uint_as_float(w.w << 16); v[u][7] = __uint_as_float(w.w & 0xffff0000u);
+                for (int e = 0; e < 4; ++e) v[u][h][e] = 0.f;
+                if (VEC) {
+                    if (d < a.D) {
+                        if (XBF16) {
+                            const uint2 wv = *(const uint2 *)((const unsigned short *)a.x + (int64_t)rows[u] * a.ldx + d);
+                            v[u][h][0] = __uint_as_float(wv.x << 16); v[u][h][1] = __uint_as_float(wv.x & 0xffff0000u);
+                            v[u][h][2] = __uint_as_float(wv.y << 16); v[u][h][3] = __uint_as_float(wv.y & 0xffff0000u);
+                        } else {
+                            const f32x4 wv = *(const f32x4 *)((const float *)a.x + (int64_t)rows[u] * a.ldx + d);
+                            v[u][h][0] = wv.x; v[u][h][1] = wv.y; v[u][h][2] = wv.z; v[u][h][3] = wv.w;
+                        }
+                    }
                 } else {
-                    const f32x4 *p = (const f32x4 *)((const float *)a.x + off);
-                    const f32x4 w0 = p[0], w1 = p[1];
-                    v[u][0] = w0.x; v[u][1] = w0.y; v[u][2] = w0.z; v[u][3] = w0.w;
-                    v[u][4] = w1.x; v[u][5] = w1.y; v[u][6] = w1.z; v[u][7] = w1.w;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (d + e < a.D) v[u][h][e] = load_elem<XBF16>(a.x, (int64_t)rows[u] * a.ldx + d + e);
                 }
             }
-        } else {
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int64_t row = (cc[u] >= 0) ? (base + 64 * u) : r_begin;
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    const int d = (cc[u] >= 0 && dcol + k < a.D) ? (dcol + k) : 0;
-                    v[u][k] = load_elem<XBF16>(a.x, row * a.ldx + d);
-                }
-            }
-        }
-        if (a.cosine) {
-#pragma unroll
-            for (int u = 0; u < U; ++u)
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    const float t = v[u][k] / rn[u];
-                    v[u][k] = XBF16 ? round_to_bf16(t) : t;
-                }
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            if (cc[u] >= 0) {
-                float *rowacc = acc + cc[u] * 32;
-                const int rot = cc[u] + 8 * l4;
+            if (r + u < end) {
 #pragma unroll
-                for (int k = 0; k < 8; ++k)
-#ifdef VQ_EXPERIMENT_RACY_STATS
-                    if (VEC || dcol + k < a.D) rowacc[(rot + k) & 31] += v[u][k];   // timing experiment only (wrong results)
-#else
-                    if (VEC || dcol + k < a.D) atomicAdd(&rowacc[(rot + k) & 31], v[u][k]);  // ds_add_f32
-#endif
-                if (do_cnt) atomicAdd(&cnt[cc[u]], 1);
+                for (int h = 0; h < NH; ++h)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float t = v[u][h][e];
+                        if (a.cosine) {
+                            t = t / rn[u];
+                            if (XBF16) t = round_to_bf16(t);
+                        }
+                        acc[h][e] += t;
+                    }
             }
         }
     }
-    __syncthreads();
-
-    for (int e = tid; e < CC * 32; e += 256) {
-        const float s = acc[e];
-        const int c = e >> 5;
-        const int d = d0 + (((e & 31) - c) & 31);
-        if (s != 0.f && d < a.D) unsafeAtomicAdd(&a.embed_sum[(size_t)(c0 + c) * a.D + d], s);
-    }
-    if (blockIdx.x == 0)
-        for (int c = tid; c < CC; c += 256)
-            if (cnt[c]) unsafeAtomicAdd(&a.count[c0 + c], (float)cnt[c]);
+#pragma unroll
+    for (int h = 0; h < NH; ++h)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int d = h * 256 + lane * 4 + e;
+            if (d < a.D && acc[h][e] != 0.f) unsafeAtomicAdd(&a.embed_sum[(size_t)c * a.D + d], acc[h][e]);
+        }
 }
 
-template <bool XBF16, bool HAS_MASK, bool VEC>
-static int launch_stats(const StatsArgs &a, dim3 grid, int smem, hipStream_t st)
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+extern "C" size_t vqhip_ema_workspace_bytes(int64_t N, int C)
 {
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void *)vq_stats_kernel<XBF16, HAS_MASK, VEC>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, VQHIP_STATS_CCHUNK * 33 * 4);
-        if (e != hipSuccess) VQ_FAIL((int)e, "hipFuncSetAttribute(stats): %s", hipGetErrorString(e));
-        attr_done = true;
-    }
-    hipLaunchKernelGGL((vq_stats_kernel<XBF16, HAS_MASK, VEC>), grid, dim3(256), smem, st, a);
-    return launch_status("vq_stats_kernel");
+    if (N < 0 || C <= 0) return 0;
+    // hist[C] | cursor[16 C] | seg_off[C+1] | chunk_off[C+1] | perm[N]   (all int32, 256-byte aligned pieces)
+    return align_up((size_t)C * 4, 256) + align_up((size_t)C * 64, 256) + 2 * align_up(((size_t)C + 1) * 4, 256) +
+           align_up((size_t)(N > 0 ? N : 1) * 4, 256);
 }
 
 extern "C" int vqhip_ema_accumulate(const void *x, int x_dtype, int64_t N, int D, int64_t ldx,
                                     const int64_t *idx, int64_t idx_stride, const float *rnorm, int metric,
                                     const uint8_t *row_mask, int C,
-                                    float *count, float *embed_sum, void *stream)
+                                    float *count, float *embed_sum, void *workspace, size_t workspace_bytes,
+                                    void *stream)
 {
     if (N < 0 || C <= 0 || D < 1) VQ_FAIL(VQHIP_EINVAL, "ema_accumulate: bad size");
     if (N == 0) return 0;
-    if (!x || !idx || !count || !embed_sum) VQ_FAIL(VQHIP_EINVAL, "ema_accumulate: null pointer");
+    if (!x || !idx || !count || !embed_sum || !workspace) VQ_FAIL(VQHIP_EINVAL, "ema_accumulate: null pointer");
+    if (D > 512) VQ_FAIL(VQHIP_EDIM, "ema_accumulate: D=%d unsupported (1..512)", D);
+    if (N >= ((int64_t)1 << 31)) VQ_FAIL(VQHIP_EINVAL, "ema_accumulate: N must be < 2^31");
     if (metric == VQHIP_COSINE && !rnorm) VQ_FAIL(VQHIP_EINVAL, "ema_accumulate: cosine needs rnorm");
     if (x_dtype != VQHIP_F32 && x_dtype != VQHIP_BF16) VQ_FAIL(VQHIP_EINVAL, "ema_accumulate: unknown dtype");
+    if (workspace_bytes < vqhip_ema_workspace_bytes(N, C)) VQ_FAIL(VQHIP_EINVAL, "ema_accumulate: workspace too small");
+    if (((uintptr_t)workspace) & 255) VQ_FAIL(VQHIP_EALIGN, "ema_accumulate: workspace must be 256-byte aligned");
 
-    StatsArgs a;
-    a.x = x; a.N = N; a.D = D; a.ldx = ldx; a.idx = idx; a.idx_stride = idx_stride; a.rnorm = rnorm;
-    a.cosine = (metric == VQHIP_COSINE); a.row_mask = row_mask; a.C = C; a.count = count; a.embed_sum = embed_sum;
-
-    const int nx = (D + VQHIP_STATS_DSLICE - 1) / VQHIP_STATS_DSLICE;
-    const int ny = (C + VQHIP_STATS_CCHUNK - 1) / VQHIP_STATS_CCHUNK;
-    // one workgroup per CU (the LDS tile is 132 KiB); at least 2048 rows per workgroup so the flush amortises
-    int64_t nz = (256 + (int64_t)nx * ny - 1) / ((int64_t)nx * ny);
-    const int64_t max_nz = (N + 2047) / 2048;
-    if (nz > max_nz) nz = max_nz;
-    if (nz < 1) nz = 1;
-    if (nz > 65535) nz = 65535;
-    a.rows_per_block = (N + nz - 1) / nz;
-    a.rows_per_block = (a.rows_per_block + 63) / 64 * 64;
-    {
-        const int es = (x_dtype == VQHIP_BF16) ? 2 : 4;
-        a.x_vec = (D % 8 == 0) && (((uintptr_t)x) % 16 == 0) && ((ldx * es) % 16 == 0);
-    }
-    nz = (N + a.rows_per_block - 1) / a.rows_per_block;
-
-    const int CCmax = C < VQHIP_STATS_CCHUNK ? C : VQHIP_STATS_CCHUNK;
-    const int smem = CCmax * 33 * 4;
-    dim3 grid(nx, ny, (unsigned)nz);
     hipStream_t st = (hipStream_t)stream;
-    const bool bf = (x_dtype == VQHIP_BF16), hm = (row_mask != nullptr), vec = (a.x_vec != 0);
-#define VQ_STATS_CASE(B, M, V) if (bf == B && hm == M && vec == V) return launch_stats<B, M, V>(a, grid, smem, st)
-    VQ_STATS_CASE(true, true, true);
-    VQ_STATS_CASE(true, true, false);
-    VQ_STATS_CASE(true, false, true);
-    VQ_STATS_CASE(true, false, false);
-    VQ_STATS_CASE(false, true, true);
-    VQ_STATS_CASE(false, true, false);
-    VQ_STATS_CASE(false, false, true);
-    VQ_STATS_CASE(false, false, false);
-#undef VQ_STATS_CASE
-    return 0;
+    char *ws = (char *)workspace;
+    SortArgs s;
+    s.idx = idx; s.idx_stride = idx_stride; s.row_mask = row_mask; s.N = N; s.C = C; s.count = count;
+    s.hist = (int *)ws;           ws += align_up((size_t)C * 4, 256);
+    s.cursor = (int *)ws;         ws += align_up((size_t)C * 64, 256);
+    s.seg_off = (int *)ws;        ws += align_up(((size_t)C + 1) * 4, 256);
+    s.chunk_off = (int *)ws;      ws += align_up(((size_t)C + 1) * 4, 256);
+    s.perm = (int *)ws;
+
+    hipError_t e = hipMemsetAsync(s.hist, 0, (size_t)C * 4, st);
+    if (e != hipSuccess) VQ_FAIL((int)e, "hipMemsetAsync(hist): %s", hipGetErrorString(e));
+    const unsigned sort_blocks = (unsigned)((N + VQ_SORT_ROWS_PER_BLOCK - 1) / VQ_SORT_ROWS_PER_BLOCK);
+    const int lds = (C <= VQ_HIST_LDS_MAX) ? C * 4 : 0;
+    hipLaunchKernelGGL(vq_hist_kernel, dim3(sort_blocks), dim3(256), lds, st, s);
+    hipLaunchKernelGGL(vq_scan_kernel, dim3(1), dim3(1024), 0, st, s);
+    hipLaunchKernelGGL(vq_scatter_kernel, dim3(sort_blocks), dim3(256), lds, st, s);
+
+    SegArgs g;
+    g.x = x; g.D = D; g.ldx = ldx; g.rnorm = rnorm; g.cosine = (metric == VQHIP_COSINE); g.C = C;
+    g.seg_off = s.seg_off; g.chunk_off = s.chunk_off; g.perm = s.perm; g.embed_sum = embed_sum;
+    const int64_t max_items = N / VQ_SEG_CH + C + 1;       // sum_c ceil(n_c / CH) <= N / CH + C
+    const unsigned seg_blocks = (unsigned)((max_items + 3) / 4);
+    const int es = (x_dtype == VQHIP_BF16) ? 2 : 4;
+    const bool vec = (D % 4 == 0) && (((uintptr_t)x) % (4 * es) == 0) && ((ldx * es) % (4 * es) == 0);
+    const bool bf = (x_dtype == VQHIP_BF16);
+    if (bf && vec) hipLaunchKernelGGL((vq_segsum_kernel<true, true>), dim3(seg_blocks), dim3(256), 0, st, g);
+    else if (bf) hipLaunchKernelGGL((vq_segsum_kernel<true, false>), dim3(seg_blocks), dim3(256), 0, st, g);
+    else if (vec) hipLaunchKernelGGL((vq_segsum_kernel<false, true>), dim3(seg_blocks), dim3(256), 0, st, g);
+    else hipLaunchKernelGGL((vq_segsum_kernel<false, false>), dim3(seg_blocks), dim3(256), 0, st, g);
+    return launch_status("vq_ema_accumulate");
 }
 
 // ------------------------------------------------------------------------------------------------
