@@ -74,6 +74,21 @@ int vqhip_assign(const void *x, int x_dtype, int64_t N, int D, int64_t ldx,
                  float *best_out, float *rnorm_out, double *sqerr_partial,
                  const uint8_t *row_mask, void *stream);
 
+/* ---- fused residual VQ loop ---------------------------------------------------------------------
+ * Replaces the per-quantizer loop of ResidualVQ.forward (rvq.py:469-568) for the Euclidean metric and a
+ * uniform codebook size: Q successive nearest-code searches on the running residual, which stays in
+ * registers between stages.  Stage q uses codebook embed + q*embed_qstride / packed + q*packed_qstride
+ * (strides in floats; 0 = all stages share one codebook, rvq.py:302-306).
+ *  idx_out        [N, Q] int64 (-1 on rows with row_mask == 0)
+ *  resid_out      nullable; [N, Q, D] in x's dtype: the input of every stage (what the reference keeps in
+ *                 `all_residuals`, rvq.py:489) for the EMA statistics / expiry afterwards
+ *  sqerr_partial  nullable; [Q, 4 * vqhip_assign_blocks(N)] doubles: per-wave sums of (quantized_q - residual_q)^2
+ * quantized_out = vqhip_decode_sum(idx_out, ...).  Requires D % 32 == 0. */
+int vqhip_rvq_forward(const void *x, int x_dtype, int64_t N, int D, int64_t ldx,
+                      const float *packed, int64_t packed_qstride, const float *embed, int64_t embed_qstride,
+                      int C, int Q, int64_t *idx_out, void *resid_out, double *sqerr_partial,
+                      const uint8_t *row_mask, void *stream);
+
 /* sum of `n` doubles times `scale` -> one fp32 (commit loss = scale * sum of partials). */
 int vqhip_reduce_partials(const double *partials, int64_t n, double scale, float *out, void *stream);
 

@@ -45,6 +45,8 @@ def lib():
     L.vqhip_pack_codebook.argtypes = [vp, i32, i32, vp, vp]
     L.vqhip_assign.argtypes = [vp, i32, i64, i32, i64, vp, vp, i32, i32, vp, vp, i32, i64, vp, vp, vp, vp, vp]
     L.vqhip_reduce_partials.argtypes = [vp, i64, f64, vp, vp]
+    L.vqhip_rvq_forward.argtypes = [vp, i32, i64, i32, i64, vp, i64, vp, i64, i32, i32, vp, vp, vp, vp, vp]
+    L.vqhip_rvq_forward.restype = i32
     L.vqhip_ema_workspace_bytes.restype = ctypes.c_size_t
     L.vqhip_ema_workspace_bytes.argtypes = [i64, i32]
     L.vqhip_ema_accumulate.argtypes = [vp, i32, i64, i32, i64, vp, i64, vp, i32, vp, i32, vp, vp, vp, ctypes.c_size_t, vp]
@@ -59,7 +61,7 @@ def lib():
 
 
 EXPORTS = ("vqhip_version", "vqhip_last_error", "vqhip_packed_bytes", "vqhip_pack_codebook",
-           "vqhip_assign_blocks", "vqhip_assign", "vqhip_reduce_partials", "vqhip_ema_workspace_bytes", "vqhip_ema_accumulate",
+           "vqhip_assign_blocks", "vqhip_assign", "vqhip_rvq_forward", "vqhip_reduce_partials", "vqhip_ema_workspace_bytes", "vqhip_ema_accumulate",
            "vqhip_ema_finalize", "vqhip_decode_sum", "vqhip_row_sumsq")
 
 
@@ -164,6 +166,32 @@ def assign(x: torch.Tensor, packed: torch.Tensor, embed2d: torch.Tensor, *, cosi
     return dict(idx=idx, q=q, sqerr_partials=partials, best=best, rnorm=rnorm, nblk=nblk)
 
 
+def rvq_forward(x: torch.Tensor, packed: torch.Tensor, embed: torch.Tensor, Q: int, *, want_resid=False,
+                want_sqerr=False, row_mask=None):
+    """Fused residual loop.  embed [C, D] (shared by all stages; packed = pack_codebook(embed)) or [Q, C, D]
+    (packed = [Q, packed_floats]).  -> dict(idx [..., Q], resid [..., Q, D] | None, sqerr_partials [Q, 4*nblk] | None)."""
+    _need_gpu(x, packed, embed, row_mask)
+    xk, N, D, ldx = as_rows(x)
+    assert embed.dtype == torch.float32 and embed.is_contiguous() and embed.shape[-1] == D
+    if embed.ndim == 2:
+        C, eq, pq = embed.shape[0], 0, 0
+    else:
+        assert embed.shape[0] == Q and packed.ndim == 2 and packed.shape[0] == Q and packed.is_contiguous()
+        C, eq, pq = embed.shape[1], embed.shape[1] * D, packed.shape[1]
+    dev, lead = x.device, x.shape[:-1]
+    idx = torch.empty(*lead, Q, dtype=torch.int64, device=dev)
+    resid = torch.empty(*lead, Q, D, dtype=x.dtype, device=dev) if want_resid else None
+    nblk = lib().vqhip_assign_blocks(N)
+    partials = torch.zeros(Q, 4 * max(nblk, 1), dtype=torch.float64, device=dev) if want_sqerr else None
+    if row_mask is not None:
+        row_mask = row_mask.reshape(-1).to(torch.uint8).contiguous()
+    if N > 0:
+        _check(lib().vqhip_rvq_forward(_ptr(xk), _dtype_code(xk), N, D, ldx, _ptr(packed), pq, _ptr(embed), eq, C, Q,
+                                       _ptr(idx), _ptr(resid), _ptr(partials), _ptr(row_mask), _stream()),
+               "vqhip_rvq_forward")
+    return dict(idx=idx, resid=resid, sqerr_partials=partials, nblk=nblk)
+
+
 def reduce_partials(partials: torch.Tensor, n: int, scale: float, out: torch.Tensor | None = None) -> torch.Tensor:
     _need_gpu(partials)
     if out is None:
@@ -173,7 +201,7 @@ def reduce_partials(partials: torch.Tensor, n: int, scale: float, out: torch.Ten
 
 
 def ema_accumulate(x: torch.Tensor, idx: torch.Tensor, C: int, *, cosine=False, rnorm=None, row_mask=None,
-                   count=None, embed_sum=None, idx_stride=1):
+                   count=None, embed_sum=None, idx_stride=1, idx_offset=0):
     """Accumulates into (count [C], embed_sum [C, D]); allocates zeroed ones if not given."""
     _need_gpu(x, idx, rnorm, row_mask)
     xk, N, D, ldx = as_rows(x)
@@ -188,7 +216,8 @@ def ema_accumulate(x: torch.Tensor, idx: torch.Tensor, C: int, *, cosine=False, 
     if N > 0:
         nbytes = lib().vqhip_ema_workspace_bytes(N, C)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)     # caching allocator: 512-byte aligned
-        _check(lib().vqhip_ema_accumulate(_ptr(xk), _dtype_code(xk), N, D, ldx, _ptr(idx), idx_stride, _ptr(rnorm),
+        idx_ptr = ctypes.c_void_p(idx.data_ptr() + 8 * idx_offset)     # e.g. column q of an [N, Q] index tensor
+        _check(lib().vqhip_ema_accumulate(_ptr(xk), _dtype_code(xk), N, D, ldx, idx_ptr, idx_stride, _ptr(rnorm),
                                           COSINE if cosine else EUCLID, _ptr(row_mask), C, _ptr(count),
                                           _ptr(embed_sum), _ptr(ws), nbytes, _stream()), "vqhip_ema_accumulate")
     return count, embed_sum

@@ -602,6 +602,289 @@ extern "C" int vqhip_assign(const void *x, int x_dtype, int64_t N, int D, int64_
 }
 
 // ------------------------------------------------------------------------------------------------
+// fused residual VQ (rvq.py:469-568): Q nearest-code sweeps on the running residual, the residual rows
+// never leave the VGPRs between stages.  Euclidean metric, uniform codebook size.
+//   per stage q:  idx[n, q] = argmin_c cdist(res, embed_q);  g = embed_q[idx]  (rounded to bf16 for bf16 I/O)
+//                 loss_q += sum (g - res)^2 ;  res <- res - g   (rvq.py:524, exact fp32 / bf16 arithmetic of the
+//                 reference: quantized and residual are x-dtype tensors there)
+// Optional resid_out [N, Q, D] (x dtype) receives the INPUT of every stage: the EMA statistics
+// (vqp.py:602-606 per layer) and the shared-codebook expiry (rvq.py:600-601) consume it afterwards.
+// quantized_out = sum_q g_q is produced by vq_decode_kernel from the indices (same q-order running sum as
+// rvq.py:525).  Masked rows (row_mask == 0): index -1, contribution 0, excluded from the loss.
+// ------------------------------------------------------------------------------------------------
+struct RvqArgs {
+    const void *x;
+    int64_t N;
+    int D;
+    int64_t ldx;
+    const float *packed;
+    int64_t packed_qstride;  // floats between the packed codebooks of consecutive stages (0: shared)
+    const float *embed;
+    int64_t embed_qstride;   // floats between codebooks (0: shared)
+    int C;
+    int n_tiles;
+    int Q;
+    int64_t *idx_out;        // [N, Q]
+    void *resid_out;         // nullable [N, Q, D] in x's dtype
+    double *sqerr_partial;   // nullable [Q, gridDim.x]
+    const uint8_t *row_mask;
+    int x_vec;
+};
+
+template <int DT, bool XBF16>
+__global__ void __launch_bounds__(256, (DT <= 256 ? 2 : 1)) vq_rvq_kernel(const RvqArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int TILE_F = 32 * DT + 256;
+    constexpr int TILE_B = TILE_F * 4;
+    constexpr int NCHUNK = TILE_B / 1024;
+    constexpr int NG = DT / 8;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 31;
+    const int hi = lane >> 5;
+    const int64_t row = (int64_t)blockIdx.x * VQHIP_ASSIGN_ROWS_PER_BLOCK + wave * 32 + j;
+    const bool row_ok = row < a.N;
+    const int64_t rowc = row_ok ? row : (a.N - 1);
+    const bool live = row_ok && (!a.row_mask || a.row_mask[rowc] != 0);
+
+    const int nt = a.n_tiles;
+    const int total_tiles = nt * a.Q;
+    auto issue_tile = [&](int gt, int buf) {   // gt = global tile counter over (stage, tile)
+        const int q = gt / nt, ct = gt - q * nt;
+        const char *g = (const char *)(a.packed + (size_t)q * a.packed_qstride) + (size_t)ct * TILE_B + lane * 16;
+        char *l = smem + buf * TILE_B;
+        for (int c = wave; c < NCHUNK; c += 4)
+            __builtin_amdgcn_global_load_lds((const AS1 void *)(g + c * 1024), (AS3 void *)(l + c * 1024), 16, 0, 0);
+    };
+    issue_tile(0, 0);
+
+    float xr[DT / 2];   // the running residual, load layout between stages, B-operand layout inside a sweep
+    if (a.x_vec) {
+        if (XBF16) {
+            const uint2 *p = (const uint2 *)((const unsigned short *)a.x + rowc * a.ldx + 4 * hi);
+#pragma unroll
+            for (int m = 0; m < NG; ++m) {
+                const uint2 w = p[m * 2];
+                xr[4 * m + 0] = __uint_as_float(w.x << 16);
+                xr[4 * m + 1] = __uint_as_float(w.x & 0xffff0000u);
+                xr[4 * m + 2] = __uint_as_float(w.y << 16);
+                xr[4 * m + 3] = __uint_as_float(w.y & 0xffff0000u);
+            }
+        } else {
+            const f32x4 *p = (const f32x4 *)((const float *)a.x + rowc * a.ldx + 4 * hi);
+#pragma unroll
+            for (int m = 0; m < NG; ++m) {
+                const f32x4 w = p[m * 2];
+                xr[4 * m + 0] = w.x; xr[4 * m + 1] = w.y; xr[4 * m + 2] = w.z; xr[4 * m + 3] = w.w;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int m = 0; m < NG; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int k = 8 * m + 4 * hi + r;
+                xr[4 * m + r] = (k < a.D) ? load_elem<XBF16>(a.x, rowc * a.ldx + k) : 0.f;
+            }
+    }
+
+    int gt = 0;
+    for (int q = 0; q < a.Q; ++q) {
+        // ---- stage input: optional dump, ATen-order ||res||^2, B-operand layout ------------------
+        if (a.resid_out && row_ok) {
+            const int64_t ro = (row * a.Q + q) * (int64_t)a.D;
+#pragma unroll
+            for (int m = 0; m < NG; ++m) {
+                const int k0 = 8 * m + 4 * hi;
+                if (a.x_vec) {
+                    if (XBF16) {
+                        uint2 w;
+                        w.x = (__float_as_uint(xr[4 * m + 0]) >> 16) | (__float_as_uint(xr[4 * m + 1]) & 0xffff0000u);
+                        w.y = (__float_as_uint(xr[4 * m + 2]) >> 16) | (__float_as_uint(xr[4 * m + 3]) & 0xffff0000u);
+                        *(uint2 *)((unsigned short *)a.resid_out + ro + k0) = w;
+                    } else {
+                        const f32x4 w = {xr[4 * m + 0], xr[4 * m + 1], xr[4 * m + 2], xr[4 * m + 3]};
+                        *(f32x4 *)((float *)a.resid_out + ro + k0) = w;
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (k0 + r < a.D) {
+                            if (XBF16) ((unsigned short *)a.resid_out)[ro + k0 + r] = (unsigned short)(__float_as_uint(xr[4 * m + r]) >> 16);
+                            else ((float *)a.resid_out)[ro + k0 + r] = xr[4 * m + r];
+                        }
+                }
+            }
+        }
+        float x2;
+        {
+            float ch[4][4];
+#pragma unroll
+            for (int mm = 0; mm < 4; ++mm)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ch[mm][r] = 0.f;
+#pragma unroll
+            for (int m = 0; m < NG; ++m)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float v = xr[4 * m + r];
+                    ch[m & 3][r] += v * v;
+                }
+            float p[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) p[r] = ((ch[0][r] + ch[1][r]) + ch[2][r]) + ch[3][r];
+            const float f_lo = ((p[0] + p[1]) + p[2]) + p[3];
+            const float f_from_lo = __shfl(f_lo, j, 64);
+            const float f_hi = (((f_from_lo + p[0]) + p[1]) + p[2]) + p[3];
+            x2 = __shfl(f_hi, j + 32, 64);
+        }
+#pragma unroll
+        for (int m = 0; m < NG; ++m) {
+            swap32(xr[4 * m + 0], xr[4 * m + 1]);
+            swap32(xr[4 * m + 2], xr[4 * m + 3]);
+        }
+
+        // ---- sweep stage q's codebook --------------------------------------------------------------
+        float bd = INFINITY, bs = INFINITY;
+        int bi = 0;
+        for (int ct = 0; ct < nt; ++ct, ++gt) {
+            const int buf = gt & 1;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (gt + 1 < total_tiles) issue_tile(gt + 1, buf ^ 1);
+
+            const char *tile = smem + buf * TILE_B;
+            const f32x4 *ap = (const f32x4 *)tile + (hi * 32 + j);
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+            for (int t4 = 0; t4 < NG; ++t4) {
+                const f32x4 av = ap[t4 * 64];
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, xr[4 * t4 + 0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, xr[4 * t4 + 2], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, xr[4 * t4 + 1], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, xr[4 * t4 + 3], acc, 0, 0, 0);
+            }
+            const float *y2s = (const float *)tile + 32 * DT;
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) {
+                const f32x4 yv = *(const f32x4 *)(y2s + 8 * qq + 4 * hi);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int code = ct * 32 + 8 * qq + 4 * hi + r;
+                    const float t = x2 + yv[r];
+                    float s = __builtin_fmaf(-2.0f, acc[4 * qq + r], t);
+                    s = fmaxf(s, 1e-8f);
+                    const bool cand = s < bs;
+                    if (__any(cand)) {
+                        const float d = sqrtf(s);
+                        const bool win = cand && (d < bd);
+                        bd = win ? d : bd;
+                        bs = win ? s : bs;
+                        bi = win ? code : bi;
+                    }
+                }
+            }
+        }
+        {
+            const float od = __shfl_xor(bd, 32, 64);
+            const int oi = __shfl_xor(bi, 32, 64);
+            const bool take = (od < bd) || (od == bd && oi < bi);
+            bd = take ? od : bd;
+            bi = take ? oi : bi;
+        }
+        if (row_ok && hi == 0) a.idx_out[row * a.Q + q] = live ? (int64_t)bi : (int64_t)-1;
+
+        // ---- residual update in the load layout --------------------------------------------------
+#pragma unroll
+        for (int m = 0; m < NG; ++m) {
+            swap32(xr[4 * m + 0], xr[4 * m + 1]);
+            swap32(xr[4 * m + 2], xr[4 * m + 3]);
+        }
+        const float *er = a.embed + (size_t)q * a.embed_qstride + (size_t)bi * a.D;
+        float lsum = 0.f;
+#pragma unroll
+        for (int m = 0; m < NG; ++m) {
+            const int k0 = 8 * m + 4 * hi;
+            float g[4];
+            if (a.x_vec) {
+                const f32x4 w = *(const f32x4 *)(er + k0);
+                g[0] = w.x; g[1] = w.y; g[2] = w.z; g[3] = w.w;
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) g[r] = (k0 + r < a.D) ? er[k0 + r] : 0.f;
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float gq = XBF16 ? round_to_bf16(g[r]) : g[r];
+                const float df = gq - xr[4 * m + r];
+                lsum += df * df;
+                float nr = xr[4 * m + r] - gq;                 // residual - quantized (rvq.py:524)
+                if (XBF16) nr = round_to_bf16(nr);             // bf16 tensors in the reference
+                xr[4 * m + r] = live ? nr : xr[4 * m + r];
+            }
+        }
+        if (a.sqerr_partial) {
+            double ds = live ? (double)lsum : 0.0;
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) ds += __shfl_xor(ds, o, 64);
+            // per-wave partials go straight to global: [q][block][wave]
+            if (lane == 0) a.sqerr_partial[((size_t)q * gridDim.x + blockIdx.x) * 4 + wave] = ds;
+        }
+    }
+}
+
+template <int DT, bool XBF16>
+static int launch_rvq(const RvqArgs &a, hipStream_t st)
+{
+    constexpr int SMEM = 2 * (32 * DT + 256) * 4;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void *)vq_rvq_kernel<DT, XBF16>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+        if (e != hipSuccess) VQ_FAIL((int)e, "hipFuncSetAttribute(rvq<%d>): %s", DT, hipGetErrorString(e));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((vq_rvq_kernel<DT, XBF16>), dim3((unsigned)vqhip_assign_blocks(a.N)), dim3(256), SMEM, st, a);
+    return launch_status("vq_rvq_kernel");
+}
+
+extern "C" int vqhip_rvq_forward(const void *x, int x_dtype, int64_t N, int D, int64_t ldx,
+                                 const float *packed, int64_t packed_qstride, const float *embed, int64_t embed_qstride,
+                                 int C, int Q, int64_t *idx_out, void *resid_out, double *sqerr_partial,
+                                 const uint8_t *row_mask, void *stream)
+{
+    if (N < 0 || C <= 0 || Q < 1) VQ_FAIL(VQHIP_EINVAL, "rvq_forward: bad size");
+    if (N == 0) return 0;
+    if (!x || !packed || !embed || !idx_out) VQ_FAIL(VQHIP_EINVAL, "rvq_forward: null pointer");
+    if (x_dtype != VQHIP_F32 && x_dtype != VQHIP_BF16) VQ_FAIL(VQHIP_EINVAL, "rvq_forward: unknown x dtype %d", x_dtype);
+    const int DT = pick_dt(D);
+    if (D < 1 || DT == 0) VQ_FAIL(VQHIP_EDIM, "rvq_forward: D=%d unsupported (1..512)", D);
+    if (D & 31) VQ_FAIL(VQHIP_EDIM, "rvq_forward: the fused residual loop needs D %% 32 == 0 (got %d); use per-stage vqhip_assign", D);
+    if (ldx < D) VQ_FAIL(VQHIP_EINVAL, "rvq_forward: row stride smaller than D");
+    if (((uintptr_t)packed) & 15) VQ_FAIL(VQHIP_EALIGN, "rvq_forward: packed must be 16-byte aligned");
+    RvqArgs a;
+    a.x = x; a.N = N; a.D = D; a.ldx = ldx; a.packed = packed; a.packed_qstride = packed_qstride; a.embed = embed;
+    a.embed_qstride = embed_qstride; a.C = C; a.n_tiles = (C + 31) / 32; a.Q = Q; a.idx_out = idx_out;
+    a.resid_out = resid_out; a.sqerr_partial = sqerr_partial; a.row_mask = row_mask;
+    const int xes = (x_dtype == VQHIP_BF16) ? 2 : 4;
+    a.x_vec = (D == DT) && (((uintptr_t)x) % (4 * xes) == 0) && ((ldx * xes) % (4 * xes) == 0) && ((((uintptr_t)embed) & 15) == 0) &&
+              (!resid_out || (((uintptr_t)resid_out) % (4 * xes) == 0)) && ((embed_qstride % 4) == 0) && ((packed_qstride % 4) == 0);
+    hipStream_t st = (hipStream_t)stream;
+    const bool bf = (x_dtype == VQHIP_BF16);
+    switch (DT) {
+        case 32: return bf ? launch_rvq<32, true>(a, st) : launch_rvq<32, false>(a, st);
+        case 64: return bf ? launch_rvq<64, true>(a, st) : launch_rvq<64, false>(a, st);
+        case 128: return bf ? launch_rvq<128, true>(a, st) : launch_rvq<128, false>(a, st);
+        case 256: return bf ? launch_rvq<256, true>(a, st) : launch_rvq<256, false>(a, st);
+        default: return bf ? launch_rvq<512, true>(a, st) : launch_rvq<512, false>(a, st);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // partial reduction (commit loss)
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) vq_reduce_kernel(const double *__restrict__ p, int64_t n, double scale, float *out)

@@ -162,6 +162,83 @@ class ResidualVQ(nn.Module):
             if self.quantize_dropout_multiple_of != 1:
                 drop_at = _round_up(drop_at + 1, self.quantize_dropout_multiple_of) - 1
 
+        if self._fused_eligible(x, mask):
+            quantized_out, all_indices, all_losses = self._forward_fused(x, mask, freeze_codebook, drop_at)
+        else:
+            quantized_out, all_indices, all_losses = self._forward_staged(x, mask, sample_codebook_temp, freeze_codebook, drop_at)
+
+        quantized_out = self.project_out(quantized_out)
+        ret = (quantized_out, all_indices, all_losses)
+        if return_all_codes:
+            ret = (*ret, self.get_codes_from_indices(ret[1]))
+        return ret
+
+    # ---- fused on-device residual loop (csrc: vq_rvq_kernel) -----------------------------------------
+    def _fused_eligible(self, x, mask):
+        vq0 = self.layers[0]
+        cb0 = vq0._codebook
+        if vq0.use_cosine_sim or not self.uniform_codebook_size or self.accept_image_fmap:
+            return False
+        if self.codebook_dim % 32 != 0 or x.ndim != 3 or x.dtype not in (torch.float32, torch.bfloat16):
+            return False
+        if self.training and x.requires_grad and torch.is_grad_enabled() and vq0.route_gradients_to_input:
+            return False            # gradients to the input take the per-stage autograd path
+        if self.quant_grad_frac > 0:
+            return False
+        return all(layer._codebook._is_initted() for layer in self.layers)     # k-means runs in the staged path
+
+    @torch.no_grad()
+    def _forward_fused(self, x, mask, freeze_codebook, drop_at):
+        Q = self.num_quantizers if drop_at is None else drop_at + 1
+        vq0 = self.layers[0]
+        D, C = self.codebook_dim, self.codebook_size
+        train = self.training
+        if self.shared_codebook:
+            embed = vq0._codebook.embed[0]
+            packed = L.pack_codebook(embed)
+        else:
+            embed = torch.stack([layer._codebook.embed[0] for layer in self.layers[:Q]]).contiguous()
+            packed = torch.stack([L.pack_codebook(embed[q]) for q in range(Q)])
+        update = train and not (freeze_codebook or vq0.freeze_codebook) and \
+            (vq0._codebook.ema_update or vq0._codebook.has_dead_code_replacement)
+        want_loss = train and vq0.has_commitment_loss
+        r = L.rvq_forward(x, packed, embed, Q, want_resid=update, want_sqerr=want_loss, row_mask=mask)
+        idx = r["idx"]
+        quantized_out = L.decode_sum(idx, embed, out_dtype=x.dtype)
+
+        losses = torch.zeros(self.num_quantizers, device=x.device, dtype=torch.float32)
+        if want_loss:
+            sums = torch.stack([L.reduce_partials(r["sqerr_partials"][q], 4 * r["nblk"], 1.0) for q in range(Q)])
+            denom = float(x.numel()) if mask is None else (mask.sum() * D).to(torch.float32)
+            losses[:Q] = sums / denom * vq0.commitment_weight
+        if train:
+            losses = torch.zeros(self.num_quantizers, device=x.device, requires_grad=True) + losses   # as vqp.py:1282
+
+        if update:
+            resid = r["resid"]
+            for q in range(Q):
+                cb = self.layers[q]._codebook
+                buf = torch.zeros(C * D + C, dtype=torch.float32, device=x.device)
+                esum, count = buf[: C * D].view(C, D), buf[C * D:]
+                L.ema_accumulate(resid[..., q, :], idx, C, row_mask=mask, count=count, embed_sum=esum,
+                                 idx_offset=q, idx_stride=Q)
+                if cb.use_ddp:
+                    dist.all_reduce(buf)
+                cb._fold_stats(0, count, esum, None, False, cb.ema_update)
+                if not self.shared_codebook:
+                    cb.expire_codes_(resid[..., q, :].reshape(1, -1, D))
+            if self.shared_codebook:                                # rvq.py:593-601
+                if self.vq_is_ema_updating:
+                    vq0._codebook.update_ema()
+                vq0._codebook.expire_codes_(resid.reshape(1, -1, D))
+
+        if Q < self.num_quantizers:
+            pad = torch.full((*idx.shape[:-1], self.num_quantizers - Q), -1, device=x.device, dtype=torch.long)
+            idx = torch.cat((idx, pad), -1)
+        return quantized_out, idx, losses
+
+    # ---- per-stage path: autograd to the input, cosine metric, k-means first step, ragged sizes --------
+    def _forward_staged(self, x, mask, sample_codebook_temp, freeze_codebook, drop_at):
         quantized_out = torch.zeros_like(x)
         residual = x
         all_idx, all_loss, stage_inputs = [], [], []
@@ -192,12 +269,7 @@ class ResidualVQ(nn.Module):
                 if self.accept_image_fmap:
                     stacked = torch.stack([s.flatten(2).transpose(1, 2) for s in stage_inputs], -2)
                 shared.expire_codes_(stacked.reshape(stacked.shape[0], -1, stacked.shape[-1]))
-
-        quantized_out = self.project_out(quantized_out)
-        ret = (quantized_out, torch.stack(all_idx, -1), torch.stack(all_loss))
-        if return_all_codes:
-            ret = (*ret, self.get_codes_from_indices(ret[1]))
-        return ret
+        return quantized_out, torch.stack(all_idx, -1), torch.stack(all_loss)
 
 
 class GroupedResidualVQ(nn.Module):
