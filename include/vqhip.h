@@ -89,6 +89,21 @@ int vqhip_rvq_forward(const void *x, int x_dtype, int64_t N, int D, int64_t ldx,
                       int C, int Q, int64_t *idx_out, void *resid_out, double *sqerr_partial,
                       const uint8_t *row_mask, void *stream);
 
+/* ---- gradient routing through the quantizer ----------------------------------------------------
+ * Replaces straight_through (vqp.py:282-283) and rotate_to / efficient_rotation_trick_transform
+ * (vqp.py:287-318) and the backward of F.mse_loss(quantize.detach(), x) (vqp.py:1327).
+ *  mode 1 = straight-through, mode 2 = rotation trick.  x, q, g_out, out, grad_x: [N, D] rows, one dtype.
+ *  vqhip_route_fwd : out = x + (q - x)                      (mode 1)
+ *                    out = |q|/|x| (x - 2 (x.w) w + 2 (x.u) qh)   (mode 2; u, qh, w as in the reference)
+ *  vqhip_route_bwd : grad_x = J^T g_out (J of the mode; mode 0 = no g_out term)
+ *                             + 2 * (*loss_coef) * (x - q) on rows with row_mask != 0  (loss_coef nullable,
+ *                             a DEVICE scalar = d loss / d sum_of_squares) */
+int vqhip_route_fwd(const void *x, const void *q, int dtype, int64_t N, int D, int64_t ldx, int64_t ldq,
+                    void *out, int64_t ldo, int mode, void *stream);
+int vqhip_route_bwd(const void *x, const void *q, const void *g_out, int dtype, int64_t N, int D,
+                    int64_t ldx, int64_t ldq, int64_t ldg, const float *loss_coef, const uint8_t *row_mask,
+                    int mode, void *grad_x, int64_t ldo, void *stream);
+
 /* sum of `n` doubles times `scale` -> one fp32 (commit loss = scale * sum of partials). */
 int vqhip_reduce_partials(const double *partials, int64_t n, double scale, float *out, void *stream);
 

@@ -261,3 +261,66 @@ def test_errors_are_loud(dev):
     vq = vq.to(dev)
     q, idx, loss = vq(torch.randn(0, 8, 64, device=dev))   # empty batch
     assert q.shape == (0, 8, 64) and idx.shape == (0, 8)
+
+
+# ---- gradient-routing kernels and the codebook-sharded path ----------------------------------------
+@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_route_kernels_match_autograd_of_the_reference_formula(dev, mode, dtype):
+    from vector_quantize_pytorch_amd import _lib as L
+    g = torch.Generator().manual_seed(3)
+    N, D = 257, 192
+    x = torch.randn(N, D, generator=g).to(dtype)
+    q = torch.randn(N, D, generator=g).to(dtype)
+    go = torch.randn(N, D, generator=g).to(dtype)
+    m = torch.rand(N, generator=g) < 0.7
+    coef = torch.tensor(0.37)
+    xr = x.float().clone().requires_grad_(True)
+    ref = O.rotate_to(xr, q.float()) if mode == 2 else xr + (q.float() - xr).detach()
+    lsum = (((q.float() - xr) ** 2).sum(-1) * m).sum()
+    (ref * go.float()).sum().backward(retain_graph=True)
+    (lsum * coef).backward()
+    out = L.route_fwd(x.to(dev), q.to(dev), mode)
+    gx = L.route_bwd(x.to(dev), q.to(dev), go.to(dev), coef.to(dev), m.to(dev), mode)
+    tol = 1e-5 if dtype == torch.float32 else 2e-2
+    _close(out.float(), ref.detach(), tol, "routed forward")
+    _close(gx.float(), xr.grad, tol, "grad_x")
+
+
+def _sharded_worker(rank, world, port, out_path, cosine):
+    import os
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)       # 2 ranks on the ONE test GPU: gloo moves cuda tensors
+    from vector_quantize_pytorch_amd.parallel import ShardedVectorQuantize
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    vq = ShardedVectorQuantize(64, 200, use_cosine_sim=cosine).to(dev).train()
+    g = torch.Generator().manual_seed(100 + rank)
+    x = torch.randn(2, 300, 64, generator=g).to(dev)
+    q, idx, loss = vq(x)
+    torch.save(dict(q=q.cpu(), idx=idx.cpu(), loss=loss.cpu(), embed=vq._codebook.embed.cpu(), lo=vq.lo, hi=vq.hi), f"{out_path}.{rank}")
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("cosine", [False, True])
+def test_sharded_codebook_equals_unsharded(dev, tmp_path, cosine):
+    """2 ranks x half the codebook each == one VectorQuantize with the full codebook on the concatenated rows."""
+    import socket
+    import torch.multiprocessing as mp
+    from vector_quantize_pytorch_amd import VectorQuantize
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    out = str(tmp_path / "sh")
+    mp.spawn(_sharded_worker, args=(2, port, out, cosine), nprocs=2, join=True)
+    r = [torch.load(f"{out}.{k}") for k in range(2)]
+    torch.manual_seed(0)
+    vq = VectorQuantize(dim=64, codebook_size=200, use_cosine_sim=cosine).to(dev).train()
+    xs = [torch.randn(2, 300, 64, generator=torch.Generator().manual_seed(100 + k)) for k in range(2)]
+    x = torch.cat(xs, 0).to(dev)
+    q, idx, loss = vq(x)
+    for k in range(2):
+        assert torch.equal(r[k]["idx"], idx[2 * k:2 * k + 2].cpu())
+        _close(r[k]["q"], q[2 * k:2 * k + 2], 1e-6, "quantized")
+    _close(torch.stack([r[0]["loss"], r[1]["loss"]]).mean(), loss, 1e-5, "loss")
+    full = torch.cat([r[0]["embed"], r[1]["embed"]], 1)
+    _close(full, vq._codebook.embed, 1e-5, "embed after the EMA step")

@@ -47,6 +47,10 @@ def lib():
     L.vqhip_reduce_partials.argtypes = [vp, i64, f64, vp, vp]
     L.vqhip_rvq_forward.argtypes = [vp, i32, i64, i32, i64, vp, i64, vp, i64, i32, i32, vp, vp, vp, vp, vp]
     L.vqhip_rvq_forward.restype = i32
+    L.vqhip_route_fwd.argtypes = [vp, vp, i32, i64, i32, i64, i64, vp, i64, i32, vp]
+    L.vqhip_route_bwd.argtypes = [vp, vp, vp, i32, i64, i32, i64, i64, i64, vp, vp, i32, vp, i64, vp]
+    L.vqhip_route_fwd.restype = i32
+    L.vqhip_route_bwd.restype = i32
     L.vqhip_ema_workspace_bytes.restype = ctypes.c_size_t
     L.vqhip_ema_workspace_bytes.argtypes = [i64, i32]
     L.vqhip_ema_accumulate.argtypes = [vp, i32, i64, i32, i64, vp, i64, vp, i32, vp, i32, vp, vp, vp, ctypes.c_size_t, vp]
@@ -54,7 +58,7 @@ def lib():
     L.vqhip_decode_sum.argtypes = [vp, i64, i32, vp, i64, i32, i32, vp, i32, i64, vp]
     L.vqhip_row_sumsq.argtypes = [vp, i32, i64, i32, i64, vp, vp]
     for name in ("vqhip_pack_codebook", "vqhip_assign", "vqhip_reduce_partials", "vqhip_ema_accumulate",
-                 "vqhip_ema_finalize", "vqhip_decode_sum", "vqhip_row_sumsq"):
+                 "vqhip_ema_finalize", "vqhip_decode_sum", "vqhip_row_sumsq", "vqhip_route_fwd", "vqhip_route_bwd"):
         getattr(L, name).restype = i32
     _lib = L
     return L
@@ -62,7 +66,7 @@ def lib():
 
 EXPORTS = ("vqhip_version", "vqhip_last_error", "vqhip_packed_bytes", "vqhip_pack_codebook",
            "vqhip_assign_blocks", "vqhip_assign", "vqhip_rvq_forward", "vqhip_reduce_partials", "vqhip_ema_workspace_bytes", "vqhip_ema_accumulate",
-           "vqhip_ema_finalize", "vqhip_decode_sum", "vqhip_row_sumsq")
+           "vqhip_ema_finalize", "vqhip_decode_sum", "vqhip_row_sumsq", "vqhip_route_fwd", "vqhip_route_bwd")
 
 
 def _check(rc, what):
@@ -190,6 +194,41 @@ def rvq_forward(x: torch.Tensor, packed: torch.Tensor, embed: torch.Tensor, Q: i
                                        _ptr(idx), _ptr(resid), _ptr(partials), _ptr(row_mask), _stream()),
                "vqhip_rvq_forward")
     return dict(idx=idx, resid=resid, sqerr_partials=partials, nblk=nblk)
+
+
+STRAIGHT_THROUGH, ROTATION = 1, 2
+
+
+def route_fwd(x: torch.Tensor, q: torch.Tensor, mode: int) -> torch.Tensor:
+    """forward value of straight-through (mode 1) / the rotation trick (mode 2), rows = last dim."""
+    _need_gpu(x, q)
+    assert x.dtype == q.dtype and x.shape == q.shape
+    xk, N, D, ldx = as_rows(x)
+    qk, _, _, ldq = as_rows(q)
+    out = torch.empty(x.shape, dtype=x.dtype, device=x.device)
+    if N > 0:
+        _check(lib().vqhip_route_fwd(_ptr(xk), _ptr(qk), _dtype_code(xk), N, D, ldx, ldq, _ptr(out), D, mode, _stream()),
+               "vqhip_route_fwd")
+    return out
+
+
+def route_bwd(x: torch.Tensor, q: torch.Tensor, g_out, loss_coef, row_mask, mode: int) -> torch.Tensor:
+    """grad wrt x of (routed output, commit-loss sum); g_out may be None (mode 0), loss_coef a 0-dim fp32 device tensor or None."""
+    _need_gpu(x, q, g_out, loss_coef, row_mask)
+    xk, N, D, ldx = as_rows(x)
+    qk, _, _, ldq = as_rows(q)
+    gk, ldg = None, 0
+    if g_out is not None and mode != 0:
+        gk, _, _, ldg = as_rows(g_out.to(x.dtype))
+    if loss_coef is not None:
+        loss_coef = loss_coef.to(torch.float32).reshape(()).contiguous()
+    if row_mask is not None:
+        row_mask = row_mask.reshape(-1).to(torch.uint8).contiguous()
+    gx = torch.empty(x.shape, dtype=x.dtype, device=x.device)
+    if N > 0:
+        _check(lib().vqhip_route_bwd(_ptr(xk), _ptr(qk), _ptr(gk), _dtype_code(xk), N, D, ldx, ldq, ldg, _ptr(loss_coef),
+                                     _ptr(row_mask), mode if gk is not None else 0, _ptr(gx), D, _stream()), "vqhip_route_bwd")
+    return gx
 
 
 def reduce_partials(partials: torch.Tensor, n: int, scale: float, out: torch.Tensor | None = None) -> torch.Tensor:

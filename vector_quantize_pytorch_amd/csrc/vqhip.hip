@@ -885,6 +885,143 @@ extern "C" int vqhip_rvq_forward(const void *x, int x_dtype, int64_t N, int D, i
 }
 
 // ------------------------------------------------------------------------------------------------
+// gradient routing through the quantizer (one wave per row, rows independent)
+//   mode 1  straight-through (vqp.py:282-283):  out = x + (q - x);            d out / d x = I
+//   mode 2  rotation trick (vqp.py:287-318, arXiv:2410.06424 s4.2), u, qh, w, s all detached:
+//           out = s (e - 2 (e.w) w + 2 (e.u) qh),   u = e/|e|, qh = q/|q|, w = l2norm(u + qh), s = |q|/|e|
+//           grad_e = s (g - 2 (g.w) w + 2 (g.qh) u)
+//   commit loss mean((q.detach() - x)^2) (vqp.py:1327): grad_x += coef * 2 (x - q), coef = dL/d(sum of squares),
+//   a DEVICE scalar (no host sync), rows with row_mask == 0 excluded.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v)
+{
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+struct RouteArgs {
+    const void *x;
+    const void *q;
+    const void *g;          // backward only, nullable
+    void *out;              // forward: out; backward: grad_x
+    int64_t N;
+    int D;
+    int64_t ldx, ldq, ldg, ldo;
+    const float *loss_coef; // backward only, nullable device scalar
+    const uint8_t *row_mask;
+    int mode;
+};
+
+template <bool BF16, bool BWD>
+__global__ void __launch_bounds__(256) vq_route_kernel(const RouteArgs a)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t n = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= a.N) return;
+    float e[8], qv[8], g[8];
+    float se = 0.f, sq = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int d = lane + 64 * k;
+        e[k] = qv[k] = g[k] = 0.f;
+        if (d < a.D) {
+            e[k] = load_elem<BF16>(a.x, n * a.ldx + d);
+            qv[k] = load_elem<BF16>(a.q, n * a.ldq + d);
+            if (BWD && a.g) g[k] = load_elem<BF16>(a.g, n * a.ldg + d);
+        }
+        se += e[k] * e[k];
+        sq += qv[k] * qv[k];
+    }
+    float r[8];
+    if (a.mode == 2) {
+        const float ne = sqrtf(wave_sum(se)), nq = sqrtf(wave_sum(sq));
+        const float de = fmaxf(ne, 1e-6f), dq = fmaxf(nq, 1e-6f);
+        float u[8], qh[8], w[8];
+        float st = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            u[k] = e[k] / de;
+            qh[k] = qv[k] / dq;
+            w[k] = u[k] + qh[k];
+            st += w[k] * w[k];
+        }
+        const float nt = fmaxf(sqrtf(wave_sum(st)), 1e-6f);
+        float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            w[k] = w[k] / nt;
+            if (BWD) { a1 += g[k] * w[k]; a2 += g[k] * qh[k]; }
+            else     { a1 += e[k] * w[k]; a2 += e[k] * u[k]; }
+        }
+        a1 = wave_sum(a1);
+        a2 = wave_sum(a2);
+        const float sc = nq / de;
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            r[k] = BWD ? sc * (g[k] - 2.f * a1 * w[k] + 2.f * a2 * u[k]) : (e[k] - 2.f * a1 * w[k] + 2.f * a2 * qh[k]) * sc;
+    } else {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) r[k] = BWD ? g[k] : (e[k] + (qv[k] - e[k]));
+    }
+    if (BWD && a.loss_coef) {
+        const bool counted = !a.row_mask || a.row_mask[n] != 0;
+        const float c2 = counted ? 2.f * (*a.loss_coef) : 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) r[k] += c2 * (e[k] - qv[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int d = lane + 64 * k;
+        if (d < a.D) {
+            if (BF16) ((unsigned short *)a.out)[n * a.ldo + d] = f32_to_bf16_rne(r[k]);
+            else ((float *)a.out)[n * a.ldo + d] = r[k];
+        }
+    }
+}
+
+static int route_launch(const RouteArgs &a, int dtype, bool bwd, hipStream_t st)
+{
+    if (a.N == 0) return 0;
+    dim3 grid((unsigned)((a.N + 3) / 4));
+    if (dtype == VQHIP_BF16) {
+        if (bwd) hipLaunchKernelGGL((vq_route_kernel<true, true>), grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((vq_route_kernel<true, false>), grid, dim3(256), 0, st, a);
+    } else {
+        if (bwd) hipLaunchKernelGGL((vq_route_kernel<false, true>), grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((vq_route_kernel<false, false>), grid, dim3(256), 0, st, a);
+    }
+    return launch_status("vq_route_kernel");
+}
+
+extern "C" int vqhip_route_fwd(const void *x, const void *q, int dtype, int64_t N, int D, int64_t ldx, int64_t ldq,
+                               void *out, int64_t ldo, int mode, void *stream)
+{
+    if (N < 0 || !x || !q || !out) VQ_FAIL(VQHIP_EINVAL, "route_fwd: bad argument");
+    if (D < 1 || D > 512) VQ_FAIL(VQHIP_EDIM, "route_fwd: D=%d unsupported (1..512)", D);
+    if (mode != 1 && mode != 2) VQ_FAIL(VQHIP_EINVAL, "route_fwd: mode must be 1 (straight-through) or 2 (rotation trick)");
+    if (dtype != VQHIP_F32 && dtype != VQHIP_BF16) VQ_FAIL(VQHIP_EINVAL, "route_fwd: unknown dtype");
+    RouteArgs a;
+    a.x = x; a.q = q; a.g = nullptr; a.out = out; a.N = N; a.D = D; a.ldx = ldx; a.ldq = ldq; a.ldg = 0; a.ldo = ldo;
+    a.loss_coef = nullptr; a.row_mask = nullptr; a.mode = mode;
+    return route_launch(a, dtype, false, (hipStream_t)stream);
+}
+
+extern "C" int vqhip_route_bwd(const void *x, const void *q, const void *g_out, int dtype, int64_t N, int D,
+                               int64_t ldx, int64_t ldq, int64_t ldg, const float *loss_coef, const uint8_t *row_mask,
+                               int mode, void *grad_x, int64_t ldo, void *stream)
+{
+    if (N < 0 || !x || !q || !grad_x) VQ_FAIL(VQHIP_EINVAL, "route_bwd: bad argument");
+    if (D < 1 || D > 512) VQ_FAIL(VQHIP_EDIM, "route_bwd: D=%d unsupported (1..512)", D);
+    if (mode < 0 || mode > 2) VQ_FAIL(VQHIP_EINVAL, "route_bwd: mode must be 0 (loss only), 1 or 2");
+    if (dtype != VQHIP_F32 && dtype != VQHIP_BF16) VQ_FAIL(VQHIP_EINVAL, "route_bwd: unknown dtype");
+    RouteArgs a;
+    a.x = x; a.q = q; a.g = (mode == 0) ? nullptr : g_out; a.out = grad_x; a.N = N; a.D = D; a.ldx = ldx; a.ldq = ldq;
+    a.ldg = ldg; a.ldo = ldo; a.loss_coef = loss_coef; a.row_mask = row_mask; a.mode = (mode == 0) ? 1 : mode;
+    return route_launch(a, dtype, true, (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------------------------------------
 // partial reduction (commit loss)
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) vq_reduce_kernel(const double *__restrict__ p, int64_t n, double scale, float *out)

@@ -60,3 +60,98 @@ def fused_stats_allreduce(embed_sum: torch.Tensor, count: torch.Tensor, group=No
     assert count.untyped_storage().data_ptr() == base, "embed_sum and count must share one buffer"
     flat = torch.as_strided(embed_sum, (embed_sum.numel() + count.numel(),), (1,), embed_sum.storage_offset())
     dist.all_reduce(flat, group=group)
+
+
+# ------------------------------------------------------------------------------------------------------
+# codebook-sharded VectorQuantize (BASELINE config 4: C = 65536, D = 512 over the 8 GPUs of one node)
+# ------------------------------------------------------------------------------------------------------
+class ShardedVectorQuantize(torch.nn.Module):
+    """Nearest-code search against a codebook partitioned over the ranks of `group` (new capability; the
+    reference only replicates codebooks).  Rank p owns codes [lo_p, hi_p) (`shard_bounds`).
+
+    forward(x): x [b, n, d] holds THIS rank's rows.  With `gather_input=True` (default) the rows of all
+    ranks are all-gathered, every rank scores all rows against its shard (vqhip_assign), ONE
+    all_reduce(MAX) of the packed int64 keys picks the global winner with the reference's tie rule, each
+    rank decodes the winners it owns and a reduce-scatter(SUM) hands every rank the quantized rows it
+    contributed.  EMA needs no collective for the sums: the owner of a code sees every row assigned to it;
+    only the scalar sum(cluster_size) of the Laplace smoothing (vqp.py:577) is all-reduced.
+    Returns (quantized [b, n, d], global indices [b, n], commit_loss) like VectorQuantize."""
+
+    def __init__(self, dim, codebook_size, *, use_cosine_sim=False, decay=0.8, eps=1e-5, commitment_weight=1.,
+                 group=None, gather_input=True):
+        super().__init__()
+        from .codebook import Codebook
+        self.group = group
+        on = dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size(group) if on else 1
+        self.rank = dist.get_rank(group) if on else 0
+        self.dim, self.codebook_size = dim, codebook_size
+        self.lo, self.hi = shard_bounds(codebook_size, self.world, self.rank)
+        self.use_cosine_sim, self.decay, self.eps = use_cosine_sim, decay, eps
+        self.commitment_weight = commitment_weight
+        self.gather_input = gather_input
+        # identical RNG consumption on every rank: build the full codebook, keep the shard
+        full = Codebook(dim=dim, codebook_size=codebook_size, use_cosine_sim=use_cosine_sim, decay=decay, eps=eps,
+                        threshold_ema_dead_code=0, manual_ema_update=True)
+        self._codebook = Codebook(dim=dim, codebook_size=self.hi - self.lo, use_cosine_sim=use_cosine_sim, decay=decay,
+                                  eps=eps, threshold_ema_dead_code=0, manual_ema_update=True)
+        with torch.no_grad():
+            self._codebook.embed.copy_(full.embed[:, self.lo:self.hi])
+            self._codebook.embed_avg.copy_(full.embed_avg[:, self.lo:self.hi])
+
+    def _collectives_on(self):
+        return self.world > 1
+
+    @torch.no_grad()
+    def forward(self, x):
+        from . import _lib as L
+        cb = self._codebook
+        b, n, d = x.shape
+        rows = x.reshape(-1, d)
+        if self._collectives_on() and self.gather_input:
+            allrows = torch.empty(self.world * rows.shape[0], d, dtype=x.dtype, device=x.device)
+            dist.all_gather_into_tensor(allrows, rows.contiguous(), group=self.group)
+        else:
+            allrows = rows
+        e = cb.embed[0]
+        r = L.assign(allrows, L.pack_codebook(e), e, cosine=self.use_cosine_sim, want_q=False, want_best=True,
+                     want_rnorm=self.use_cosine_sim)
+        gidx, _ = merge_sharded_argmin(r["best"], r["idx"], self.lo, euclid=not self.use_cosine_sim, group=self.group)
+        mine = (gidx >= self.lo) & (gidx < self.hi)
+        local = torch.where(mine, gidx - self.lo, torch.full_like(gidx, -1))
+        q_part = L.decode_sum(local[:, None].contiguous(), e, out_dtype=torch.float32)      # zeros where another rank owns the winner
+        n_local = rows.shape[0]
+        if self._collectives_on():
+            if self.gather_input:
+                backend = dist.get_backend(self.group)
+                if backend == "nccl":
+                    q_rows = torch.empty(n_local, d, dtype=torch.float32, device=x.device)
+                    dist.reduce_scatter_tensor(q_rows, q_part, group=self.group)
+                else:       # gloo (CPU-side tests): no reduce-scatter
+                    dist.all_reduce(q_part, group=self.group)
+                    q_rows = q_part[self.rank * n_local:(self.rank + 1) * n_local]
+                idx_rows = gidx[self.rank * n_local:(self.rank + 1) * n_local]
+            else:
+                dist.all_reduce(q_part, group=self.group)
+                q_rows, idx_rows = q_part, gidx
+        else:
+            q_rows, idx_rows = q_part, gidx
+        q_rows = q_rows.to(x.dtype)
+
+        loss = torch.zeros((), device=x.device)
+        if self.training:
+            xin = torch.nn.functional.normalize(rows.float(), dim=-1, eps=1e-6) if self.use_cosine_sim else rows.float()
+            loss = ((q_rows.float() - xin) ** 2).mean() * self.commitment_weight
+            # EMA on the owner: all rows, indices of foreign winners masked to -1 (skipped by the kernel)
+            C = self.hi - self.lo
+            count, esum = L.ema_accumulate(allrows, local.contiguous(), C, cosine=self.use_cosine_sim, rnorm=r["rnorm"])
+            cb._fold_stats(0, count, esum, None, False, True)        # lerp only (manual_ema_update)
+            total = cb.cluster_size.sum()
+            if self._collectives_on():
+                dist.all_reduce(total, group=self.group)
+            smoothed = (cb.cluster_size + self.eps) / (total + self.codebook_size * self.eps) * total
+            new = cb.embed_avg / smoothed[..., None]
+            if self.use_cosine_sim:
+                new = torch.nn.functional.normalize(new, dim=-1, eps=1e-6)
+            cb.embed.copy_(new)
+        return q_rows.reshape(b, n, d), idx_rows.reshape(b, n), loss

@@ -28,31 +28,17 @@ def _is_distributed():
     return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
 
 
-def _rot_fwd(x, q):
-    """Forward value of the rotation trick (vqp.py:287-318, arXiv:2410.06424 §4.2), rows independent:
-    out = s (e - 2 (e.w) w + 2 (e.u) qh),  u = e/|e|, qh = q/|q|, w = l2norm(u + qh), s = |q|/|e|."""
-    e = x.float()
-    qf = q.float()
-    ne = e.norm(dim=-1, keepdim=True).clamp(min=1e-6)
-    nq = qf.norm(dim=-1, keepdim=True)
-    u = e / ne
-    qh = qf / nq.clamp(min=1e-6)
-    w = F.normalize(u + qh, p=2, dim=-1, eps=1e-6)
-    out = e - 2 * (e * w).sum(-1, keepdim=True) * w + 2 * (e * u).sum(-1, keepdim=True) * qh
-    return out * (nq / ne), (u, qh, w, nq / ne)
-
-
 class _QuantizeFn(torch.autograd.Function):
-    """Forward = HIP assign/gather/EMA; backward = closed-form gradients of the reference's graph:
+    """Forward = HIP assign/gather/EMA (+ vq_route_kernel for the routed value); backward = vq_route_kernel,
+    the closed-form gradients of the reference's graph:
       commit loss   mean((q.detach() - x)^2)              -> 2 (x - q) / count        (vqp.py:1327)
       straight-through x + (q - x).detach()               -> g                        (vqp.py:282-283)
       rotation trick (all of u, qh, w, s detached)        -> s (g - 2 (g.w) w + 2 (g.qh) u)   (vqp.py:287-318)
-    """
+    Only x and q are saved; u, qh, w, s are recomputed in the backward kernel."""
 
     @staticmethod
     def forward(ctx, x, vq, mask, kw):
         cb = vq._codebook
-        N_rows = x.numel() // x.shape[-1]
         r = cb.quantize(x, mask=mask, want_sqerr=vq.training and vq.has_commitment_loss, **kw)
         q, idx = r["q"], r["idx"]
         loss_sum = None
@@ -60,19 +46,12 @@ class _QuantizeFn(torch.autograd.Function):
             loss_sum = L.reduce_partials(r["sqerr_partials"], r["nblk"], 1.0)
         out = q
         mode = 0
-        saved = []
         if vq.training and x.requires_grad and vq.route_gradients_to_input:
-            if vq.rotation_trick:
-                mode = 2
-                out32, (u, qh, w, s) = _rot_fwd(x, q)
-                out = out32.to(x.dtype)
-                saved = [u, qh, w, s]
-            else:
-                mode = 1
-                out = x + (q - x)
+            mode = L.ROTATION if vq.rotation_trick else L.STRAIGHT_THROUGH
+            out = L.route_fwd(x, q, mode)
         ctx.mode = mode
         ctx.has_mask = mask is not None
-        ctx.save_for_backward(x, q, *( [mask] if mask is not None else []), *saved)
+        ctx.save_for_backward(x, q, *([mask] if mask is not None else []))
         ctx.mark_non_differentiable(idx)
         if loss_sum is None:
             loss_sum = torch.zeros((), dtype=torch.float32, device=x.device)
@@ -80,26 +59,14 @@ class _QuantizeFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_out, g_idx, g_loss):
-        tensors = list(ctx.saved_tensors)
+        tensors = ctx.saved_tensors
         x, q = tensors[0], tensors[1]
-        pos = 2
-        mask = None
-        if ctx.has_mask:
-            mask = tensors[pos]
-            pos += 1
-        gx = None
-        if ctx.mode == 1 and g_out is not None:
-            gx = g_out.float()
-        elif ctx.mode == 2 and g_out is not None:
-            u, qh, w, s = tensors[pos:pos + 4]
-            g = g_out.float()
-            gx = s * (g - 2 * (g * w).sum(-1, keepdim=True) * w + 2 * (g * qh).sum(-1, keepdim=True) * u)
-        if g_loss is not None:
-            gl = (2.0 * g_loss) * (x.float() - q.float())      # d/dx sum (q - x)^2 ; the caller divides by the count
-            if mask is not None:
-                gl = gl * mask[..., None]
-            gx = gl if gx is None else gx + gl
-        return (None if gx is None else gx.to(x.dtype)), None, None, None
+        mask = tensors[2] if ctx.has_mask else None
+        use_g = ctx.mode != 0 and g_out is not None
+        if not use_g and g_loss is None:
+            return None, None, None, None
+        gx = L.route_bwd(x, q, g_out.contiguous() if use_g else None, g_loss, mask, ctx.mode if use_g else 0)
+        return gx, None, None, None
 
 
 class VectorQuantize(nn.Module):
