@@ -136,6 +136,11 @@ if __name__ == "__main__":
     run_case("vq_expire", VectorQuantize, dict(dim=32, codebook_size=128, threshold_ema_dead_code=2), [randn(1, 256, 32, seed=13), randn(1, 256, 32, seed=14)],
              unit_codebook=True, deterministic_sampling=True)
     run_case("vq_fmap", VectorQuantize, dict(dim=32, codebook_size=64, accept_image_fmap=True), [randn(2, 32, 8, 8, seed=15)], unit_codebook=True)
+    run_case("vq_heads", VectorQuantize, dict(dim=64, codebook_size=64, heads=4, codebook_dim=16), [randn(2, 60, 64, seed=30)], unit_codebook=True)
+    run_case("vq_heads_sep", VectorQuantize, dict(dim=64, codebook_size=64, heads=4, codebook_dim=16, separate_codebook_per_head=True),
+             [randn(2, 60, 64, seed=31)], unit_codebook=True)
+    run_case("vq_3d", VectorQuantize, dict(dim=32, codebook_size=64, accept_3d_fmap=True), [randn(1, 32, 4, 4, 4, seed=32)], unit_codebook=True)
+    run_case("vq_channel_first", VectorQuantize, dict(dim=32, codebook_size=64, channel_last=False), [randn(2, 32, 50, seed=33)], unit_codebook=True)
     run_case("vq_proj", VectorQuantize, dict(dim=48, codebook_size=64, codebook_dim=16), [randn(2, 50, 48, seed=16)], unit_codebook=True)
     # cfg 3: ResidualVQ shared codebook, scaled down
     run_case("rvq_shared", ResidualVQ, dict(dim=256, num_quantizers=8, codebook_size=256, shared_codebook=True), [randn(2, 128, 256, seed=17), randn(2, 128, 256, seed=18)])
