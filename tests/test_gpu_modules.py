@@ -324,3 +324,41 @@ def test_sharded_codebook_equals_unsharded(dev, tmp_path, cosine):
     _close(torch.stack([r[0]["loss"], r[1]["loss"]]).mean(), loss, 1e-5, "loss")
     full = torch.cat([r[0]["embed"], r[1]["embed"]], 1)
     _close(full, vq._codebook.embed, 1e-5, "embed after the EMA step")
+
+
+def _dp_worker(rank, world, port, out_path):
+    import os
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)       # 2 ranks sharing the one test GPU
+    from vector_quantize_pytorch_amd import VectorQuantize
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    vq = VectorQuantize(dim=64, codebook_size=128, sync_codebook=True).to(dev).train()
+    assert vq._codebook.use_ddp
+    x = torch.randn(2, 500, 64, generator=torch.Generator().manual_seed(200 + rank)).to(dev)
+    for _ in range(2):
+        q, idx, loss = vq(x)
+    torch.save(dict(idx=idx.cpu(), embed=vq._codebook.embed.cpu(), cs=vq._codebook.cluster_size.cpu()), f"{out_path}.{rank}")
+    dist.destroy_process_group()
+
+
+def test_data_parallel_stat_sync_equals_single_process(dev, tmp_path):
+    """row-sharded data parallel (SURVEY §8e scheme 1): 2 ranks, one all-reduce of the fused statistics per
+    step == one process on the concatenated batch (the reference offers no harness for this)."""
+    import socket
+    import torch.multiprocessing as mp
+    from vector_quantize_pytorch_amd import VectorQuantize
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    out = str(tmp_path / "dp")
+    mp.spawn(_dp_worker, args=(2, port, out), nprocs=2, join=True)
+    r = [torch.load(f"{out}.{k}") for k in range(2)]
+    torch.manual_seed(0)
+    vq = VectorQuantize(dim=64, codebook_size=128, sync_codebook=False).to(dev).train()
+    x = torch.cat([torch.randn(2, 500, 64, generator=torch.Generator().manual_seed(200 + k)) for k in range(2)], 0).to(dev)
+    for _ in range(2):
+        q, idx, loss = vq(x)
+    assert torch.equal(r[0]["embed"], r[1]["embed"])                      # replicas stay identical
+    assert torch.equal(torch.cat([r[0]["idx"], r[1]["idx"]], 0), idx.cpu())
+    _close(r[0]["embed"], vq._codebook.embed, 1e-5, "embed")
+    _close(r[0]["cs"], vq._codebook.cluster_size, 1e-6, "cluster_size")
