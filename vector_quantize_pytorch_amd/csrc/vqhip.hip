@@ -5,8 +5,8 @@
 //
 //   vq_pack_kernel      codebook -> MFMA A-operand tiles (+ ||c||^2 in ATen's summation order)
 //   vq_assign_kernel    x rows stay resident in VGPRs as the MFMA B operand for the whole codebook
-//                       sweep; codebook tiles are streamed L2 -> LDS by LDS-DMA (global_load_lds),
-//                       double buffered; v_mfma_f32_32x32x2_f32 computes code x row score tiles with
+//                       sweep; codebook tiles are streamed L2 -> LDS (register-staged, interleaved with the
+//                       MFMAs), double buffered; v_mfma_f32_32x32x2_f32 computes code x row score tiles with
 //                       the CODE index on the accumulator-register axis, so the per-row argmin is
 //                       lane-local (no cross-lane reduce inside the sweep) and the N x C distance
 //                       matrix is never written; gather + squared-error partials in the epilogue.
@@ -30,8 +30,6 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
-#define AS1 __attribute__((address_space(1)))
-#define AS3 __attribute__((address_space(3)))
 
 static thread_local char g_err[256] = "";
 #define VQ_FAIL(code, ...)                           \
@@ -135,7 +133,7 @@ extern "C" size_t vqhip_packed_bytes(int C, int D)
     const int DT = pick_dt(D);
     if (DT == 0 || C <= 0) return 0;
     const size_t tiles = ((size_t)C + 31) / 32;
-    return tiles * ((size_t)32 * DT + 256) * sizeof(float);
+    return tiles * ((size_t)32 * DT + 256) * sizeof(float) + 4096;   // + tail pad: the staged copy over-reads <= 3 KiB
 }
 
 __global__ void __launch_bounds__(256) vq_pack_kernel(const float *__restrict__ embed, int C, int D, int DT,
@@ -183,6 +181,129 @@ extern "C" int vqhip_pack_codebook(const float *embed, int C, int D, float *pack
 // ------------------------------------------------------------------------------------------------
 // assignment
 // ------------------------------------------------------------------------------------------------
+// The DT/2 MFMAs of one 32-code tile, with the copy of the NEXT tile (L2 -> LDS) interleaved.
+// The copy is register-staged in 3 batches: `gsrc` / `ldst` point at this lane's 16 bytes of piece 0 of the next
+// tile (global / LDS); piece k of this wave is 4 KiB further (waves interleave 1-KiB pieces).  Loads of a batch
+// are issued behind one MFMA, the ds_write_b128s a few MFMA groups later when the data has arrived.
+// Why not LDS-DMA (global_load_lds) as in the first version: each glds kept the issuing wave busy ~270 cycles
+// (9 per tile = 2.4k cycles per wave and tile, tools/ablate.py), and because a wave's MFMAs form ONE dependent
+// chain nothing of that hides behind its own MFMAs; a global_load + ds_write pair costs the wave ~30 cycles.
+template <int DT>
+__device__ __forceinline__ void mfma_sweep_tile(const f32x4 *ap, const float (&xr)[DT / 2], f32x16 &acc,
+                                                const char *gsrc, char *ldst, int npieces)
+{
+    constexpr int NG = DT / 8;
+    constexpr int NCHUNK = (32 * DT + 256) * 4 / 1024;
+    constexpr int PMAX = (NCHUNK + 3) / 4;              // pieces per wave (wave 0 may own one more than wave 3)
+    constexpr int NB = (NG >= 12) ? 3 : ((NG >= 4) ? 2 : 1);   // batches
+    constexpr int BS = (PMAX + NB - 1) / NB;            // pieces per batch
+    constexpr int SP = (NG * 3 / 4) / NB > 0 ? (NG * 3 / 4) / NB : 1;   // t4 steps between batch starts
+    constexpr int LAG = (SP * 2 / 3) > 0 ? (SP * 2 / 3) : 1;            // t4 steps between a batch's loads and its stores
+    f32x4 stg[BS];
+#pragma unroll
+    for (int t4 = 0; t4 < NG; ++t4) {
+        const f32x4 av = ap[t4 * 64];
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, xr[4 * t4 + 0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, xr[4 * t4 + 2], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, xr[4 * t4 + 1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, xr[4 * t4 + 3], acc, 0, 0, 0);
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            if (t4 == b * SP) {
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < BS; ++i)   // UNCONDITIONAL (a guarded load makes hipcc wait vmcnt(0) right behind it);
+                    if (b * BS + i < PMAX)     // a piece beyond this wave's share reads into the 4 KiB tail pad at worst
+                        stg[i] = *(const f32x4 *)(gsrc + (size_t)(b * BS + i) * 4096);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (t4 == b * SP + LAG) {
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < BS; ++i)
+                    if (b * BS + i < npieces) *(f32x4 *)(ldst + (b * BS + i) * 4096) = stg[i];
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+}
+
+// Per-tile argmin epilogue.  acc[4q + r] = <code base + 8q + 4hi + r, row j>: 16 scores of ONE row per lane,
+// codes ascending with the register index, tiles ascending, so "first minimum" == lowest code index.
+//
+// Cost model (measured with s_memtime stamps, tools/trace_tiles.py): v_mfma_f32_32x32x2_f32 runs on the SIMD's fp32
+// lanes, so every VALU instruction of either resident wave takes ~7 cycles AWAY from the MFMA stream -- VALU work is
+// not hidden behind fp32 MFMAs, it is serialised with them.  The epilogue is therefore written for minimum VALU
+// instruction COUNT (about 90 per tile; the first version, one wave-level branch per element, had ~190 + 16 branches):
+//   1. s = (x2 + y2) + (-2 xy)          v_pk_add_f32 + v_pk_fma_f32, two codes per instruction  (vqp.py:62, one
+//                                        rounding per operation exactly like the reference; the product by -2 is exact)
+//   2. s_min                             v_min3_f32 tree; clamp(min=1e-8) applied to the minimum only (monotone)
+//   3. skip the tile (wave-uniform) unless some lane has s_min < s_best: sqrt is monotone, it cannot win
+//   4. d = sqrt_rn(s_min)                ONE correctly rounded sqrt per lane and tile
+//   5. the reference compares d, and the sqrt collapses neighbouring s: the winner is the FIRST element whose sqrt
+//      rounds to d.  {s : sqrt_rn(s) <= d} = {s < m^2}, m = midpoint of d and the next float; m has 25 significant
+//      bits so m^2 is exact in double and never equals an fp32 value: U = largest fp32 below m^2, then a descending
+//      scan "s_e <= U ? e" leaves the first such element.  Exact, no per-element sqrt, no per-element branch.
+template <int METRIC>
+__device__ __forceinline__ void argmin_tile(const f32x16 &acc, const float *y2s, float x2, int base, int hi, int C,
+                                            float &bd, float &bs, int &bi)
+{
+    if (METRIC != 0) {   // cosine: first maximum of the raw dot products (vqp.py:741, 140)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int code = base + 8 * (e >> 2) + 4 * hi + (e & 3);
+            const bool win = (acc[e] > bd) && (code < C);
+            bd = win ? acc[e] : bd;
+            bi = win ? code : bi;
+        }
+        return;
+    }
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    f32x2 s2[8];
+    const f32x2 xx = {x2, x2};
+    const f32x2 m2c = {-2.0f, -2.0f};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const f32x4 yv = *(const f32x4 *)(y2s + 8 * q + 4 * hi);
+        const f32x2 y01 = {yv.x, yv.y}, y23 = {yv.z, yv.w};
+        const f32x2 a01 = {acc[4 * q + 0], acc[4 * q + 1]}, a23 = {acc[4 * q + 2], acc[4 * q + 3]};
+        s2[2 * q + 0] = __builtin_elementwise_fma(m2c, a01, xx + y01);
+        s2[2 * q + 1] = __builtin_elementwise_fma(m2c, a23, xx + y23);
+    }
+    float s[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) s[e] = s2[e >> 1][e & 1];
+    // v_min3_f32 tree
+    float m0 = fminf(fminf(s[0], s[1]), s[2]), m1 = fminf(fminf(s[3], s[4]), s[5]), m2 = fminf(fminf(s[6], s[7]), s[8]);
+    float m3 = fminf(fminf(s[9], s[10]), s[11]), m4 = fminf(fminf(s[12], s[13]), s[14]);
+    m0 = fminf(fminf(m0, m1), m2);
+    m3 = fminf(fminf(m3, m4), s[15]);
+    const float sm = fmaxf(fminf(m0, m3), 1e-8f);   // clamp(min = 1e-8) commutes with the minimum
+    const bool improving = sm < bs;                  // sm >= bs  =>  sqrt(sm) >= bd: this tile cannot win for this lane
+    if (!__any(improving)) return;
+    const float d = sqrtf(sm);
+    const bool win = improving && (d < bd);
+    if (!__any(win)) return;
+    const double mid = 0.5 * ((double)d + (double)__uint_as_float(__float_as_uint(d) + 1u));
+    const double mid2 = mid * mid;
+    float U = (float)mid2;                           // round to nearest ...
+    U = ((double)U > mid2) ? __uint_as_float(__float_as_uint(U) - 1u) : U;   // ... then down: largest fp32 < m^2
+    int ew = 15;
+#pragma unroll
+    for (int e = 14; e >= 0; --e) ew = (s[e] <= U) ? e : ew;   // s[15] <= U is implied when nothing earlier matches
+    bd = win ? d : bd;
+    bs = win ? sm : bs;
+    bi = win ? (base + 8 * (ew >> 2) + 4 * hi + (ew & 3)) : bi;
+}
+
+#ifdef VQ_TRACE
+static long long *g_trace = nullptr;
+extern "C" void vqhip_set_trace(long long *p) { g_trace = p; }
+#define VQ_STAMP(slot) do { if (a.trace && blockIdx.x < 16 && lane == 0 && ct < 64) a.trace[(((size_t)blockIdx.x * 4 + wave) * 64 + ct) * 4 + (slot)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define VQ_STAMP(slot) do {} while (0)
+#endif
+
 struct AssignArgs {
     const void *x;
     int64_t N;
@@ -203,6 +324,9 @@ struct AssignArgs {
     int x_vec;  // 1: D == DT and x rows are vector-load aligned
     int q_vec;  // 1: D == DT and q rows are vector-store aligned
     int skip_norm;  // cosine: rows are already unit-norm
+#ifdef VQ_TRACE
+    long long *trace;
+#endif
 };
 
 __device__ __forceinline__ void swap32(float &a, float &b)
@@ -231,14 +355,11 @@ __global__ void __launch_bounds__(256, (DT <= 256 ? 2 : 1)) vq_assign_kernel(con
     const bool row_ok = row < a.N;
     const int64_t rowc = row_ok ? row : (a.N - 1);
 
-    // ---- kick off the DMA of codebook tile 0 while x is being loaded -----------------------------
-    auto issue_tile = [&](int ct, int buf) {
-        const char *g = (const char *)a.packed + (size_t)ct * TILE_B + lane * 16;
-        char *l = smem + buf * TILE_B;
-        for (int c = wave; c < NCHUNK; c += 4)
-            __builtin_amdgcn_global_load_lds((const AS1 void *)(g + c * 1024), (AS3 void *)(l + c * 1024), 16, 0, 0);
-    };
-    issue_tile(0, 0);
+    // ---- codebook tiles L2 -> LDS: wave w moves the 1-KiB pieces w, w+4, ... of a tile (this lane: 16 bytes of each) ----
+    const int my_pieces = (NCHUNK - wave + 3) / 4;
+    const int piece_off = wave * 1024 + lane * 16;
+    for (int k = 0; k < my_pieces; ++k)   // tile 0, while x is being loaded
+        *(f32x4 *)(smem + piece_off + k * 4096) = *(const f32x4 *)((const char *)a.packed + piece_off + (size_t)k * 4096);
 
     // ---- x rows -> registers.  xr[4m + r] = x[row][8m + 4hi + r]  ("load layout") ----------------
     float xr[DT / 2];
@@ -334,54 +455,21 @@ __global__ void __launch_bounds__(256, (DT <= 256 ? 2 : 1)) vq_assign_kernel(con
     const int nt = a.n_tiles;
     for (int ct = 0; ct < nt; ++ct) {
         const int buf = ct & 1;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();  // tile ct has landed for every wave; everyone is done with the other buffer
-        if (ct + 1 < nt) issue_tile(ct + 1, buf ^ 1);
+        VQ_STAMP(0);
+        __syncthreads();  // tile ct is in LDS for every wave; everyone is done with the other buffer
+        VQ_STAMP(1);
 
         const char *tile = smem + buf * TILE_B;
         const f32x4 *ap = (const f32x4 *)tile + (hi * 32 + j);
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-#pragma unroll
-        for (int t4 = 0; t4 < NG; ++t4) {
-            const f32x4 av = ap[t4 * 64];
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, xr[4 * t4 + 0], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, xr[4 * t4 + 2], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, xr[4 * t4 + 1], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, xr[4 * t4 + 3], acc, 0, 0, 0);
-        }
-
-        // acc[4q + r] = <code ct*32 + 8q + 4hi + r , row j>.  Codes ascend with (ct, q, r), so a
-        // strict comparison keeps the lowest index among equal distances (ATen argmax semantics).
-        const float *y2s = (const float *)tile + 32 * DT;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const f32x4 yv = *(const f32x4 *)(y2s + 8 * q + 4 * hi);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int code = ct * 32 + 8 * q + 4 * hi + r;
-                const float v = acc[4 * q + r];
-                if (METRIC == 0) {
-                    // vqp.py:62  (x2 + y2) + (-2 xy), clamp(min=1e-8), sqrt -- one rounding each
-                    const float t = x2 + yv[r];
-                    float s = __builtin_fmaf(-2.0f, v, t);
-                    s = fmaxf(s, 1e-8f);
-                    const bool cand = s < bs;  // s >= bs implies sqrt(s) >= bd: cannot win
-                    if (__any(cand)) {
-                        const float d = sqrtf(s);
-                        const bool win = cand && (d < bd);
-                        bd = win ? d : bd;
-                        bs = win ? s : bs;
-                        bi = win ? code : bi;
-                    }
-                } else {
-                    const bool win = (v > bd) && (code < a.C);
-                    bd = win ? v : bd;
-                    bi = win ? code : bi;
-                }
-            }
-        }
+        const bool more = ct + 1 < nt;
+        mfma_sweep_tile<DT>(ap, xr, acc, (const char *)a.packed + (size_t)(more ? ct + 1 : ct) * TILE_B + piece_off,
+                            smem + (buf ^ 1) * TILE_B + piece_off, more ? my_pieces : 0);
+        VQ_STAMP(2);
+        argmin_tile<METRIC>(acc, (const float *)tile + 32 * DT, x2, ct * 32, hi, a.C, bd, bs, bi);
+        VQ_STAMP(3);
     }
 
     // ---- merge the two half-waves (same row, disjoint code subsets) ------------------------------
@@ -582,6 +670,9 @@ extern "C" int vqhip_assign(const void *x, int x_dtype, int64_t N, int D, int64_
     a.n_tiles = (C + 31) / 32;
     a.idx_out = idx_out; a.q_out = q_out; a.q_bf16 = (q_dtype == VQHIP_BF16); a.ldq = ldq;
     a.skip_norm = (metric == VQHIP_COSINE_PRENORM);
+#ifdef VQ_TRACE
+    a.trace = g_trace;
+#endif
     a.best_out = best_out; a.rnorm_out = rnorm_out; a.sqerr_partial = sqerr_partial; a.row_mask = row_mask;
     const int xes = (x_dtype == VQHIP_BF16) ? 2 : 4;
     a.x_vec = (D == DT) && (((uintptr_t)x) % (4 * xes) == 0) && ((ldx * xes) % (4 * xes) == 0) && ((((uintptr_t)embed) & 15) == 0);
@@ -652,14 +743,14 @@ __global__ void __launch_bounds__(256, (DT <= 256 ? 2 : 1)) vq_rvq_kernel(const 
 
     const int nt = a.n_tiles;
     const int total_tiles = nt * a.Q;
-    auto issue_tile = [&](int gt, int buf) {   // gt = global tile counter over (stage, tile)
+    const int my_pieces = (NCHUNK - wave + 3) / 4;
+    const int piece_off = wave * 1024 + lane * 16;
+    auto tile_src = [&](int gt) {   // gt = global tile counter over (stage, tile); LDS buffer = gt & 1
         const int q = gt / nt, ct = gt - q * nt;
-        const char *g = (const char *)(a.packed + (size_t)q * a.packed_qstride) + (size_t)ct * TILE_B + lane * 16;
-        char *l = smem + buf * TILE_B;
-        for (int c = wave; c < NCHUNK; c += 4)
-            __builtin_amdgcn_global_load_lds((const AS1 void *)(g + c * 1024), (AS3 void *)(l + c * 1024), 16, 0, 0);
+        return (const char *)(a.packed + (size_t)q * a.packed_qstride) + (size_t)ct * TILE_B + piece_off;
     };
-    issue_tile(0, 0);
+    for (int k = 0; k < my_pieces; ++k)
+        *(f32x4 *)(smem + piece_off + k * 4096) = *(const f32x4 *)(tile_src(0) + (size_t)k * 4096);
 
     float xr[DT / 2];   // the running residual, load layout between stages, B-operand layout inside a sweep
     if (a.x_vec) {
@@ -752,43 +843,16 @@ __global__ void __launch_bounds__(256, (DT <= 256 ? 2 : 1)) vq_rvq_kernel(const 
         int bi = 0;
         for (int ct = 0; ct < nt; ++ct, ++gt) {
             const int buf = gt & 1;
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            if (gt + 1 < total_tiles) issue_tile(gt + 1, buf ^ 1);
 
             const char *tile = smem + buf * TILE_B;
             const f32x4 *ap = (const f32x4 *)tile + (hi * 32 + j);
             f32x16 acc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-#pragma unroll
-            for (int t4 = 0; t4 < NG; ++t4) {
-                const f32x4 av = ap[t4 * 64];
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, xr[4 * t4 + 0], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, xr[4 * t4 + 2], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, xr[4 * t4 + 1], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, xr[4 * t4 + 3], acc, 0, 0, 0);
-            }
-            const float *y2s = (const float *)tile + 32 * DT;
-#pragma unroll
-            for (int qq = 0; qq < 4; ++qq) {
-                const f32x4 yv = *(const f32x4 *)(y2s + 8 * qq + 4 * hi);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int code = ct * 32 + 8 * qq + 4 * hi + r;
-                    const float t = x2 + yv[r];
-                    float s = __builtin_fmaf(-2.0f, acc[4 * qq + r], t);
-                    s = fmaxf(s, 1e-8f);
-                    const bool cand = s < bs;
-                    if (__any(cand)) {
-                        const float d = sqrtf(s);
-                        const bool win = cand && (d < bd);
-                        bd = win ? d : bd;
-                        bs = win ? s : bs;
-                        bi = win ? code : bi;
-                    }
-                }
-            }
+            const bool more = gt + 1 < total_tiles;
+            mfma_sweep_tile<DT>(ap, xr, acc, tile_src(more ? gt + 1 : gt), smem + ((gt + 1) & 1) * TILE_B + piece_off, more ? my_pieces : 0);
+            argmin_tile<0>(acc, (const float *)tile + 32 * DT, x2, ct * 32, hi, a.C, bd, bs, bi);
         }
         {
             const float od = __shfl_xor(bd, 32, 64);
