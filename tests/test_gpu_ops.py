@@ -181,3 +181,40 @@ def test_decode_sum(dev):
     out1 = L.decode_sum(idx.to(dev), cb[0].contiguous().to(dev)).cpu()
     want1 = sum(O.decode(cb[0], idx[..., q]) for q in range(Q))
     assert (out1 - want1).abs().max().item() <= 1e-6
+
+
+@pytest.mark.parametrize("N,C,D,Q,dtype,shared", [(300, 64, 512, 3, torch.float32, True), (515, 100, 128, 4, torch.float32, False),
+                                                   (1000, 256, 256, 8, torch.bfloat16, True), (129, 33, 32, 2, torch.float32, False)])
+def test_fused_rvq_kernel_vs_stagewise_oracle(dev, N, C, D, Q, dtype, shared):
+    """vqhip_rvq_forward == Q successive oracle assignments on the running residual (rvq.py:469-568),
+    incl. the bf16 arithmetic of the reference when the input is bf16 (quantized and residual are bf16 tensors)."""
+    from vector_quantize_pytorch_amd import _lib as L
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(N, D, generator=g).to(dtype)
+    cbs = torch.randn(1 if shared else Q, C, D, generator=g)
+    m = torch.rand(N, generator=g) < 0.9
+    xd = x.to(dev)
+    if shared:
+        e = cbs[0].contiguous().to(dev)
+        pk = L.pack_codebook(e)
+    else:
+        e = cbs.contiguous().to(dev)
+        pk = torch.stack([L.pack_codebook(e[q]) for q in range(Q)])
+    r = L.rvq_forward(xd, pk, e, Q, want_resid=True, want_sqerr=True, row_mask=m.to(dev))
+    res = x.clone()
+    for q in range(Q):
+        cb = cbs[0 if shared else q]
+        assert torch.equal(r["resid"][:, q].cpu(), res), f"stage {q} input residual"
+        idx_o, _ = O.c_assign(res.float(), cb)
+        want_idx = torch.where(m, idx_o, torch.full_like(idx_o, -1))
+        assert torch.equal(r["idx"][:, q].cpu(), want_idx), f"stage {q} indices"
+        quant = cb[idx_o].to(dtype)
+        want_sq = (((quant.double() - res.double()) ** 2).sum(-1) * m).sum().item()
+        got_sq = r["sqerr_partials"][q].sum().item()
+        assert abs(got_sq - want_sq) <= 1e-5 * max(want_sq, 1e-12), f"stage {q} squared error"
+        res = torch.where(m[:, None], res - quant, res)
+    out = L.decode_sum(r["idx"], e, out_dtype=torch.float32).cpu()
+    want = torch.zeros(N, D)
+    for q in range(Q):
+        want = want + O.decode(cbs[0 if shared else q], r["idx"][:, q].cpu())
+    assert torch.equal(out, want)

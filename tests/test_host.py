@@ -33,8 +33,8 @@ def test_library_exports_every_declared_symbol():
 def test_host_only_entry_points():
     from vector_quantize_pytorch_amd import _lib
     L = _lib.lib()
-    assert L.vqhip_packed_bytes(1024, 256) == 32 * (32 * 256 + 256) * 4 + 4096
-    assert L.vqhip_packed_bytes(33, 100) == 2 * (32 * 128 + 256) * 4 + 4096   # D padded to 128, C to 64, + tail pad
+    assert L.vqhip_packed_bytes(1024, 256) == 32 * (32 * 256 + 256) * 4 + 4096 + 1024 * 256 * 2
+    assert L.vqhip_packed_bytes(33, 100) == 2 * (32 * 128 + 256) * 4 + 4096 + 33 * 100 * 2 + 8   # D padded to 128, C to 64, + tail pad + bf16 copy (16-byte rounded)
     assert L.vqhip_packed_bytes(16, 513) == 0                              # unsupported D
     assert L.vqhip_assign_blocks(0) == 0 and L.vqhip_assign_blocks(1) == 1 and L.vqhip_assign_blocks(129) == 2
 

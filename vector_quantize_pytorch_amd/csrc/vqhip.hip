@@ -29,6 +29,7 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 
 static thread_local char g_err[256] = "";
@@ -133,13 +134,25 @@ extern "C" size_t vqhip_packed_bytes(int C, int D)
     const int DT = pick_dt(D);
     if (DT == 0 || C <= 0) return 0;
     const size_t tiles = ((size_t)C + 31) / 32;
-    return tiles * ((size_t)32 * DT + 256) * sizeof(float) + 4096;   // + tail pad: the staged copy over-reads <= 3 KiB
+    // tiles | 4 KiB tail pad (the staged copy over-reads <= 3 KiB) | codebook rounded to bf16 [C, D] (q / loss of the bf16 path)
+    return tiles * ((size_t)32 * DT + 256) * sizeof(float) + 4096 + (((size_t)C * D * 2 + 15) & ~(size_t)15);
+}
+
+static inline size_t packed_bf16_offset(int C, int D)   // bytes from the start of the packed buffer
+{
+    const int DT = pick_dt(D);
+    const size_t tiles = ((size_t)C + 31) / 32;
+    return tiles * ((size_t)32 * DT + 256) * sizeof(float) + 4096;
 }
 
 __global__ void __launch_bounds__(256) vq_pack_kernel(const float *__restrict__ embed, int C, int D, int DT,
-                                                      float *__restrict__ packed)
+                                                      float *__restrict__ packed, unsigned short *__restrict__ ebf)
 {
     const int t = blockIdx.x;
+    for (int p = threadIdx.x; p < 32 * D; p += 256) {   // RNE-rounded bf16 copy of this tile's 32 code rows
+        const size_t o = (size_t)t * 32 * D + p;
+        if (o < (size_t)C * D) ebf[o] = f32_to_bf16_rne(embed[o]);
+    }
     const int tile_f = 32 * DT + 256;
     float *out = packed + (size_t)t * tile_f;
     for (int p = threadIdx.x; p < 32 * DT; p += 256) {
@@ -174,7 +187,8 @@ extern "C" int vqhip_pack_codebook(const float *embed, int C, int D, float *pack
     if (D < 1 || DT == 0) VQ_FAIL(VQHIP_EDIM, "pack_codebook: D=%d unsupported (1..512)", D);
     if (((uintptr_t)packed) & 15) VQ_FAIL(VQHIP_EALIGN, "pack_codebook: packed must be 16-byte aligned");
     const int tiles = (C + 31) / 32;
-    hipLaunchKernelGGL(vq_pack_kernel, dim3(tiles), dim3(256), 0, (hipStream_t)stream, embed, C, D, DT, packed);
+    hipLaunchKernelGGL(vq_pack_kernel, dim3(tiles), dim3(256), 0, (hipStream_t)stream, embed, C, D, DT, packed,
+                       (unsigned short *)((char *)packed + packed_bf16_offset(C, D)));
     return launch_status("vq_pack_kernel");
 }
 
@@ -258,7 +272,6 @@ __device__ __forceinline__ void argmin_tile(const f32x16 &acc, const float *y2s,
         }
         return;
     }
-    typedef float f32x2 __attribute__((ext_vector_type(2)));
     f32x2 s2[8];
     const f32x2 xx = {x2, x2};
     const f32x2 m2c = {-2.0f, -2.0f};
@@ -311,6 +324,7 @@ struct AssignArgs {
     int64_t ldx;
     const float *packed;
     const float *embed;
+    const unsigned short *embed_bf16;  // RNE-rounded copy inside the packed buffer
     int C;
     int n_tiles;
     int64_t *idx_out;
@@ -402,21 +416,19 @@ __global__ void __launch_bounds__(256, (DT <= 256 ? 2 : 1)) vq_assign_kernel(con
     //      multiple of 32 take x2 from a pre-pass (a.rnorm_out pre-filled) -- see host wrapper. ----
     float x2;
     {
-        float ch[4][4];
+        // two chains per v_pk_mul_f32 / v_pk_add_f32 (each component rounds exactly like the scalar op)
+        f32x2 ch[4][2];
 #pragma unroll
-        for (int mm = 0; mm < 4; ++mm)
+        for (int mm = 0; mm < 4; ++mm) { ch[mm][0] = f32x2{0.f, 0.f}; ch[mm][1] = f32x2{0.f, 0.f}; }
 #pragma unroll
-            for (int r = 0; r < 4; ++r) ch[mm][r] = 0.f;
-#pragma unroll
-        for (int m = 0; m < NG; ++m)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float v = xr[4 * m + r];
-                ch[m & 3][r] += v * v;
-            }
+        for (int m = 0; m < NG; ++m) {
+            const f32x2 v01 = {xr[4 * m + 0], xr[4 * m + 1]}, v23 = {xr[4 * m + 2], xr[4 * m + 3]};
+            ch[m & 3][0] = ch[m & 3][0] + v01 * v01;
+            ch[m & 3][1] = ch[m & 3][1] + v23 * v23;
+        }
         float p[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) p[r] = ((ch[0][r] + ch[1][r]) + ch[2][r]) + ch[3][r];
+        for (int r = 0; r < 4; ++r) p[r] = ((ch[0][r >> 1][r & 1] + ch[1][r >> 1][r & 1]) + ch[2][r >> 1][r & 1]) + ch[3][r >> 1][r & 1];
         const float f_lo = ((p[0] + p[1]) + p[2]) + p[3];          // SIMD lanes 0..3 (hi == 0 half)
         const float f_from_lo = __shfl(f_lo, j, 64);               // value of the hi == 0 partner
         const float f_hi = (((f_from_lo + p[0]) + p[1]) + p[2]) + p[3];  // continue with lanes 4..7
@@ -493,7 +505,33 @@ __global__ void __launch_bounds__(256, (DT <= 256 ? 2 : 1)) vq_assign_kernel(con
     if (a.q_out) {
         const int64_t wrow0 = (int64_t)blockIdx.x * VQHIP_ASSIGN_ROWS_PER_BLOCK + wave * 32;
         const bool qb = a.q_bf16 != 0;
-        if (a.q_vec && a.x_vec) {
+        if (a.q_vec && a.x_vec && qb) {     // bf16 out: verbatim copy of the pre-rounded rows, 8 bytes per lane
+#pragma unroll
+            for (int r0 = 0; r0 < 32; r0 += 8) {
+                uint2 g[8][(DT + 255) / 256];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int c = __builtin_amdgcn_readlane(bi, r0 + u);
+                    const unsigned short *er = a.embed_bf16 + (size_t)c * DT;
+#pragma unroll
+                    for (int h = 0; h < (DT + 255) / 256; ++h) {
+                        const int d = h * 256 + lane * 4;
+                        if (d < DT) g[u][h] = *(const uint2 *)(er + d);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int64_t rr = wrow0 + r0 + u;
+                    if (rr < a.N) {
+#pragma unroll
+                        for (int h = 0; h < (DT + 255) / 256; ++h) {
+                            const int d = h * 256 + lane * 4;
+                            if (d < DT) *(uint2 *)((unsigned short *)a.q_out + rr * a.ldq + d) = g[u][h];
+                        }
+                    }
+                }
+            }
+        } else if (a.q_vec && a.x_vec) {
 #pragma unroll
             for (int r0 = 0; r0 < 32; r0 += 8) {
                 f32x4 g[8][(DT + 255) / 256];
@@ -514,16 +552,7 @@ __global__ void __launch_bounds__(256, (DT <= 256 ? 2 : 1)) vq_assign_kernel(con
 #pragma unroll
                         for (int h = 0; h < (DT + 255) / 256; ++h) {
                             const int d = h * 256 + lane * 4;
-                            if (d < DT) {
-                                if (qb) {
-                                    uint2 w;
-                                    w.x = (unsigned)f32_to_bf16_rne(g[u][h].x) | ((unsigned)f32_to_bf16_rne(g[u][h].y) << 16);
-                                    w.y = (unsigned)f32_to_bf16_rne(g[u][h].z) | ((unsigned)f32_to_bf16_rne(g[u][h].w) << 16);
-                                    *(uint2 *)((unsigned short *)a.q_out + rr * a.ldq + d) = w;
-                                } else {
-                                    *(f32x4 *)((float *)a.q_out + rr * a.ldq + d) = g[u][h];
-                                }
-                            }
+                            if (d < DT) *(f32x4 *)((float *)a.q_out + rr * a.ldq + d) = g[u][h];
                         }
                     }
                 }
@@ -551,29 +580,42 @@ __global__ void __launch_bounds__(256, (DT <= 256 ? 2 : 1)) vq_assign_kernel(con
             swap32(xr[4 * m + 2], xr[4 * m + 3]);
         }
         const float *er = a.embed + (size_t)bi * a.D;
+        const unsigned short *erb = a.embed_bf16 + (size_t)bi * a.D;
         const bool qb = a.q_bf16 != 0;
         float lsum = 0.f;
+        f32x2 lsum2 = {0.f, 0.f};
 #pragma unroll
         for (int m = 0; m < NG; ++m) {
             const int k0 = 8 * m + 4 * hi;
             float g[4];
-            if (a.x_vec) {  // D == DT: embed rows are 16-byte aligned whenever embed is
+            if (a.x_vec && qb) {        // 4 pre-rounded bf16 values in one 8-byte load
+                const uint2 w = *(const uint2 *)(erb + k0);
+                g[0] = __uint_as_float(w.x << 16); g[1] = __uint_as_float(w.x & 0xffff0000u);
+                g[2] = __uint_as_float(w.y << 16); g[3] = __uint_as_float(w.y & 0xffff0000u);
+            } else if (a.x_vec) {       // D == DT: embed rows are 16-byte aligned whenever embed is
                 const f32x4 w = *(const f32x4 *)(er + k0);
                 g[0] = w.x; g[1] = w.y; g[2] = w.z; g[3] = w.w;
             } else {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) g[r] = (k0 + r < a.D) ? er[k0 + r] : 0.f;
+                for (int r = 0; r < 4; ++r) {
+                    g[r] = (k0 + r < a.D) ? er[k0 + r] : 0.f;
+                    if (qb) g[r] = round_to_bf16(g[r]);
+                }
             }
-            if (qb) {
+            if (DT <= 256) {
+                const f32x2 d01 = f32x2{g[0], g[1]} - f32x2{xr[4 * m + 0], xr[4 * m + 1]};
+                const f32x2 d23 = f32x2{g[2], g[3]} - f32x2{xr[4 * m + 2], xr[4 * m + 3]};
+                lsum2 = __builtin_elementwise_fma(d01, d01, lsum2);
+                lsum2 = __builtin_elementwise_fma(d23, d23, lsum2);
+            } else {   // DT = 512 (x spread over VGPRs + AGPRs): the packed form measured ~1e-3 relative error on the GPU
 #pragma unroll
-                for (int r = 0; r < 4; ++r) g[r] = round_to_bf16(g[r]);
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float df = g[r] - xr[4 * m + r];
-                lsum += df * df;
+                for (int r = 0; r < 4; ++r) {
+                    const float df = g[r] - xr[4 * m + r];
+                    lsum += df * df;
+                }
             }
         }
+        lsum += lsum2[0] + lsum2[1];
         const bool counted = row_ok && (!a.row_mask || a.row_mask[row] != 0);
         double ds = counted ? (double)lsum : 0.0;
 #pragma unroll
@@ -667,6 +709,7 @@ extern "C" int vqhip_assign(const void *x, int x_dtype, int64_t N, int D, int64_
 
     AssignArgs a;
     a.x = x; a.N = N; a.D = D; a.ldx = ldx; a.packed = packed; a.embed = embed; a.C = C;
+    a.embed_bf16 = (const unsigned short *)((const char *)packed + packed_bf16_offset(C, D));
     a.n_tiles = (C + 31) / 32;
     a.idx_out = idx_out; a.q_out = q_out; a.q_bf16 = (q_dtype == VQHIP_BF16); a.ldq = ldq;
     a.skip_norm = (metric == VQHIP_COSINE_PRENORM);
@@ -712,6 +755,7 @@ struct RvqArgs {
     int64_t packed_qstride;  // floats between the packed codebooks of consecutive stages (0: shared)
     const float *embed;
     int64_t embed_qstride;   // floats between codebooks (0: shared)
+    size_t bf16_off;         // byte offset of the bf16 codebook copy inside each stage's packed buffer
     int C;
     int n_tiles;
     int Q;
@@ -812,21 +856,18 @@ __global__ void __launch_bounds__(256, (DT <= 256 ? 2 : 1)) vq_rvq_kernel(const 
         }
         float x2;
         {
-            float ch[4][4];
+            f32x2 ch[4][2];
 #pragma unroll
-            for (int mm = 0; mm < 4; ++mm)
+            for (int mm = 0; mm < 4; ++mm) { ch[mm][0] = f32x2{0.f, 0.f}; ch[mm][1] = f32x2{0.f, 0.f}; }
 #pragma unroll
-                for (int r = 0; r < 4; ++r) ch[mm][r] = 0.f;
-#pragma unroll
-            for (int m = 0; m < NG; ++m)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float v = xr[4 * m + r];
-                    ch[m & 3][r] += v * v;
-                }
+            for (int m = 0; m < NG; ++m) {
+                const f32x2 v01 = {xr[4 * m + 0], xr[4 * m + 1]}, v23 = {xr[4 * m + 2], xr[4 * m + 3]};
+                ch[m & 3][0] = ch[m & 3][0] + v01 * v01;
+                ch[m & 3][1] = ch[m & 3][1] + v23 * v23;
+            }
             float p[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) p[r] = ((ch[0][r] + ch[1][r]) + ch[2][r]) + ch[3][r];
+            for (int r = 0; r < 4; ++r) p[r] = ((ch[0][r >> 1][r & 1] + ch[1][r >> 1][r & 1]) + ch[2][r >> 1][r & 1]) + ch[3][r >> 1][r & 1];
             const float f_lo = ((p[0] + p[1]) + p[2]) + p[3];
             const float f_from_lo = __shfl(f_lo, j, 64);
             const float f_hi = (((f_from_lo + p[0]) + p[1]) + p[2]) + p[3];
@@ -870,24 +911,31 @@ __global__ void __launch_bounds__(256, (DT <= 256 ? 2 : 1)) vq_rvq_kernel(const 
             swap32(xr[4 * m + 2], xr[4 * m + 3]);
         }
         const float *er = a.embed + (size_t)q * a.embed_qstride + (size_t)bi * a.D;
+        const unsigned short *erb = (const unsigned short *)((const char *)(a.packed + (size_t)q * a.packed_qstride) + a.bf16_off) + (size_t)bi * a.D;
         float lsum = 0.f;
 #pragma unroll
         for (int m = 0; m < NG; ++m) {
             const int k0 = 8 * m + 4 * hi;
             float g[4];
-            if (a.x_vec) {
+            if (a.x_vec && XBF16) {     // quantized is a bf16 tensor in the reference: pre-rounded rows
+                const uint2 w = *(const uint2 *)(erb + k0);
+                g[0] = __uint_as_float(w.x << 16); g[1] = __uint_as_float(w.x & 0xffff0000u);
+                g[2] = __uint_as_float(w.y << 16); g[3] = __uint_as_float(w.y & 0xffff0000u);
+            } else if (a.x_vec) {
                 const f32x4 w = *(const f32x4 *)(er + k0);
                 g[0] = w.x; g[1] = w.y; g[2] = w.z; g[3] = w.w;
             } else {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) g[r] = (k0 + r < a.D) ? er[k0 + r] : 0.f;
+                for (int r = 0; r < 4; ++r) {
+                    g[r] = (k0 + r < a.D) ? er[k0 + r] : 0.f;
+                    if (XBF16) g[r] = round_to_bf16(g[r]);
+                }
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float gq = XBF16 ? round_to_bf16(g[r]) : g[r];
-                const float df = gq - xr[4 * m + r];
+                const float df = g[r] - xr[4 * m + r];
                 lsum += df * df;
-                float nr = xr[4 * m + r] - gq;                 // residual - quantized (rvq.py:524)
+                float nr = xr[4 * m + r] - g[r];               // residual - quantized (rvq.py:524)
                 if (XBF16) nr = round_to_bf16(nr);             // bf16 tensors in the reference
                 xr[4 * m + r] = live ? nr : xr[4 * m + r];
             }
@@ -934,6 +982,7 @@ extern "C" int vqhip_rvq_forward(const void *x, int x_dtype, int64_t N, int D, i
     a.x = x; a.N = N; a.D = D; a.ldx = ldx; a.packed = packed; a.packed_qstride = packed_qstride; a.embed = embed;
     a.embed_qstride = embed_qstride; a.C = C; a.n_tiles = (C + 31) / 32; a.Q = Q; a.idx_out = idx_out;
     a.resid_out = resid_out; a.sqerr_partial = sqerr_partial; a.row_mask = row_mask;
+    a.bf16_off = packed_bf16_offset(C, D);
     const int xes = (x_dtype == VQHIP_BF16) ? 2 : 4;
     a.x_vec = (D == DT) && (((uintptr_t)x) % (4 * xes) == 0) && ((ldx * xes) % (4 * xes) == 0) && ((((uintptr_t)embed) & 15) == 0) &&
               (!resid_out || (((uintptr_t)resid_out) % (4 * xes) == 0)) && ((embed_qstride % 4) == 0) && ((packed_qstride % 4) == 0);
