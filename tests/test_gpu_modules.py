@@ -362,3 +362,71 @@ def test_data_parallel_stat_sync_equals_single_process(dev, tmp_path):
     assert torch.equal(torch.cat([r[0]["idx"], r[1]["idx"]], 0), idx.cpu())
     _close(r[0]["embed"], vq._codebook.embed, 1e-5, "embed")
     _close(r[0]["cs"], vq._codebook.cluster_size, 1e-6, "cluster_size")
+
+
+# ---- BASELINE configs 3-5 at full size: size-independent properties + oracle on a slice -------------
+def test_cfg3_full_size_rvq_properties(dev):
+    """cfg 3: ResidualVQ(dim=256, Q=8, C=1024, shared_codebook=True), x = (32, 8192, 256) fp32, train step."""
+    from vector_quantize_pytorch_amd import ResidualVQ
+    torch.manual_seed(0)
+    rvq = ResidualVQ(dim=256, num_quantizers=8, codebook_size=1024, shared_codebook=True).to(dev).train()
+    e0 = rvq.layers[0]._codebook.embed[0].clone()
+    x = torch.randn(32, 8192, 256, device=dev)
+    q, idx, losses = rvq(x)
+    assert q.shape == x.shape and idx.shape == (32, 8192, 8) and losses.shape == (8,)
+    assert int(idx.min()) >= 0 and int(idx.max()) < 1024
+    # round trip against the PRE-update codebook (the forward quantizes with it, rvq.py:593-597 updates afterwards)
+    want = torch.zeros_like(x)
+    for s in range(8):
+        want = want + e0[idx[..., s]]
+    assert torch.equal(q, want)
+    # residual norms decrease stage by stage; the per-stage loss is the mean squared residual after that stage
+    res = x.clone()
+    for s in range(8):
+        res = res - e0[idx[..., s]]
+        assert abs(losses[s].item() - (res ** 2).mean().item()) <= 1e-5 * (res ** 2).mean().item()
+    # oracle on one batch row (8192 vectors), every stage bit-exact
+    r = x[5].cpu()
+    for s in range(8):
+        io, _ = O.c_assign(r, e0.cpu())
+        assert torch.equal(idx[5, :, s].cpu(), io), f"stage {s}"
+        r = r - e0.cpu()[io]
+    assert not torch.equal(rvq.layers[0]._codebook.embed[0], e0)          # the EMA step happened
+
+
+def test_cfg4_one_shard_cosine_65536(dev):
+    """cfg 4, what ONE of the 8 GPUs computes: cosine, dim 512, its 8192-code shard of the 65536 codebook,
+    all 262144 rows.  Checked: best similarity / index bit-exact vs the chain oracle on a slice; unit-norm codes."""
+    from vector_quantize_pytorch_amd import _lib as L
+    g = torch.Generator().manual_seed(4)
+    e = O.l2norm(torch.randn(8192, 512, generator=g))
+    x = torch.randn(16 * 16384, 512, generator=g)
+    ed, xd = e.to(dev), x.to(dev)
+    r = L.assign(xd, L.pack_codebook(ed), ed, cosine=True, want_q=True, want_best=True)
+    sl = slice(100000, 100000 + 4096)
+    io, bo = O.c_assign(O.c_l2norm(x[sl]), e, cosine=True)
+    assert torch.equal(r["idx"][sl].cpu(), io) and torch.equal(r["best"][sl].cpu(), bo)
+    assert torch.equal(r["q"], ed[r["idx"]])
+    hist = torch.bincount(r["idx"], minlength=8192)
+    assert int(hist.sum()) == x.shape[0]
+
+
+def test_cfg5_full_size_grouped_rvq_with_kmeans(dev):
+    """cfg 5: GroupedResidualVQ(dim=512, groups=4, Q=8, C=4096, kmeans_init=True), x = (32, 8192, 512): first
+    forward runs the on-device k-means (10 iterations per codebook), second forward is the steady state."""
+    from vector_quantize_pytorch_amd import GroupedResidualVQ
+    torch.manual_seed(0)
+    m = GroupedResidualVQ(dim=512, groups=4, num_quantizers=8, codebook_size=4096, kmeans_init=True).to(dev).train()
+    x = torch.randn(32, 8192, 512, device=dev)
+    q1, idx1, l1 = m(x)
+    assert all(bool(r.layers[s]._codebook.initted) for r in m.rvqs for s in range(8))
+    q, idx, losses = m(x)
+    assert q.shape == x.shape and idx.shape == (4, 32, 8192, 8) and losses.shape == (4, 8)
+    assert int(idx.min()) >= 0 and int(idx.max()) < 4096 and torch.isfinite(losses).all()
+    assert (losses[:, 1:] <= losses[:, :-1] * 1.0001).all()                  # every stage reduces the residual
+    m.eval()
+    q, idx, _ = m(x)
+    out = m.get_output_from_indices(idx)
+    assert torch.allclose(q, out, atol=1e-5)
+    # k-means lowered the quantisation error well below that of a random codebook
+    assert ((q - x) ** 2).mean().item() < 0.75
