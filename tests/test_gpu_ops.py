@@ -218,3 +218,53 @@ def test_fused_rvq_kernel_vs_stagewise_oracle(dev, N, C, D, Q, dtype, shared):
     for q in range(Q):
         want = want + O.decode(cbs[0 if shared else q], r["idx"][:, q].cpu())
     assert torch.equal(out, want)
+
+
+def test_assign_fuzz_shapes_against_chain_oracle(dev):
+    """60 random (N, C, D, dtype, metric, scale) draws, including C = 1, N = 1, D = 1 .. 512 (odd sizes take the
+    pre-pass / scalar-load paths), tiny and huge magnitudes: indices and winning scores bit-exact every time."""
+    import random
+    from vector_quantize_pytorch_amd import _lib as L
+    rnd = random.Random(1234)
+    g = torch.Generator().manual_seed(99)
+    for it in range(60):
+        N = rnd.choice([1, 2, 31, 33, 127, 129, 500, 1000])
+        C = rnd.choice([1, 2, 31, 32, 33, 100, 257, 1000])
+        D = rnd.choice([1, 2, 3, 7, 8, 31, 32, 33, 64, 96, 100, 128, 200, 256, 300, 512])
+        cosine = rnd.random() < 0.3
+        dtype = torch.bfloat16 if rnd.random() < 0.3 else torch.float32
+        scale = rnd.choice([1e-4, 1.0, 30.0])
+        x = (torch.randn(N, D, generator=g) * scale).to(dtype)
+        e = torch.randn(C, D, generator=g) * rnd.choice([1e-3, 1.0])
+        if cosine:
+            e = O.l2norm(e)
+        xd, ed = x.to(dev), e.to(dev)
+        r = L.assign(xd, L.pack_codebook(ed), ed, cosine=cosine, want_q=True, want_best=True)
+        xf = x.float()
+        if cosine:
+            if dtype == torch.bfloat16:
+                nrm = O.c_row_sumsq(xf).sqrt().bfloat16().float().clamp(min=1e-6)
+                xf = (xf / nrm[:, None]).bfloat16().float()
+            else:
+                xf = O.c_l2norm(xf)
+        io, bo = O.c_assign(xf, e, cosine)
+        tag = f"draw {it}: N={N} C={C} D={D} cosine={cosine} {dtype} scale={scale}"
+        assert torch.equal(r["idx"].cpu(), io), tag
+        assert torch.equal(r["best"].cpu(), bo), tag
+        assert torch.equal(r["q"].cpu(), e[io].to(dtype)), tag
+
+
+def test_assign_exact_duplicates_and_zero_rows(dev):
+    """rows equal to a code (distance clamps to sqrt(1e-8)), all-zero rows, all-equal codebook."""
+    from vector_quantize_pytorch_amd import _lib as L
+    g = torch.Generator().manual_seed(5)
+    e = torch.randn(64, 64, generator=g)
+    x = torch.cat([e[[3, 17, 63]], torch.zeros(2, 64), torch.randn(27, 64, generator=g)])
+    ed = e.to(dev)
+    r = L.assign(x.to(dev), L.pack_codebook(ed), ed, want_best=True)
+    io, bo = O.c_assign(x, e)
+    assert torch.equal(r["idx"].cpu(), io) and torch.equal(r["best"].cpu(), bo)
+    assert r["idx"][:3].tolist() == [3, 17, 63]
+    e2 = torch.ones(40, 32) * 0.5                     # every code identical: index 0 must win everywhere
+    r2 = L.assign(torch.randn(100, 32, generator=g).to(dev), L.pack_codebook(e2.to(dev)), e2.to(dev))
+    assert int(r2["idx"].max()) == 0
