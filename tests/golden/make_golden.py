@@ -53,23 +53,25 @@ def inject(mod):
             m.replace_sample_fn = first_rows
 
 
-def run_case(name, cls, kwargs, xs, *, train=True, fwd_kwargs=None, grad=False, unit_codebook=False, deterministic_sampling=False):
+def run_case(name, cls, kwargs, xs, *, train=True, fwd_kwargs=None, grad=False, unit_codebook=False, deterministic_sampling=False,
+             build=None, param_grad=False):
     torch.manual_seed(1234)
-    mod = cls(**kwargs)
+    mod = cls(**kwargs) if build is None else build()
     if unit_codebook:
         for m in mod.modules():
             if hasattr(m, "embed"):
                 e = torch.randn_like(m.embed)
                 if getattr(m, "use_cosine_sim", False):
                     e = torch.nn.functional.normalize(e, dim=-1)
-                m.embed.copy_(e)
-                m.embed_avg.copy_(e)
+                m.embed.data.copy_(e)
+                m.embed_avg.data.copy_(e)
     if deterministic_sampling:
         inject(mod)
     mod.train(train)
     out = {"meta": dict(name=name, cls=cls.__name__, kwargs={k: (list(v) if isinstance(v, tuple) else v) for k, v in kwargs.items()},
                         train=train, steps=len(xs), grad=grad, fwd_kwargs=fwd_kwargs or {},
-                        deterministic_sampling=deterministic_sampling, bf16=bool(xs[0].dtype == torch.bfloat16))}
+                        deterministic_sampling=deterministic_sampling, bf16=bool(xs[0].dtype == torch.bfloat16),
+                        build=None if build is None else name, param_grad=param_grad)}
     arrays = {}
     shared = bool(kwargs.get("shared_codebook", False))
 
@@ -98,12 +100,19 @@ def run_case(name, cls, kwargs, xs, *, train=True, fwd_kwargs=None, grad=False, 
         out["meta"][f"qsha{s}"] = sha(q)
         if grad or q.dtype != torch.float32 or "lens" in fk or cls is not VectorQuantize:
             arrays[f"q{s}"] = to_np(q)          # not reconstructible as embed[idx]: store it
-        if grad:
+        if grad or param_grad:
             g = torch.Generator().manual_seed(77 + s)
             w = torch.randn(q.shape, generator=g).to(q.dtype)
+            for p_ in mod.parameters():
+                p_.grad = None
             (loss.sum() * 3.0 + (q * w).sum()).backward()
             arrays[f"gw{s}"] = to_np(w)
-            arrays[f"gx{s}"] = to_np(x.grad)
+            if grad:
+                arrays[f"gx{s}"] = to_np(x.grad)
+            if param_grad:
+                for pn, p_ in mod.named_parameters():
+                    if p_.grad is not None:
+                        arrays[f"pg{s}/{pn}"] = to_np(p_.grad)
     if train:
         for k, v in mod.state_dict().items():
             if not aliased(k):
@@ -141,6 +150,20 @@ if __name__ == "__main__":
              [randn(2, 60, 64, seed=31)], unit_codebook=True)
     run_case("vq_3d", VectorQuantize, dict(dim=32, codebook_size=64, accept_3d_fmap=True), [randn(1, 32, 4, 4, 4, seed=32)], unit_codebook=True)
     run_case("vq_channel_first", VectorQuantize, dict(dim=32, codebook_size=64, channel_last=False), [randn(2, 32, 50, seed=33)], unit_codebook=True)
+    # codebooks that receive gradients (search on the HIP kernel, autograd glue in torch)
+    run_case("vq_learnable", VectorQuantize, dict(dim=64, codebook_size=128, learnable_codebook=True, ema_update=False),
+             [randn(2, 100, 64, seed=40)], grad=True, param_grad=True, unit_codebook=True)
+    run_case("vq_learnable_sync_v", VectorQuantize, dict(dim=32, codebook_size=64, learnable_codebook=True, ema_update=False, sync_update_v=0.3, rotation_trick=False),
+             [randn(2, 80, 32, seed=41)], grad=True, param_grad=True, unit_codebook=True)
+    run_case("vq_orthogonal", VectorQuantize, dict(dim=32, codebook_size=64, orthogonal_reg_weight=10.),
+             [randn(2, 80, 32, seed=42)], param_grad=True, unit_codebook=True)
+    run_case("vq_inplace_opt", VectorQuantize, dict(dim=32, codebook_size=64, learnable_codebook=True, ema_update=False),
+             [randn(2, 80, 32, seed=43), randn(2, 80, 32, seed=44)], unit_codebook=True,
+             build=lambda: VectorQuantize(dim=32, codebook_size=64, learnable_codebook=True, ema_update=False,
+                                          in_place_codebook_optimizer=lambda p: torch.optim.SGD(p, lr=0.5)))
+    run_case("vq_bridge", VectorQuantize, dict(dim=32, codebook_size=64, learnable_codebook=True, ema_update=False),
+             [randn(2, 80, 32, seed=45)], grad=True, param_grad=True, unit_codebook=True,
+             build=lambda: VectorQuantize(dim=32, codebook_size=64, vq_bridge=torch.nn.Linear(32, 32)))
     run_case("vq_proj", VectorQuantize, dict(dim=48, codebook_size=64, codebook_dim=16), [randn(2, 50, 48, seed=16)], unit_codebook=True)
     # cfg 3: ResidualVQ shared codebook, scaled down
     run_case("rvq_shared", ResidualVQ, dict(dim=256, num_quantizers=8, codebook_size=256, shared_codebook=True), [randn(2, 128, 256, seed=17), randn(2, 128, 256, seed=18)])

@@ -60,6 +60,16 @@ class Fixture:
         return fk
 
 
+def build_special(name, A):
+    """fixtures whose constructor takes callables / modules (not serialisable in the fixture's kwargs)"""
+    if name == "vq_inplace_opt":
+        return A.VectorQuantize(dim=32, codebook_size=64, learnable_codebook=True, ema_update=False,
+                                in_place_codebook_optimizer=lambda p: torch.optim.SGD(p, lr=0.5))
+    if name == "vq_bridge":
+        return A.VectorQuantize(dim=32, codebook_size=64, vq_bridge=torch.nn.Linear(32, 32))
+    raise KeyError(name)
+
+
 def first_rows(samples, num):
     n = samples.shape[1]
     if n >= num:

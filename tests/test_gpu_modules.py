@@ -24,7 +24,7 @@ def _close(a, b, tol, what):
 
 def _build(fx, dev):
     import vector_quantize_pytorch_amd as A
-    mod = getattr(A, fx.meta["cls"])(**fx.kwargs)
+    mod = G.build_special(fx.name, A) if fx.meta.get("build") else getattr(A, fx.meta["cls"])(**fx.kwargs)
     missing, unexpected = mod.load_state_dict(fx.state("before"), strict=True)
     mod = mod.to(dev)
     if fx.meta["deterministic_sampling"]:
@@ -53,16 +53,25 @@ def test_module_matches_reference_golden(dev, name):
         _close(loss.reshape(-1), fx.t(f"loss{s}").reshape(-1), tol, f"loss step {s}")
         if fx.has(f"q{s}"):
             _close(q.float(), fx.t(f"q{s}").float(), tol, f"quantized step {s}")
-        elif s == 0 and not fx.meta["kwargs"].get("kmeans_init") and "codebook_dim" not in fx.meta["kwargs"]:
+        elif s == 0 and not fx.meta["kwargs"].get("kmeans_init") and "codebook_dim" not in fx.meta["kwargs"] and not fx.meta.get("build"):
             # no-grad fp32, first step: quantized is an exact copy of rows of the (identical) codebook -> bitwise (sha1)
             import hashlib
             assert hashlib.sha1(q.detach().cpu().contiguous().numpy().tobytes()).hexdigest() == fx.meta[f"qsha{s}"]
         else:   # rows of a codebook that already went through fp32 k-means / EMA arithmetic, or a projection
             want = float(fx.arr[f"qsum{s}"])
             assert abs(q.double().sum().item() - want) <= 1e-4 * max(1.0, abs(want))
-        if fx.meta["grad"]:
+        if fx.meta["grad"] or fx.meta.get("param_grad"):
+            for p_ in mod.parameters():
+                p_.grad = None
             (loss.sum() * 3.0 + (q * fx.t(f"gw{s}").to(dev)).sum()).backward()
-            _close(x.grad.float(), fx.t(f"gx{s}").float(), tol, f"grad_x step {s}")
+            if fx.meta["grad"]:
+                _close(x.grad.float(), fx.t(f"gx{s}").float(), tol, f"grad_x step {s}")
+            if fx.meta.get("param_grad"):
+                want = {k[len(f"pg{s}/"):]: fx.t(k) for k in fx.arr if k.startswith(f"pg{s}/")}
+                got = {n: p_.grad for n, p_ in mod.named_parameters() if p_.grad is not None}
+                assert set(want) == set(got), (sorted(want), sorted(got))
+                for n in want:
+                    _close(got[n].float(), want[n].float(), tol, f"grad of {n} step {s}")
     if fx.meta["train"]:
         after = fx.state("after")
         mine = mod.state_dict()
@@ -256,6 +265,8 @@ def test_errors_are_loud(dev):
         vq(torch.randn(1, 8, 64))                      # CPU tensor: no fallback
     with pytest.raises(NotImplementedError):
         VectorQuantize(dim=64, codebook_size=32, stochastic_sample_codes=True)
+    with pytest.raises(NotImplementedError):
+        VectorQuantize(dim=64, codebook_size=32, affine_param=True)
     with pytest.raises(NotImplementedError):
         VectorQuantize(dim=1024, codebook_size=32)
     vq = vq.to(dev)

@@ -85,14 +85,20 @@ def test_default_init_matches_reference_statistics():
 def test_unsupported_options_fail_loudly_and_cpu_is_refused():
     from vector_quantize_pytorch_amd import ResidualVQ, VectorQuantize
     from vector_quantize_pytorch_amd._lib import VQHipError
-    for kw in (dict(stochastic_sample_codes=True), dict(learnable_codebook=True, ema_update=False), dict(affine_param=True),
-               dict(orthogonal_reg_weight=1.), dict(codebook_diversity_loss_weight=1.), dict(directional_reparam=True, threshold_ema_dead_code=2)):
+    for kw in (dict(stochastic_sample_codes=True), dict(affine_param=True), dict(codebook_diversity_loss_weight=1.),
+               dict(commitment_use_cross_entropy_loss=True), dict(straight_through=True, rotation_trick=False)):
         with pytest.raises(NotImplementedError):
             VectorQuantize(dim=32, codebook_size=16, **kw)
     with pytest.raises(NotImplementedError):
         ResidualVQ(dim=32, num_quantizers=2, codebook_size=16, implicit_neural_codebook=True)
     with pytest.raises(AssertionError):
         ResidualVQ(dim=32, num_quantizers=2, codebook_size=16, heads=2)
+    for kw in (dict(learnable_codebook=True), dict(learnable_codebook=True, ema_update=False, use_cosine_sim=True),
+               dict(sync_update_v=0.5), dict(directional_reparam=True)):       # the reference's own cross-flag asserts
+        with pytest.raises(AssertionError):
+            VectorQuantize(dim=32, codebook_size=16, **kw)
+    vq = VectorQuantize(dim=32, codebook_size=16, learnable_codebook=True, ema_update=False)
+    assert isinstance(vq._codebook.embed, torch.nn.Parameter) and "_codebook.embed" in vq.state_dict()
     vq = VectorQuantize(dim=32, codebook_size=16)
     with pytest.raises(VQHipError, match="no CPU fallback"):
         vq(torch.randn(1, 4, 32))

@@ -110,10 +110,9 @@ class Codebook(nn.Module):
         vq_bridge: Optional[nn.Module] = None,
     ):
         super().__init__()
-        if learnable_codebook or affine_param or vq_bridge is not None:
-            raise NotImplementedError(
-                "learnable_codebook / affine_param / vq_bridge are outside the MI355X hot path (SURVEY.md §2.1, "
-                "§8f) and are not implemented in vector_quantize_pytorch_amd")
+        if affine_param:
+            raise NotImplementedError("affine_param is outside the MI355X hot path (SURVEY.md §2.1, §8f) and is not "
+                                      "implemented in vector_quantize_pytorch_amd")
         if not (1 <= dim <= 512):
             raise NotImplementedError(f"codebook dim {dim}: the HIP path supports 1 <= dim <= 512")
 
@@ -132,9 +131,9 @@ class Codebook(nn.Module):
         self.has_dead_code_replacement = threshold_ema_dead_code > 0
         self.reset_cluster_size = threshold_ema_dead_code if reset_cluster_size is None else reset_cluster_size
         self.sample_codebook_temp = sample_codebook_temp
-        self.learnable_codebook = False
+        self.learnable_codebook = learnable_codebook
         self.affine_param = False
-        self.vq_bridge = None
+        self.vq_bridge = vq_bridge
 
         self.use_ddp = use_ddp
         assert not (use_ddp and num_codebooks > 1 and kmeans_init), \
@@ -154,7 +153,10 @@ class Codebook(nn.Module):
         self.register_buffer('initted', torch.tensor(not kmeans_init))
         self.register_buffer('cluster_size', torch.ones(num_codebooks, codebook_size))
         self.register_buffer('embed_avg', embed.clone())
-        self.register_buffer('embed', embed)
+        if learnable_codebook:                     # vqp.py:419-423: same state_dict key, Parameter instead of buffer
+            self.embed = nn.Parameter(embed)
+        else:
+            self.register_buffer('embed', embed)
 
         self._initted_known = not kmeans_init     # python-side cache: no host sync per forward
 
@@ -169,7 +171,7 @@ class Codebook(nn.Module):
         return self._initted_known
 
     def _views(self, h: int):
-        return self.cluster_size[h], self.embed_avg[h], self.embed[h]
+        return self.cluster_size[h], self.embed_avg[h], self.embed.data[h]
 
     # ---- k-means initialisation (vqp.py:238-278, 450-473) -----------------------------------------
     @torch.no_grad()
@@ -232,7 +234,7 @@ class Codebook(nn.Module):
             if samples.numel() == 0:
                 continue
             picked = self.replace_sample_fn(samples[None], int(m.sum().item()))[0].to(self.embed.dtype)
-            self.embed[h][m] = picked
+            self.embed.data[h][m] = picked
             self.cluster_size[h][m] = self.reset_cluster_size
             self.embed_avg[h][m] = picked * self.reset_cluster_size
 
@@ -274,7 +276,7 @@ class Codebook(nn.Module):
     @torch.no_grad()
     def quantize(self, x: Tensor, *, mask: Optional[Tensor] = None, freeze_codebook=False,
                  ema_update_weight=None, accum_ema_update=False, ema_update=None, update_usage=True,
-                 want_sqerr=False, input_normalized=False, q_out=None):
+                 want_sqerr=False, input_normalized=False, q_out=None, embed_override=None, want_q=True):
         """x [b, n, d] (or [h, b, n, d] when num_codebooks > 1), float32 / bfloat16, RAW input: for the
         cosine metric the l2norm of vqp.py:1159 is fused into the kernel (pass input_normalized=True
         when x is already unit-norm).  Returns dict(q, idx, sqerr_partials, nblk, rnorm)."""
@@ -294,9 +296,10 @@ class Codebook(nn.Module):
                      and (ema_update or self.has_dead_code_replacement))
         outs = []
         for h in range(H):
-            e = self.embed[h]
+            # embed_override: the codebook actually searched when it is a function of the stored one (vq_bridge)
+            e = (self.embed if embed_override is None else embed_override)[h].detach().contiguous()
             packed = L.pack_codebook(e)
-            r = L.assign(xs[h], packed, e, cosine=self.use_cosine_sim, want_q=True, want_sqerr=want_sqerr,
+            r = L.assign(xs[h], packed, e, cosine=self.use_cosine_sim, want_q=want_q, want_sqerr=want_sqerr,
                          row_mask=rmask, skip_l2norm=input_normalized, want_rnorm=self.use_cosine_sim,
                          q_out=q_out if H == 1 else None)
             if do_update:
@@ -312,7 +315,7 @@ class Codebook(nn.Module):
             self.expire_codes_(xs.reshape(H, -1, self.dim), seq_mask=None if rmask is None else rmask[None].expand(H, -1).bool())
         if H == 1:
             return outs[0]
-        return dict(q=torch.stack([o["q"] for o in outs]), idx=torch.stack([o["idx"] for o in outs]),
+        return dict(q=torch.stack([o["q"] for o in outs]) if want_q else None, idx=torch.stack([o["idx"] for o in outs]),
                     sqerr_partials=None if not want_sqerr else torch.cat([o["sqerr_partials"][: o["nblk"]] for o in outs]),
                     nblk=sum(o["nblk"] for o in outs), rnorm=None)
 

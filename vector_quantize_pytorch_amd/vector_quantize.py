@@ -69,6 +69,22 @@ class _QuantizeFn(torch.autograd.Function):
         return gx, None, None, None
 
 
+class _RouteFn(torch.autograd.Function):
+    """routed value (straight-through / rotation trick) with gradient to x only -- the target is detached inside the
+    reference's formula as well (vqp.py:292-316); HIP kernels vq_route_kernel fwd / bwd."""
+
+    @staticmethod
+    def forward(ctx, x, q, mode):
+        ctx.mode = mode
+        ctx.save_for_backward(x, q)
+        return L.route_fwd(x, q, mode)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, q = ctx.saved_tensors
+        return L.route_bwd(x, q, g.contiguous(), None, None, ctx.mode), None, None
+
+
 class VectorQuantize(nn.Module):
     def __init__(
         self,
@@ -126,22 +142,27 @@ class VectorQuantize(nn.Module):
 
         unsupported = dict(
             commitment_use_cross_entropy_loss=commitment_use_cross_entropy_loss,
-            orthogonal_reg_weight=orthogonal_reg_weight > 0., codebook_diversity_loss_weight=codebook_diversity_loss_weight > 0.,
-            stochastic_sample_codes=stochastic_sample_codes, straight_through=straight_through,
-            directional_reparam=directional_reparam, vq_bridge=vq_bridge is not None, learnable_codebook=learnable_codebook,
-            in_place_codebook_optimizer=in_place_codebook_optimizer is not None, affine_param=affine_param,
-            sync_update_v=sync_update_v > 0.)
+            codebook_diversity_loss_weight=codebook_diversity_loss_weight > 0.,
+            stochastic_sample_codes=stochastic_sample_codes, straight_through=straight_through, affine_param=affine_param)
         bad = [k for k, v in unsupported.items() if v]
         if bad:
             raise NotImplementedError(
-                f"VectorQuantize options {bad} need the full N x C distance matrix, an RNG inside the kernel or a "
-                "learnable codebook; they are outside the MI355X hot path (SURVEY.md §2.1 / §8f) and are not "
-                "implemented. There is deliberately no fallback.")
+                f"VectorQuantize options {bad} need the full N x C distance matrix or an RNG inside the search; they "
+                "are outside the MI355X hot path (SURVEY.md §2.1 / §8f) and are not implemented. There is deliberately "
+                "no fallback.")
 
         # the reference's own cross-flag checks (vqp.py:884, 898-913), for identical error behaviour
         assert not (use_cosine_sim and learnable_codebook), 'cosine sim distance codebook not compatible with learnable codebook yet'
         assert sum(map(int, (straight_through, rotation_trick, directional_reparam))) <= 1
+        assert not (directional_reparam and threshold_ema_dead_code == 0), 'periodic dead code replacement should be enabled when differential reparam method is turned on'
+        assert not (ema_update and learnable_codebook), 'learnable codebook not compatible with EMA update'
+        assert not (vq_bridge is not None and not learnable_codebook), 'learnable_codebook must be set to True if vq_bridge is passed in'
+        assert not (vq_bridge is not None and ema_update), 'ema_update must be False if vq_bridge is passed in'
         assert 0 <= sync_update_v <= 1.
+        assert not (sync_update_v > 0. and not learnable_codebook), 'learnable codebook must be turned on'
+        has_orth = orthogonal_reg_weight > 0.
+        if (learnable_codebook or has_orth) and separate_codebook_per_head:
+            raise NotImplementedError("a learnable / orthogonally regularised codebook with separate_codebook_per_head is not implemented")
 
         self.dim = dim
         self.heads = heads
@@ -162,9 +183,16 @@ class VectorQuantize(nn.Module):
         self.has_projections = requires_projection
 
         self.eps = eps
-        self.has_commitment_loss = commitment_weight > 0.
+        self.has_commitment_loss = commitment_weight > 0. and not directional_reparam
         self.commitment_weight = commitment_weight
-        self.learnable_codebook = False
+        self.learnable_codebook = learnable_codebook
+        self.has_codebook_orthogonal_loss = has_orth
+        self.orthogonal_reg_weight = orthogonal_reg_weight
+        self.orthogonal_reg_active_codes_only = orthogonal_reg_active_codes_only
+        self.orthogonal_reg_max_codes = orthogonal_reg_max_codes
+        self.directional_reparam = directional_reparam
+        self.directional_reparam_variance = directional_reparam_variance
+        self.sync_update_v = sync_update_v
         self.rotation_trick = rotation_trick
         self.route_gradients_to_input = route_gradients_to_input
         self.use_cosine_sim = use_cosine_sim
@@ -193,8 +221,12 @@ class VectorQuantize(nn.Module):
             ema_update=ema_update,
             manual_ema_update=manual_ema_update,
             use_cosine_sim=use_cosine_sim,
+            learnable_codebook=has_orth or learnable_codebook,           # vqp.py:939
+            vq_bridge=vq_bridge,
         )
-        self.in_place_codebook_optimizer = None
+        self.in_place_codebook_optimizer = in_place_codebook_optimizer(self._codebook.parameters()) \
+            if in_place_codebook_optimizer is not None else None
+        self.manual_in_place_optimizer_update = manual_in_place_optimizer_update
         self.register_buffer('zero', torch.tensor(0.), persistent=False)
 
     # ---- reference-compatible accessors (vqp.py:978-1022) -----------------------------------------
@@ -235,8 +267,66 @@ class VectorQuantize(nn.Module):
             return self.project_out(codes.movedim(1, -1)).movedim(-1, 1)
         return self.project_out(codes)
 
-    def update_in_place_optimizer(self):
-        return  # no learnable codebook on this path
+    def update_in_place_optimizer(self):                                     # vqp.py:1024-1042
+        if self.in_place_codebook_optimizer is None:
+            return
+        if self._codebook.use_ddp:
+            for param in self._codebook.parameters():
+                if param.grad is not None:
+                    dist.all_reduce(param.grad)
+                    param.grad /= dist.get_world_size()
+        self.in_place_codebook_optimizer.step()
+        self.in_place_codebook_optimizer.zero_grad()
+
+    # ---- codebooks that receive gradients (learnable / orthogonal reg / vq_bridge / in-place optimizer) ----
+    # The nearest-code search still runs on the HIP kernel (no gradient flows through an argmin); what changes is
+    # that `quantize` is a differentiable gather of the (possibly bridged) codebook parameter and that the losses
+    # are built from autograd ops.  Reference: vqp.py:710-717 (learnable embed / bridge), :1186-1237.
+    def _forward_param_codebook(self, xs, rmask, freeze_codebook, kw):
+        cb = self._codebook
+        embed_eff = cb.embed if cb.vq_bridge is None else cb.vq_bridge(cb.embed)      # [1, C, D]
+        if not cb.learnable_codebook:
+            embed_eff = embed_eff.detach()
+
+        def search(update_usage=True):
+            r = cb.quantize(xs.detach(), mask=rmask, embed_override=embed_eff, update_usage=update_usage, **kw)
+            # value: the rows of the PRE-update codebook (the EMA fold inside quantize() runs after the gather, like
+            # vqp.py:766 vs :783); gradient: that of a gather from the parameter (vqp.py:710, 766)
+            g = F.embedding(r["idx"], embed_eff[0]).to(xs.dtype)
+            q = r["q"] + (g - g.detach()) if embed_eff.requires_grad else r["q"]
+            return q, r["idx"]
+
+        quantize, embed_ind = search()
+        inplace_loss = self.zero
+        if self.in_place_codebook_optimizer is not None and self.training and not freeze_codebook:   # vqp.py:1186-1210
+            if rmask is not None:
+                l = F.mse_loss(quantize, xs.detach(), reduction='none')[rmask].mean()
+            else:
+                l = F.mse_loss(quantize, xs.detach())
+            l.backward()
+            if not self.manual_in_place_optimizer_update:
+                self.update_in_place_optimizer()
+            inplace_loss = l
+            embed_eff = cb.embed if cb.vq_bridge is None else cb.vq_bridge(cb.embed)
+            quantize, embed_ind = search(update_usage=False)
+
+        commit_quantize = quantize
+        if self.training:
+            if not self.learnable_codebook or freeze_codebook:
+                commit_quantize = quantize.detach()
+            if xs.requires_grad and self.route_gradients_to_input and torch.is_grad_enabled():
+                if self.rotation_trick:
+                    quantize = _RouteFn.apply(xs, quantize.detach(), L.ROTATION)     # no gradient reaches the target (vqp.py:292-316)
+                elif self.directional_reparam:                                        # vqp.py:323-330
+                    err = quantize - xs
+                    nrm = err.norm(dim=-1, keepdim=True)
+                    noised = err + (self.directional_reparam_variance ** 0.5) * torch.randn_like(err)
+                    quantize = xs + F.normalize(noised, p=2, dim=-1, eps=1e-6).detach() * nrm
+                else:
+                    quantize = xs + (quantize - xs).detach()
+            if self.sync_update_v > 0.:                                               # vqp.py:1235-1237
+                quantize = quantize + self.sync_update_v * (quantize - quantize.detach())
+        return quantize, embed_ind, commit_quantize, inplace_loss
 
     def _split_heads(self, x):
         if self.heads == 1:
@@ -331,12 +421,36 @@ class VectorQuantize(nn.Module):
 
         kw = dict(freeze_codebook=freeze_codebook, ema_update_weight=ema_update_weight,
                   accum_ema_update=accum_ema_update, ema_update=ema_update, input_normalized=pre_normalized)
-        quantize, embed_ind, sq_sum = _QuantizeFn.apply(xs, self, rmask, kw)
+        param_path = self._codebook.learnable_codebook or self._codebook.vq_bridge is not None or self.directional_reparam
+        inplace_loss = orth_loss = self.zero
+        if param_path:
+            quantize, embed_ind, commit_quantize, inplace_loss = self._forward_param_codebook(xs, rmask, freeze_codebook, kw)
+        else:
+            quantize, embed_ind, sq_sum = _QuantizeFn.apply(xs, self, rmask, kw)
 
-        # ---- loss (vqp.py:1282-1329) --------------------------------------------------------------
+        # ---- loss (vqp.py:1282-1348) --------------------------------------------------------------
         loss = torch.zeros((), device=x.device, dtype=torch.float32, requires_grad=self.training)
         commit_loss = self.zero
-        if self.training and self.has_commitment_loss:
+        if self.training and param_path:
+            if self.has_commitment_loss:
+                if mask is not None:
+                    commit_loss = F.mse_loss(commit_quantize, orig_input if xs.shape == orig_input.shape else xs, reduction='none')[rmask].mean()
+                else:
+                    commit_loss = F.mse_loss(commit_quantize, xs)
+                loss = loss + commit_loss * self.commitment_weight
+            if self.has_codebook_orthogonal_loss:                                     # vqp.py:1331-1348, 340-345
+                codebook = self._codebook.embed
+                if self.orthogonal_reg_active_codes_only:
+                    codebook = codebook[:, torch.unique(embed_ind)]
+                ncodes = codebook.shape[-2]
+                if self.orthogonal_reg_max_codes is not None and ncodes > self.orthogonal_reg_max_codes:
+                    codebook = codebook[:, torch.randperm(ncodes, device=x.device)[:self.orthogonal_reg_max_codes]]
+                normed = F.normalize(codebook, p=2, dim=-1, eps=1e-6)
+                cos = torch.einsum('hid,hjd->hij', normed, normed)
+                h_, n_ = codebook.shape[:2]
+                orth_loss = (cos ** 2).sum() / (h_ * n_ ** 2) - (1 / n_)
+                loss = loss + orth_loss * self.orthogonal_reg_weight
+        elif self.training and self.has_commitment_loss:
             d = xs.shape[-1]
             if mask is None:
                 commit_loss = sq_sum / float(xs.numel())
@@ -378,4 +492,4 @@ class VectorQuantize(nn.Module):
 
         if not return_loss_breakdown:
             return quantize, embed_ind, loss
-        return quantize, embed_ind, loss, LossBreakdown(commit_loss, self.zero, self.zero, self.zero)
+        return quantize, embed_ind, loss, LossBreakdown(commit_loss, self.zero, orth_loss, inplace_loss)
