@@ -24,7 +24,7 @@ sys.path.insert(0, ROOT)
 import numpy as np
 import torch
 
-from vector_quantize_pytorch import GroupedResidualVQ, ResidualVQ, VectorQuantize  # the live reference
+from vector_quantize_pytorch import GroupedResidualVQ, ResidualSimVQ, ResidualVQ, SimVQ, VectorQuantize  # the live reference
 
 
 def first_rows(samples, num):           # deterministic stand-in for batched_sample_vectors (vqp.py:165)
@@ -164,6 +164,11 @@ if __name__ == "__main__":
     run_case("vq_bridge", VectorQuantize, dict(dim=32, codebook_size=64, learnable_codebook=True, ema_update=False),
              [randn(2, 80, 32, seed=45)], grad=True, param_grad=True, unit_codebook=True,
              build=lambda: VectorQuantize(dim=32, codebook_size=64, vq_bridge=torch.nn.Linear(32, 32)))
+    # SimVQ / ResidualSimVQ (torch.cdist + argmin on an implicit codebook)
+    run_case("simvq", SimVQ, dict(dim=64, codebook_size=256), [randn(2, 150, 64, seed=50)], grad=True, param_grad=True)
+    run_case("simvq_ste_channel_first", SimVQ, dict(dim=32, codebook_size=128, rotation_trick=False, channel_first=True),
+             [randn(2, 32, 6, 6, seed=51)], grad=True, param_grad=True)
+    run_case("residual_simvq", ResidualSimVQ, dict(dim=64, num_quantizers=4, codebook_size=128), [randn(2, 100, 64, seed=52)], grad=True, param_grad=True)
     run_case("vq_proj", VectorQuantize, dict(dim=48, codebook_size=64, codebook_dim=16), [randn(2, 50, 48, seed=16)], unit_codebook=True)
     # cfg 3: ResidualVQ shared codebook, scaled down
     run_case("rvq_shared", ResidualVQ, dict(dim=256, num_quantizers=8, codebook_size=256, shared_codebook=True), [randn(2, 128, 256, seed=17), randn(2, 128, 256, seed=18)])

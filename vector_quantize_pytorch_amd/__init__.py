@@ -4,5 +4,6 @@ include/vqhip.h."""
 from .codebook import Codebook
 from .vector_quantize import VectorQuantize, LossBreakdown
 from .residual_vq import ResidualVQ, GroupedResidualVQ
+from .sim_vq import SimVQ, ResidualSimVQ
 
-__all__ = ["VectorQuantize", "ResidualVQ", "GroupedResidualVQ", "Codebook", "LossBreakdown"]
+__all__ = ["VectorQuantize", "ResidualVQ", "GroupedResidualVQ", "SimVQ", "ResidualSimVQ", "Codebook", "LossBreakdown"]
