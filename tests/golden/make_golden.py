@@ -24,7 +24,8 @@ sys.path.insert(0, ROOT)
 import numpy as np
 import torch
 
-from vector_quantize_pytorch import GroupedResidualVQ, ResidualSimVQ, ResidualVQ, SimVQ, VectorQuantize  # the live reference
+from vector_quantize_pytorch import (GroupedResidualVQ, HierarchicalVQ, RandomProjectionQuantizer, ResidualSimVQ, ResidualVQ, SimVQ,
+                                     VectorQuantize)  # the live reference
 
 
 def first_rows(samples, num):           # deterministic stand-in for batched_sample_vectors (vqp.py:165)
@@ -92,7 +93,11 @@ def run_case(name, cls, kwargs, xs, *, train=True, fwd_kwargs=None, grad=False, 
         if grad:
             x.requires_grad_(True)
         res = mod(x, **fk)
+        if torch.is_tensor(res):                      # RandomProjectionQuantizer returns indices only
+            res = (torch.zeros(1), res, torch.zeros(()))
         q, idx, loss = res[0], res[1], res[2]
+        if isinstance(idx, tuple):                    # HierarchicalVQ: one index map per scale
+            idx = torch.cat([i.flatten(1) for i in idx], 1)
         arrays[f"x{s}"] = to_np(x)
         arrays[f"idx{s}"] = to_np(idx)
         arrays[f"loss{s}"] = to_np(loss.float())
@@ -169,6 +174,13 @@ if __name__ == "__main__":
     run_case("simvq_ste_channel_first", SimVQ, dict(dim=32, codebook_size=128, rotation_trick=False, channel_first=True),
              [randn(2, 32, 6, 6, seed=51)], grad=True, param_grad=True)
     run_case("residual_simvq", ResidualSimVQ, dict(dim=64, num_quantizers=4, codebook_size=128), [randn(2, 100, 64, seed=52)], grad=True, param_grad=True)
+    # callers
+    run_case("rpq", RandomProjectionQuantizer, dict(dim=64, codebook_size=32, codebook_dim=16, num_codebooks=4), [randn(2, 50, 64, seed=60)])
+    run_case("hvq", HierarchicalVQ, dict(dim=32, codebook_size=64, scales=(1, 2, 4, 8), accept_image_fmap=True),
+             [randn(2, 32, 8, 8, seed=61), randn(2, 32, 8, 8, seed=62)], deterministic_sampling=True)
+    run_case("hvq_nokmeans", HierarchicalVQ, dict(dim=32, codebook_size=64, scales=(2, 4), kmeans_init=False, threshold_ema_dead_code=0,
+                                                  rotation_trick=True, share_quant_resi=2, accept_image_fmap=True),
+             [randn(2, 32, 8, 8, seed=63)], grad=True, unit_codebook=True)
     run_case("vq_proj", VectorQuantize, dict(dim=48, codebook_size=64, codebook_dim=16), [randn(2, 50, 48, seed=16)], unit_codebook=True)
     # cfg 3: ResidualVQ shared codebook, scaled down
     run_case("rvq_shared", ResidualVQ, dict(dim=256, num_quantizers=8, codebook_size=256, shared_codebook=True), [randn(2, 128, 256, seed=17), randn(2, 128, 256, seed=18)])

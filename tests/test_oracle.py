@@ -22,7 +22,7 @@ def _close(a, b, tol, what):
 # layout / projection / multi-head fixtures are module-level only (checked on the GPU against the fixture itself)
 _MODULE_ONLY = ("vq_fmap", "vq_proj", "vq_heads", "vq_heads_sep", "vq_3d", "vq_channel_first",
                 "vq_learnable", "vq_learnable_sync_v", "vq_orthogonal", "vq_inplace_opt", "vq_bridge",
-                "simvq", "simvq_ste_channel_first", "residual_simvq")
+                "simvq", "simvq_ste_channel_first", "residual_simvq", "rpq", "hvq", "hvq_nokmeans")
 
 
 @pytest.mark.parametrize("name", [n for n in G.names() if n not in _MODULE_ONLY])
