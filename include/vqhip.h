@@ -74,6 +74,15 @@ int vqhip_assign(const void *x, int x_dtype, int64_t N, int D, int64_t ldx,
                  float *best_out, float *rnorm_out, double *sqerr_partial,
                  const uint8_t *row_mask, void *stream);
 
+/* ---- dense scores (rare options only) ------------------------------------------------------------
+ * Materialises the tensor the reference calls `dist` (vqp.py:741-743): scores_out[n, c] = -cdist(x_n, c) for the
+ * Euclidean metric (same rounding sequence as vqhip_assign), x^_n . c for cosine.  Needed by the options that read
+ * the whole row: top-k / beam search (vqp.py:137-138), gumbel sampling (:132-133), cross-entropy / diversity losses
+ * (:1242-1261, :1287-1292).  idx_out [N] (argmax) must be given; rnorm_out as in vqhip_assign. */
+int vqhip_scores(const void *x, int x_dtype, int64_t N, int D, int64_t ldx,
+                 const float *packed, const float *embed, int C, int metric,
+                 float *scores_out, int64_t lds, int64_t *idx_out, float *rnorm_out, void *stream);
+
 /* ---- fused residual VQ loop ---------------------------------------------------------------------
  * Replaces the per-quantizer loop of ResidualVQ.forward (rvq.py:469-568) for the Euclidean metric and a
  * uniform codebook size: Q successive nearest-code searches on the running residual, which stays in

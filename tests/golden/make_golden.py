@@ -88,6 +88,8 @@ def run_case(name, cls, kwargs, xs, *, train=True, fwd_kwargs=None, grad=False, 
     fk = dict(fwd_kwargs or {})
     if "lens" in fk:
         fk["lens"] = torch.tensor(fk["lens"])
+    if "indices" in fk:
+        fk["indices"] = torch.tensor(fk["indices"])
     for s, x in enumerate(xs):
         x = x.clone()
         if grad:
@@ -95,6 +97,8 @@ def run_case(name, cls, kwargs, xs, *, train=True, fwd_kwargs=None, grad=False, 
         res = mod(x, **fk)
         if torch.is_tensor(res):                      # RandomProjectionQuantizer returns indices only
             res = (torch.zeros(1), res, torch.zeros(()))
+        if len(res) == 2:                             # forward(indices=...) returns (quantize, cross-entropy loss)
+            res = (res[0], torch.zeros(1, dtype=torch.long), res[1])
         q, idx, loss = res[0], res[1], res[2]
         if isinstance(idx, tuple):                    # HierarchicalVQ: one index map per scale
             idx = torch.cat([i.flatten(1) for i in idx], 1)
@@ -181,6 +185,20 @@ if __name__ == "__main__":
     run_case("hvq_nokmeans", HierarchicalVQ, dict(dim=32, codebook_size=64, scales=(2, 4), kmeans_init=False, threshold_ema_dead_code=0,
                                                   rotation_trick=True, share_quant_resi=2, accept_image_fmap=True),
              [randn(2, 32, 8, 8, seed=63)], grad=True, unit_codebook=True)
+    # options that read the whole distance row
+    run_case("vq_ce_commit", VectorQuantize, dict(dim=32, codebook_size=64, commitment_use_cross_entropy_loss=True),
+             [randn(2, 80, 32, seed=70)], grad=True, unit_codebook=True)
+    run_case("vq_diversity", VectorQuantize, dict(dim=32, codebook_size=64, codebook_diversity_loss_weight=0.5, codebook_diversity_temperature=10.),
+             [randn(2, 80, 32, seed=71)], grad=True, unit_codebook=True)
+    run_case("vq_topk", VectorQuantize, dict(dim=32, codebook_size=64), [randn(2, 40, 32, seed=72)], fwd_kwargs=dict(topk=3), unit_codebook=True)
+    run_case("vq_topk_cos", VectorQuantize, dict(dim=32, codebook_size=64, use_cosine_sim=True), [randn(2, 40, 32, seed=73)],
+             fwd_kwargs=dict(topk=2))       # (the reference's eval-mode gather does not support topk)
+    run_case("vq_indices_ce", VectorQuantize, dict(dim=32, codebook_size=64), [randn(2, 40, 32, seed=74)],
+             fwd_kwargs=dict(indices=torch.randint(0, 64, (2, 40), generator=torch.Generator().manual_seed(5)).tolist()), grad=True, unit_codebook=True)
+    run_case("vq_stochastic_temp0", VectorQuantize, dict(dim=32, codebook_size=64, stochastic_sample_codes=True, sample_codebook_temp=0.),
+             [randn(2, 80, 32, seed=75)], unit_codebook=True)
+    run_case("vq_gumbel_st", VectorQuantize, dict(dim=32, codebook_size=64, straight_through=True, rotation_trick=False, sample_codebook_temp=0.5),
+             [randn(2, 80, 32, seed=76)], grad=True, unit_codebook=True)
     run_case("vq_proj", VectorQuantize, dict(dim=48, codebook_size=64, codebook_dim=16), [randn(2, 50, 48, seed=16)], unit_codebook=True)
     # cfg 3: ResidualVQ shared codebook, scaled down
     run_case("rvq_shared", ResidualVQ, dict(dim=256, num_quantizers=8, codebook_size=256, shared_codebook=True), [randn(2, 128, 256, seed=17), randn(2, 128, 256, seed=18)])

@@ -57,6 +57,8 @@ class Fixture:
         fk = dict(self.meta["fwd_kwargs"])
         if "lens" in fk:
             fk["lens"] = torch.tensor(fk["lens"], device=device)
+        if "indices" in fk:
+            fk["indices"] = torch.tensor(fk["indices"], device=device)
         return fk
 
 

@@ -268,3 +268,18 @@ def test_assign_exact_duplicates_and_zero_rows(dev):
     e2 = torch.ones(40, 32) * 0.5                     # every code identical: index 0 must win everywhere
     r2 = L.assign(torch.randn(100, 32, generator=g).to(dev), L.pack_codebook(e2.to(dev)), e2.to(dev))
     assert int(r2["idx"].max()) == 0
+
+
+@pytest.mark.parametrize("N,C,D,cos", [(300, 100, 64, False), (257, 33, 256, False), (128, 512, 128, True), (77, 40, 100, False)])
+def test_dense_scores_match_oracle_bitwise(dev, N, C, D, cos):
+    """vqhip_scores == the reference's `dist` tensor in the oracle's chain arithmetic (-cdist / cosine similarity)."""
+    from vector_quantize_pytorch_amd import _lib as L
+    x, e = _mk(N, C, D, unit=True)
+    if cos:
+        e = O.l2norm(e)
+    ed = e.to(dev)
+    dist, idx, _ = L.scores(x.to(dev), L.pack_codebook(ed), ed, cosine=cos)
+    xo = O.c_l2norm(x) if cos else x
+    want = O.c_scores(xo, e, cos)
+    assert torch.equal(dist.cpu(), want)
+    assert torch.equal(idx.cpu(), want.argmax(-1))

@@ -85,8 +85,8 @@ def test_default_init_matches_reference_statistics():
 def test_unsupported_options_fail_loudly_and_cpu_is_refused():
     from vector_quantize_pytorch_amd import ResidualVQ, VectorQuantize
     from vector_quantize_pytorch_amd._lib import VQHipError
-    for kw in (dict(stochastic_sample_codes=True), dict(affine_param=True), dict(codebook_diversity_loss_weight=1.),
-               dict(commitment_use_cross_entropy_loss=True), dict(straight_through=True, rotation_trick=False)):
+    for kw in (dict(affine_param=True), dict(stochastic_sample_codes=True, heads=2, codebook_dim=16),
+               dict(commitment_use_cross_entropy_loss=True, heads=2, codebook_dim=16)):
         with pytest.raises(NotImplementedError):
             VectorQuantize(dim=32, codebook_size=16, **kw)
     with pytest.raises(NotImplementedError):
@@ -103,7 +103,7 @@ def test_unsupported_options_fail_loudly_and_cpu_is_refused():
     with pytest.raises(VQHipError, match="no CPU fallback"):
         vq(torch.randn(1, 4, 32))
     with pytest.raises(NotImplementedError):
-        vq(torch.randn(1, 4, 32), topk=2)
+        vq(torch.randn(1, 4, 32), codebook_transform_fn=lambda e: e)
 
 
 def test_product_never_imports_the_oracle():

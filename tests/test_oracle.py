@@ -22,7 +22,8 @@ def _close(a, b, tol, what):
 # layout / projection / multi-head fixtures are module-level only (checked on the GPU against the fixture itself)
 _MODULE_ONLY = ("vq_fmap", "vq_proj", "vq_heads", "vq_heads_sep", "vq_3d", "vq_channel_first",
                 "vq_learnable", "vq_learnable_sync_v", "vq_orthogonal", "vq_inplace_opt", "vq_bridge",
-                "simvq", "simvq_ste_channel_first", "residual_simvq", "rpq", "hvq", "hvq_nokmeans")
+                "simvq", "simvq_ste_channel_first", "residual_simvq", "rpq", "hvq", "hvq_nokmeans",
+                "vq_ce_commit", "vq_diversity", "vq_topk", "vq_topk_cos", "vq_indices_ce", "vq_stochastic_temp0", "vq_gumbel_st")
 
 
 @pytest.mark.parametrize("name", [n for n in G.names() if n not in _MODULE_ONLY])

@@ -47,6 +47,8 @@ def lib():
     L.vqhip_reduce_partials.argtypes = [vp, i64, f64, vp, vp]
     L.vqhip_rvq_forward.argtypes = [vp, i32, i64, i32, i64, vp, i64, vp, i64, i32, i32, vp, vp, vp, vp, vp]
     L.vqhip_rvq_forward.restype = i32
+    L.vqhip_scores.argtypes = [vp, i32, i64, i32, i64, vp, vp, i32, i32, vp, i64, vp, vp, vp]
+    L.vqhip_scores.restype = i32
     L.vqhip_route_fwd.argtypes = [vp, vp, i32, i64, i32, i64, i64, vp, i64, i32, vp]
     L.vqhip_route_bwd.argtypes = [vp, vp, vp, i32, i64, i32, i64, i64, i64, vp, vp, i32, vp, i64, vp]
     L.vqhip_route_fwd.restype = i32
@@ -65,7 +67,7 @@ def lib():
 
 
 EXPORTS = ("vqhip_version", "vqhip_last_error", "vqhip_packed_bytes", "vqhip_pack_codebook",
-           "vqhip_assign_blocks", "vqhip_assign", "vqhip_rvq_forward", "vqhip_reduce_partials", "vqhip_ema_workspace_bytes", "vqhip_ema_accumulate",
+           "vqhip_assign_blocks", "vqhip_assign", "vqhip_scores", "vqhip_rvq_forward", "vqhip_reduce_partials", "vqhip_ema_workspace_bytes", "vqhip_ema_accumulate",
            "vqhip_ema_finalize", "vqhip_decode_sum", "vqhip_row_sumsq", "vqhip_route_fwd", "vqhip_route_bwd")
 
 
@@ -168,6 +170,21 @@ def assign(x: torch.Tensor, packed: torch.Tensor, embed2d: torch.Tensor, *, cosi
     elif partials is not None:
         partials.zero_()
     return dict(idx=idx, q=q, sqerr_partials=partials, best=best, rnorm=rnorm, nblk=nblk)
+
+
+def scores(x: torch.Tensor, packed: torch.Tensor, embed2d: torch.Tensor, *, cosine=False, skip_l2norm=False):
+    """x [..., D] -> (dist [..., C] fp32 = -cdist or cosine similarity, argmax idx [...], rnorm).  Rare options only."""
+    _need_gpu(x, packed, embed2d)
+    xk, N, D, ldx = as_rows(x)
+    C = embed2d.shape[0]
+    out = torch.empty(*x.shape[:-1], C, dtype=torch.float32, device=x.device)
+    idx = torch.empty(x.shape[:-1], dtype=torch.int64, device=x.device)
+    rnorm = torch.empty(x.shape[:-1], dtype=torch.float32, device=x.device)
+    if N > 0:
+        metric = (COSINE_PRENORM if skip_l2norm else COSINE) if cosine else EUCLID
+        _check(lib().vqhip_scores(_ptr(xk), _dtype_code(xk), N, D, ldx, _ptr(packed), _ptr(embed2d), C, metric,
+                                  _ptr(out), C, _ptr(idx), _ptr(rnorm), _stream()), "vqhip_scores")
+    return out, idx, rnorm
 
 
 def rvq_forward(x: torch.Tensor, packed: torch.Tensor, embed: torch.Tensor, Q: int, *, want_resid=False,

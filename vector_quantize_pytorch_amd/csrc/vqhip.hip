@@ -335,6 +335,8 @@ struct AssignArgs {
     float *rnorm_out;
     double *sqerr_partial;
     const uint8_t *row_mask;
+    float *scores_out;  // nullable [N, lds]: the reference's `dist` tensor (-cdist or cosine similarity), rare options only
+    int64_t lds;
     int x_vec;  // 1: D == DT and x rows are vector-load aligned
     int q_vec;  // 1: D == DT and q rows are vector-store aligned
     int skip_norm;  // cosine: rows are already unit-norm
@@ -482,6 +484,19 @@ __global__ void __launch_bounds__(256, (DT <= 256 ? 2 : 1)) vq_assign_kernel(con
         VQ_STAMP(2);
         argmin_tile<METRIC>(acc, (const float *)tile + 32 * DT, x2, ct * 32, hi, a.C, bd, bs, bi);
         VQ_STAMP(3);
+        if (a.scores_out) {   // cold path: materialise dist[row, code] (vqp.py:741-743) for top-k / sampling / CE / diversity
+            const float *y2s = (const float *)tile + 32 * DT;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int code = ct * 32 + 8 * (e >> 2) + 4 * hi + (e & 3);
+                float v = acc[e];
+                if (METRIC == 0) {
+                    const float t = x2 + y2s[8 * (e >> 2) + 4 * hi + (e & 3)];
+                    v = -sqrtf(fmaxf(__builtin_fmaf(-2.0f, v, t), 1e-8f));
+                }
+                if (row_ok && code < a.C) a.scores_out[row * a.lds + code] = v;
+            }
+        }
     }
 
     // ---- merge the two half-waves (same row, disjoint code subsets) ------------------------------
@@ -683,11 +698,36 @@ extern "C" int vqhip_row_sumsq(const void *x, int x_dtype, int64_t N, int D, int
     return launch_status("vq_row_sumsq_kernel");
 }
 
+static int assign_impl(const void *x, int x_dtype, int64_t N, int D, int64_t ldx,
+                       const float *packed, const float *embed, int C, int metric,
+                       int64_t *idx_out, void *q_out, int q_dtype, int64_t ldq,
+                       float *best_out, float *rnorm_out, double *sqerr_partial,
+                       const uint8_t *row_mask, float *scores_out, int64_t lds, void *stream);
+
 extern "C" int vqhip_assign(const void *x, int x_dtype, int64_t N, int D, int64_t ldx,
                             const float *packed, const float *embed, int C, int metric,
                             int64_t *idx_out, void *q_out, int q_dtype, int64_t ldq,
                             float *best_out, float *rnorm_out, double *sqerr_partial,
                             const uint8_t *row_mask, void *stream)
+{
+    return assign_impl(x, x_dtype, N, D, ldx, packed, embed, C, metric, idx_out, q_out, q_dtype, ldq, best_out, rnorm_out,
+                       sqerr_partial, row_mask, nullptr, 0, stream);
+}
+
+extern "C" int vqhip_scores(const void *x, int x_dtype, int64_t N, int D, int64_t ldx,
+                            const float *packed, const float *embed, int C, int metric,
+                            float *scores_out, int64_t lds, int64_t *idx_out, float *rnorm_out, void *stream)
+{
+    if (!scores_out || lds < C) VQ_FAIL(VQHIP_EINVAL, "scores: scores_out null or row stride smaller than C");
+    return assign_impl(x, x_dtype, N, D, ldx, packed, embed, C, metric, idx_out, nullptr, VQHIP_F32, D, nullptr, rnorm_out,
+                       nullptr, nullptr, scores_out, lds, stream);
+}
+
+static int assign_impl(const void *x, int x_dtype, int64_t N, int D, int64_t ldx,
+                            const float *packed, const float *embed, int C, int metric,
+                            int64_t *idx_out, void *q_out, int q_dtype, int64_t ldq,
+                            float *best_out, float *rnorm_out, double *sqerr_partial,
+                            const uint8_t *row_mask, float *scores_out, int64_t lds, void *stream)
 {
     if (N < 0 || C <= 0) VQ_FAIL(VQHIP_EINVAL, "assign: N < 0 or C <= 0");
     if (N == 0) return 0;
@@ -716,6 +756,7 @@ extern "C" int vqhip_assign(const void *x, int x_dtype, int64_t N, int D, int64_
 #ifdef VQ_TRACE
     a.trace = g_trace;
 #endif
+    a.scores_out = scores_out; a.lds = lds;
     a.best_out = best_out; a.rnorm_out = rnorm_out; a.sqerr_partial = sqerr_partial; a.row_mask = row_mask;
     const int xes = (x_dtype == VQHIP_BF16) ? 2 : 4;
     a.x_vec = (D == DT) && (((uintptr_t)x) % (4 * xes) == 0) && ((ldx * xes) % (4 * xes) == 0) && ((((uintptr_t)embed) & 15) == 0);

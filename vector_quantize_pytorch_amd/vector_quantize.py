@@ -85,6 +85,38 @@ class _RouteFn(torch.autograd.Function):
         return L.route_bwd(x, q, g.contiguous(), None, None, ctx.mode), None, None
 
 
+class _ScoresFn(torch.autograd.Function):
+    """dist [b, n, C] = -cdist(x, embed) (Euclidean) or x . embed^T (cosine, x already unit-norm): forward on the HIP
+    kernel (vqhip_scores, the reference's rounding sequence), backward = the closed-form gradients of vqp.py:58-62 /
+    :741 as two GEMMs:  d(-d_ij)/dx_i = (c_j - x_i) / d_ij,  d(-d_ij)/dc_j = (x_i - c_j) / d_ij  (zero where the
+    clamp(min=1e-8) is active).  Only the rare options that read the whole row use it."""
+
+    @staticmethod
+    def forward(ctx, x, embed, cosine):
+        e = embed.detach().float().contiguous()
+        dist, _, _ = L.scores(x.detach(), L.pack_codebook(e), e, cosine=cosine, skip_l2norm=True)
+        ctx.cosine = cosine
+        ctx.save_for_backward(x, embed, dist)
+        return dist
+
+    @staticmethod
+    def backward(ctx, g):
+        x, embed, dist = ctx.saved_tensors
+        xf, ef = x.float().reshape(-1, x.shape[-1]), embed.float()
+        g2 = g.reshape(-1, g.shape[-1]).float()
+        if ctx.cosine:
+            gx, ge = g2 @ ef, g2.t() @ xf
+        else:
+            d = -dist.reshape(g2.shape)
+            w = torch.where(d > 1.0001e-4, g2 / d, torch.zeros_like(g2))        # sqrt(1e-8) = 1e-4: clamp active -> zero gradient
+            gx = w @ ef - w.sum(-1, keepdim=True) * xf
+            ge = w.sum(0)[:, None] * ef - w.t() @ xf
+            ge = -ge
+        gx = gx.reshape(x.shape).to(x.dtype) if ctx.needs_input_grad[0] else None
+        ge = ge.to(embed.dtype) if ctx.needs_input_grad[1] else None
+        return gx, ge, None
+
+
 class VectorQuantize(nn.Module):
     def __init__(
         self,
@@ -140,20 +172,19 @@ class VectorQuantize(nn.Module):
         learnable_codebook = (directional_reparam or vq_bridge is not None) if learnable_codebook is None else learnable_codebook
         rotation_trick = (not directional_reparam and dim > 1) if rotation_trick is None else rotation_trick
 
-        unsupported = dict(
-            commitment_use_cross_entropy_loss=commitment_use_cross_entropy_loss,
-            codebook_diversity_loss_weight=codebook_diversity_loss_weight > 0.,
-            stochastic_sample_codes=stochastic_sample_codes, straight_through=straight_through, affine_param=affine_param)
-        bad = [k for k, v in unsupported.items() if v]
-        if bad:
-            raise NotImplementedError(
-                f"VectorQuantize options {bad} need the full N x C distance matrix or an RNG inside the search; they "
-                "are outside the MI355X hot path (SURVEY.md §2.1 / §8f) and are not implemented. There is deliberately "
-                "no fallback.")
+        if affine_param:
+            raise NotImplementedError("affine_param is outside the MI355X hot path (SURVEY.md §2.1 / §8f) and is not implemented; "
+                                      "there is deliberately no fallback.")
+        dense_options = (commitment_use_cross_entropy_loss or codebook_diversity_loss_weight > 0. or stochastic_sample_codes
+                         or straight_through)
+        if dense_options and (heads > 1):
+            raise NotImplementedError("options that read the full distance row (cross-entropy / diversity losses, gumbel sampling) "
+                                      "are implemented for heads == 1 only")
 
         # the reference's own cross-flag checks (vqp.py:884, 898-913), for identical error behaviour
         assert not (use_cosine_sim and learnable_codebook), 'cosine sim distance codebook not compatible with learnable codebook yet'
         assert sum(map(int, (straight_through, rotation_trick, directional_reparam))) <= 1
+        assert not (straight_through and learnable_codebook), 'gumbel straight through not allowed when learning the codebook'
         assert not (directional_reparam and threshold_ema_dead_code == 0), 'periodic dead code replacement should be enabled when differential reparam method is turned on'
         assert not (ema_update and learnable_codebook), 'learnable codebook not compatible with EMA update'
         assert not (vq_bridge is not None and not learnable_codebook), 'learnable_codebook must be set to True if vq_bridge is passed in'
@@ -193,6 +224,12 @@ class VectorQuantize(nn.Module):
         self.directional_reparam = directional_reparam
         self.directional_reparam_variance = directional_reparam_variance
         self.sync_update_v = sync_update_v
+        self.commitment_use_cross_entropy_loss = commitment_use_cross_entropy_loss
+        self.has_codebook_diversity_loss = codebook_diversity_loss_weight > 0.
+        self.codebook_diversity_loss_weight = codebook_diversity_loss_weight
+        self.codebook_diversity_temperature = codebook_diversity_temperature
+        self.stochastic_sample_codes = stochastic_sample_codes
+        self.gumbel_straight_through = straight_through
         self.rotation_trick = rotation_trick
         self.route_gradients_to_input = route_gradients_to_input
         self.use_cosine_sim = use_cosine_sim
@@ -282,21 +319,41 @@ class VectorQuantize(nn.Module):
     # The nearest-code search still runs on the HIP kernel (no gradient flows through an argmin); what changes is
     # that `quantize` is a differentiable gather of the (possibly bridged) codebook parameter and that the losses
     # are built from autograd ops.  Reference: vqp.py:710-717 (learnable embed / bridge), :1186-1237.
-    def _forward_param_codebook(self, xs, rmask, freeze_codebook, kw):
+    def _forward_general(self, xs, rmask, freeze_codebook, kw, *, dense, topk, temp):
+        """everything that is not the fused hot path: codebooks with gradients and/or options that read the full score row"""
         cb = self._codebook
         embed_eff = cb.embed if cb.vq_bridge is None else cb.vq_bridge(cb.embed)      # [1, C, D]
         if not cb.learnable_codebook:
             embed_eff = embed_eff.detach()
+        temp = cb.sample_codebook_temp if temp is None else temp
 
         def search(update_usage=True):
-            r = cb.quantize(xs.detach(), mask=rmask, embed_override=embed_eff, update_usage=update_usage, **kw)
-            # value: the rows of the PRE-update codebook (the EMA fold inside quantize() runs after the gather, like
-            # vqp.py:766 vs :783); gradient: that of a gather from the parameter (vqp.py:710, 766)
-            g = F.embedding(r["idx"], embed_eff[0]).to(xs.dtype)
-            q = r["q"] + (g - g.detach()) if embed_eff.requires_grad else r["q"]
-            return q, r["idx"]
+            if not dense:
+                r = cb.quantize(xs.detach(), mask=rmask, embed_override=embed_eff, update_usage=update_usage, **kw)
+                # value: the rows of the PRE-update codebook (the EMA fold inside quantize() runs after the gather, like
+                # vqp.py:766 vs :783); gradient: that of a gather from the parameter (vqp.py:710, 766)
+                g = F.embedding(r["idx"], embed_eff[0]).to(xs.dtype)
+                q = r["q"] + (g - g.detach()) if embed_eff.requires_grad else r["q"]
+                return q, r["idx"], None
+            if not cb._is_initted():
+                cb.init_embed_(xs.detach().reshape(1, -1, xs.shape[-1]).float(), None if rmask is None else rmask.reshape(1, -1))
+            dist = _ScoresFn.apply(xs, embed_eff[0], cb.use_cosine_sim)               # vqp.py:740-743, [b, n, C]
+            logits = dist
+            if self.training and self.stochastic_sample_codes and temp > 0:           # vqp.py:117-119, 132-133
+                u = torch.zeros_like(dist).uniform_(0, 1)
+                logits = dist / temp - torch.log((-torch.log(u.clamp(min=1e-20))).clamp(min=1e-20))
+            ind = logits.topk(topk, dim=-1).indices if topk is not None else logits.argmax(dim=-1)   # vqp.py:137-140
+            q = F.embedding(ind, embed_eff[0])        # materialised before any EMA fold below touches the codebook
+            if self.gumbel_straight_through and temp > 0 and self.training:           # vqp.py:144-148: one_hot + pi - pi.detach()
+                assert topk is None
+                pi = (dist / temp).softmax(dim=-1)
+                q = q + (pi - pi.detach()) @ embed_eff[0].detach()
+            if self.training and update_usage and not freeze_codebook and topk is None:                 # vqp.py:783-784
+                cb.update_indices(xs.detach(), ind, mask=rmask, ema_update_weight=kw.get("ema_update_weight"),
+                                  accum_ema_update=kw.get("accum_ema_update", False), ema_update=kw.get("ema_update"))
+            return q.to(xs.dtype), ind, dist
 
-        quantize, embed_ind = search()
+        quantize, embed_ind, distances = search()
         inplace_loss = self.zero
         if self.in_place_codebook_optimizer is not None and self.training and not freeze_codebook:   # vqp.py:1186-1210
             if rmask is not None:
@@ -308,25 +365,26 @@ class VectorQuantize(nn.Module):
                 self.update_in_place_optimizer()
             inplace_loss = l
             embed_eff = cb.embed if cb.vq_bridge is None else cb.vq_bridge(cb.embed)
-            quantize, embed_ind = search(update_usage=False)
+            quantize, embed_ind, distances = search(update_usage=False)
 
         commit_quantize = quantize
         if self.training:
             if not self.learnable_codebook or freeze_codebook:
                 commit_quantize = quantize.detach()
+            src = xs if topk is None else xs[..., None, :].expand(*xs.shape[:-1], topk, xs.shape[-1])   # vqp.py:1220-1221
             if xs.requires_grad and self.route_gradients_to_input and torch.is_grad_enabled():
                 if self.rotation_trick:
-                    quantize = _RouteFn.apply(xs, quantize.detach(), L.ROTATION)     # no gradient reaches the target (vqp.py:292-316)
+                    quantize = _RouteFn.apply(src.contiguous(), quantize.detach().contiguous(), L.ROTATION)   # target detached in the formula (vqp.py:292-316)
                 elif self.directional_reparam:                                        # vqp.py:323-330
-                    err = quantize - xs
+                    err = quantize - src
                     nrm = err.norm(dim=-1, keepdim=True)
                     noised = err + (self.directional_reparam_variance ** 0.5) * torch.randn_like(err)
-                    quantize = xs + F.normalize(noised, p=2, dim=-1, eps=1e-6).detach() * nrm
+                    quantize = src + F.normalize(noised, p=2, dim=-1, eps=1e-6).detach() * nrm
                 else:
-                    quantize = xs + (quantize - xs).detach()
+                    quantize = src + (quantize - src).detach()
             if self.sync_update_v > 0.:                                               # vqp.py:1235-1237
                 quantize = quantize + self.sync_update_v * (quantize - quantize.detach())
-        return quantize, embed_ind, commit_quantize, inplace_loss
+        return quantize, embed_ind, commit_quantize, inplace_loss, distances
 
     def _split_heads(self, x):
         if self.heads == 1:
@@ -383,10 +441,12 @@ class VectorQuantize(nn.Module):
         accum_ema_update=False,
         ema_update=None,
     ):
-        if indices is not None or topk is not None or codebook_transform_fn is not None:
-            raise NotImplementedError("forward(indices= / topk= / codebook_transform_fn=) read the full distance matrix; "
-                                      "not on the MI355X hot path (SURVEY.md §8f)")
+        if codebook_transform_fn is not None:
+            raise NotImplementedError("codebook_transform_fn (QINCo implicit codebooks) is not on the MI355X hot path (SURVEY.md §8f)")
+        if (indices is not None or topk is not None) and self.heads > 1:
+            raise NotImplementedError("forward(indices= / topk=) is implemented for heads == 1 only")
         L._need_gpu(x)
+        return_loss = indices is not None
         orig_input = x
         freeze_codebook = self.freeze_codebook if freeze_codebook is None else freeze_codebook
 
@@ -415,25 +475,50 @@ class VectorQuantize(nn.Module):
         # normalisation stays an autograd op and the kernel is told the rows are already unit-norm.
         pre_normalized = False
         needs_grad = self.training and xs.requires_grad and torch.is_grad_enabled()
-        if self.use_cosine_sim and (needs_grad or (mask is not None and self.training)):
+        dense = (return_loss or topk is not None or self.commitment_use_cross_entropy_loss or self.has_codebook_diversity_loss
+                 or self.stochastic_sample_codes or self.gumbel_straight_through)
+        if self.use_cosine_sim and (needs_grad or dense or (mask is not None and self.training)):
             xs = F.normalize(xs, p=2, dim=-1, eps=1e-6)
             pre_normalized = True
 
         kw = dict(freeze_codebook=freeze_codebook, ema_update_weight=ema_update_weight,
-                  accum_ema_update=accum_ema_update, ema_update=ema_update, input_normalized=pre_normalized)
-        param_path = self._codebook.learnable_codebook or self._codebook.vq_bridge is not None or self.directional_reparam
-        inplace_loss = orth_loss = self.zero
+                  accum_ema_update=accum_ema_update, ema_update=(ema_update if topk is None else False),
+                  input_normalized=pre_normalized)
+        param_path = (self._codebook.learnable_codebook or self._codebook.vq_bridge is not None or self.directional_reparam or dense)
+        inplace_loss = orth_loss = diversity_loss = self.zero
+        distances = None
         if param_path:
-            quantize, embed_ind, commit_quantize, inplace_loss = self._forward_param_codebook(xs, rmask, freeze_codebook, kw)
+            quantize, embed_ind, commit_quantize, inplace_loss, distances = self._forward_general(
+                xs, rmask, freeze_codebook, kw, dense=dense, topk=topk, temp=sample_codebook_temp)
         else:
             quantize, embed_ind, sq_sum = _QuantizeFn.apply(xs, self, rmask, kw)
 
         # ---- loss (vqp.py:1282-1348) --------------------------------------------------------------
         loss = torch.zeros((), device=x.device, dtype=torch.float32, requires_grad=self.training)
         commit_loss = self.zero
+        def ce_loss(codes):                                                          # vqp.py:1242-1256, heads == 1
+            return F.cross_entropy(distances.permute(0, 2, 1), codes, ignore_index=-1)
+
+        if return_loss:                                                              # vqp.py:1260-1261
+            return quantize, ce_loss(indices)
+
         if self.training and param_path:
+            if self.has_codebook_diversity_loss:                                     # vqp.py:1287-1292, 67-68
+                prob = (distances * self.codebook_diversity_temperature).softmax(dim=-1)
+                avg = prob.mean(dim=0)                                               # over the batch, per position
+                ent = (-avg * torch.log(avg.clamp(min=1e-5))).sum(dim=-1)
+                diversity_loss = -ent.mean()
+                loss = loss + diversity_loss * self.codebook_diversity_loss_weight
             if self.has_commitment_loss:
-                if mask is not None:
+                if self.commitment_use_cross_entropy_loss:                           # vqp.py:1297-1305
+                    codes = embed_ind if mask is None else embed_ind.masked_fill(~mask, -1)
+                    commit_loss = ce_loss(codes)
+                elif topk is not None:                                               # vqp.py:1307-1315
+                    rep = orig_input[..., None, :].expand(*orig_input.shape[:-1], topk, orig_input.shape[-1])
+                    commit_loss = F.mse_loss(commit_quantize, rep, reduction='none').mean(dim=-1)
+                    if mask is not None:
+                        commit_loss = torch.where(mask[..., None], commit_loss, torch.zeros_like(commit_loss))
+                elif mask is not None:
                     commit_loss = F.mse_loss(commit_quantize, orig_input if xs.shape == orig_input.shape else xs, reduction='none')[rmask].mean()
                 else:
                     commit_loss = F.mse_loss(commit_quantize, xs)
@@ -486,10 +571,13 @@ class VectorQuantize(nn.Module):
 
         if mask is not None:
             fill = torch.zeros_like(orig_input) if self.return_zeros_for_masked_padding else orig_input
-            quantize = torch.where(mask[..., None], quantize, fill)
-            m = mask if embed_ind.ndim == mask.ndim else mask[..., None]
+            if topk is not None:
+                fill = fill[..., None, :]
+            mq = mask.reshape(*mask.shape, *([1] * (quantize.ndim - mask.ndim)))
+            quantize = torch.where(mq, quantize, fill)
+            m = mask.reshape(*mask.shape, *([1] * (embed_ind.ndim - mask.ndim)))
             embed_ind = torch.where(m, embed_ind, torch.full_like(embed_ind, -1))
 
         if not return_loss_breakdown:
             return quantize, embed_ind, loss
-        return quantize, embed_ind, loss, LossBreakdown(commit_loss, self.zero, orth_loss, inplace_loss)
+        return quantize, embed_ind, loss, LossBreakdown(commit_loss, diversity_loss, orth_loss, inplace_loss)
