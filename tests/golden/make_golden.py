@@ -90,6 +90,8 @@ def run_case(name, cls, kwargs, xs, *, train=True, fwd_kwargs=None, grad=False, 
         fk["lens"] = torch.tensor(fk["lens"])
     if "indices" in fk:
         fk["indices"] = torch.tensor(fk["indices"])
+    if "mask" in fk:
+        fk["mask"] = torch.tensor(fk["mask"])
     for s, x in enumerate(xs):
         x = x.clone()
         if grad:
@@ -199,6 +201,11 @@ if __name__ == "__main__":
              [randn(2, 80, 32, seed=75)], unit_codebook=True)
     run_case("vq_gumbel_st", VectorQuantize, dict(dim=32, codebook_size=64, straight_through=True, rotation_trick=False, sample_codebook_temp=0.5),
              [randn(2, 80, 32, seed=76)], grad=True, unit_codebook=True)
+    # beam search: batch 1 only -- the reference's post-search update_indices mis-shapes the indices for batch > 1 (vqp.py:664)
+    run_case("rvq_beam", ResidualVQ, dict(dim=32, num_quantizers=4, codebook_size=64, beam_size=3), [randn(1, 80, 32, seed=80)], unit_codebook=True)
+    run_case("rvq_beam_shared_mask", ResidualVQ, dict(dim=32, num_quantizers=3, codebook_size=64, beam_size=2, shared_codebook=True,
+                                                      beam_score_quantizer_weights=[1., 0.5, 0.25]),
+             [randn(1, 60, 32, seed=81)], fwd_kwargs=dict(mask=[[True] * 43 + [False] * 17]), unit_codebook=True)
     run_case("vq_proj", VectorQuantize, dict(dim=48, codebook_size=64, codebook_dim=16), [randn(2, 50, 48, seed=16)], unit_codebook=True)
     # cfg 3: ResidualVQ shared codebook, scaled down
     run_case("rvq_shared", ResidualVQ, dict(dim=256, num_quantizers=8, codebook_size=256, shared_codebook=True), [randn(2, 128, 256, seed=17), randn(2, 128, 256, seed=18)])

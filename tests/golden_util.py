@@ -59,6 +59,8 @@ class Fixture:
             fk["lens"] = torch.tensor(fk["lens"], device=device)
         if "indices" in fk:
             fk["indices"] = torch.tensor(fk["indices"], device=device)
+        if "mask" in fk:
+            fk["mask"] = torch.tensor(fk["mask"], device=device)
         return fk
 
 

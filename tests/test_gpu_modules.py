@@ -447,3 +447,35 @@ def test_cfg5_full_size_grouped_rvq_with_kmeans(dev):
     assert torch.allclose(q, out, atol=1e-5)
     # k-means lowered the quantisation error well below that of a random codebook
     assert ((q - x) ** 2).mean().item() < 0.75
+
+
+def test_topk_and_manual_ema_update(dev):                                     # reference tests/test_beam.py:7-47
+    from vector_quantize_pytorch_amd import VectorQuantize
+    vq1 = VectorQuantize(dim=256, codebook_size=512).to(dev)
+    vq2 = VectorQuantize(dim=256, codebook_size=512).to(dev)
+    vq2.load_state_dict(vq1.state_dict())
+    x = torch.randn(1, 1024, 256, device=dev)
+    mask = torch.randint(0, 2, (1, 1024), device=dev).bool()
+    vq1.train(); vq2.train()
+    quantize1, indices1, commit_loss1 = vq1(x, mask=mask)
+    quantize2, indices2, commit_losses = vq2(x, mask=mask, topk=1, ema_update=False)
+    assert quantize2.shape == (1, 1024, 1, 256) and indices2.shape == (1, 1024, 1) and commit_losses.shape == (1, 1024, 1)
+    assert torch.allclose(commit_loss1, commit_losses.sum() / mask.sum())
+    assert torch.equal(indices1, indices2[..., 0])
+    assert torch.allclose(quantize1, quantize2[..., 0, :])
+    assert not torch.allclose(vq1._codebook.embed_avg, vq2._codebook.embed_avg)
+    vq2.update_ema_indices(x, indices2[..., 0], mask=mask)
+    assert torch.allclose(vq1._codebook.cluster_size, vq2._codebook.cluster_size)
+    assert torch.allclose(vq1._codebook.embed_avg, vq2._codebook.embed_avg, rtol=1e-5, atol=1e-6)
+    assert torch.allclose(vq1.codebook, vq2.codebook, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("codebook_dim", (256, 128))
+def test_beam_search(dev, codebook_dim):                                      # reference tests/test_beam.py:49-73
+    from vector_quantize_pytorch_amd import ResidualVQ
+    rvq = ResidualVQ(dim=256, codebook_dim=codebook_dim, num_quantizers=8, codebook_size=1024, quantize_dropout=True,
+                     beam_size=2, eval_beam_size=3).to(dev)
+    x = torch.randn(1, 1024, 256, device=dev).requires_grad_()
+    for _ in range(3):
+        quantized, indices, commit_loss = rvq(x)
+    assert quantized.shape == (1, 1024, 256) and indices.shape == (1, 1024, 8) and commit_loss.shape == (8,)

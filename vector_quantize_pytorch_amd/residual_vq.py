@@ -59,9 +59,10 @@ class ResidualVQ(nn.Module):
         super().__init__()
         assert heads == 1, 'residual vq is not compatible with multi-headed codes'
         assert num_quantizers is not None or isinstance(codebook_size, tuple)
-        if diveq or implicit_neural_codebook or (beam_size or 0) > 1 or (eval_beam_size or 0) > 1:
-            raise NotImplementedError("diveq / implicit_neural_codebook (QINCo) / beam search are outside the MI355X hot "
-                                      "path (SURVEY.md §2.1, §8f); no fallback is provided")
+        if diveq or implicit_neural_codebook:
+            raise NotImplementedError("diveq / implicit_neural_codebook (QINCo) are outside the MI355X hot path (SURVEY.md §2.1, §8f); "
+                                      "no fallback is provided")
+        assert not (eval_beam_size is not None and beam_size is None)
 
         codebook_dim = dim if codebook_dim is None else codebook_dim
         self.codebook_dim = codebook_dim
@@ -94,8 +95,11 @@ class ResidualVQ(nn.Module):
         self.quantize_dropout_multiple_of = quantize_dropout_multiple_of
         self.vq_is_ema_updating = self.layers[0].ema_update
         self.quant_grad_frac = quant_grad_frac
-        self.beam_size = None
-        self.eval_beam_size = None
+        self.beam_size = beam_size
+        self.eval_beam_size = beam_size if eval_beam_size is None else eval_beam_size
+        weights = [1.] * num_quantizers if beam_score_quantizer_weights is None else beam_score_quantizer_weights
+        assert len(weights) == num_quantizers
+        self.register_buffer('beam_score_weights', torch.tensor(weights), persistent=False)
         self.mlps = (None,) * (num_quantizers - 1)
 
         self.shared_codebook = shared_codebook
@@ -147,9 +151,11 @@ class ResidualVQ(nn.Module):
         beam_size=None,
         rand_quantize_dropout_fixed_seed=None,
     ):
-        if indices is not None or (beam_size or 0) > 1:
-            raise NotImplementedError("forward(indices=) / beam search are not on the MI355X hot path (SURVEY.md §8f)")
+        if indices is not None:
+            raise NotImplementedError("forward(indices=) (cross-entropy to given codes) is not implemented for ResidualVQ")
         L._need_gpu(x)
+        beam_size = (self.beam_size if self.training else self.eval_beam_size) if beam_size is None else beam_size
+        is_beam = beam_size is not None and beam_size > 1
         Q = self.num_quantizers
         x = self.project_in(x)
 
@@ -162,7 +168,9 @@ class ResidualVQ(nn.Module):
             if self.quantize_dropout_multiple_of != 1:
                 drop_at = _round_up(drop_at + 1, self.quantize_dropout_multiple_of) - 1
 
-        if self._fused_eligible(x, mask):
+        if is_beam:
+            quantized_out, all_indices, all_losses = self._forward_beam(x, mask, sample_codebook_temp, freeze_codebook, beam_size, drop_at)
+        elif self._fused_eligible(x, mask):
             quantized_out, all_indices, all_losses = self._forward_fused(x, mask, freeze_codebook, drop_at)
         else:
             quantized_out, all_indices, all_losses = self._forward_staged(x, mask, sample_codebook_temp, freeze_codebook, drop_at)
@@ -236,6 +244,65 @@ class ResidualVQ(nn.Module):
             pad = torch.full((*idx.shape[:-1], self.num_quantizers - Q), -1, device=x.device, dtype=torch.long)
             idx = torch.cat((idx, pad), -1)
         return quantized_out, idx, losses
+
+    # ---- beam search over the quantizers (rvq.py:445-590): every stage keeps the `beam_size` best partial code
+    #      sequences by accumulated (weighted) negative commit loss; the per-stage top-k comes from the dense-score path ----
+    def _forward_beam(self, x, mask, sample_codebook_temp, freeze_codebook, beam_size, drop_at):
+        lead = x.shape[:-1]
+        J = 1
+        scores = torch.zeros(*lead, 1, device=x.device, dtype=x.dtype)
+        residual = x[..., None, :]                                  # [b, n, J, d]
+        out = torch.zeros_like(residual)
+        inputs = torch.empty(*lead, 1, 0, x.shape[-1], device=x.device, dtype=x.dtype)     # [b, n, J, l, d] stage inputs
+        idxs = torch.empty(*lead, 1, 0, device=x.device, dtype=torch.long)                  # [b, n, J, l]
+        losses = torch.empty(*lead, 1, 0, device=x.device, dtype=torch.float32)             # [b, n, J, l]
+        last = (len(self.layers) - 1) if drop_at is None else drop_at
+
+        def pick(t, sel):                                           # t [b, n, J', ...] -> rows `sel` [b, n, keep] of the beam axis
+            extra = t.ndim - sel.ndim
+            s_ = sel.reshape(*sel.shape, *([1] * extra)).expand(*sel.shape, *t.shape[sel.ndim:])
+            return t.gather(sel.ndim - 1, s_)
+
+        for qi, vq in enumerate(self.layers):
+            if drop_at is not None and qi > drop_at:
+                idxs = torch.nn.functional.pad(idxs, (0, 1), value=-1)
+                losses = torch.nn.functional.pad(losses, (0, 1), value=0.)
+                continue
+            inputs = torch.cat((inputs, residual[..., None, :]), dim=-2)
+            quantized, ind, loss = vq(residual, mask=mask, sample_codebook_temp=sample_codebook_temp,
+                                      freeze_codebook=freeze_codebook, topk=beam_size)       # [b,n,J,K,d], [b,n,J,K], [b,n,J,K]
+            K = ind.shape[-1]
+            scores = (scores[..., None] - loss * self.beam_score_weights[qi]).flatten(-2)   # [b, n, J K]
+            step = quantized.detach() if self.quant_grad_frac <= 0 else (
+                self.quant_grad_frac * quantized + (1. - self.quant_grad_frac) * quantized.detach())
+            residual = (residual[..., None, :] - step).flatten(-3, -2)
+            out = (out[..., None, :] + quantized).flatten(-3, -2)
+            inputs = inputs[..., None, :, :].expand(*inputs.shape[:-2], K, *inputs.shape[-2:]).flatten(-4, -3)
+            idxs = torch.cat((idxs[..., None, :].expand(*idxs.shape[:-1], K, idxs.shape[-1]), ind[..., None]), dim=-1).flatten(-3, -2)
+            losses = torch.cat((losses[..., None, :].expand(*losses.shape[:-1], K, losses.shape[-1]), loss[..., None].float()), dim=-1).flatten(-3, -2)
+            keep = beam_size if qi != last else 1
+            if scores.shape[-1] > keep:
+                scores, sel = scores.topk(keep, dim=-1)
+                residual, out, idxs, losses, inputs = (pick(t, sel) for t in (residual, out, idxs, losses, inputs))
+
+        out, idxs, losses, inputs = out[..., 0, :], idxs[..., 0, :], losses[..., 0, :], inputs[..., 0, :, :]
+        if mask is not None:
+            losses = torch.where(mask[..., None], losses, torch.zeros_like(losses))
+            losses = losses.flatten(0, -2).sum(0) / mask.sum().clamp_min(1e-4)
+        else:
+            losses = losses.flatten(0, -2).mean(0)
+        if self.training:
+            # rvq.py:574, 586-589.  REFERENCE QUIRK, replicated for parity: `all_residuals[..., 0, :]` selects stage 0 (not beam 0)
+            # of the [.., beam, stage, d] tensor, the following unbind runs over the beam axis (length 1), and the zip therefore
+            # stops after the FIRST quantizer: only layer 0 receives EMA statistics after a beam search.
+            self.layers[0].update_indices(inputs[..., 0, :], idxs[..., 0], mask=mask)
+            if self.shared_codebook:
+                shared = self.layers[0]
+                if self.vq_is_ema_updating:
+                    shared._codebook.update_ema()
+                if shared._codebook.has_dead_code_replacement:
+                    shared.expire_codes_(inputs.reshape(inputs.shape[0], -1, inputs.shape[-1]))
+        return out, idxs, losses
 
     # ---- per-stage path: autograd to the input, cosine metric, k-means first step, ragged sizes --------
     def _forward_staged(self, x, mask, sample_codebook_temp, freeze_codebook, drop_at):

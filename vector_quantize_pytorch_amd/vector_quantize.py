@@ -517,7 +517,8 @@ class VectorQuantize(nn.Module):
                     rep = orig_input[..., None, :].expand(*orig_input.shape[:-1], topk, orig_input.shape[-1])
                     commit_loss = F.mse_loss(commit_quantize, rep, reduction='none').mean(dim=-1)
                     if mask is not None:
-                        commit_loss = torch.where(mask[..., None], commit_loss, torch.zeros_like(commit_loss))
+                        mk = mask.reshape(*mask.shape, *([1] * (commit_loss.ndim - mask.ndim)))
+                        commit_loss = torch.where(mk, commit_loss, torch.zeros_like(commit_loss))
                 elif mask is not None:
                     commit_loss = F.mse_loss(commit_quantize, orig_input if xs.shape == orig_input.shape else xs, reduction='none')[rmask].mean()
                 else:
