@@ -206,6 +206,8 @@ if __name__ == "__main__":
     run_case("rvq_beam_shared_mask", ResidualVQ, dict(dim=32, num_quantizers=3, codebook_size=64, beam_size=2, shared_codebook=True,
                                                       beam_score_quantizer_weights=[1., 0.5, 0.25]),
              [randn(1, 60, 32, seed=81)], fwd_kwargs=dict(mask=[[True] * 43 + [False] * 17]), unit_codebook=True)
+    run_case("vq_affine", VectorQuantize, dict(dim=32, codebook_size=64, affine_param=True, affine_param_batch_decay=0.9, affine_param_codebook_decay=0.8),
+             [randn(2, 80, 32, seed=90) * 2 + 1, randn(2, 80, 32, seed=91) * 2 + 1], unit_codebook=True)
     run_case("vq_proj", VectorQuantize, dict(dim=48, codebook_size=64, codebook_dim=16), [randn(2, 50, 48, seed=16)], unit_codebook=True)
     # cfg 3: ResidualVQ shared codebook, scaled down
     run_case("rvq_shared", ResidualVQ, dict(dim=256, num_quantizers=8, codebook_size=256, shared_codebook=True), [randn(2, 128, 256, seed=17), randn(2, 128, 256, seed=18)])

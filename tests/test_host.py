@@ -85,7 +85,7 @@ def test_default_init_matches_reference_statistics():
 def test_unsupported_options_fail_loudly_and_cpu_is_refused():
     from vector_quantize_pytorch_amd import ResidualVQ, VectorQuantize
     from vector_quantize_pytorch_amd._lib import VQHipError
-    for kw in (dict(affine_param=True), dict(stochastic_sample_codes=True, heads=2, codebook_dim=16),
+    for kw in (dict(affine_param=True, heads=2, codebook_dim=16), dict(stochastic_sample_codes=True, heads=2, codebook_dim=16),
                dict(commitment_use_cross_entropy_loss=True, heads=2, codebook_dim=16)):
         with pytest.raises(NotImplementedError):
             VectorQuantize(dim=32, codebook_size=16, **kw)

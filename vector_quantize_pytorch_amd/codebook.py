@@ -110,9 +110,8 @@ class Codebook(nn.Module):
         vq_bridge: Optional[nn.Module] = None,
     ):
         super().__init__()
-        if affine_param:
-            raise NotImplementedError("affine_param is outside the MI355X hot path (SURVEY.md §2.1, §8f) and is not "
-                                      "implemented in vector_quantize_pytorch_amd")
+        if affine_param and num_codebooks != 1:
+            raise NotImplementedError("affine_param with several codebooks is not implemented")
         if not (1 <= dim <= 512):
             raise NotImplementedError(f"codebook dim {dim}: the HIP path supports 1 <= dim <= 512")
 
@@ -132,7 +131,10 @@ class Codebook(nn.Module):
         self.reset_cluster_size = threshold_ema_dead_code if reset_cluster_size is None else reset_cluster_size
         self.sample_codebook_temp = sample_codebook_temp
         self.learnable_codebook = learnable_codebook
-        self.affine_param = False
+        self.affine_param = affine_param
+        self.sync_affine_param = sync_affine_param
+        self.affine_param_batch_decay = affine_param_batch_decay
+        self.affine_param_codebook_decay = affine_param_codebook_decay
         self.vq_bridge = vq_bridge
 
         self.use_ddp = use_ddp
@@ -159,6 +161,47 @@ class Codebook(nn.Module):
             self.register_buffer('embed', embed)
 
         self._initted_known = not kmeans_init     # python-side cache: no host sync per forward
+
+        if affine_param:                           # vqp.py:442-448: same buffer names / state_dict keys
+            self.register_buffer('batch_mean', None)
+            self.register_buffer('batch_variance', None)
+            self.register_buffer('codebook_mean_needs_init', torch.tensor(True))
+            self.register_buffer('codebook_mean', torch.empty(num_codebooks, 1, dim))
+            self.register_buffer('codebook_variance_needs_init', torch.tensor(True))
+            self.register_buffer('codebook_variance', torch.empty(num_codebooks, 1, dim))
+
+    # ---- affine reparametrisation of the codebook (vqp.py:475-542): running first / second moments of the batch and
+    #      of the codebook; the codebook is searched after being mapped onto the batch statistics ----
+    def _decayed(self, name: str, new: Tensor, decay: float):
+        old = getattr(self, name)
+        needs_init = bool(getattr(self, name + '_needs_init', False))
+        if needs_init:
+            self.register_buffer(name + '_needs_init', torch.tensor(False, device=new.device))
+        if old is None or needs_init:
+            self.register_buffer(name, new.detach())
+            return
+        self.register_buffer(name, old * decay + new.detach() * (1 - decay))
+
+    @torch.no_grad()
+    def update_affine(self, data: Tensor, embed: Tensor, mask: Optional[Tensor] = None):
+        if self.training:
+            self._decayed('codebook_mean', embed.mean(dim=1, keepdim=True), self.affine_param_codebook_decay)
+            self._decayed('codebook_variance', embed.var(dim=1, unbiased=False, keepdim=True), self.affine_param_codebook_decay)
+        if mask is not None:
+            data = data[mask].reshape(data.shape[0], -1, data.shape[-1])
+        if not self.sync_affine_param:
+            self._decayed('batch_mean', data.mean(dim=1, keepdim=True), self.affine_param_batch_decay)
+            self._decayed('batch_variance', data.var(dim=1, unbiased=False, keepdim=True), self.affine_param_batch_decay)
+            return
+        n = torch.tensor(float(data.shape[-2]), device=data.device, dtype=data.dtype)
+        dist.all_reduce(n)
+        total = data.sum(dim=1, keepdim=True)
+        dist.all_reduce(total)
+        mean = total / n
+        self._decayed('batch_mean', mean, self.affine_param_batch_decay)
+        sq = ((data - mean) ** 2).sum(dim=1, keepdim=True)
+        dist.all_reduce(sq)
+        self._decayed('batch_variance', sq / n, self.affine_param_batch_decay)
 
     # ---- state handling --------------------------------------------------------------------------
     def _load_from_state_dict(self, *args, **kwargs):
@@ -294,6 +337,16 @@ class Codebook(nn.Module):
 
         do_update = (self.training and update_usage and not freeze_codebook
                      and (ema_update or self.has_dead_code_replacement))
+        x_stats = xs
+        if self.affine_param:                                   # vqp.py:705-706, 721-724, 594-597
+            flat = xs.reshape(H, -1, self.dim).float()
+            self.update_affine(flat, self.embed, None if rmask is None else rmask[None].expand(H, -1).bool())
+            cstd = self.codebook_variance.clamp(min=1e-5).sqrt()
+            bstd = self.batch_variance.clamp(min=1e-5).sqrt()
+            base = self.embed if embed_override is None else embed_override
+            embed_override = (base.detach() - self.codebook_mean) * (bstd / cstd) + self.batch_mean
+            if do_update:
+                x_stats = ((flat - self.batch_mean) * (cstd / bstd) + self.codebook_mean).reshape(xs.shape)
         outs = []
         for h in range(H):
             # embed_override: the codebook actually searched when it is a function of the stored one (vq_bridge)
@@ -305,7 +358,7 @@ class Codebook(nn.Module):
             if do_update:
                 buf = torch.zeros(C * self.dim + C, dtype=torch.float32, device=x.device)
                 esum, count = buf[: C * self.dim].view(C, self.dim), buf[C * self.dim:]
-                L.ema_accumulate(xs[h], r["idx"].reshape(-1), C, cosine=self.use_cosine_sim and not input_normalized,
+                L.ema_accumulate(x_stats[h], r["idx"].reshape(-1), C, cosine=self.use_cosine_sim and not input_normalized,
                                  rnorm=r["rnorm"], row_mask=rmask, count=count, embed_sum=esum)
                 if self.use_ddp:
                     dist.all_reduce(buf)          # ONE collective for count || embed_sum (RCCL over xGMI)

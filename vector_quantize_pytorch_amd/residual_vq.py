@@ -59,9 +59,9 @@ class ResidualVQ(nn.Module):
         super().__init__()
         assert heads == 1, 'residual vq is not compatible with multi-headed codes'
         assert num_quantizers is not None or isinstance(codebook_size, tuple)
-        if diveq or implicit_neural_codebook:
-            raise NotImplementedError("diveq / implicit_neural_codebook (QINCo) are outside the MI355X hot path (SURVEY.md §2.1, §8f); "
-                                      "no fallback is provided")
+        if implicit_neural_codebook:
+            raise NotImplementedError("implicit_neural_codebook (QINCo: a separate codebook per row) is outside the MI355X hot path "
+                                      "(SURVEY.md §2.1, §8f); no fallback is provided")
         assert not (eval_beam_size is not None and beam_size is None)
 
         codebook_dim = dim if codebook_dim is None else codebook_dim
@@ -72,7 +72,9 @@ class ResidualVQ(nn.Module):
         self.has_projections = requires_projection
         self.accept_image_fmap = accept_image_fmap
         self.implicit_neural_codebook = False
-        self.diveq = False
+        self.diveq = diveq
+        if diveq:                                             # rvq.py:226-232: DiVeQ learns the codebook through the reparametrised output
+            vq_kwargs.update(ema_update=False, learnable_codebook=True, route_gradients_to_input=False, commitment_weight=0.)
 
         if shared_codebook:                                   # rvq.py:213-217
             vq_kwargs.update(manual_ema_update=True, manual_in_place_optimizer_update=True)
@@ -94,7 +96,8 @@ class ResidualVQ(nn.Module):
         self.quantize_dropout_cutoff_index = quantize_dropout_cutoff_index
         self.quantize_dropout_multiple_of = quantize_dropout_multiple_of
         self.vq_is_ema_updating = self.layers[0].ema_update
-        self.quant_grad_frac = quant_grad_frac
+        assert not (self.vq_is_ema_updating and diveq), 'Only one of ema_update or self.diveq must be used for updating the codebook'
+        self.quant_grad_frac = quant_grad_frac if not diveq else 1.
         self.beam_size = beam_size
         self.eval_beam_size = beam_size if eval_beam_size is None else eval_beam_size
         weights = [1.] * num_quantizers if beam_score_quantizer_weights is None else beam_score_quantizer_weights
@@ -174,6 +177,11 @@ class ResidualVQ(nn.Module):
             quantized_out, all_indices, all_losses = self._forward_fused(x, mask, freeze_codebook, drop_at)
         else:
             quantized_out, all_indices, all_losses = self._forward_staged(x, mask, sample_codebook_temp, freeze_codebook, drop_at)
+
+        if self.diveq:                                        # rvq.py:605-606, vqp.py:323-330 (noise from the device RNG)
+            err = quantized_out - x
+            noised = err + (5e-3 ** 0.5) * torch.randn_like(err)
+            quantized_out = x + torch.nn.functional.normalize(noised, p=2, dim=-1, eps=1e-6).detach() * err.norm(dim=-1, keepdim=True)
 
         quantized_out = self.project_out(quantized_out)
         ret = (quantized_out, all_indices, all_losses)

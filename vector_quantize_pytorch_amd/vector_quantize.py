@@ -173,8 +173,9 @@ class VectorQuantize(nn.Module):
         rotation_trick = (not directional_reparam and dim > 1) if rotation_trick is None else rotation_trick
 
         if affine_param:
-            raise NotImplementedError("affine_param is outside the MI355X hot path (SURVEY.md §2.1 / §8f) and is not implemented; "
-                                      "there is deliberately no fallback.")
+            assert not use_cosine_sim, 'affine param is only compatible with euclidean codebook'
+            if heads > 1:
+                raise NotImplementedError("affine_param is implemented for heads == 1 only")
         dense_options = (commitment_use_cross_entropy_loss or codebook_diversity_loss_weight > 0. or stochastic_sample_codes
                          or straight_through)
         if dense_options and (heads > 1):
@@ -260,6 +261,10 @@ class VectorQuantize(nn.Module):
             use_cosine_sim=use_cosine_sim,
             learnable_codebook=has_orth or learnable_codebook,           # vqp.py:939
             vq_bridge=vq_bridge,
+            affine_param=affine_param,
+            sync_affine_param=sync_affine_param,
+            affine_param_batch_decay=affine_param_batch_decay,
+            affine_param_codebook_decay=affine_param_codebook_decay,
         )
         self.in_place_codebook_optimizer = in_place_codebook_optimizer(self._codebook.parameters()) \
             if in_place_codebook_optimizer is not None else None
