@@ -49,6 +49,16 @@ def lib():
     L.vqhip_rvq_forward.restype = i32
     L.vqhip_scores.argtypes = [vp, i32, i64, i32, i64, vp, vp, i32, i32, vp, i64, vp, vp, vp]
     L.vqhip_scores.restype = i32
+    L.vqhip_screen_supported.argtypes = [i64, i32, i32]
+    L.vqhip_screen_supported.restype = i32
+    L.vqhip_screen_workspace_bytes.argtypes = [i64]
+    L.vqhip_screen_workspace_bytes.restype = ctypes.c_size_t
+    L.vqhip_screen_blocks.argtypes = [i64]
+    L.vqhip_screen_blocks.restype = i64
+    L.vqhip_screen_partials.argtypes = [i64]
+    L.vqhip_screen_partials.restype = i64
+    L.vqhip_assign_screened.argtypes = [vp, i64, i32, i64, vp, vp, i32, vp, vp, i64, vp, vp, vp, ctypes.c_size_t, vp, vp]
+    L.vqhip_assign_screened.restype = i32
     L.vqhip_route_fwd.argtypes = [vp, vp, i32, i64, i32, i64, i64, vp, i64, i32, vp]
     L.vqhip_route_bwd.argtypes = [vp, vp, vp, i32, i64, i32, i64, i64, i64, vp, vp, i32, vp, i64, vp]
     L.vqhip_route_fwd.restype = i32
@@ -67,7 +77,8 @@ def lib():
 
 
 EXPORTS = ("vqhip_version", "vqhip_last_error", "vqhip_packed_bytes", "vqhip_pack_codebook",
-           "vqhip_assign_blocks", "vqhip_assign", "vqhip_scores", "vqhip_rvq_forward", "vqhip_reduce_partials", "vqhip_ema_workspace_bytes", "vqhip_ema_accumulate",
+           "vqhip_assign_blocks", "vqhip_assign", "vqhip_screen_supported", "vqhip_screen_workspace_bytes",
+           "vqhip_screen_blocks", "vqhip_screen_partials", "vqhip_assign_screened", "vqhip_scores", "vqhip_rvq_forward", "vqhip_reduce_partials", "vqhip_ema_workspace_bytes", "vqhip_ema_accumulate",
            "vqhip_ema_finalize", "vqhip_decode_sum", "vqhip_row_sumsq", "vqhip_route_fwd", "vqhip_route_bwd")
 
 
@@ -137,6 +148,14 @@ def pack_codebook(embed2d: torch.Tensor, out: torch.Tensor | None = None) -> tor
     return out
 
 
+screen_debug = False   # tests: also return the screening kernel's per-row (best, second, threshold, flagged)
+
+
+def screening_enabled() -> bool:
+    """VQHIP_SCREEN=0 forces the exact fp32-MFMA kernel for bf16 inputs too (A/B measurements, profiling)."""
+    return os.environ.get("VQHIP_SCREEN", "1") != "0"
+
+
 def assign(x: torch.Tensor, packed: torch.Tensor, embed2d: torch.Tensor, *, cosine=False,
            want_q=True, want_sqerr=False, want_best=False, want_rnorm=False, row_mask=None, q_out=None,
            skip_l2norm=False):
@@ -153,14 +172,27 @@ def assign(x: torch.Tensor, packed: torch.Tensor, embed2d: torch.Tensor, *, cosi
     if want_q:
         q = q_out if q_out is not None else torch.empty(*lead, D, dtype=x.dtype, device=dev)
         assert q.is_contiguous() and q.dtype == x.dtype
+    if row_mask is not None:
+        row_mask = row_mask.reshape(-1).to(torch.uint8).contiguous()
+        assert row_mask.numel() == N
+    if (not cosine and not want_best and not want_rnorm and N > 0 and screening_enabled()
+            and xk.dtype == torch.bfloat16 and xk.data_ptr() % 16 == 0 and (ldx * 2) % 16 == 0
+            and lib().vqhip_screen_supported(N, D, C)):
+        # bf16 rows: bf16-MFMA screen + exact fp32 pass on the uncertified rows only (csrc/vq_screen.hip); same outputs
+        nblk = lib().vqhip_screen_partials(N)
+        partials = torch.empty(nblk, dtype=torch.float64, device=dev) if want_sqerr else None
+        nws = lib().vqhip_screen_workspace_bytes(N)
+        ws = torch.empty((nws + 3) // 4, dtype=torch.int32, device=dev)
+        dbg = torch.empty(N, 4, dtype=torch.float32, device=dev) if screen_debug else None
+        _check(lib().vqhip_assign_screened(_ptr(xk), N, D, ldx, _ptr(packed), _ptr(embed2d), C, _ptr(idx), _ptr(q), ldq,
+                                           _ptr(partials), _ptr(row_mask), _ptr(ws), nws, _ptr(dbg), _stream()),
+               "vqhip_assign_screened")
+        return dict(idx=idx, q=q, sqerr_partials=partials, best=None, rnorm=None, nblk=nblk, n_exact=ws[:1], screen_debug=dbg)
     need_rn = want_rnorm or cosine or (D % 32 != 0)
     rnorm = torch.empty(lead, dtype=torch.float32, device=dev) if need_rn else None
     best = torch.empty(lead, dtype=torch.float32, device=dev) if want_best else None
     nblk = lib().vqhip_assign_blocks(N)
     partials = torch.empty(max(nblk, 1), dtype=torch.float64, device=dev) if want_sqerr else None
-    if row_mask is not None:
-        row_mask = row_mask.reshape(-1).to(torch.uint8).contiguous()
-        assert row_mask.numel() == N
     if N > 0:
         _check(lib().vqhip_assign(_ptr(xk), _dtype_code(xk), N, D, ldx, _ptr(packed), _ptr(embed2d), C,
                                   (COSINE_PRENORM if skip_l2norm else COSINE) if cosine else EUCLID, _ptr(idx), _ptr(q),

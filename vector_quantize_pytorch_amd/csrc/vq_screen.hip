@@ -1,0 +1,360 @@
+// vq_screen.hip -- screened nearest-code assignment for bf16 inputs (Euclidean), gfx950 only.
+//
+// The exact kernel (vqhip.hip, vq_assign_kernel) evaluates the reference's cdist (vqp.py:58-62) bit for bit on the
+// fp32 MFMA pipe, which runs at 1/16 of the bf16 MFMA rate.  For bf16 inputs the same INDICES can be had much
+// cheaper, still exactly:
+//
+//   1. screen (this file): bf16 rows are exact MFMA operands; the fp32 codebook is split c = c_hi + c_lo into two
+//      bf16 parts (|c - c_hi - c_lo| <= 2^-18 |c|) and  t[n, c] = x_n . c_hi + x_n . c_lo - ||c||^2 / 2  is
+//      accumulated by v_mfma_f32_32x32x16_bf16 (2 passes at 16x the fp32 rate).  argmax_c t = argmin_c cdist up to an
+//      error eps(n) that is bounded below; per row the kernel keeps the best and the second best t.
+//   2. a row whose margin (best - second) exceeds the bound has a certified winner: every other code is farther in
+//      the reference's own fp32 arithmetic as well, ties of the rounded sqrt included.  Its index, its gathered code
+//      and its squared error are final.
+//   3. the few rows that are not certified (a fraction of a percent to a few percent) are appended to a list and
+//      re-done by the exact kernel (vq_assign_listed), which overwrites their outputs.
+//
+// Error bound, in units of s = ||x||^2 + ||c||^2 - 2 x.c (u = 2^-24, D features, X = ||x||, Y = max_c ||c||):
+//   reference chain (oracle/vq_oracle.c::vqo_assign):  |s_ref - s| <= u (x2 + y2) + u s + 2 D u X Y
+//   screen:  split 2 * 2^-18 X Y;  accumulation of 2 D products + the initial value inside the MFMAs, modelled as one
+//            rounding per added term with TRUNCATION (2u) -- pessimistic for a fused dot-product unit --
+//            2 * 2 D * 2u * (X Y + Y^2 / 2), then doubled again as a safety factor: 16 D u (X Y + Y^2 / 2)
+//   sqrt collapse: distances that differ by < 4 ulp(s) may round to the same sqrt (vqp.py:62) and tie: 8 u s
+//   index bits: the kernel stores the lane-local code number in the 4 low mantissa bits of t: 2 * 16 ulp(t)
+// A row is certified when  t_best - t_second > eps_t,  eps_t = eps_s (an s margin of 2 eps_s).  tests/test_gpu_ops.py
+// measures the actual |t - t_exact| against this bound (it stays below 3 % of it) and checks indices bit for bit.
+
+#include <math.h>
+#include <string.h>
+
+#include "vqhip_internal.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+#define VQ_SCREEN_ROWS 256   // rows per workgroup: 4 waves x 2 row blocks x 32
+
+struct ScreenArgs {
+    const unsigned short *x;
+    int64_t N;
+    int64_t ldx;
+    const char *tiles;                 // screening tiles inside the packed codebook
+    const unsigned short *embed_bf16;  // bf16 codebook copy inside the packed codebook
+    const unsigned *scalars;           // [0] = float bits of max ||c||^2
+    int C;
+    int n_tiles;
+    int64_t *idx_out;
+    unsigned short *q_out;             // nullable
+    int64_t ldq;
+    double *sqerr_partial;             // nullable, one entry per workgroup
+    const uint8_t *row_mask;
+    int *flag_count;
+    int *flag_rows;
+    float *dbg;                        // nullable [N, 4]: t_best, t_second, eps_t, flagged
+};
+
+// best / second best of a 16-score accumulator.  key = score with its 4 low mantissa bits replaced by the register
+// number, so one v_med3 + one v_max per score track both values AND the position of the best.
+__device__ __forceinline__ void top2_tile(const f32x16 &acc, float &m1, float &m2, int &tix, int ct)
+{
+    const float om = m1;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const float k = __uint_as_float((__float_as_uint(acc[e]) & 0xfffffff0u) | (unsigned)e);
+        m2 = __builtin_amdgcn_fmed3f(m1, m2, k);      // m1 >= m2: the median is the new runner-up
+        // fmaxf() on a value made by integer ops costs an extra canonicalising v_max_f32 k, k, k: emit the bare instruction
+        asm("v_max_f32 %0, %1, %2" : "=v"(m1) : "v"(m1), "v"(k));
+    }
+    tix = (m1 != om) ? ct : tix;
+}
+
+template <int DT>
+__global__ void __launch_bounds__(256, 2) vq_screen_kernel(const ScreenArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int TILE_B = 128 * DT + 1024;
+    constexpr int NCHUNK = TILE_B / 1024;          // 1-KiB pieces per tile
+    constexpr int NK = DT / 16;                    // MFMA k-steps
+    constexpr int STEPS = 2 * NK;                  // (k-step, hi/lo part) pairs, 2 MFMAs each
+    constexpr int PMAX = (NCHUNK + 3) / 4;         // pieces per wave
+    constexpr int NB = 2;                          // staging batches
+    constexpr int BS = (PMAX + NB - 1) / NB;
+    constexpr int HALF = STEPS / 2;
+    constexpr int LAG = (HALF > 3) ? HALF - 2 : 1; // steps between a batch's loads and its LDS stores
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 31;
+    const int half = lane >> 5;
+    const int64_t wrow0 = (int64_t)blockIdx.x * VQ_SCREEN_ROWS + wave * 64;
+
+    // ---- tile 0: wave w copies the 1-KiB pieces w, w+4, ... ----
+    const int my_pieces = (NCHUNK - wave + 3) / 4;
+    const int piece_off = wave * 1024 + lane * 16;
+    for (int k = 0; k < my_pieces; ++k)
+        *(f32x4 *)(smem + piece_off + k * 4096) = *(const f32x4 *)(a.tiles + piece_off + (size_t)k * 4096);
+
+    // ---- x rows -> B operands: lane (j, half) holds x[row][16 ks + 8 half + 0..7] for every k-step ----
+    uint4 xb[2][NK];
+    int64_t rows[2];
+    bool row_ok[2];
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) {
+        rows[rb] = wrow0 + rb * 32 + j;
+        row_ok[rb] = rows[rb] < a.N;
+        const int64_t rc = row_ok[rb] ? rows[rb] : (a.N - 1);
+        const unsigned short *p = a.x + rc * a.ldx + 8 * half;
+#pragma unroll
+        for (int ks = 0; ks < NK; ++ks) xb[rb][ks] = *(const uint4 *)(p + ks * 16);
+    }
+
+    // ---- ||x||^2 (any order: it only scales the error bound) ----
+    float eps[2];
+    {
+        const float y2max = __uint_as_float(a.scalars[0]);
+        const float ymax = sqrtf(y2max) * 1.0001f;
+        const float u = 5.9604645e-8f;   // 2^-24
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) {
+            float xs = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < NK; ++ks) {
+                const unsigned w[4] = {xb[rb][ks].x, xb[rb][ks].y, xb[rb][ks].z, xb[rb][ks].w};
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    xs = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, w[q]), __builtin_bit_cast(bf16x2, w[q]), xs, false);
+            }
+            xs += __shfl_xor(xs, 32, 64);
+            xs *= 1.001f;
+            const float xn = sqrtf(xs) * 1.0001f;
+            const float xy = xn * ymax;
+            // eps_s (see the header): 10 u (x2 + y2max + 2 xy)  >=  u (x2 + y2) + 9 u s
+            eps[rb] = u * (10.f * (xs + y2max + 2.f * xy) + (2.f * DT + 128.f) * xy + 16.f * DT * (xy + 0.5f * y2max)) + 4e-8f;
+        }
+    }
+
+    float m1[2] = {-__builtin_inff(), -__builtin_inff()};
+    float m2[2] = {-__builtin_inff(), -__builtin_inff()};
+    int tix[2] = {0, 0};
+
+    const int nt = a.n_tiles;
+    for (int ct = 0; ct < nt; ++ct) {
+        const int buf = ct & 1;
+        __syncthreads();   // tile ct has landed for every wave; the other buffer is free
+        const char *tile = smem + buf * TILE_B;
+        const bool more = ct + 1 < nt;
+        const char *gsrc = a.tiles + (size_t)(more ? ct + 1 : ct) * TILE_B + piece_off;
+        char *ldst = smem + (buf ^ 1) * TILE_B + piece_off;
+        const int npieces = more ? my_pieces : 0;
+
+        // accumulators start at -||c||^2 / 2 of the register's code (same mapping as the fp32 kernel:
+        // register e <-> code 8 (e >> 2) + 4 half + (e & 3) of the tile)
+        const float *nh = (const float *)(tile + 128 * DT);
+        f32x16 acc0, acc1;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 v = *(const f32x4 *)(nh + 8 * q + 4 * half);
+            acc0[4 * q + 0] = v.x; acc0[4 * q + 1] = v.y; acc0[4 * q + 2] = v.z; acc0[4 * q + 3] = v.w;
+        }
+        acc1 = acc0;
+
+        const uint4 *ap = (const uint4 *)tile + lane;
+        f32x4 stg[BS];
+#pragma unroll
+        for (int s = 0; s < STEPS; ++s) {
+            const int ks = s >> 1;
+            const bf16x8 av = __builtin_bit_cast(bf16x8, ap[s * 64]);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, __builtin_bit_cast(bf16x8, xb[0][ks]), acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, __builtin_bit_cast(bf16x8, xb[1][ks]), acc1, 0, 0, 0);
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                if (s == b * HALF) {
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int i = 0; i < BS; ++i)   // unconditional: a piece past this wave's share reads the tail pad
+                        if (b * BS + i < PMAX) stg[i] = *(const f32x4 *)(gsrc + (size_t)(b * BS + i) * 4096);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (s == b * HALF + LAG) {
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int i = 0; i < BS; ++i)
+                        if (b * BS + i < npieces) *(f32x4 *)(ldst + (b * BS + i) * 4096) = stg[i];
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+        top2_tile(acc0, m1[0], m2[0], tix[0], ct);
+        top2_tile(acc1, m1[1], m2[1], tix[1], ct);
+    }
+
+    // ---- merge the half-waves, certify, emit ----
+    int code[2];
+    bool flagged[2];
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) {
+        const int e = (int)(__float_as_uint(m1[rb]) & 15u);
+        const int c_own = tix[rb] * 32 + 8 * (e >> 2) + 4 * half + (e & 3);
+        const float o1 = __shfl_xor(m1[rb], 32, 64);
+        const float o2 = __shfl_xor(m2[rb], 32, 64);
+        const int oc = __shfl_xor(c_own, 32, 64);
+        const bool take = o1 > m1[rb];
+        const float b1 = take ? o1 : m1[rb];
+        const float lo1 = take ? m1[rb] : o1;
+        const float b2 = fmaxf(lo1, fmaxf(m2[rb], o2));
+        code[rb] = take ? oc : c_own;
+        const float thr = eps[rb] + 8e-6f * fabsf(b1);
+        flagged[rb] = !((b1 - b2) > thr) || code[rb] >= a.C;
+        if (row_ok[rb] && half == 0) {
+            a.idx_out[rows[rb]] = (int64_t)(code[rb] < a.C ? code[rb] : 0);
+            if (a.dbg) {
+                float *d = a.dbg + rows[rb] * 4;
+                d[0] = b1; d[1] = b2; d[2] = thr; d[3] = flagged[rb] ? 1.f : 0.f;
+            }
+        }
+        if (code[rb] >= a.C) code[rb] = 0;
+        // append the uncertified rows to the list (one atomic per wave and row block)
+        const bool f = flagged[rb] && row_ok[rb] && half == 0;
+        const unsigned long long bal = __ballot(f);
+        if (bal) {
+            int base = 0;
+            if (lane == 0) base = atomicAdd(a.flag_count, (int)__popcll(bal));
+            base = __builtin_amdgcn_readfirstlane(base);
+            if (f) a.flag_rows[base + (int)__popcll(bal & ((1ull << lane) - 1ull))] = (int)rows[rb];
+        }
+    }
+
+    // ---- q = bf16 codebook rows, whole rows per wave (8 in flight) ----
+    if (a.q_out) {
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) {
+#pragma unroll
+            for (int r0 = 0; r0 < 32; r0 += 8) {
+                uint2 g[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int c = __builtin_amdgcn_readlane(code[rb], r0 + u);
+                    if (lane * 4 < DT) g[u] = *(const uint2 *)(a.embed_bf16 + (size_t)c * DT + lane * 4);
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int64_t rr = wrow0 + rb * 32 + r0 + u;
+                    if (rr < a.N && lane * 4 < DT) *(uint2 *)(a.q_out + rr * a.ldq + lane * 4) = g[u];
+                }
+            }
+        }
+    }
+
+    // ---- squared-error partial of the certified rows (the listed rows are counted by the exact pass) ----
+    if (a.sqerr_partial) {
+        double ds = 0.0;
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) {
+            const unsigned short *er = a.embed_bf16 + (size_t)code[rb] * DT + 8 * half;
+            f32x2 ls = {0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < NK; ++ks) {
+                const uint4 gq = *(const uint4 *)(er + ks * 16);
+                const unsigned gw[4] = {gq.x, gq.y, gq.z, gq.w};
+                const unsigned xw[4] = {xb[rb][ks].x, xb[rb][ks].y, xb[rb][ks].z, xb[rb][ks].w};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x2 gv = {__uint_as_float(gw[q] << 16), __uint_as_float(gw[q] & 0xffff0000u)};
+                    const f32x2 xv = {__uint_as_float(xw[q] << 16), __uint_as_float(xw[q] & 0xffff0000u)};
+                    const f32x2 df = gv - xv;
+                    ls = __builtin_elementwise_fma(df, df, ls);
+                }
+            }
+            const bool counted = row_ok[rb] && !flagged[rb] && (!a.row_mask || a.row_mask[rows[rb]] != 0);
+            ds += counted ? (double)(ls[0] + ls[1]) : 0.0;
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) ds += __shfl_xor(ds, o, 64);
+        __syncthreads();
+        double *red = (double *)smem;
+        if (lane == 0) red[wave] = ds;
+        __syncthreads();
+        if (tid == 0) a.sqerr_partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+    }
+}
+
+extern "C" int64_t vqhip_screen_blocks(int64_t N)
+{
+    return N <= 0 ? 0 : (N + VQ_SCREEN_ROWS - 1) / VQ_SCREEN_ROWS;
+}
+
+extern "C" int64_t vqhip_screen_partials(int64_t N)
+{
+    return vqhip_screen_blocks(N) + vqhip_assign_blocks(N);
+}
+
+extern "C" size_t vqhip_screen_workspace_bytes(int64_t N)
+{
+    return N <= 0 ? 0 : (size_t)(N + 4) * sizeof(int);
+}
+
+extern "C" int vqhip_screen_supported(int64_t N, int D, int C)
+{
+    return (D == 64 || D == 128 || D == 256) && N > 0 && N < ((int64_t)1 << 31) - 512 && C >= 2;
+}
+
+template <int DT>
+static int launch_screen(const ScreenArgs &a, hipStream_t st)
+{
+    constexpr int SMEM = 2 * (128 * DT + 1024);
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void *)vq_screen_kernel<DT>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+        if (e != hipSuccess) VQ_FAIL((int)e, "hipFuncSetAttribute(screen<%d>): %s", DT, hipGetErrorString(e));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((vq_screen_kernel<DT>), dim3((unsigned)vqhip_screen_blocks(a.N)), dim3(256), SMEM, st, a);
+    return vq_launch_status("vq_screen_kernel");
+}
+
+extern "C" int vqhip_assign_screened(const void *x, int64_t N, int D, int64_t ldx, const float *packed, const float *embed,
+                                     int C, int64_t *idx_out, void *q_out, int64_t ldq, double *sqerr_partial,
+                                     const uint8_t *row_mask, void *workspace, size_t workspace_bytes, float *debug_out,
+                                     void *stream)
+{
+    if (N < 0 || C <= 0) VQ_FAIL(VQHIP_EINVAL, "assign_screened: N < 0 or C <= 0");
+    if (N == 0) return 0;
+    if (!x || !packed || !embed || !idx_out || !workspace) VQ_FAIL(VQHIP_EINVAL, "assign_screened: null pointer");
+    if (!vqhip_screen_supported(N, D, C)) VQ_FAIL(VQHIP_EDIM, "assign_screened: N=%lld D=%d C=%d outside the screened path (D in {64,128,256}, C >= 2)", (long long)N, D, C);
+    if (workspace_bytes < vqhip_screen_workspace_bytes(N)) VQ_FAIL(VQHIP_EINVAL, "assign_screened: workspace too small");
+    if (ldx < D || (q_out && ldq < D)) VQ_FAIL(VQHIP_EINVAL, "assign_screened: row stride smaller than D");
+    if ((((uintptr_t)packed) & 15) || (((uintptr_t)embed) & 15) || (((uintptr_t)workspace) & 3))
+        VQ_FAIL(VQHIP_EALIGN, "assign_screened: packed / embed must be 16-byte aligned");
+    if ((((uintptr_t)x) & 15) || ((ldx * 2) & 15)) VQ_FAIL(VQHIP_EALIGN, "assign_screened: x rows must be 16-byte aligned");
+    if (q_out && ((((uintptr_t)q_out) & 7) || ((ldq * 2) & 7))) VQ_FAIL(VQHIP_EALIGN, "assign_screened: q rows must be 8-byte aligned");
+
+    hipStream_t st = (hipStream_t)stream;
+    int *count = (int *)workspace;
+    int *rows = count + 4;
+    hipError_t e = hipMemsetAsync(count, 0, 16, st);
+    if (e != hipSuccess) VQ_FAIL((int)e, "assign_screened: hipMemsetAsync: %s", hipGetErrorString(e));
+
+    const char *base = (const char *)packed;
+    ScreenArgs a;
+    a.x = (const unsigned short *)x; a.N = N; a.ldx = ldx;
+    a.tiles = base + vq_packed_screen_offset(C, D);
+    a.embed_bf16 = (const unsigned short *)(base + vq_packed_bf16_offset(C, D));
+    a.scalars = (const unsigned *)(base + vq_packed_scalars_offset(C, D));
+    a.C = C; a.n_tiles = (C + 31) / 32;
+    a.idx_out = idx_out; a.q_out = (unsigned short *)q_out; a.ldq = ldq;
+    a.sqerr_partial = sqerr_partial; a.row_mask = row_mask;
+    a.flag_count = count; a.flag_rows = rows; a.dbg = debug_out;
+    int rc;
+    switch (D) {
+        case 64: rc = launch_screen<64>(a, st); break;
+        case 128: rc = launch_screen<128>(a, st); break;
+        default: rc = launch_screen<256>(a, st); break;
+    }
+    if (rc) return rc;
+    return vq_assign_listed(x, N, D, ldx, packed, embed, C, idx_out, q_out, ldq,
+                            sqerr_partial ? sqerr_partial + vqhip_screen_blocks(N) : nullptr, row_mask, rows, count, st);
+}

@@ -10,39 +10,37 @@
 //                       the CODE index on the accumulator-register axis, so the per-row argmin is
 //                       lane-local (no cross-lane reduce inside the sweep) and the N x C distance
 //                       matrix is never written; gather + squared-error partials in the epilogue.
-//   vq_stats_kernel     EMA sufficient statistics via LDS-privatised fp32 accumulators + global atomics
+//   vq_rvq_kernel       the same sweep repeated over Q residual stages with the residual updated in the
+//                       resident B-operand registers (ResidualVQ.forward's loop in one launch)
+//   vq_hist / vq_scan / vq_scatter / vq_segsum_kernel
+//                       EMA sufficient statistics: counting sort of the rows by code, then one workgroup
+//                       per (code, row-segment) sums full rows -- no fp32 atomics on the hot part
 //   vq_ema_*_kernel     lerp fold, Laplace smoothing, codebook renormalisation
+//   vq_route_kernel     straight-through / rotation-trick output and its backward (+ commit-loss grad)
 //   vq_decode_kernel    indices -> (summed) codes
+//   vq_reduce_kernel    deterministic fp64 reduction of the per-block loss partials
 //
 // Numerics contract (see DESIGN.md "bit-exact indices"): every fp32 rounding after the dot product
 // follows the reference's CPU arithmetic; the dot product itself is ONE fp32 FMA chain in ascending
 // k (what the f32 MFMA computes), which oracle/vq_oracle.c restates.  BUILD WITH -ffp-contract=off.
 
-#include <hip/hip_runtime.h>
-#include <stdint.h>
-#include <stdio.h>
 #include <string.h>
 #include <math.h>
 
-#include "../../include/vqhip.h"
+#include "vqhip_internal.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-
-static thread_local char g_err[256] = "";
-#define VQ_FAIL(code, ...)                           \
-    do {                                             \
-        snprintf(g_err, sizeof g_err, __VA_ARGS__);  \
-        return (code);                               \
-    } while (0)
+thread_local char vq_g_err[256] = "";
+#define g_err vq_g_err
 
 extern "C" const char *vqhip_last_error(void) { return g_err; }
-extern "C" const char *vqhip_version(void) { return "vqhip 0.1 (gfx950)"; }
+extern "C" const char *vqhip_version(void) { return "vqhip 0.2 (gfx950)"; }
 
-static inline int launch_status(const char *what)
+int vq_launch_status(const char *what)
 {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
@@ -51,6 +49,7 @@ static inline int launch_status(const char *what)
     }
     return 0;
 }
+#define launch_status vq_launch_status
 
 // ------------------------------------------------------------------------------------------------
 // small device helpers
@@ -119,35 +118,21 @@ __device__ float aten_sumsq_seq(F ld, int D)
 // so that lane (i, hi) fetches the A values of MFMA k-steps 4*t4 .. 4*t4+3 with one ds_read_b128
 // and a whole wave reads 1 KiB contiguous (conflict-free).
 // ------------------------------------------------------------------------------------------------
-static inline int pick_dt(int D)
-{
-    if (D <= 32) return 32;
-    if (D <= 64) return 64;
-    if (D <= 128) return 128;
-    if (D <= 256) return 256;
-    if (D <= 512) return 512;
-    return 0;
-}
+#define pick_dt vq_pick_dt
+#define packed_bf16_offset vq_packed_bf16_offset
 
 extern "C" size_t vqhip_packed_bytes(int C, int D)
 {
     const int DT = pick_dt(D);
     if (DT == 0 || C <= 0) return 0;
-    const size_t tiles = ((size_t)C + 31) / 32;
-    // tiles | 4 KiB tail pad (the staged copy over-reads <= 3 KiB) | codebook rounded to bf16 [C, D] (q / loss of the bf16 path)
-    return tiles * ((size_t)32 * DT + 256) * sizeof(float) + 4096 + (((size_t)C * D * 2 + 15) & ~(size_t)15);
-}
-
-static inline size_t packed_bf16_offset(int C, int D)   // bytes from the start of the packed buffer
-{
-    const int DT = pick_dt(D);
-    const size_t tiles = ((size_t)C + 31) / 32;
-    return tiles * ((size_t)32 * DT + 256) * sizeof(float) + 4096;
+    return vq_packed_scalars_offset(C, D) + 16;   // layout: vqhip_internal.h
 }
 
 __global__ void __launch_bounds__(256) vq_pack_kernel(const float *__restrict__ embed, int C, int D, int DT,
-                                                      float *__restrict__ packed, unsigned short *__restrict__ ebf)
+                                                      float *__restrict__ packed, unsigned short *__restrict__ ebf,
+                                                      char *__restrict__ screen, unsigned *__restrict__ scalars)
 {
+    __shared__ float y2sh[32];
     const int t = blockIdx.x;
     for (int p = threadIdx.x; p < 32 * D; p += 256) {   // RNE-rounded bf16 copy of this tile's 32 code rows
         const size_t o = (size_t)t * 32 * D + p;
@@ -164,7 +149,7 @@ __global__ void __launch_bounds__(256) vq_pack_kernel(const float *__restrict__ 
         const int k = 8 * t4 + 2 * jj + hi;
         out[p] = (code < C && k < D) ? embed[(size_t)code * D + k] : 0.f;
     }
-    if (threadIdx.x < 256) {
+    {
         const int i = threadIdx.x;
         float v = 0.f;
         if (i < 32) {
@@ -175,8 +160,33 @@ __global__ void __launch_bounds__(256) vq_pack_kernel(const float *__restrict__ 
             } else {
                 v = INFINITY;
             }
+            y2sh[i] = v;
         }
         out[32 * DT + i] = v;
+    }
+    // ---- screening tile (vq_screen.hip): c = c_hi + c_lo (+ <= 2^-18 |c|), both bf16, in the A-operand order of
+    //      v_mfma_f32_32x32x16_bf16: 16 bytes per lane and (k-step, part); lane l = code (l & 31), k-slot 8 * (l >> 5) + e.
+    //      Then 32 floats -||c||^2 / 2 (the accumulator's initial value; -3e38 for padding codes).
+    unsigned short *st = (unsigned short *)(screen + (size_t)t * vq_tile_bytes(DT));
+    for (int p = threadIdx.x; p < 64 * DT; p += 256) {
+        const int e = p & 7;
+        const int l = (p >> 3) & 63;
+        const int part = (p >> 9) & 1;
+        const int ks = p >> 10;
+        const int code = t * 32 + (l & 31);
+        const int k = ks * 16 + 8 * (l >> 5) + e;
+        const float v = (code < C && k < D) ? embed[(size_t)code * D + k] : 0.f;
+        const unsigned short h = f32_to_bf16_rne(v);
+        const unsigned short lo = f32_to_bf16_rne(v - bf16_bits_to_f32(h));   // v - h is exact in fp32
+        st[p] = part ? lo : h;
+    }
+    __syncthreads();
+    {
+        float *nh = (float *)((char *)st + (size_t)128 * DT);
+        const int i = threadIdx.x;
+        const bool real = (i < 32) && (t * 32 + i < C);
+        nh[i] = (i < 32) ? (real ? -0.5f * y2sh[i] : -3.0e38f) : 0.f;
+        if (real) atomicMax(scalars, __float_as_uint(y2sh[i]));   // non-negative floats order like their bit patterns
     }
 }
 
@@ -187,8 +197,12 @@ extern "C" int vqhip_pack_codebook(const float *embed, int C, int D, float *pack
     if (D < 1 || DT == 0) VQ_FAIL(VQHIP_EDIM, "pack_codebook: D=%d unsupported (1..512)", D);
     if (((uintptr_t)packed) & 15) VQ_FAIL(VQHIP_EALIGN, "pack_codebook: packed must be 16-byte aligned");
     const int tiles = (C + 31) / 32;
+    char *base = (char *)packed;
+    unsigned *scalars = (unsigned *)(base + vq_packed_scalars_offset(C, D));
+    hipError_t e = hipMemsetAsync(scalars, 0, 16, (hipStream_t)stream);
+    if (e != hipSuccess) VQ_FAIL((int)e, "pack_codebook: hipMemsetAsync: %s", hipGetErrorString(e));
     hipLaunchKernelGGL(vq_pack_kernel, dim3(tiles), dim3(256), 0, (hipStream_t)stream, embed, C, D, DT, packed,
-                       (unsigned short *)((char *)packed + packed_bf16_offset(C, D)));
+                       (unsigned short *)(base + packed_bf16_offset(C, D)), base + vq_packed_screen_offset(C, D), scalars);
     return launch_status("vq_pack_kernel");
 }
 
@@ -340,6 +354,8 @@ struct AssignArgs {
     int x_vec;  // 1: D == DT and x rows are vector-load aligned
     int q_vec;  // 1: D == DT and q rows are vector-store aligned
     int skip_norm;  // cosine: rows are already unit-norm
+    const int *row_list;   // LIST instantiation only: the rows to process, [*row_count] (vq_assign_listed)
+    const int *row_count;
 #ifdef VQ_TRACE
     long long *trace;
 #endif
@@ -353,7 +369,7 @@ __device__ __forceinline__ void swap32(float &a, float &b)
     b = __uint_as_float(r[1]);
 }
 
-template <int DT, bool XBF16, int METRIC>
+template <int DT, bool XBF16, int METRIC, bool LIST = false>
 __global__ void __launch_bounds__(256, (DT <= 256 ? 2 : 1)) vq_assign_kernel(const AssignArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -367,9 +383,26 @@ __global__ void __launch_bounds__(256, (DT <= 256 ? 2 : 1)) vq_assign_kernel(con
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 31;   // row within the wave's 32-row block  (MFMA N index)
     const int hi = lane >> 5;  // which of the 2 k's of an MFMA step this lane feeds
-    const int64_t row = (int64_t)blockIdx.x * VQHIP_ASSIGN_ROWS_PER_BLOCK + wave * 32 + j;
-    const bool row_ok = row < a.N;
-    const int64_t rowc = row_ok ? row : (a.N - 1);
+    // LIST: this workgroup owns positions [128 * blockIdx.x, +128) of the row list instead of a contiguous row range
+    int list_n = 0;
+    if (LIST) {
+        list_n = __builtin_amdgcn_readfirstlane(*a.row_count);
+        if ((int64_t)blockIdx.x * VQHIP_ASSIGN_ROWS_PER_BLOCK >= list_n) {
+            if (tid == 0 && a.sqerr_partial) a.sqerr_partial[blockIdx.x] = 0.0;
+            return;
+        }
+    }
+    const int64_t pos = (int64_t)blockIdx.x * VQHIP_ASSIGN_ROWS_PER_BLOCK + wave * 32 + j;
+    const bool row_ok = LIST ? (pos < list_n) : (pos < a.N);
+    const int lrow = LIST ? a.row_list[row_ok ? pos : (list_n - 1)] : 0;
+    const int64_t row = LIST ? (int64_t)lrow : pos;
+    const int64_t rowc = row_ok ? row : (LIST ? row : (a.N - 1));
+    // output row of the wave's r-th row, -1 when there is none (r wave-uniform)
+    auto out_row = [&](int r) -> int64_t {
+        const int64_t p0 = (int64_t)blockIdx.x * VQHIP_ASSIGN_ROWS_PER_BLOCK + wave * 32 + r;
+        if (LIST) return (p0 < list_n) ? (int64_t)__builtin_amdgcn_readlane(lrow, r) : (int64_t)-1;
+        return (p0 < a.N) ? p0 : (int64_t)-1;
+    };
 
     // ---- codebook tiles L2 -> LDS: wave w moves the 1-KiB pieces w, w+4, ... of a tile (this lane: 16 bytes of each) ----
     const int my_pieces = (NCHUNK - wave + 3) / 4;
@@ -518,7 +551,6 @@ __global__ void __launch_bounds__(256, (DT <= 256 ? 2 : 1)) vq_assign_kernel(con
     //      winning code row L2 -> HBM as whole contiguous rows (per-lane-row stores of 8..16 bytes were
     //      measured at 1.7x write amplification: profiles/r1_first).  8 rows in flight per wave. ------
     if (a.q_out) {
-        const int64_t wrow0 = (int64_t)blockIdx.x * VQHIP_ASSIGN_ROWS_PER_BLOCK + wave * 32;
         const bool qb = a.q_bf16 != 0;
         if (a.q_vec && a.x_vec && qb) {     // bf16 out: verbatim copy of the pre-rounded rows, 8 bytes per lane
 #pragma unroll
@@ -536,8 +568,8 @@ __global__ void __launch_bounds__(256, (DT <= 256 ? 2 : 1)) vq_assign_kernel(con
                 }
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
-                    const int64_t rr = wrow0 + r0 + u;
-                    if (rr < a.N) {
+                    const int64_t rr = out_row(r0 + u);
+                    if (rr >= 0) {
 #pragma unroll
                         for (int h = 0; h < (DT + 255) / 256; ++h) {
                             const int d = h * 256 + lane * 4;
@@ -562,8 +594,8 @@ __global__ void __launch_bounds__(256, (DT <= 256 ? 2 : 1)) vq_assign_kernel(con
                 }
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
-                    const int64_t rr = wrow0 + r0 + u;
-                    if (rr < a.N) {
+                    const int64_t rr = out_row(r0 + u);
+                    if (rr >= 0) {
 #pragma unroll
                         for (int h = 0; h < (DT + 255) / 256; ++h) {
                             const int d = h * 256 + lane * 4;
@@ -574,8 +606,8 @@ __global__ void __launch_bounds__(256, (DT <= 256 ? 2 : 1)) vq_assign_kernel(con
             }
         } else {
             for (int r = 0; r < 32; ++r) {
-                const int64_t rr = wrow0 + r;
-                if (rr >= a.N) break;
+                const int64_t rr = out_row(r);
+                if (rr < 0) break;
                 const int c = __builtin_amdgcn_readlane(bi, r);
                 const float *er = a.embed + (size_t)c * a.D;
                 for (int d = lane; d < a.D; d += 64) {
@@ -667,6 +699,44 @@ static int launch_assign(const AssignArgs &a, hipStream_t st)
 }
 
 template <int DT>
+static int launch_assign_listed(const AssignArgs &a, hipStream_t st)
+{
+    constexpr int TILE_B = (32 * DT + 256) * 4;
+    constexpr int SMEM = 2 * TILE_B;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void *)vq_assign_kernel<DT, true, 0, true>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+        if (e != hipSuccess) VQ_FAIL((int)e, "hipFuncSetAttribute(assign_listed<%d>): %s", DT, hipGetErrorString(e));
+        attr_done = true;
+    }
+    const int64_t blocks = vqhip_assign_blocks(a.N);   // worst case: every row listed
+    hipLaunchKernelGGL((vq_assign_kernel<DT, true, 0, true>), dim3((unsigned)blocks), dim3(256), SMEM, st, a);
+    return launch_status("vq_assign_kernel<listed>");
+}
+
+int vq_assign_listed(const void *x, int64_t N, int D, int64_t ldx, const float *packed, const float *embed, int C,
+                     int64_t *idx_out, void *q_out, int64_t ldq, double *sqerr_partial, const uint8_t *row_mask,
+                     const int *row_list, const int *row_count, hipStream_t st)
+{
+    AssignArgs a;
+    memset(&a, 0, sizeof a);
+    a.x = x; a.N = N; a.D = D; a.ldx = ldx; a.packed = packed; a.embed = embed; a.C = C;
+    a.embed_bf16 = (const unsigned short *)((const char *)packed + packed_bf16_offset(C, D));
+    a.n_tiles = (C + 31) / 32;
+    a.idx_out = idx_out; a.q_out = q_out; a.q_bf16 = 1; a.ldq = ldq;
+    a.sqerr_partial = sqerr_partial; a.row_mask = row_mask;
+    a.x_vec = 1; a.q_vec = q_out ? 1 : 0;   // the caller (vqhip_assign_screened) checked D == DT and the alignments
+    a.row_list = row_list; a.row_count = row_count;
+    switch (pick_dt(D)) {
+        case 64: return launch_assign_listed<64>(a, st);
+        case 128: return launch_assign_listed<128>(a, st);
+        case 256: return launch_assign_listed<256>(a, st);
+        default: VQ_FAIL(VQHIP_EDIM, "assign_listed: D=%d unsupported", D);
+    }
+}
+
+template <int DT>
 static int dispatch_assign(const AssignArgs &a, int x_dtype, int metric, hipStream_t st)
 {
     if (x_dtype == VQHIP_BF16)
@@ -753,6 +823,7 @@ static int assign_impl(const void *x, int x_dtype, int64_t N, int D, int64_t ldx
     a.n_tiles = (C + 31) / 32;
     a.idx_out = idx_out; a.q_out = q_out; a.q_bf16 = (q_dtype == VQHIP_BF16); a.ldq = ldq;
     a.skip_norm = (metric == VQHIP_COSINE_PRENORM);
+    a.row_list = nullptr; a.row_count = nullptr;
 #ifdef VQ_TRACE
     a.trace = g_trace;
 #endif

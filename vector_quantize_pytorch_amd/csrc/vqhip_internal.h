@@ -1,0 +1,58 @@
+// vqhip_internal.h -- declarations shared by the translation units of libvqhip.so (not part of the C ABI).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/vqhip.h"
+
+extern thread_local char vq_g_err[256];
+#define VQ_FAIL(code, ...)                                 \
+    do {                                                   \
+        snprintf(vq_g_err, sizeof vq_g_err, __VA_ARGS__);  \
+        return (code);                                     \
+    } while (0)
+
+int vq_launch_status(const char *what);
+
+// feature-tile width: D is padded to DT in the packed codebook
+static inline int vq_pick_dt(int D)
+{
+    if (D <= 32) return 32;
+    if (D <= 64) return 64;
+    if (D <= 128) return 128;
+    if (D <= 256) return 256;
+    if (D <= 512) return 512;
+    return 0;
+}
+
+// ---- layout of the packed codebook (vqhip_pack_codebook), in bytes from its start ----------------
+//   [0)                     fp32 A-operand tiles of the exact kernel: tiles * (128*DT + 1024)
+//   [+4096)                 tail pad (the staged tile copy over-reads <= 3 KiB)
+//   [bf16_offset)           codebook rounded to bf16, [C, D] row-major (q / loss of bf16 I/O), 16-byte padded
+//   [screen_offset)         bf16 hi/lo split A-operand tiles of the screening kernel: tiles * (128*DT + 1024)
+//   [+4096)                 tail pad
+//   [scalars_offset)        16 bytes: float bits of max_c ||c||^2, 3 reserved words
+__host__ __device__ static inline size_t vq_tile_bytes(int DT) { return (size_t)128 * DT + 1024; }
+static inline size_t vq_packed_bf16_offset(int C, int D)
+{
+    const size_t tiles = ((size_t)C + 31) / 32;
+    return tiles * vq_tile_bytes(vq_pick_dt(D)) + 4096;
+}
+static inline size_t vq_packed_screen_offset(int C, int D)
+{
+    return vq_packed_bf16_offset(C, D) + (((size_t)C * D * 2 + 15) & ~(size_t)15);
+}
+static inline size_t vq_packed_scalars_offset(int C, int D)
+{
+    const size_t tiles = ((size_t)C + 31) / 32;
+    return vq_packed_screen_offset(C, D) + tiles * vq_tile_bytes(vq_pick_dt(D)) + 4096;
+}
+
+// exact fp32-MFMA assignment (vqhip.hip) restricted to the rows listed in row_list[0 .. *row_count), both on the
+// device; x and q are bf16, Euclidean metric.  The grid covers the worst case (every row listed); workgroups past
+// *row_count exit at once.  sqerr_partial (nullable) receives vqhip_assign_blocks(N) entries, zero for idle groups.
+int vq_assign_listed(const void *x, int64_t N, int D, int64_t ldx, const float *packed, const float *embed, int C,
+                     int64_t *idx_out, void *q_out, int64_t ldq, double *sqerr_partial, const uint8_t *row_mask,
+                     const int *row_list, const int *row_count, hipStream_t st);
