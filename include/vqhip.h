@@ -81,7 +81,7 @@ int vqhip_assign(const void *x, int x_dtype, int64_t N, int D, int64_t ldx,
  * best-vs-second margin is inside the proven error bound (csrc/vq_screen.hip) are re-evaluated by the exact fp32 kernel,
  * on the same stream, before the call's work completes.  Replaces the same reference lines as vqhip_assign.
  *   supported:      vqhip_screen_supported(N, D, C) != 0  (D in {64, 128, 256}); x rows 16-byte aligned, q rows 8-byte
- *   workspace:      vqhip_screen_workspace_bytes(N) bytes, 4-byte aligned; on completion ((int *)workspace)[0] is the
+ *   workspace:      vqhip_screen_workspace_bytes(N) bytes, 8-byte aligned; on completion ((int *)workspace)[0] is the
  *                   number of rows that took the exact pass (diagnostic)
  *   sqerr_partial:  nullable, vqhip_screen_partials(N) doubles, all written; feed them to vqhip_reduce_partials
  *   debug_out:      nullable [N, 4] floats: best score, runner-up, certification threshold, 1.0 if re-evaluated */

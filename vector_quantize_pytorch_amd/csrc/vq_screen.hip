@@ -5,7 +5,7 @@
 // cheaper, still exactly:
 //
 //   1. screen (this file): bf16 rows are exact MFMA operands; the fp32 codebook is split c = c_hi + c_lo into two
-//      bf16 parts (|c - c_hi - c_lo| <= 2^-18 |c|) and  t[n, c] = x_n . c_hi + x_n . c_lo - ||c||^2 / 2  is
+//      bf16 parts (bf16 keeps 8 significant bits: |c - c_hi - c_lo| <= 2^-16 |c|) and  t[n, c] = x_n . c_hi + x_n . c_lo - ||c||^2 / 2  is
 //      accumulated by v_mfma_f32_32x32x16_bf16 (2 passes at 16x the fp32 rate).  argmax_c t = argmin_c cdist up to an
 //      error eps(n) that is bounded below; per row the kernel keeps the best and the second best t.
 //   2. a row whose margin (best - second) exceeds the bound has a certified winner: every other code is farther in
@@ -16,13 +16,13 @@
 //
 // Error bound, in units of s = ||x||^2 + ||c||^2 - 2 x.c (u = 2^-24, D features, X = ||x||, Y = max_c ||c||):
 //   reference chain (oracle/vq_oracle.c::vqo_assign):  |s_ref - s| <= u (x2 + y2) + u s + 2 D u X Y
-//   screen:  split 2 * 2^-18 X Y;  accumulation of 2 D products + the initial value inside the MFMAs, modelled as one
+//   screen:  split 2 * 2^-16 X Y = 512 u X Y;  accumulation of 2 D products + the initial value inside the MFMAs, modelled as one
 //            rounding per added term with TRUNCATION (2u) -- pessimistic for a fused dot-product unit --
 //            2 * 2 D * 2u * (X Y + Y^2 / 2), then doubled again as a safety factor: 16 D u (X Y + Y^2 / 2)
 //   sqrt collapse: distances that differ by < 4 ulp(s) may round to the same sqrt (vqp.py:62) and tie: 8 u s
 //   index bits: the kernel stores the lane-local code number in the 4 low mantissa bits of t: 2 * 16 ulp(t)
 // A row is certified when  t_best - t_second > eps_t,  eps_t = eps_s (an s margin of 2 eps_s).  tests/test_gpu_ops.py
-// measures the actual |t - t_exact| against this bound (it stays below 3 % of it) and checks indices bit for bit.
+// measures the actual |t - t_exact| against this bound (observed: below 2 % of it) and checks indices bit for bit.
 
 #include <math.h>
 #include <string.h>
@@ -35,7 +35,15 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 
-#define VQ_SCREEN_ROWS 256   // rows per workgroup: 4 waves x 2 row blocks x 32
+#ifndef VQS_PF
+#define VQS_PF 4             // depth of the A-fragment ring (LDS -> VGPR prefetch distance in steps of 2 MFMAs)
+#define VQS_PIN 1
+#endif
+#ifndef VQS_WAVES
+#define VQS_WAVES 4          // waves per workgroup (2 workgroups of 4 or 1 of 8 per CU: 2 waves per SIMD either way)
+#endif
+
+#define VQ_SCREEN_ROWS (VQS_WAVES * 64)   // rows per workgroup: waves x 2 row blocks x 32
 
 struct ScreenArgs {
     const unsigned short *x;
@@ -72,14 +80,14 @@ __device__ __forceinline__ void top2_tile(const f32x16 &acc, float &m1, float &m
 }
 
 template <int DT>
-__global__ void __launch_bounds__(256, 2) vq_screen_kernel(const ScreenArgs a)
+__global__ void __launch_bounds__(VQS_WAVES * 64, 8 / VQS_WAVES) vq_screen_kernel(const ScreenArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int TILE_B = 128 * DT + 1024;
     constexpr int NCHUNK = TILE_B / 1024;          // 1-KiB pieces per tile
     constexpr int NK = DT / 16;                    // MFMA k-steps
     constexpr int STEPS = 2 * NK;                  // (k-step, hi/lo part) pairs, 2 MFMAs each
-    constexpr int PMAX = (NCHUNK + 3) / 4;         // pieces per wave
+    constexpr int PMAX = (NCHUNK + VQS_WAVES - 1) / VQS_WAVES;   // pieces per wave
     constexpr int NB = 2;                          // staging batches
     constexpr int BS = (PMAX + NB - 1) / NB;
     constexpr int HALF = STEPS / 2;
@@ -92,11 +100,12 @@ __global__ void __launch_bounds__(256, 2) vq_screen_kernel(const ScreenArgs a)
     const int half = lane >> 5;
     const int64_t wrow0 = (int64_t)blockIdx.x * VQ_SCREEN_ROWS + wave * 64;
 
-    // ---- tile 0: wave w copies the 1-KiB pieces w, w+4, ... ----
-    const int my_pieces = (NCHUNK - wave + 3) / 4;
+    // ---- tile 0: wave w copies the 1-KiB pieces w, w + WAVES, ... ----
+    constexpr int PSTRIDE = VQS_WAVES * 1024;
+    const int my_pieces = (NCHUNK - wave + VQS_WAVES - 1) / VQS_WAVES;
     const int piece_off = wave * 1024 + lane * 16;
     for (int k = 0; k < my_pieces; ++k)
-        *(f32x4 *)(smem + piece_off + k * 4096) = *(const f32x4 *)(a.tiles + piece_off + (size_t)k * 4096);
+        *(f32x4 *)(smem + piece_off + k * PSTRIDE) = *(const f32x4 *)(a.tiles + piece_off + (size_t)k * PSTRIDE);
 
     // ---- x rows -> B operands: lane (j, half) holds x[row][16 ks + 8 half + 0..7] for every k-step ----
     uint4 xb[2][NK];
@@ -133,7 +142,7 @@ __global__ void __launch_bounds__(256, 2) vq_screen_kernel(const ScreenArgs a)
             const float xn = sqrtf(xs) * 1.0001f;
             const float xy = xn * ymax;
             // eps_s (see the header): 10 u (x2 + y2max + 2 xy)  >=  u (x2 + y2) + 9 u s
-            eps[rb] = u * (10.f * (xs + y2max + 2.f * xy) + (2.f * DT + 128.f) * xy + 16.f * DT * (xy + 0.5f * y2max)) + 4e-8f;
+            eps[rb] = u * (10.f * (xs + y2max + 2.f * xy) + (2.f * DT + 512.f) * xy + 16.f * DT * (xy + 0.5f * y2max)) + 4e-8f;
         }
     }
 
@@ -164,32 +173,45 @@ __global__ void __launch_bounds__(256, 2) vq_screen_kernel(const ScreenArgs a)
 
         const uint4 *ap = (const uint4 *)tile + lane;
         f32x4 stg[BS];
+        uint4 af[VQS_PF];   // A-fragment ring: the ds_read of step s + VQS_PF is issued behind the MFMAs of step s
+#pragma unroll
+        for (int p = 0; p < VQS_PF; ++p) af[p] = ap[p * 64];
 #pragma unroll
         for (int s = 0; s < STEPS; ++s) {
             const int ks = s >> 1;
-            const bf16x8 av = __builtin_bit_cast(bf16x8, ap[s * 64]);
+            const bf16x8 av = __builtin_bit_cast(bf16x8, af[s % VQS_PF]);
             acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, __builtin_bit_cast(bf16x8, xb[0][ks]), acc0, 0, 0, 0);
             acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, __builtin_bit_cast(bf16x8, xb[1][ks]), acc1, 0, 0, 0);
+            if (s + VQS_PF < STEPS) af[s % VQS_PF] = ap[(s + VQS_PF) * 64];
+#ifdef VQS_PIN
+            __builtin_amdgcn_sched_barrier(0);   // keep the prefetch distance: hipcc otherwise sinks the ds_reads next to their use
+#endif
+#ifndef VQS_NO_STAGE
 #pragma unroll
             for (int b = 0; b < NB; ++b) {
                 if (s == b * HALF) {
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int i = 0; i < BS; ++i)   // unconditional: a piece past this wave's share reads the tail pad
-                        if (b * BS + i < PMAX) stg[i] = *(const f32x4 *)(gsrc + (size_t)(b * BS + i) * 4096);
+                        if (b * BS + i < PMAX) stg[i] = *(const f32x4 *)(gsrc + (size_t)(b * BS + i) * PSTRIDE);
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 if (s == b * HALF + LAG) {
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int i = 0; i < BS; ++i)
-                        if (b * BS + i < npieces) *(f32x4 *)(ldst + (b * BS + i) * 4096) = stg[i];
+                        if (b * BS + i < npieces) *(f32x4 *)(ldst + (b * BS + i) * PSTRIDE) = stg[i];
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
+#endif
         }
+#ifndef VQS_NO_EPI
         top2_tile(acc0, m1[0], m2[0], tix[0], ct);
         top2_tile(acc1, m1[1], m2[1], tix[1], ct);
+#else
+        m1[0] = fmaxf(m1[0], acc0[ct & 15]); m1[1] = fmaxf(m1[1], acc1[ct & 15]);
+#endif
     }
 
     // ---- merge the half-waves, certify, emit ----
@@ -278,7 +300,12 @@ __global__ void __launch_bounds__(256, 2) vq_screen_kernel(const ScreenArgs a)
         double *red = (double *)smem;
         if (lane == 0) red[wave] = ds;
         __syncthreads();
-        if (tid == 0) a.sqerr_partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+        if (tid == 0) {
+            double t = 0.0;
+#pragma unroll
+            for (int w = 0; w < VQS_WAVES; ++w) t += red[w];
+            a.sqerr_partial[blockIdx.x] = t;
+        }
     }
 }
 
@@ -289,12 +316,13 @@ extern "C" int64_t vqhip_screen_blocks(int64_t N)
 
 extern "C" int64_t vqhip_screen_partials(int64_t N)
 {
-    return vqhip_screen_blocks(N) + vqhip_assign_blocks(N);
+    return N <= 0 ? 0 : vqhip_screen_blocks(N) + VQ_FINISH_BLOCKS;
 }
 
 extern "C" size_t vqhip_screen_workspace_bytes(int64_t N)
 {
-    return N <= 0 ? 0 : (size_t)(N + 4) * sizeof(int);
+    // 16-byte header (count) | N ints (row list, padded to 8 bytes) | N u64 (keys of the exact pass)
+    return N <= 0 ? 0 : 16 + (((size_t)N * sizeof(int) + 7) & ~(size_t)7) + (size_t)N * sizeof(unsigned long long);
 }
 
 extern "C" int vqhip_screen_supported(int64_t N, int D, int C)
@@ -312,7 +340,7 @@ static int launch_screen(const ScreenArgs &a, hipStream_t st)
         if (e != hipSuccess) VQ_FAIL((int)e, "hipFuncSetAttribute(screen<%d>): %s", DT, hipGetErrorString(e));
         attr_done = true;
     }
-    hipLaunchKernelGGL((vq_screen_kernel<DT>), dim3((unsigned)vqhip_screen_blocks(a.N)), dim3(256), SMEM, st, a);
+    hipLaunchKernelGGL((vq_screen_kernel<DT>), dim3((unsigned)vqhip_screen_blocks(a.N)), dim3(VQS_WAVES * 64), SMEM, st, a);
     return vq_launch_status("vq_screen_kernel");
 }
 
@@ -327,8 +355,8 @@ extern "C" int vqhip_assign_screened(const void *x, int64_t N, int D, int64_t ld
     if (!vqhip_screen_supported(N, D, C)) VQ_FAIL(VQHIP_EDIM, "assign_screened: N=%lld D=%d C=%d outside the screened path (D in {64,128,256}, C >= 2)", (long long)N, D, C);
     if (workspace_bytes < vqhip_screen_workspace_bytes(N)) VQ_FAIL(VQHIP_EINVAL, "assign_screened: workspace too small");
     if (ldx < D || (q_out && ldq < D)) VQ_FAIL(VQHIP_EINVAL, "assign_screened: row stride smaller than D");
-    if ((((uintptr_t)packed) & 15) || (((uintptr_t)embed) & 15) || (((uintptr_t)workspace) & 3))
-        VQ_FAIL(VQHIP_EALIGN, "assign_screened: packed / embed must be 16-byte aligned");
+    if ((((uintptr_t)packed) & 15) || (((uintptr_t)embed) & 15) || (((uintptr_t)workspace) & 7))
+        VQ_FAIL(VQHIP_EALIGN, "assign_screened: packed / embed must be 16-byte aligned, workspace 8-byte aligned");
     if ((((uintptr_t)x) & 15) || ((ldx * 2) & 15)) VQ_FAIL(VQHIP_EALIGN, "assign_screened: x rows must be 16-byte aligned");
     if (q_out && ((((uintptr_t)q_out) & 7) || ((ldq * 2) & 7))) VQ_FAIL(VQHIP_EALIGN, "assign_screened: q rows must be 8-byte aligned");
 
@@ -356,5 +384,6 @@ extern "C" int vqhip_assign_screened(const void *x, int64_t N, int D, int64_t ld
     }
     if (rc) return rc;
     return vq_assign_listed(x, N, D, ldx, packed, embed, C, idx_out, q_out, ldq,
-                            sqerr_partial ? sqerr_partial + vqhip_screen_blocks(N) : nullptr, row_mask, rows, count, st);
+                            sqerr_partial ? sqerr_partial + vqhip_screen_blocks(N) : nullptr, row_mask, rows, count,
+                            (unsigned long long *)((char *)workspace + 16 + (((size_t)N * sizeof(int) + 7) & ~(size_t)7)), st);
 }

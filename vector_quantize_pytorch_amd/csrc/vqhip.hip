@@ -164,7 +164,7 @@ __global__ void __launch_bounds__(256) vq_pack_kernel(const float *__restrict__ 
         }
         out[32 * DT + i] = v;
     }
-    // ---- screening tile (vq_screen.hip): c = c_hi + c_lo (+ <= 2^-18 |c|), both bf16, in the A-operand order of
+    // ---- screening tile (vq_screen.hip): c = c_hi + c_lo (+ <= 2^-16 |c|), both bf16, in the A-operand order of
     //      v_mfma_f32_32x32x16_bf16: 16 bytes per lane and (k-step, part); lane l = code (l & 31), k-slot 8 * (l >> 5) + e.
     //      Then 32 floats -||c||^2 / 2 (the accumulator's initial value; -3e38 for padding codes).
     unsigned short *st = (unsigned short *)(screen + (size_t)t * vq_tile_bytes(DT));
@@ -323,6 +323,33 @@ __device__ __forceinline__ void argmin_tile(const f32x16 &acc, const float *y2s,
     bi = win ? (base + 8 * (ew >> 2) + 4 * hi + (ew & 3)) : bi;
 }
 
+// ||x||^2 of the wave's rows in ATen's CPU order (vqp.py:59), from the "load layout" registers
+// xr[4m + r] = x[row][8m + 4hi + r]: chain (e % 32) over e ascending, then lane-wise ((a0+a1)+a2)+a3 over the ILP
+// accumulators, then the 8 SIMD lanes left to right.  Element e = 8m + 4hi + r sits in chain [m & 3][4hi + r].
+// Zero padding (D < DT) only adds +0 to non-negative chains.  Valid for D % 32 == 0 (odd D: pre-pass, see host).
+template <int DT>
+__device__ __forceinline__ float x2_aten_order(const float (&xr)[DT / 2], int j)
+{
+    constexpr int NG = DT / 8;
+    // two chains per v_pk_mul_f32 / v_pk_add_f32 (each component rounds exactly like the scalar op)
+    f32x2 ch[4][2];
+#pragma unroll
+    for (int mm = 0; mm < 4; ++mm) { ch[mm][0] = f32x2{0.f, 0.f}; ch[mm][1] = f32x2{0.f, 0.f}; }
+#pragma unroll
+    for (int m = 0; m < NG; ++m) {
+        const f32x2 v01 = {xr[4 * m + 0], xr[4 * m + 1]}, v23 = {xr[4 * m + 2], xr[4 * m + 3]};
+        ch[m & 3][0] = ch[m & 3][0] + v01 * v01;
+        ch[m & 3][1] = ch[m & 3][1] + v23 * v23;
+    }
+    float p[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) p[r] = ((ch[0][r >> 1][r & 1] + ch[1][r >> 1][r & 1]) + ch[2][r >> 1][r & 1]) + ch[3][r >> 1][r & 1];
+    const float f_lo = ((p[0] + p[1]) + p[2]) + p[3];          // SIMD lanes 0..3 (hi == 0 half)
+    const float f_from_lo = __shfl(f_lo, j, 64);               // value of the hi == 0 partner
+    const float f_hi = (((f_from_lo + p[0]) + p[1]) + p[2]) + p[3];  // continue with lanes 4..7
+    return __shfl(f_hi, j + 32, 64);
+}
+
 #ifdef VQ_TRACE
 static long long *g_trace = nullptr;
 extern "C" void vqhip_set_trace(long long *p) { g_trace = p; }
@@ -354,8 +381,6 @@ struct AssignArgs {
     int x_vec;  // 1: D == DT and x rows are vector-load aligned
     int q_vec;  // 1: D == DT and q rows are vector-store aligned
     int skip_norm;  // cosine: rows are already unit-norm
-    const int *row_list;   // LIST instantiation only: the rows to process, [*row_count] (vq_assign_listed)
-    const int *row_count;
 #ifdef VQ_TRACE
     long long *trace;
 #endif
@@ -369,7 +394,7 @@ __device__ __forceinline__ void swap32(float &a, float &b)
     b = __uint_as_float(r[1]);
 }
 
-template <int DT, bool XBF16, int METRIC, bool LIST = false>
+template <int DT, bool XBF16, int METRIC>
 __global__ void __launch_bounds__(256, (DT <= 256 ? 2 : 1)) vq_assign_kernel(const AssignArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -383,26 +408,9 @@ __global__ void __launch_bounds__(256, (DT <= 256 ? 2 : 1)) vq_assign_kernel(con
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 31;   // row within the wave's 32-row block  (MFMA N index)
     const int hi = lane >> 5;  // which of the 2 k's of an MFMA step this lane feeds
-    // LIST: this workgroup owns positions [128 * blockIdx.x, +128) of the row list instead of a contiguous row range
-    int list_n = 0;
-    if (LIST) {
-        list_n = __builtin_amdgcn_readfirstlane(*a.row_count);
-        if ((int64_t)blockIdx.x * VQHIP_ASSIGN_ROWS_PER_BLOCK >= list_n) {
-            if (tid == 0 && a.sqerr_partial) a.sqerr_partial[blockIdx.x] = 0.0;
-            return;
-        }
-    }
-    const int64_t pos = (int64_t)blockIdx.x * VQHIP_ASSIGN_ROWS_PER_BLOCK + wave * 32 + j;
-    const bool row_ok = LIST ? (pos < list_n) : (pos < a.N);
-    const int lrow = LIST ? a.row_list[row_ok ? pos : (list_n - 1)] : 0;
-    const int64_t row = LIST ? (int64_t)lrow : pos;
-    const int64_t rowc = row_ok ? row : (LIST ? row : (a.N - 1));
-    // output row of the wave's r-th row, -1 when there is none (r wave-uniform)
-    auto out_row = [&](int r) -> int64_t {
-        const int64_t p0 = (int64_t)blockIdx.x * VQHIP_ASSIGN_ROWS_PER_BLOCK + wave * 32 + r;
-        if (LIST) return (p0 < list_n) ? (int64_t)__builtin_amdgcn_readlane(lrow, r) : (int64_t)-1;
-        return (p0 < a.N) ? p0 : (int64_t)-1;
-    };
+    const int64_t row = (int64_t)blockIdx.x * VQHIP_ASSIGN_ROWS_PER_BLOCK + wave * 32 + j;
+    const bool row_ok = row < a.N;
+    const int64_t rowc = row_ok ? row : (a.N - 1);
 
     // ---- codebook tiles L2 -> LDS: wave w moves the 1-KiB pieces w, w+4, ... of a tile (this lane: 16 bytes of each) ----
     const int my_pieces = (NCHUNK - wave + 3) / 4;
@@ -449,26 +457,7 @@ __global__ void __launch_bounds__(256, (DT <= 256 ? 2 : 1)) vq_assign_kernel(con
     //      In the load layout element e = 8m + 4hi + r sits in chain [m & 3][4hi + r].
     //      Zero padding (D < DT) only adds +0 to non-negative chains.  Rows whose D is not a
     //      multiple of 32 take x2 from a pre-pass (a.rnorm_out pre-filled) -- see host wrapper. ----
-    float x2;
-    {
-        // two chains per v_pk_mul_f32 / v_pk_add_f32 (each component rounds exactly like the scalar op)
-        f32x2 ch[4][2];
-#pragma unroll
-        for (int mm = 0; mm < 4; ++mm) { ch[mm][0] = f32x2{0.f, 0.f}; ch[mm][1] = f32x2{0.f, 0.f}; }
-#pragma unroll
-        for (int m = 0; m < NG; ++m) {
-            const f32x2 v01 = {xr[4 * m + 0], xr[4 * m + 1]}, v23 = {xr[4 * m + 2], xr[4 * m + 3]};
-            ch[m & 3][0] = ch[m & 3][0] + v01 * v01;
-            ch[m & 3][1] = ch[m & 3][1] + v23 * v23;
-        }
-        float p[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) p[r] = ((ch[0][r >> 1][r & 1] + ch[1][r >> 1][r & 1]) + ch[2][r >> 1][r & 1]) + ch[3][r >> 1][r & 1];
-        const float f_lo = ((p[0] + p[1]) + p[2]) + p[3];          // SIMD lanes 0..3 (hi == 0 half)
-        const float f_from_lo = __shfl(f_lo, j, 64);               // value of the hi == 0 partner
-        const float f_hi = (((f_from_lo + p[0]) + p[1]) + p[2]) + p[3];  // continue with lanes 4..7
-        x2 = __shfl(f_hi, j + 32, 64);
-    }
+    float x2 = x2_aten_order<DT>(xr, j);
     if (a.D & 31) x2 = a.rnorm_out[rowc];  // exact ATen order for odd D was precomputed
 
     float nrm = 0.f;
@@ -551,6 +540,7 @@ __global__ void __launch_bounds__(256, (DT <= 256 ? 2 : 1)) vq_assign_kernel(con
     //      winning code row L2 -> HBM as whole contiguous rows (per-lane-row stores of 8..16 bytes were
     //      measured at 1.7x write amplification: profiles/r1_first).  8 rows in flight per wave. ------
     if (a.q_out) {
+        const int64_t wrow0 = (int64_t)blockIdx.x * VQHIP_ASSIGN_ROWS_PER_BLOCK + wave * 32;
         const bool qb = a.q_bf16 != 0;
         if (a.q_vec && a.x_vec && qb) {     // bf16 out: verbatim copy of the pre-rounded rows, 8 bytes per lane
 #pragma unroll
@@ -568,8 +558,8 @@ __global__ void __launch_bounds__(256, (DT <= 256 ? 2 : 1)) vq_assign_kernel(con
                 }
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
-                    const int64_t rr = out_row(r0 + u);
-                    if (rr >= 0) {
+                    const int64_t rr = wrow0 + r0 + u;
+                    if (rr < a.N) {
 #pragma unroll
                         for (int h = 0; h < (DT + 255) / 256; ++h) {
                             const int d = h * 256 + lane * 4;
@@ -594,8 +584,8 @@ __global__ void __launch_bounds__(256, (DT <= 256 ? 2 : 1)) vq_assign_kernel(con
                 }
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
-                    const int64_t rr = out_row(r0 + u);
-                    if (rr >= 0) {
+                    const int64_t rr = wrow0 + r0 + u;
+                    if (rr < a.N) {
 #pragma unroll
                         for (int h = 0; h < (DT + 255) / 256; ++h) {
                             const int d = h * 256 + lane * 4;
@@ -606,8 +596,8 @@ __global__ void __launch_bounds__(256, (DT <= 256 ? 2 : 1)) vq_assign_kernel(con
             }
         } else {
             for (int r = 0; r < 32; ++r) {
-                const int64_t rr = out_row(r);
-                if (rr < 0) break;
+                const int64_t rr = wrow0 + r;
+                if (rr >= a.N) break;
                 const int c = __builtin_amdgcn_readlane(bi, r);
                 const float *er = a.embed + (size_t)c * a.D;
                 for (int d = lane; d < a.D; d += 64) {
@@ -699,44 +689,6 @@ static int launch_assign(const AssignArgs &a, hipStream_t st)
 }
 
 template <int DT>
-static int launch_assign_listed(const AssignArgs &a, hipStream_t st)
-{
-    constexpr int TILE_B = (32 * DT + 256) * 4;
-    constexpr int SMEM = 2 * TILE_B;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void *)vq_assign_kernel<DT, true, 0, true>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
-        if (e != hipSuccess) VQ_FAIL((int)e, "hipFuncSetAttribute(assign_listed<%d>): %s", DT, hipGetErrorString(e));
-        attr_done = true;
-    }
-    const int64_t blocks = vqhip_assign_blocks(a.N);   // worst case: every row listed
-    hipLaunchKernelGGL((vq_assign_kernel<DT, true, 0, true>), dim3((unsigned)blocks), dim3(256), SMEM, st, a);
-    return launch_status("vq_assign_kernel<listed>");
-}
-
-int vq_assign_listed(const void *x, int64_t N, int D, int64_t ldx, const float *packed, const float *embed, int C,
-                     int64_t *idx_out, void *q_out, int64_t ldq, double *sqerr_partial, const uint8_t *row_mask,
-                     const int *row_list, const int *row_count, hipStream_t st)
-{
-    AssignArgs a;
-    memset(&a, 0, sizeof a);
-    a.x = x; a.N = N; a.D = D; a.ldx = ldx; a.packed = packed; a.embed = embed; a.C = C;
-    a.embed_bf16 = (const unsigned short *)((const char *)packed + packed_bf16_offset(C, D));
-    a.n_tiles = (C + 31) / 32;
-    a.idx_out = idx_out; a.q_out = q_out; a.q_bf16 = 1; a.ldq = ldq;
-    a.sqerr_partial = sqerr_partial; a.row_mask = row_mask;
-    a.x_vec = 1; a.q_vec = q_out ? 1 : 0;   // the caller (vqhip_assign_screened) checked D == DT and the alignments
-    a.row_list = row_list; a.row_count = row_count;
-    switch (pick_dt(D)) {
-        case 64: return launch_assign_listed<64>(a, st);
-        case 128: return launch_assign_listed<128>(a, st);
-        case 256: return launch_assign_listed<256>(a, st);
-        default: VQ_FAIL(VQHIP_EDIM, "assign_listed: D=%d unsupported", D);
-    }
-}
-
-template <int DT>
 static int dispatch_assign(const AssignArgs &a, int x_dtype, int metric, hipStream_t st)
 {
     if (x_dtype == VQHIP_BF16)
@@ -823,7 +775,6 @@ static int assign_impl(const void *x, int x_dtype, int64_t N, int D, int64_t ldx
     a.n_tiles = (C + 31) / 32;
     a.idx_out = idx_out; a.q_out = q_out; a.q_bf16 = (q_dtype == VQHIP_BF16); a.ldq = ldq;
     a.skip_norm = (metric == VQHIP_COSINE_PRENORM);
-    a.row_list = nullptr; a.row_count = nullptr;
 #ifdef VQ_TRACE
     a.trace = g_trace;
 #endif
@@ -845,6 +796,197 @@ static int assign_impl(const void *x, int x_dtype, int64_t N, int D, int64_t ldx
         case 256: return dispatch_assign<256>(a, x_dtype, metric, st);
         default: return dispatch_assign<512>(a, x_dtype, metric, st);  // metric != 0 -> cosine family
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// exact pass over a LIST of rows (the rows vq_screen.hip could not certify).  Same arithmetic as
+// vq_assign_kernel<DT, bf16, euclid> -- same device functions -- but organised for a short list: the codebook sweep
+// is split over gridDim.y workgroups per 128-row chunk (a few thousand rows would otherwise occupy a fraction of the
+// CUs for a full sweep each), the partial winners meet in an atomicMin on the 64-bit key (bits(d) << 32 | index),
+// which is exactly "smallest distance, then lowest index", and vq_finish_listed_kernel emits index, q and the
+// squared error.  The list length is only known on the device: fixed grids, chunk loops.
+// ------------------------------------------------------------------------------------------------
+struct RefineArgs {
+    const unsigned short *x;
+    int64_t ldx;
+    const float *packed;
+    int C;
+    int n_tiles;
+    const int *row_list;
+    const int *row_count;
+    unsigned long long *keys;   // [list capacity], preset to ~0
+};
+
+template <int DT>
+__global__ void __launch_bounds__(256, 2) vq_refine_kernel(const RefineArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int TILE_F = 32 * DT + 256;
+    constexpr int TILE_B = TILE_F * 4;
+    constexpr int NCHUNK = TILE_B / 1024;
+    constexpr int NG = DT / 8;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 31;
+    const int hi = lane >> 5;
+    const int list_n = __builtin_amdgcn_readfirstlane(*a.row_count);
+    const int tps = (a.n_tiles + (int)gridDim.y - 1) / (int)gridDim.y;   // tiles per split
+    const int ct0 = (int)blockIdx.y * tps;
+    const int ct1 = min(a.n_tiles, ct0 + tps);
+    if (ct0 >= ct1) return;
+    const int my_pieces = (NCHUNK - wave + 3) / 4;
+    const int piece_off = wave * 1024 + lane * 16;
+
+    for (int64_t chunk = blockIdx.x; chunk * VQHIP_ASSIGN_ROWS_PER_BLOCK < list_n; chunk += gridDim.x) {
+        __syncthreads();   // the previous chunk's last tile has been consumed by every wave
+        for (int k = 0; k < my_pieces; ++k)
+            *(f32x4 *)(smem + piece_off + k * 4096) =
+                *(const f32x4 *)((const char *)a.packed + (size_t)ct0 * TILE_B + piece_off + (size_t)k * 4096);
+
+        const int64_t pos = chunk * VQHIP_ASSIGN_ROWS_PER_BLOCK + wave * 32 + j;
+        const bool row_ok = pos < list_n;
+        const int64_t row = a.row_list[row_ok ? pos : (int64_t)(list_n - 1)];
+        float xr[DT / 2];   // load layout, as in vq_assign_kernel
+        {
+            const uint2 *p = (const uint2 *)(a.x + row * a.ldx + 4 * hi);
+#pragma unroll
+            for (int m = 0; m < NG; ++m) {
+                const uint2 w = p[m * 2];
+                xr[4 * m + 0] = __uint_as_float(w.x << 16);
+                xr[4 * m + 1] = __uint_as_float(w.x & 0xffff0000u);
+                xr[4 * m + 2] = __uint_as_float(w.y << 16);
+                xr[4 * m + 3] = __uint_as_float(w.y & 0xffff0000u);
+            }
+        }
+        const float x2 = x2_aten_order<DT>(xr, j);
+#pragma unroll
+        for (int m = 0; m < NG; ++m) {   // -> MFMA B-operand layout
+            swap32(xr[4 * m + 0], xr[4 * m + 1]);
+            swap32(xr[4 * m + 2], xr[4 * m + 3]);
+        }
+
+        float bd = INFINITY, bs = INFINITY;
+        int bi = 0;
+        for (int ct = ct0; ct < ct1; ++ct) {
+            const int buf = (ct - ct0) & 1;
+            __syncthreads();
+            const char *tile = smem + buf * TILE_B;
+            const f32x4 *ap = (const f32x4 *)tile + (hi * 32 + j);
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            const bool more = ct + 1 < ct1;
+            mfma_sweep_tile<DT>(ap, xr, acc, (const char *)a.packed + (size_t)(more ? ct + 1 : ct) * TILE_B + piece_off,
+                                smem + (buf ^ 1) * TILE_B + piece_off, more ? my_pieces : 0);
+            argmin_tile<0>(acc, (const float *)tile + 32 * DT, x2, ct * 32, hi, a.C, bd, bs, bi);
+        }
+        {
+            const float od = __shfl_xor(bd, 32, 64);
+            const int oi = __shfl_xor(bi, 32, 64);
+            const bool take = (od < bd) || (od == bd && oi < bi);
+            bd = take ? od : bd;
+            bi = take ? oi : bi;
+        }
+        if (row_ok && hi == 0)
+            atomicMin(a.keys + pos, ((unsigned long long)__float_as_uint(bd) << 32) | (unsigned long long)(unsigned)bi);
+    }
+}
+
+struct FinishArgs {
+    const unsigned short *x;
+    int64_t ldx;
+    const unsigned short *embed_bf16;
+    int D;
+    const int *row_list;
+    const int *row_count;
+    const unsigned long long *keys;
+    int64_t *idx_out;
+    unsigned short *q_out;   // nullable
+    int64_t ldq;
+    double *sqerr_partial;   // nullable, one entry per workgroup
+    const uint8_t *row_mask;
+};
+
+// one wave per listed row: idx, q row, sum (q - x)^2
+__global__ void __launch_bounds__(256) vq_finish_listed_kernel(const FinishArgs a)
+{
+    __shared__ double red[4];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int n = *a.row_count;
+    double acc = 0.0;
+    for (int64_t pos = (int64_t)blockIdx.x * 4 + wave; pos < n; pos += (int64_t)gridDim.x * 4) {
+        const int64_t row = a.row_list[pos];
+        const int idx = (int)(unsigned)(a.keys[pos] & 0xffffffffull);
+        if (lane == 0) a.idx_out[row] = (int64_t)idx;
+        float ls = 0.f;
+        if (lane * 4 < a.D) {
+            const uint2 g = *(const uint2 *)(a.embed_bf16 + (size_t)idx * a.D + lane * 4);
+            const uint2 xv = *(const uint2 *)(a.x + row * a.ldx + lane * 4);
+            if (a.q_out) *(uint2 *)(a.q_out + row * a.ldq + lane * 4) = g;
+            const float d0 = __uint_as_float(g.x << 16) - __uint_as_float(xv.x << 16);
+            const float d1 = __uint_as_float(g.x & 0xffff0000u) - __uint_as_float(xv.x & 0xffff0000u);
+            const float d2 = __uint_as_float(g.y << 16) - __uint_as_float(xv.y << 16);
+            const float d3 = __uint_as_float(g.y & 0xffff0000u) - __uint_as_float(xv.y & 0xffff0000u);
+            ls = ((d0 * d0 + d1 * d1) + d2 * d2) + d3 * d3;
+        }
+        double ds = (double)ls;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) ds += __shfl_xor(ds, o, 64);
+        if (!a.row_mask || a.row_mask[row] != 0) acc += ds;
+    }
+    if (a.sqerr_partial) {
+        if (lane == 0) red[wave] = acc;
+        __syncthreads();
+        if (threadIdx.x == 0) a.sqerr_partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+    }
+}
+
+template <int DT>
+static int launch_refine(const RefineArgs &a, unsigned gx, unsigned gy, hipStream_t st)
+{
+    constexpr int SMEM = 2 * (32 * DT + 256) * 4;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void *)vq_refine_kernel<DT>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+        if (e != hipSuccess) VQ_FAIL((int)e, "hipFuncSetAttribute(refine<%d>): %s", DT, hipGetErrorString(e));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((vq_refine_kernel<DT>), dim3(gx, gy), dim3(256), SMEM, st, a);
+    return launch_status("vq_refine_kernel");
+}
+
+int vq_assign_listed(const void *x, int64_t N, int D, int64_t ldx, const float *packed, const float *embed, int C,
+                     int64_t *idx_out, void *q_out, int64_t ldq, double *sqerr_partial, const uint8_t *row_mask,
+                     const int *row_list, const int *row_count, unsigned long long *keys, hipStream_t st)
+{
+    (void)embed;
+    hipError_t e = hipMemsetAsync(keys, 0xff, (size_t)N * sizeof(unsigned long long), st);
+    if (e != hipSuccess) VQ_FAIL((int)e, "assign_listed: hipMemsetAsync: %s", hipGetErrorString(e));
+    RefineArgs r;
+    r.x = (const unsigned short *)x; r.ldx = ldx; r.packed = packed; r.C = C; r.n_tiles = (C + 31) / 32;
+    r.row_list = row_list; r.row_count = row_count; r.keys = keys;
+    const int64_t chunks = vqhip_assign_blocks(N);
+    const unsigned gx = (unsigned)(chunks < 1024 ? chunks : 1024);
+    int splits = r.n_tiles / 8;   // >= 8 tiles per workgroup, at most 8 splits
+    splits = splits < 1 ? 1 : (splits > 8 ? 8 : splits);
+    int rc;
+    switch (pick_dt(D)) {
+        case 64: rc = launch_refine<64>(r, gx, (unsigned)splits, st); break;
+        case 128: rc = launch_refine<128>(r, gx, (unsigned)splits, st); break;
+        case 256: rc = launch_refine<256>(r, gx, (unsigned)splits, st); break;
+        default: VQ_FAIL(VQHIP_EDIM, "assign_listed: D=%d unsupported", D);
+    }
+    if (rc) return rc;
+    FinishArgs f;
+    f.x = (const unsigned short *)x; f.ldx = ldx;
+    f.embed_bf16 = (const unsigned short *)((const char *)packed + packed_bf16_offset(C, D));
+    f.D = D; f.row_list = row_list; f.row_count = row_count; f.keys = keys;
+    f.idx_out = idx_out; f.q_out = (unsigned short *)q_out; f.ldq = ldq; f.sqerr_partial = sqerr_partial; f.row_mask = row_mask;
+    hipLaunchKernelGGL(vq_finish_listed_kernel, dim3(VQ_FINISH_BLOCKS), dim3(256), 0, st, f);
+    return launch_status("vq_finish_listed_kernel");
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -32,7 +32,7 @@ static inline int vq_pick_dt(int D)
 //   [+4096)                 tail pad (the staged tile copy over-reads <= 3 KiB)
 //   [bf16_offset)           codebook rounded to bf16, [C, D] row-major (q / loss of bf16 I/O), 16-byte padded
 //   [screen_offset)         bf16 hi/lo split A-operand tiles of the screening kernel: tiles * (128*DT + 1024)
-//   [+4096)                 tail pad
+//   [+8192)                 tail pad (8 waves x 1 KiB over-read at most)
 //   [scalars_offset)        16 bytes: float bits of max_c ||c||^2, 3 reserved words
 __host__ __device__ static inline size_t vq_tile_bytes(int DT) { return (size_t)128 * DT + 1024; }
 static inline size_t vq_packed_bf16_offset(int C, int D)
@@ -47,12 +47,13 @@ static inline size_t vq_packed_screen_offset(int C, int D)
 static inline size_t vq_packed_scalars_offset(int C, int D)
 {
     const size_t tiles = ((size_t)C + 31) / 32;
-    return vq_packed_screen_offset(C, D) + tiles * vq_tile_bytes(vq_pick_dt(D)) + 4096;
+    return vq_packed_screen_offset(C, D) + tiles * vq_tile_bytes(vq_pick_dt(D)) + 8192;
 }
 
 // exact fp32-MFMA assignment (vqhip.hip) restricted to the rows listed in row_list[0 .. *row_count), both on the
-// device; x and q are bf16, Euclidean metric.  The grid covers the worst case (every row listed); workgroups past
-// *row_count exit at once.  sqerr_partial (nullable) receives vqhip_assign_blocks(N) entries, zero for idle groups.
+// device; x and q are bf16 with D == DT and vector-aligned rows, Euclidean metric.  keys: scratch, N u64.
+// sqerr_partial (nullable) receives VQ_FINISH_BLOCKS entries.
+#define VQ_FINISH_BLOCKS 128
 int vq_assign_listed(const void *x, int64_t N, int D, int64_t ldx, const float *packed, const float *embed, int C,
                      int64_t *idx_out, void *q_out, int64_t ldq, double *sqerr_partial, const uint8_t *row_mask,
-                     const int *row_list, const int *row_count, hipStream_t st);
+                     const int *row_list, const int *row_count, unsigned long long *keys, hipStream_t st);
