@@ -283,3 +283,100 @@ def test_dense_scores_match_oracle_bitwise(dev, N, C, D, cos):
     want = O.c_scores(xo, e, cos)
     assert torch.equal(dist.cpu(), want)
     assert torch.equal(idx.cpu(), want.argmax(-1))
+
+
+# ---- screened assignment (csrc/vq_screen.hip): bf16 rows, bf16-MFMA screen + exact pass on the uncertified rows --------
+def _screen_case(N, C, D, kind, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(N, D, generator=g).bfloat16()
+    if kind == "kaiming":      # the reference's default init (vqp.py:28-31): tiny codes, the near-tie worst case
+        e = (torch.rand(C, D, generator=g) * 2 - 1) * (6.0 / D) ** 0.5
+    elif kind == "unit":
+        e = torch.randn(C, D, generator=g)
+    elif kind == "rows":       # codes drawn from the data, as after k-means init / dead-code replacement
+        e = x[torch.randperm(N, generator=g)[:C]].float().contiguous()
+    elif kind == "dups":       # duplicated codes: no row whose best code has a twin can be certified
+        e = torch.randn(C, D, generator=g)
+        e[C // 2:] = e[: C - C // 2]
+    elif kind == "tiny":       # collapsed codebook, score gaps close to the rounding level
+        e = torch.randn(C, D, generator=g) * 1e-3
+    else:
+        raise ValueError(kind)
+    return x, e
+
+
+@pytest.mark.parametrize("N,C,D,kind", [
+    (4099, 1024, 256, "kaiming"),    # cfg 2 shape, ragged N
+    (5000, 1000, 256, "unit"),       # C not a multiple of 32
+    (300, 37, 128, "unit"),
+    (20000, 512, 64, "rows"),
+    (8192, 1024, 256, "dups"),
+    (8192, 1024, 256, "tiny"),
+    (1000, 2, 64, "unit"),
+    (3000, 4096, 128, "kaiming"),    # cfg 5 per-group shape
+])
+def test_screened_assign_matches_chain_oracle(dev, N, C, D, kind):
+    from vector_quantize_pytorch_amd import _lib as L
+    x, e = _screen_case(N, C, D, kind)
+    xd, ed = x.to(dev), e.to(dev)
+    r = L.assign(xd, L.pack_codebook(ed), ed, want_q=True, want_sqerr=True)
+    assert r.get("n_exact") is not None, "bf16 rows with D in {64,128,256} must take the screened path"
+    idx_o, _ = O.c_assign(x.float(), e)
+    mism = (r["idx"].cpu() != idx_o).sum().item()
+    assert mism == 0, f"{mism}/{N} index mismatches vs chain oracle"
+    want_q = e[idx_o].bfloat16()
+    assert torch.equal(r["q"].cpu(), want_q)
+    sq = r["sqerr_partials"][: r["nblk"]].sum().item()
+    want_sq = ((want_q.double() - x.double()) ** 2).sum().item()
+    assert abs(sq - want_sq) <= 1e-5 * max(want_sq, 1e-12)
+    n_exact = int(r["n_exact"].item())
+    if kind == "dups":
+        assert n_exact == N            # every best code has an identical twin: all rows go through the exact kernel
+    elif kind in ("kaiming", "unit", "rows"):
+        assert n_exact <= 0.1 * N      # the screen certifies the bulk (observed: 0.3 .. 3 %)
+
+
+def test_screened_scores_stay_inside_certified_bound(dev):
+    """|screen score - exact score| must be far below the certification threshold (csrc/vq_screen.hip header):
+    the bound is a pessimistic model of the MFMA's internal accumulation, this measures the real thing."""
+    from vector_quantize_pytorch_amd import _lib as L
+    worst = 0.0
+    for (N, C, D, kind) in [(8192, 1024, 256, "kaiming"), (8192, 1024, 256, "unit"), (8192, 512, 64, "rows"), (8192, 1024, 128, "tiny")]:
+        x, e = _screen_case(N, C, D, kind, seed=3)
+        xd, ed = x.to(dev), e.to(dev)
+        L.screen_debug = True
+        try:
+            r = L.assign(xd, L.pack_codebook(ed), ed, want_q=False)
+        finally:
+            L.screen_debug = False
+        dbg = r["screen_debug"].double().cpu()
+        y2 = O.c_row_sumsq(e).double()
+        t = x.double() @ e.double().t() - 0.5 * y2[None, :]       # what the screen approximates
+        top = t.topk(2, dim=1).values
+        err = torch.maximum((dbg[:, 0] - top[:, 0]).abs(), (dbg[:, 1] - top[:, 1]).abs())
+        worst = max(worst, float((err / dbg[:, 2]).max()))
+        # every row the screen certified really has a margin above the threshold in exact arithmetic too
+        cert = dbg[:, 3] == 0
+        assert bool(((top[:, 0] - top[:, 1])[cert] > 0.5 * dbg[:, 2][cert]).all())
+    assert worst < 0.1, f"screen error reaches {worst:.3f} of the certified threshold"
+
+
+def test_screened_masked_strided_rows_and_toggle(dev, monkeypatch):
+    from vector_quantize_pytorch_amd import _lib as L
+    x, e = _screen_case(3000, 256, 128, "unit", seed=5)
+    big = torch.randn(3000, 512).bfloat16()
+    big[:, 128:256] = x
+    xd = big.to(dev)[:, 128:256]                       # strided view, 16-byte aligned rows
+    m = torch.rand(3000) < 0.5
+    ed = e.to(dev)
+    packed = L.pack_codebook(ed)
+    r = L.assign(xd, packed, ed, want_q=True, want_sqerr=True, row_mask=m.to(dev))
+    assert r.get("n_exact") is not None
+    idx_o, _ = O.c_assign(x.float(), e)
+    assert torch.equal(r["idx"].cpu(), idx_o)
+    want = (((e[idx_o].bfloat16().double() - x.double()) ** 2).sum(-1) * m).sum().item()
+    assert abs(r["sqerr_partials"][: r["nblk"]].sum().item() - want) <= 1e-5 * want
+    monkeypatch.setenv("VQHIP_SCREEN", "0")            # the exact kernel on the same input: identical outputs
+    r0 = L.assign(xd, packed, ed, want_q=True, want_sqerr=True, row_mask=m.to(dev))
+    assert r0.get("n_exact") is None
+    assert torch.equal(r0["idx"], r["idx"]) and torch.equal(r0["q"], r["q"])
