@@ -74,25 +74,26 @@ int vqhip_assign(const void *x, int x_dtype, int64_t N, int D, int64_t ldx,
                  float *best_out, float *rnorm_out, double *sqerr_partial,
                  const uint8_t *row_mask, void *stream);
 
-/* ---- screened assignment for bf16 rows (Euclidean) -----------------------------------------------
- * Same contract as vqhip_assign(x bf16, metric VQHIP_EUCLID, q bf16): idx_out bit-identical to the exact kernel, q_out
- * the gathered bf16 code rows, sqerr_partial the squared-error partials -- but the codebook sweep runs on the bf16 MFMA
- * pipe against a two-part bf16 split of the codebook (made by vqhip_pack_codebook), and only the rows whose
- * best-vs-second margin is inside the proven error bound (csrc/vq_screen.hip) are re-evaluated by the exact fp32 kernel,
- * on the same stream, before the call's work completes.  Replaces the same reference lines as vqhip_assign.
- *   supported:      vqhip_screen_supported(N, D, C) != 0  (D in {64, 128, 256}); x rows 16-byte aligned, q rows 8-byte
+/* ---- screened assignment (Euclidean, D in {64, 128, 256}) ------------------------------------------
+ * Same contract as vqhip_assign(metric VQHIP_EUCLID, q in x's dtype): idx_out bit-identical to the exact kernel, q_out
+ * the gathered code rows, sqerr_partial the squared-error partials -- but the codebook sweep runs on the bf16 MFMA pipe
+ * against a two-part bf16 split of the codebook made by vqhip_pack_codebook (fp32 rows are split as well, three products
+ * per k-step), and only the rows whose best-vs-second margin is inside the proven error bound (csrc/vq_screen.hip) are
+ * re-evaluated by the exact fp32-MFMA arithmetic, on the same stream, before the call's work completes.  Replaces the
+ * same reference lines as vqhip_assign.
+ *   supported:      vqhip_screen_supported(N, D, C) != 0; x rows 16-byte aligned, q rows aligned to 4 elements
  *   workspace:      vqhip_screen_workspace_bytes(N) bytes, 8-byte aligned; on completion ((int *)workspace)[0] is the
  *                   number of rows that took the exact pass (diagnostic)
- *   sqerr_partial:  nullable, vqhip_screen_partials(N) doubles, all written; feed them to vqhip_reduce_partials
+ *   sqerr_partial:  nullable, vqhip_screen_partials(N, x_dtype) doubles, all written; feed them to vqhip_reduce_partials
  *   debug_out:      nullable [N, 4] floats: best score, runner-up, certification threshold, 1.0 if re-evaluated */
 int vqhip_screen_supported(int64_t N, int D, int C);
 size_t vqhip_screen_workspace_bytes(int64_t N);
-int64_t vqhip_screen_blocks(int64_t N);
-int64_t vqhip_screen_partials(int64_t N);
-int vqhip_assign_screened(const void *x, int64_t N, int D, int64_t ldx, const float *packed, const float *embed,
-                          int C, int64_t *idx_out, void *q_out, int64_t ldq, double *sqerr_partial,
-                          const uint8_t *row_mask, void *workspace, size_t workspace_bytes, float *debug_out,
-                          void *stream);
+int64_t vqhip_screen_blocks(int64_t N, int x_dtype);
+int64_t vqhip_screen_partials(int64_t N, int x_dtype);
+int vqhip_assign_screened(const void *x, int x_dtype, int64_t N, int D, int64_t ldx, const float *packed,
+                          const float *embed, int C, int64_t *idx_out, void *q_out, int64_t ldq,
+                          double *sqerr_partial, const uint8_t *row_mask, void *workspace, size_t workspace_bytes,
+                          float *debug_out, void *stream);
 
 /* ---- dense scores (rare options only) ------------------------------------------------------------
  * Materialises the tensor the reference calls `dist` (vqp.py:741-743): scores_out[n, c] = -cdist(x_n, c) for the

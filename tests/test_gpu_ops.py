@@ -286,9 +286,9 @@ def test_dense_scores_match_oracle_bitwise(dev, N, C, D, cos):
 
 
 # ---- screened assignment (csrc/vq_screen.hip): bf16 rows, bf16-MFMA screen + exact pass on the uncertified rows --------
-def _screen_case(N, C, D, kind, seed=0):
+def _screen_case(N, C, D, kind, seed=0, dtype=torch.bfloat16):
     g = torch.Generator().manual_seed(seed)
-    x = torch.randn(N, D, generator=g).bfloat16()
+    x = torch.randn(N, D, generator=g).to(dtype)
     if kind == "kaiming":      # the reference's default init (vqp.py:28-31): tiny codes, the near-tie worst case
         e = (torch.rand(C, D, generator=g) * 2 - 1) * (6.0 / D) ** 0.5
     elif kind == "unit":
@@ -315,16 +315,17 @@ def _screen_case(N, C, D, kind, seed=0):
     (1000, 2, 64, "unit"),
     (3000, 4096, 128, "kaiming"),    # cfg 5 per-group shape
 ])
-def test_screened_assign_matches_chain_oracle(dev, N, C, D, kind):
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_screened_assign_matches_chain_oracle(dev, N, C, D, kind, dtype):
     from vector_quantize_pytorch_amd import _lib as L
-    x, e = _screen_case(N, C, D, kind)
+    x, e = _screen_case(N, C, D, kind, dtype=dtype)
     xd, ed = x.to(dev), e.to(dev)
     r = L.assign(xd, L.pack_codebook(ed), ed, want_q=True, want_sqerr=True)
-    assert r.get("n_exact") is not None, "bf16 rows with D in {64,128,256} must take the screened path"
+    assert r.get("n_exact") is not None, "rows with D in {64,128,256} must take the screened path"
     idx_o, _ = O.c_assign(x.float(), e)
     mism = (r["idx"].cpu() != idx_o).sum().item()
     assert mism == 0, f"{mism}/{N} index mismatches vs chain oracle"
-    want_q = e[idx_o].bfloat16()
+    want_q = e[idx_o].to(dtype)
     assert torch.equal(r["q"].cpu(), want_q)
     sq = r["sqerr_partials"][: r["nblk"]].sum().item()
     want_sq = ((want_q.double() - x.double()) ** 2).sum().item()
@@ -341,8 +342,11 @@ def test_screened_scores_stay_inside_certified_bound(dev):
     the bound is a pessimistic model of the MFMA's internal accumulation, this measures the real thing."""
     from vector_quantize_pytorch_amd import _lib as L
     worst = 0.0
-    for (N, C, D, kind) in [(8192, 1024, 256, "kaiming"), (8192, 1024, 256, "unit"), (8192, 512, 64, "rows"), (8192, 1024, 128, "tiny")]:
-        x, e = _screen_case(N, C, D, kind, seed=3)
+    for (N, C, D, kind, dtype) in [(8192, 1024, 256, "kaiming", torch.bfloat16), (8192, 1024, 256, "unit", torch.bfloat16),
+                                   (8192, 512, 64, "rows", torch.bfloat16), (8192, 1024, 128, "tiny", torch.bfloat16),
+                                   (8192, 1024, 256, "kaiming", torch.float32), (8192, 1000, 128, "unit", torch.float32),
+                                   (8192, 512, 64, "rows", torch.float32)]:
+        x, e = _screen_case(N, C, D, kind, seed=3, dtype=dtype)
         xd, ed = x.to(dev), e.to(dev)
         L.screen_debug = True
         try:

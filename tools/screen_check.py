@@ -37,8 +37,8 @@ def codebooks(kind, C, D, x, gen):
     raise ValueError(kind)
 
 
-def check(N, C, D, kind, gen, timing=False):
-    x = torch.randn(N, D, device="cuda", generator=gen).to(torch.bfloat16)
+def check(N, C, D, kind, gen, timing=False, dtype=torch.bfloat16):
+    x = torch.randn(N, D, device="cuda", generator=gen).to(dtype)
     embed = codebooks(kind, C, D, x, gen)
     packed = L.pack_codebook(embed)
     r0 = run(x, embed, packed, False)
@@ -50,7 +50,7 @@ def check(N, C, D, kind, gen, timing=False):
     nex = int(r1["n_exact"].item())
     same_idx = bool((r0["idx"] == r1["idx"]).all())
     nbad = int((r0["idx"] != r1["idx"]).sum())
-    same_q = bool((r0["q"].view(torch.int16) == r1["q"].view(torch.int16)).all())
+    same_q = bool(torch.equal(r0["q"], r1["q"]))
     s0 = r0["sqerr_partials"][: r0["nblk"]].sum().item()
     s1 = r1["sqerr_partials"][: r1["nblk"]].sum().item()
     # accuracy of the screening scores on a sample: t = x.c - y2/2 in float64 (y2 = the fp32 value the kernels use)
@@ -65,7 +65,7 @@ def check(N, C, D, kind, gen, timing=False):
     thr = dbg[sel, 2].double()
     ratio = float((torch.maximum(err1, err2) / thr).max())
     flagged = dbg[:, 3].sum().item()
-    line = (f"N={N} C={C} D={D} {kind:8s} idx_equal={same_idx} (bad {nbad}) q_equal={same_q} "
+    line = (f"{str(dtype)[6:]:8s} N={N} C={C} D={D} {kind:8s} idx_equal={same_idx} (bad {nbad}) q_equal={same_q} "
             f"sqerr rel diff={abs(s0 - s1) / max(abs(s0), 1e-30):.2e} exact_rows={nex} ({100.0 * nex / N:.3f}%) "
             f"flagged_dbg={int(flagged)} max|t_err|/thr={ratio:.4f}")
     print(line, flush=True)
@@ -92,11 +92,12 @@ def main():
     cases = [(4096, 1024, 256, "kaiming"), (5000, 1000, 256, "randn"), (300, 37, 128, "randn"), (70000, 512, 64, "rows"),
              (65536, 1024, 256, "rows"), (65536, 1024, 256, "dups"), (65536, 1024, 256, "tiny"), (1000, 2, 64, "randn"),
              (33333, 4096, 128, "kaiming")]
-    for c in cases:
-        ok &= check(*c, gen)
-    if not quick:
-        ok &= check(1 << 20, 1024, 256, "kaiming", gen, timing=True)
-        ok &= check(1 << 20, 1024, 256, "rows", gen, timing=True)
+    for dtype in (torch.bfloat16, torch.float32):
+        for c in cases:
+            ok &= check(*c, gen, dtype=dtype)
+        if not quick:
+            ok &= check(1 << 20, 1024, 256, "kaiming", gen, timing=True, dtype=dtype)
+            ok &= check(1 << 20, 1024, 256, "rows", gen, timing=True, dtype=dtype)
     print("ALL OK" if ok else "FAILURES", flush=True)
     sys.exit(0 if ok else 1)
 

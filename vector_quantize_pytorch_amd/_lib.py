@@ -53,11 +53,11 @@ def lib():
     L.vqhip_screen_supported.restype = i32
     L.vqhip_screen_workspace_bytes.argtypes = [i64]
     L.vqhip_screen_workspace_bytes.restype = ctypes.c_size_t
-    L.vqhip_screen_blocks.argtypes = [i64]
+    L.vqhip_screen_blocks.argtypes = [i64, i32]
     L.vqhip_screen_blocks.restype = i64
-    L.vqhip_screen_partials.argtypes = [i64]
+    L.vqhip_screen_partials.argtypes = [i64, i32]
     L.vqhip_screen_partials.restype = i64
-    L.vqhip_assign_screened.argtypes = [vp, i64, i32, i64, vp, vp, i32, vp, vp, i64, vp, vp, vp, ctypes.c_size_t, vp, vp]
+    L.vqhip_assign_screened.argtypes = [vp, i32, i64, i32, i64, vp, vp, i32, vp, vp, i64, vp, vp, vp, ctypes.c_size_t, vp, vp]
     L.vqhip_assign_screened.restype = i32
     L.vqhip_route_fwd.argtypes = [vp, vp, i32, i64, i32, i64, i64, vp, i64, i32, vp]
     L.vqhip_route_bwd.argtypes = [vp, vp, vp, i32, i64, i32, i64, i64, i64, vp, vp, i32, vp, i64, vp]
@@ -176,15 +176,16 @@ def assign(x: torch.Tensor, packed: torch.Tensor, embed2d: torch.Tensor, *, cosi
         row_mask = row_mask.reshape(-1).to(torch.uint8).contiguous()
         assert row_mask.numel() == N
     if (not cosine and not want_best and not want_rnorm and N > 0 and screening_enabled()
-            and xk.dtype == torch.bfloat16 and xk.data_ptr() % 16 == 0 and (ldx * 2) % 16 == 0
+            and xk.dtype in (torch.bfloat16, torch.float32) and xk.data_ptr() % 16 == 0
+            and (ldx * xk.element_size()) % 16 == 0 and embed2d.data_ptr() % 16 == 0
             and lib().vqhip_screen_supported(N, D, C)):
-        # bf16 rows: bf16-MFMA screen + exact fp32 pass on the uncertified rows only (csrc/vq_screen.hip); same outputs
-        nblk = lib().vqhip_screen_partials(N)
+        # bf16-MFMA screen + exact fp32 pass on the uncertified rows only (csrc/vq_screen.hip); same outputs
+        nblk = lib().vqhip_screen_partials(N, _dtype_code(xk))
         partials = torch.empty(nblk, dtype=torch.float64, device=dev) if want_sqerr else None
         nws = lib().vqhip_screen_workspace_bytes(N)
         ws = torch.empty((nws + 3) // 4, dtype=torch.int32, device=dev)
         dbg = torch.empty(N, 4, dtype=torch.float32, device=dev) if screen_debug else None
-        _check(lib().vqhip_assign_screened(_ptr(xk), N, D, ldx, _ptr(packed), _ptr(embed2d), C, _ptr(idx), _ptr(q), ldq,
+        _check(lib().vqhip_assign_screened(_ptr(xk), _dtype_code(xk), N, D, ldx, _ptr(packed), _ptr(embed2d), C, _ptr(idx), _ptr(q), ldq,
                                            _ptr(partials), _ptr(row_mask), _ptr(ws), nws, _ptr(dbg), _stream()),
                "vqhip_assign_screened")
         return dict(idx=idx, q=q, sqerr_partials=partials, best=None, rnorm=None, nblk=nblk, n_exact=ws[:1], screen_debug=dbg)

@@ -46,23 +46,35 @@ typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 #define VQ_SCREEN_ROWS (VQS_WAVES * 64)   // rows per workgroup: waves x 2 row blocks x 32
 
 struct ScreenArgs {
-    const unsigned short *x;
+    const void *x;                     // rows, bf16 (vq_screen_kernel) or fp32 (vq_screen_f32_kernel)
     int64_t N;
     int64_t ldx;
     const char *tiles;                 // screening tiles inside the packed codebook
     const unsigned short *embed_bf16;  // bf16 codebook copy inside the packed codebook
+    const float *embed;                // fp32 codebook (q rows of fp32 I/O)
     const unsigned *scalars;           // [0] = float bits of max ||c||^2
     int C;
     int n_tiles;
     int64_t *idx_out;
-    unsigned short *q_out;             // nullable
+    void *q_out;                       // nullable, x's dtype
     int64_t ldq;
     double *sqerr_partial;             // nullable, one entry per workgroup
     const uint8_t *row_mask;
     int *flag_count;
     int *flag_rows;
+    unsigned long long *flag_keys;     // [N] keys of the exact pass, preset to ~0 for every appended row
     float *dbg;                        // nullable [N, 4]: t_best, t_second, eps_t, flagged
+#ifdef VQ_TRACE
+    long long *trace;
+#endif
 };
+
+#ifdef VQ_TRACE
+extern long long *vq_g_trace;
+#define VQ_STAMP(slot) do { if (a.trace && blockIdx.x < 16 && lane == 0 && ct < 64) a.trace[(((size_t)blockIdx.x * 4 + wave) * 64 + ct) * 4 + (slot)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define VQ_STAMP(slot) do {} while (0)
+#endif
 
 // best / second best of a 16-score accumulator.  key = score with its 4 low mantissa bits replaced by the register
 // number, so one v_med3 + one v_max per score track both values AND the position of the best.
@@ -116,7 +128,7 @@ __global__ void __launch_bounds__(VQS_WAVES * 64, 8 / VQS_WAVES) vq_screen_kerne
         rows[rb] = wrow0 + rb * 32 + j;
         row_ok[rb] = rows[rb] < a.N;
         const int64_t rc = row_ok[rb] ? rows[rb] : (a.N - 1);
-        const unsigned short *p = a.x + rc * a.ldx + 8 * half;
+        const unsigned short *p = (const unsigned short *)a.x + rc * a.ldx + 8 * half;
 #pragma unroll
         for (int ks = 0; ks < NK; ++ks) xb[rb][ks] = *(const uint4 *)(p + ks * 16);
     }
@@ -153,7 +165,9 @@ __global__ void __launch_bounds__(VQS_WAVES * 64, 8 / VQS_WAVES) vq_screen_kerne
     const int nt = a.n_tiles;
     for (int ct = 0; ct < nt; ++ct) {
         const int buf = ct & 1;
+        VQ_STAMP(0);
         __syncthreads();   // tile ct has landed for every wave; the other buffer is free
+        VQ_STAMP(1);
         const char *tile = smem + buf * TILE_B;
         const bool more = ct + 1 < nt;
         const char *gsrc = a.tiles + (size_t)(more ? ct + 1 : ct) * TILE_B + piece_off;
@@ -206,9 +220,11 @@ __global__ void __launch_bounds__(VQS_WAVES * 64, 8 / VQS_WAVES) vq_screen_kerne
             }
 #endif
         }
+        VQ_STAMP(2);
 #ifndef VQS_NO_EPI
         top2_tile(acc0, m1[0], m2[0], tix[0], ct);
         top2_tile(acc1, m1[1], m2[1], tix[1], ct);
+        VQ_STAMP(3);
 #else
         m1[0] = fmaxf(m1[0], acc0[ct & 15]); m1[1] = fmaxf(m1[1], acc1[ct & 15]);
 #endif
@@ -246,42 +262,47 @@ __global__ void __launch_bounds__(VQS_WAVES * 64, 8 / VQS_WAVES) vq_screen_kerne
             int base = 0;
             if (lane == 0) base = atomicAdd(a.flag_count, (int)__popcll(bal));
             base = __builtin_amdgcn_readfirstlane(base);
-            if (f) a.flag_rows[base + (int)__popcll(bal & ((1ull << lane) - 1ull))] = (int)rows[rb];
-        }
-    }
-
-    // ---- q = bf16 codebook rows, whole rows per wave (8 in flight) ----
-    if (a.q_out) {
-#pragma unroll
-        for (int rb = 0; rb < 2; ++rb) {
-#pragma unroll
-            for (int r0 = 0; r0 < 32; r0 += 8) {
-                uint2 g[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int c = __builtin_amdgcn_readlane(code[rb], r0 + u);
-                    if (lane * 4 < DT) g[u] = *(const uint2 *)(a.embed_bf16 + (size_t)c * DT + lane * 4);
-                }
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int64_t rr = wrow0 + rb * 32 + r0 + u;
-                    if (rr < a.N && lane * 4 < DT) *(uint2 *)(a.q_out + rr * a.ldq + lane * 4) = g[u];
-                }
+            if (f) {
+                const int slot = base + (int)__popcll(bal & ((1ull << lane) - 1ull));
+                a.flag_rows[slot] = (int)rows[rb];
+                a.flag_keys[slot] = ~0ull;
             }
         }
     }
 
-    // ---- squared-error partial of the certified rows (the listed rows are counted by the exact pass) ----
-    if (a.sqerr_partial) {
-        double ds = 0.0;
+    // ---- outputs per row block: the loss operands (this lane's slice of its row's code, L2) are requested first so
+    //      their latency hides behind the q copy; q = bf16 codebook rows written as whole rows, 16 rows in flight;
+    //      squared error of the certified rows from the registers (the listed rows are counted by the exact pass) ----
+    double ds = 0.0;
 #pragma unroll
-        for (int rb = 0; rb < 2; ++rb) {
+    for (int rb = 0; rb < 2; ++rb) {
+        uint4 gq[NK];
+        if (a.sqerr_partial) {
             const unsigned short *er = a.embed_bf16 + (size_t)code[rb] * DT + 8 * half;
+#pragma unroll
+            for (int ks = 0; ks < NK; ++ks) gq[ks] = *(const uint4 *)(er + ks * 16);
+        }
+        if (a.q_out) {
+#pragma unroll
+            for (int r0 = 0; r0 < 32; r0 += 16) {
+                uint2 g[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    const int c = __builtin_amdgcn_readlane(code[rb], r0 + u);
+                    if (lane * 4 < DT) g[u] = *(const uint2 *)(a.embed_bf16 + (size_t)c * DT + lane * 4);
+                }
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    const int64_t rr = wrow0 + rb * 32 + r0 + u;
+                    if (rr < a.N && lane * 4 < DT) *(uint2 *)((unsigned short *)a.q_out + rr * a.ldq + lane * 4) = g[u];
+                }
+            }
+        }
+        if (a.sqerr_partial) {
             f32x2 ls = {0.f, 0.f};
 #pragma unroll
             for (int ks = 0; ks < NK; ++ks) {
-                const uint4 gq = *(const uint4 *)(er + ks * 16);
-                const unsigned gw[4] = {gq.x, gq.y, gq.z, gq.w};
+                const unsigned gw[4] = {gq[ks].x, gq[ks].y, gq[ks].z, gq[ks].w};
                 const unsigned xw[4] = {xb[rb][ks].x, xb[rb][ks].y, xb[rb][ks].z, xb[rb][ks].w};
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
@@ -294,6 +315,8 @@ __global__ void __launch_bounds__(VQS_WAVES * 64, 8 / VQS_WAVES) vq_screen_kerne
             const bool counted = row_ok[rb] && !flagged[rb] && (!a.row_mask || a.row_mask[rows[rb]] != 0);
             ds += counted ? (double)(ls[0] + ls[1]) : 0.0;
         }
+    }
+    if (a.sqerr_partial) {
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) ds += __shfl_xor(ds, o, 64);
         __syncthreads();
@@ -309,14 +332,258 @@ __global__ void __launch_bounds__(VQS_WAVES * 64, 8 / VQS_WAVES) vq_screen_kerne
     }
 }
 
-extern "C" int64_t vqhip_screen_blocks(int64_t N)
+// ------------------------------------------------------------------------------------------------
+// fp32 rows.  x is split as well, x = x_hi + x_mid + r_x (bf16 parts, |r_x| <= 2^-16 |x|), and three products are
+// accumulated per k-step: c_hi x_hi, c_hi x_mid, c_lo x_hi.  Dropped: c_lo x_mid, c r_x, r_c x -- each <= 2^-16 |x||c|
+// (+ second order), so the split term of the bound becomes 3.03 * 2 * 2^-16 X Y <= 1600 u X Y and the accumulation term
+// 24 D u (3 D products).  One 32-row block per wave (the two operand sets of a row block fill the registers the bf16
+// kernel spends on a second row block), VQS_F32_WAVES waves per workgroup; the three MFMAs of a k-step alternate between
+// two accumulators so that no MFMA waits for its predecessor.  q (fp32 code rows) and the squared error are produced by
+// a row-cooperative pass that re-reads x, because the registers only hold x to 16 bits.
+// ------------------------------------------------------------------------------------------------
+#ifndef VQS_F32_WAVES
+#define VQS_F32_WAVES 8
+#endif
+#define VQ_SCREEN_F32_ROWS (VQS_F32_WAVES * 32)
+
+__device__ __forceinline__ void split8_bf16(const f32x4 &v0, const f32x4 &v1, uint4 &h, uint4 &m)
 {
-    return N <= 0 ? 0 : (N + VQ_SCREEN_ROWS - 1) / VQ_SCREEN_ROWS;
+    const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+    unsigned hw[4], mw[4];
+#pragma unroll
+    for (int e = 0; e < 8; e += 2) {
+        const unsigned short h0 = vq_f32_to_bf16_rne(v[e]), h1 = vq_f32_to_bf16_rne(v[e + 1]);
+        const unsigned short m0 = vq_f32_to_bf16_rne(v[e] - vq_bf16_bits_to_f32(h0));       // v - h is exact in fp32
+        const unsigned short m1 = vq_f32_to_bf16_rne(v[e + 1] - vq_bf16_bits_to_f32(h1));
+        hw[e >> 1] = (unsigned)h0 | ((unsigned)h1 << 16);
+        mw[e >> 1] = (unsigned)m0 | ((unsigned)m1 << 16);
+    }
+    h = make_uint4(hw[0], hw[1], hw[2], hw[3]);
+    m = make_uint4(mw[0], mw[1], mw[2], mw[3]);
 }
 
-extern "C" int64_t vqhip_screen_partials(int64_t N)
+template <int DT>
+__global__ void __launch_bounds__(VQS_F32_WAVES * 64, 8 / VQS_F32_WAVES) vq_screen_f32_kernel(const ScreenArgs a)
 {
-    return N <= 0 ? 0 : vqhip_screen_blocks(N) + VQ_FINISH_BLOCKS;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int W = VQS_F32_WAVES;
+    constexpr int TILE_B = 128 * DT + 1024;
+    constexpr int NCHUNK = TILE_B / 1024;
+    constexpr int NK = DT / 16;
+    constexpr int STEPS = 2 * NK;
+    constexpr int PMAX = (NCHUNK + W - 1) / W;
+    constexpr int NB = 2;
+    constexpr int BS = (PMAX + NB - 1) / NB;
+    constexpr int HALF = STEPS / 2;
+    constexpr int LAG = (HALF > 3) ? HALF - 2 : 1;
+    constexpr int PSTRIDE = W * 1024;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 31;
+    const int half = lane >> 5;
+    const int64_t wrow0 = (int64_t)blockIdx.x * VQ_SCREEN_F32_ROWS + wave * 32;
+
+    const int my_pieces = (NCHUNK - wave + W - 1) / W;
+    const int piece_off = wave * 1024 + lane * 16;
+    for (int k = 0; k < my_pieces; ++k)
+        *(f32x4 *)(smem + piece_off + k * PSTRIDE) = *(const f32x4 *)(a.tiles + piece_off + (size_t)k * PSTRIDE);
+
+    // ---- x rows -> two bf16 B-operand sets; lane (j, half) holds features 16 ks + 8 half + 0..7 ----
+    const int64_t row = wrow0 + j;
+    const bool row_ok = row < a.N;
+    uint4 xh[NK], xm[NK];
+    float eps;
+    {
+        const float *p = (const float *)a.x + (row_ok ? row : (a.N - 1)) * a.ldx + 8 * half;
+        float xs = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < NK; ++ks) {
+            const f32x4 v0 = *(const f32x4 *)(p + ks * 16), v1 = *(const f32x4 *)(p + ks * 16 + 4);
+            split8_bf16(v0, v1, xh[ks], xm[ks]);
+            xs = __builtin_fmaf(v0.x, v0.x, xs); xs = __builtin_fmaf(v0.y, v0.y, xs);
+            xs = __builtin_fmaf(v0.z, v0.z, xs); xs = __builtin_fmaf(v0.w, v0.w, xs);
+            xs = __builtin_fmaf(v1.x, v1.x, xs); xs = __builtin_fmaf(v1.y, v1.y, xs);
+            xs = __builtin_fmaf(v1.z, v1.z, xs); xs = __builtin_fmaf(v1.w, v1.w, xs);
+        }
+        xs += __shfl_xor(xs, 32, 64);
+        xs *= 1.001f;
+        const float y2max = __uint_as_float(a.scalars[0]);
+        const float xy = sqrtf(xs) * 1.0001f * sqrtf(y2max) * 1.0001f;
+        const float u = 5.9604645e-8f;   // 2^-24
+        eps = u * (10.f * (xs + y2max + 2.f * xy) + (2.f * DT + 1600.f) * xy + 24.f * DT * (xy + 0.5f * y2max)) + 4e-8f;
+    }
+
+    float m1 = -__builtin_inff(), m2 = -__builtin_inff();
+    int tix = 0;
+    const int nt = a.n_tiles;
+    for (int ct = 0; ct < nt; ++ct) {
+        const int buf = ct & 1;
+        __syncthreads();
+        const char *tile = smem + buf * TILE_B;
+        const bool more = ct + 1 < nt;
+        const char *gsrc = a.tiles + (size_t)(more ? ct + 1 : ct) * TILE_B + piece_off;
+        char *ldst = smem + (buf ^ 1) * TILE_B + piece_off;
+        const int npieces = more ? my_pieces : 0;
+
+        const float *nh = (const float *)(tile + 128 * DT);
+        f32x16 acc0, acc1;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 v = *(const f32x4 *)(nh + 8 * q + 4 * half);
+            acc0[4 * q + 0] = v.x; acc0[4 * q + 1] = v.y; acc0[4 * q + 2] = v.z; acc0[4 * q + 3] = v.w;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc1[r] = 0.f;
+
+        const uint4 *ap = (const uint4 *)tile + lane;
+        f32x4 stg[BS];
+        uint4 af[VQS_PF];
+#pragma unroll
+        for (int p = 0; p < VQS_PF; ++p) af[p] = ap[p * 64];
+#pragma unroll
+        for (int s = 0; s < STEPS; ++s) {
+            const int ks = s >> 1;
+            const bf16x8 av = __builtin_bit_cast(bf16x8, af[s % VQS_PF]);
+            const bf16x8 bh = __builtin_bit_cast(bf16x8, xh[ks]);
+            // accumulators strictly alternate over the 3 MFMAs of a k-step (k-step parity picks who starts)
+            if ((s & 1) == 0) {        // c_hi: times x_hi and x_mid
+                const bf16x8 bm = __builtin_bit_cast(bf16x8, xm[ks]);
+                if ((ks & 1) == 0) {
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bh, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bm, acc1, 0, 0, 0);
+                } else {
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bh, acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bm, acc0, 0, 0, 0);
+                }
+            } else {                   // c_lo: times x_hi
+                if ((ks & 1) == 0) acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bh, acc0, 0, 0, 0);
+                else               acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bh, acc1, 0, 0, 0);
+            }
+            if (s + VQS_PF < STEPS) af[s % VQS_PF] = ap[(s + VQS_PF) * 64];
+#ifdef VQS_PIN
+            __builtin_amdgcn_sched_barrier(0);
+#endif
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                if (s == b * HALF) {
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int i = 0; i < BS; ++i)
+                        if (b * BS + i < PMAX) stg[i] = *(const f32x4 *)(gsrc + (size_t)(b * BS + i) * PSTRIDE);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (s == b * HALF + LAG) {
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int i = 0; i < BS; ++i)
+                        if (b * BS + i < npieces) *(f32x4 *)(ldst + (b * BS + i) * PSTRIDE) = stg[i];
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc0[r] += acc1[r];
+        top2_tile(acc0, m1, m2, tix, ct);
+    }
+
+    // ---- merge the half-waves, certify, emit ----
+    int code;
+    bool flagged;
+    {
+        const int e = (int)(__float_as_uint(m1) & 15u);
+        const int c_own = tix * 32 + 8 * (e >> 2) + 4 * half + (e & 3);
+        const float o1 = __shfl_xor(m1, 32, 64);
+        const float o2 = __shfl_xor(m2, 32, 64);
+        const int oc = __shfl_xor(c_own, 32, 64);
+        const bool take = o1 > m1;
+        const float b1 = take ? o1 : m1;
+        const float lo1 = take ? m1 : o1;
+        const float b2 = fmaxf(lo1, fmaxf(m2, o2));
+        code = take ? oc : c_own;
+        const float thr = eps + 8e-6f * fabsf(b1);
+        flagged = !((b1 - b2) > thr) || code >= a.C;
+        if (code >= a.C) code = 0;
+        if (row_ok && half == 0) {
+            a.idx_out[row] = (int64_t)code;
+            if (a.dbg) {
+                float *d = a.dbg + row * 4;
+                d[0] = b1; d[1] = b2; d[2] = thr; d[3] = flagged ? 1.f : 0.f;
+            }
+        }
+        const bool f = flagged && row_ok && half == 0;
+        const unsigned long long bal = __ballot(f);
+        if (bal) {
+            int base = 0;
+            if (lane == 0) base = atomicAdd(a.flag_count, (int)__popcll(bal));
+            base = __builtin_amdgcn_readfirstlane(base);
+            if (f) {
+                const int slot = base + (int)__popcll(bal & ((1ull << lane) - 1ull));
+                a.flag_rows[slot] = (int)row;
+                a.flag_keys[slot] = ~0ull;
+            }
+        }
+    }
+
+    // ---- q rows (fp32, from embed) and squared error: whole rows per wave, 8 in flight; x is re-read (coalesced) ----
+    if (a.q_out || a.sqerr_partial) {
+        const int counted = (row_ok && !flagged && (!a.row_mask || a.row_mask[row] != 0)) ? 1 : 0;
+        const bool want_sq = a.sqerr_partial != nullptr;
+        double ds = 0.0;
+#pragma unroll
+        for (int r0 = 0; r0 < 32; r0 += 8) {
+            f32x4 g[8], xv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int c = __builtin_amdgcn_readlane(code, r0 + u);
+                const int64_t rr = wrow0 + r0 + u;
+                if (lane * 4 < DT) {
+                    g[u] = *(const f32x4 *)(a.embed + (size_t)c * DT + lane * 4);
+                    if (want_sq) xv[u] = *(const f32x4 *)((const float *)a.x + (rr < a.N ? rr : a.N - 1) * a.ldx + lane * 4);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int64_t rr = wrow0 + r0 + u;
+                const int cnt = __builtin_amdgcn_readlane(counted, r0 + u);
+                if (lane * 4 < DT) {
+                    if (a.q_out && rr < a.N) *(f32x4 *)((float *)a.q_out + rr * a.ldq + lane * 4) = g[u];
+                    if (want_sq && cnt) {
+                        const float d0 = g[u].x - xv[u].x, d1 = g[u].y - xv[u].y, d2 = g[u].z - xv[u].z, d3 = g[u].w - xv[u].w;
+                        ds += (double)(((d0 * d0 + d1 * d1) + d2 * d2) + d3 * d3);
+                    }
+                }
+            }
+        }
+        if (a.sqerr_partial) {
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) ds += __shfl_xor(ds, o, 64);
+            __syncthreads();
+            double *red = (double *)smem;
+            if (lane == 0) red[wave] = ds;
+            __syncthreads();
+            if (tid == 0) {
+                double t = 0.0;
+#pragma unroll
+                for (int w = 0; w < W; ++w) t += red[w];
+                a.sqerr_partial[blockIdx.x] = t;
+            }
+        }
+    }
+}
+
+static inline int64_t screen_rows_per_block(int x_dtype) { return x_dtype == VQHIP_BF16 ? VQ_SCREEN_ROWS : VQ_SCREEN_F32_ROWS; }
+
+extern "C" int64_t vqhip_screen_blocks(int64_t N, int x_dtype)
+{
+    const int64_t r = screen_rows_per_block(x_dtype);
+    return N <= 0 ? 0 : (N + r - 1) / r;
+}
+
+extern "C" int64_t vqhip_screen_partials(int64_t N, int x_dtype)
+{
+    return N <= 0 ? 0 : vqhip_screen_blocks(N, x_dtype) + VQ_FINISH_BLOCKS;
 }
 
 extern "C" size_t vqhip_screen_workspace_bytes(int64_t N)
@@ -331,34 +598,42 @@ extern "C" int vqhip_screen_supported(int64_t N, int D, int C)
 }
 
 template <int DT>
-static int launch_screen(const ScreenArgs &a, hipStream_t st)
+static int launch_screen(const ScreenArgs &a, int x_dtype, hipStream_t st)
 {
     constexpr int SMEM = 2 * (128 * DT + 1024);
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute((const void *)vq_screen_kernel<DT>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute((const void *)vq_screen_f32_kernel<DT>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
         if (e != hipSuccess) VQ_FAIL((int)e, "hipFuncSetAttribute(screen<%d>): %s", DT, hipGetErrorString(e));
         attr_done = true;
     }
-    hipLaunchKernelGGL((vq_screen_kernel<DT>), dim3((unsigned)vqhip_screen_blocks(a.N)), dim3(VQS_WAVES * 64), SMEM, st, a);
+    const unsigned blocks = (unsigned)vqhip_screen_blocks(a.N, x_dtype);
+    if (x_dtype == VQHIP_BF16)
+        hipLaunchKernelGGL((vq_screen_kernel<DT>), dim3(blocks), dim3(VQS_WAVES * 64), SMEM, st, a);
+    else
+        hipLaunchKernelGGL((vq_screen_f32_kernel<DT>), dim3(blocks), dim3(VQS_F32_WAVES * 64), SMEM, st, a);
     return vq_launch_status("vq_screen_kernel");
 }
 
-extern "C" int vqhip_assign_screened(const void *x, int64_t N, int D, int64_t ldx, const float *packed, const float *embed,
-                                     int C, int64_t *idx_out, void *q_out, int64_t ldq, double *sqerr_partial,
-                                     const uint8_t *row_mask, void *workspace, size_t workspace_bytes, float *debug_out,
-                                     void *stream)
+extern "C" int vqhip_assign_screened(const void *x, int x_dtype, int64_t N, int D, int64_t ldx, const float *packed,
+                                     const float *embed, int C, int64_t *idx_out, void *q_out, int64_t ldq,
+                                     double *sqerr_partial, const uint8_t *row_mask, void *workspace, size_t workspace_bytes,
+                                     float *debug_out, void *stream)
 {
     if (N < 0 || C <= 0) VQ_FAIL(VQHIP_EINVAL, "assign_screened: N < 0 or C <= 0");
     if (N == 0) return 0;
     if (!x || !packed || !embed || !idx_out || !workspace) VQ_FAIL(VQHIP_EINVAL, "assign_screened: null pointer");
+    if (x_dtype != VQHIP_F32 && x_dtype != VQHIP_BF16) VQ_FAIL(VQHIP_EINVAL, "assign_screened: unknown x dtype %d", x_dtype);
     if (!vqhip_screen_supported(N, D, C)) VQ_FAIL(VQHIP_EDIM, "assign_screened: N=%lld D=%d C=%d outside the screened path (D in {64,128,256}, C >= 2)", (long long)N, D, C);
     if (workspace_bytes < vqhip_screen_workspace_bytes(N)) VQ_FAIL(VQHIP_EINVAL, "assign_screened: workspace too small");
     if (ldx < D || (q_out && ldq < D)) VQ_FAIL(VQHIP_EINVAL, "assign_screened: row stride smaller than D");
+    const int es = (x_dtype == VQHIP_BF16) ? 2 : 4;
     if ((((uintptr_t)packed) & 15) || (((uintptr_t)embed) & 15) || (((uintptr_t)workspace) & 7))
         VQ_FAIL(VQHIP_EALIGN, "assign_screened: packed / embed must be 16-byte aligned, workspace 8-byte aligned");
-    if ((((uintptr_t)x) & 15) || ((ldx * 2) & 15)) VQ_FAIL(VQHIP_EALIGN, "assign_screened: x rows must be 16-byte aligned");
-    if (q_out && ((((uintptr_t)q_out) & 7) || ((ldq * 2) & 7))) VQ_FAIL(VQHIP_EALIGN, "assign_screened: q rows must be 8-byte aligned");
+    if ((((uintptr_t)x) & 15) || ((ldx * es) & 15)) VQ_FAIL(VQHIP_EALIGN, "assign_screened: x rows must be 16-byte aligned");
+    if (q_out && ((((uintptr_t)q_out) % (4 * es)) || ((ldq * es) % (4 * es)))) VQ_FAIL(VQHIP_EALIGN, "assign_screened: q rows must be aligned to 4 elements");
 
     hipStream_t st = (hipStream_t)stream;
     int *count = (int *)workspace;
@@ -368,22 +643,26 @@ extern "C" int vqhip_assign_screened(const void *x, int64_t N, int D, int64_t ld
 
     const char *base = (const char *)packed;
     ScreenArgs a;
-    a.x = (const unsigned short *)x; a.N = N; a.ldx = ldx;
+    a.x = x; a.N = N; a.ldx = ldx;
     a.tiles = base + vq_packed_screen_offset(C, D);
     a.embed_bf16 = (const unsigned short *)(base + vq_packed_bf16_offset(C, D));
+    a.embed = embed;
     a.scalars = (const unsigned *)(base + vq_packed_scalars_offset(C, D));
     a.C = C; a.n_tiles = (C + 31) / 32;
-    a.idx_out = idx_out; a.q_out = (unsigned short *)q_out; a.ldq = ldq;
+    a.idx_out = idx_out; a.q_out = q_out; a.ldq = ldq;
     a.sqerr_partial = sqerr_partial; a.row_mask = row_mask;
-    a.flag_count = count; a.flag_rows = rows; a.dbg = debug_out;
+    unsigned long long *keys = (unsigned long long *)((char *)workspace + 16 + (((size_t)N * sizeof(int) + 7) & ~(size_t)7));
+    a.flag_count = count; a.flag_rows = rows; a.flag_keys = keys; a.dbg = debug_out;
+#ifdef VQ_TRACE
+    a.trace = vq_g_trace;
+#endif
     int rc;
     switch (D) {
-        case 64: rc = launch_screen<64>(a, st); break;
-        case 128: rc = launch_screen<128>(a, st); break;
-        default: rc = launch_screen<256>(a, st); break;
+        case 64: rc = launch_screen<64>(a, x_dtype, st); break;
+        case 128: rc = launch_screen<128>(a, x_dtype, st); break;
+        default: rc = launch_screen<256>(a, x_dtype, st); break;
     }
     if (rc) return rc;
-    return vq_assign_listed(x, N, D, ldx, packed, embed, C, idx_out, q_out, ldq,
-                            sqerr_partial ? sqerr_partial + vqhip_screen_blocks(N) : nullptr, row_mask, rows, count,
-                            (unsigned long long *)((char *)workspace + 16 + (((size_t)N * sizeof(int) + 7) & ~(size_t)7)), st);
+    return vq_assign_listed(x, x_dtype, N, D, ldx, packed, embed, C, idx_out, q_out, ldq,
+                            sqerr_partial ? sqerr_partial + vqhip_screen_blocks(N, x_dtype) : nullptr, row_mask, rows, count, keys, st);
 }

@@ -134,9 +134,22 @@ __global__ void __launch_bounds__(256) vq_pack_kernel(const float *__restrict__ 
 {
     __shared__ float y2sh[32];
     const int t = blockIdx.x;
-    for (int p = threadIdx.x; p < 32 * D; p += 256) {   // RNE-rounded bf16 copy of this tile's 32 code rows
-        const size_t o = (size_t)t * 32 * D + p;
-        if (o < (size_t)C * D) ebf[o] = f32_to_bf16_rne(embed[o]);
+    if ((D & 3) == 0) {   // RNE-rounded bf16 copy of this tile's 32 code rows, 4 elements per store
+        for (int p = threadIdx.x; p < 8 * D; p += 256) {
+            const size_t o = (size_t)t * 32 * D + 4 * (size_t)p;
+            if (o < (size_t)C * D) {
+                const f32x4 v = *(const f32x4 *)(embed + o);
+                uint2 w;
+                w.x = (unsigned)f32_to_bf16_rne(v.x) | ((unsigned)f32_to_bf16_rne(v.y) << 16);
+                w.y = (unsigned)f32_to_bf16_rne(v.z) | ((unsigned)f32_to_bf16_rne(v.w) << 16);
+                *(uint2 *)(ebf + o) = w;
+            }
+        }
+    } else {
+        for (int p = threadIdx.x; p < 32 * D; p += 256) {
+            const size_t o = (size_t)t * 32 * D + p;
+            if (o < (size_t)C * D) ebf[o] = f32_to_bf16_rne(embed[o]);
+        }
     }
     const int tile_f = 32 * DT + 256;
     float *out = packed + (size_t)t * tile_f;
@@ -168,17 +181,30 @@ __global__ void __launch_bounds__(256) vq_pack_kernel(const float *__restrict__ 
     //      v_mfma_f32_32x32x16_bf16: 16 bytes per lane and (k-step, part); lane l = code (l & 31), k-slot 8 * (l >> 5) + e.
     //      Then 32 floats -||c||^2 / 2 (the accumulator's initial value; -3e38 for padding codes).
     unsigned short *st = (unsigned short *)(screen + (size_t)t * vq_tile_bytes(DT));
-    for (int p = threadIdx.x; p < 64 * DT; p += 256) {
-        const int e = p & 7;
-        const int l = (p >> 3) & 63;
-        const int part = (p >> 9) & 1;
-        const int ks = p >> 10;
+    for (int p = threadIdx.x; p < 4 * DT; p += 256) {   // one (k-step, lane) per iteration: 8 features -> hi and lo fragment
+        const int l = p & 63;
+        const int ks = p >> 6;
         const int code = t * 32 + (l & 31);
-        const int k = ks * 16 + 8 * (l >> 5) + e;
-        const float v = (code < C && k < D) ? embed[(size_t)code * D + k] : 0.f;
-        const unsigned short h = f32_to_bf16_rne(v);
-        const unsigned short lo = f32_to_bf16_rne(v - bf16_bits_to_f32(h));   // v - h is exact in fp32
-        st[p] = part ? lo : h;
+        const int k0 = ks * 16 + 8 * (l >> 5);
+        float v[8];
+        if (code < C && k0 + 8 <= D && (D & 3) == 0) {
+            const f32x4 a0 = *(const f32x4 *)(embed + (size_t)code * D + k0), a1 = *(const f32x4 *)(embed + (size_t)code * D + k0 + 4);
+            v[0] = a0.x; v[1] = a0.y; v[2] = a0.z; v[3] = a0.w; v[4] = a1.x; v[5] = a1.y; v[6] = a1.z; v[7] = a1.w;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (code < C && k0 + e < D) ? embed[(size_t)code * D + k0 + e] : 0.f;
+        }
+        unsigned hw[4], lw[4];
+#pragma unroll
+        for (int e = 0; e < 8; e += 2) {
+            const unsigned short h0 = f32_to_bf16_rne(v[e]), h1 = f32_to_bf16_rne(v[e + 1]);
+            const unsigned short l0 = f32_to_bf16_rne(v[e] - bf16_bits_to_f32(h0));       // v - h is exact in fp32
+            const unsigned short l1 = f32_to_bf16_rne(v[e + 1] - bf16_bits_to_f32(h1));
+            hw[e >> 1] = (unsigned)h0 | ((unsigned)h1 << 16);
+            lw[e >> 1] = (unsigned)l0 | ((unsigned)l1 << 16);
+        }
+        *(uint4 *)(st + ((size_t)(ks * 2 + 0) * 64 + l) * 8) = make_uint4(hw[0], hw[1], hw[2], hw[3]);
+        *(uint4 *)(st + ((size_t)(ks * 2 + 1) * 64 + l) * 8) = make_uint4(lw[0], lw[1], lw[2], lw[3]);
     }
     __syncthreads();
     {
@@ -351,7 +377,8 @@ __device__ __forceinline__ float x2_aten_order(const float (&xr)[DT / 2], int j)
 }
 
 #ifdef VQ_TRACE
-static long long *g_trace = nullptr;
+long long *vq_g_trace = nullptr;
+#define g_trace vq_g_trace
 extern "C" void vqhip_set_trace(long long *p) { g_trace = p; }
 #define VQ_STAMP(slot) do { if (a.trace && blockIdx.x < 16 && lane == 0 && ct < 64) a.trace[(((size_t)blockIdx.x * 4 + wave) * 64 + ct) * 4 + (slot)] = __builtin_readcyclecounter(); } while (0)
 #else
@@ -807,7 +834,7 @@ static int assign_impl(const void *x, int x_dtype, int64_t N, int D, int64_t ldx
 // squared error.  The list length is only known on the device: fixed grids, chunk loops.
 // ------------------------------------------------------------------------------------------------
 struct RefineArgs {
-    const unsigned short *x;
+    const void *x;
     int64_t ldx;
     const float *packed;
     int C;
@@ -817,7 +844,7 @@ struct RefineArgs {
     unsigned long long *keys;   // [list capacity], preset to ~0
 };
 
-template <int DT>
+template <int DT, bool XBF16>
 __global__ void __launch_bounds__(256, 2) vq_refine_kernel(const RefineArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -849,8 +876,8 @@ __global__ void __launch_bounds__(256, 2) vq_refine_kernel(const RefineArgs a)
         const bool row_ok = pos < list_n;
         const int64_t row = a.row_list[row_ok ? pos : (int64_t)(list_n - 1)];
         float xr[DT / 2];   // load layout, as in vq_assign_kernel
-        {
-            const uint2 *p = (const uint2 *)(a.x + row * a.ldx + 4 * hi);
+        if (XBF16) {
+            const uint2 *p = (const uint2 *)((const unsigned short *)a.x + row * a.ldx + 4 * hi);
 #pragma unroll
             for (int m = 0; m < NG; ++m) {
                 const uint2 w = p[m * 2];
@@ -858,6 +885,16 @@ __global__ void __launch_bounds__(256, 2) vq_refine_kernel(const RefineArgs a)
                 xr[4 * m + 1] = __uint_as_float(w.x & 0xffff0000u);
                 xr[4 * m + 2] = __uint_as_float(w.y << 16);
                 xr[4 * m + 3] = __uint_as_float(w.y & 0xffff0000u);
+            }
+        } else {
+            const f32x4 *p = (const f32x4 *)((const float *)a.x + row * a.ldx + 4 * hi);
+#pragma unroll
+            for (int m = 0; m < NG; ++m) {
+                const f32x4 w = p[m * 2];
+                xr[4 * m + 0] = w.x;
+                xr[4 * m + 1] = w.y;
+                xr[4 * m + 2] = w.z;
+                xr[4 * m + 3] = w.w;
             }
         }
         const float x2 = x2_aten_order<DT>(xr, j);
@@ -895,21 +932,22 @@ __global__ void __launch_bounds__(256, 2) vq_refine_kernel(const RefineArgs a)
 }
 
 struct FinishArgs {
-    const unsigned short *x;
+    const void *x;
     int64_t ldx;
-    const unsigned short *embed_bf16;
+    const void *codes;       // bf16 rows: the bf16 codebook copy; fp32 rows: embed
     int D;
     const int *row_list;
     const int *row_count;
     const unsigned long long *keys;
     int64_t *idx_out;
-    unsigned short *q_out;   // nullable
+    void *q_out;             // nullable, x's dtype
     int64_t ldq;
     double *sqerr_partial;   // nullable, one entry per workgroup
     const uint8_t *row_mask;
 };
 
 // one wave per listed row: idx, q row, sum (q - x)^2
+template <bool XBF16>
 __global__ void __launch_bounds__(256) vq_finish_listed_kernel(const FinishArgs a)
 {
     __shared__ double red[4];
@@ -923,13 +961,21 @@ __global__ void __launch_bounds__(256) vq_finish_listed_kernel(const FinishArgs 
         if (lane == 0) a.idx_out[row] = (int64_t)idx;
         float ls = 0.f;
         if (lane * 4 < a.D) {
-            const uint2 g = *(const uint2 *)(a.embed_bf16 + (size_t)idx * a.D + lane * 4);
-            const uint2 xv = *(const uint2 *)(a.x + row * a.ldx + lane * 4);
-            if (a.q_out) *(uint2 *)(a.q_out + row * a.ldq + lane * 4) = g;
-            const float d0 = __uint_as_float(g.x << 16) - __uint_as_float(xv.x << 16);
-            const float d1 = __uint_as_float(g.x & 0xffff0000u) - __uint_as_float(xv.x & 0xffff0000u);
-            const float d2 = __uint_as_float(g.y << 16) - __uint_as_float(xv.y << 16);
-            const float d3 = __uint_as_float(g.y & 0xffff0000u) - __uint_as_float(xv.y & 0xffff0000u);
+            float d0, d1, d2, d3;
+            if (XBF16) {
+                const uint2 g = *(const uint2 *)((const unsigned short *)a.codes + (size_t)idx * a.D + lane * 4);
+                const uint2 xv = *(const uint2 *)((const unsigned short *)a.x + row * a.ldx + lane * 4);
+                if (a.q_out) *(uint2 *)((unsigned short *)a.q_out + row * a.ldq + lane * 4) = g;
+                d0 = __uint_as_float(g.x << 16) - __uint_as_float(xv.x << 16);
+                d1 = __uint_as_float(g.x & 0xffff0000u) - __uint_as_float(xv.x & 0xffff0000u);
+                d2 = __uint_as_float(g.y << 16) - __uint_as_float(xv.y << 16);
+                d3 = __uint_as_float(g.y & 0xffff0000u) - __uint_as_float(xv.y & 0xffff0000u);
+            } else {
+                const f32x4 g = *(const f32x4 *)((const float *)a.codes + (size_t)idx * a.D + lane * 4);
+                const f32x4 xv = *(const f32x4 *)((const float *)a.x + row * a.ldx + lane * 4);
+                if (a.q_out) *(f32x4 *)((float *)a.q_out + row * a.ldq + lane * 4) = g;
+                d0 = g.x - xv.x; d1 = g.y - xv.y; d2 = g.z - xv.z; d3 = g.w - xv.w;
+            }
             ls = ((d0 * d0 + d1 * d1) + d2 * d2) + d3 * d3;
         }
         double ds = (double)ls;
@@ -944,29 +990,33 @@ __global__ void __launch_bounds__(256) vq_finish_listed_kernel(const FinishArgs 
     }
 }
 
-template <int DT>
+template <int DT, bool XBF16>
 static int launch_refine(const RefineArgs &a, unsigned gx, unsigned gy, hipStream_t st)
 {
     constexpr int SMEM = 2 * (32 * DT + 256) * 4;
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void *)vq_refine_kernel<DT>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+        hipError_t e = hipFuncSetAttribute((const void *)vq_refine_kernel<DT, XBF16>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
         if (e != hipSuccess) VQ_FAIL((int)e, "hipFuncSetAttribute(refine<%d>): %s", DT, hipGetErrorString(e));
         attr_done = true;
     }
-    hipLaunchKernelGGL((vq_refine_kernel<DT>), dim3(gx, gy), dim3(256), SMEM, st, a);
+    hipLaunchKernelGGL((vq_refine_kernel<DT, XBF16>), dim3(gx, gy), dim3(256), SMEM, st, a);
     return launch_status("vq_refine_kernel");
 }
 
-int vq_assign_listed(const void *x, int64_t N, int D, int64_t ldx, const float *packed, const float *embed, int C,
+template <int DT>
+static int dispatch_refine(const RefineArgs &a, int x_dtype, unsigned gx, unsigned gy, hipStream_t st)
+{
+    return x_dtype == VQHIP_BF16 ? launch_refine<DT, true>(a, gx, gy, st) : launch_refine<DT, false>(a, gx, gy, st);
+}
+
+int vq_assign_listed(const void *x, int x_dtype, int64_t N, int D, int64_t ldx, const float *packed, const float *embed, int C,
                      int64_t *idx_out, void *q_out, int64_t ldq, double *sqerr_partial, const uint8_t *row_mask,
                      const int *row_list, const int *row_count, unsigned long long *keys, hipStream_t st)
 {
-    (void)embed;
-    hipError_t e = hipMemsetAsync(keys, 0xff, (size_t)N * sizeof(unsigned long long), st);
-    if (e != hipSuccess) VQ_FAIL((int)e, "assign_listed: hipMemsetAsync: %s", hipGetErrorString(e));
+    // keys[0 .. *row_count) were preset to ~0 by whoever built the list (vq_screen_kernel)
     RefineArgs r;
-    r.x = (const unsigned short *)x; r.ldx = ldx; r.packed = packed; r.C = C; r.n_tiles = (C + 31) / 32;
+    r.x = x; r.ldx = ldx; r.packed = packed; r.C = C; r.n_tiles = (C + 31) / 32;
     r.row_list = row_list; r.row_count = row_count; r.keys = keys;
     const int64_t chunks = vqhip_assign_blocks(N);
     const unsigned gx = (unsigned)(chunks < 1024 ? chunks : 1024);
@@ -974,18 +1024,21 @@ int vq_assign_listed(const void *x, int64_t N, int D, int64_t ldx, const float *
     splits = splits < 1 ? 1 : (splits > 8 ? 8 : splits);
     int rc;
     switch (pick_dt(D)) {
-        case 64: rc = launch_refine<64>(r, gx, (unsigned)splits, st); break;
-        case 128: rc = launch_refine<128>(r, gx, (unsigned)splits, st); break;
-        case 256: rc = launch_refine<256>(r, gx, (unsigned)splits, st); break;
+        case 64: rc = dispatch_refine<64>(r, x_dtype, gx, (unsigned)splits, st); break;
+        case 128: rc = dispatch_refine<128>(r, x_dtype, gx, (unsigned)splits, st); break;
+        case 256: rc = dispatch_refine<256>(r, x_dtype, gx, (unsigned)splits, st); break;
         default: VQ_FAIL(VQHIP_EDIM, "assign_listed: D=%d unsupported", D);
     }
     if (rc) return rc;
     FinishArgs f;
-    f.x = (const unsigned short *)x; f.ldx = ldx;
-    f.embed_bf16 = (const unsigned short *)((const char *)packed + packed_bf16_offset(C, D));
+    f.x = x; f.ldx = ldx;
+    f.codes = (x_dtype == VQHIP_BF16) ? (const void *)((const char *)packed + packed_bf16_offset(C, D)) : (const void *)embed;
     f.D = D; f.row_list = row_list; f.row_count = row_count; f.keys = keys;
-    f.idx_out = idx_out; f.q_out = (unsigned short *)q_out; f.ldq = ldq; f.sqerr_partial = sqerr_partial; f.row_mask = row_mask;
-    hipLaunchKernelGGL(vq_finish_listed_kernel, dim3(VQ_FINISH_BLOCKS), dim3(256), 0, st, f);
+    f.idx_out = idx_out; f.q_out = q_out; f.ldq = ldq; f.sqerr_partial = sqerr_partial; f.row_mask = row_mask;
+    if (x_dtype == VQHIP_BF16)
+        hipLaunchKernelGGL(vq_finish_listed_kernel<true>, dim3(VQ_FINISH_BLOCKS), dim3(256), 0, st, f);
+    else
+        hipLaunchKernelGGL(vq_finish_listed_kernel<false>, dim3(VQ_FINISH_BLOCKS), dim3(256), 0, st, f);
     return launch_status("vq_finish_listed_kernel");
 }
 
@@ -1427,7 +1480,9 @@ extern "C" int vqhip_reduce_partials(const double *partials, int64_t n, double s
 // 3 clocks on gfx950 -- measured 1.36 ms vs 0.36 ms for the same kernel with plain racy adds at
 // N = 2^20, C = 1024, D = 256 (profiles/README.md).  Integer LDS atomics are only used for counting.
 // ------------------------------------------------------------------------------------------------
+#ifndef VQ_SEG_CH
 #define VQ_SEG_CH 256          // rows per segmented-sum work item
+#endif
 #define VQ_HIST_LDS_MAX 16384  // codes whose histogram fits the LDS path (64 KiB)
 #define VQ_SORT_ROWS_PER_BLOCK 4096
 

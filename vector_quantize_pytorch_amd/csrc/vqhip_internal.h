@@ -16,6 +16,14 @@ extern thread_local char vq_g_err[256];
 
 int vq_launch_status(const char *what);
 
+__device__ __forceinline__ float vq_bf16_bits_to_f32(unsigned short b) { return __uint_as_float(((unsigned)b) << 16); }
+__device__ __forceinline__ unsigned short vq_f32_to_bf16_rne(float f)
+{
+    unsigned u = __float_as_uint(f);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+
 // feature-tile width: D is padded to DT in the packed codebook
 static inline int vq_pick_dt(int D)
 {
@@ -51,9 +59,10 @@ static inline size_t vq_packed_scalars_offset(int C, int D)
 }
 
 // exact fp32-MFMA assignment (vqhip.hip) restricted to the rows listed in row_list[0 .. *row_count), both on the
-// device; x and q are bf16 with D == DT and vector-aligned rows, Euclidean metric.  keys: scratch, N u64.
+// device; x and q share a dtype (fp32 / bf16) with D == DT and vector-aligned rows, Euclidean metric.  keys: N u64, entries
+// [0 .. *row_count) preset to ~0 by the list builder.
 // sqerr_partial (nullable) receives VQ_FINISH_BLOCKS entries.
 #define VQ_FINISH_BLOCKS 128
-int vq_assign_listed(const void *x, int64_t N, int D, int64_t ldx, const float *packed, const float *embed, int C,
+int vq_assign_listed(const void *x, int x_dtype, int64_t N, int D, int64_t ldx, const float *packed, const float *embed, int C,
                      int64_t *idx_out, void *q_out, int64_t ldq, double *sqerr_partial, const uint8_t *row_mask,
                      const int *row_list, const int *row_count, unsigned long long *keys, hipStream_t st);

@@ -201,9 +201,10 @@ class ResidualVQ(nn.Module):
             return False            # gradients to the input take the per-stage autograd path
         if self.quant_grad_frac > 0:
             return False
-        if x.dtype == torch.bfloat16 and L.screening_enabled() and self.codebook_dim in (64, 128, 256):
-            # bf16 rows: the per-stage path runs every stage's search as a screened assignment on the bf16 MFMA pipe
-            # (csrc/vq_screen.hip), which beats the fused exact-fp32 residual kernel (cfg 3 in bf16: 5.9 vs 11.4 ms)
+        if L.screening_enabled() and self.codebook_dim in (64, 128, 256):
+            # the per-stage path runs every stage's search as a screened assignment on the bf16 MFMA pipe
+            # (csrc/vq_screen.hip), which beats the fused exact-fp32 residual kernel (cfg 3: 5.6 vs 11.4 ms in bf16,
+            # 8.3 vs 11.4 ms in fp32); the fused kernel keeps the dims the screen does not cover (32, 96, ..., 512)
             return False
         return all(layer._codebook._is_initted() for layer in self.layers)     # k-means runs in the staged path
 
