@@ -85,6 +85,8 @@ int vqhip_assign(const void *x, int x_dtype, int64_t N, int D, int64_t ldx,
  *   workspace:      vqhip_screen_workspace_bytes(N) bytes, 8-byte aligned; on completion ((int *)workspace)[0] is the
  *                   number of rows that took the exact pass (diagnostic)
  *   sqerr_partial:  nullable, vqhip_screen_partials(N, x_dtype) doubles, all written; feed them to vqhip_reduce_partials
+ *   resid_out:      nullable [N, ldr] in x's dtype: x - q in the reference's tensor arithmetic (bf16 tensors subtract in
+ *                   fp32 and round to bf16), i.e. the input of the next ResidualVQ stage (rvq.py:524); q_out may be null
  *   debug_out:      nullable [N, 4] floats: best score, runner-up, certification threshold, 1.0 if re-evaluated */
 int vqhip_screen_supported(int64_t N, int D, int C);
 size_t vqhip_screen_workspace_bytes(int64_t N);
@@ -92,8 +94,8 @@ int64_t vqhip_screen_blocks(int64_t N, int x_dtype);
 int64_t vqhip_screen_partials(int64_t N, int x_dtype);
 int vqhip_assign_screened(const void *x, int x_dtype, int64_t N, int D, int64_t ldx, const float *packed,
                           const float *embed, int C, int64_t *idx_out, void *q_out, int64_t ldq,
-                          double *sqerr_partial, const uint8_t *row_mask, void *workspace, size_t workspace_bytes,
-                          float *debug_out, void *stream);
+                          void *resid_out, int64_t ldr, double *sqerr_partial, const uint8_t *row_mask,
+                          void *workspace, size_t workspace_bytes, float *debug_out, void *stream);
 
 /* ---- dense scores (rare options only) ------------------------------------------------------------
  * Materialises the tensor the reference calls `dist` (vqp.py:741-743): scores_out[n, c] = -cdist(x_n, c) for the

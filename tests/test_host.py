@@ -36,8 +36,8 @@ def test_host_only_entry_points():
     tile = 128 * 256 + 1024   # fp32 A-operand tile == bf16 hi/lo screening tile, bytes (csrc/vqhip_internal.h)
     assert L.vqhip_packed_bytes(1024, 256) == (32 * tile + 4096) + 1024 * 256 * 2 + (32 * tile + 8192) + 16
     assert L.vqhip_screen_supported(1 << 20, 256, 1024) == 1 and L.vqhip_screen_supported(1 << 20, 512, 1024) == 0
-    assert L.vqhip_screen_partials(1 << 20, 1) == (1 << 20) // 256 + 128   # bf16: screen workgroups + finish workgroups of the exact pass
-    assert L.vqhip_screen_partials(1 << 20, 0) == (1 << 20) // 256 + 128   # fp32: 8 waves x 32 rows per workgroup
+    assert L.vqhip_screen_partials(1 << 20, 1) == (1 << 20) // 256 + 512   # bf16: screen workgroups + finish workgroups of the exact pass
+    assert L.vqhip_screen_partials(1 << 20, 0) == (1 << 20) // 256 + 512   # fp32: 8 waves x 32 rows per workgroup
     assert L.vqhip_screen_workspace_bytes(1000) >= 16 + 4 * 1000 + 8 * 1000
     assert L.vqhip_packed_bytes(33, 100) == 2 * 2 * (128 * 128 + 1024) + 4096 + 8192 + 33 * 100 * 2 + 8 + 16   # D padded to 128, C to 64; bf16 copy 16-byte rounded
     assert L.vqhip_packed_bytes(16, 513) == 0                              # unsupported D

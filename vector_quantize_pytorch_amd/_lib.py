@@ -57,7 +57,7 @@ def lib():
     L.vqhip_screen_blocks.restype = i64
     L.vqhip_screen_partials.argtypes = [i64, i32]
     L.vqhip_screen_partials.restype = i64
-    L.vqhip_assign_screened.argtypes = [vp, i32, i64, i32, i64, vp, vp, i32, vp, vp, i64, vp, vp, vp, ctypes.c_size_t, vp, vp]
+    L.vqhip_assign_screened.argtypes = [vp, i32, i64, i32, i64, vp, vp, i32, vp, vp, i64, vp, i64, vp, vp, vp, ctypes.c_size_t, vp, vp]
     L.vqhip_assign_screened.restype = i32
     L.vqhip_route_fwd.argtypes = [vp, vp, i32, i64, i32, i64, i64, vp, i64, i32, vp]
     L.vqhip_route_bwd.argtypes = [vp, vp, vp, i32, i64, i32, i64, i64, i64, vp, vp, i32, vp, i64, vp]
@@ -158,8 +158,9 @@ def screening_enabled() -> bool:
 
 def assign(x: torch.Tensor, packed: torch.Tensor, embed2d: torch.Tensor, *, cosine=False,
            want_q=True, want_sqerr=False, want_best=False, want_rnorm=False, row_mask=None, q_out=None,
-           skip_l2norm=False):
-    """x [..., D] -> dict(idx [...], q [..., D] | None, sqerr_partials | None, best, rnorm)."""
+           skip_l2norm=False, resid_out=None):
+    """x [..., D] -> dict(idx [...], q [..., D] | None, sqerr_partials | None, best, rnorm).
+    resid_out (optional, x's shape and dtype, rows may be strided) receives x - q, the next residual-VQ stage's input."""
     _need_gpu(x, packed, embed2d, row_mask)
     xk, N, D, ldx = as_rows(x)
     C = embed2d.shape[0]
@@ -175,6 +176,9 @@ def assign(x: torch.Tensor, packed: torch.Tensor, embed2d: torch.Tensor, *, cosi
     if row_mask is not None:
         row_mask = row_mask.reshape(-1).to(torch.uint8).contiguous()
         assert row_mask.numel() == N
+    if resid_out is not None and not want_q:
+        want_q = True          # the exact kernel has no residual output: x - q below (only reached off the screened path)
+        q = torch.empty(*lead, D, dtype=x.dtype, device=dev)
     if (not cosine and not want_best and not want_rnorm and N > 0 and screening_enabled()
             and xk.dtype in (torch.bfloat16, torch.float32) and xk.data_ptr() % 16 == 0
             and (ldx * xk.element_size()) % 16 == 0 and embed2d.data_ptr() % 16 == 0
@@ -185,8 +189,12 @@ def assign(x: torch.Tensor, packed: torch.Tensor, embed2d: torch.Tensor, *, cosi
         nws = lib().vqhip_screen_workspace_bytes(N)
         ws = torch.empty((nws + 3) // 4, dtype=torch.int32, device=dev)
         dbg = torch.empty(N, 4, dtype=torch.float32, device=dev) if screen_debug else None
+        rk, ldr = None, 0
+        if resid_out is not None:
+            rk, rN, rD, ldr = as_rows(resid_out)
+            assert rN == N and rD == D and rk.dtype == xk.dtype
         _check(lib().vqhip_assign_screened(_ptr(xk), _dtype_code(xk), N, D, ldx, _ptr(packed), _ptr(embed2d), C, _ptr(idx), _ptr(q), ldq,
-                                           _ptr(partials), _ptr(row_mask), _ptr(ws), nws, _ptr(dbg), _stream()),
+                                           _ptr(rk), ldr, _ptr(partials), _ptr(row_mask), _ptr(ws), nws, _ptr(dbg), _stream()),
                "vqhip_assign_screened")
         return dict(idx=idx, q=q, sqerr_partials=partials, best=None, rnorm=None, nblk=nblk, n_exact=ws[:1], screen_debug=dbg)
     need_rn = want_rnorm or cosine or (D % 32 != 0)
@@ -202,6 +210,8 @@ def assign(x: torch.Tensor, packed: torch.Tensor, embed2d: torch.Tensor, *, cosi
                "vqhip_assign")
     elif partials is not None:
         partials.zero_()
+    if resid_out is not None:
+        torch.sub(x, q, out=resid_out)
     return dict(idx=idx, q=q, sqerr_partials=partials, best=best, rnorm=rnorm, nblk=nblk)
 
 
@@ -218,6 +228,34 @@ def scores(x: torch.Tensor, packed: torch.Tensor, embed2d: torch.Tensor, *, cosi
         _check(lib().vqhip_scores(_ptr(xk), _dtype_code(xk), N, D, ldx, _ptr(packed), _ptr(embed2d), C, metric,
                                   _ptr(out), C, _ptr(idx), _ptr(rnorm), _stream()), "vqhip_scores")
     return out, idx, rnorm
+
+
+def rvq_forward_screened(x: torch.Tensor, packed: torch.Tensor, embed: torch.Tensor, Q: int, *, want_resid=False,
+                         want_sqerr=False, row_mask=None):
+    """The residual loop (rvq.py:469-568) as Q screened assignments: each stage's search runs on the bf16 MFMA pipe
+    (csrc/vq_screen.hip) and writes the next stage's input x - q itself, so no N x D tensor op runs between stages.
+    Same arguments as rvq_forward; -> dict(idx [..., Q], inputs = the Q stage inputs (inputs[0] is x) | None,
+    sqerr_partials [Q, P] | None)."""
+    _need_gpu(x, packed, embed, row_mask)
+    shared = embed.ndim == 2
+    lead, D, dev = x.shape[:-1], x.shape[-1], x.device
+    idx = torch.empty(*lead, Q, dtype=torch.int64, device=dev)
+    nbuf = (Q - 1) if want_resid else min(Q - 1, 2)
+    bufs = torch.empty(max(nbuf, 1), *lead, D, dtype=x.dtype, device=dev)
+    inputs, parts, cur = [], [], x
+    for q in range(Q):
+        nxt = None if q + 1 == Q else bufs[q if want_resid else q % 2]
+        r = assign(cur, packed if shared else packed[q], embed if shared else embed[q], want_q=False, want_sqerr=want_sqerr,
+                   row_mask=row_mask, resid_out=nxt)
+        idx[..., q] = r["idx"]
+        if want_sqerr:
+            parts.append(r["sqerr_partials"][: r["nblk"]])
+        inputs.append(cur)
+        cur = nxt
+    if row_mask is not None:      # as the fused kernel: masked rows carry index -1 (decode contributes nothing)
+        idx.masked_fill_(~row_mask.reshape(*lead, 1).bool(), -1)
+    return dict(idx=idx, resid=None, inputs=inputs if want_resid else None,
+                sqerr_partials=torch.stack(parts) if want_sqerr else None)
 
 
 def rvq_forward(x: torch.Tensor, packed: torch.Tensor, embed: torch.Tensor, Q: int, *, want_resid=False,

@@ -58,6 +58,8 @@ struct ScreenArgs {
     int64_t *idx_out;
     void *q_out;                       // nullable, x's dtype
     int64_t ldq;
+    void *resid_out;                   // nullable, x's dtype: x - q (the next residual-VQ stage's input, rvq.py:524)
+    int64_t ldr;
     double *sqerr_partial;             // nullable, one entry per workgroup
     const uint8_t *row_mask;
     int *flag_count;
@@ -282,19 +284,27 @@ __global__ void __launch_bounds__(VQS_WAVES * 64, 8 / VQS_WAVES) vq_screen_kerne
 #pragma unroll
             for (int ks = 0; ks < NK; ++ks) gq[ks] = *(const uint4 *)(er + ks * 16);
         }
-        if (a.q_out) {
+        if (a.q_out || a.resid_out) {
+            const bool want_r = a.resid_out != nullptr;
 #pragma unroll
             for (int r0 = 0; r0 < 32; r0 += 16) {
-                uint2 g[16];
+                uint2 g[16], xv[16];
 #pragma unroll
                 for (int u = 0; u < 16; ++u) {
                     const int c = __builtin_amdgcn_readlane(code[rb], r0 + u);
-                    if (lane * 4 < DT) g[u] = *(const uint2 *)(a.embed_bf16 + (size_t)c * DT + lane * 4);
+                    const int64_t rr = wrow0 + rb * 32 + r0 + u;
+                    if (lane * 4 < DT) {
+                        g[u] = *(const uint2 *)(a.embed_bf16 + (size_t)c * DT + lane * 4);
+                        if (want_r) xv[u] = *(const uint2 *)((const unsigned short *)a.x + (rr < a.N ? rr : a.N - 1) * a.ldx + lane * 4);
+                    }
                 }
 #pragma unroll
                 for (int u = 0; u < 16; ++u) {
                     const int64_t rr = wrow0 + rb * 32 + r0 + u;
-                    if (rr < a.N && lane * 4 < DT) *(uint2 *)((unsigned short *)a.q_out + rr * a.ldq + lane * 4) = g[u];
+                    if (rr < a.N && lane * 4 < DT) {
+                        if (a.q_out) *(uint2 *)((unsigned short *)a.q_out + rr * a.ldq + lane * 4) = g[u];
+                        if (want_r) *(uint2 *)((unsigned short *)a.resid_out + rr * a.ldr + lane * 4) = vq_bf16x4_sub(xv[u], g[u]);
+                    }
                 }
             }
         }
@@ -527,9 +537,10 @@ __global__ void __launch_bounds__(VQS_F32_WAVES * 64, 8 / VQS_F32_WAVES) vq_scre
     }
 
     // ---- q rows (fp32, from embed) and squared error: whole rows per wave, 8 in flight; x is re-read (coalesced) ----
-    if (a.q_out || a.sqerr_partial) {
+    if (a.q_out || a.sqerr_partial || a.resid_out) {
         const int counted = (row_ok && !flagged && (!a.row_mask || a.row_mask[row] != 0)) ? 1 : 0;
         const bool want_sq = a.sqerr_partial != nullptr;
+        const bool want_x = want_sq || a.resid_out != nullptr;
         double ds = 0.0;
 #pragma unroll
         for (int r0 = 0; r0 < 32; r0 += 8) {
@@ -540,7 +551,7 @@ __global__ void __launch_bounds__(VQS_F32_WAVES * 64, 8 / VQS_F32_WAVES) vq_scre
                 const int64_t rr = wrow0 + r0 + u;
                 if (lane * 4 < DT) {
                     g[u] = *(const f32x4 *)(a.embed + (size_t)c * DT + lane * 4);
-                    if (want_sq) xv[u] = *(const f32x4 *)((const float *)a.x + (rr < a.N ? rr : a.N - 1) * a.ldx + lane * 4);
+                    if (want_x) xv[u] = *(const f32x4 *)((const float *)a.x + (rr < a.N ? rr : a.N - 1) * a.ldx + lane * 4);
                 }
             }
 #pragma unroll
@@ -549,6 +560,7 @@ __global__ void __launch_bounds__(VQS_F32_WAVES * 64, 8 / VQS_F32_WAVES) vq_scre
                 const int cnt = __builtin_amdgcn_readlane(counted, r0 + u);
                 if (lane * 4 < DT) {
                     if (a.q_out && rr < a.N) *(f32x4 *)((float *)a.q_out + rr * a.ldq + lane * 4) = g[u];
+                    if (a.resid_out && rr < a.N) *(f32x4 *)((float *)a.resid_out + rr * a.ldr + lane * 4) = xv[u] - g[u];
                     if (want_sq && cnt) {
                         const float d0 = g[u].x - xv[u].x, d1 = g[u].y - xv[u].y, d2 = g[u].z - xv[u].z, d3 = g[u].w - xv[u].w;
                         ds += (double)(((d0 * d0 + d1 * d1) + d2 * d2) + d3 * d3);
@@ -619,8 +631,8 @@ static int launch_screen(const ScreenArgs &a, int x_dtype, hipStream_t st)
 
 extern "C" int vqhip_assign_screened(const void *x, int x_dtype, int64_t N, int D, int64_t ldx, const float *packed,
                                      const float *embed, int C, int64_t *idx_out, void *q_out, int64_t ldq,
-                                     double *sqerr_partial, const uint8_t *row_mask, void *workspace, size_t workspace_bytes,
-                                     float *debug_out, void *stream)
+                                     void *resid_out, int64_t ldr, double *sqerr_partial, const uint8_t *row_mask,
+                                     void *workspace, size_t workspace_bytes, float *debug_out, void *stream)
 {
     if (N < 0 || C <= 0) VQ_FAIL(VQHIP_EINVAL, "assign_screened: N < 0 or C <= 0");
     if (N == 0) return 0;
@@ -628,12 +640,13 @@ extern "C" int vqhip_assign_screened(const void *x, int x_dtype, int64_t N, int 
     if (x_dtype != VQHIP_F32 && x_dtype != VQHIP_BF16) VQ_FAIL(VQHIP_EINVAL, "assign_screened: unknown x dtype %d", x_dtype);
     if (!vqhip_screen_supported(N, D, C)) VQ_FAIL(VQHIP_EDIM, "assign_screened: N=%lld D=%d C=%d outside the screened path (D in {64,128,256}, C >= 2)", (long long)N, D, C);
     if (workspace_bytes < vqhip_screen_workspace_bytes(N)) VQ_FAIL(VQHIP_EINVAL, "assign_screened: workspace too small");
-    if (ldx < D || (q_out && ldq < D)) VQ_FAIL(VQHIP_EINVAL, "assign_screened: row stride smaller than D");
+    if (ldx < D || (q_out && ldq < D) || (resid_out && ldr < D)) VQ_FAIL(VQHIP_EINVAL, "assign_screened: row stride smaller than D");
     const int es = (x_dtype == VQHIP_BF16) ? 2 : 4;
     if ((((uintptr_t)packed) & 15) || (((uintptr_t)embed) & 15) || (((uintptr_t)workspace) & 7))
         VQ_FAIL(VQHIP_EALIGN, "assign_screened: packed / embed must be 16-byte aligned, workspace 8-byte aligned");
     if ((((uintptr_t)x) & 15) || ((ldx * es) & 15)) VQ_FAIL(VQHIP_EALIGN, "assign_screened: x rows must be 16-byte aligned");
     if (q_out && ((((uintptr_t)q_out) % (4 * es)) || ((ldq * es) % (4 * es)))) VQ_FAIL(VQHIP_EALIGN, "assign_screened: q rows must be aligned to 4 elements");
+    if (resid_out && ((((uintptr_t)resid_out) % (4 * es)) || ((ldr * es) % (4 * es)))) VQ_FAIL(VQHIP_EALIGN, "assign_screened: residual rows must be aligned to 4 elements");
 
     hipStream_t st = (hipStream_t)stream;
     int *count = (int *)workspace;
@@ -649,7 +662,7 @@ extern "C" int vqhip_assign_screened(const void *x, int x_dtype, int64_t N, int 
     a.embed = embed;
     a.scalars = (const unsigned *)(base + vq_packed_scalars_offset(C, D));
     a.C = C; a.n_tiles = (C + 31) / 32;
-    a.idx_out = idx_out; a.q_out = q_out; a.ldq = ldq;
+    a.idx_out = idx_out; a.q_out = q_out; a.ldq = ldq; a.resid_out = resid_out; a.ldr = ldr;
     a.sqerr_partial = sqerr_partial; a.row_mask = row_mask;
     unsigned long long *keys = (unsigned long long *)((char *)workspace + 16 + (((size_t)N * sizeof(int) + 7) & ~(size_t)7));
     a.flag_count = count; a.flag_rows = rows; a.flag_keys = keys; a.dbg = debug_out;
@@ -663,6 +676,6 @@ extern "C" int vqhip_assign_screened(const void *x, int x_dtype, int64_t N, int 
         default: rc = launch_screen<256>(a, x_dtype, st); break;
     }
     if (rc) return rc;
-    return vq_assign_listed(x, x_dtype, N, D, ldx, packed, embed, C, idx_out, q_out, ldq,
+    return vq_assign_listed(x, x_dtype, N, D, ldx, packed, embed, C, idx_out, q_out, ldq, resid_out, ldr,
                             sqerr_partial ? sqerr_partial + vqhip_screen_blocks(N, x_dtype) : nullptr, row_mask, rows, count, keys, st);
 }

@@ -942,6 +942,8 @@ struct FinishArgs {
     int64_t *idx_out;
     void *q_out;             // nullable, x's dtype
     int64_t ldq;
+    void *resid_out;         // nullable, x's dtype: x - q
+    int64_t ldr;
     double *sqerr_partial;   // nullable, one entry per workgroup
     const uint8_t *row_mask;
 };
@@ -966,6 +968,7 @@ __global__ void __launch_bounds__(256) vq_finish_listed_kernel(const FinishArgs 
                 const uint2 g = *(const uint2 *)((const unsigned short *)a.codes + (size_t)idx * a.D + lane * 4);
                 const uint2 xv = *(const uint2 *)((const unsigned short *)a.x + row * a.ldx + lane * 4);
                 if (a.q_out) *(uint2 *)((unsigned short *)a.q_out + row * a.ldq + lane * 4) = g;
+                if (a.resid_out) *(uint2 *)((unsigned short *)a.resid_out + row * a.ldr + lane * 4) = vq_bf16x4_sub(xv, g);
                 d0 = __uint_as_float(g.x << 16) - __uint_as_float(xv.x << 16);
                 d1 = __uint_as_float(g.x & 0xffff0000u) - __uint_as_float(xv.x & 0xffff0000u);
                 d2 = __uint_as_float(g.y << 16) - __uint_as_float(xv.y << 16);
@@ -974,6 +977,7 @@ __global__ void __launch_bounds__(256) vq_finish_listed_kernel(const FinishArgs 
                 const f32x4 g = *(const f32x4 *)((const float *)a.codes + (size_t)idx * a.D + lane * 4);
                 const f32x4 xv = *(const f32x4 *)((const float *)a.x + row * a.ldx + lane * 4);
                 if (a.q_out) *(f32x4 *)((float *)a.q_out + row * a.ldq + lane * 4) = g;
+                if (a.resid_out) *(f32x4 *)((float *)a.resid_out + row * a.ldr + lane * 4) = xv - g;
                 d0 = g.x - xv.x; d1 = g.y - xv.y; d2 = g.z - xv.z; d3 = g.w - xv.w;
             }
             ls = ((d0 * d0 + d1 * d1) + d2 * d2) + d3 * d3;
@@ -1011,8 +1015,8 @@ static int dispatch_refine(const RefineArgs &a, int x_dtype, unsigned gx, unsign
 }
 
 int vq_assign_listed(const void *x, int x_dtype, int64_t N, int D, int64_t ldx, const float *packed, const float *embed, int C,
-                     int64_t *idx_out, void *q_out, int64_t ldq, double *sqerr_partial, const uint8_t *row_mask,
-                     const int *row_list, const int *row_count, unsigned long long *keys, hipStream_t st)
+                     int64_t *idx_out, void *q_out, int64_t ldq, void *resid_out, int64_t ldr, double *sqerr_partial,
+                     const uint8_t *row_mask, const int *row_list, const int *row_count, unsigned long long *keys, hipStream_t st)
 {
     // keys[0 .. *row_count) were preset to ~0 by whoever built the list (vq_screen_kernel)
     RefineArgs r;
@@ -1020,7 +1024,7 @@ int vq_assign_listed(const void *x, int x_dtype, int64_t N, int D, int64_t ldx, 
     r.row_list = row_list; r.row_count = row_count; r.keys = keys;
     const int64_t chunks = vqhip_assign_blocks(N);
     const unsigned gx = (unsigned)(chunks < 1024 ? chunks : 1024);
-    int splits = r.n_tiles / 8;   // >= 8 tiles per workgroup, at most 8 splits
+    int splits = r.n_tiles / 4;   // >= 4 tiles per workgroup, at most 8 splits
     splits = splits < 1 ? 1 : (splits > 8 ? 8 : splits);
     int rc;
     switch (pick_dt(D)) {
@@ -1034,7 +1038,7 @@ int vq_assign_listed(const void *x, int x_dtype, int64_t N, int D, int64_t ldx, 
     f.x = x; f.ldx = ldx;
     f.codes = (x_dtype == VQHIP_BF16) ? (const void *)((const char *)packed + packed_bf16_offset(C, D)) : (const void *)embed;
     f.D = D; f.row_list = row_list; f.row_count = row_count; f.keys = keys;
-    f.idx_out = idx_out; f.q_out = q_out; f.ldq = ldq; f.sqerr_partial = sqerr_partial; f.row_mask = row_mask;
+    f.idx_out = idx_out; f.q_out = q_out; f.ldq = ldq; f.resid_out = resid_out; f.ldr = ldr; f.sqerr_partial = sqerr_partial; f.row_mask = row_mask;
     if (x_dtype == VQHIP_BF16)
         hipLaunchKernelGGL(vq_finish_listed_kernel<true>, dim3(VQ_FINISH_BLOCKS), dim3(256), 0, st, f);
     else

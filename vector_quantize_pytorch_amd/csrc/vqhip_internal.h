@@ -24,6 +24,19 @@ __device__ __forceinline__ unsigned short vq_f32_to_bf16_rne(float f)
     return (unsigned short)(u >> 16);
 }
 
+// bf16 tensor arithmetic of the reference (x - q on bf16 tensors: fp32 subtract, RNE back to bf16), 4 packed elements
+__device__ __forceinline__ uint2 vq_bf16x4_sub(uint2 x, uint2 g)
+{
+    const float d0 = __uint_as_float(x.x << 16) - __uint_as_float(g.x << 16);
+    const float d1 = __uint_as_float(x.x & 0xffff0000u) - __uint_as_float(g.x & 0xffff0000u);
+    const float d2 = __uint_as_float(x.y << 16) - __uint_as_float(g.y << 16);
+    const float d3 = __uint_as_float(x.y & 0xffff0000u) - __uint_as_float(g.y & 0xffff0000u);
+    uint2 r;
+    r.x = (unsigned)vq_f32_to_bf16_rne(d0) | ((unsigned)vq_f32_to_bf16_rne(d1) << 16);
+    r.y = (unsigned)vq_f32_to_bf16_rne(d2) | ((unsigned)vq_f32_to_bf16_rne(d3) << 16);
+    return r;
+}
+
 // feature-tile width: D is padded to DT in the packed codebook
 static inline int vq_pick_dt(int D)
 {
@@ -62,7 +75,7 @@ static inline size_t vq_packed_scalars_offset(int C, int D)
 // device; x and q share a dtype (fp32 / bf16) with D == DT and vector-aligned rows, Euclidean metric.  keys: N u64, entries
 // [0 .. *row_count) preset to ~0 by the list builder.
 // sqerr_partial (nullable) receives VQ_FINISH_BLOCKS entries.
-#define VQ_FINISH_BLOCKS 128
+#define VQ_FINISH_BLOCKS 512
 int vq_assign_listed(const void *x, int x_dtype, int64_t N, int D, int64_t ldx, const float *packed, const float *embed, int C,
-                     int64_t *idx_out, void *q_out, int64_t ldq, double *sqerr_partial, const uint8_t *row_mask,
-                     const int *row_list, const int *row_count, unsigned long long *keys, hipStream_t st);
+                     int64_t *idx_out, void *q_out, int64_t ldq, void *resid_out, int64_t ldr, double *sqerr_partial,
+                     const uint8_t *row_mask, const int *row_list, const int *row_count, unsigned long long *keys, hipStream_t st);

@@ -201,11 +201,6 @@ class ResidualVQ(nn.Module):
             return False            # gradients to the input take the per-stage autograd path
         if self.quant_grad_frac > 0:
             return False
-        if L.screening_enabled() and self.codebook_dim in (64, 128, 256):
-            # the per-stage path runs every stage's search as a screened assignment on the bf16 MFMA pipe
-            # (csrc/vq_screen.hip), which beats the fused exact-fp32 residual kernel (cfg 3: 5.6 vs 11.4 ms in bf16,
-            # 8.3 vs 11.4 ms in fp32); the fused kernel keeps the dims the screen does not cover (32, 96, ..., 512)
-            return False
         return all(layer._codebook._is_initted() for layer in self.layers)     # k-means runs in the staged path
 
     @torch.no_grad()
@@ -223,13 +218,18 @@ class ResidualVQ(nn.Module):
         update = train and not (freeze_codebook or vq0.freeze_codebook) and \
             (vq0._codebook.ema_update or vq0._codebook.has_dead_code_replacement)
         want_loss = train and vq0.has_commitment_loss
-        r = L.rvq_forward(x, packed, embed, Q, want_resid=update, want_sqerr=want_loss, row_mask=mask)
+        if L.screening_enabled() and D in (64, 128, 256) and x.data_ptr() % 16 == 0:
+            # Q screened searches on the bf16 MFMA pipe (csrc/vq_screen.hip), each writing the next stage's input; beats
+            # the fused exact-fp32 kernel, which keeps the dims the screen does not cover (32, 96, ..., 512)
+            r = L.rvq_forward_screened(x, packed, embed, Q, want_resid=update, want_sqerr=want_loss, row_mask=mask)
+        else:
+            r = L.rvq_forward(x, packed, embed, Q, want_resid=update, want_sqerr=want_loss, row_mask=mask)
         idx = r["idx"]
         quantized_out = L.decode_sum(idx, embed, out_dtype=x.dtype)
 
         losses = torch.zeros(self.num_quantizers, device=x.device, dtype=torch.float32)
         if want_loss:
-            sums = torch.stack([L.reduce_partials(r["sqerr_partials"][q], 4 * r["nblk"], 1.0) for q in range(Q)])
+            sums = torch.stack([L.reduce_partials(r["sqerr_partials"][q], r["sqerr_partials"].shape[1], 1.0) for q in range(Q)])
             denom = float(x.numel()) if mask is None else (mask.sum() * D).to(torch.float32)
             losses[:Q] = sums / denom * vq0.commitment_weight
         if train:
@@ -237,21 +237,24 @@ class ResidualVQ(nn.Module):
 
         if update:
             resid = r["resid"]
+            stage_in = (lambda q: r["inputs"][q]) if r.get("inputs") is not None else (lambda q: resid[..., q, :])
             for q in range(Q):
                 cb = self.layers[q]._codebook
                 buf = torch.zeros(C * D + C, dtype=torch.float32, device=x.device)
                 esum, count = buf[: C * D].view(C, D), buf[C * D:]
-                L.ema_accumulate(resid[..., q, :], idx, C, row_mask=mask, count=count, embed_sum=esum,
+                L.ema_accumulate(stage_in(q), idx, C, row_mask=mask, count=count, embed_sum=esum,
                                  idx_offset=q, idx_stride=Q)
                 if cb.use_ddp:
                     dist.all_reduce(buf)
                 cb._fold_stats(0, count, esum, None, False, cb.ema_update)
                 if not self.shared_codebook:
-                    cb.expire_codes_(resid[..., q, :].reshape(1, -1, D))
+                    cb.expire_codes_(stage_in(q).reshape(1, -1, D))
             if self.shared_codebook:                                # rvq.py:593-601
                 if self.vq_is_ema_updating:
                     vq0._codebook.update_ema()
-                vq0._codebook.expire_codes_(resid.reshape(1, -1, D))
+                if vq0._codebook.has_dead_code_replacement:
+                    allin = resid if resid is not None else torch.stack([stage_in(q) for q in range(Q)], -2)
+                    vq0._codebook.expire_codes_(allin.reshape(1, -1, D))
 
         if Q < self.num_quantizers:
             pad = torch.full((*idx.shape[:-1], self.num_quantizers - Q), -1, device=x.device, dtype=torch.long)
