@@ -384,3 +384,41 @@ def test_screened_masked_strided_rows_and_toggle(dev, monkeypatch):
     r0 = L.assign(xd, packed, ed, want_q=True, want_sqerr=True, row_mask=m.to(dev))
     assert r0.get("n_exact") is None
     assert torch.equal(r0["idx"], r["idx"]) and torch.equal(r0["q"], r["q"])
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("kind", ["unit", "dups"])
+def test_screened_residual_output(dev, dtype, kind):
+    """resid_out = x - q in the reference's tensor arithmetic (rvq.py:524), from the screen kernel for certified rows and
+    from the finish kernel for the rows of the exact pass ('dups' sends every row there)."""
+    from vector_quantize_pytorch_amd import _lib as L
+    N, C, D = 3001, 256, 128
+    x, e = _screen_case(N, C, D, kind, seed=7, dtype=dtype)
+    xd, ed = x.to(dev), e.to(dev)
+    big = torch.zeros(N, 3, D, dtype=dtype, device=dev)           # strided destination rows, like the RVQ stage buffers
+    r = L.assign(xd, L.pack_codebook(ed), ed, want_q=False, want_sqerr=True, resid_out=big[:, 1, :])
+    assert r.get("n_exact") is not None and r["q"] is None
+    idx_o, _ = O.c_assign(x.float(), e)
+    assert torch.equal(r["idx"].cpu(), idx_o)
+    want = x - e[idx_o].to(dtype)                                  # torch bf16 subtraction == fp32 subtract + RNE
+    assert torch.equal(big[:, 1, :].cpu(), want)
+    assert not big[:, 0, :].any() and not big[:, 2, :].any()
+
+
+@pytest.mark.parametrize("N,C,D,Q,dtype,shared", [(3000, 256, 256, 4, torch.float32, True), (2049, 100, 128, 3, torch.bfloat16, False),
+                                                   (1500, 512, 64, 8, torch.bfloat16, True)])
+def test_rvq_screened_loop_equals_fused_exact_kernel(dev, N, C, D, Q, dtype, shared):
+    from vector_quantize_pytorch_amd import _lib as L
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(2, N // 2, D, generator=g).to(dtype).to(dev)
+    e = (torch.randn(C, D, generator=g) if shared else torch.randn(Q, C, D, generator=g)).to(dev)
+    packed = L.pack_codebook(e) if shared else torch.stack([L.pack_codebook(e[q]) for q in range(Q)])
+    mask = (torch.rand(2, N // 2, generator=g) < 0.8).to(dev)
+    a = L.rvq_forward(x, packed, e, Q, want_resid=True, want_sqerr=True, row_mask=mask)
+    b = L.rvq_forward_screened(x, packed, e, Q, want_resid=True, want_sqerr=True, row_mask=mask)
+    assert torch.equal(a["idx"], b["idx"])
+    for q in range(Q):
+        rows = mask.reshape(-1)
+        assert torch.equal(a["resid"][..., q, :].reshape(-1, D)[rows], b["inputs"][q].reshape(-1, D)[rows])
+        sa, sb = a["sqerr_partials"][q].sum().item(), b["sqerr_partials"][q].sum().item()
+        assert abs(sa - sb) <= 1e-5 * max(abs(sa), 1e-12)

@@ -176,13 +176,14 @@ def assign(x: torch.Tensor, packed: torch.Tensor, embed2d: torch.Tensor, *, cosi
     if row_mask is not None:
         row_mask = row_mask.reshape(-1).to(torch.uint8).contiguous()
         assert row_mask.numel() == N
-    if resid_out is not None and not want_q:
-        want_q = True          # the exact kernel has no residual output: x - q below (only reached off the screened path)
+    screened = (not cosine and not want_best and not want_rnorm and N > 0 and screening_enabled()
+                and xk.dtype in (torch.bfloat16, torch.float32) and xk.data_ptr() % 16 == 0
+                and (ldx * xk.element_size()) % 16 == 0 and embed2d.data_ptr() % 16 == 0
+                and bool(lib().vqhip_screen_supported(N, D, C)))
+    if resid_out is not None and not want_q and not screened:
+        want_q = True          # the exact kernel has no residual output: x - q is formed below
         q = torch.empty(*lead, D, dtype=x.dtype, device=dev)
-    if (not cosine and not want_best and not want_rnorm and N > 0 and screening_enabled()
-            and xk.dtype in (torch.bfloat16, torch.float32) and xk.data_ptr() % 16 == 0
-            and (ldx * xk.element_size()) % 16 == 0 and embed2d.data_ptr() % 16 == 0
-            and lib().vqhip_screen_supported(N, D, C)):
+    if screened:
         # bf16-MFMA screen + exact fp32 pass on the uncertified rows only (csrc/vq_screen.hip); same outputs
         nblk = lib().vqhip_screen_partials(N, _dtype_code(xk))
         partials = torch.empty(nblk, dtype=torch.float64, device=dev) if want_sqerr else None
