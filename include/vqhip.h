@@ -74,8 +74,15 @@ int vqhip_assign(const void *x, int x_dtype, int64_t N, int D, int64_t ldx,
                  float *best_out, float *rnorm_out, double *sqerr_partial,
                  const uint8_t *row_mask, void *stream);
 
-/* ---- screened assignment (Euclidean, D in {64, 128, 256}) ------------------------------------------
- * Same contract as vqhip_assign(metric VQHIP_EUCLID, q in x's dtype): idx_out bit-identical to the exact kernel, q_out
+/* ---- l2norm of rows ------------------------------------------------------------------------------
+ * Replaces l2norm (vqp.py:37-38) as applied to the input at :1159: out = x / max(||x||, 1e-6) with ||x||^2 summed in
+ * ATen's CPU order and, for bf16 tensors, norm and quotient rounded to bf16 as the reference's bf16 ops do -- the same
+ * arithmetic vqhip_assign(metric VQHIP_COSINE) applies internally.  D in {64, 128, 256}; rows aligned to 4 elements. */
+int vqhip_l2norm_rows(const void *x, int x_dtype, int64_t N, int D, int64_t ldx, void *out, int64_t ldo, void *stream);
+
+/* ---- screened assignment (D in {64, 128, 256}) ------------------------------------------------------
+ * metric: VQHIP_EUCLID, or VQHIP_COSINE_PRENORM on rows already normalised (vqhip_l2norm_rows).
+ * Same contract as vqhip_assign(same metric, q in x's dtype): idx_out bit-identical to the exact kernel, q_out
  * the gathered code rows, sqerr_partial the squared-error partials -- but the codebook sweep runs on the bf16 MFMA pipe
  * against a two-part bf16 split of the codebook made by vqhip_pack_codebook (fp32 rows are split as well, three products
  * per k-step), and only the rows whose best-vs-second margin is inside the proven error bound (csrc/vq_screen.hip) are
@@ -93,7 +100,7 @@ size_t vqhip_screen_workspace_bytes(int64_t N);
 int64_t vqhip_screen_blocks(int64_t N, int x_dtype);
 int64_t vqhip_screen_partials(int64_t N, int x_dtype);
 int vqhip_assign_screened(const void *x, int x_dtype, int64_t N, int D, int64_t ldx, const float *packed,
-                          const float *embed, int C, int64_t *idx_out, void *q_out, int64_t ldq,
+                          const float *embed, int C, int metric, int64_t *idx_out, void *q_out, int64_t ldq,
                           void *resid_out, int64_t ldr, double *sqerr_partial, const uint8_t *row_mask,
                           void *workspace, size_t workspace_bytes, float *debug_out, void *stream);
 

@@ -218,9 +218,16 @@ def test_vq_vs_oracle_multi_step_64k(dev):
             assert len(audit) == 0, audit[:5]
         assert all(gap <= 4.0 for *_, gap in audit), audit[:5]       # only near-ties once codebooks differ by round-off
         assert len(audit) <= 16
-        _close(loss, loss2, 1e-5, f"loss step {step}")
-        _close(vq._codebook.embed.cpu(), st.embed, 1e-5, f"embed step {step}")
-        _close(vq._codebook.cluster_size.cpu(), st.cluster_size, 1e-5, f"cluster_size step {step}")
+        # codes touched by an (audited) near-tie flip received one row more / less: compare the others, then continue both
+        # sides from the SAME state so that every step is a like-for-like comparison (the EMA sums are accumulated in a
+        # run-dependent order on the GPU, so the two codebooks differ by round-off after a step and a near-tie may flip)
+        keep = torch.ones(1024, dtype=torch.bool)
+        for _, ia, ib, _ in audit:
+            keep[ia] = keep[ib] = False
+        _close(loss, loss2, 1e-5 if not audit else 1e-4, f"loss step {step}")
+        _close(vq._codebook.embed.cpu()[:, keep], st.embed[:, keep], 1e-5, f"embed step {step}")
+        _close(vq._codebook.cluster_size.cpu()[:, keep], st.cluster_size[:, keep], 1e-5, f"cluster_size step {step}")
+        st = O.VQState.from_state_dict({k: v.cpu() for k, v in vq.state_dict().items()})
 
 
 def test_cfg2_full_size_properties(dev):

@@ -422,3 +422,48 @@ def test_rvq_screened_loop_equals_fused_exact_kernel(dev, N, C, D, Q, dtype, sha
         assert torch.equal(a["resid"][..., q, :].reshape(-1, D)[rows], b["inputs"][q].reshape(-1, D)[rows])
         sa, sb = a["sqerr_partials"][q].sum().item(), b["sqerr_partials"][q].sum().item()
         assert abs(sa - sb) <= 1e-5 * max(abs(sa), 1e-12)
+
+
+def _l2norm_ref(x):
+    """the reference's l2norm on a tensor of x's dtype (vqp.py:37-38): bf16 tensors round the norm and the quotient to bf16"""
+    if x.dtype == torch.bfloat16:
+        nrm = O.c_row_sumsq(x.float()).sqrt().bfloat16().float().clamp(min=1e-6)
+        return (x.float() / nrm[:, None]).bfloat16()
+    return O.c_l2norm(x)
+
+
+@pytest.mark.parametrize("N,D,dtype", [(4099, 256, torch.bfloat16), (1000, 128, torch.float32), (333, 64, torch.bfloat16),
+                                       (2048, 256, torch.float32)])
+def test_l2norm_rows_matches_reference_arithmetic(dev, N, D, dtype):
+    from vector_quantize_pytorch_amd import _lib as L
+    g = torch.Generator().manual_seed(2)
+    x = (torch.randn(N, D, generator=g) * torch.rand(N, 1, generator=g) * 3).to(dtype)
+    x[5] = 0                                                       # zero row: divided by the 1e-6 floor
+    assert torch.equal(L.l2norm_rows(x.to(dev)).cpu(), _l2norm_ref(x))
+
+
+@pytest.mark.parametrize("N,C,D,kind", [(4099, 1024, 256, "unit"), (5000, 1000, 128, "unit"), (3000, 37, 64, "unit"),
+                                        (8192, 1024, 256, "dups")])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_screened_cosine_matches_chain_oracle(dev, N, C, D, kind, dtype):
+    """cosine metric through the screen: l2norm_rows + screened search on unit-norm rows == the exact cosine kernel's
+    reference arithmetic (indices, q, squared error against the normalised rows)."""
+    from vector_quantize_pytorch_amd import _lib as L
+    x, e = _screen_case(N, C, D, kind, dtype=dtype)
+    e = O.l2norm(e)
+    xd, ed = x.to(dev), e.to(dev)
+    xn_d = L.l2norm_rows(xd)
+    r = L.assign(xn_d, L.pack_codebook(ed), ed, cosine=True, skip_l2norm=True, want_q=True, want_sqerr=True)
+    assert r.get("n_exact") is not None
+    xn = _l2norm_ref(x)
+    assert torch.equal(xn_d.cpu(), xn)
+    idx_o, _ = O.c_assign(xn.float(), e, cosine=True)
+    mism = (r["idx"].cpu() != idx_o).sum().item()
+    assert mism == 0, f"{mism}/{N} index mismatches vs chain oracle"
+    want_q = e[idx_o].to(dtype)
+    assert torch.equal(r["q"].cpu(), want_q)
+    sq = r["sqerr_partials"][: r["nblk"]].sum().item()
+    want_sq = ((want_q.double() - xn.double()) ** 2).sum().item()
+    assert abs(sq - want_sq) <= 1e-5 * max(want_sq, 1e-12)
+    if kind == "dups":
+        assert int(r["n_exact"].item()) == N

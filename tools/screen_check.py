@@ -12,9 +12,12 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from vector_quantize_pytorch_amd import _lib as L  # noqa: E402
 
 
-def run(x, embed, packed, screened, **kw):
+def run(x, embed, packed, screened, cosine=False, **kw):
     os.environ["VQHIP_SCREEN"] = "1" if screened else "0"
-    r = L.assign(x, packed, embed, want_q=True, want_sqerr=True, **kw)
+    if cosine and screened:      # what Codebook.quantize does: normalise once, then the screened search on unit-norm rows
+        r = L.assign(L.l2norm_rows(x), packed, embed, cosine=True, skip_l2norm=True, want_q=True, want_sqerr=True, **kw)
+    else:                        # exact kernel, normalisation fused
+        r = L.assign(x, packed, embed, cosine=cosine, want_q=True, want_sqerr=True, **kw)
     os.environ["VQHIP_SCREEN"] = "1"
     return r
 
@@ -37,13 +40,15 @@ def codebooks(kind, C, D, x, gen):
     raise ValueError(kind)
 
 
-def check(N, C, D, kind, gen, timing=False, dtype=torch.bfloat16):
+def check(N, C, D, kind, gen, timing=False, dtype=torch.bfloat16, cosine=False):
     x = torch.randn(N, D, device="cuda", generator=gen).to(dtype)
     embed = codebooks(kind, C, D, x, gen)
+    if cosine:
+        embed = torch.nn.functional.normalize(embed, dim=-1)
     packed = L.pack_codebook(embed)
-    r0 = run(x, embed, packed, False)
+    r0 = run(x, embed, packed, False, cosine)
     L.screen_debug = True
-    r1 = run(x, embed, packed, True)
+    r1 = run(x, embed, packed, True, cosine)
     L.screen_debug = False
     torch.cuda.synchronize()
     assert "n_exact" in r1, "screened path not taken"
@@ -58,14 +63,15 @@ def check(N, C, D, kind, gen, timing=False, dtype=torch.bfloat16):
     ns = min(N, 8192)
     sel = torch.randperm(N, device="cuda", generator=gen)[:ns]
     y2 = L.row_sumsq(embed).double()
-    t = x[sel].double() @ embed.double().t() - 0.5 * y2[None, :]
+    xs = (L.l2norm_rows(x) if cosine else x)[sel].double()
+    t = xs @ embed.double().t() - (0.0 if cosine else 0.5) * y2[None, :]
     top = t.topk(2, dim=1).values
     err1 = (dbg[sel, 0].double() - top[:, 0]).abs()
     err2 = (dbg[sel, 1].double() - top[:, 1]).abs()
     thr = dbg[sel, 2].double()
     ratio = float((torch.maximum(err1, err2) / thr).max())
     flagged = dbg[:, 3].sum().item()
-    line = (f"{str(dtype)[6:]:8s} N={N} C={C} D={D} {kind:8s} idx_equal={same_idx} (bad {nbad}) q_equal={same_q} "
+    line = (f"{'cos' if cosine else 'l2 '} {str(dtype)[6:]:8s} N={N} C={C} D={D} {kind:8s} idx_equal={same_idx} (bad {nbad}) q_equal={same_q} "
             f"sqerr rel diff={abs(s0 - s1) / max(abs(s0), 1e-30):.2e} exact_rows={nex} ({100.0 * nex / N:.3f}%) "
             f"flagged_dbg={int(flagged)} max|t_err|/thr={ratio:.4f}")
     print(line, flush=True)
@@ -73,11 +79,11 @@ def check(N, C, D, kind, gen, timing=False, dtype=torch.bfloat16):
     if timing:
         for screened in (False, True):
             for _ in range(3):
-                run(x, embed, packed, screened)
+                run(x, embed, packed, screened, cosine)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             for _ in range(20):
-                run(x, embed, packed, screened)
+                run(x, embed, packed, screened, cosine)
             torch.cuda.synchronize()
             dt = (time.perf_counter() - t0) / 20
             print(f"   {'screened' if screened else 'exact   '}: {dt * 1e3:.3f} ms/call  {N / dt:.3e} vec/s", flush=True)
@@ -92,12 +98,15 @@ def main():
     cases = [(4096, 1024, 256, "kaiming"), (5000, 1000, 256, "randn"), (300, 37, 128, "randn"), (70000, 512, 64, "rows"),
              (65536, 1024, 256, "rows"), (65536, 1024, 256, "dups"), (65536, 1024, 256, "tiny"), (1000, 2, 64, "randn"),
              (33333, 4096, 128, "kaiming")]
-    for dtype in (torch.bfloat16, torch.float32):
-        for c in cases:
-            ok &= check(*c, gen, dtype=dtype)
-        if not quick:
-            ok &= check(1 << 20, 1024, 256, "kaiming", gen, timing=True, dtype=dtype)
-            ok &= check(1 << 20, 1024, 256, "rows", gen, timing=True, dtype=dtype)
+    only_cos = "--cosine" in sys.argv
+    for cosine in ((True,) if only_cos else (False, True)):
+        for dtype in (torch.bfloat16, torch.float32):
+            for c in cases:
+                ok &= check(*c, gen, dtype=dtype, cosine=cosine)
+            if not quick:
+                ok &= check(1 << 20, 1024, 256, "kaiming", gen, timing=True, dtype=dtype, cosine=cosine)
+                if not cosine:
+                    ok &= check(1 << 20, 1024, 256, "rows", gen, timing=True, dtype=dtype)
     print("ALL OK" if ok else "FAILURES", flush=True)
     sys.exit(0 if ok else 1)
 

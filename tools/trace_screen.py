@@ -15,11 +15,14 @@ lib.vqhip_set_trace.argtypes = [ctypes.c_void_p]
 for blocks in (256, 512, 4096):
     x = xf[: blocks * 256]
     L.assign(x, pk, e, want_q=True, want_sqerr=True); torch.cuda.synchronize()
-    tr = torch.zeros(16 * 4 * 64 * 4, dtype=torch.int64, device=dev)
+    tr = torch.zeros(16 * 4 * 64 * 4 + 16 * 4 * 8, dtype=torch.int64, device=dev)
     lib.vqhip_set_trace(ctypes.c_void_p(tr.data_ptr()))
     L.assign(x, pk, e, want_q=True, want_sqerr=True); torch.cuda.synchronize()
     lib.vqhip_set_trace(ctypes.c_void_p(0))
-    t = tr.cpu().reshape(16, 4, 64, 4)[:, :, :32].double()
+    ph = tr.cpu()[16 * 4 * 64 * 4:].reshape(16, 4, 8).double()
+    d = [(ph[:, :, i + 1] - ph[:, :, i]).mean().item() for i in range(4)]
+    print(f"blocks={blocks}: phases (cycles): load x + eps {d[0]:.0f} | sweep {d[1]:.0f} | merge/idx/list {d[2]:.0f} | q rows + sqerr {d[3]:.0f}")
+    t = tr.cpu()[: 16 * 4 * 64 * 4].reshape(16, 4, 64, 4)[:, :, :32].double()
     bar = t[..., 1] - t[..., 0]
     mf = t[..., 2] - t[..., 1]
     ep = t[..., 3] - t[..., 2]

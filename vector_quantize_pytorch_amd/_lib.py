@@ -57,7 +57,9 @@ def lib():
     L.vqhip_screen_blocks.restype = i64
     L.vqhip_screen_partials.argtypes = [i64, i32]
     L.vqhip_screen_partials.restype = i64
-    L.vqhip_assign_screened.argtypes = [vp, i32, i64, i32, i64, vp, vp, i32, vp, vp, i64, vp, i64, vp, vp, vp, ctypes.c_size_t, vp, vp]
+    L.vqhip_assign_screened.argtypes = [vp, i32, i64, i32, i64, vp, vp, i32, i32, vp, vp, i64, vp, i64, vp, vp, vp, ctypes.c_size_t, vp, vp]
+    L.vqhip_l2norm_rows.argtypes = [vp, i32, i64, i32, i64, vp, i64, vp]
+    L.vqhip_l2norm_rows.restype = i32
     L.vqhip_assign_screened.restype = i32
     L.vqhip_route_fwd.argtypes = [vp, vp, i32, i64, i32, i64, i64, vp, i64, i32, vp]
     L.vqhip_route_bwd.argtypes = [vp, vp, vp, i32, i64, i32, i64, i64, i64, vp, vp, i32, vp, i64, vp]
@@ -78,7 +80,7 @@ def lib():
 
 EXPORTS = ("vqhip_version", "vqhip_last_error", "vqhip_packed_bytes", "vqhip_pack_codebook",
            "vqhip_assign_blocks", "vqhip_assign", "vqhip_screen_supported", "vqhip_screen_workspace_bytes",
-           "vqhip_screen_blocks", "vqhip_screen_partials", "vqhip_assign_screened", "vqhip_scores", "vqhip_rvq_forward", "vqhip_reduce_partials", "vqhip_ema_workspace_bytes", "vqhip_ema_accumulate",
+           "vqhip_screen_blocks", "vqhip_screen_partials", "vqhip_assign_screened", "vqhip_l2norm_rows", "vqhip_scores", "vqhip_rvq_forward", "vqhip_reduce_partials", "vqhip_ema_workspace_bytes", "vqhip_ema_accumulate",
            "vqhip_ema_finalize", "vqhip_decode_sum", "vqhip_row_sumsq", "vqhip_route_fwd", "vqhip_route_bwd")
 
 
@@ -176,7 +178,7 @@ def assign(x: torch.Tensor, packed: torch.Tensor, embed2d: torch.Tensor, *, cosi
     if row_mask is not None:
         row_mask = row_mask.reshape(-1).to(torch.uint8).contiguous()
         assert row_mask.numel() == N
-    screened = (not cosine and not want_best and not want_rnorm and N > 0 and screening_enabled()
+    screened = ((not cosine or skip_l2norm) and not want_best and not want_rnorm and N > 0 and screening_enabled()
                 and xk.dtype in (torch.bfloat16, torch.float32) and xk.data_ptr() % 16 == 0
                 and (ldx * xk.element_size()) % 16 == 0 and embed2d.data_ptr() % 16 == 0
                 and bool(lib().vqhip_screen_supported(N, D, C)))
@@ -194,7 +196,8 @@ def assign(x: torch.Tensor, packed: torch.Tensor, embed2d: torch.Tensor, *, cosi
         if resid_out is not None:
             rk, rN, rD, ldr = as_rows(resid_out)
             assert rN == N and rD == D and rk.dtype == xk.dtype
-        _check(lib().vqhip_assign_screened(_ptr(xk), _dtype_code(xk), N, D, ldx, _ptr(packed), _ptr(embed2d), C, _ptr(idx), _ptr(q), ldq,
+        _check(lib().vqhip_assign_screened(_ptr(xk), _dtype_code(xk), N, D, ldx, _ptr(packed), _ptr(embed2d), C,
+                                           COSINE_PRENORM if cosine else EUCLID, _ptr(idx), _ptr(q), ldq,
                                            _ptr(rk), ldr, _ptr(partials), _ptr(row_mask), _ptr(ws), nws, _ptr(dbg), _stream()),
                "vqhip_assign_screened")
         return dict(idx=idx, q=q, sqerr_partials=partials, best=None, rnorm=None, nblk=nblk, n_exact=ws[:1], screen_debug=dbg)
@@ -229,6 +232,23 @@ def scores(x: torch.Tensor, packed: torch.Tensor, embed2d: torch.Tensor, *, cosi
         _check(lib().vqhip_scores(_ptr(xk), _dtype_code(xk), N, D, ldx, _ptr(packed), _ptr(embed2d), C, metric,
                                   _ptr(out), C, _ptr(idx), _ptr(rnorm), _stream()), "vqhip_scores")
     return out, idx, rnorm
+
+
+def screen_supported(x: torch.Tensor, C: int) -> bool:
+    """True when assign() would take the screened path for rows like x (Euclidean, or cosine on unit-norm rows)."""
+    xk, N, D, ldx = as_rows(x)
+    return bool(N > 0 and screening_enabled() and xk.dtype in (torch.bfloat16, torch.float32) and xk.data_ptr() % 16 == 0
+                and (ldx * xk.element_size()) % 16 == 0 and lib().vqhip_screen_supported(N, D, C))
+
+
+def l2norm_rows(x: torch.Tensor) -> torch.Tensor:
+    """x / max(||x||, 1e-6) row-wise in the reference's arithmetic (vqp.py:37-38 at :1159); D in {64, 128, 256}."""
+    _need_gpu(x)
+    xk, N, D, ldx = as_rows(x)
+    out = torch.empty(*x.shape, dtype=x.dtype, device=x.device)
+    if N > 0:
+        _check(lib().vqhip_l2norm_rows(_ptr(xk), _dtype_code(xk), N, D, ldx, _ptr(out), D, _stream()), "vqhip_l2norm_rows")
+    return out
 
 
 def rvq_forward_screened(x: torch.Tensor, packed: torch.Tensor, embed: torch.Tensor, Q: int, *, want_resid=False,

@@ -352,13 +352,19 @@ class Codebook(nn.Module):
             # embed_override: the codebook actually searched when it is a function of the stored one (vq_bridge)
             e = (self.embed if embed_override is None else embed_override)[h].detach().contiguous()
             packed = L.pack_codebook(e)
-            r = L.assign(xs[h], packed, e, cosine=self.use_cosine_sim, want_q=want_q, want_sqerr=want_sqerr,
-                         row_mask=rmask, skip_l2norm=input_normalized, want_rnorm=self.use_cosine_sim,
+            xh, xst, prenorm = xs[h], x_stats[h], input_normalized
+            if self.use_cosine_sim and not prenorm and not self.affine_param and L.screen_supported(xh, C):
+                # cosine through the screened search (csrc/vq_screen.hip), which takes unit-norm rows: normalise once with
+                # the arithmetic the exact kernel applies internally (vqp.py:37-38 at :1159), then search / sum those rows
+                xh = xst = L.l2norm_rows(xh)
+                prenorm = True
+            r = L.assign(xh, packed, e, cosine=self.use_cosine_sim, want_q=want_q, want_sqerr=want_sqerr,
+                         row_mask=rmask, skip_l2norm=prenorm, want_rnorm=self.use_cosine_sim and not prenorm,
                          q_out=q_out if H == 1 else None)
             if do_update:
                 buf = torch.zeros(C * self.dim + C, dtype=torch.float32, device=x.device)
                 esum, count = buf[: C * self.dim].view(C, self.dim), buf[C * self.dim:]
-                L.ema_accumulate(x_stats[h], r["idx"].reshape(-1), C, cosine=self.use_cosine_sim and not input_normalized,
+                L.ema_accumulate(xst, r["idx"].reshape(-1), C, cosine=self.use_cosine_sim and not prenorm,
                                  rnorm=r["rnorm"], row_mask=rmask, count=count, embed_sum=esum)
                 if self.use_ddp:
                     dist.all_reduce(buf)          # ONE collective for count || embed_sum (RCCL over xGMI)

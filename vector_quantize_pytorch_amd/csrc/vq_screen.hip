@@ -73,9 +73,15 @@ struct ScreenArgs {
 
 #ifdef VQ_TRACE
 extern long long *vq_g_trace;
-#define VQ_STAMP(slot) do { if (a.trace && blockIdx.x < 16 && lane == 0 && ct < 64) a.trace[(((size_t)blockIdx.x * 4 + wave) * 64 + ct) * 4 + (slot)] = __builtin_readcyclecounter(); } while (0)
+#ifndef VQ_TRACE_BLOCK0
+#define VQ_TRACE_BLOCK0 0    // first of the 16 traced workgroups (a mid-grid value shows the steady state)
+#endif
+#define VQ_TB ((int)blockIdx.x - VQ_TRACE_BLOCK0)
+#define VQ_STAMP(slot) do { if (a.trace && VQ_TB >= 0 && VQ_TB < 16 && lane == 0 && ct < 64) a.trace[(((size_t)VQ_TB * 4 + wave) * 64 + ct) * 4 + (slot)] = __builtin_readcyclecounter(); } while (0)
+#define VQ_PHASE(slot) do { if (a.trace && VQ_TB >= 0 && VQ_TB < 16 && lane == 0) a.trace[16 * 4 * 64 * 4 + ((size_t)VQ_TB * 4 + wave) * 8 + (slot)] = __builtin_readcyclecounter(); } while (0)
 #else
 #define VQ_STAMP(slot) do {} while (0)
+#define VQ_PHASE(slot) do {} while (0)
 #endif
 
 // best / second best of a 16-score accumulator.  key = score with its 4 low mantissa bits replaced by the register
@@ -93,7 +99,10 @@ __device__ __forceinline__ void top2_tile(const f32x16 &acc, float &m1, float &m
     tix = (m1 != om) ? ct : tix;
 }
 
-template <int DT>
+// METRIC 0: Euclidean (t = x.c - ||c||^2 / 2).  METRIC 1: cosine on rows that are already unit-norm (t = x.c, the
+// reference's einsum at vqp.py:741; no sqrt, ties only between equal floats): the accumulator starts at 0 and the bound has
+// no norm terms -- reference chain D u XY, split 2^-16 XY, accumulation 8 D u XY, and the margin must cover both codes: 2x.
+template <int DT, int METRIC>
 __global__ void __launch_bounds__(VQS_WAVES * 64, 8 / VQS_WAVES) vq_screen_kernel(const ScreenArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -113,6 +122,7 @@ __global__ void __launch_bounds__(VQS_WAVES * 64, 8 / VQS_WAVES) vq_screen_kerne
     const int j = lane & 31;
     const int half = lane >> 5;
     const int64_t wrow0 = (int64_t)blockIdx.x * VQ_SCREEN_ROWS + wave * 64;
+    VQ_PHASE(0);
 
     // ---- tile 0: wave w copies the 1-KiB pieces w, w + WAVES, ... ----
     constexpr int PSTRIDE = VQS_WAVES * 1024;
@@ -156,13 +166,15 @@ __global__ void __launch_bounds__(VQS_WAVES * 64, 8 / VQS_WAVES) vq_screen_kerne
             const float xn = sqrtf(xs) * 1.0001f;
             const float xy = xn * ymax;
             // eps_s (see the header): 10 u (x2 + y2max + 2 xy)  >=  u (x2 + y2) + 9 u s
-            eps[rb] = u * (10.f * (xs + y2max + 2.f * xy) + (2.f * DT + 512.f) * xy + 16.f * DT * (xy + 0.5f * y2max)) + 4e-8f;
+            if (METRIC == 0) eps[rb] = u * (10.f * (xs + y2max + 2.f * xy) + (2.f * DT + 512.f) * xy + 16.f * DT * (xy + 0.5f * y2max)) + 4e-8f;
+            else             eps[rb] = 2.f * u * (9.f * DT + 256.f) * xy + 1e-30f;
         }
     }
 
     float m1[2] = {-__builtin_inff(), -__builtin_inff()};
     float m2[2] = {-__builtin_inff(), -__builtin_inff()};
     int tix[2] = {0, 0};
+    VQ_PHASE(1);   // x loaded, eps computed
 
     const int nt = a.n_tiles;
     for (int ct = 0; ct < nt; ++ct) {
@@ -180,10 +192,17 @@ __global__ void __launch_bounds__(VQS_WAVES * 64, 8 / VQS_WAVES) vq_screen_kerne
         // register e <-> code 8 (e >> 2) + 4 half + (e & 3) of the tile)
         const float *nh = (const float *)(tile + 128 * DT);
         f32x16 acc0, acc1;
+        if (METRIC == 0 || (ct == nt - 1 && (a.C & 31))) {   // cosine starts at 0; only a ragged last tile needs the
+#pragma unroll                                               // -3e38 of its padding codes (they would score 0 otherwise)
+            for (int q = 0; q < 4; ++q) {
+                f32x4 v = *(const f32x4 *)(nh + 8 * q + 4 * half);
+                if (METRIC != 0) { v.x = v.x < -1e38f ? v.x : 0.f; v.y = v.y < -1e38f ? v.y : 0.f;
+                                   v.z = v.z < -1e38f ? v.z : 0.f; v.w = v.w < -1e38f ? v.w : 0.f; }
+                acc0[4 * q + 0] = v.x; acc0[4 * q + 1] = v.y; acc0[4 * q + 2] = v.z; acc0[4 * q + 3] = v.w;
+            }
+        } else {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const f32x4 v = *(const f32x4 *)(nh + 8 * q + 4 * half);
-            acc0[4 * q + 0] = v.x; acc0[4 * q + 1] = v.y; acc0[4 * q + 2] = v.z; acc0[4 * q + 3] = v.w;
+            for (int r = 0; r < 16; ++r) acc0[r] = 0.f;
         }
         acc1 = acc0;
 
@@ -232,6 +251,7 @@ __global__ void __launch_bounds__(VQS_WAVES * 64, 8 / VQS_WAVES) vq_screen_kerne
 #endif
     }
 
+    VQ_PHASE(2);   // sweep done
     // ---- merge the half-waves, certify, emit ----
     int code[2];
     bool flagged[2];
@@ -272,6 +292,7 @@ __global__ void __launch_bounds__(VQS_WAVES * 64, 8 / VQS_WAVES) vq_screen_kerne
         }
     }
 
+    VQ_PHASE(3);   // idx + list written
     // ---- outputs per row block: the loss operands (this lane's slice of its row's code, L2) are requested first so
     //      their latency hides behind the q copy; q = bf16 codebook rows written as whole rows, 16 rows in flight;
     //      squared error of the certified rows from the registers (the listed rows are counted by the exact pass) ----
@@ -326,6 +347,7 @@ __global__ void __launch_bounds__(VQS_WAVES * 64, 8 / VQS_WAVES) vq_screen_kerne
             ds += counted ? (double)(ls[0] + ls[1]) : 0.0;
         }
     }
+    VQ_PHASE(4);   // q rows + squared error done
     if (a.sqerr_partial) {
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) ds += __shfl_xor(ds, o, 64);
@@ -372,7 +394,7 @@ __device__ __forceinline__ void split8_bf16(const f32x4 &v0, const f32x4 &v1, ui
     m = make_uint4(mw[0], mw[1], mw[2], mw[3]);
 }
 
-template <int DT>
+template <int DT, int METRIC>
 __global__ void __launch_bounds__(VQS_F32_WAVES * 64, 8 / VQS_F32_WAVES) vq_screen_f32_kernel(const ScreenArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -422,7 +444,8 @@ __global__ void __launch_bounds__(VQS_F32_WAVES * 64, 8 / VQS_F32_WAVES) vq_scre
         const float y2max = __uint_as_float(a.scalars[0]);
         const float xy = sqrtf(xs) * 1.0001f * sqrtf(y2max) * 1.0001f;
         const float u = 5.9604645e-8f;   // 2^-24
-        eps = u * (10.f * (xs + y2max + 2.f * xy) + (2.f * DT + 1600.f) * xy + 24.f * DT * (xy + 0.5f * y2max)) + 4e-8f;
+        if (METRIC == 0) eps = u * (10.f * (xs + y2max + 2.f * xy) + (2.f * DT + 1600.f) * xy + 24.f * DT * (xy + 0.5f * y2max)) + 4e-8f;
+        else             eps = 2.f * u * (13.f * DT + 800.f) * xy + 1e-30f;
     }
 
     float m1 = -__builtin_inff(), m2 = -__builtin_inff();
@@ -439,10 +462,17 @@ __global__ void __launch_bounds__(VQS_F32_WAVES * 64, 8 / VQS_F32_WAVES) vq_scre
 
         const float *nh = (const float *)(tile + 128 * DT);
         f32x16 acc0, acc1;
+        if (METRIC == 0 || (ct == nt - 1 && (a.C & 31))) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const f32x4 v = *(const f32x4 *)(nh + 8 * q + 4 * half);
-            acc0[4 * q + 0] = v.x; acc0[4 * q + 1] = v.y; acc0[4 * q + 2] = v.z; acc0[4 * q + 3] = v.w;
+            for (int q = 0; q < 4; ++q) {
+                f32x4 v = *(const f32x4 *)(nh + 8 * q + 4 * half);
+                if (METRIC != 0) { v.x = v.x < -1e38f ? v.x : 0.f; v.y = v.y < -1e38f ? v.y : 0.f;
+                                   v.z = v.z < -1e38f ? v.z : 0.f; v.w = v.w < -1e38f ? v.w : 0.f; }
+                acc0[4 * q + 0] = v.x; acc0[4 * q + 1] = v.y; acc0[4 * q + 2] = v.z; acc0[4 * q + 3] = v.w;
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc0[r] = 0.f;
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc1[r] = 0.f;
@@ -609,28 +639,34 @@ extern "C" int vqhip_screen_supported(int64_t N, int D, int C)
     return (D == 64 || D == 128 || D == 256) && N > 0 && N < ((int64_t)1 << 31) - 512 && C >= 2;
 }
 
-template <int DT>
+template <int DT, int METRIC>
 static int launch_screen(const ScreenArgs &a, int x_dtype, hipStream_t st)
 {
     constexpr int SMEM = 2 * (128 * DT + 1024);
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void *)vq_screen_kernel<DT>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+        hipError_t e = hipFuncSetAttribute((const void *)vq_screen_kernel<DT, METRIC>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
         if (e == hipSuccess)
-            e = hipFuncSetAttribute((const void *)vq_screen_f32_kernel<DT>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+            e = hipFuncSetAttribute((const void *)vq_screen_f32_kernel<DT, METRIC>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
         if (e != hipSuccess) VQ_FAIL((int)e, "hipFuncSetAttribute(screen<%d>): %s", DT, hipGetErrorString(e));
         attr_done = true;
     }
     const unsigned blocks = (unsigned)vqhip_screen_blocks(a.N, x_dtype);
     if (x_dtype == VQHIP_BF16)
-        hipLaunchKernelGGL((vq_screen_kernel<DT>), dim3(blocks), dim3(VQS_WAVES * 64), SMEM, st, a);
+        hipLaunchKernelGGL((vq_screen_kernel<DT, METRIC>), dim3(blocks), dim3(VQS_WAVES * 64), SMEM, st, a);
     else
-        hipLaunchKernelGGL((vq_screen_f32_kernel<DT>), dim3(blocks), dim3(VQS_F32_WAVES * 64), SMEM, st, a);
+        hipLaunchKernelGGL((vq_screen_f32_kernel<DT, METRIC>), dim3(blocks), dim3(VQS_F32_WAVES * 64), SMEM, st, a);
     return vq_launch_status("vq_screen_kernel");
 }
 
+template <int DT>
+static int dispatch_screen(const ScreenArgs &a, int x_dtype, int metric, hipStream_t st)
+{
+    return metric == VQHIP_EUCLID ? launch_screen<DT, 0>(a, x_dtype, st) : launch_screen<DT, 1>(a, x_dtype, st);
+}
+
 extern "C" int vqhip_assign_screened(const void *x, int x_dtype, int64_t N, int D, int64_t ldx, const float *packed,
-                                     const float *embed, int C, int64_t *idx_out, void *q_out, int64_t ldq,
+                                     const float *embed, int C, int metric, int64_t *idx_out, void *q_out, int64_t ldq,
                                      void *resid_out, int64_t ldr, double *sqerr_partial, const uint8_t *row_mask,
                                      void *workspace, size_t workspace_bytes, float *debug_out, void *stream)
 {
@@ -638,6 +674,8 @@ extern "C" int vqhip_assign_screened(const void *x, int x_dtype, int64_t N, int 
     if (N == 0) return 0;
     if (!x || !packed || !embed || !idx_out || !workspace) VQ_FAIL(VQHIP_EINVAL, "assign_screened: null pointer");
     if (x_dtype != VQHIP_F32 && x_dtype != VQHIP_BF16) VQ_FAIL(VQHIP_EINVAL, "assign_screened: unknown x dtype %d", x_dtype);
+    if (metric != VQHIP_EUCLID && metric != VQHIP_COSINE_PRENORM)
+        VQ_FAIL(VQHIP_EINVAL, "assign_screened: metric %d (VQHIP_EUCLID, or VQHIP_COSINE_PRENORM on rows normalised by vqhip_l2norm_rows)", metric);
     if (!vqhip_screen_supported(N, D, C)) VQ_FAIL(VQHIP_EDIM, "assign_screened: N=%lld D=%d C=%d outside the screened path (D in {64,128,256}, C >= 2)", (long long)N, D, C);
     if (workspace_bytes < vqhip_screen_workspace_bytes(N)) VQ_FAIL(VQHIP_EINVAL, "assign_screened: workspace too small");
     if (ldx < D || (q_out && ldq < D) || (resid_out && ldr < D)) VQ_FAIL(VQHIP_EINVAL, "assign_screened: row stride smaller than D");
@@ -671,11 +709,11 @@ extern "C" int vqhip_assign_screened(const void *x, int x_dtype, int64_t N, int 
 #endif
     int rc;
     switch (D) {
-        case 64: rc = launch_screen<64>(a, x_dtype, st); break;
-        case 128: rc = launch_screen<128>(a, x_dtype, st); break;
-        default: rc = launch_screen<256>(a, x_dtype, st); break;
+        case 64: rc = dispatch_screen<64>(a, x_dtype, metric, st); break;
+        case 128: rc = dispatch_screen<128>(a, x_dtype, metric, st); break;
+        default: rc = dispatch_screen<256>(a, x_dtype, metric, st); break;
     }
     if (rc) return rc;
-    return vq_assign_listed(x, x_dtype, N, D, ldx, packed, embed, C, idx_out, q_out, ldq, resid_out, ldr,
+    return vq_assign_listed(x, x_dtype, metric, N, D, ldx, packed, embed, C, idx_out, q_out, ldq, resid_out, ldr,
                             sqerr_partial ? sqerr_partial + vqhip_screen_blocks(N, x_dtype) : nullptr, row_mask, rows, count, keys, st);
 }

@@ -826,6 +826,93 @@ static int assign_impl(const void *x, int x_dtype, int64_t N, int D, int64_t ldx
 }
 
 // ------------------------------------------------------------------------------------------------
+// l2norm of the rows (vqp.py:37-38 applied at :1159), in exactly the arithmetic vq_assign_kernel<.., COSINE> uses in its
+// prologue: ||x||^2 in ATen's order, x / max(||x||, 1e-6), for bf16 tensors norm and quotient rounded to bf16 as the
+// reference's bf16 ops do.  Lets the cosine metric run through the screened search (which takes unit-norm rows).
+// D == DT in {64, 128, 256}, vector-aligned rows.  32 rows per wave, same load layout as the assign kernels.
+// ------------------------------------------------------------------------------------------------
+template <int DT, bool XBF16>
+__global__ void __launch_bounds__(256) vq_l2norm_kernel(const void *x, int64_t N, int64_t ldx, void *out, int64_t ldo)
+{
+    constexpr int NG = DT / 8;
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int j = lane & 31;
+    const int hi = lane >> 5;
+    const int64_t row = (int64_t)blockIdx.x * 128 + wave * 32 + j;
+    const bool row_ok = row < N;
+    const int64_t rowc = row_ok ? row : (N - 1);
+    float xr[DT / 2];
+    if (XBF16) {
+        const uint2 *p = (const uint2 *)((const unsigned short *)x + rowc * ldx + 4 * hi);
+#pragma unroll
+        for (int m = 0; m < NG; ++m) {
+            const uint2 w = p[m * 2];
+            xr[4 * m + 0] = __uint_as_float(w.x << 16);
+            xr[4 * m + 1] = __uint_as_float(w.x & 0xffff0000u);
+            xr[4 * m + 2] = __uint_as_float(w.y << 16);
+            xr[4 * m + 3] = __uint_as_float(w.y & 0xffff0000u);
+        }
+    } else {
+        const f32x4 *p = (const f32x4 *)((const float *)x + rowc * ldx + 4 * hi);
+#pragma unroll
+        for (int m = 0; m < NG; ++m) {
+            const f32x4 w = p[m * 2];
+            xr[4 * m + 0] = w.x; xr[4 * m + 1] = w.y; xr[4 * m + 2] = w.z; xr[4 * m + 3] = w.w;
+        }
+    }
+    const float x2 = x2_aten_order<DT>(xr, j);
+    float nrm = sqrtf(x2);
+    if (XBF16) nrm = round_to_bf16(nrm);
+    nrm = fmaxf(nrm, XBF16 ? round_to_bf16(1e-6f) : 1e-6f);
+    if (!row_ok) return;
+#pragma unroll
+    for (int m = 0; m < NG; ++m) {
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            v[r] = xr[4 * m + r] / nrm;
+            if (XBF16) v[r] = round_to_bf16(v[r]);
+        }
+        if (XBF16) {
+            uint2 w;
+            w.x = (__float_as_uint(v[0]) >> 16) | (__float_as_uint(v[1]) & 0xffff0000u);
+            w.y = (__float_as_uint(v[2]) >> 16) | (__float_as_uint(v[3]) & 0xffff0000u);
+            *(uint2 *)((unsigned short *)out + row * ldo + 8 * m + 4 * hi) = w;
+        } else {
+            *(f32x4 *)((float *)out + row * ldo + 8 * m + 4 * hi) = f32x4{v[0], v[1], v[2], v[3]};
+        }
+    }
+}
+
+extern "C" int vqhip_l2norm_rows(const void *x, int x_dtype, int64_t N, int D, int64_t ldx, void *out, int64_t ldo, void *stream)
+{
+    if (N < 0) VQ_FAIL(VQHIP_EINVAL, "l2norm_rows: N < 0");
+    if (N == 0) return 0;
+    if (!x || !out) VQ_FAIL(VQHIP_EINVAL, "l2norm_rows: null pointer");
+    if (x_dtype != VQHIP_F32 && x_dtype != VQHIP_BF16) VQ_FAIL(VQHIP_EINVAL, "l2norm_rows: unknown dtype %d", x_dtype);
+    if (D != 64 && D != 128 && D != 256) VQ_FAIL(VQHIP_EDIM, "l2norm_rows: D=%d unsupported (64, 128, 256)", D);
+    const int es = (x_dtype == VQHIP_BF16) ? 2 : 4;
+    if (ldx < D || ldo < D) VQ_FAIL(VQHIP_EINVAL, "l2norm_rows: row stride smaller than D");
+    if ((((uintptr_t)x) % (4 * es)) || ((ldx * es) % (4 * es)) || (((uintptr_t)out) % (4 * es)) || ((ldo * es) % (4 * es)))
+        VQ_FAIL(VQHIP_EALIGN, "l2norm_rows: rows must be aligned to 4 elements");
+    const unsigned blocks = (unsigned)((N + 127) / 128);
+    hipStream_t st = (hipStream_t)stream;
+#define VQ_L2N(DTV)                                                                                                   \
+    do {                                                                                                              \
+        if (x_dtype == VQHIP_BF16) hipLaunchKernelGGL((vq_l2norm_kernel<DTV, true>), dim3(blocks), dim3(256), 0, st, x, N, ldx, out, ldo);  \
+        else hipLaunchKernelGGL((vq_l2norm_kernel<DTV, false>), dim3(blocks), dim3(256), 0, st, x, N, ldx, out, ldo); \
+    } while (0)
+    switch (D) {
+        case 64: VQ_L2N(64); break;
+        case 128: VQ_L2N(128); break;
+        default: VQ_L2N(256); break;
+    }
+#undef VQ_L2N
+    return launch_status("vq_l2norm_kernel");
+}
+
+// ------------------------------------------------------------------------------------------------
 // exact pass over a LIST of rows (the rows vq_screen.hip could not certify).  Same arithmetic as
 // vq_assign_kernel<DT, bf16, euclid> -- same device functions -- but organised for a short list: the codebook sweep
 // is split over gridDim.y workgroups per 128-row chunk (a few thousand rows would otherwise occupy a fraction of the
@@ -844,7 +931,7 @@ struct RefineArgs {
     unsigned long long *keys;   // [list capacity], preset to ~0
 };
 
-template <int DT, bool XBF16>
+template <int DT, bool XBF16, int METRIC>
 __global__ void __launch_bounds__(256, 2) vq_refine_kernel(const RefineArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -897,14 +984,14 @@ __global__ void __launch_bounds__(256, 2) vq_refine_kernel(const RefineArgs a)
                 xr[4 * m + 3] = w.w;
             }
         }
-        const float x2 = x2_aten_order<DT>(xr, j);
+        const float x2 = (METRIC == 0) ? x2_aten_order<DT>(xr, j) : 0.f;   // cosine (rows already unit-norm): raw dot products
 #pragma unroll
         for (int m = 0; m < NG; ++m) {   // -> MFMA B-operand layout
             swap32(xr[4 * m + 0], xr[4 * m + 1]);
             swap32(xr[4 * m + 2], xr[4 * m + 3]);
         }
 
-        float bd = INFINITY, bs = INFINITY;
+        float bd = (METRIC == 0) ? INFINITY : -INFINITY, bs = INFINITY;
         int bi = 0;
         for (int ct = ct0; ct < ct1; ++ct) {
             const int buf = (ct - ct0) & 1;
@@ -917,17 +1004,21 @@ __global__ void __launch_bounds__(256, 2) vq_refine_kernel(const RefineArgs a)
             const bool more = ct + 1 < ct1;
             mfma_sweep_tile<DT>(ap, xr, acc, (const char *)a.packed + (size_t)(more ? ct + 1 : ct) * TILE_B + piece_off,
                                 smem + (buf ^ 1) * TILE_B + piece_off, more ? my_pieces : 0);
-            argmin_tile<0>(acc, (const float *)tile + 32 * DT, x2, ct * 32, hi, a.C, bd, bs, bi);
+            argmin_tile<METRIC>(acc, (const float *)tile + 32 * DT, x2, ct * 32, hi, a.C, bd, bs, bi);
         }
         {
             const float od = __shfl_xor(bd, 32, 64);
             const int oi = __shfl_xor(bi, 32, 64);
-            const bool take = (od < bd) || (od == bd && oi < bi);
+            const bool take = (METRIC == 0) ? ((od < bd) || (od == bd && oi < bi)) : ((od > bd) || (od == bd && oi < bi));
             bd = take ? od : bd;
             bi = take ? oi : bi;
         }
+        // key order = (better score, then lower index): distances are >= 0, so their bit patterns order like the values;
+        // similarities go through the usual sign fix (monotone map to uint) and are inverted so that larger is smaller
+        unsigned hk = __float_as_uint(bd);
+        if (METRIC != 0) hk = ~(hk ^ ((hk >> 31) ? 0xffffffffu : 0x80000000u));
         if (row_ok && hi == 0)
-            atomicMin(a.keys + pos, ((unsigned long long)__float_as_uint(bd) << 32) | (unsigned long long)(unsigned)bi);
+            atomicMin(a.keys + pos, ((unsigned long long)hk << 32) | (unsigned long long)(unsigned)bi);
     }
 }
 
@@ -994,27 +1085,29 @@ __global__ void __launch_bounds__(256) vq_finish_listed_kernel(const FinishArgs 
     }
 }
 
-template <int DT, bool XBF16>
+template <int DT, bool XBF16, int METRIC>
 static int launch_refine(const RefineArgs &a, unsigned gx, unsigned gy, hipStream_t st)
 {
     constexpr int SMEM = 2 * (32 * DT + 256) * 4;
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void *)vq_refine_kernel<DT, XBF16>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+        hipError_t e = hipFuncSetAttribute((const void *)vq_refine_kernel<DT, XBF16, METRIC>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
         if (e != hipSuccess) VQ_FAIL((int)e, "hipFuncSetAttribute(refine<%d>): %s", DT, hipGetErrorString(e));
         attr_done = true;
     }
-    hipLaunchKernelGGL((vq_refine_kernel<DT, XBF16>), dim3(gx, gy), dim3(256), SMEM, st, a);
+    hipLaunchKernelGGL((vq_refine_kernel<DT, XBF16, METRIC>), dim3(gx, gy), dim3(256), SMEM, st, a);
     return launch_status("vq_refine_kernel");
 }
 
 template <int DT>
-static int dispatch_refine(const RefineArgs &a, int x_dtype, unsigned gx, unsigned gy, hipStream_t st)
+static int dispatch_refine(const RefineArgs &a, int x_dtype, int metric, unsigned gx, unsigned gy, hipStream_t st)
 {
-    return x_dtype == VQHIP_BF16 ? launch_refine<DT, true>(a, gx, gy, st) : launch_refine<DT, false>(a, gx, gy, st);
+    if (metric == VQHIP_EUCLID)
+        return x_dtype == VQHIP_BF16 ? launch_refine<DT, true, 0>(a, gx, gy, st) : launch_refine<DT, false, 0>(a, gx, gy, st);
+    return x_dtype == VQHIP_BF16 ? launch_refine<DT, true, 1>(a, gx, gy, st) : launch_refine<DT, false, 1>(a, gx, gy, st);
 }
 
-int vq_assign_listed(const void *x, int x_dtype, int64_t N, int D, int64_t ldx, const float *packed, const float *embed, int C,
+int vq_assign_listed(const void *x, int x_dtype, int metric, int64_t N, int D, int64_t ldx, const float *packed, const float *embed, int C,
                      int64_t *idx_out, void *q_out, int64_t ldq, void *resid_out, int64_t ldr, double *sqerr_partial,
                      const uint8_t *row_mask, const int *row_list, const int *row_count, unsigned long long *keys, hipStream_t st)
 {
@@ -1028,9 +1121,9 @@ int vq_assign_listed(const void *x, int x_dtype, int64_t N, int D, int64_t ldx, 
     splits = splits < 1 ? 1 : (splits > 8 ? 8 : splits);
     int rc;
     switch (pick_dt(D)) {
-        case 64: rc = dispatch_refine<64>(r, x_dtype, gx, (unsigned)splits, st); break;
-        case 128: rc = dispatch_refine<128>(r, x_dtype, gx, (unsigned)splits, st); break;
-        case 256: rc = dispatch_refine<256>(r, x_dtype, gx, (unsigned)splits, st); break;
+        case 64: rc = dispatch_refine<64>(r, x_dtype, metric, gx, (unsigned)splits, st); break;
+        case 128: rc = dispatch_refine<128>(r, x_dtype, metric, gx, (unsigned)splits, st); break;
+        case 256: rc = dispatch_refine<256>(r, x_dtype, metric, gx, (unsigned)splits, st); break;
         default: VQ_FAIL(VQHIP_EDIM, "assign_listed: D=%d unsupported", D);
     }
     if (rc) return rc;

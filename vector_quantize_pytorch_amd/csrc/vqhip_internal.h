@@ -72,10 +72,11 @@ static inline size_t vq_packed_scalars_offset(int C, int D)
 }
 
 // exact fp32-MFMA assignment (vqhip.hip) restricted to the rows listed in row_list[0 .. *row_count), both on the
-// device; x and q share a dtype (fp32 / bf16) with D == DT and vector-aligned rows, Euclidean metric.  keys: N u64, entries
+// device; x and q share a dtype (fp32 / bf16) with D == DT and vector-aligned rows; metric VQHIP_EUCLID or
+// VQHIP_COSINE_PRENORM.  keys: N u64, entries
 // [0 .. *row_count) preset to ~0 by the list builder.
 // sqerr_partial (nullable) receives VQ_FINISH_BLOCKS entries.
 #define VQ_FINISH_BLOCKS 512
-int vq_assign_listed(const void *x, int x_dtype, int64_t N, int D, int64_t ldx, const float *packed, const float *embed, int C,
+int vq_assign_listed(const void *x, int x_dtype, int metric, int64_t N, int D, int64_t ldx, const float *packed, const float *embed, int C,
                      int64_t *idx_out, void *q_out, int64_t ldq, void *resid_out, int64_t ldr, double *sqerr_partial,
                      const uint8_t *row_mask, const int *row_list, const int *row_count, unsigned long long *keys, hipStream_t st);
