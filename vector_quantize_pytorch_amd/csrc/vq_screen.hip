@@ -39,6 +39,9 @@ typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 #define VQS_PF 4             // depth of the A-fragment ring (LDS -> VGPR prefetch distance in steps of 2 MFMAs)
 #define VQS_PIN 1
 #endif
+#ifndef VQS_OUT1
+#define VQS_OUT2 1           // output phase ordering (see below); -DVQS_OUT1 selects the first version for A/B runs
+#endif
 #ifndef VQS_WAVES
 #define VQS_WAVES 4          // waves per workgroup (2 workgroups of 4 or 1 of 8 per CU: 2 waves per SIMD either way)
 #endif
@@ -297,6 +300,60 @@ __global__ void __launch_bounds__(VQS_WAVES * 64, 8 / VQS_WAVES) vq_screen_kerne
     //      their latency hides behind the q copy; q = bf16 codebook rows written as whole rows, 16 rows in flight;
     //      squared error of the certified rows from the registers (the listed rows are counted by the exact pass) ----
     double ds = 0.0;
+#ifdef VQS_OUT2
+    if (!a.resid_out) {
+        // loss(rb 0) -> [q rows of rb 0, 32 in flight || loss operands of rb 1] -> loss(rb 1) -> q rows of rb 1, 32 in flight:
+        // three load round trips, no batch waits for the previous batch's stores (its registers are not reused)
+        auto loss_of = [&](int rb, const uint4 (&gq)[NK]) {
+            f32x2 ls = {0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < NK; ++ks) {
+                const unsigned gw[4] = {gq[ks].x, gq[ks].y, gq[ks].z, gq[ks].w};
+                const unsigned xw[4] = {xb[rb][ks].x, xb[rb][ks].y, xb[rb][ks].z, xb[rb][ks].w};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x2 gv = {__uint_as_float(gw[q] << 16), __uint_as_float(gw[q] & 0xffff0000u)};
+                    const f32x2 xv = {__uint_as_float(xw[q] << 16), __uint_as_float(xw[q] & 0xffff0000u)};
+                    const f32x2 df = gv - xv;
+                    ls = __builtin_elementwise_fma(df, df, ls);
+                }
+            }
+            const bool counted = row_ok[rb] && !flagged[rb] && (!a.row_mask || a.row_mask[rows[rb]] != 0);
+            ds += counted ? (double)(ls[0] + ls[1]) : 0.0;
+        };
+        uint4 gq0[NK], gq1[NK];
+        if (a.sqerr_partial) {
+            const unsigned short *er = a.embed_bf16 + (size_t)code[0] * DT + 8 * half;
+#pragma unroll
+            for (int ks = 0; ks < NK; ++ks) gq0[ks] = *(const uint4 *)(er + ks * 16);
+            loss_of(0, gq0);
+            __builtin_amdgcn_sched_barrier(0);
+            const unsigned short *er1 = a.embed_bf16 + (size_t)code[1] * DT + 8 * half;
+#pragma unroll
+            for (int ks = 0; ks < NK; ++ks) gq1[ks] = *(const uint4 *)(er1 + ks * 16);
+        }
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) {
+            if (a.q_out) {
+                uint2 g[32];
+#pragma unroll
+                for (int u = 0; u < 32; ++u) {
+                    const int c = __builtin_amdgcn_readlane(code[rb], u);
+                    if (lane * 4 < DT) g[u] = *(const uint2 *)(a.embed_bf16 + (size_t)c * DT + lane * 4);
+                }
+#pragma unroll
+                for (int u = 0; u < 32; ++u) {
+                    const int64_t rr = wrow0 + rb * 32 + u;
+                    if (rr < a.N && lane * 4 < DT) *(uint2 *)((unsigned short *)a.q_out + rr * a.ldq + lane * 4) = g[u];
+                }
+            }
+            if (rb == 0 && a.sqerr_partial) {
+                loss_of(1, gq1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    } else
+#endif
 #pragma unroll
     for (int rb = 0; rb < 2; ++rb) {
         uint4 gq[NK];
