@@ -201,7 +201,10 @@ def main():
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                          "traffic": traffic, "kernel_ms": k_ms, "algorithmic_flops_per_launch": flops,
                          "algorithmic_bytes_per_launch": n_vec * 1032 + C * D * 4,
-                         "achieved_vs_fp32_mfma_peak": achieved / PEAK_FP32_MFMA_TFLOPS},
+                         "achieved_vs_fp32_mfma_peak": achieved / PEAK_FP32_MFMA_TFLOPS,
+                         "note": ("achieved counts algorithmic flops (2*C*D per vector); the screen executes 2x that on the bf16 "
+                                  "MFMA pipe (hi + lo codebook part), MFMA pipes 53 % busy per PMC (profiles/r1_screen)") if screened else
+                                 "exact fp32-MFMA search (VQHIP_SCREEN=0)"},
         }
         if screened and exact_rows:
             out["roofline"]["rows_exact_pass_frac"] = float(torch.stack(exact_rows).double().mean().item()) / n_vec

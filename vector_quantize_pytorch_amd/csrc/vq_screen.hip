@@ -224,7 +224,13 @@ __global__ void __launch_bounds__(VQS_WAVES * 64, 8 / VQS_WAVES) vq_screen_kerne
 #ifdef VQS_PIN
             __builtin_amdgcn_sched_barrier(0);   // keep the prefetch distance: hipcc otherwise sinks the ds_reads next to their use
 #endif
-#ifndef VQS_NO_STAGE
+#ifdef VQS_GLDS
+            // LDS-DMA variant: piece s of this wave's share goes L2 -> LDS directly (no staging registers, no ds_write);
+            // the wave waits for its DMAs at the end of the tile, before the barrier that publishes the buffer
+            if (s < PMAX && s < npieces)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gsrc + (size_t)s * PSTRIDE),
+                                                 (__attribute__((address_space(3))) void *)(ldst - lane * 16 + s * PSTRIDE), 16, 0, 0);
+#elif !defined(VQS_NO_STAGE)
 #pragma unroll
             for (int b = 0; b < NB; ++b) {
                 if (s == b * HALF) {
@@ -244,6 +250,9 @@ __global__ void __launch_bounds__(VQS_WAVES * 64, 8 / VQS_WAVES) vq_screen_kerne
             }
 #endif
         }
+#ifdef VQS_GLDS
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
         VQ_STAMP(2);
 #ifndef VQS_NO_EPI
         top2_tile(acc0, m1[0], m2[0], tix[0], ct);
