@@ -314,6 +314,8 @@ def _screen_case(N, C, D, kind, seed=0, dtype=torch.bfloat16):
     (8192, 1024, 256, "tiny"),
     (1000, 2, 64, "unit"),
     (3000, 4096, 128, "kaiming"),    # cfg 5 per-group shape
+    (5000, 8192, 32, "unit"),        # low-dimensional codebook (codebook_dim = 32)
+    (2500, 100, 32, "rows"),
 ])
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
 def test_screened_assign_matches_chain_oracle(dev, N, C, D, kind, dtype):
@@ -321,7 +323,7 @@ def test_screened_assign_matches_chain_oracle(dev, N, C, D, kind, dtype):
     x, e = _screen_case(N, C, D, kind, dtype=dtype)
     xd, ed = x.to(dev), e.to(dev)
     r = L.assign(xd, L.pack_codebook(ed), ed, want_q=True, want_sqerr=True)
-    assert r.get("n_exact") is not None, "rows with D in {64,128,256} must take the screened path"
+    assert r.get("n_exact") is not None, "rows with D in {32,64,128,256} must take the screened path"
     idx_o, _ = O.c_assign(x.float(), e)
     mism = (r["idx"].cpu() != idx_o).sum().item()
     assert mism == 0, f"{mism}/{N} index mismatches vs chain oracle"
@@ -433,7 +435,7 @@ def _l2norm_ref(x):
 
 
 @pytest.mark.parametrize("N,D,dtype", [(4099, 256, torch.bfloat16), (1000, 128, torch.float32), (333, 64, torch.bfloat16),
-                                       (2048, 256, torch.float32)])
+                                       (2048, 256, torch.float32), (700, 32, torch.bfloat16), (700, 32, torch.float32)])
 def test_l2norm_rows_matches_reference_arithmetic(dev, N, D, dtype):
     from vector_quantize_pytorch_amd import _lib as L
     g = torch.Generator().manual_seed(2)
@@ -443,7 +445,7 @@ def test_l2norm_rows_matches_reference_arithmetic(dev, N, D, dtype):
 
 
 @pytest.mark.parametrize("N,C,D,kind", [(4099, 1024, 256, "unit"), (5000, 1000, 128, "unit"), (3000, 37, 64, "unit"),
-                                        (8192, 1024, 256, "dups")])
+                                        (8192, 1024, 256, "dups"), (4000, 2048, 32, "unit")])
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
 def test_screened_cosine_matches_chain_oracle(dev, N, C, D, kind, dtype):
     """cosine metric through the screen: l2norm_rows + screened search on unit-norm rows == the exact cosine kernel's

@@ -98,6 +98,12 @@ def main():
     cases = [(4096, 1024, 256, "kaiming"), (5000, 1000, 256, "randn"), (300, 37, 128, "randn"), (70000, 512, 64, "rows"),
              (65536, 1024, 256, "rows"), (65536, 1024, 256, "dups"), (65536, 1024, 256, "tiny"), (1000, 2, 64, "randn"),
              (33333, 4096, 128, "kaiming")]
+    if "--d32" in sys.argv:      # low-dimensional codebooks: timing + agreement only
+        for dtype in (torch.bfloat16, torch.float32):
+            ok &= check(1 << 20, 8192, 32, "randn", gen, timing=True, dtype=dtype)
+            ok &= check(1 << 20, 1024, 64, "randn", gen, timing=True, dtype=dtype)
+        print("ALL OK" if ok else "FAILURES", flush=True)
+        sys.exit(0 if ok else 1)
     only_cos = "--cosine" in sys.argv
     for cosine in ((True,) if only_cos else (False, True)):
         for dtype in (torch.bfloat16, torch.float32):

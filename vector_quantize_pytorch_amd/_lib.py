@@ -242,7 +242,7 @@ def screen_supported(x: torch.Tensor, C: int) -> bool:
 
 
 def l2norm_rows(x: torch.Tensor) -> torch.Tensor:
-    """x / max(||x||, 1e-6) row-wise in the reference's arithmetic (vqp.py:37-38 at :1159); D in {64, 128, 256}."""
+    """x / max(||x||, 1e-6) row-wise in the reference's arithmetic (vqp.py:37-38 at :1159); D in {32, 64, 128, 256}."""
     _need_gpu(x)
     xk, N, D, ldx = as_rows(x)
     out = torch.empty(*x.shape, dtype=x.dtype, device=x.device)

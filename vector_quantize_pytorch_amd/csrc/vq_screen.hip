@@ -213,7 +213,7 @@ __global__ void __launch_bounds__(VQS_WAVES * 64, 8 / VQS_WAVES) vq_screen_kerne
         f32x4 stg[BS];
         uint4 af[VQS_PF];   // A-fragment ring: the ds_read of step s + VQS_PF is issued behind the MFMAs of step s
 #pragma unroll
-        for (int p = 0; p < VQS_PF; ++p) af[p] = ap[p * 64];
+        for (int p = 0; p < VQS_PF; ++p) af[p] = ap[(p < STEPS ? p : 0) * 64];
 #pragma unroll
         for (int s = 0; s < STEPS; ++s) {
             const int ks = s >> 1;
@@ -547,7 +547,7 @@ __global__ void __launch_bounds__(VQS_F32_WAVES * 64, 8 / VQS_F32_WAVES) vq_scre
         f32x4 stg[BS];
         uint4 af[VQS_PF];
 #pragma unroll
-        for (int p = 0; p < VQS_PF; ++p) af[p] = ap[p * 64];
+        for (int p = 0; p < VQS_PF; ++p) af[p] = ap[(p < STEPS ? p : 0) * 64];
 #pragma unroll
         for (int s = 0; s < STEPS; ++s) {
             const int ks = s >> 1;
@@ -702,7 +702,7 @@ extern "C" size_t vqhip_screen_workspace_bytes(int64_t N)
 
 extern "C" int vqhip_screen_supported(int64_t N, int D, int C)
 {
-    return (D == 64 || D == 128 || D == 256) && N > 0 && N < ((int64_t)1 << 31) - 512 && C >= 2;
+    return (D == 32 || D == 64 || D == 128 || D == 256) && N > 0 && N < ((int64_t)1 << 31) - 512 && C >= 2;
 }
 
 template <int DT, int METRIC>
@@ -742,7 +742,7 @@ extern "C" int vqhip_assign_screened(const void *x, int x_dtype, int64_t N, int 
     if (x_dtype != VQHIP_F32 && x_dtype != VQHIP_BF16) VQ_FAIL(VQHIP_EINVAL, "assign_screened: unknown x dtype %d", x_dtype);
     if (metric != VQHIP_EUCLID && metric != VQHIP_COSINE_PRENORM)
         VQ_FAIL(VQHIP_EINVAL, "assign_screened: metric %d (VQHIP_EUCLID, or VQHIP_COSINE_PRENORM on rows normalised by vqhip_l2norm_rows)", metric);
-    if (!vqhip_screen_supported(N, D, C)) VQ_FAIL(VQHIP_EDIM, "assign_screened: N=%lld D=%d C=%d outside the screened path (D in {64,128,256}, C >= 2)", (long long)N, D, C);
+    if (!vqhip_screen_supported(N, D, C)) VQ_FAIL(VQHIP_EDIM, "assign_screened: N=%lld D=%d C=%d outside the screened path (D in {32,64,128,256}, C >= 2)", (long long)N, D, C);
     if (workspace_bytes < vqhip_screen_workspace_bytes(N)) VQ_FAIL(VQHIP_EINVAL, "assign_screened: workspace too small");
     if (ldx < D || (q_out && ldq < D) || (resid_out && ldr < D)) VQ_FAIL(VQHIP_EINVAL, "assign_screened: row stride smaller than D");
     const int es = (x_dtype == VQHIP_BF16) ? 2 : 4;
@@ -775,6 +775,7 @@ extern "C" int vqhip_assign_screened(const void *x, int x_dtype, int64_t N, int 
 #endif
     int rc;
     switch (D) {
+        case 32: rc = dispatch_screen<32>(a, x_dtype, metric, st); break;
         case 64: rc = dispatch_screen<64>(a, x_dtype, metric, st); break;
         case 128: rc = dispatch_screen<128>(a, x_dtype, metric, st); break;
         default: rc = dispatch_screen<256>(a, x_dtype, metric, st); break;

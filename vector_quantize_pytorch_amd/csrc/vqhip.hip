@@ -829,7 +829,7 @@ static int assign_impl(const void *x, int x_dtype, int64_t N, int D, int64_t ldx
 // l2norm of the rows (vqp.py:37-38 applied at :1159), in exactly the arithmetic vq_assign_kernel<.., COSINE> uses in its
 // prologue: ||x||^2 in ATen's order, x / max(||x||, 1e-6), for bf16 tensors norm and quotient rounded to bf16 as the
 // reference's bf16 ops do.  Lets the cosine metric run through the screened search (which takes unit-norm rows).
-// D == DT in {64, 128, 256}, vector-aligned rows.  32 rows per wave, same load layout as the assign kernels.
+// D == DT in {32, 64, 128, 256}, vector-aligned rows.  32 rows per wave, same load layout as the assign kernels.
 // ------------------------------------------------------------------------------------------------
 template <int DT, bool XBF16>
 __global__ void __launch_bounds__(256) vq_l2norm_kernel(const void *x, int64_t N, int64_t ldx, void *out, int64_t ldo)
@@ -891,7 +891,7 @@ extern "C" int vqhip_l2norm_rows(const void *x, int x_dtype, int64_t N, int D, i
     if (N == 0) return 0;
     if (!x || !out) VQ_FAIL(VQHIP_EINVAL, "l2norm_rows: null pointer");
     if (x_dtype != VQHIP_F32 && x_dtype != VQHIP_BF16) VQ_FAIL(VQHIP_EINVAL, "l2norm_rows: unknown dtype %d", x_dtype);
-    if (D != 64 && D != 128 && D != 256) VQ_FAIL(VQHIP_EDIM, "l2norm_rows: D=%d unsupported (64, 128, 256)", D);
+    if (D != 32 && D != 64 && D != 128 && D != 256) VQ_FAIL(VQHIP_EDIM, "l2norm_rows: D=%d unsupported (32, 64, 128, 256)", D);
     const int es = (x_dtype == VQHIP_BF16) ? 2 : 4;
     if (ldx < D || ldo < D) VQ_FAIL(VQHIP_EINVAL, "l2norm_rows: row stride smaller than D");
     if ((((uintptr_t)x) % (4 * es)) || ((ldx * es) % (4 * es)) || (((uintptr_t)out) % (4 * es)) || ((ldo * es) % (4 * es)))
@@ -904,6 +904,7 @@ extern "C" int vqhip_l2norm_rows(const void *x, int x_dtype, int64_t N, int D, i
         else hipLaunchKernelGGL((vq_l2norm_kernel<DTV, false>), dim3(blocks), dim3(256), 0, st, x, N, ldx, out, ldo); \
     } while (0)
     switch (D) {
+        case 32: VQ_L2N(32); break;
         case 64: VQ_L2N(64); break;
         case 128: VQ_L2N(128); break;
         default: VQ_L2N(256); break;
@@ -1121,6 +1122,7 @@ int vq_assign_listed(const void *x, int x_dtype, int metric, int64_t N, int D, i
     splits = splits < 1 ? 1 : (splits > 8 ? 8 : splits);
     int rc;
     switch (pick_dt(D)) {
+        case 32: rc = dispatch_refine<32>(r, x_dtype, metric, gx, (unsigned)splits, st); break;
         case 64: rc = dispatch_refine<64>(r, x_dtype, metric, gx, (unsigned)splits, st); break;
         case 128: rc = dispatch_refine<128>(r, x_dtype, metric, gx, (unsigned)splits, st); break;
         case 256: rc = dispatch_refine<256>(r, x_dtype, metric, gx, (unsigned)splits, st); break;

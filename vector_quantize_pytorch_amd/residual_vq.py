@@ -218,9 +218,9 @@ class ResidualVQ(nn.Module):
         update = train and not (freeze_codebook or vq0.freeze_codebook) and \
             (vq0._codebook.ema_update or vq0._codebook.has_dead_code_replacement)
         want_loss = train and vq0.has_commitment_loss
-        if L.screening_enabled() and D in (64, 128, 256) and x.data_ptr() % 16 == 0:
+        if L.screening_enabled() and D in (32, 64, 128, 256) and x.data_ptr() % 16 == 0:
             # Q screened searches on the bf16 MFMA pipe (csrc/vq_screen.hip), each writing the next stage's input; beats
-            # the fused exact-fp32 kernel, which keeps the dims the screen does not cover (32, 96, ..., 512)
+            # the fused exact-fp32 kernel, which keeps the dims the screen does not cover (96, 160, ..., 512)
             r = L.rvq_forward_screened(x, packed, embed, Q, want_resid=update, want_sqerr=want_loss, row_mask=mask)
         else:
             r = L.rvq_forward(x, packed, embed, Q, want_resid=update, want_sqerr=want_loss, row_mask=mask)
