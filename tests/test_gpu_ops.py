@@ -469,3 +469,27 @@ def test_screened_cosine_matches_chain_oracle(dev, N, C, D, kind, dtype):
     assert abs(sq - want_sq) <= 1e-5 * max(want_sq, 1e-12)
     if kind == "dups":
         assert int(r["n_exact"].item()) == N
+
+
+def test_screened_large_codebook_and_nonfinite_rows(dev, monkeypatch):
+    """C = 65536 (2048 tiles, many near-ties) and rows containing NaN / inf: the screened path must return exactly what
+    the exact kernel returns (non-finite rows are never certified and fall to the exact pass)."""
+    from vector_quantize_pytorch_amd import _lib as L
+    g = torch.Generator().manual_seed(9)
+    N, C, D = 3000, 65536, 128
+    x = torch.randn(N, D, generator=g).bfloat16()
+    x[7, 3] = float("nan")
+    x[100, :] = float("inf")
+    x[200, 5] = -float("inf")
+    e = torch.randn(C, D, generator=g) * 0.3
+    xd, ed = x.to(dev), e.to(dev)
+    packed = L.pack_codebook(ed)
+    r1 = L.assign(xd, packed, ed, want_q=True)
+    assert r1.get("n_exact") is not None
+    monkeypatch.setenv("VQHIP_SCREEN", "0")
+    r0 = L.assign(xd, packed, ed, want_q=True)
+    assert r0.get("n_exact") is None
+    assert torch.equal(r0["idx"], r1["idx"]) and torch.equal(r0["q"], r1["q"])
+    fin = torch.isfinite(x.float()).all(-1)
+    idx_o, _ = O.c_assign(x.float()[fin], e)
+    assert torch.equal(r1["idx"].cpu()[fin], idx_o)
