@@ -493,3 +493,18 @@ def test_screened_large_codebook_and_nonfinite_rows(dev, monkeypatch):
     fin = torch.isfinite(x.float()).all(-1)
     idx_o, _ = O.c_assign(x.float()[fin], e)
     assert torch.equal(r1["idx"].cpu()[fin], idx_o)
+
+
+def test_screen_verify_switch(dev, monkeypatch):
+    """VQHIP_SCREEN_VERIFY=1 re-runs the exact kernel behind every screened search and raises on any disagreement."""
+    from vector_quantize_pytorch_amd import _lib as L
+    monkeypatch.setenv("VQHIP_SCREEN_VERIFY", "1")
+    for dtype, cos in ((torch.bfloat16, False), (torch.float32, False), (torch.bfloat16, True)):
+        x, e = _screen_case(5000, 1024, 128, "kaiming" if not cos else "unit", seed=13, dtype=dtype)
+        xd = x.to(dev)
+        if cos:
+            e = O.l2norm(e)
+            xd = L.l2norm_rows(xd)
+        ed = e.to(dev)
+        r = L.assign(xd, L.pack_codebook(ed), ed, cosine=cos, skip_l2norm=cos)
+        assert r.get("n_exact") is not None

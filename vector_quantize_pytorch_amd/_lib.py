@@ -200,6 +200,17 @@ def assign(x: torch.Tensor, packed: torch.Tensor, embed2d: torch.Tensor, *, cosi
                                            COSINE_PRENORM if cosine else EUCLID, _ptr(idx), _ptr(q), ldq,
                                            _ptr(rk), ldr, _ptr(partials), _ptr(row_mask), _ptr(ws), nws, _ptr(dbg), _stream()),
                "vqhip_assign_screened")
+        if os.environ.get("VQHIP_SCREEN_VERIFY", "0") == "1":
+            # paranoia switch: run the exact fp32-MFMA kernel on the same input as well and insist on identical indices
+            # (costs the exact kernel's time plus a host sync; meant for validating the certification on one's own data)
+            chk = torch.empty_like(idx)
+            rn = torch.empty(lead, dtype=torch.float32, device=dev) if cosine else None
+            _check(lib().vqhip_assign(_ptr(xk), _dtype_code(xk), N, D, ldx, _ptr(packed), _ptr(embed2d), C,
+                                      COSINE_PRENORM if cosine else EUCLID, _ptr(chk), None, _dtype_code(x), ldq,
+                                      None, _ptr(rn), None, None, _stream()), "vqhip_assign (verify)")
+            bad = int((chk != idx).sum().item())
+            if bad:
+                raise VQHipError(f"VQHIP_SCREEN_VERIFY: screened and exact search disagree on {bad} of {N} rows")
         return dict(idx=idx, q=q, sqerr_partials=partials, best=None, rnorm=None, nblk=nblk, n_exact=ws[:1], screen_debug=dbg)
     need_rn = want_rnorm or cosine or (D % 32 != 0)
     rnorm = torch.empty(lead, dtype=torch.float32, device=dev) if need_rn else None
