@@ -114,10 +114,17 @@ __global__ void __launch_bounds__(VQS_WAVES * 64, 8 / VQS_WAVES) vq_screen_kerne
     constexpr int NK = DT / 16;                    // MFMA k-steps
     constexpr int STEPS = 2 * NK;                  // (k-step, hi/lo part) pairs, 2 MFMAs each
     constexpr int PMAX = (NCHUNK + VQS_WAVES - 1) / VQS_WAVES;   // pieces per wave
-    constexpr int NB = 2;                          // staging batches
+#ifndef VQS_NB
+#define VQS_NB 2
+#endif
+    constexpr int NB = (STEPS >= 2 * VQS_NB) ? VQS_NB : 2;   // staging batches
     constexpr int BS = (PMAX + NB - 1) / NB;
-    constexpr int HALF = STEPS / 2;
+    constexpr int HALF = STEPS / NB;               // steps between batch starts
+#ifdef VQS_LAGM
+    constexpr int LAG = (HALF > VQS_LAGM + 1) ? HALF - VQS_LAGM : 1;
+#else
     constexpr int LAG = (HALF > 3) ? HALF - 2 : 1; // steps between a batch's loads and its LDS stores
+#endif
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
