@@ -504,3 +504,34 @@ def test_diveq_residual_vq(dev):
     assert torch.allclose((out - x).norm(dim=-1), (qb - x).norm(dim=-1), rtol=1e-4, atol=1e-5)
     out.pow(2).sum().backward()
     assert all(l._codebook.embed.grad is not None and torch.isfinite(l._codebook.embed.grad).all() for l in a.layers)
+
+
+def test_train_step_is_hip_graph_capturable(dev):
+    """The whole train step (search + EMA update) runs without host synchronisation on the current stream, so it can be
+    captured in a HIP graph (torch.cuda.CUDAGraph) and replayed: same outputs and same codebook as eager execution."""
+    from vector_quantize_pytorch_amd import VectorQuantize
+    torch.manual_seed(0)
+    vq_e = VectorQuantize(dim=128, codebook_size=512).to(dev).train()
+    vq_g = VectorQuantize(dim=128, codebook_size=512).to(dev).train()
+    vq_g.load_state_dict(vq_e.state_dict())
+    xs = [torch.randn(4, 2048, 128, device=dev).bfloat16() for _ in range(4)]
+    static_x = xs[0].clone()
+    with torch.no_grad():
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):                     # one eager step outside the graph on both modules: first-use
+            vq_g(static_x)                             # attribute calls, the allocator, and the cached `initted` flag
+            vq_e(static_x)                             # (its first read is a host sync, vqp.py:703)
+        torch.cuda.current_stream().wait_stream(s)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            out_g = vq_g(static_x)
+        # the capture itself does not execute: replay once per input
+        for x in xs:
+            static_x.copy_(x)
+            g.replay()
+            q_e, idx_e, loss_e = vq_e(x)
+            assert torch.equal(out_g[1], idx_e) and torch.equal(out_g[0], q_e)
+            assert abs(out_g[2].item() - loss_e.item()) <= 1e-6 * abs(loss_e.item())
+    for k in ("embed", "cluster_size", "embed_avg"):
+        assert torch.allclose(getattr(vq_g._codebook, k), getattr(vq_e._codebook, k), rtol=1e-5, atol=1e-7), k
