@@ -1997,6 +1997,10 @@ extern "C" int vqhip_ema_finalize(float *cluster_size, float *embed_avg, float *
 // ------------------------------------------------------------------------------------------------
 // decode: out[n,:] = sum_q embed_q[idx[n,q],:]   (sequential in q, like the reference's running sum)
 // ------------------------------------------------------------------------------------------------
+// one wave per output row.  The Q indices of a row are fetched first, then the code rows of 8 stages at a time are all
+// requested before any is added (the first version chained index load -> row load -> add per stage: latency bound at
+// 1.1 TB/s of output); the adds keep the stage order, so the result is the same running sum as rvq.py:525.
+template <bool VEC>
 __global__ void __launch_bounds__(256) vq_decode_kernel(const int64_t *__restrict__ idx, int64_t N, int Q,
                                                         const float *__restrict__ embed, int64_t qstride, int C, int D,
                                                         void *out, int out_bf16, int64_t ldo)
@@ -2004,6 +2008,46 @@ __global__ void __launch_bounds__(256) vq_decode_kernel(const int64_t *__restric
     const int lane = threadIdx.x & 63;
     const int64_t n = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (n >= N) return;
+    constexpr int U = 8;
+    if (VEC) {                      // D % 4 == 0, 16-byte aligned rows: lane owns columns 4 lane + 256 h .. +3
+        f32x4 s[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+        for (int q0 = 0; q0 < Q; q0 += U) {
+            int64_t c[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) c[u] = (q0 + u < Q) ? idx[n * Q + q0 + u] : -1;
+            f32x4 v[U][2];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const bool ok = c[u] >= 0 && c[u] < C;
+                const float *r = embed + (size_t)(q0 + u < Q ? q0 + u : 0) * qstride + (size_t)(ok ? c[u] : 0) * D;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int d = lane * 4 + 256 * h;
+                    v[u][h] = (ok && d < D) ? *(const f32x4 *)(r + d) : f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const bool ok = c[u] >= 0 && c[u] < C;      // a skipped stage adds nothing (not even +0 to a -0)
+                if (ok) { s[0] += v[u][0]; s[1] += v[u][1]; }
+            }
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int d = lane * 4 + 256 * h;
+            if (d < D) {
+                if (out_bf16) {
+                    uint2 w;
+                    w.x = (unsigned)f32_to_bf16_rne(s[h].x) | ((unsigned)f32_to_bf16_rne(s[h].y) << 16);
+                    w.y = (unsigned)f32_to_bf16_rne(s[h].z) | ((unsigned)f32_to_bf16_rne(s[h].w) << 16);
+                    *(uint2 *)((unsigned short *)out + n * ldo + d) = w;
+                } else {
+                    *(f32x4 *)((float *)out + n * ldo + d) = s[h];
+                }
+            }
+        }
+        return;
+    }
     float s[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) s[u] = 0.f;
@@ -2035,7 +2079,14 @@ extern "C" int vqhip_decode_sum(const int64_t *idx, int64_t N, int Q, const floa
     if (!idx || !embed || !out) VQ_FAIL(VQHIP_EINVAL, "decode_sum: null pointer");
     if (D < 1 || D > 512) VQ_FAIL(VQHIP_EDIM, "decode_sum: D=%d unsupported (1..512)", D);
     if (out_dtype != VQHIP_F32 && out_dtype != VQHIP_BF16) VQ_FAIL(VQHIP_EINVAL, "decode_sum: unknown dtype");
-    hipLaunchKernelGGL(vq_decode_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, (hipStream_t)stream, idx, N, Q, embed,
-                       embed_qstride, C, D, out, out_dtype == VQHIP_BF16, ldo);
+    const int oes = (out_dtype == VQHIP_BF16) ? 2 : 4;
+    const bool vec = (D % 4 == 0) && (embed_qstride % 4 == 0) && ((((uintptr_t)embed) & 15) == 0) &&
+                     ((((uintptr_t)out) % (4 * oes)) == 0) && ((ldo * oes) % (4 * oes) == 0);
+    if (vec)
+        hipLaunchKernelGGL(vq_decode_kernel<true>, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, (hipStream_t)stream, idx, N, Q, embed,
+                           embed_qstride, C, D, out, out_dtype == VQHIP_BF16, ldo);
+    else
+        hipLaunchKernelGGL(vq_decode_kernel<false>, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, (hipStream_t)stream, idx, N, Q, embed,
+                           embed_qstride, C, D, out, out_dtype == VQHIP_BF16, ldo);
     return launch_status("vq_decode_kernel");
 }
