@@ -1583,7 +1583,9 @@ extern "C" int vqhip_reduce_partials(const double *partials, int64_t n, double s
 #define VQ_SEG_CH 256          // rows per segmented-sum work item
 #endif
 #define VQ_HIST_LDS_MAX 16384  // codes whose histogram fits the LDS path (64 KiB)
+#ifndef VQ_SORT_ROWS_PER_BLOCK
 #define VQ_SORT_ROWS_PER_BLOCK 4096
+#endif
 
 struct SortArgs {
     const int64_t *idx;
