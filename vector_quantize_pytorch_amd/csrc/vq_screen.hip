@@ -1,8 +1,9 @@
-// vq_screen.hip -- screened nearest-code assignment for bf16 inputs (Euclidean), gfx950 only.
+// vq_screen.hip -- screened nearest-code assignment, gfx950 only.  D in {32, 64, 128, 256}; bf16 rows (vq_screen_kernel)
+// and fp32 rows (vq_screen_f32_kernel, further down); Euclidean metric, or cosine on unit-norm rows (METRIC 1).
 //
 // The exact kernel (vqhip.hip, vq_assign_kernel) evaluates the reference's cdist (vqp.py:58-62) bit for bit on the
-// fp32 MFMA pipe, which runs at 1/16 of the bf16 MFMA rate.  For bf16 inputs the same INDICES can be had much
-// cheaper, still exactly:
+// fp32 MFMA pipe, which runs at 1/16 of the bf16 MFMA rate.  The same INDICES can be had much cheaper, still exactly
+// (described for bf16 rows and the Euclidean metric; the other variants state their differences where they are defined):
 //
 //   1. screen (this file): bf16 rows are exact MFMA operands; the fp32 codebook is split c = c_hi + c_lo into two
 //      bf16 parts (bf16 keeps 8 significant bits: |c - c_hi - c_lo| <= 2^-16 |c|) and  t[n, c] = x_n . c_hi + x_n . c_lo - ||c||^2 / 2  is
