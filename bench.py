@@ -1,18 +1,27 @@
 #!/usr/bin/env python
 """bench.py -- BASELINE.json's headline metric on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--workload ...]
 
-A "step" is one training forward of the hot path (codebook pack + fused fp32-MFMA assign/gather/loss +
-EMA statistics + EMA fold) over one synthetic batch already resident in HBM.  At N = 1 the workload is
-BASELINE config[1]: VectorQuantize(dim=256, codebook_size=1024), x = (64, 16384, 256) bf16 (2^20
-vectors).  For N > 1 (launched by torch.distributed.run, one rank per GPU, RCCL) every rank owns its
-own batch of that shape (weak scaling) and the EMA statistics are summed with ONE all-reduce per step,
-which is the reference's data-parallel scheme (vqp.py:603, 607).  value = all ranks' vectors / max time.
+A "step" is one training forward of the hot path (codebook pack + nearest-code search + gather + commit loss +
+EMA statistics + EMA fold) over one synthetic batch already resident in HBM.  Default workload = BASELINE
+config[1] ("vq_cfg2"): VectorQuantize(dim=256, codebook_size=1024), x = (64, 16384, 256) bf16 (2^20 vectors).
+
+N > 1: one process per GPU over RCCL.  Launched by the driver as `python -m torch.distributed.run ... bench.py
+--gpus N ...` (RANK / LOCAL_RANK / WORLD_SIZE in the environment), or, when WORLD_SIZE is not set, bench.py starts
+those N ranks itself by re-executing under torch.distributed.run.  WORLD_SIZE must equal --gpus.  Every rank owns
+its own batch (weak scaling); the EMA statistics are summed with ONE all-reduce per step, the reference's
+data-parallel scheme (vqp.py:603, 607).  value = all ranks' vectors / max-over-ranks time.
+
+Other workloads (informational, same JSON shape): rvq_cfg3, grvq_cfg5 (BASELINE configs 3 and 5 on one GPU),
+vq_cfg4_shard (config 4: the work of ONE of the 8 ranks -- all 262144 rows against an 8192-code shard, D = 512,
+cosine -- on one GPU) and vq_cfg4_sharded (config 4 with the codebook sharded over the N ranks, RCCL argmin merge).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -25,13 +34,20 @@ import torch.distributed as dist
 B, S, D, C = 64, 16384, 256, 1024
 PEAK_FP32_MFMA_TFLOPS = 157.3        # /opt/skills/guides/MI355X_MICROARCH.md, v_mfma_f32_32x32x2_f32 dense peak
 PEAK_BF16_MFMA_TFLOPS = 2500.0       # same guide: dense bf16 MFMA peak (AMD's 2:1-sparse headline is not used)
+PEAK_HBM_GBPS = 8000.0               # same guide: HBM3E 8 TB/s spec (6.3 TB/s achievable)
+N_BATCHES = 4                        # distinct synthetic batches cycled through the timed steps (2 GiB at cfg 2)
 
 
-def cpu_baseline(nthreads):
-    """The reference's CPU op sequence (oracle mode="aten": 3 N*C*D contractions + the N*C temporaries,
-    bit-identical to the live reference) on the host cores, bounded sample of the same workload."""
+# ----------------------------------------------------------------------------------------------------------------------
+# CPU baseline + parity audit against the reference's op sequence (oracle mode "aten")
+# ----------------------------------------------------------------------------------------------------------------------
+def cpu_baseline_and_audit(nthreads, dev):
+    """Times the reference's CPU op sequence (oracle mode="aten": 3 N*C*D contractions + the N*C temporaries; proven
+    bit-identical to the live reference in the build container, tests/test_oracle.py -- /root/reference itself is not on
+    the GPU box) on a bounded sample of the cfg-2 workload, and compares the GPU path's indices with the oracle's on the
+    SAME rows and codebook (mismatch count with tie audit)."""
     from oracle import vq_oracle as O
-    # torch's own default thread count is what the reference would run with on this host
+    from vector_quantize_pytorch_amd import _lib
     rows_b, rows_s = 8, 16384                       # 131072 of the 2^20 vectors per timed forward
     g = torch.Generator().manual_seed(0)
     x = torch.randn(rows_b, rows_s, D, generator=g).bfloat16()
@@ -40,88 +56,148 @@ def cpu_baseline(nthreads):
     st = O.VQState(embed=e.clone(), embed_avg=e.clone(), cluster_size=torch.ones(1, C))
     cfg = O.VQConfig(dim=D, codebook_size=C)
     with torch.no_grad():
-        O.vq_forward(st, cfg, x)                    # warm-up
+        _, idx_aten, _ = O.vq_forward(st, cfg, x)   # warm-up; its indices (first step, codebook e) feed the audit
         ts = []
         for _ in range(3):
             t0 = time.perf_counter()
             O.vq_forward(st, cfg, x)
             ts.append(time.perf_counter() - t0)
     t = sorted(ts)[1]
-    return dict(value=rows_b * rows_s / t, unit="vectors/s", cores=nthreads, kind="port",
-                sample=f"oracle mode=aten (reference op sequence) x=({rows_b},{rows_s},{D}) bf16, C={C}, train step, median of 3 after 1 warm-up, {t:.3f} s/forward")
+    base = dict(value=rows_b * rows_s / t, unit="vectors/s", cores=nthreads, kind="port",
+                sample=(f"oracle mode=aten = the reference's ATen op sequence (live reference not on the GPU box), "
+                        f"x=({rows_b},{rows_s},{D}) bf16 input as in cfg 2, fp32 arithmetic (the reference casts at vqp.py:692), "
+                        f"C={C}, train step, median of 3 after 1 warm-up, {t:.3f} s/forward"))
+
+    # ---- audit: GPU (screened and exact) vs the reference op sequence on the same rows / codebook ----
+    xd, ed = x.reshape(-1, D).to(dev), e[0].to(dev).contiguous()
+    packed = _lib.pack_codebook(ed)
+    gi = _lib.assign(xd, packed, ed, want_q=False)["idx"].cpu()
+    ia = idx_aten.reshape(-1)
+    mism = (gi != ia).nonzero().flatten()
+    max_ulps = 0
+    if mism.numel():
+        # tie audit: the reference's own fp32 distances of the two candidates, in units in the last place
+        rows = x.reshape(-1, D)[mism].float()
+        d = -O.neg_cdist(rows[None], e)[0]                                   # [m, C] cdist as the reference computes it
+        da = d.gather(1, ia[mism][:, None])[:, 0]
+        dg = d.gather(1, gi[mism][:, None])[:, 0]
+        ulps = (da.view(torch.int32).long() - dg.view(torch.int32).long()).abs()
+        max_ulps = int(ulps.max())
+    audit = dict(rows_checked_vs_aten=int(ia.numel()), mismatches_vs_aten=int(mism.numel()), tie_audit_max_ulps=max_ulps)
+    return base, audit
 
 
-def other_workload(args):
-    """BASELINE configs 3 and 5 on one GPU (informational; the contract line is vq_cfg2)."""
-    dev = torch.device("cuda", 0)
-    torch.cuda.set_device(0)
-    from vector_quantize_pytorch_amd import GroupedResidualVQ, ResidualVQ
-    torch.manual_seed(0)
-    if args.workload == "rvq_cfg3":
-        mod = ResidualVQ(dim=256, num_quantizers=8, codebook_size=1024, shared_codebook=True).to(dev).train()
-        x = torch.randn(32, 8192, 256, device=dev)
-        stages, flops = 8, 2.0 * 32 * 8192 * 8 * 1024 * 256
-        name = "ResidualVQ(dim=256, num_quantizers=8, codebook_size=1024, shared_codebook=True) train forward, x=(32,8192,256) fp32"
-    else:
-        mod = GroupedResidualVQ(dim=512, groups=4, num_quantizers=8, codebook_size=4096, kmeans_init=True).to(dev).train()
-        x = torch.randn(32, 8192, 512, device=dev)
-        stages, flops = 32, 2.0 * 32 * 8192 * 4 * 8 * 4096 * 128
-        name = "GroupedResidualVQ(dim=512, groups=4, num_quantizers=8, codebook_size=4096, kmeans_init=True) steady-state train forward, x=(32,8192,512) fp32"
+def screened_vs_exact(x, vq):
+    """whole-batch comparison of the screened search with the exact fp32-MFMA kernel on the current codebook"""
+    from vector_quantize_pytorch_amd import _lib
+    e = vq._codebook.embed[0].detach().contiguous()
+    packed = _lib.pack_codebook(e)
+    rows = x.reshape(-1, x.shape[-1])
+    old = os.environ.get("VQHIP_SCREEN")
+    try:
+        os.environ["VQHIP_SCREEN"] = "1"
+        r1 = _lib.assign(rows, packed, e, want_q=True)
+        os.environ["VQHIP_SCREEN"] = "0"
+        r0 = _lib.assign(rows, packed, e, want_q=True)
+    finally:
+        if old is None:
+            os.environ.pop("VQHIP_SCREEN", None)
+        else:
+            os.environ["VQHIP_SCREEN"] = old
+    bad = int((r1["idx"] != r0["idx"]).sum()) + int((r1["q"] != r0["q"]).any(-1).sum())
+    return rows.shape[0], bad
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+def _time_module(mod, batches, steps, warmup, sync):
     with torch.no_grad():
         torch.cuda.synchronize(); t0 = time.perf_counter()
-        mod(x)                                   # first forward (includes the on-device k-means for cfg 5)
+        mod(batches[0])                                 # first forward (k-means init for cfg 5)
         torch.cuda.synchronize(); first = time.perf_counter() - t0
-        for _ in range(args.warmup):
-            mod(x)
-        torch.cuda.synchronize(); t0 = time.perf_counter()
-        for _ in range(args.steps):
-            mod(x)
-        torch.cuda.synchronize(); dt = time.perf_counter() - t0
-    n = x.shape[0] * x.shape[1]
-    from vector_quantize_pytorch_amd import _lib
-    peak = PEAK_BF16_MFMA_TFLOPS if _lib.screening_enabled() else PEAK_FP32_MFMA_TFLOPS
-    print(json.dumps({"metric": "vectors quantized/sec", "value": n * args.steps / dt, "unit": "vectors/s", "n_gpus": 1,
-                      "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-                      "scaling": "weak", "vs_baseline": None, "dtype": "bf16x3+f32" if _lib.screening_enabled() else "f32", "data": "synthetic",
-                      "config": {"workload": name, "vector_stages_per_s": n * stages * args.steps / dt, "first_forward_ms": first * 1e3},
-                      "roofline": {"bound": "mfma", "achieved": flops * args.steps / dt / 1e12, "peak": peak,
-                                   "unit": "TFLOP/s", "frac": flops * args.steps / dt / 1e12 / peak, "traffic": None,
-                                   "achieved_vs_fp32_mfma_peak": flops * args.steps / dt / 1e12 / PEAK_FP32_MFMA_TFLOPS,
-                                   "note": "whole step (all kernels), not one kernel; algorithmic flops (2*C*D per vector and stage); "
-                                           "peak = bf16 MFMA when the stages run the screened search, fp32 MFMA otherwise"}}), flush=True)
+        for i in range(warmup):
+            mod(batches[i % len(batches)])
+        sync()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            out = mod(batches[i % len(batches)])
+        sync()
+        dt = time.perf_counter() - t0
+    return dt, first, out
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", default="vq_cfg2", choices=["vq_cfg2", "rvq_cfg3", "grvq_cfg5"],
-                    help="vq_cfg2 (default) is BASELINE.json's headline configuration; the others are informational")
-    args = ap.parse_args()
-    if args.workload != "vq_cfg2":
-        return other_workload(args)
+def other_workload(args, world, rank, dev):
+    """BASELINE configs 3, 4 and 5 (informational; the contract line is vq_cfg2)."""
+    from vector_quantize_pytorch_amd import GroupedResidualVQ, ResidualVQ, _lib
+    from vector_quantize_pytorch_amd.parallel import ShardedVectorQuantize
+    torch.manual_seed(0)
+    gen = torch.Generator(device=dev).manual_seed(1 + rank)
+    par = "single GPU"
+    if args.workload == "rvq_cfg3":
+        mod = ResidualVQ(dim=256, num_quantizers=8, codebook_size=1024, shared_codebook=True).to(dev).train()
+        shape, stages, flops = (32, 8192, 256), 8, 2.0 * 32 * 8192 * 8 * 1024 * 256
+        name = "ResidualVQ(dim=256, num_quantizers=8, codebook_size=1024, shared_codebook=True) train forward, x=(32,8192,256) fp32"
+    elif args.workload == "grvq_cfg5":
+        mod = GroupedResidualVQ(dim=512, groups=4, num_quantizers=8, codebook_size=4096, kmeans_init=True).to(dev).train()
+        shape, stages, flops = (32, 8192, 512), 32, 2.0 * 32 * 8192 * 4 * 8 * 4096 * 128
+        name = "GroupedResidualVQ(dim=512, groups=4, num_quantizers=8, codebook_size=4096, kmeans_init=True) steady-state train forward, x=(32,8192,512) fp32"
+    elif args.workload == "vq_cfg4_shard":
+        # the per-rank work of config 4 on 8 GPUs: every row of the batch against this rank's 8192 of the 65536 codes
+        mod = ShardedVectorQuantize(512, 65536, use_cosine_sim=True, emulate=(0, 8)).to(dev).train()
+        shape, stages, flops = (16, 16384, 512), 1, 2.0 * 16 * 16384 * 8192 * 512
+        name = ("VectorQuantize(dim=512, codebook_size=65536, use_cosine_sim=True) sharded over 8 ranks: ONE rank's work "
+                "(all 262144 rows x its 8192 codes, search + decode + EMA; collectives excluded), x=(16,16384,512) fp32")
+    else:   # vq_cfg4_sharded: the whole of config 4 over the `world` ranks
+        mod = ShardedVectorQuantize(512, 65536, use_cosine_sim=True).to(dev).train()
+        assert 16 % world == 0
+        shape, stages, flops = (16 // world, 16384, 512), 1, 2.0 * 16 * 16384 * 65536 * 512 / world
+        name = (f"VectorQuantize(dim=512, codebook_size=65536, use_cosine_sim=True), codebook sharded over {world} rank(s), "
+                f"x=(16,16384,512) fp32 in total ({16 // world} x 16384 rows per rank, all-gathered), RCCL MAX all-reduce of packed (score, index) keys")
+        par = f"codebook sharded x{world} (rows all-gathered, one int64 MAX all-reduce, reduce-scatter of q)"
+    nb = 2
+    batches = [torch.randn(*shape, generator=gen, device=dev) for _ in range(nb)]
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    dt, first, _ = _time_module(mod, batches, args.steps, args.warmup, sync)
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    if rank != 0:
+        return
+    strong = args.workload == "vq_cfg4_sharded"
+    n = shape[0] * shape[1] * (world if strong else 1)
+    screened = _lib.screening_enabled()
+    peak = PEAK_BF16_MFMA_TFLOPS if screened else PEAK_FP32_MFMA_TFLOPS
+    ach = flops * args.steps / dt / 1e12
+    print(json.dumps({"metric": "vectors quantized/sec", "value": n * args.steps / dt, "unit": "vectors/s", "n_gpus": world,
+                      "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+                      "scaling": "strong" if strong else "weak", "vs_baseline": None,
+                      "dtype": "bf16x3+f32" if screened else "f32", "data": "synthetic",
+                      "config": {"workload": name, "parallelism": par, "vector_stages_per_s": n * stages * args.steps / dt,
+                                 "first_forward_ms": first * 1e3},
+                      "roofline": {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
+                                   "traffic": None, "achieved_vs_fp32_mfma_peak": ach / PEAK_FP32_MFMA_TFLOPS,
+                                   "note": "whole step (all kernels) PER GPU, not one kernel; algorithmic flops (2*C*D per vector and stage); "
+                                           "peak = bf16 MFMA when the search runs screened (VQHIP_SCREEN != 0), fp32 MFMA otherwise"}}), flush=True)
 
+
+# ----------------------------------------------------------------------------------------------------------------------
+def vq_cfg2(args, world, rank, dev):
     from vector_quantize_pytorch_amd import VectorQuantize, _lib
+    import vector_quantize_pytorch_amd.codebook as cbmod
 
     torch.manual_seed(0)
     vq = VectorQuantize(dim=D, codebook_size=C, sync_codebook=(world > 1)).to(dev).train()
-    g = torch.Generator().manual_seed(rank)
-    x = torch.randn(B, S, D, generator=g).bfloat16().to(dev)       # resident in HBM before timing
+    gen = torch.Generator(device=dev).manual_seed(100 + rank)
+    batches = [torch.randn(B, S, D, generator=gen, device=dev).bfloat16() for _ in range(N_BATCHES)]   # resident in HBM
 
-    # per-launch timing of the dominant kernel (vq_assign_kernel) with events on the launch stream
-    ev = []
-    exact_rows = []
+    # per-launch timing of the dominant work (the nearest-code search) with events on the launch stream (= torch's current
+    # stream: the library launches on the stream it is handed)
+    ev, exact_rows = [], []
     orig_assign = _lib.assign
 
     def timed_assign(*a, **k):
@@ -134,7 +210,6 @@ def main():
             exact_rows.append(r["n_exact"][0])
         return r
 
-    import vector_quantize_pytorch_amd.codebook as cbmod
     cbmod.L.assign = timed_assign
 
     def sync():
@@ -143,14 +218,16 @@ def main():
         torch.cuda.synchronize()
 
     with torch.no_grad():
-        for _ in range(args.warmup):
-            vq(x)
+        vq(batches[0])                               # step 1 on the reference's default init
         sync()
-        ev.clear()
-        exact_rows.clear()
+        first_exact = float(exact_rows[0].item()) / (B * S) if exact_rows else None
+        for i in range(max(args.warmup - 1, 0)):
+            vq(batches[(i + 1) % N_BATCHES])
+        sync()
+        ev.clear(); exact_rows.clear()
         t0 = time.perf_counter()
-        for _ in range(args.steps):
-            q, idx, loss = vq(x)
+        for i in range(args.steps):
+            q, idx, loss = vq(batches[i % N_BATCHES])
         sync()
         dt = time.perf_counter() - t0
 
@@ -158,61 +235,141 @@ def main():
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
+    if rank != 0:
+        return
 
-    if rank == 0:
-        n_vec = B * S
-        k_ms = sum(a.elapsed_time(b) for a, b in ev) / max(len(ev), 1)
-        flops = 2.0 * n_vec * C * D                                  # 2*C*D per vector
-        achieved = flops / (k_ms * 1e-3) / 1e12
-        screened = _lib.screening_enabled()
-        traffic = None
-        tp = os.path.join(ROOT, "profiles", "traffic.json")          # HBM bytes per launch from rocprofv3 PMC passes
-        if os.path.exists(tp):
-            try:
-                traffic = json.load(open(tp)).get("assign_screened_cfg2_bytes_per_launch" if screened
-                                                   else "vq_assign_kernel_cfg2_bytes_per_launch")
-            except Exception:
-                traffic = None
-        # The dominant work of a step is the nearest-code search.  For bf16 rows it is two kernels on one stream, timed
-        # together by the events above: vq_screen_kernel (bf16 MFMA over a 2-part bf16 split of the codebook, certifies
-        # ~98 % of the rows) and vq_refine_kernel + vq_finish_listed_kernel (the exact fp32-MFMA pass over the uncertified rows).  The
-        # roofline that bounds the search is therefore the bf16 MFMA peak; `achieved` counts ALGORITHMIC flops only
-        # (2*C*D per vector) -- the hardware executes 2x that in the screen (hi + lo part) plus the exact pass.
-        peak = PEAK_BF16_MFMA_TFLOPS if screened else PEAK_FP32_MFMA_TFLOPS
-        out = {
-            "metric": "vectors quantized/sec (VectorQuantize train forward, dim=256 cb=1024)",
-            "value": world * n_vec * args.steps / dt,
-            "unit": "vectors/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "bf16x2+f32" if screened else "f32",
-            "data": "synthetic",
-            "config": {"workload": f"VectorQuantize(dim={D}, codebook_size={C}) train forward + EMA update, x=({B},{S},{D}) bf16 per GPU",
-                       "vectors_per_gpu": n_vec, "parallelism": f"dp{world} (rows sharded, one all-reduce of EMA statistics per step)" if world > 1 else "single GPU",
-                       "loss": float(loss.item())},
-            "roofline": {"bound": "mfma",
-                         "kernel": ("vq_screen_kernel<256> + vq_refine_kernel<256> + vq_finish_listed_kernel" if screened
-                                    else "vq_assign_kernel<256,bf16,euclid>"),
-                         "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-                         "traffic": traffic, "kernel_ms": k_ms, "algorithmic_flops_per_launch": flops,
-                         "algorithmic_bytes_per_launch": n_vec * 1032 + C * D * 4,
-                         "achieved_vs_fp32_mfma_peak": achieved / PEAK_FP32_MFMA_TFLOPS,
-                         "note": ("achieved counts algorithmic flops (2*C*D per vector); the screen executes 2x that on the bf16 "
-                                  "MFMA pipe (hi + lo codebook part), MFMA pipes 53 % busy per PMC (profiles/r1_screen)") if screened else
-                                 "exact fp32-MFMA search (VQHIP_SCREEN=0)"},
-        }
-        if screened and exact_rows:
-            out["roofline"]["rows_exact_pass_frac"] = float(torch.stack(exact_rows).double().mean().item()) / n_vec
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(torch.get_num_threads())
-        print(json.dumps(out), flush=True)
+    n_vec = B * S
+    k_ms = sum(a.elapsed_time(b) for a, b in ev) / max(len(ev), 1)
+    flops = 2.0 * n_vec * C * D                                  # 2*C*D per vector
+    alg_bytes = n_vec * 1032 + C * D * 4                         # D*2 in + D*2 out + 8 per vector (+ codebook once)
+    achieved = flops / (k_ms * 1e-3) / 1e12
+    screened = _lib.screening_enabled()
+    traffic, traffic_src = None, None
+    tp = os.path.join(ROOT, "profiles", "traffic.json")          # HBM bytes per launch from rocprofv3 PMC passes (not measured in this run)
+    if os.path.exists(tp):
+        try:
+            tj = json.load(open(tp))
+            traffic = tj.get("assign_screened_cfg2_bytes_per_launch" if screened else "vq_assign_kernel_cfg2_bytes_per_launch")
+            traffic_src = "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, committed; not re-measured in this run)"
+        except Exception:
+            traffic = None
+    peak = PEAK_BF16_MFMA_TFLOPS if screened else PEAK_FP32_MFMA_TFLOPS
+    step_s = dt / args.steps
+    out = {
+        "metric": "vectors quantized/sec (VectorQuantize train forward, dim=256 cb=1024)",
+        "value": world * n_vec * args.steps / dt,
+        "unit": "vectors/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": step_s * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "bf16x2+f32" if screened else "f32",
+        "data": "synthetic",
+        "hbm_gbps": alg_bytes / step_s / 1e9,                     # algorithmic bytes of a step / step time, per GPU
+        "hbm_frac": alg_bytes / step_s / 1e9 / PEAK_HBM_GBPS,
+        "config": {"workload": f"VectorQuantize(dim={D}, codebook_size={C}) train forward + EMA update, x=({B},{S},{D}) bf16 per GPU, "
+                               f"{N_BATCHES} distinct batches cycled, codebook evolving by EMA",
+                   "vectors_per_gpu": n_vec,
+                   "parallelism": f"dp{world} (rows sharded, one all-reduce of EMA statistics per step)" if world > 1 else "single GPU",
+                   "world_size": world, "backend": (dist.get_backend() if world > 1 else None),
+                   "loss": float(loss.item())},
+        "roofline": {"bound": "mfma",
+                     "kernel": ("vq_screen_kernel<256> + vq_refine_kernel<256> + vq_finish_listed_kernel" if screened
+                                else "vq_assign_kernel<256,bf16,euclid>"),
+                     "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+                     "traffic": traffic, "traffic_source": traffic_src, "kernel_ms": k_ms, "algorithmic_flops_per_launch": flops,
+                     "algorithmic_bytes_per_launch": alg_bytes,
+                     "achieved_vs_fp32_mfma_peak": achieved / PEAK_FP32_MFMA_TFLOPS,
+                     "note": ("achieved counts algorithmic flops (2*C*D per vector) over the whole search (screen + exact pass on the "
+                              "uncertified rows + finish), timed with events on the launch stream") if screened else
+                             "exact fp32-MFMA search (VQHIP_SCREEN=0)"},
+    }
+    if screened and exact_rows:
+        out["roofline"]["rows_exact_pass_frac"] = float(torch.stack(exact_rows).double().mean().item()) / n_vec
+        out["roofline"]["rows_exact_pass_frac_first_step"] = first_exact
+    if world == 1:
+        cbmod.L.assign = orig_assign
+        parity = {}
+        if screened:
+            n_chk, bad = screened_vs_exact(batches[0], vq)
+            parity.update(rows_checked=n_chk, mismatches_vs_exact=bad)
+        if not args.no_adversarial and screened:
+            # throughput floor: a codebook in which every code has an identical twin -- no row can be certified, every row
+            # takes the screen AND the exact pass
+            dup = VectorQuantize(dim=D, codebook_size=C).to(dev).train()
+            with torch.no_grad():
+                cb = dup._codebook
+                cb.embed[0, C // 2:] = cb.embed[0, : C // 2]
+                cb.embed_avg.copy_(cb.embed)
+                k = 3
+                dup(batches[0])
+                torch.cuda.synchronize(); t0 = time.perf_counter()
+                for i in range(k):
+                    cb.embed[0, C // 2:] = cb.embed[0, : C // 2]          # keep the twins identical across the EMA update
+                    dup(batches[i % N_BATCHES])
+                torch.cuda.synchronize(); ta = (time.perf_counter() - t0) / k
+            out["adversarial"] = {"workload": "same step with a duplicated codebook (every code has a twin): 100 % of the rows take the exact pass",
+                                  "ms_per_step": ta * 1e3, "value": n_vec / ta, "unit": "vectors/s"}
+        if not args.no_cpu_baseline:
+            base, audit = cpu_baseline_and_audit(torch.get_num_threads(), dev)
+            out["cpu_baseline"] = base
+            parity.update(audit)
+        out["parity"] = parity
+    print(json.dumps(out), flush=True)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-adversarial", action="store_true")
+    ap.add_argument("--workload", default="vq_cfg2", choices=["vq_cfg2", "rvq_cfg3", "grvq_cfg5", "vq_cfg4_shard", "vq_cfg4_sharded"],
+                    help="vq_cfg2 (default) is BASELINE.json's headline configuration; the others are informational")
+    args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # not under a launcher: start the N ranks ourselves (one process per GPU, RCCL), same contract as the driver's command
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__), *sys.argv[1:]]
+        sys.exit(subprocess.call(cmd))
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: refusing to report a line for the wrong GPU count", file=sys.stderr)
+        sys.exit(2)
+    if args.workload in ("rvq_cfg3", "grvq_cfg5", "vq_cfg4_shard") and world != 1:
+        print(f"bench.py: workload {args.workload} is a single-GPU workload", file=sys.stderr)
+        sys.exit(2)
     if world > 1:
-        dist.destroy_process_group()
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        assert dist.get_world_size() == world
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    try:
+        if args.workload == "vq_cfg2":
+            vq_cfg2(args, world, rank, dev)
+        else:
+            other_workload(args, world, rank, dev)
+    finally:
+        if world > 1:
+            dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -7,6 +7,7 @@ call raises.
 from __future__ import annotations
 
 import ctypes
+import functools
 import os
 
 import torch
@@ -90,7 +91,28 @@ def _check(rc, what):
 
 
 def _stream():
+    # always called inside an @_on_device wrapper: the current device is the tensors' device
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _on_device(fn):
+    """Run `fn` with the CUDA tensors' device current, so that the stream handed to the library and the kernels it
+    launches belong to the device that owns the memory (a module on cuda:1 while cuda:0 is current).  Tensors on
+    different GPUs are an error; CPU tensors are rejected by _need_gpu inside `fn`."""
+    @functools.wraps(fn)
+    def wrapped(*args, **kwargs):
+        dev = None
+        for t in (*args, *kwargs.values()):
+            if torch.is_tensor(t) and t.is_cuda:
+                if dev is None:
+                    dev = t.device
+                elif t.device != dev:
+                    raise VQHipError(f"{fn.__name__}: tensors on different devices ({dev} and {t.device})")
+        if dev is None or dev.index == torch.cuda.current_device():
+            return fn(*args, **kwargs)
+        with torch.cuda.device(dev):
+            return fn(*args, **kwargs)
+    return wrapped
 
 
 def _dtype_code(t: torch.Tensor) -> int:
@@ -137,6 +159,7 @@ def as_rows(x: torch.Tensor):
 # ------------------------------------------------------------------------------------------------
 # thin wrappers (allocation is done here, in torch; the library never allocates)
 # ------------------------------------------------------------------------------------------------
+@_on_device
 def pack_codebook(embed2d: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
     _need_gpu(embed2d)
     assert embed2d.dtype == torch.float32 and embed2d.is_contiguous() and embed2d.ndim == 2
@@ -158,6 +181,7 @@ def screening_enabled() -> bool:
     return os.environ.get("VQHIP_SCREEN", "1") != "0"
 
 
+@_on_device
 def assign(x: torch.Tensor, packed: torch.Tensor, embed2d: torch.Tensor, *, cosine=False,
            want_q=True, want_sqerr=False, want_best=False, want_rnorm=False, row_mask=None, q_out=None,
            skip_l2norm=False, resid_out=None):
@@ -230,6 +254,7 @@ def assign(x: torch.Tensor, packed: torch.Tensor, embed2d: torch.Tensor, *, cosi
     return dict(idx=idx, q=q, sqerr_partials=partials, best=best, rnorm=rnorm, nblk=nblk)
 
 
+@_on_device
 def scores(x: torch.Tensor, packed: torch.Tensor, embed2d: torch.Tensor, *, cosine=False, skip_l2norm=False):
     """x [..., D] -> (dist [..., C] fp32 = -cdist or cosine similarity, argmax idx [...], rnorm).  Rare options only."""
     _need_gpu(x, packed, embed2d)
@@ -252,6 +277,7 @@ def screen_supported(x: torch.Tensor, C: int) -> bool:
                 and (ldx * xk.element_size()) % 16 == 0 and lib().vqhip_screen_supported(N, D, C))
 
 
+@_on_device
 def l2norm_rows(x: torch.Tensor) -> torch.Tensor:
     """x / max(||x||, 1e-6) row-wise in the reference's arithmetic (vqp.py:37-38 at :1159); D in {32, 64, 128, 256}."""
     _need_gpu(x)
@@ -262,6 +288,7 @@ def l2norm_rows(x: torch.Tensor) -> torch.Tensor:
     return out
 
 
+@_on_device
 def rvq_forward_screened(x: torch.Tensor, packed: torch.Tensor, embed: torch.Tensor, Q: int, *, want_resid=False,
                          want_sqerr=False, row_mask=None):
     """The residual loop (rvq.py:469-568) as Q screened assignments: each stage's search runs on the bf16 MFMA pipe
@@ -290,6 +317,7 @@ def rvq_forward_screened(x: torch.Tensor, packed: torch.Tensor, embed: torch.Ten
                 sqerr_partials=torch.stack(parts) if want_sqerr else None)
 
 
+@_on_device
 def rvq_forward(x: torch.Tensor, packed: torch.Tensor, embed: torch.Tensor, Q: int, *, want_resid=False,
                 want_sqerr=False, row_mask=None):
     """Fused residual loop.  embed [C, D] (shared by all stages; packed = pack_codebook(embed)) or [Q, C, D]
@@ -319,6 +347,7 @@ def rvq_forward(x: torch.Tensor, packed: torch.Tensor, embed: torch.Tensor, Q: i
 STRAIGHT_THROUGH, ROTATION = 1, 2
 
 
+@_on_device
 def route_fwd(x: torch.Tensor, q: torch.Tensor, mode: int) -> torch.Tensor:
     """forward value of straight-through (mode 1) / the rotation trick (mode 2), rows = last dim."""
     _need_gpu(x, q)
@@ -332,6 +361,7 @@ def route_fwd(x: torch.Tensor, q: torch.Tensor, mode: int) -> torch.Tensor:
     return out
 
 
+@_on_device
 def route_bwd(x: torch.Tensor, q: torch.Tensor, g_out, loss_coef, row_mask, mode: int) -> torch.Tensor:
     """grad wrt x of (routed output, commit-loss sum); g_out may be None (mode 0), loss_coef a 0-dim fp32 device tensor or None."""
     _need_gpu(x, q, g_out, loss_coef, row_mask)
@@ -351,6 +381,7 @@ def route_bwd(x: torch.Tensor, q: torch.Tensor, g_out, loss_coef, row_mask, mode
     return gx
 
 
+@_on_device
 def reduce_partials(partials: torch.Tensor, n: int, scale: float, out: torch.Tensor | None = None) -> torch.Tensor:
     _need_gpu(partials)
     if out is None:
@@ -359,6 +390,7 @@ def reduce_partials(partials: torch.Tensor, n: int, scale: float, out: torch.Ten
     return out
 
 
+@_on_device
 def ema_accumulate(x: torch.Tensor, idx: torch.Tensor, C: int, *, cosine=False, rnorm=None, row_mask=None,
                    count=None, embed_sum=None, idx_stride=1, idx_offset=0):
     """Accumulates into (count [C], embed_sum [C, D]); allocates zeroed ones if not given."""
@@ -382,6 +414,7 @@ def ema_accumulate(x: torch.Tensor, idx: torch.Tensor, C: int, *, cosine=False, 
     return count, embed_sum
 
 
+@_on_device
 def ema_finalize(cluster_size, embed_avg, embed, count, embed_sum, *, decay, eps, cosine=False, weight=None,
                  do_lerp=True, do_update_ema=True, denom_ws=None):
     """In place on cluster_size [C], embed_avg [C, D], embed [C, D] (2-D views of the module buffers)."""
@@ -398,6 +431,7 @@ def ema_finalize(cluster_size, embed_avg, embed, count, embed_sum, *, decay, eps
                                     int(do_update_ema), _ptr(denom_ws), _stream()), "vqhip_ema_finalize")
 
 
+@_on_device
 def decode_sum(idx: torch.Tensor, embed: torch.Tensor, out_dtype=torch.float32) -> torch.Tensor:
     """idx [..., Q] int64, embed [Q, C, D] or [C, D] (shared by all Q) -> [..., D] = sum_q embed_q[idx_q]."""
     _need_gpu(idx, embed)
@@ -419,6 +453,7 @@ def decode_sum(idx: torch.Tensor, embed: torch.Tensor, out_dtype=torch.float32) 
     return out
 
 
+@_on_device
 def row_sumsq(x: torch.Tensor) -> torch.Tensor:
     _need_gpu(x)
     xk, N, D, ldx = as_rows(x)

@@ -161,6 +161,7 @@ class Codebook(nn.Module):
             self.register_buffer('embed', embed)
 
         self._initted_known = not kmeans_init     # python-side cache: no host sync per forward
+        self._affine_needs_init = {}              # same idea for the affine_param moment buffers
 
         if affine_param:                           # vqp.py:442-448: same buffer names / state_dict keys
             self.register_buffer('batch_mean', None)
@@ -173,14 +174,25 @@ class Codebook(nn.Module):
     # ---- affine reparametrisation of the codebook (vqp.py:475-542): running first / second moments of the batch and
     #      of the codebook; the codebook is searched after being mapped onto the batch statistics ----
     def _decayed(self, name: str, new: Tensor, decay: float):
+        """update_with_decay (vqp.py:475-492) without a host sync per step: whether the statistic still needs its first
+        value is cached on the Python side (re-read from the `*_needs_init` buffer once after a checkpoint load), and the
+        running value is updated in place, so external references to the buffer stay valid."""
         old = getattr(self, name)
-        needs_init = bool(getattr(self, name + '_needs_init', False))
+        flag = getattr(self, name + '_needs_init', None)
+        needs_init = self._affine_needs_init.get(name)
+        if needs_init is None:
+            needs_init = old is None or (flag is not None and bool(flag))
         if needs_init:
-            self.register_buffer(name + '_needs_init', torch.tensor(False, device=new.device))
-        if old is None or needs_init:
-            self.register_buffer(name, new.detach())
+            if old is None:
+                self.register_buffer(name, new.detach().clone())
+            else:
+                old.copy_(new.detach())
+            if flag is not None:
+                flag.fill_(False)
+            self._affine_needs_init[name] = False
             return
-        self.register_buffer(name, old * decay + new.detach() * (1 - decay))
+        self._affine_needs_init[name] = False
+        old.mul_(decay).add_(new.detach() * (1 - decay))      # == old * decay + new * (1 - decay), same roundings
 
     @torch.no_grad()
     def update_affine(self, data: Tensor, embed: Tensor, mask: Optional[Tensor] = None):
@@ -207,6 +219,7 @@ class Codebook(nn.Module):
     def _load_from_state_dict(self, *args, **kwargs):
         super()._load_from_state_dict(*args, **kwargs)
         self._initted_known = None                # re-read `initted` lazily after a checkpoint load
+        self._affine_needs_init = {}
 
     def _is_initted(self) -> bool:
         if self._initted_known is None:
@@ -312,6 +325,9 @@ class Codebook(nn.Module):
         if self.cluster_size.grad is not None:      # vqp.py:80-82: fold parked statistics first
             count = count + self.cluster_size.grad[h]
             esum = esum + self.embed_avg.grad[h]
+            if h == self.num_codebooks - 1:         # ... "and set it to None": folded once, not on every later step
+                self.cluster_size.grad = None
+                self.embed_avg.grad = None
         L.ema_finalize(cs, ea, e, count, esum, decay=self.decay, eps=self.eps, cosine=self.use_cosine_sim, weight=w,
                        do_lerp=True, do_update_ema=bool(ema_update and not self.manual_ema_update))
 

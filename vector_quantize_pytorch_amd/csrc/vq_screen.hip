@@ -717,14 +717,9 @@ template <int DT, int METRIC>
 static int launch_screen(const ScreenArgs &a, int x_dtype, hipStream_t st)
 {
     constexpr int SMEM = 2 * (128 * DT + 1024);
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void *)vq_screen_kernel<DT, METRIC>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
-        if (e == hipSuccess)
-            e = hipFuncSetAttribute((const void *)vq_screen_f32_kernel<DT, METRIC>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
-        if (e != hipSuccess) VQ_FAIL((int)e, "hipFuncSetAttribute(screen<%d>): %s", DT, hipGetErrorString(e));
-        attr_done = true;
-    }
+    static VqAttrOnce once_b, once_f;
+    if (int rc = vq_set_max_smem(once_b, (const void *)vq_screen_kernel<DT, METRIC>, SMEM, "vq_screen_kernel")) return rc;
+    if (int rc = vq_set_max_smem(once_f, (const void *)vq_screen_f32_kernel<DT, METRIC>, SMEM, "vq_screen_f32_kernel")) return rc;
     const unsigned blocks = (unsigned)vqhip_screen_blocks(a.N, x_dtype);
     if (x_dtype == VQHIP_BF16)
         hipLaunchKernelGGL((vq_screen_kernel<DT, METRIC>), dim3(blocks), dim3(VQS_WAVES * 64), SMEM, st, a);

@@ -703,13 +703,8 @@ static int launch_assign(const AssignArgs &a, hipStream_t st)
 {
     constexpr int TILE_B = (32 * DT + 256) * 4;
     constexpr int SMEM = 2 * TILE_B;
-    static bool attr_done = false;  // per instantiation
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void *)vq_assign_kernel<DT, XBF16, METRIC>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
-        if (e != hipSuccess) VQ_FAIL((int)e, "hipFuncSetAttribute(assign<%d>): %s", DT, hipGetErrorString(e));
-        attr_done = true;
-    }
+    static VqAttrOnce once;   // per instantiation and device
+    if (int rc = vq_set_max_smem(once, (const void *)vq_assign_kernel<DT, XBF16, METRIC>, SMEM, "vq_assign_kernel")) return rc;
     const int64_t blocks = vqhip_assign_blocks(a.N);
     hipLaunchKernelGGL((vq_assign_kernel<DT, XBF16, METRIC>), dim3((unsigned)blocks), dim3(256), SMEM, st, a);
     return launch_status("vq_assign_kernel");
@@ -1090,12 +1085,8 @@ template <int DT, bool XBF16, int METRIC>
 static int launch_refine(const RefineArgs &a, unsigned gx, unsigned gy, hipStream_t st)
 {
     constexpr int SMEM = 2 * (32 * DT + 256) * 4;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void *)vq_refine_kernel<DT, XBF16, METRIC>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
-        if (e != hipSuccess) VQ_FAIL((int)e, "hipFuncSetAttribute(refine<%d>): %s", DT, hipGetErrorString(e));
-        attr_done = true;
-    }
+    static VqAttrOnce once;
+    if (int rc = vq_set_max_smem(once, (const void *)vq_refine_kernel<DT, XBF16, METRIC>, SMEM, "vq_refine_kernel")) return rc;
     hipLaunchKernelGGL((vq_refine_kernel<DT, XBF16, METRIC>), dim3(gx, gy), dim3(256), SMEM, st, a);
     return launch_status("vq_refine_kernel");
 }
@@ -1360,12 +1351,8 @@ template <int DT, bool XBF16>
 static int launch_rvq(const RvqArgs &a, hipStream_t st)
 {
     constexpr int SMEM = 2 * (32 * DT + 256) * 4;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void *)vq_rvq_kernel<DT, XBF16>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
-        if (e != hipSuccess) VQ_FAIL((int)e, "hipFuncSetAttribute(rvq<%d>): %s", DT, hipGetErrorString(e));
-        attr_done = true;
-    }
+    static VqAttrOnce once;
+    if (int rc = vq_set_max_smem(once, (const void *)vq_rvq_kernel<DT, XBF16>, SMEM, "vq_rvq_kernel")) return rc;
     hipLaunchKernelGGL((vq_rvq_kernel<DT, XBF16>), dim3((unsigned)vqhip_assign_blocks(a.N)), dim3(256), SMEM, st, a);
     return launch_status("vq_rvq_kernel");
 }

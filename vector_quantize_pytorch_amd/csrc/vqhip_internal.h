@@ -16,6 +16,20 @@ extern thread_local char vq_g_err[256];
 
 int vq_launch_status(const char *what);
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a per-DEVICE setting: remember it per (kernel instantiation, device),
+// so that a process driving several GPUs raises the 64-KiB default on each of them (bit d = done on device d).
+struct VqAttrOnce { unsigned long long mask = 0; };
+static inline int vq_set_max_smem(VqAttrOnce &once, const void *fn, int bytes, const char *what)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    if (dev >= 0 && dev < 64 && ((once.mask >> dev) & 1ull)) return 0;
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) VQ_FAIL((int)e, "hipFuncSetAttribute(%s, %d bytes of LDS): %s", what, bytes, hipGetErrorString(e));
+    if (dev >= 0 && dev < 64) once.mask |= 1ull << dev;   // idempotent: a race between threads only repeats the call
+    return 0;
+}
+
 __device__ __forceinline__ float vq_bf16_bits_to_f32(unsigned short b) { return __uint_as_float(((unsigned)b) << 16); }
 __device__ __forceinline__ unsigned short vq_f32_to_bf16_rne(float f)
 {

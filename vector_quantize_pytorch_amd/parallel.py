@@ -78,13 +78,16 @@ class ShardedVectorQuantize(torch.nn.Module):
     Returns (quantized [b, n, d], global indices [b, n], commit_loss) like VectorQuantize."""
 
     def __init__(self, dim, codebook_size, *, use_cosine_sim=False, decay=0.8, eps=1e-5, commitment_weight=1.,
-                 group=None, gather_input=True):
+                 group=None, gather_input=True, emulate=None):
         super().__init__()
         from .codebook import Codebook
         self.group = group
         on = dist.is_available() and dist.is_initialized()
         self.world = dist.get_world_size(group) if on else 1
         self.rank = dist.get_rank(group) if on else 0
+        self._emulated = emulate is not None
+        if emulate is not None:        # (rank, world): this process plays ONE rank of a larger job, collectives skipped --
+            self.rank, self.world = emulate    # the per-rank work of a sharded configuration on a single GPU (bench.py vq_cfg4_shard)
         self.dim, self.codebook_size = dim, codebook_size
         self.lo, self.hi = shard_bounds(codebook_size, self.world, self.rank)
         self.use_cosine_sim, self.decay, self.eps = use_cosine_sim, decay, eps
@@ -100,7 +103,7 @@ class ShardedVectorQuantize(torch.nn.Module):
             self._codebook.embed_avg.copy_(full.embed_avg[:, self.lo:self.hi])
 
     def _collectives_on(self):
-        return self.world > 1
+        return self.world > 1 and not self._emulated
 
     @torch.no_grad()
     def forward(self, x):

@@ -201,6 +201,22 @@ class ResidualVQ(nn.Module):
             return False            # gradients to the input take the per-stage autograd path
         if self.quant_grad_frac > 0:
             return False
+        # The fused loop searches the stored `embed` with a plain argmin under no_grad: only plain EMA / frozen codebooks
+        # qualify.  Anything that changes the searched codebook (vq_bridge, affine_param), needs autograd (learnable
+        # codebook, in-place optimizer, orthogonal / diversity / cross-entropy losses, DiVeQ / directional reparam) or
+        # reads the whole score row (gumbel sampling, gumbel straight-through) takes the per-stage path.
+        for layer in self.layers:
+            cb = layer._codebook
+            if (cb.learnable_codebook or cb.vq_bridge is not None or cb.affine_param
+                    or layer.in_place_codebook_optimizer is not None or layer.directional_reparam
+                    or layer.stochastic_sample_codes or layer.gumbel_straight_through
+                    or layer.commitment_use_cross_entropy_loss or layer.has_codebook_diversity_loss
+                    or layer.has_codebook_orthogonal_loss or layer.sync_update_v > 0.):
+                return False
+        # shared codebook + dead-code replacement: the reference expires inside every stage's update (vqp.py:635-641),
+        # which changes `embed` before the next stage's search -- a stage-by-stage dependency the fused loop cannot honour
+        if self.shared_codebook and cb0.has_dead_code_replacement and self.training:
+            return False
         return all(layer._codebook._is_initted() for layer in self.layers)     # k-means runs in the staged path
 
     @torch.no_grad()
@@ -247,14 +263,11 @@ class ResidualVQ(nn.Module):
                 if cb.use_ddp:
                     dist.all_reduce(buf)
                 cb._fold_stats(0, count, esum, None, False, cb.ema_update)
-                if not self.shared_codebook:
-                    cb.expire_codes_(stage_in(q).reshape(1, -1, D))
-            if self.shared_codebook:                                # rvq.py:593-601
-                if self.vq_is_ema_updating:
-                    vq0._codebook.update_ema()
-                if vq0._codebook.has_dead_code_replacement:
-                    allin = resid if resid is not None else torch.stack([stage_in(q) for q in range(Q)], -2)
-                    vq0._codebook.expire_codes_(allin.reshape(1, -1, D))
+                if not self.shared_codebook:                        # vqp.py:641: expire_codes_(flatten, seq_mask = mask)
+                    cb.expire_codes_(stage_in(q).reshape(1, -1, D),
+                                     seq_mask=None if mask is None else mask.reshape(1, -1).bool())
+            if self.shared_codebook and self.vq_is_ema_updating:    # rvq.py:593-598 (dead-code replacement never gets here:
+                vq0._codebook.update_ema()                           # _fused_eligible sends it to the per-stage path)
 
         if Q < self.num_quantizers:
             pad = torch.full((*idx.shape[:-1], self.num_quantizers - Q), -1, device=x.device, dtype=torch.long)
