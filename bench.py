@@ -197,7 +197,7 @@ def vq_cfg2(args, world, rank, dev):
 
     # per-launch timing of the dominant work (the nearest-code search) with events on the launch stream (= torch's current
     # stream: the library launches on the stream it is handed)
-    ev, exact_rows = [], []
+    ev, exact_rows, pair_rows = [], [], []
     orig_assign = _lib.assign
 
     def timed_assign(*a, **k):
@@ -208,6 +208,7 @@ def vq_cfg2(args, world, rank, dev):
         ev.append((e0, e1))
         if r.get("n_exact") is not None:
             exact_rows.append(r["n_exact"][0])
+            pair_rows.append(r["n_pair"][0])
         return r
 
     cbmod.L.assign = timed_assign
@@ -221,10 +222,11 @@ def vq_cfg2(args, world, rank, dev):
         vq(batches[0])                               # step 1 on the reference's default init
         sync()
         first_exact = float(exact_rows[0].item()) / (B * S) if exact_rows else None
+        first_pair = float(pair_rows[0].item()) / (B * S) if pair_rows else None
         for i in range(max(args.warmup - 1, 0)):
             vq(batches[(i + 1) % N_BATCHES])
         sync()
-        ev.clear(); exact_rows.clear()
+        ev.clear(); exact_rows.clear(); pair_rows.clear()
         t0 = time.perf_counter()
         for i in range(args.steps):
             q, idx, loss = vq(batches[i % N_BATCHES])
@@ -266,7 +268,7 @@ def vq_cfg2(args, world, rank, dev):
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "bf16x2+f32" if screened else "f32",
+        "dtype": "f16+f32" if screened else "f32",
         "data": "synthetic",
         "hbm_gbps": alg_bytes / step_s / 1e9,                     # algorithmic bytes of a step / step time, per GPU
         "hbm_frac": alg_bytes / step_s / 1e9 / PEAK_HBM_GBPS,
@@ -277,7 +279,7 @@ def vq_cfg2(args, world, rank, dev):
                    "world_size": world, "backend": (dist.get_backend() if world > 1 else None),
                    "loss": float(loss.item())},
         "roofline": {"bound": "mfma",
-                     "kernel": ("vq_screen_kernel<256> + vq_refine_kernel<256> + vq_finish_listed_kernel" if screened
+                     "kernel": ("vq_screen16_kernel<256> + vq_refine_kernel<256> + vq_pair_kernel<256> + vq_finish_listed_kernel" if screened
                                 else "vq_assign_kernel<256,bf16,euclid>"),
                      "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                      "traffic": traffic, "traffic_source": traffic_src, "kernel_ms": k_ms, "algorithmic_flops_per_launch": flops,
@@ -290,6 +292,8 @@ def vq_cfg2(args, world, rank, dev):
     if screened and exact_rows:
         out["roofline"]["rows_exact_pass_frac"] = float(torch.stack(exact_rows).double().mean().item()) / n_vec
         out["roofline"]["rows_exact_pass_frac_first_step"] = first_exact
+        out["roofline"]["rows_pair_pass_frac"] = float(torch.stack(pair_rows).double().mean().item()) / n_vec
+        out["roofline"]["rows_pair_pass_frac_first_step"] = first_pair
     if world == 1:
         cbmod.L.assign = orig_assign
         parity = {}

@@ -332,11 +332,11 @@ def test_screened_assign_matches_chain_oracle(dev, N, C, D, kind, dtype):
     sq = r["sqerr_partials"][: r["nblk"]].sum().item()
     want_sq = ((want_q.double() - x.double()) ** 2).sum().item()
     assert abs(sq - want_sq) <= 1e-5 * max(want_sq, 1e-12)
-    n_exact = int(r["n_exact"].item())
+    n_exact = int(r["n_exact"].item()) + int(r["n_pair"].item())      # rows of the full exact sweep + rows decided between two codes
     if kind == "dups":
-        assert n_exact == N            # every best code has an identical twin: all rows go through the exact kernel
+        assert n_exact == N            # every best code has an identical twin: no row can be certified by the screen alone
     elif kind in ("kaiming", "unit", "rows"):
-        assert n_exact <= 0.1 * N      # the screen certifies the bulk (observed: 0.3 .. 3 %)
+        assert n_exact <= 0.1 * N      # the screen certifies the bulk (observed: 0.3 .. 5 %)
 
 
 def test_screened_scores_stay_inside_certified_bound(dev):
@@ -468,7 +468,7 @@ def test_screened_cosine_matches_chain_oracle(dev, N, C, D, kind, dtype):
     want_sq = ((want_q.double() - xn.double()) ** 2).sum().item()
     assert abs(sq - want_sq) <= 1e-5 * max(want_sq, 1e-12)
     if kind == "dups":
-        assert int(r["n_exact"].item()) == N
+        assert int(r["n_exact"].item()) + int(r["n_pair"].item()) == N
 
 
 def test_screened_large_codebook_and_nonfinite_rows(dev, monkeypatch):

@@ -24,7 +24,7 @@ def child():
     for _ in range(12):
         r = L.assign(x, packed, e, want_q=True, want_sqerr=True)
     torch.cuda.synchronize()
-    print("n_exact", int(r["n_exact"].item()))
+    print("n_exact", int(r["n_exact"].item()), "n_pair", int(r["n_pair"].item()))
 
 
 def main():
@@ -40,10 +40,13 @@ def main():
         nex = [l for l in p.stdout.splitlines() if l.startswith("n_exact")]
         f = glob.glob(os.path.join(d, "**", "*kernel_stats.csv"), recursive=True)
         line = f"{tag:10s} rc={p.returncode} {nex[0] if nex else ''} "
+        tot = 0.0
         if f:
             for row in csv.DictReader(open(f[0])):
-                if "vq_screen" in row["Name"] or "vq_assign" in row["Name"]:
-                    line += f"| {row['Name'].split('(')[0][-28:]} avg {float(row['AverageNs']) / 1e3:.1f} us min {float(row['MinNs']) / 1e3:.1f} "
+                if any(k in row["Name"] for k in ("vq_screen", "vq_assign", "vq_refine", "vq_pair", "vq_finish")):
+                    tot += float(row["AverageNs"]) / 1e3
+                    line += f"| {row['Name'].split('(')[0].split('vq_')[-1][:18]} avg {float(row['AverageNs']) / 1e3:.1f} min {float(row['MinNs']) / 1e3:.1f} "
+            line += f"| SEARCH avg {tot:.1f} us"
         else:
             line += p.stdout[-400:]
         print(line, flush=True)

@@ -1,4 +1,6 @@
-"""Dev tool: s_memtime stamps inside vq_screen_kernel (build: -DVQ_TRACE into tools/variants/libvqhip_trace.so)."""
+"""Dev tool: s_memtime stamps inside vq_screen16_kernel (build: tools/build_variants.sh trace="-DVQ_TRACE -DVQ_TRACE_BLOCK0=2048").
+Phases per workgroup (load x + scale + convert | sweep | merge / idx / list | output rows) and, inside the sweep, per barrier
+interval (SUB tiles): wait at the barrier, MFMA + staging + top-2 of the interval."""
 import sys, os, ctypes, torch
 os.environ["VQHIP_SO"] = os.path.join(os.path.dirname(os.path.abspath(__file__)), "variants", "libvqhip_trace.so")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -12,6 +14,7 @@ pk = L.pack_codebook(e)
 xf = torch.randn(1 << 20, D, device=dev, generator=g).bfloat16()
 lib = L.lib()
 lib.vqhip_set_trace.argtypes = [ctypes.c_void_p]
+NI = 16   # barrier intervals at C = 1024, SUB = 2
 for blocks in (256, 512, 4096):
     x = xf[: blocks * 256]
     L.assign(x, pk, e, want_q=True, want_sqerr=True); torch.cuda.synchronize()
@@ -21,13 +24,10 @@ for blocks in (256, 512, 4096):
     lib.vqhip_set_trace(ctypes.c_void_p(0))
     ph = tr.cpu()[16 * 4 * 64 * 4:].reshape(16, 4, 8).double()
     d = [(ph[:, :, i + 1] - ph[:, :, i]).mean().item() for i in range(4)]
-    print(f"blocks={blocks}: phases (cycles): load x + eps {d[0]:.0f} | sweep {d[1]:.0f} | merge/idx/list {d[2]:.0f} | q rows + sqerr {d[3]:.0f}")
-    t = tr.cpu()[: 16 * 4 * 64 * 4].reshape(16, 4, 64, 4)[:, :, :32].double()
+    print(f"blocks={blocks}: phases (cycles): load x + convert {d[0]:.0f} | sweep {d[1]:.0f} | merge/idx/list {d[2]:.0f} | output rows {d[3]:.0f} | total {sum(d):.0f}")
+    t = tr.cpu()[: 16 * 4 * 64 * 4].reshape(16, 4, 64, 4)[:, :, :NI].double()
     bar = t[..., 1] - t[..., 0]
-    mf = t[..., 2] - t[..., 1]
-    ep = t[..., 3] - t[..., 2]
-    tile = t[:, :, 1:, 0] - t[:, :, :-1, 0]
-    total = t[:, :, 31, 3] - t[:, :, 0, 0]
-    print(f"blocks={blocks}: barrier {bar[:, :, 1:].mean():.0f} (max {bar[:, :, 1:].max():.0f})  mfma phase {mf.mean():.0f}  top2 {ep.mean():.0f}  tile period {tile.mean():.0f}  sweep total {total.mean():.0f}")
-    print("   block0 wave0 tiles 4..9 [barrier, mfma, top2]:", [(int(bar[0,0,i]), int(mf[0,0,i]), int(ep[0,0,i])) for i in range(4, 10)])
-    print("   block0 tile 8 all waves barrier:", [int(bar[0,w,8]) for w in range(4)], " mfma:", [int(mf[0,w,8]) for w in range(4)], " top2:", [int(ep[0,w,8]) for w in range(4)])
+    work = t[..., 2] - t[..., 1]
+    period = t[:, :, 1:, 0] - t[:, :, :-1, 0]
+    print(f"   per interval: barrier wait {bar[:, :, 1:].mean():.0f} (max {bar[:, :, 1:].max():.0f})  mfma+stage+top2 {work.mean():.0f}  period {period.mean():.0f}  (pure MFMA issue of one wave: {2 * 2 * 16 * 32})")
+    print("   block0 per wave, interval 8: barrier", [int(bar[0, w, 8]) for w in range(4)], " work", [int(work[0, w, 8]) for w in range(4)])

@@ -210,7 +210,8 @@ def assign(x: torch.Tensor, packed: torch.Tensor, embed2d: torch.Tensor, *, cosi
         want_q = True          # the exact kernel has no residual output: x - q is formed below
         q = torch.empty(*lead, D, dtype=x.dtype, device=dev)
     if screened:
-        # bf16-MFMA screen + exact fp32 pass on the uncertified rows only (csrc/vq_screen.hip); same outputs
+        # MFMA screen + exact arithmetic on the uncertified rows only (csrc/vq_screen.hip); same outputs.  n_exact = rows that
+        # took the full exact sweep, n_pair = rows decided between two candidate codes (bf16 rows), both device-side counters
         nblk = lib().vqhip_screen_partials(N, _dtype_code(xk))
         partials = torch.empty(nblk, dtype=torch.float64, device=dev) if want_sqerr else None
         nws = lib().vqhip_screen_workspace_bytes(N)
@@ -235,7 +236,7 @@ def assign(x: torch.Tensor, packed: torch.Tensor, embed2d: torch.Tensor, *, cosi
             bad = int((chk != idx).sum().item())
             if bad:
                 raise VQHipError(f"VQHIP_SCREEN_VERIFY: screened and exact search disagree on {bad} of {N} rows")
-        return dict(idx=idx, q=q, sqerr_partials=partials, best=None, rnorm=None, nblk=nblk, n_exact=ws[:1], screen_debug=dbg)
+        return dict(idx=idx, q=q, sqerr_partials=partials, best=None, rnorm=None, nblk=nblk, n_exact=ws[:1], n_pair=ws[1:2], screen_debug=dbg)
     need_rn = want_rnorm or cosine or (D % 32 != 0)
     rnorm = torch.empty(lead, dtype=torch.float32, device=dev) if need_rn else None
     best = torch.empty(lead, dtype=torch.float32, device=dev) if want_best else None

@@ -26,6 +26,7 @@
 // measures the actual |t - t_exact| against this bound (observed: below 5 % of it) and checks indices bit for bit.
 
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "vqhip_internal.h"
@@ -53,10 +54,12 @@ struct ScreenArgs {
     const void *x;                     // rows, bf16 (vq_screen_kernel) or fp32 (vq_screen_f32_kernel)
     int64_t N;
     int64_t ldx;
-    const char *tiles;                 // screening tiles inside the packed codebook
+    const char *tiles;                 // bf16 hi/lo screening tiles inside the packed codebook
+    const char *tiles16;               // fp16 screening tiles (vq_screen16_kernel)
+    int n_tiles16;                     // fp16 tiles incl. padding tiles (multiple of VQ_F16_TILE_GROUP)
     const unsigned short *embed_bf16;  // bf16 codebook copy inside the packed codebook
     const float *embed;                // fp32 codebook (q rows of fp32 I/O)
-    const unsigned *scalars;           // [0] = float bits of max ||c||^2
+    const unsigned *scalars;           // [0] = float bits of max ||c||^2, [1] = float bits of max ||c - c_f16||, [2] = sc
     int C;
     int n_tiles;
     int64_t *idx_out;
@@ -66,7 +69,7 @@ struct ScreenArgs {
     int64_t ldr;
     double *sqerr_partial;             // nullable, one entry per workgroup
     const uint8_t *row_mask;
-    int *flag_count;
+    int *flag_count;                   // [0] open rows (list front), [1] pair rows (list back)
     int *flag_rows;
     unsigned long long *flag_keys;     // [N] keys of the exact pass, preset to ~0 for every appended row
     float *dbg;                        // nullable [N, 4]: t_best, t_second, eps_t, flagged
@@ -101,6 +104,26 @@ __device__ __forceinline__ void top2_tile(const f32x16 &acc, float &m1, float &m
         asm("v_max_f32 %0, %1, %2" : "=v"(m1) : "v"(m1), "v"(k));
     }
     tix = (m1 != om) ? ct : tix;
+}
+
+// best / second / third of a 16-score accumulator, and which tile the best and the second came from.  The third value
+// separates "the winner is one of two known codes" (decided by two exact distances, vq_pair_kernel) from "anything
+// goes" (full exact sweep): one more v_med3 per score.  When the new runner-up carries the bits of the old best, it IS the
+// old best (or an equal key, in which case second == third and the pair class is never entered).
+__device__ __forceinline__ void top3_tile(const f32x16 &acc, float &m1, float &m2, float &m3, int &t1, int &t2, int ct)
+{
+    const float om1 = m1, om2 = m2;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const float k = __uint_as_float((__float_as_uint(acc[e]) & 0xfffffff0u) | (unsigned)e);
+        m3 = __builtin_amdgcn_fmed3f(m2, m3, k);
+        m2 = __builtin_amdgcn_fmed3f(m1, m2, k);
+        asm("v_max_f32 %0, %1, %2" : "=v"(m1) : "v"(m1), "v"(k));
+    }
+    const bool c1 = m1 != om1;
+    const int from_old_best = (c1 && m2 == om1) ? t1 : ct;
+    t2 = (m2 != om2) ? from_old_best : t2;
+    t1 = c1 ? ct : t1;
 }
 
 // METRIC 0: Euclidean (t = x.c - ||c||^2 / 2).  METRIC 1: cosine on rows that are already unit-norm (t = x.c, the
@@ -439,6 +462,553 @@ __global__ void __launch_bounds__(VQS_WAVES * 64, 8 / VQS_WAVES) vq_screen_kerne
 }
 
 // ------------------------------------------------------------------------------------------------
+// Single-pass fp16 screen for bf16 rows (vq_screen16_kernel).  Half the MFMAs of the hi/lo kernel above:
+//   * bf16 rows are converted to fp16 in registers after an exact power-of-two scaling 2^SX chosen per WAVE so that the
+//     largest element of the wave's 64 rows lands in [2^14, 2^15): a bf16 value (8 significant bits) is an exact fp16
+//     value (11 bits) unless it falls below 2^-14 after scaling, i.e. below 2^-28 of the wave's largest element -- those
+//     elements are truncated with an absolute error <= 2^-24 (scaled units) that the threshold charges;
+//   * the codebook comes as ONE fp16 part, c_h = fp16(c 2^sc) (vq_pack16_kernel): 11 significant bits instead of the
+//     16 of the hi/lo split.  The certificate charges the rounding through the exact residual norm,
+//     |x.(c - c_h)| <= X * max_c ||c - c_h|| (scalars[1]), for both codes of the margin;
+//   * scores live in scaled units, t' = 2^(SX + sc) (x.c_h - ||c||^2 / 2): the accumulator starts at -||c||^2/2 * 2^(SX+sc)
+//     (one v_mul per score register and tile, shared by both row blocks through the MFMA's separate C operand);
+//   * the MFMA accumulation term of the bound halves as well (D + 1 added terms instead of 2 D + 1);
+//   * rows that fail the (larger) threshold go to the exact pass as before.  Measured on the reference's default init at
+//     cfg 2: see DESIGN.md.
+// The loop processes SUB 32-code tiles per barrier (one LDS buffer = SUB tiles, double buffered).
+// Outputs (q rows, residual rows, squared error) are produced by a row-cooperative pass that re-reads x -- the registers
+// hold the scaled fp16 copy -- which also frees the sweep from the output phase's registers.
+// ------------------------------------------------------------------------------------------------
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+
+#ifndef VQS16_PF
+#define VQS16_PF 4
+#endif
+
+template <int DT> struct Screen16Cfg {
+    static constexpr int TILE_B = 64 * DT + 1024;
+#ifdef VQS16_SUB
+    static constexpr int SUB = VQS16_SUB;
+#else
+    static constexpr int SUB = DT >= 256 ? 2 : (DT == 128 ? 4 : 8);   // 32-code tiles per barrier (divides VQ_F16_TILE_GROUP)
+#endif
+    static constexpr int BUF_B = (SUB * TILE_B / 1024 + VQS_WAVES - 1) / VQS_WAVES * VQS_WAVES * 1024;   // whole pieces for every wave
+    static constexpr int SMEM = 2 * BUF_B;
+};
+
+template <int DT, int METRIC>
+__global__ void __launch_bounds__(VQS_WAVES * 64, 8 / VQS_WAVES) vq_screen16_kernel(const ScreenArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    using Cfg = Screen16Cfg<DT>;
+    constexpr int TILE_B = Cfg::TILE_B;
+    constexpr int SUB = Cfg::SUB;
+    constexpr int SUPER_B = SUB * TILE_B;           // bytes per LDS buffer
+    constexpr int NCHUNK = SUPER_B / 1024;          // 1-KiB pieces per buffer
+    constexpr int NK = DT / 16;                     // MFMA k-steps = steps per tile (one MFMA per row block each)
+    constexpr int PMAX = (NCHUNK + VQS_WAVES - 1) / VQS_WAVES;   // pieces per wave and buffer
+    constexpr int BUF_B = Cfg::BUF_B;               // LDS bytes per buffer: PMAX pieces for EVERY wave, so that no copy is conditional
+    constexpr int PPS = (PMAX + SUB - 1) / SUB;     // pieces a wave copies during one tile
+    constexpr int NBS = (NK >= 16) ? 2 : 1;         // staging batches per tile
+    constexpr int BS = (PPS + NBS - 1) / NBS;
+    constexpr int SPAN = NK / NBS;                  // steps between batch starts
+    constexpr int LAG = (SPAN >= 8) ? SPAN - 2 : SPAN - 1;   // steps between a batch's loads and its LDS stores
+    static_assert(VQ_F16_TILE_GROUP % SUB == 0, "tile padding must cover the tiles of one barrier");
+    static_assert(LAG >= 1 && (NBS - 1) * SPAN + LAG < NK, "staging schedule");
+    constexpr int BS2 = (PPS + 1) / 2;              // skewed sweep: two staging batches per tile, one per row-block phase
+    constexpr int LAG2 = (NK >= 8) ? NK - 2 : NK - 1;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 31;
+    const int half = lane >> 5;
+    const int64_t wrow0 = (int64_t)blockIdx.x * VQ_SCREEN_ROWS + wave * 64;
+    VQ_PHASE(0);
+
+    // ---- first buffer: wave w copies the 1-KiB pieces w, w + WAVES, ... ----
+    constexpr int PSTRIDE = VQS_WAVES * 1024;
+    const int piece_off = wave * 1024 + lane * 16;
+    const char *tiles = a.tiles16;
+
+    // ---- x rows (bf16), requested first: lane (j, half) holds x[row][16 ks + 8 half + 0..7] for every k-step ----
+    uint4 xb[2][NK];
+    int64_t rows[2];
+    bool row_ok[2];
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) {
+        rows[rb] = wrow0 + rb * 32 + j;
+        row_ok[rb] = rows[rb] < a.N;
+        const int64_t rc = row_ok[rb] ? rows[rb] : (a.N - 1);
+        const unsigned short *p = (const unsigned short *)a.x + rc * a.ldx + 8 * half;
+#pragma unroll
+        for (int ks = 0; ks < NK; ++ks) xb[rb][ks] = *(const uint4 *)(p + ks * 16);
+    }
+    // ---- first buffer: wave w copies the 1-KiB pieces w, w + WAVES, ... (PMAX of them: a piece past the buffer's end reads
+    //      the next tiles / the tail pad and lands in the LDS pad) ----
+#pragma unroll
+    for (int k = 0; k < PMAX; ++k)
+        *(f32x4 *)(smem + piece_off + k * PSTRIDE) = *(const f32x4 *)(tiles + piece_off + (size_t)k * PSTRIDE);
+
+    // ---- ||x||^2 per row (any order: it only scales the bound) ----
+    float xs2[2];
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) {
+        float xs = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < NK; ++ks) {
+            const unsigned w[4] = {xb[rb][ks].x, xb[rb][ks].y, xb[rb][ks].z, xb[rb][ks].w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                xs = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, w[q]), __builtin_bit_cast(bf16x2, w[q]), xs, false);
+        }
+        xs += __shfl_xor(xs, 32, 64);
+        xs2[rb] = xs * 1.001f;
+    }
+    // scale exponents.  SX: every element is <= ||x||, so bringing the largest FINITE row norm of the wave below 2^14 keeps
+    // every element of those rows below fp16's 65504 (rows with a non-finite norm can never be certified anyway); elements
+    // then sit around 2^14 / sqrt(D), far above fp16's 2^-14.  sc is the codebook's (scalars[2]); the sum SX + sc is kept
+    // inside fp32's exponent range so that every power of two below is exact.
+    unsigned mx = 0;
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) {
+        const unsigned bits = __float_as_uint(xs2[rb]);
+        const unsigned fin = (bits & 0x7f800000u) == 0x7f800000u ? 0u : (bits & 0x7fffffffu);
+        mx = fin > mx ? fin : mx;
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) { const unsigned t = (unsigned)__shfl_xor((int)mx, o, 64); mx = t > mx ? t : mx; }
+    mx = (unsigned)__builtin_amdgcn_readfirstlane((int)mx);
+    const int sc = (int)a.scalars[2];
+    const int e2 = (int)(mx >> 23) - 127;          // largest ||x||^2 in [2^e2, 2^(e2+1))  =>  ||x|| < 2^((e2 >> 1) + 1)
+    int SX = (mx == 0u) ? 0 : 14 - ((e2 >> 1) + 1);
+    SX = SX > 120 - sc ? 120 - sc : SX;
+    SX = SX < -120 - sc ? -120 - sc : SX;
+    SX = SX > sc + 90 ? sc + 90 : SX;      // -||c||^2/2 * 2^(SX+sc) < 2^27 * 2^(SX-sc) stays finite (rows that tiny against the codebook
+                                           // lose bits in the conversion, which `conv` below charges)
+    SX = SX > 126 ? 126 : (SX < -126 ? -126 : SX);
+    const float S = __uint_as_float((unsigned)(SX + 127) << 23);
+    const float SS = __uint_as_float((unsigned)(SX + sc + 127) << 23);
+    const float iSS = __uint_as_float((unsigned)(127 - SX - sc) << 23);
+
+    // ---- threshold (unscaled units; see the file header for the terms that did not change) ----
+    float eps[2];
+    {
+        const float y2max = __uint_as_float(a.scalars[0]);
+        const float rmax = __uint_as_float(a.scalars[1]);
+        const float ymax = sqrtf(y2max) * 1.0001f;
+        const float u = 5.9604645e-8f;   // 2^-24
+        // truncated elements: |dx_k| <= 2^-24 / S each, sum_k |dx_k| |c1_k - c2_k| <= 2^-24 / S * sqrt(D) * 2 Y
+        const float conv = 2.f * 5.9604645e-8f * sqrtf((float)DT) * ymax * __uint_as_float((unsigned)(127 - SX) << 23);
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) {
+            const float xs = xs2[rb];
+            const float xn = sqrtf(xs) * 1.0001f;
+            const float xy = xn * ymax;
+            if (METRIC == 0) eps[rb] = u * (10.f * (xs + y2max + 2.f * xy) + 2.f * DT * xy + 4.f * (DT + 1) * 1.001f * (xy + 0.5f * y2max))
+                                       + 2.f * xn * rmax + conv + 4e-8f;
+            else             eps[rb] = 2.f * (u * 3.f * DT * 1.001f * xy + xn * rmax) + conv + 1e-30f;
+        }
+    }
+
+    // ---- bf16 -> scaled fp16, in place ----
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int ks = 0; ks < NK; ++ks) {
+            unsigned w[4] = {xb[rb][ks].x, xb[rb][ks].y, xb[rb][ks].z, xb[rb][ks].w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float lo = __uint_as_float(w[q] << 16) * S, hi = __uint_as_float(w[q] & 0xffff0000u) * S;
+                w[q] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(lo, hi));
+            }
+            xb[rb][ks] = make_uint4(w[0], w[1], w[2], w[3]);
+        }
+
+    float m1[2] = {-__builtin_inff(), -__builtin_inff()};
+    float m2[2] = {-__builtin_inff(), -__builtin_inff()};
+    float m3[2] = {-__builtin_inff(), -__builtin_inff()};
+    int tix[2] = {0, 0}, tix2[2] = {0, 0};
+    VQ_PHASE(1);
+
+    const int nst = a.n_tiles16 / SUB;   // barriers
+#ifndef VQS16_FLAT
+    // ---- skewed sweep: a tile is swept for row block 0 (NK MFMAs into acc0), then for row block 1 (NK MFMAs into acc1).
+    //      The top-3 epilogue of a finished accumulator is issued in slices BETWEEN the MFMAs of the other row block -- acc1 of
+    //      the previous tile beside this tile's row-block-0 MFMAs, acc0 beside the row-block-1 MFMAs -- so a wave's VALU work
+    //      runs in the shadow of its own matrix instructions (measured: a lone wave needed 2.5k cycles per tile for 1k cycles
+    //      of MFMA issue with the epilogue behind the MFMAs).  Costs a second LDS read of every A fragment, no registers. ----
+    f32x16 pa1;                                           // row block 1's scores of the previous tile
+#pragma unroll
+    for (int r = 0; r < 16; ++r) pa1[r] = -3.0e38f;      // "a padding code": never wins against a real one
+    int ptile = 0;
+    // one score into (best, second, third).  The key is formed by the compiler (it pads the MFMA -> VALU read hazard of
+    // acc[e]); the three updates are ONE volatile asm statement: as builtins, hipcc sinks every v_med3 of a tile behind the
+    // tile's last MFMA (their results are only needed there), which un-does the overlap and keeps 32 temporaries alive.
+    auto fold = [&](const f32x16 &acc, int e, float &b1, float &b2, float &b3) {
+        const float k = __uint_as_float((__float_as_uint(acc[e]) & 0xfffffff0u) | (unsigned)e);
+        asm volatile("v_med3_f32 %2, %1, %2, %3\n\tv_med3_f32 %1, %0, %1, %3\n\tv_max_f32 %0, %0, %3"
+                     : "+v"(b1), "+v"(b2), "+v"(b3) : "v"(k));
+    };
+    auto book = [&](float om1, float om2, float n1, float n2, int &t1, int &t2, int tile_id) {   // which tiles hold best / second
+        const bool c1 = n1 != om1;
+        const int from_old_best = (c1 && n2 == om1) ? t1 : tile_id;
+        t2 = (n2 != om2) ? from_old_best : t2;
+        t1 = c1 ? tile_id : t1;
+    };
+    for (int st = 0; st < nst; ++st) {
+        const int buf = st & 1;
+        const int ct = st;   // trace index
+        VQ_STAMP(0);
+        __syncthreads();     // buffer `buf` has landed for every wave; the other buffer is free
+        VQ_STAMP(1);
+        const char *sbase = smem + buf * BUF_B;
+        const bool more = st + 1 < nst;
+        const char *gsrc = tiles + (size_t)(more ? st + 1 : st) * SUPER_B + piece_off;
+        char *ldst = smem + (buf ^ 1) * BUF_B + piece_off;   // (the last interval re-copies its own buffer into the idle one: no branch)
+#pragma unroll 1
+        for (int sub = 0; sub < SUB; ++sub) {
+            const char *tile = sbase + sub * TILE_B;
+            const float *nh = (const float *)(tile + 64 * DT);
+            const int tile_id = st * SUB + sub;
+            const bool has_pad = (tile_id + 1) * 32 > a.C;
+            const uint4 *ap = (const uint4 *)tile + lane;
+            uint4 af[VQS16_PF];
+            f32x4 stg[BS];
+            f32x16 acc0, acc1;
+            const int p0 = sub * PPS;
+            float o1 = m1[1], o2 = m2[1];     // row block 1's best / second before the previous tile is folded in
+            f32x16 init;
+#pragma unroll
+            for (int p = 0; p < VQS16_PF; ++p) af[p] = ap[(p % NK) * 64];
+#pragma unroll
+            for (int s = 0; s < 2 * NK; ++s) {
+                const int ph = s / NK, ks = s % NK;
+                const f16x8 av = __builtin_bit_cast(f16x8, af[s % VQS16_PF]);
+#ifdef VQS16_INIT2
+                if (ks == 0) {
+#else
+                if (s == 0) {
+#endif
+                    // start value -||c||^2 / 2 (scaled); register e <-> code 8 (e >> 2) + 4 half + (e & 3) of the tile.  Tiles with
+                    // padding codes clamp it to a finite -3e38 (scaled, the padding's -3e38 overflows to -inf, and -inf with the
+                    // code number in its mantissa is a NaN key that v_med3_f32 must never see).
+                    if (METRIC == 0 || has_pad) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            f32x4 v = *(const f32x4 *)(nh + 8 * q + 4 * half);
+                            if (METRIC != 0) { v.x = v.x < -1e38f ? v.x : 0.f; v.y = v.y < -1e38f ? v.y : 0.f;
+                                               v.z = v.z < -1e38f ? v.z : 0.f; v.w = v.w < -1e38f ? v.w : 0.f; }
+                            init[4 * q + 0] = v.x * SS; init[4 * q + 1] = v.y * SS; init[4 * q + 2] = v.z * SS; init[4 * q + 3] = v.w * SS;
+                        }
+                        if (has_pad) {
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) init[r] = fmaxf(init[r], -3.0e38f);
+                        }
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) init[r] = 0.f;
+                    }
+                }
+                if (ks == 0) {
+                    if (ph == 0) acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, __builtin_bit_cast(f16x8, xb[0][ks]), init, 0, 0, 0);
+                    else         acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, __builtin_bit_cast(f16x8, xb[1][ks]), init, 0, 0, 0);
+                } else {
+                    if (ph == 0) acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, __builtin_bit_cast(f16x8, xb[0][ks]), acc0, 0, 0, 0);
+                    else         acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, __builtin_bit_cast(f16x8, xb[1][ks]), acc1, 0, 0, 0);
+                }
+                if (s + VQS16_PF < 2 * NK) af[s % VQS16_PF] = ap[((s + VQS16_PF) % NK) * 64];
+#ifndef VQS16_NO_EPI
+                // epilogue slice of the accumulator the OTHER row block finished: independent of the MFMA just issued
+                if (ks >= 1) {   // the 16 scores spread evenly over the steps 1 .. NK - 1 of the phase
+#pragma unroll
+                    for (int e = (ks - 1) * 16 / (NK - 1); e < ks * 16 / (NK - 1); ++e) {
+                        if (ph == 0) fold(pa1, e, m1[1], m2[1], m3[1]);
+                        else         fold(acc0, e, m1[0], m2[0], m3[0]);
+                    }
+                }
+#endif
+                __builtin_amdgcn_sched_barrier(0);   // pins the slice and the prefetch distance between the MFMAs
+                if (s == NK - 1) {                    // the previous tile's row block 1 is folded in: which tiles hold its best / second
+                    book(o1, o2, m1[1], m2[1], tix[1], tix2[1], ptile);
+                    o1 = m1[0]; o2 = m2[0];           // row block 0's state before this tile's scores
+                }
+#ifndef VQS16_NO_STAGE
+#pragma unroll
+                for (int bt = 0; bt < 2; ++bt) {
+                    if (s == bt * NK) {
+#pragma unroll
+                        for (int i = 0; i < BS2; ++i)   // unconditional (a guarded load makes hipcc wait right behind it, a guarded store
+                            if (bt * BS2 + i < PPS) {   // costs a scalar branch each): a piece past this wave's share repeats its last one
+                                const int pc = min(p0 + bt * BS2 + i, PMAX - 1);
+                                stg[i] = *(const f32x4 *)(gsrc + (size_t)pc * PSTRIDE);
+                            }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    if (s == bt * NK + LAG2) {
+#pragma unroll
+                        for (int i = 0; i < BS2; ++i)
+                            if (bt * BS2 + i < PPS) *(f32x4 *)(ldst + min(p0 + bt * BS2 + i, PMAX - 1) * PSTRIDE) = stg[i];
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+#endif
+            }
+#ifndef VQS16_NO_EPI
+            book(o1, o2, m1[0], m2[0], tix[0], tix2[0], tile_id);
+#else
+            m1[0] = fmaxf(m1[0], acc0[st & 15]);
+#endif
+            pa1 = acc1;
+            ptile = tile_id;
+        }
+        VQ_STAMP(2);
+    }
+    {   // row block 1 of the last tile
+        const float o1 = m1[1], o2 = m2[1];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) fold(pa1, e, m1[1], m2[1], m3[1]);
+        book(o1, o2, m1[1], m2[1], tix[1], tix2[1], ptile);
+    }
+#else   // VQS16_FLAT: both row blocks interleaved, epilogue behind the tile's MFMAs (first version, kept for A/B runs)
+    for (int st = 0; st < nst; ++st) {
+        const int buf = st & 1;
+        const int ct = st;   // trace index
+        VQ_STAMP(0);
+        __syncthreads();     // buffer `buf` has landed for every wave; the other buffer is free
+        VQ_STAMP(1);
+        const char *sbase = smem + buf * BUF_B;
+        const bool more = st + 1 < nst;
+        const char *gsrc = tiles + (size_t)(more ? st + 1 : st) * SUPER_B + piece_off;
+        char *ldst = smem + (buf ^ 1) * BUF_B + piece_off;
+        const int npieces = more ? (NCHUNK - wave + VQS_WAVES - 1) / VQS_WAVES : 0;
+
+        // NOT unrolled over the tiles of a buffer: unrolled, hipcc hoists every tile's LDS reads to the top of the interval
+        // and spills the resident rows; each tile stages its own share (PPS pieces) of the next buffer instead
+#pragma unroll 1
+        for (int sub = 0; sub < SUB; ++sub) {
+            const char *tile = sbase + sub * TILE_B;
+            // accumulators start at -||c||^2 / 2 (scaled); register e <-> code 8 (e >> 2) + 4 half + (e & 3) of the tile.
+            // Tiles that contain padding codes (the ragged last tile, the tiles that pad the count to a multiple of SUB) clamp the
+            // start value to a finite -3e38: scaled, the padding's -3e38 would overflow to -inf, and -inf with the code number
+            // in its mantissa bits is a NaN key that v_med3_f32 must never see.
+            const float *nh = (const float *)(tile + 64 * DT);
+            const bool has_pad = (st * SUB + sub + 1) * 32 > a.C;
+            f32x16 init;
+            if (METRIC == 0 || has_pad) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    f32x4 v = *(const f32x4 *)(nh + 8 * q + 4 * half);
+                    if (METRIC != 0) { v.x = v.x < -1e38f ? v.x : 0.f; v.y = v.y < -1e38f ? v.y : 0.f;
+                                       v.z = v.z < -1e38f ? v.z : 0.f; v.w = v.w < -1e38f ? v.w : 0.f; }
+                    init[4 * q + 0] = v.x * SS; init[4 * q + 1] = v.y * SS; init[4 * q + 2] = v.z * SS; init[4 * q + 3] = v.w * SS;
+                }
+                if (has_pad) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) init[r] = fmaxf(init[r], -3.0e38f);
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) init[r] = 0.f;
+            }
+            f32x16 acc0, acc1;
+            const uint4 *ap = (const uint4 *)tile + lane;
+            uint4 af[VQS16_PF];
+            f32x4 stg[BS];
+            const int p0 = sub * PPS;   // first piece of this tile's share
+#pragma unroll
+            for (int p = 0; p < VQS16_PF; ++p) af[p] = ap[(p < NK ? p : 0) * 64];
+#pragma unroll
+            for (int s = 0; s < NK; ++s) {
+                const f16x8 av = __builtin_bit_cast(f16x8, af[s % VQS16_PF]);
+                if (s == 0) {
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, __builtin_bit_cast(f16x8, xb[0][s]), init, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, __builtin_bit_cast(f16x8, xb[1][s]), init, 0, 0, 0);
+                } else {
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, __builtin_bit_cast(f16x8, xb[0][s]), acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, __builtin_bit_cast(f16x8, xb[1][s]), acc1, 0, 0, 0);
+                }
+                if (s + VQS16_PF < NK) af[s % VQS16_PF] = ap[(s + VQS16_PF) * 64];
+                __builtin_amdgcn_sched_barrier(0);   // keep the prefetch distance: hipcc otherwise sinks the ds_reads next to their use
+#ifndef VQS16_NO_STAGE
+#pragma unroll
+                for (int b = 0; b < NBS; ++b) {
+                    if (s == b * SPAN) {
+#pragma unroll
+                        for (int i = 0; i < BS; ++i)   // unconditional loads (a guarded load makes hipcc wait right behind it): a piece
+                            if (b * BS + i < PPS) {    // past this wave's share re-reads its last one
+                                const int pc = min(p0 + b * BS + i, PMAX - 1);
+                                stg[i] = *(const f32x4 *)(gsrc + (size_t)pc * PSTRIDE);
+                            }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    if (s == b * SPAN + LAG) {
+#pragma unroll
+                        for (int i = 0; i < BS; ++i)
+                            if (b * BS + i < PPS && p0 + b * BS + i < npieces) *(f32x4 *)(ldst + (p0 + b * BS + i) * PSTRIDE) = stg[i];
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+#endif
+            }
+#ifndef VQS16_NO_EPI
+#ifdef VQS16_TOP2   // A/B: no third value, no pair class (every uncertified row takes the full exact sweep)
+            top2_tile(acc0, m1[0], m2[0], tix[0], st * SUB + sub);
+            top2_tile(acc1, m1[1], m2[1], tix[1], st * SUB + sub);
+#else
+            top3_tile(acc0, m1[0], m2[0], m3[0], tix[0], tix2[0], st * SUB + sub);
+            top3_tile(acc1, m1[1], m2[1], m3[1], tix[1], tix2[1], st * SUB + sub);
+#endif
+#else
+            m1[0] = fmaxf(m1[0], acc0[st & 15]); m1[1] = fmaxf(m1[1], acc1[st & 15]);
+#endif
+        }
+        VQ_STAMP(2);
+    }
+
+#endif
+
+    VQ_PHASE(2);   // sweep done
+    // ---- merge the half-waves (each holds the top 3 of its 16 of a tile's 32 codes), classify, emit ----
+    //   certified:  best - second > thr                      -> final here
+    //   pair:       best - third  > thr (second is too close) -> vq_pair_kernel decides between the two codes exactly
+    //   open:       otherwise                                 -> full exact sweep (vq_refine_kernel)
+    int code[2], cls[2], id2s[2];
+    bool flagged[2];
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) {
+        const int e1 = (int)(__float_as_uint(m1[rb]) & 15u), e2 = (int)(__float_as_uint(m2[rb]) & 15u);
+        const int ia1 = tix[rb] * 32 + 8 * (e1 >> 2) + 4 * half + (e1 & 3);
+        const int ia2 = tix2[rb] * 32 + 8 * (e2 >> 2) + 4 * half + (e2 & 3);
+        const float a1 = m1[rb], a2 = m2[rb], a3 = m3[rb];
+        const float p1 = __shfl_xor(a1, 32, 64), p2 = __shfl_xor(a2, 32, 64), p3 = __shfl_xor(a3, 32, 64);
+        const int ib1 = __shfl_xor(ia1, 32, 64), ib2 = __shfl_xor(ia2, 32, 64);
+        // merge of two descending triples (a from this half, p from the partner)
+        const bool take = p1 > a1;
+        const float h1 = take ? p1 : a1, h2 = take ? p2 : a2, h3 = take ? p3 : a3;   // the triple that holds the best
+        const float l1 = take ? a1 : p1, l2 = take ? a2 : p2;                          // the other one
+        const int ih1 = take ? ib1 : ia1, ih2 = take ? ib2 : ia2, il1 = take ? ia1 : ib1;
+        const float b1 = h1;
+        const bool second_low = l1 > h2;                  // runner-up comes from the other triple
+        const float b2 = second_low ? l1 : h2;
+        const int id2 = second_low ? il1 : ih2;
+        const float b3 = second_low ? fmaxf(h2, l2) : fmaxf(h3, l1);
+        code[rb] = ih1;
+        const float thr = eps[rb] * SS + 8e-6f * fabsf(b1);
+        const bool certified = ((b1 - b2) > thr) && code[rb] < a.C;
+        const bool pair = !certified && ((b1 - b3) > thr) && code[rb] < a.C && id2 < a.C;
+        flagged[rb] = !certified;
+        if (row_ok[rb] && half == 0) {
+            a.idx_out[rows[rb]] = (int64_t)(code[rb] < a.C ? code[rb] : 0);
+            if (a.dbg) {
+                float *d = a.dbg + rows[rb] * 4;
+                d[0] = b1 * iSS; d[1] = b2 * iSS; d[2] = thr * iSS; d[3] = certified ? 0.f : (pair ? 2.f : 1.f);
+            }
+        }
+        if (code[rb] >= a.C) code[rb] = 0;
+        const bool on = row_ok[rb] && half == 0;
+        cls[rb] = !on ? 0 : (certified ? 0 : (pair ? 2 : 1));
+        id2s[rb] = id2;
+    }
+    // the uncertified rows go to their lists -- open rows from the front, pair rows from the back of the same arrays.  ONE
+    // atomic per wave and list, issued here; the slots are only needed after the output phase, which hides the round trip
+    // (four dependent atomics in a row cost 20k cycles per workgroup)
+    const unsigned long long balo0 = __ballot(cls[0] == 1), balo1 = __ballot(cls[1] == 1);
+    const unsigned long long balp0 = __ballot(cls[0] == 2), balp1 = __ballot(cls[1] == 2);
+    const int n_open = (int)(__popcll(balo0) + __popcll(balo1)), n_pair = (int)(__popcll(balp0) + __popcll(balp1));
+    int base_o = 0, base_p = 0;
+    if (lane == 0) {
+        if (n_open) base_o = atomicAdd(a.flag_count, n_open);
+        if (n_pair) base_p = atomicAdd(a.flag_count + 1, n_pair);
+    }
+
+    VQ_PHASE(3);   // idx + list written
+    // ---- outputs: whole rows per wave instruction (lane l moves elements 4 l .. 4 l + 3), RU rows in flight; x is re-read
+    //      (coalesced) for the squared error and the residual.  Rows of the exact pass are skipped in the loss here. ----
+    double ds = 0.0;
+    if (a.q_out || a.resid_out || a.sqerr_partial) {
+        constexpr int RU = 16;
+        const bool want_x = a.sqerr_partial != nullptr || a.resid_out != nullptr;
+        const bool lane_on = lane * 4 < DT;
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) {
+            const bool counted = row_ok[rb] && !flagged[rb] && (!a.row_mask || a.row_mask[rows[rb]] != 0);
+            const unsigned long long cmask = __ballot(counted && half == 0);
+#pragma unroll
+            for (int r0 = 0; r0 < 32; r0 += RU) {
+                uint2 g[RU], xv[RU];
+#pragma unroll
+                for (int u = 0; u < RU; ++u) {
+                    const int c = __builtin_amdgcn_readlane(code[rb], r0 + u);
+                    const int64_t rr = wrow0 + rb * 32 + r0 + u;
+                    if (lane_on) {
+                        g[u] = *(const uint2 *)(a.embed_bf16 + (size_t)c * DT + lane * 4);
+                        if (want_x) xv[u] = *(const uint2 *)((const unsigned short *)a.x + (rr < a.N ? rr : a.N - 1) * a.ldx + lane * 4);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < RU; ++u) {
+                    const int64_t rr = wrow0 + rb * 32 + r0 + u;
+                    if (rr < a.N && lane_on) {
+                        if (a.q_out) *(uint2 *)((unsigned short *)a.q_out + rr * a.ldq + lane * 4) = g[u];
+                        if (a.resid_out) *(uint2 *)((unsigned short *)a.resid_out + rr * a.ldr + lane * 4) = vq_bf16x4_sub(xv[u], g[u]);
+                    }
+                    if (a.sqerr_partial && lane_on && ((cmask >> (r0 + u)) & 1ull)) {
+                        const float d0 = __uint_as_float(g[u].x << 16) - __uint_as_float(xv[u].x << 16);
+                        const float d1 = __uint_as_float(g[u].x & 0xffff0000u) - __uint_as_float(xv[u].x & 0xffff0000u);
+                        const float d2 = __uint_as_float(g[u].y << 16) - __uint_as_float(xv[u].y << 16);
+                        const float d3 = __uint_as_float(g[u].y & 0xffff0000u) - __uint_as_float(xv[u].y & 0xffff0000u);
+                        ds += (double)(((d0 * d0 + d1 * d1) + d2 * d2) + d3 * d3);
+                    }
+                }
+            }
+        }
+    }
+    if (n_open) {
+        const int bo = __builtin_amdgcn_readfirstlane(base_o);
+        const unsigned long long below = (1ull << lane) - 1ull;
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) {
+            const unsigned long long bal = rb ? balo1 : balo0;
+            if (cls[rb] == 1) {
+                const int slot = bo + (rb ? (int)__popcll(balo0) : 0) + (int)__popcll(bal & below);
+                a.flag_rows[slot] = (int)rows[rb];
+                a.flag_keys[slot] = ~0ull;
+            }
+        }
+    }
+    if (n_pair) {
+        const int bp = __builtin_amdgcn_readfirstlane(base_p);
+        const unsigned long long below = (1ull << lane) - 1ull;
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) {
+            const unsigned long long bal = rb ? balp1 : balp0;
+            if (cls[rb] == 2) {
+                const int64_t slot = a.N - 1 - (bp + (rb ? (int)__popcll(balp0) : 0) + (int)__popcll(bal & below));
+                a.flag_rows[slot] = (int)rows[rb];
+                a.flag_keys[slot] = (unsigned long long)(unsigned)code[rb] | ((unsigned long long)(unsigned)id2s[rb] << 32);
+            }
+        }
+    }
+    VQ_PHASE(4);
+    if (a.sqerr_partial) {
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) ds += __shfl_xor(ds, o, 64);
+        __syncthreads();
+        double *red = (double *)smem;
+        if (lane == 0) red[wave] = ds;
+        __syncthreads();
+        if (tid == 0) {
+            double t = 0.0;
+#pragma unroll
+            for (int w = 0; w < VQS_WAVES; ++w) t += red[w];
+            a.sqerr_partial[blockIdx.x] = t;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // fp32 rows.  x is split as well, x = x_hi + x_mid + r_x (bf16 parts, |r_x| <= 2^-16 |x|), and three products are
 // accumulated per k-step: c_hi x_hi, c_hi x_mid, c_lo x_hi.  Dropped: c_lo x_mid, c r_x, r_c x -- each <= 2^-16 |x||c|
 // (+ second order), so the split term of the bound becomes 3.03 * 2 * 2^-16 X Y <= 1600 u X Y and the accumulation term
@@ -713,14 +1283,28 @@ extern "C" int vqhip_screen_supported(int64_t N, int D, int C)
     return (D == 32 || D == 64 || D == 128 || D == 256) && N > 0 && N < ((int64_t)1 << 31) - 512 && C >= 2;
 }
 
+// VQHIP_SCREEN_BF16X2=1 selects the two-pass bf16 hi/lo kernel for bf16 rows (A/B runs against vq_screen16_kernel)
+static bool screen_bf16x2()
+{
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("VQHIP_SCREEN_BF16X2"); v = (e && e[0] == '1') ? 1 : 0; }
+    return v == 1;
+}
+
 template <int DT, int METRIC>
 static int launch_screen(const ScreenArgs &a, int x_dtype, hipStream_t st)
 {
     constexpr int SMEM = 2 * (128 * DT + 1024);
-    static VqAttrOnce once_b, once_f;
+    static VqAttrOnce once_b, once_f, once_h;
+    const unsigned blocks = (unsigned)vqhip_screen_blocks(a.N, x_dtype);
+    if (x_dtype == VQHIP_BF16 && !screen_bf16x2()) {
+        constexpr int SMEM16 = Screen16Cfg<DT>::SMEM;
+        if (int rc = vq_set_max_smem(once_h, (const void *)vq_screen16_kernel<DT, METRIC>, SMEM16, "vq_screen16_kernel")) return rc;
+        hipLaunchKernelGGL((vq_screen16_kernel<DT, METRIC>), dim3(blocks), dim3(VQS_WAVES * 64), SMEM16, st, a);
+        return vq_launch_status("vq_screen16_kernel");
+    }
     if (int rc = vq_set_max_smem(once_b, (const void *)vq_screen_kernel<DT, METRIC>, SMEM, "vq_screen_kernel")) return rc;
     if (int rc = vq_set_max_smem(once_f, (const void *)vq_screen_f32_kernel<DT, METRIC>, SMEM, "vq_screen_f32_kernel")) return rc;
-    const unsigned blocks = (unsigned)vqhip_screen_blocks(a.N, x_dtype);
     if (x_dtype == VQHIP_BF16)
         hipLaunchKernelGGL((vq_screen_kernel<DT, METRIC>), dim3(blocks), dim3(VQS_WAVES * 64), SMEM, st, a);
     else
@@ -765,6 +1349,8 @@ extern "C" int vqhip_assign_screened(const void *x, int x_dtype, int64_t N, int 
     ScreenArgs a;
     a.x = x; a.N = N; a.ldx = ldx;
     a.tiles = base + vq_packed_screen_offset(C, D);
+    a.tiles16 = base + vq_packed_f16_offset(C, D);
+    a.n_tiles16 = (int)vq_tiles16(C);
     a.embed_bf16 = (const unsigned short *)(base + vq_packed_bf16_offset(C, D));
     a.embed = embed;
     a.scalars = (const unsigned *)(base + vq_packed_scalars_offset(C, D));
@@ -784,6 +1370,8 @@ extern "C" int vqhip_assign_screened(const void *x, int x_dtype, int64_t N, int 
         default: rc = dispatch_screen<256>(a, x_dtype, metric, st); break;
     }
     if (rc) return rc;
+    const int with_pairs = (x_dtype == VQHIP_BF16 && !screen_bf16x2()) ? 1 : 0;   // vq_screen16_kernel also builds the pair list
     return vq_assign_listed(x, x_dtype, metric, N, D, ldx, packed, embed, C, idx_out, q_out, ldq, resid_out, ldr,
-                            sqerr_partial ? sqerr_partial + vqhip_screen_blocks(N, x_dtype) : nullptr, row_mask, rows, count, keys, st);
+                            sqerr_partial ? sqerr_partial + vqhip_screen_blocks(N, x_dtype) : nullptr, row_mask, rows, count, keys,
+                            with_pairs, st);
 }

@@ -125,7 +125,7 @@ extern "C" size_t vqhip_packed_bytes(int C, int D)
 {
     const int DT = pick_dt(D);
     if (DT == 0 || C <= 0) return 0;
-    return vq_packed_scalars_offset(C, D) + 16;   // layout: vqhip_internal.h
+    return vq_packed_total_bytes(C, D);   // layout: vqhip_internal.h
 }
 
 __global__ void __launch_bounds__(256) vq_pack_kernel(const float *__restrict__ embed, int C, int D, int DT,
@@ -216,6 +216,72 @@ __global__ void __launch_bounds__(256) vq_pack_kernel(const float *__restrict__ 
     }
 }
 
+// Second pack phase (needs max ||c||^2 of the first): fp16 A-operand tiles of the single-pass screening kernel
+// (vq_screen.hip, vq_screen16_kernel).  The codebook is scaled by 2^sc so that max ||c|| lands in [2^13, 2^14) -- every
+// element then is below 2^14 and fp16 keeps 11 significant bits down to 2^-28 of the largest possible element -- and
+// rounded to fp16 (RNE); the kernel compensates the scale exactly (powers of two).  Same lane order as the bf16 tiles:
+// 16 bytes per lane and k-step; lane l = code (l & 31), k-slot 8 * (l >> 5) + e.  Tile tail: 32 floats -||c||^2 / 2
+// (-3e38 for padding codes).  scalars[1] <- max_c ||c - c_f16|| (the certificate charges X * that for the rounding),
+// scalars[2] <- sc.
+__global__ void __launch_bounds__(256) vq_pack16_kernel(const float *__restrict__ embed, int C, int D, int DT, int n_tiles,
+                                                        const float *__restrict__ packed, char *__restrict__ tiles16,
+                                                        unsigned *__restrict__ scalars)
+{
+    __shared__ float rsq[32];
+    const int t = blockIdx.x;
+    const unsigned y2bits = scalars[0];
+    int sc = 0;
+    if (y2bits != 0u) {
+        const int e2 = (int)((y2bits >> 23) & 0xffu) - 127;   // max ||c||^2 in [2^e2, 2^(e2+1))  =>  max ||c|| < 2^((e2 >> 1) + 1)
+        sc = 13 - (e2 >> 1);
+        sc = sc < -100 ? -100 : (sc > 100 ? 100 : sc);
+    }
+    const float Sc = __uint_as_float((unsigned)(sc + 127) << 23), iSc = __uint_as_float((unsigned)(127 - sc) << 23);
+    if (threadIdx.x < 32) rsq[threadIdx.x] = 0.f;
+    __syncthreads();
+    _Float16 *st = (_Float16 *)(tiles16 + (size_t)t * vq_tile16_bytes(DT));
+    for (int p = threadIdx.x; p < 4 * DT; p += 256) {   // one (k-step, lane) per iteration: 8 features -> one fp16 fragment
+        const int l = p & 63;
+        const int ks = p >> 6;
+        const int code = t * 32 + (l & 31);
+        const int k0 = ks * 16 + 8 * (l >> 5);
+        float v[8];
+        if (code < C && k0 + 8 <= D && (D & 3) == 0) {
+            const f32x4 a0 = *(const f32x4 *)(embed + (size_t)code * D + k0), a1 = *(const f32x4 *)(embed + (size_t)code * D + k0 + 4);
+            v[0] = a0.x; v[1] = a0.y; v[2] = a0.z; v[3] = a0.w; v[4] = a1.x; v[5] = a1.y; v[6] = a1.z; v[7] = a1.w;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (code < C && k0 + e < D) ? embed[(size_t)code * D + k0 + e] : 0.f;
+        }
+        typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+        f16x8 h;
+        float r2 = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const _Float16 he = (_Float16)(v[e] * Sc);          // the scaling is exact, the conversion rounds to nearest even
+            h[e] = he;
+            const float d = v[e] - (float)he * iSc;              // exact difference of two fp32 values that agree to 11 bits
+            r2 = __builtin_fmaf(d, d, r2);
+        }
+        *(f16x8 *)(st + ((size_t)ks * 64 + l) * 8) = h;
+        if (code < C) atomicAdd(&rsq[l & 31], r2);
+    }
+    __syncthreads();
+    {
+        float *nh = (float *)((char *)st + (size_t)64 * DT);
+        const int i = threadIdx.x;
+        const bool real = (i < 32) && (t * 32 + i < C);
+        // ||c||^2 of the tile's codes sits behind the fp32 tile of the exact section (written by vq_pack_kernel)
+        const float y2 = (real && t < n_tiles) ? packed[(size_t)t * (32 * DT + 256) + 32 * DT + i] : 0.f;
+        nh[i] = (i < 32) ? (real ? -0.5f * y2 : -3.0e38f) : 0.f;
+        if (real) {
+            const float r = sqrtf(rsq[i]) * 1.01f + 1e-38f;     // slack for the fp32 rounding of the sum above
+            atomicMax(scalars + 1, __float_as_uint(r));
+        }
+        if (t == 0 && i == 0) scalars[2] = (unsigned)sc;
+    }
+}
+
 extern "C" int vqhip_pack_codebook(const float *embed, int C, int D, float *packed, void *stream)
 {
     if (!embed || !packed || C <= 0) VQ_FAIL(VQHIP_EINVAL, "pack_codebook: null pointer or C <= 0");
@@ -225,11 +291,14 @@ extern "C" int vqhip_pack_codebook(const float *embed, int C, int D, float *pack
     const int tiles = (C + 31) / 32;
     char *base = (char *)packed;
     unsigned *scalars = (unsigned *)(base + vq_packed_scalars_offset(C, D));
-    hipError_t e = hipMemsetAsync(scalars, 0, 16, (hipStream_t)stream);
+    hipError_t e = hipMemsetAsync(scalars, 0, VQ_PACKED_SCALARS_BYTES, (hipStream_t)stream);
     if (e != hipSuccess) VQ_FAIL((int)e, "pack_codebook: hipMemsetAsync: %s", hipGetErrorString(e));
     hipLaunchKernelGGL(vq_pack_kernel, dim3(tiles), dim3(256), 0, (hipStream_t)stream, embed, C, D, DT, packed,
                        (unsigned short *)(base + packed_bf16_offset(C, D)), base + vq_packed_screen_offset(C, D), scalars);
-    return launch_status("vq_pack_kernel");
+    if (int rc = launch_status("vq_pack_kernel")) return rc;
+    hipLaunchKernelGGL(vq_pack16_kernel, dim3((unsigned)vq_tiles16(C)), dim3(256), 0, (hipStream_t)stream, embed, C, D, DT, tiles,
+                       (const float *)packed, base + vq_packed_f16_offset(C, D), scalars);
+    return launch_status("vq_pack16_kernel");
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -911,11 +980,14 @@ extern "C" int vqhip_l2norm_rows(const void *x, int x_dtype, int64_t N, int D, i
 // ------------------------------------------------------------------------------------------------
 // exact pass over a LIST of rows (the rows vq_screen.hip could not certify).  Same arithmetic as
 // vq_assign_kernel<DT, bf16, euclid> -- same device functions -- but organised for a short list: the codebook sweep
-// is split over gridDim.y workgroups per 128-row chunk (a few thousand rows would otherwise occupy a fraction of the
+// is split over several workgroups per 128-row chunk (a few thousand rows would otherwise occupy a fraction of the
 // CUs for a full sweep each), the partial winners meet in an atomicMin on the 64-bit key (bits(d) << 32 | index),
 // which is exactly "smallest distance, then lowest index", and vq_finish_listed_kernel emits index, q and the
 // squared error.  The list length is only known on the device: fixed grids, chunk loops.
 // ------------------------------------------------------------------------------------------------
+#ifndef VQ_REFINE_GRID
+#define VQ_REFINE_GRID 1024
+#endif
 struct RefineArgs {
     const void *x;
     int64_t ldx;
@@ -942,14 +1014,22 @@ __global__ void __launch_bounds__(256, 2) vq_refine_kernel(const RefineArgs a)
     const int j = lane & 31;
     const int hi = lane >> 5;
     const int list_n = __builtin_amdgcn_readfirstlane(*a.row_count);
-    const int tps = (a.n_tiles + (int)gridDim.y - 1) / (int)gridDim.y;   // tiles per split
-    const int ct0 = (int)blockIdx.y * tps;
-    const int ct1 = min(a.n_tiles, ct0 + tps);
-    if (ct0 >= ct1) return;
+    if (list_n <= 0) return;
+    // the list length only exists on the device: a fixed 1-D grid, and the codebook sweep of every 128-row chunk is split over
+    // as many workgroups as the grid has to spare (a short list would otherwise keep a handful of workgroups busy for a whole
+    // sweep each: 70 us for a few hundred rows); the partial winners meet in the atomicMin below
+    const int n_chunks = (list_n + VQHIP_ASSIGN_ROWS_PER_BLOCK - 1) / VQHIP_ASSIGN_ROWS_PER_BLOCK;
+    int splits = (int)gridDim.x / n_chunks;
+    splits = splits < 1 ? 1 : (splits > a.n_tiles ? a.n_tiles : splits);
+    const int tps = (a.n_tiles + splits - 1) / splits;   // tiles per split
+    splits = (a.n_tiles + tps - 1) / tps;
     const int my_pieces = (NCHUNK - wave + 3) / 4;
     const int piece_off = wave * 1024 + lane * 16;
 
-    for (int64_t chunk = blockIdx.x; chunk * VQHIP_ASSIGN_ROWS_PER_BLOCK < list_n; chunk += gridDim.x) {
+    for (int64_t w = blockIdx.x; w < (int64_t)n_chunks * splits; w += gridDim.x) {
+        const int64_t chunk = w / splits;
+        const int ct0 = (int)(w % splits) * tps;
+        const int ct1 = min(a.n_tiles, ct0 + tps);
         __syncthreads();   // the previous chunk's last tile has been consumed by every wave
         for (int k = 0; k < my_pieces; ++k)
             *(f32x4 *)(smem + piece_off + k * 4096) =
@@ -1024,7 +1104,8 @@ struct FinishArgs {
     const void *codes;       // bf16 rows: the bf16 codebook copy; fp32 rows: embed
     int D;
     const int *row_list;
-    const int *row_count;
+    const int *row_count;    // [0] rows of the full exact pass (list front), [1] rows of the pair pass (list back, from cap - 1 down)
+    int64_t cap;             // list capacity (N)
     const unsigned long long *keys;
     int64_t *idx_out;
     void *q_out;             // nullable, x's dtype
@@ -1042,9 +1123,11 @@ __global__ void __launch_bounds__(256) vq_finish_listed_kernel(const FinishArgs 
     __shared__ double red[4];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const int n = *a.row_count;
+    const int n_full = a.row_count[0];
+    const int n = n_full + a.row_count[1];
     double acc = 0.0;
-    for (int64_t pos = (int64_t)blockIdx.x * 4 + wave; pos < n; pos += (int64_t)gridDim.x * 4) {
+    for (int64_t v = (int64_t)blockIdx.x * 4 + wave; v < n; v += (int64_t)gridDim.x * 4) {
+        const int64_t pos = v < n_full ? v : a.cap - 1 - (v - n_full);
         const int64_t row = a.row_list[pos];
         const int idx = (int)(unsigned)(a.keys[pos] & 0xffffffffull);
         if (lane == 0) a.idx_out[row] = (int64_t)idx;
@@ -1082,48 +1165,151 @@ __global__ void __launch_bounds__(256) vq_finish_listed_kernel(const FinishArgs 
 }
 
 template <int DT, bool XBF16, int METRIC>
-static int launch_refine(const RefineArgs &a, unsigned gx, unsigned gy, hipStream_t st)
+static int launch_refine(const RefineArgs &a, unsigned gx, hipStream_t st)
 {
     constexpr int SMEM = 2 * (32 * DT + 256) * 4;
     static VqAttrOnce once;
     if (int rc = vq_set_max_smem(once, (const void *)vq_refine_kernel<DT, XBF16, METRIC>, SMEM, "vq_refine_kernel")) return rc;
-    hipLaunchKernelGGL((vq_refine_kernel<DT, XBF16, METRIC>), dim3(gx, gy), dim3(256), SMEM, st, a);
+    hipLaunchKernelGGL((vq_refine_kernel<DT, XBF16, METRIC>), dim3(gx), dim3(256), SMEM, st, a);
     return launch_status("vq_refine_kernel");
 }
 
 template <int DT>
-static int dispatch_refine(const RefineArgs &a, int x_dtype, int metric, unsigned gx, unsigned gy, hipStream_t st)
+static int dispatch_refine(const RefineArgs &a, int x_dtype, int metric, unsigned gx, hipStream_t st)
 {
     if (metric == VQHIP_EUCLID)
-        return x_dtype == VQHIP_BF16 ? launch_refine<DT, true, 0>(a, gx, gy, st) : launch_refine<DT, false, 0>(a, gx, gy, st);
-    return x_dtype == VQHIP_BF16 ? launch_refine<DT, true, 1>(a, gx, gy, st) : launch_refine<DT, false, 1>(a, gx, gy, st);
+        return x_dtype == VQHIP_BF16 ? launch_refine<DT, true, 0>(a, gx, st) : launch_refine<DT, false, 0>(a, gx, st);
+    return x_dtype == VQHIP_BF16 ? launch_refine<DT, true, 1>(a, gx, st) : launch_refine<DT, false, 1>(a, gx, st);
+}
+
+// Rows whose winner is one of TWO known codes (the screen's best and runner-up, every third code certified out):
+// both distances in the reference's own arithmetic -- ATen-order ||x||^2, ||c||^2 from the packed codebook, x.c as ONE fp32
+// FMA chain in ascending k (what the exact kernels' f32 MFMAs and oracle/vq_oracle.c compute), (x2 + y2) + (-2 xy),
+// clamp, correctly rounded sqrt -- smaller distance wins, the lower index on a tie (vqp.py:58-62, 140).  Cosine: the two
+// dot products of the unit-norm row, larger wins.  One row per lane; the winner replaces the candidates in keys[pos].
+struct PairArgs {
+    const void *x;
+    int64_t ldx;
+    const float *embed;
+    const float *packed;      // exact section: ||c||^2 sits behind each 32-code tile
+    int D;
+    const int *row_list;
+    const int *row_count;     // [1] = number of pair rows, stored at list positions cap - 1 - p
+    int64_t cap;
+    unsigned long long *keys;
+};
+
+template <int DT, bool XBF16, int METRIC>
+__global__ void __launch_bounds__(256) vq_pair_kernel(const PairArgs a)
+{
+    const int n = a.row_count[1];
+    for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < n; p += (int64_t)gridDim.x * 256) {
+        const int64_t pos = a.cap - 1 - p;
+        const int64_t row = a.row_list[pos];
+        const unsigned long long cand = a.keys[pos];
+        const int c1 = (int)(unsigned)(cand & 0xffffffffull), c2 = (int)(unsigned)(cand >> 32);
+        const float *e1 = a.embed + (size_t)c1 * DT, *e2 = a.embed + (size_t)c2 * DT;
+        float xy1 = 0.f, xy2 = 0.f;
+        float ch[32];                      // ATen-order ||x||^2: 32 interleaved chains, combined below (aten_sumsq_seq's order)
+#pragma unroll
+        for (int c = 0; c < 32; ++c) ch[c] = 0.f;
+#pragma unroll 2
+        for (int k0 = 0; k0 < DT; k0 += 32) {
+            float xv[32];
+            if (XBF16) {
+                const uint4 *px = (const uint4 *)((const unsigned short *)a.x + row * a.ldx + k0);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const uint4 w = px[q];
+                    const unsigned ww[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { xv[8 * q + 2 * r] = __uint_as_float(ww[r] << 16); xv[8 * q + 2 * r + 1] = __uint_as_float(ww[r] & 0xffff0000u); }
+                }
+            } else {
+                const f32x4 *px = (const f32x4 *)((const float *)a.x + row * a.ldx + k0);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) { const f32x4 w = px[q]; xv[4 * q] = w.x; xv[4 * q + 1] = w.y; xv[4 * q + 2] = w.z; xv[4 * q + 3] = w.w; }
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const f32x4 u1 = *(const f32x4 *)(e1 + k0 + 4 * q), u2 = *(const f32x4 *)(e2 + k0 + 4 * q);
+                xy1 = __builtin_fmaf(xv[4 * q + 0], u1.x, xy1); xy1 = __builtin_fmaf(xv[4 * q + 1], u1.y, xy1);
+                xy1 = __builtin_fmaf(xv[4 * q + 2], u1.z, xy1); xy1 = __builtin_fmaf(xv[4 * q + 3], u1.w, xy1);
+                xy2 = __builtin_fmaf(xv[4 * q + 0], u2.x, xy2); xy2 = __builtin_fmaf(xv[4 * q + 1], u2.y, xy2);
+                xy2 = __builtin_fmaf(xv[4 * q + 2], u2.z, xy2); xy2 = __builtin_fmaf(xv[4 * q + 3], u2.w, xy2);
+            }
+            if (METRIC == 0) {
+#pragma unroll
+                for (int c = 0; c < 32; ++c) ch[c] += xv[c] * xv[c];
+            }
+        }
+        int win;
+        if (METRIC == 0) {
+            float x2 = 0.f;
+#pragma unroll
+            for (int l = 0; l < 8; ++l) x2 += ((ch[l] + ch[8 + l]) + ch[16 + l]) + ch[24 + l];
+            const int tf = 32 * DT + 256;
+            const float y1 = a.packed[(size_t)(c1 >> 5) * tf + 32 * DT + (c1 & 31)], y2 = a.packed[(size_t)(c2 >> 5) * tf + 32 * DT + (c2 & 31)];
+            const float s1 = __builtin_fmaf(-2.f, xy1, x2 + y1), s2 = __builtin_fmaf(-2.f, xy2, x2 + y2);
+            const float d1 = sqrtf(fmaxf(s1, 1e-8f)), d2 = sqrtf(fmaxf(s2, 1e-8f));
+            win = (d2 < d1 || (d2 == d1 && c2 < c1)) ? c2 : c1;
+        } else {
+            win = (xy2 > xy1 || (xy2 == xy1 && c2 < c1)) ? c2 : c1;
+        }
+        a.keys[pos] = (unsigned long long)(unsigned)win;
+    }
+}
+
+template <int DT>
+static int dispatch_pair(const PairArgs &a, int x_dtype, int metric, unsigned blocks, hipStream_t st)
+{
+#define VQ_PAIR(B, M) hipLaunchKernelGGL((vq_pair_kernel<DT, B, M>), dim3(blocks), dim3(256), 0, st, a)
+    if (metric == VQHIP_EUCLID) { if (x_dtype == VQHIP_BF16) VQ_PAIR(true, 0); else VQ_PAIR(false, 0); }
+    else                        { if (x_dtype == VQHIP_BF16) VQ_PAIR(true, 1); else VQ_PAIR(false, 1); }
+#undef VQ_PAIR
+    return launch_status("vq_pair_kernel");
 }
 
 int vq_assign_listed(const void *x, int x_dtype, int metric, int64_t N, int D, int64_t ldx, const float *packed, const float *embed, int C,
                      int64_t *idx_out, void *q_out, int64_t ldq, void *resid_out, int64_t ldr, double *sqerr_partial,
-                     const uint8_t *row_mask, const int *row_list, const int *row_count, unsigned long long *keys, hipStream_t st)
+                     const uint8_t *row_mask, const int *row_list, const int *row_count, unsigned long long *keys, int with_pairs,
+                     hipStream_t st)
 {
-    // keys[0 .. *row_count) were preset to ~0 by whoever built the list (vq_screen_kernel)
+    // keys[0 .. row_count[0]) were preset to ~0 by whoever built the list (the screening kernels); the pair entries at
+    // [N - row_count[1], N) hold their two candidates
     RefineArgs r;
     r.x = x; r.ldx = ldx; r.packed = packed; r.C = C; r.n_tiles = (C + 31) / 32;
     r.row_list = row_list; r.row_count = row_count; r.keys = keys;
     const int64_t chunks = vqhip_assign_blocks(N);
-    const unsigned gx = (unsigned)(chunks < 1024 ? chunks : 1024);
-    int splits = r.n_tiles / 8;   // >= 8 tiles per workgroup, at most 8 splits (4 tiles per workgroup measured slower)
-    splits = splits < 1 ? 1 : (splits > 8 ? 8 : splits);
+    const int64_t want = chunks * r.n_tiles;              // one workgroup per (chunk, tile) at most
+    const unsigned gx = (unsigned)(want < VQ_REFINE_GRID ? want : VQ_REFINE_GRID);
     int rc;
     switch (pick_dt(D)) {
-        case 32: rc = dispatch_refine<32>(r, x_dtype, metric, gx, (unsigned)splits, st); break;
-        case 64: rc = dispatch_refine<64>(r, x_dtype, metric, gx, (unsigned)splits, st); break;
-        case 128: rc = dispatch_refine<128>(r, x_dtype, metric, gx, (unsigned)splits, st); break;
-        case 256: rc = dispatch_refine<256>(r, x_dtype, metric, gx, (unsigned)splits, st); break;
+        case 32: rc = dispatch_refine<32>(r, x_dtype, metric, gx, st); break;
+        case 64: rc = dispatch_refine<64>(r, x_dtype, metric, gx, st); break;
+        case 128: rc = dispatch_refine<128>(r, x_dtype, metric, gx, st); break;
+        case 256: rc = dispatch_refine<256>(r, x_dtype, metric, gx, st); break;
         default: VQ_FAIL(VQHIP_EDIM, "assign_listed: D=%d unsupported", D);
     }
     if (rc) return rc;
+    if (with_pairs) {
+        PairArgs pa;
+        pa.x = x; pa.ldx = ldx; pa.embed = embed; pa.packed = packed; pa.D = D;
+        pa.row_list = row_list; pa.row_count = row_count; pa.cap = N; pa.keys = keys;
+        const int64_t pb = (N + 255) / 256;
+        const unsigned blocks = (unsigned)(pb < 512 ? pb : 512);
+        switch (pick_dt(D)) {
+            case 32: rc = dispatch_pair<32>(pa, x_dtype, metric, blocks, st); break;
+            case 64: rc = dispatch_pair<64>(pa, x_dtype, metric, blocks, st); break;
+            case 128: rc = dispatch_pair<128>(pa, x_dtype, metric, blocks, st); break;
+            default: rc = dispatch_pair<256>(pa, x_dtype, metric, blocks, st); break;
+        }
+        if (rc) return rc;
+    }
     FinishArgs f;
     f.x = x; f.ldx = ldx;
     f.codes = (x_dtype == VQHIP_BF16) ? (const void *)((const char *)packed + packed_bf16_offset(C, D)) : (const void *)embed;
-    f.D = D; f.row_list = row_list; f.row_count = row_count; f.keys = keys;
+    f.D = D; f.row_list = row_list; f.row_count = row_count; f.cap = N; f.keys = keys;
     f.idx_out = idx_out; f.q_out = q_out; f.ldq = ldq; f.resid_out = resid_out; f.ldr = ldr; f.sqerr_partial = sqerr_partial; f.row_mask = row_mask;
     if (x_dtype == VQHIP_BF16)
         hipLaunchKernelGGL(vq_finish_listed_kernel<true>, dim3(VQ_FINISH_BLOCKS), dim3(256), 0, st, f);

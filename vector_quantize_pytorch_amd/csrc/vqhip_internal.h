@@ -66,10 +66,22 @@ static inline int vq_pick_dt(int D)
 //   [0)                     fp32 A-operand tiles of the exact kernel: tiles * (128*DT + 1024)
 //   [+4096)                 tail pad (the staged tile copy over-reads <= 3 KiB)
 //   [bf16_offset)           codebook rounded to bf16, [C, D] row-major (q / loss of bf16 I/O), 16-byte padded
-//   [screen_offset)         bf16 hi/lo split A-operand tiles of the screening kernel: tiles * (128*DT + 1024)
+//   [screen_offset)         bf16 hi/lo split A-operand tiles of the fp32-row screening kernel: tiles * (128*DT + 1024)
 //   [+8192)                 tail pad (8 waves x 1 KiB over-read at most)
-//   [scalars_offset)        16 bytes: float bits of max_c ||c||^2, 3 reserved words
+//   [scalars_offset)        64 bytes: [0] float bits of max_c ||c||^2, [1] float bits of max_c ||c - c_f16|| (x 1.01),
+//                           [2] int sc: the fp16 tiles hold c * 2^sc, rest reserved
+//   [f16_offset)            fp16 A-operand tiles of the single-pass screening kernel (vq_screen16_kernel):
+//                           tiles16 * (64*DT + 1024), tiles16 = tiles rounded up to a multiple of VQ_F16_TILE_GROUP
+//                           (padding tiles score -3e38), then an 8192-byte tail pad
+#define VQ_F16_TILE_GROUP 8
+#define VQ_PACKED_SCALARS_BYTES 64
 __host__ __device__ static inline size_t vq_tile_bytes(int DT) { return (size_t)128 * DT + 1024; }
+__host__ __device__ static inline size_t vq_tile16_bytes(int DT) { return (size_t)64 * DT + 1024; }
+static inline size_t vq_tiles16(int C)
+{
+    const size_t tiles = ((size_t)C + 31) / 32;
+    return (tiles + VQ_F16_TILE_GROUP - 1) / VQ_F16_TILE_GROUP * VQ_F16_TILE_GROUP;
+}
 static inline size_t vq_packed_bf16_offset(int C, int D)
 {
     const size_t tiles = ((size_t)C + 31) / 32;
@@ -84,13 +96,20 @@ static inline size_t vq_packed_scalars_offset(int C, int D)
     const size_t tiles = ((size_t)C + 31) / 32;
     return vq_packed_screen_offset(C, D) + tiles * vq_tile_bytes(vq_pick_dt(D)) + 8192;
 }
+static inline size_t vq_packed_f16_offset(int C, int D) { return vq_packed_scalars_offset(C, D) + VQ_PACKED_SCALARS_BYTES; }
+static inline size_t vq_packed_total_bytes(int C, int D)
+{
+    return vq_packed_f16_offset(C, D) + vq_tiles16(C) * vq_tile16_bytes(vq_pick_dt(D)) + 8192;
+}
 
 // exact fp32-MFMA assignment (vqhip.hip) restricted to the rows listed in row_list[0 .. *row_count), both on the
 // device; x and q share a dtype (fp32 / bf16) with D == DT and vector-aligned rows; metric VQHIP_EUCLID or
-// VQHIP_COSINE_PRENORM.  keys: N u64, entries
-// [0 .. *row_count) preset to ~0 by the list builder.
+// VQHIP_COSINE_PRENORM.  keys: N u64, entries [0 .. row_count[0]) preset to ~0 by the list builder.  with_pairs: rows whose
+// winner is one of two known codes sit at list positions N - 1 - p, p < row_count[1], their keys hold the candidates
+// (c1 | c2 << 32); vq_pair_kernel decides them with two exact distances instead of a codebook sweep.
 // sqerr_partial (nullable) receives VQ_FINISH_BLOCKS entries.
 #define VQ_FINISH_BLOCKS 512
 int vq_assign_listed(const void *x, int x_dtype, int metric, int64_t N, int D, int64_t ldx, const float *packed, const float *embed, int C,
                      int64_t *idx_out, void *q_out, int64_t ldq, void *resid_out, int64_t ldr, double *sqerr_partial,
-                     const uint8_t *row_mask, const int *row_list, const int *row_count, unsigned long long *keys, hipStream_t st);
+                     const uint8_t *row_mask, const int *row_list, const int *row_count, unsigned long long *keys, int with_pairs,
+                     hipStream_t st);
