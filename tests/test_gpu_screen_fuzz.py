@@ -162,7 +162,7 @@ def _bf16_exact(t):
     return t.bfloat16().float()
 
 
-def _adversarial_pairs(N, D, gen):
+def _adversarial_pairs(N, D, gen, big=20, spread=12):
     """rows x [N, D] and ONE code c [D], bf16-exact, products with heavy cancellation; several pattern families by row."""
     x = torch.zeros(N, D)
     c = _bf16_exact((torch.rand(D, generator=gen) + 0.5) * torch.where(torch.rand(D, generator=gen) < 0.5, -1.0, 1.0))
@@ -171,18 +171,18 @@ def _adversarial_pairs(N, D, gen):
     mant = _bf16_exact(torch.rand(N, D, generator=gen) + 1.0)                # 8-bit mantissas in [1, 2)
     sign = torch.where(torch.rand(N, D, generator=gen) < 0.5, -1.0, 1.0)
     # family 0: random exponents in [-12, 12]
-    e0 = torch.randint(-12, 13, (N, D), generator=gen).float()
+    e0 = torch.randint(-spread, spread + 1, (N, D), generator=gen).float()
     x0 = sign * mant * torch.exp2(e0)
     # family 1: product +2^20 first, tiny same-sign terms, product -2^20 LAST (different MFMAs)
     x1 = _bf16_exact(mant * torch.sign(c)[None, :])                             # all products positive, ~1
-    x1[:, 0] = _bf16_exact(torch.full((N,), 2.0 ** 20) / c[0])
-    x1[:, D - 1] = _bf16_exact(-torch.full((N,), 2.0 ** 20) / c[D - 1])
+    x1[:, 0] = _bf16_exact(torch.full((N,), 2.0 ** big) / c[0])
+    x1[:, D - 1] = _bf16_exact(-torch.full((N,), 2.0 ** big) / c[D - 1])
     # family 2: the cancelling pair sits inside ONE 16-term group (k = 3 and k = 12), tiny terms everywhere else
     x2 = _bf16_exact(mant * torch.sign(c)[None, :] * 2.0 ** -3)
-    x2[:, 3] = _bf16_exact(torch.full((N,), 2.0 ** 18) / c[3])
-    x2[:, 12] = _bf16_exact(-torch.full((N,), 2.0 ** 18) / c[12])
+    x2[:, 3] = _bf16_exact(torch.full((N,), 2.0 ** (big - 2)) / c[3])
+    x2[:, 12] = _bf16_exact(-torch.full((N,), 2.0 ** (big - 2)) / c[12])
     # family 3: alternating signs of equal magnitude per adjacent pair, magnitudes growing with k
-    grow = torch.exp2((torch.arange(D) // 2).float() * (20.0 / (D // 2)))[None, :]
+    grow = torch.exp2((torch.arange(D) // 2).float() * (float(big) / (D // 2)))[None, :]
     alt = torch.where(torch.arange(D) % 2 == 0, 1.0, -1.0)[None, :]
     x3 = _bf16_exact(mant * alt * grow * torch.sign(c)[None, :])
     for f, xf in enumerate((x0, x1, x2, x3)):
@@ -242,16 +242,18 @@ def test_mfma_accumulation_error_within_model(dev, D, wide):
 
 
 def test_mfma_accumulation_error_f32_rows(dev):
-    """same measurement through vq_screen_f32_kernel (x = x_hi + x_mid, three products per k-step)."""
+    """same measurement through vq_screen16_f32_kernel (x' = x_h + x_m in fp16, two products per k-step).  The dynamic range
+    inside a wave is kept below 2^13 so that the second operand set x_m stays in fp16's normal range (what falls below is
+    truncated and charged by the kernel's `conv` term -- a conversion loss, not the accumulation error measured here)."""
     from oracle import vq_oracle as O
     from vector_quantize_pytorch_amd import _lib as L
     D, N = 256, 4096
     gen = torch.Generator().manual_seed(5)
-    x, c = _adversarial_pairs(N, D, gen)
+    x, c = _adversarial_pairs(N, D, gen, big=8, spread=4)
     x = x + _bf16_exact(x * 2.0 ** -9 * 0.8)             # 16 significant bits: hi + mid exact, no dropped remainder
     xh = _bf16_exact(x)
     xm = _bf16_exact(x - xh)
-    assert torch.equal(xh + xm, x)
+    assert torch.equal(xh + xm, x)           # 16 significant bits: also exactly two fp16 parts
     e = torch.stack([c, torch.zeros(D)])                 # bf16-exact codes: c_lo = 0, so the dropped c_lo x_mid term is 0 too
     e[1, 0] = 2.0 ** -20
     xd, ed = x.to(dev), e.to(dev)
@@ -268,7 +270,7 @@ def test_mfma_accumulation_error_f32_rows(dev):
     a_sum = (xh.double().abs()[:, None, :] * e.double().abs()[None]).sum(-1) + (xm.double().abs()[:, None, :] * e.double().abs()[None]).sum(-1) + nh.abs()[None, :]
     order = t_exact.argsort(dim=1, descending=True)
     t_sorted, a_sorted = t_exact.gather(1, order), a_sum.gather(1, order)
-    n_terms = 3 * D + 2
+    n_terms = 2 * D + 1
     for k in range(2):
         got = dbg[:, k]
         err = (got - t_sorted[:, k]).abs()

@@ -1009,6 +1009,344 @@ __global__ void __launch_bounds__(VQS_WAVES * 64, 8 / VQS_WAVES) vq_screen16_ker
 }
 
 // ------------------------------------------------------------------------------------------------
+// fp32 rows through the fp16 screen (vq_screen16_f32_kernel).  x' = x 2^SX is split into two fp16 parts,
+// x' = x_h + x_m + r with |r| <= 2^-20 |x'| (two truncating conversions, the first remainder is exact in fp32), and both
+// parts are multiplied with the ONE fp16 codebook part: 2 MFMAs per k-step instead of the 3 of the bf16 kernel below, one
+// A-fragment read for the two.  One 32-row block per wave (x_h and x_m fill the registers the bf16-row kernel spends on a
+// second row block), VQS_F32_WAVES waves per workgroup.  The skew is over tiles here: the top-3 epilogue of tile t - 1
+// (accumulator `pa`) is issued in slices between the 2 NK MFMAs of tile t.  Bound: the bf16-row kernel's terms with
+// 2 D + 1 accumulated terms, the dropped remainder 2 * 2^-20 X Y and two truncated operand sets in `conv`.
+// q (fp32 code rows from `embed`), residual and squared error come from the row-cooperative pass that re-reads x.
+// ------------------------------------------------------------------------------------------------
+#ifndef VQS_F32_WAVES
+#define VQS_F32_WAVES 8
+#endif
+#define VQ_SCREEN_F32_ROWS (VQS_F32_WAVES * 32)
+
+template <int DT> struct Screen16F32Cfg {
+    static constexpr int TILE_B = 64 * DT + 1024;
+    static constexpr int SUB = Screen16Cfg<DT>::SUB;
+    static constexpr int BUF_B = (SUB * TILE_B / 1024 + VQS_F32_WAVES - 1) / VQS_F32_WAVES * VQS_F32_WAVES * 1024;
+    static constexpr int SMEM = 2 * BUF_B;
+};
+
+template <int DT, int METRIC>
+__global__ void __launch_bounds__(VQS_F32_WAVES * 64, 8 / VQS_F32_WAVES) vq_screen16_f32_kernel(const ScreenArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    using Cfg = Screen16F32Cfg<DT>;
+    constexpr int W = VQS_F32_WAVES;
+    constexpr int TILE_B = Cfg::TILE_B;
+    constexpr int SUB = Cfg::SUB;
+    constexpr int SUPER_B = SUB * TILE_B;
+    constexpr int BUF_B = Cfg::BUF_B;
+    constexpr int NCHUNK = SUPER_B / 1024;
+    constexpr int NK = DT / 16;
+    constexpr int TS = 2 * NK;                      // MFMAs (steps) per tile: each k-step with x_h and with x_m
+    constexpr int PMAX = (NCHUNK + W - 1) / W;      // pieces per wave and buffer
+    constexpr int PPS = (PMAX + SUB - 1) / SUB;     // pieces a wave copies during one tile
+    constexpr int BS2 = (PPS + 1) / 2;
+    constexpr int LAG2 = (NK >= 8) ? NK - 2 : NK - 1;
+    constexpr int PSTRIDE = W * 1024;
+    static_assert(VQ_F16_TILE_GROUP % SUB == 0, "tile padding must cover the tiles of one barrier");
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 31;
+    const int half = lane >> 5;
+    const int64_t wrow0 = (int64_t)blockIdx.x * VQ_SCREEN_F32_ROWS + wave * 32;
+    const int piece_off = wave * 1024 + lane * 16;
+    const char *tiles = a.tiles16;
+
+    // ---- x rows (fp32): lane (j, half) holds features 16 ks + 8 half + 0..7 of its row for every k-step ----
+    const int64_t row = wrow0 + j;
+    const bool row_ok = row < a.N;
+    f32x4 xr[NK][2];
+    {
+        const float *p = (const float *)a.x + (row_ok ? row : (a.N - 1)) * a.ldx + 8 * half;
+#pragma unroll
+        for (int ks = 0; ks < NK; ++ks) { xr[ks][0] = *(const f32x4 *)(p + ks * 16); xr[ks][1] = *(const f32x4 *)(p + ks * 16 + 4); }
+    }
+#pragma unroll
+    for (int k = 0; k < PMAX; ++k)
+        *(f32x4 *)(smem + piece_off + k * PSTRIDE) = *(const f32x4 *)(tiles + piece_off + (size_t)k * PSTRIDE);
+
+    float xs2;
+    {
+        float xs = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < NK; ++ks)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const f32x4 v = xr[ks][q];
+                xs = __builtin_fmaf(v.x, v.x, xs); xs = __builtin_fmaf(v.y, v.y, xs);
+                xs = __builtin_fmaf(v.z, v.z, xs); xs = __builtin_fmaf(v.w, v.w, xs);
+            }
+        xs += __shfl_xor(xs, 32, 64);
+        xs2 = xs * 1.001f;
+    }
+    // scale exponents: as in vq_screen16_kernel (largest finite row norm of the wave below 2^14)
+    unsigned mx;
+    {
+        const unsigned bits = __float_as_uint(xs2);
+        mx = (bits & 0x7f800000u) == 0x7f800000u ? 0u : (bits & 0x7fffffffu);
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) { const unsigned t = (unsigned)__shfl_xor((int)mx, o, 64); mx = t > mx ? t : mx; }
+    mx = (unsigned)__builtin_amdgcn_readfirstlane((int)mx);
+    const int sc = (int)a.scalars[2];
+    const int e2 = (int)(mx >> 23) - 127;
+    int SX = (mx == 0u) ? 0 : 14 - ((e2 >> 1) + 1);
+    SX = SX > 120 - sc ? 120 - sc : SX;
+    SX = SX < -120 - sc ? -120 - sc : SX;
+    SX = SX > sc + 90 ? sc + 90 : SX;
+    SX = SX > 126 ? 126 : (SX < -126 ? -126 : SX);
+    const float S = __uint_as_float((unsigned)(SX + 127) << 23);
+    const float SS = __uint_as_float((unsigned)(SX + sc + 127) << 23);
+    const float iSS = __uint_as_float((unsigned)(127 - SX - sc) << 23);
+
+    float eps;
+    {
+        const float y2max = __uint_as_float(a.scalars[0]);
+        const float rmax = __uint_as_float(a.scalars[1]);
+        const float ymax = sqrtf(y2max) * 1.0001f;
+        const float u = 5.9604645e-8f;   // 2^-24
+        const float conv = 4.f * 5.9604645e-8f * sqrtf((float)DT) * ymax * __uint_as_float((unsigned)(127 - SX) << 23);   // two truncated operand sets
+        const float xn = sqrtf(xs2) * 1.0001f;
+        const float xy = xn * ymax;
+        const float drop = 2.f * 9.5367432e-7f * 1.01f * xy;   // 2 codes x 2^-20 X Y: the part of x' neither x_h nor x_m carries
+        if (METRIC == 0) eps = u * (10.f * (xs2 + y2max + 2.f * xy) + 2.f * DT * xy + 4.f * (2 * DT + 1) * 1.001f * (xy + 0.5f * y2max))
+                               + 2.f * xn * rmax + drop + conv + 4e-8f;
+        else             eps = 2.f * (u * 5.f * DT * 1.001f * xy + xn * rmax) + drop + conv + 1e-30f;
+    }
+
+    // ---- fp32 -> two scaled fp16 operand sets (x_h: truncated x', x_m: truncated exact remainder) ----
+    uint4 xh[NK], xm[NK];
+#pragma unroll
+    for (int ks = 0; ks < NK; ++ks) {
+        const float v[8] = {xr[ks][0].x * S, xr[ks][0].y * S, xr[ks][0].z * S, xr[ks][0].w * S,
+                            xr[ks][1].x * S, xr[ks][1].y * S, xr[ks][1].z * S, xr[ks][1].w * S};
+        unsigned hw[4], mw[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+            const f16x2 h = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(v[2 * q], v[2 * q + 1]));
+            const float r0 = v[2 * q] - (float)h[0], r1 = v[2 * q + 1] - (float)h[1];   // exact: the low bits of x'
+            hw[q] = __builtin_bit_cast(unsigned, h);
+            mw[q] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(r0, r1));
+        }
+        xh[ks] = make_uint4(hw[0], hw[1], hw[2], hw[3]);
+        xm[ks] = make_uint4(mw[0], mw[1], mw[2], mw[3]);
+    }
+
+    float m1 = -__builtin_inff(), m2 = -__builtin_inff(), m3 = -__builtin_inff();
+    int tix = 0, tix2 = 0;
+    f32x16 pa;                                            // the previous tile's scores
+#pragma unroll
+    for (int r = 0; r < 16; ++r) pa[r] = -3.0e38f;       // "a padding code": never wins against a real one
+    int ptile = 0;
+    auto fold = [&](const f32x16 &acc, int e) {
+        const float k = __uint_as_float((__float_as_uint(acc[e]) & 0xfffffff0u) | (unsigned)e);
+        asm volatile("v_med3_f32 %2, %1, %2, %3\n\tv_med3_f32 %1, %0, %1, %3\n\tv_max_f32 %0, %0, %3"
+                     : "+v"(m1), "+v"(m2), "+v"(m3) : "v"(k));
+    };
+    auto book = [&](float om1, float om2, int tile_id) {
+        const bool c1 = m1 != om1;
+        const int from_old_best = (c1 && m2 == om1) ? tix : tile_id;
+        tix2 = (m2 != om2) ? from_old_best : tix2;
+        tix = c1 ? tile_id : tix;
+    };
+
+    const int nst = a.n_tiles16 / SUB;
+    for (int st = 0; st < nst; ++st) {
+        const int buf = st & 1;
+        __syncthreads();
+        const char *sbase = smem + buf * BUF_B;
+        const bool more = st + 1 < nst;
+        const char *gsrc = tiles + (size_t)(more ? st + 1 : st) * SUPER_B + piece_off;
+        char *ldst = smem + (buf ^ 1) * BUF_B + piece_off;
+#pragma unroll 1
+        for (int sub = 0; sub < SUB; ++sub) {
+            const char *tile = sbase + sub * TILE_B;
+            const float *nh = (const float *)(tile + 64 * DT);
+            const int tile_id = st * SUB + sub;
+            const bool has_pad = (tile_id + 1) * 32 > a.C;
+            const uint4 *ap = (const uint4 *)tile + lane;
+            uint4 af[VQS16_PF];
+            f32x4 stg[BS2];
+            f32x16 acc;
+            const int p0 = sub * PPS;
+            const float o1 = m1, o2 = m2;
+#pragma unroll
+            for (int p = 0; p < VQS16_PF; ++p) af[p] = ap[(p % NK) * 64];
+#pragma unroll
+            for (int s = 0; s < TS; ++s) {
+                const int ks = s >> 1;
+                const f16x8 av = __builtin_bit_cast(f16x8, af[ks % VQS16_PF]);
+                const f16x8 bv = __builtin_bit_cast(f16x8, (s & 1) ? xm[ks] : xh[ks]);
+                if (s == 0) {
+                    f32x16 init;
+                    if (METRIC == 0 || has_pad) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            f32x4 v = *(const f32x4 *)(nh + 8 * q + 4 * half);
+                            if (METRIC != 0) { v.x = v.x < -1e38f ? v.x : 0.f; v.y = v.y < -1e38f ? v.y : 0.f;
+                                               v.z = v.z < -1e38f ? v.z : 0.f; v.w = v.w < -1e38f ? v.w : 0.f; }
+                            init[4 * q + 0] = v.x * SS; init[4 * q + 1] = v.y * SS; init[4 * q + 2] = v.z * SS; init[4 * q + 3] = v.w * SS;
+                        }
+                        if (has_pad) {
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) init[r] = fmaxf(init[r], -3.0e38f);
+                        }
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) init[r] = 0.f;
+                    }
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bv, init, 0, 0, 0);
+                } else {
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bv, acc, 0, 0, 0);
+                }
+                if ((s & 1) && ks + VQS16_PF < NK) af[ks % VQS16_PF] = ap[(ks + VQS16_PF) * 64];
+                if (s >= 1) {   // epilogue slice of the previous tile: 16 scores over the steps 1 .. TS - 1
+#pragma unroll
+                    for (int e = (s - 1) * 16 / (TS - 1); e < s * 16 / (TS - 1); ++e) fold(pa, e);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int bt = 0; bt < 2; ++bt) {
+                    if (s == bt * NK) {
+#pragma unroll
+                        for (int i = 0; i < BS2; ++i)
+                            if (bt * BS2 + i < PPS) {
+                                const int pc = min(p0 + bt * BS2 + i, PMAX - 1);
+                                stg[i] = *(const f32x4 *)(gsrc + (size_t)pc * PSTRIDE);
+                            }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    if (s == bt * NK + LAG2) {
+#pragma unroll
+                        for (int i = 0; i < BS2; ++i)
+                            if (bt * BS2 + i < PPS) *(f32x4 *)(ldst + min(p0 + bt * BS2 + i, PMAX - 1) * PSTRIDE) = stg[i];
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            }
+            book(o1, o2, ptile);
+            pa = acc;
+            ptile = tile_id;
+        }
+    }
+    {
+        const float o1 = m1, o2 = m2;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) fold(pa, e);
+        book(o1, o2, ptile);
+    }
+
+    // ---- merge the half-waves, classify (certified / pair / open), emit ----
+    int code, cls, id2;
+    bool flagged;
+    {
+        const int e1 = (int)(__float_as_uint(m1) & 15u), e2b = (int)(__float_as_uint(m2) & 15u);
+        const int ia1 = tix * 32 + 8 * (e1 >> 2) + 4 * half + (e1 & 3);
+        const int ia2 = tix2 * 32 + 8 * (e2b >> 2) + 4 * half + (e2b & 3);
+        const float a1 = m1, a2 = m2, a3 = m3;
+        const float p1 = __shfl_xor(a1, 32, 64), p2 = __shfl_xor(a2, 32, 64), p3 = __shfl_xor(a3, 32, 64);
+        const int ib1 = __shfl_xor(ia1, 32, 64), ib2 = __shfl_xor(ia2, 32, 64);
+        const bool take = p1 > a1;
+        const float h1 = take ? p1 : a1, h2 = take ? p2 : a2, h3 = take ? p3 : a3;
+        const float l1 = take ? a1 : p1, l2 = take ? a2 : p2;
+        const int ih1 = take ? ib1 : ia1, ih2 = take ? ib2 : ia2, il1 = take ? ia1 : ib1;
+        const float b1 = h1;
+        const bool second_low = l1 > h2;
+        const float b2 = second_low ? l1 : h2;
+        id2 = second_low ? il1 : ih2;
+        const float b3 = second_low ? fmaxf(h2, l2) : fmaxf(h3, l1);
+        code = ih1;
+        const float thr = eps * SS + 8e-6f * fabsf(b1);
+        const bool certified = ((b1 - b2) > thr) && code < a.C;
+        const bool pair = !certified && ((b1 - b3) > thr) && code < a.C && id2 < a.C;
+        flagged = !certified;
+        if (row_ok && half == 0) {
+            a.idx_out[row] = (int64_t)(code < a.C ? code : 0);
+            if (a.dbg) {
+                float *d = a.dbg + row * 4;
+                d[0] = b1 * iSS; d[1] = b2 * iSS; d[2] = thr * iSS; d[3] = certified ? 0.f : (pair ? 2.f : 1.f);
+            }
+        }
+        if (code >= a.C) code = 0;
+        const bool on = row_ok && half == 0;
+        cls = !on ? 0 : (certified ? 0 : (pair ? 2 : 1));
+    }
+    const unsigned long long balo = __ballot(cls == 1), balp = __ballot(cls == 2);
+    int base_o = 0, base_p = 0;
+    if (lane == 0) {
+        if (balo) base_o = atomicAdd(a.flag_count, (int)__popcll(balo));
+        if (balp) base_p = atomicAdd(a.flag_count + 1, (int)__popcll(balp));
+    }
+
+    // ---- q rows (fp32, from embed), residual and squared error: whole rows per wave, 8 in flight; x is re-read (coalesced) ----
+    if (a.q_out || a.sqerr_partial || a.resid_out) {
+        const int counted = (row_ok && !flagged && (!a.row_mask || a.row_mask[row] != 0)) ? 1 : 0;
+        const unsigned long long cmask = __ballot(counted && half == 0);
+        const bool want_sq = a.sqerr_partial != nullptr;
+        const bool want_x = want_sq || a.resid_out != nullptr;
+        double ds = 0.0;
+#pragma unroll
+        for (int r0 = 0; r0 < 32; r0 += 8) {
+            f32x4 g[8], xv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int c = __builtin_amdgcn_readlane(code, r0 + u);
+                const int64_t rr = wrow0 + r0 + u;
+                if (lane * 4 < DT) {
+                    g[u] = *(const f32x4 *)(a.embed + (size_t)c * DT + lane * 4);
+                    if (want_x) xv[u] = *(const f32x4 *)((const float *)a.x + (rr < a.N ? rr : a.N - 1) * a.ldx + lane * 4);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int64_t rr = wrow0 + r0 + u;
+                if (lane * 4 < DT) {
+                    if (a.q_out && rr < a.N) *(f32x4 *)((float *)a.q_out + rr * a.ldq + lane * 4) = g[u];
+                    if (a.resid_out && rr < a.N) *(f32x4 *)((float *)a.resid_out + rr * a.ldr + lane * 4) = xv[u] - g[u];
+                    if (want_sq && ((cmask >> (r0 + u)) & 1ull)) {
+                        const float d0 = g[u].x - xv[u].x, d1 = g[u].y - xv[u].y, d2 = g[u].z - xv[u].z, d3 = g[u].w - xv[u].w;
+                        ds += (double)(((d0 * d0 + d1 * d1) + d2 * d2) + d3 * d3);
+                    }
+                }
+            }
+        }
+        if (a.sqerr_partial) {
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) ds += __shfl_xor(ds, o, 64);
+            __syncthreads();
+            double *red = (double *)smem;
+            if (lane == 0) red[wave] = ds;
+            __syncthreads();
+            if (tid == 0) {
+                double t = 0.0;
+#pragma unroll
+                for (int w = 0; w < W; ++w) t += red[w];
+                a.sqerr_partial[blockIdx.x] = t;
+            }
+        }
+    }
+    const int bo = __builtin_amdgcn_readfirstlane(base_o), bp = __builtin_amdgcn_readfirstlane(base_p);   // lane 0's, read with all lanes active
+    if (balo && cls == 1) {
+        const int slot = bo + (int)__popcll(balo & ((1ull << lane) - 1ull));
+        a.flag_rows[slot] = (int)row;
+        a.flag_keys[slot] = ~0ull;
+    }
+    if (balp && cls == 2) {
+        const int64_t slot = a.N - 1 - (bp + (int)__popcll(balp & ((1ull << lane) - 1ull)));
+        a.flag_rows[slot] = (int)row;
+        a.flag_keys[slot] = (unsigned long long)(unsigned)code | ((unsigned long long)(unsigned)id2 << 32);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // fp32 rows.  x is split as well, x = x_hi + x_mid + r_x (bf16 parts, |r_x| <= 2^-16 |x|), and three products are
 // accumulated per k-step: c_hi x_hi, c_hi x_mid, c_lo x_hi.  Dropped: c_lo x_mid, c r_x, r_c x -- each <= 2^-16 |x||c|
 // (+ second order), so the split term of the bound becomes 3.03 * 2 * 2^-16 X Y <= 1600 u X Y and the accumulation term
@@ -1017,11 +1355,6 @@ __global__ void __launch_bounds__(VQS_WAVES * 64, 8 / VQS_WAVES) vq_screen16_ker
 // two accumulators so that no MFMA waits for its predecessor.  q (fp32 code rows) and the squared error are produced by
 // a row-cooperative pass that re-reads x, because the registers only hold x to 16 bits.
 // ------------------------------------------------------------------------------------------------
-#ifndef VQS_F32_WAVES
-#define VQS_F32_WAVES 8
-#endif
-#define VQ_SCREEN_F32_ROWS (VQS_F32_WAVES * 32)
-
 __device__ __forceinline__ void split8_bf16(const f32x4 &v0, const f32x4 &v1, uint4 &h, uint4 &m)
 {
     const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
@@ -1303,6 +1636,13 @@ static int launch_screen(const ScreenArgs &a, int x_dtype, hipStream_t st)
         hipLaunchKernelGGL((vq_screen16_kernel<DT, METRIC>), dim3(blocks), dim3(VQS_WAVES * 64), SMEM16, st, a);
         return vq_launch_status("vq_screen16_kernel");
     }
+    if (x_dtype == VQHIP_F32 && !screen_bf16x2()) {
+        static VqAttrOnce once_hf;
+        constexpr int SMEM16 = Screen16F32Cfg<DT>::SMEM;
+        if (int rc = vq_set_max_smem(once_hf, (const void *)vq_screen16_f32_kernel<DT, METRIC>, SMEM16, "vq_screen16_f32_kernel")) return rc;
+        hipLaunchKernelGGL((vq_screen16_f32_kernel<DT, METRIC>), dim3(blocks), dim3(VQS_F32_WAVES * 64), SMEM16, st, a);
+        return vq_launch_status("vq_screen16_f32_kernel");
+    }
     if (int rc = vq_set_max_smem(once_b, (const void *)vq_screen_kernel<DT, METRIC>, SMEM, "vq_screen_kernel")) return rc;
     if (int rc = vq_set_max_smem(once_f, (const void *)vq_screen_f32_kernel<DT, METRIC>, SMEM, "vq_screen_f32_kernel")) return rc;
     if (x_dtype == VQHIP_BF16)
@@ -1370,7 +1710,7 @@ extern "C" int vqhip_assign_screened(const void *x, int x_dtype, int64_t N, int 
         default: rc = dispatch_screen<256>(a, x_dtype, metric, st); break;
     }
     if (rc) return rc;
-    const int with_pairs = (x_dtype == VQHIP_BF16 && !screen_bf16x2()) ? 1 : 0;   // vq_screen16_kernel also builds the pair list
+    const int with_pairs = screen_bf16x2() ? 0 : 1;   // the fp16 screening kernels also build the pair list
     return vq_assign_listed(x, x_dtype, metric, N, D, ldx, packed, embed, C, idx_out, q_out, ldq, resid_out, ldr,
                             sqerr_partial ? sqerr_partial + vqhip_screen_blocks(N, x_dtype) : nullptr, row_mask, rows, count, keys,
                             with_pairs, st);
