@@ -181,6 +181,14 @@ int vqhip_decode_sum(const int64_t *idx, int64_t N, int Q, const float *embed, i
                      int C, int D, void *out, int out_dtype, int64_t ldo, void *stream);
 
 /* ---- ATen-order row sum of squares (vqp.py:59) -- exposed for tests / odd D -------------------- */
+/* Score of ONE given code per row in the reference's arithmetic: cdist(x_n, embed[idx_n]) (vector_quantize_pytorch.py:58-62)
+ * for VQHIP_EUCLID, the similarity x_n . embed[idx_n] (:741) for VQHIP_COSINE_PRENORM (rows already unit-norm) -- bit for bit
+ * the winner's score vqhip_assign reports through best_out.  Replaces nothing in the reference (it always has the whole
+ * `dist` tensor); it exists for the codebook-sharded argmin (vector_quantize_pytorch_amd/parallel.py), which merges the
+ * shards' winners by (score, index) after a screened search that does not produce scores.  D % 4 == 0, D <= 512. */
+int vqhip_score_indices(const void *x, int x_dtype, int64_t N, int D, int64_t ldx, const float *packed, const float *embed,
+                        int C, int metric, const int64_t *idx, float *out, void *stream);
+
 int vqhip_row_sumsq(const void *x, int x_dtype, int64_t N, int D, int64_t ldx, float *out, void *stream);
 
 #ifdef __cplusplus

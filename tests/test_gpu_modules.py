@@ -538,3 +538,31 @@ def test_train_step_is_hip_graph_capturable(dev):
             # the EMA sums are accumulated in a run-dependent order (round-off level differences): continue both from the
             # same state so that the next step's indices are comparable bit for bit
             vq_e.load_state_dict(vq_g.state_dict())
+
+
+@pytest.mark.parametrize("cosine,dim,dtype", [(False, 64, torch.float32), (True, 512, torch.float32), (True, 256, torch.bfloat16)])
+def test_shard_codebook_single_rank_equals_plain_module(dev, cosine, dim, dtype):
+    """VectorQuantize(shard_codebook=True) with one rank (shard = whole codebook): same indices, quantized, loss, input gradient
+    (rotation trick + commit loss) and EMA state as the unsharded module, through the screened search + score merge."""
+    from vector_quantize_pytorch_amd import VectorQuantize
+    torch.manual_seed(3)
+    a = VectorQuantize(dim=dim, codebook_size=300, use_cosine_sim=cosine)
+    torch.manual_seed(3)
+    b = VectorQuantize(dim=dim, codebook_size=300, use_cosine_sim=cosine, shard_codebook=True)
+    a, b = a.to(dev).train(), b.to(dev).train()
+    assert torch.equal(a._codebook.embed, b._codebook.embed)
+    g = torch.Generator().manual_seed(5)
+    for step in range(2):
+        x = torch.randn(3, 700, dim, generator=g).to(dtype).to(dev)
+        xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+        qa, ia, la = a(xa)
+        qb, ib, lb = b(xb)
+        assert torch.equal(ia, ib)
+        tol = 1e-5 if dtype == torch.float32 else 1e-2
+        assert (qa.float() - qb.float()).abs().max().item() <= tol * max(qa.float().abs().max().item(), 1e-6)
+        assert abs(la.item() - lb.item()) <= tol * max(abs(la.item()), 1e-6)
+        w = torch.randn(3, 700, dim, generator=g).to(dev)            # a generic cotangent (sum of squares of unit-norm rows has ~zero gradient)
+        ((qa.float() * w).sum() + la).backward()
+        ((qb.float() * w).sum() + lb).backward()
+        assert (xa.grad.float() - xb.grad.float()).abs().max().item() <= 10 * tol * max(xa.grad.float().abs().max().item(), 1e-6)
+        assert (a._codebook.embed - b._codebook.embed).abs().max().item() <= 1e-5 * a._codebook.embed.abs().max().item()

@@ -316,6 +316,8 @@ def _screen_case(N, C, D, kind, seed=0, dtype=torch.bfloat16):
     (3000, 4096, 128, "kaiming"),    # cfg 5 per-group shape
     (5000, 8192, 32, "unit"),        # low-dimensional codebook (codebook_dim = 32)
     (2500, 100, 32, "rows"),
+    (3000, 2048, 512, "unit"),       # cfg 4's dimension: one row block per wave
+    (1500, 300, 512, "kaiming"),
 ])
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
 def test_screened_assign_matches_chain_oracle(dev, N, C, D, kind, dtype):
@@ -323,7 +325,7 @@ def test_screened_assign_matches_chain_oracle(dev, N, C, D, kind, dtype):
     x, e = _screen_case(N, C, D, kind, dtype=dtype)
     xd, ed = x.to(dev), e.to(dev)
     r = L.assign(xd, L.pack_codebook(ed), ed, want_q=True, want_sqerr=True)
-    assert r.get("n_exact") is not None, "rows with D in {32,64,128,256} must take the screened path"
+    assert r.get("n_exact") is not None, "rows with D in {32,64,128,256,512} must take the screened path"
     idx_o, _ = O.c_assign(x.float(), e)
     mism = (r["idx"].cpu() != idx_o).sum().item()
     assert mism == 0, f"{mism}/{N} index mismatches vs chain oracle"
@@ -448,7 +450,7 @@ def test_l2norm_rows_matches_reference_arithmetic(dev, N, D, dtype):
 
 
 @pytest.mark.parametrize("N,C,D,kind", [(4099, 1024, 256, "unit"), (5000, 1000, 128, "unit"), (3000, 37, 64, "unit"),
-                                        (8192, 1024, 256, "dups"), (4000, 2048, 32, "unit")])
+                                        (8192, 1024, 256, "dups"), (4000, 2048, 32, "unit"), (2000, 4096, 512, "unit")])
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
 def test_screened_cosine_matches_chain_oracle(dev, N, C, D, kind, dtype):
     """cosine metric through the screen: l2norm_rows + screened search on unit-norm rows == the exact cosine kernel's
@@ -511,3 +513,22 @@ def test_screen_verify_switch(dev, monkeypatch):
         ed = e.to(dev)
         r = L.assign(xd, L.pack_codebook(ed), ed, cosine=cos, skip_l2norm=cos)
         assert r.get("n_exact") is not None
+
+
+@pytest.mark.parametrize("N,C,D,dtype,cos", [(3000, 1024, 256, torch.bfloat16, False), (2000, 300, 512, torch.float32, True),
+                                             (1000, 64, 64, torch.float32, False), (777, 2048, 512, torch.bfloat16, True)])
+def test_score_indices_equals_exact_kernels_winner_score(dev, N, C, D, dtype, cos):
+    """vqhip_score_indices: the reference-arithmetic score of a given code == what the exact kernel reports for its winner
+    (needed by the codebook-sharded merge after a screened search, which certifies indices but produces no scores)."""
+    from vector_quantize_pytorch_amd import _lib as L
+    x, e = _mk(N, C, D, dtype, unit=True, seed=21)
+    xd, ed = x.to(dev), e.to(dev)
+    if cos:
+        ed = torch.nn.functional.normalize(ed, dim=-1).contiguous()
+        xd = L.l2norm_rows(xd)
+    packed = L.pack_codebook(ed)
+    r0 = L.assign(xd, packed, ed, cosine=cos, skip_l2norm=cos, want_q=False, want_best=True)     # exact kernel (want_best disables the screen)
+    r1 = L.assign(xd, packed, ed, cosine=cos, skip_l2norm=cos, want_q=False)                     # screened
+    assert r1.get("n_exact") is not None and torch.equal(r0["idx"], r1["idx"])
+    s = L.score_indices(xd, packed, ed, r1["idx"], cosine=cos)
+    assert torch.equal(s, r0["best"])

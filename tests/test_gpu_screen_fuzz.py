@@ -4,7 +4,7 @@ The screened path certifies an index from a bf16-MFMA score and a model of that 
 certificate under load instead of trusting the model:
 
 * a fuzz over magnitudes 1e-6 .. 1e4, DC offsets, heavy tails, mixed-norm codebooks, 2 <= C <= 65536,
-  D in {32, 64, 128, 256}, both dtypes and both metrics, > 10^7 rows in total, every row compared bit for bit with the
+  D in {32, 64, 128, 256, 512}, both dtypes and both metrics, > 10^7 rows in total, every row compared bit for bit with the
   exact fp32-MFMA kernel (which the other test files pin to oracle/vq_oracle.c);
 * the full BASELINE cfg-2 batch (2^20 rows) at step 1 and over five EMA steps with VQHIP_SCREEN_VERIFY=1;
 * a direct measurement of the MFMA unit's accumulation error (fp16 single-pass kernel for bf16 rows, bf16 three-product
@@ -75,6 +75,10 @@ _CASES = [
     ("randn", "kaiming", 1 << 15, 65536, 256, 1.0, 1.0),
     ("heavy", "lognorm", 1 << 18, 1024, 256, 1e-6, 0.0),
     ("rowscale", "rows", 1 << 18, 1024, 64, 1e4, 0.0),
+    ("randn", "randn", 1 << 16, 8192, 512, 1.0, 0.0),         # D = 512: one row block per wave (cfg 4's dimension)
+    ("randn", "kaiming", 1 << 16, 1024, 512, 1.0, 0.0),
+    ("heavy", "rows", 1 << 15, 4096, 512, 1e-3, 0.0),
+    ("rowscale", "cluster", 1 << 16, 1000, 512, 1.0, 10.0),
 ]
 
 

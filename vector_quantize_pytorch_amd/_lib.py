@@ -72,8 +72,10 @@ def lib():
     L.vqhip_ema_finalize.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, f32, f32, i32, i32, i32, vp, vp]
     L.vqhip_decode_sum.argtypes = [vp, i64, i32, vp, i64, i32, i32, vp, i32, i64, vp]
     L.vqhip_row_sumsq.argtypes = [vp, i32, i64, i32, i64, vp, vp]
+    L.vqhip_score_indices.argtypes = [vp, i32, i64, i32, i64, vp, vp, i32, i32, vp, vp, vp]
+    L.vqhip_score_indices.restype = i32
     for name in ("vqhip_pack_codebook", "vqhip_assign", "vqhip_reduce_partials", "vqhip_ema_accumulate",
-                 "vqhip_ema_finalize", "vqhip_decode_sum", "vqhip_row_sumsq", "vqhip_route_fwd", "vqhip_route_bwd"):
+                 "vqhip_ema_finalize", "vqhip_decode_sum", "vqhip_row_sumsq", "vqhip_score_indices", "vqhip_route_fwd", "vqhip_route_bwd"):
         getattr(L, name).restype = i32
     _lib = L
     return L
@@ -82,7 +84,7 @@ def lib():
 EXPORTS = ("vqhip_version", "vqhip_last_error", "vqhip_packed_bytes", "vqhip_pack_codebook",
            "vqhip_assign_blocks", "vqhip_assign", "vqhip_screen_supported", "vqhip_screen_workspace_bytes",
            "vqhip_screen_blocks", "vqhip_screen_partials", "vqhip_assign_screened", "vqhip_l2norm_rows", "vqhip_scores", "vqhip_rvq_forward", "vqhip_reduce_partials", "vqhip_ema_workspace_bytes", "vqhip_ema_accumulate",
-           "vqhip_ema_finalize", "vqhip_decode_sum", "vqhip_row_sumsq", "vqhip_route_fwd", "vqhip_route_bwd")
+           "vqhip_ema_finalize", "vqhip_decode_sum", "vqhip_row_sumsq", "vqhip_score_indices", "vqhip_route_fwd", "vqhip_route_bwd")
 
 
 def _check(rc, what):
@@ -451,6 +453,20 @@ def decode_sum(idx: torch.Tensor, embed: torch.Tensor, out_dtype=torch.float32) 
     if N > 0:
         _check(lib().vqhip_decode_sum(_ptr(idx), N, Q, _ptr(embed), qstride, C, D, _ptr(out),
                                       F32 if out_dtype == torch.float32 else BF16, D, _stream()), "vqhip_decode_sum")
+    return out
+
+
+@_on_device
+def score_indices(x: torch.Tensor, packed: torch.Tensor, embed2d: torch.Tensor, idx: torch.Tensor, *, cosine=False) -> torch.Tensor:
+    """The reference-arithmetic score of code idx[n] for row n: cdist (Euclidean) or similarity (cosine; rows must already be
+    unit-norm) -- what assign(want_best=True) reports for the winner, for searches that ran screened."""
+    _need_gpu(x, packed, embed2d, idx)
+    xk, N, D, ldx = as_rows(x)
+    assert idx.dtype == torch.int64 and idx.is_contiguous() and idx.numel() == N
+    out = torch.empty(x.shape[:-1], dtype=torch.float32, device=x.device)
+    if N > 0:
+        _check(lib().vqhip_score_indices(_ptr(xk), _dtype_code(xk), N, D, ldx, _ptr(packed), _ptr(embed2d), embed2d.shape[0],
+                                         COSINE_PRENORM if cosine else EUCLID, _ptr(idx), _ptr(out), _stream()), "vqhip_score_indices")
     return out
 
 

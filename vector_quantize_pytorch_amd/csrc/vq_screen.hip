@@ -491,7 +491,7 @@ template <int DT> struct Screen16Cfg {
 #ifdef VQS16_SUB
     static constexpr int SUB = VQS16_SUB;
 #else
-    static constexpr int SUB = DT >= 256 ? 2 : (DT == 128 ? 4 : 8);   // 32-code tiles per barrier (divides VQ_F16_TILE_GROUP)
+    static constexpr int SUB = DT >= 512 ? 1 : (DT == 256 ? 2 : (DT == 128 ? 4 : 8));   // 32-code tiles per barrier (divides VQ_F16_TILE_GROUP)
 #endif
     static constexpr int BUF_B = (SUB * TILE_B / 1024 + VQS_WAVES - 1) / VQS_WAVES * VQS_WAVES * 1024;   // whole pieces for every wave
     static constexpr int SMEM = 2 * BUF_B;
@@ -1030,8 +1030,13 @@ template <int DT> struct Screen16F32Cfg {
     static constexpr int SMEM = 2 * BUF_B;
 };
 
-template <int DT, int METRIC>
-__global__ void __launch_bounds__(VQS_F32_WAVES * 64, 8 / VQS_F32_WAVES) vq_screen16_f32_kernel(const ScreenArgs a)
+// One 32-row block per wave, NPART fp16 operand sets per row:
+//   XBF16 = false, NPART = 2 : fp32 rows, D <= 256 (x_h + x_m, described above)
+//   XBF16 = false, NPART = 1 : fp32 rows, D = 512 -- the registers hold ONE operand set, x_h = fp16_rne(x'); the certificate
+//                              charges the measured residual, |(x' - x_h).c| <= ||x' - x_h|| Y per code (computed per row)
+//   XBF16 = true,  NPART = 1 : bf16 rows, D = 512 -- exact operands like vq_screen16_kernel, half its rows per wave
+template <int DT, int METRIC, bool XBF16, int NPART>
+__global__ void __launch_bounds__(VQS_F32_WAVES * 64, 8 / VQS_F32_WAVES) vq_screen16_1rb_kernel(const ScreenArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using Cfg = Screen16F32Cfg<DT>;
@@ -1042,13 +1047,17 @@ __global__ void __launch_bounds__(VQS_F32_WAVES * 64, 8 / VQS_F32_WAVES) vq_scre
     constexpr int BUF_B = Cfg::BUF_B;
     constexpr int NCHUNK = SUPER_B / 1024;
     constexpr int NK = DT / 16;
-    constexpr int TS = 2 * NK;                      // MFMAs (steps) per tile: each k-step with x_h and with x_m
+    constexpr int TS = NPART * NK;                  // MFMAs (steps) per tile
     constexpr int PMAX = (NCHUNK + W - 1) / W;      // pieces per wave and buffer
     constexpr int PPS = (PMAX + SUB - 1) / SUB;     // pieces a wave copies during one tile
     constexpr int BS2 = (PPS + 1) / 2;
-    constexpr int LAG2 = (NK >= 8) ? NK - 2 : NK - 1;
+    constexpr int HALF = TS / 2;                    // second staging batch starts here
+    constexpr int LAG2 = (HALF >= 8) ? HALF - 2 : HALF - 1;
     constexpr int PSTRIDE = W * 1024;
+    constexpr int ES = XBF16 ? 2 : 4;               // element size of x / q
     static_assert(VQ_F16_TILE_GROUP % SUB == 0, "tile padding must cover the tiles of one barrier");
+    static_assert(!(XBF16 && NPART != 1), "bf16 rows are exact fp16 operands: one set");
+    static_assert(TS >= 2 && LAG2 >= 1, "staging schedule");
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -1059,14 +1068,20 @@ __global__ void __launch_bounds__(VQS_F32_WAVES * 64, 8 / VQS_F32_WAVES) vq_scre
     const int piece_off = wave * 1024 + lane * 16;
     const char *tiles = a.tiles16;
 
-    // ---- x rows (fp32): lane (j, half) holds features 16 ks + 8 half + 0..7 of its row for every k-step ----
+    // ---- x rows: lane (j, half) holds features 16 ks + 8 half + 0..7 of its row for every k-step ----
     const int64_t row = wrow0 + j;
     const bool row_ok = row < a.N;
-    f32x4 xr[NK][2];
-    {
-        const float *p = (const float *)a.x + (row_ok ? row : (a.N - 1)) * a.ldx + 8 * half;
+    constexpr bool KEEP = !XBF16 && DT <= 256;      // fp32 rows of 512 features do not fit the registers raw (256 of them): two passes
+    uint4 xh[NK], xm[NPART == 2 ? NK : 1];
+    f32x4 xr[KEEP ? NK : 1][2];
+    const float *xrow = (const float *)a.x + (row_ok ? row : (a.N - 1)) * a.ldx + 8 * half;
+    if (XBF16) {
+        const unsigned short *p = (const unsigned short *)a.x + (row_ok ? row : (a.N - 1)) * a.ldx + 8 * half;
 #pragma unroll
-        for (int ks = 0; ks < NK; ++ks) { xr[ks][0] = *(const f32x4 *)(p + ks * 16); xr[ks][1] = *(const f32x4 *)(p + ks * 16 + 4); }
+        for (int ks = 0; ks < NK; ++ks) xh[ks] = *(const uint4 *)(p + ks * 16);
+    } else if (KEEP) {
+#pragma unroll
+        for (int ks = 0; ks < NK; ++ks) { xr[ks][0] = *(const f32x4 *)(xrow + ks * 16); xr[ks][1] = *(const f32x4 *)(xrow + ks * 16 + 4); }
     }
 #pragma unroll
     for (int k = 0; k < PMAX; ++k)
@@ -1075,14 +1090,25 @@ __global__ void __launch_bounds__(VQS_F32_WAVES * 64, 8 / VQS_F32_WAVES) vq_scre
     float xs2;
     {
         float xs = 0.f;
+        if (XBF16) {
 #pragma unroll
-        for (int ks = 0; ks < NK; ++ks)
+            for (int ks = 0; ks < NK; ++ks) {
+                const unsigned w[4] = {xh[ks].x, xh[ks].y, xh[ks].z, xh[ks].w};
 #pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                const f32x4 v = xr[ks][q];
-                xs = __builtin_fmaf(v.x, v.x, xs); xs = __builtin_fmaf(v.y, v.y, xs);
-                xs = __builtin_fmaf(v.z, v.z, xs); xs = __builtin_fmaf(v.w, v.w, xs);
+                for (int q = 0; q < 4; ++q)
+                    xs = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, w[q]), __builtin_bit_cast(bf16x2, w[q]), xs, false);
             }
+        } else {
+#pragma unroll
+            for (int ks = 0; ks < NK; ++ks)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const f32x4 v = KEEP ? xr[KEEP ? ks : 0][q] : *(const f32x4 *)(xrow + ks * 16 + 4 * q);
+                    xs = __builtin_fmaf(v.x, v.x, xs); xs = __builtin_fmaf(v.y, v.y, xs);
+                    xs = __builtin_fmaf(v.z, v.z, xs); xs = __builtin_fmaf(v.w, v.w, xs);
+                    if (!KEEP && q == 1 && (ks & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+                }
+        }
         xs += __shfl_xor(xs, 32, 64);
         xs2 = xs * 1.001f;
     }
@@ -1103,8 +1129,53 @@ __global__ void __launch_bounds__(VQS_F32_WAVES * 64, 8 / VQS_F32_WAVES) vq_scre
     SX = SX > sc + 90 ? sc + 90 : SX;
     SX = SX > 126 ? 126 : (SX < -126 ? -126 : SX);
     const float S = __uint_as_float((unsigned)(SX + 127) << 23);
+    const float iS = __uint_as_float((unsigned)(127 - SX) << 23);
     const float SS = __uint_as_float((unsigned)(SX + sc + 127) << 23);
     const float iSS = __uint_as_float((unsigned)(127 - SX - sc) << 23);
+
+    // ---- rows -> scaled fp16 operand set(s) ----
+    float rx2 = 0.f;   // fp32 rows, one operand set: ||x' - x_h||^2 (scaled units)
+    if (XBF16) {
+#pragma unroll
+        for (int ks = 0; ks < NK; ++ks) {
+            unsigned w[4] = {xh[ks].x, xh[ks].y, xh[ks].z, xh[ks].w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float lo = __uint_as_float(w[q] << 16) * S, hi = __uint_as_float(w[q] & 0xffff0000u) * S;
+                w[q] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(lo, hi));   // exact above 2^-14, truncated below (conv)
+            }
+            xh[ks] = make_uint4(w[0], w[1], w[2], w[3]);
+        }
+    } else {
+        typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+        for (int ks = 0; ks < NK; ++ks) {
+            const f32x4 w0 = KEEP ? xr[KEEP ? ks : 0][0] : *(const f32x4 *)(xrow + ks * 16);        // second pass over the row (L2)
+            const f32x4 w1 = KEEP ? xr[KEEP ? ks : 0][1] : *(const f32x4 *)(xrow + ks * 16 + 4);
+            const float v[8] = {w0.x * S, w0.y * S, w0.z * S, w0.w * S, w1.x * S, w1.y * S, w1.z * S, w1.w * S};
+            unsigned hw[4], mw[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (NPART == 2) {      // x_h: truncated x', x_m: truncated exact remainder
+                    const f16x2 h = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(v[2 * q], v[2 * q + 1]));
+                    const float r0 = v[2 * q] - (float)h[0], r1 = v[2 * q + 1] - (float)h[1];   // exact: the low bits of x'
+                    hw[q] = __builtin_bit_cast(unsigned, h);
+                    mw[q] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(r0, r1));
+                } else {               // one set, rounded to nearest; the residual is measured, not modelled
+                    f16x2 h;
+                    h[0] = (_Float16)v[2 * q]; h[1] = (_Float16)v[2 * q + 1];
+                    const float r0 = v[2 * q] - (float)h[0], r1 = v[2 * q + 1] - (float)h[1];
+                    rx2 = __builtin_fmaf(r0, r0, rx2); rx2 = __builtin_fmaf(r1, r1, rx2);
+                    hw[q] = __builtin_bit_cast(unsigned, h);
+                    mw[q] = 0u;
+                }
+            }
+            xh[ks] = make_uint4(hw[0], hw[1], hw[2], hw[3]);
+            if (NPART == 2) xm[ks] = make_uint4(mw[0], mw[1], mw[2], mw[3]);
+            if (!KEEP && (ks & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // 4 k-steps of raw loads in flight, not all 32 (256 registers)
+        }
+        if (NPART == 1) rx2 += __shfl_xor(rx2, 32, 64);
+    }
 
     float eps;
     {
@@ -1112,32 +1183,17 @@ __global__ void __launch_bounds__(VQS_F32_WAVES * 64, 8 / VQS_F32_WAVES) vq_scre
         const float rmax = __uint_as_float(a.scalars[1]);
         const float ymax = sqrtf(y2max) * 1.0001f;
         const float u = 5.9604645e-8f;   // 2^-24
-        const float conv = 4.f * 5.9604645e-8f * sqrtf((float)DT) * ymax * __uint_as_float((unsigned)(127 - SX) << 23);   // two truncated operand sets
+        const float conv = 2.f * NPART * 5.9604645e-8f * sqrtf((float)DT) * ymax * iS;   // truncated elements of each operand set
         const float xn = sqrtf(xs2) * 1.0001f;
         const float xy = xn * ymax;
-        const float drop = 2.f * 9.5367432e-7f * 1.01f * xy;   // 2 codes x 2^-20 X Y: the part of x' neither x_h nor x_m carries
-        if (METRIC == 0) eps = u * (10.f * (xs2 + y2max + 2.f * xy) + 2.f * DT * xy + 4.f * (2 * DT + 1) * 1.001f * (xy + 0.5f * y2max))
+        // the part of x' the operand sets do not carry, for both codes of the margin
+        float drop = 0.f;
+        if (!XBF16 && NPART == 2) drop = 2.f * 9.5367432e-7f * 1.01f * xy;                       // 2^-20 X Y
+        if (!XBF16 && NPART == 1) drop = 2.f * sqrtf(rx2 * 1.001f) * 1.001f * iS * ymax;          // ||x' - x_h|| Y, measured
+        const float nacc = (float)(NPART * DT + 1);                                               // accumulated terms
+        if (METRIC == 0) eps = u * (10.f * (xs2 + y2max + 2.f * xy) + 2.f * DT * xy + 4.f * nacc * 1.001f * (xy + 0.5f * y2max))
                                + 2.f * xn * rmax + drop + conv + 4e-8f;
-        else             eps = 2.f * (u * 5.f * DT * 1.001f * xy + xn * rmax) + drop + conv + 1e-30f;
-    }
-
-    // ---- fp32 -> two scaled fp16 operand sets (x_h: truncated x', x_m: truncated exact remainder) ----
-    uint4 xh[NK], xm[NK];
-#pragma unroll
-    for (int ks = 0; ks < NK; ++ks) {
-        const float v[8] = {xr[ks][0].x * S, xr[ks][0].y * S, xr[ks][0].z * S, xr[ks][0].w * S,
-                            xr[ks][1].x * S, xr[ks][1].y * S, xr[ks][1].z * S, xr[ks][1].w * S};
-        unsigned hw[4], mw[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
-            const f16x2 h = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(v[2 * q], v[2 * q + 1]));
-            const float r0 = v[2 * q] - (float)h[0], r1 = v[2 * q + 1] - (float)h[1];   // exact: the low bits of x'
-            hw[q] = __builtin_bit_cast(unsigned, h);
-            mw[q] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(r0, r1));
-        }
-        xh[ks] = make_uint4(hw[0], hw[1], hw[2], hw[3]);
-        xm[ks] = make_uint4(mw[0], mw[1], mw[2], mw[3]);
+        else             eps = 2.f * (u * (DT + 2.f * NPART * DT) * 1.001f * xy + xn * rmax) + drop + conv + 1e-30f;
     }
 
     float m1 = -__builtin_inff(), m2 = -__builtin_inff(), m3 = -__builtin_inff();
@@ -1182,9 +1238,9 @@ __global__ void __launch_bounds__(VQS_F32_WAVES * 64, 8 / VQS_F32_WAVES) vq_scre
             for (int p = 0; p < VQS16_PF; ++p) af[p] = ap[(p % NK) * 64];
 #pragma unroll
             for (int s = 0; s < TS; ++s) {
-                const int ks = s >> 1;
+                const int ks = s / NPART;
                 const f16x8 av = __builtin_bit_cast(f16x8, af[ks % VQS16_PF]);
-                const f16x8 bv = __builtin_bit_cast(f16x8, (s & 1) ? xm[ks] : xh[ks]);
+                const f16x8 bv = __builtin_bit_cast(f16x8, (NPART == 2 && (s & 1)) ? xm[NPART == 2 ? ks : 0] : xh[ks]);
                 if (s == 0) {
                     f32x16 init;
                     if (METRIC == 0 || has_pad) {
@@ -1207,7 +1263,7 @@ __global__ void __launch_bounds__(VQS_F32_WAVES * 64, 8 / VQS_F32_WAVES) vq_scre
                 } else {
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bv, acc, 0, 0, 0);
                 }
-                if ((s & 1) && ks + VQS16_PF < NK) af[ks % VQS16_PF] = ap[(ks + VQS16_PF) * 64];
+                if ((s % NPART) == NPART - 1 && ks + VQS16_PF < NK) af[ks % VQS16_PF] = ap[(ks + VQS16_PF) * 64];
                 if (s >= 1) {   // epilogue slice of the previous tile: 16 scores over the steps 1 .. TS - 1
 #pragma unroll
                     for (int e = (s - 1) * 16 / (TS - 1); e < s * 16 / (TS - 1); ++e) fold(pa, e);
@@ -1215,7 +1271,7 @@ __global__ void __launch_bounds__(VQS_F32_WAVES * 64, 8 / VQS_F32_WAVES) vq_scre
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int bt = 0; bt < 2; ++bt) {
-                    if (s == bt * NK) {
+                    if (s == bt * HALF) {
 #pragma unroll
                         for (int i = 0; i < BS2; ++i)
                             if (bt * BS2 + i < PPS) {
@@ -1224,7 +1280,7 @@ __global__ void __launch_bounds__(VQS_F32_WAVES * 64, 8 / VQS_F32_WAVES) vq_scre
                             }
                         __builtin_amdgcn_sched_barrier(0);
                     }
-                    if (s == bt * NK + LAG2) {
+                    if (s == bt * HALF + LAG2) {
 #pragma unroll
                         for (int i = 0; i < BS2; ++i)
                             if (bt * BS2 + i < PPS) *(f32x4 *)(ldst + min(p0 + bt * BS2 + i, PMAX - 1) * PSTRIDE) = stg[i];
@@ -1286,34 +1342,57 @@ __global__ void __launch_bounds__(VQS_F32_WAVES * 64, 8 / VQS_F32_WAVES) vq_scre
         if (balp) base_p = atomicAdd(a.flag_count + 1, (int)__popcll(balp));
     }
 
-    // ---- q rows (fp32, from embed), residual and squared error: whole rows per wave, 8 in flight; x is re-read (coalesced) ----
+    // ---- q rows, residual and squared error: whole rows per wave instruction (lane l moves elements c0 + 4 l .. + 3 of a
+    //      256-element chunk), 8 rows in flight; x is re-read (coalesced).  Rows of the exact passes are skipped in the loss. ----
     if (a.q_out || a.sqerr_partial || a.resid_out) {
         const int counted = (row_ok && !flagged && (!a.row_mask || a.row_mask[row] != 0)) ? 1 : 0;
         const unsigned long long cmask = __ballot(counted && half == 0);
         const bool want_sq = a.sqerr_partial != nullptr;
         const bool want_x = want_sq || a.resid_out != nullptr;
         double ds = 0.0;
+        const char *codes = XBF16 ? (const char *)a.embed_bf16 : (const char *)a.embed;
 #pragma unroll
-        for (int r0 = 0; r0 < 32; r0 += 8) {
-            f32x4 g[8], xv[8];
+        for (int c0 = 0; c0 < DT; c0 += 256) {
+            const bool lane_on = c0 + lane * 4 < DT;
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int c = __builtin_amdgcn_readlane(code, r0 + u);
-                const int64_t rr = wrow0 + r0 + u;
-                if (lane * 4 < DT) {
-                    g[u] = *(const f32x4 *)(a.embed + (size_t)c * DT + lane * 4);
-                    if (want_x) xv[u] = *(const f32x4 *)((const float *)a.x + (rr < a.N ? rr : a.N - 1) * a.ldx + lane * 4);
+            for (int r0 = 0; r0 < 32; r0 += 8) {
+                f32x4 g[8], xv[8];     // bf16: the low two dwords carry the 4 elements
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int c = __builtin_amdgcn_readlane(code, r0 + u);
+                    const int64_t rr = wrow0 + r0 + u;
+                    if (lane_on) {
+                        const char *gp = codes + ((size_t)c * DT + c0 + lane * 4) * ES;
+                        const char *xp = (const char *)a.x + ((rr < a.N ? rr : a.N - 1) * a.ldx + c0 + lane * 4) * ES;
+                        if (XBF16) {
+                            const uint2 t = *(const uint2 *)gp; g[u].x = __uint_as_float(t.x); g[u].y = __uint_as_float(t.y);
+                            if (want_x) { const uint2 t2 = *(const uint2 *)xp; xv[u].x = __uint_as_float(t2.x); xv[u].y = __uint_as_float(t2.y); }
+                        } else {
+                            g[u] = *(const f32x4 *)gp;
+                            if (want_x) xv[u] = *(const f32x4 *)xp;
+                        }
+                    }
                 }
-            }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int64_t rr = wrow0 + r0 + u;
-                if (lane * 4 < DT) {
-                    if (a.q_out && rr < a.N) *(f32x4 *)((float *)a.q_out + rr * a.ldq + lane * 4) = g[u];
-                    if (a.resid_out && rr < a.N) *(f32x4 *)((float *)a.resid_out + rr * a.ldr + lane * 4) = xv[u] - g[u];
-                    if (want_sq && ((cmask >> (r0 + u)) & 1ull)) {
-                        const float d0 = g[u].x - xv[u].x, d1 = g[u].y - xv[u].y, d2 = g[u].z - xv[u].z, d3 = g[u].w - xv[u].w;
-                        ds += (double)(((d0 * d0 + d1 * d1) + d2 * d2) + d3 * d3);
+                for (int u = 0; u < 8; ++u) {
+                    const int64_t rr = wrow0 + r0 + u;
+                    if (lane_on) {
+                        float d0, d1, d2, d3;
+                        if (XBF16) {
+                            const uint2 gb = make_uint2(__float_as_uint(g[u].x), __float_as_uint(g[u].y));
+                            const uint2 xb2 = make_uint2(__float_as_uint(xv[u].x), __float_as_uint(xv[u].y));
+                            if (a.q_out && rr < a.N) *(uint2 *)((unsigned short *)a.q_out + rr * a.ldq + c0 + lane * 4) = gb;
+                            if (a.resid_out && rr < a.N) *(uint2 *)((unsigned short *)a.resid_out + rr * a.ldr + c0 + lane * 4) = vq_bf16x4_sub(xb2, gb);
+                            d0 = __uint_as_float(gb.x << 16) - __uint_as_float(xb2.x << 16);
+                            d1 = __uint_as_float(gb.x & 0xffff0000u) - __uint_as_float(xb2.x & 0xffff0000u);
+                            d2 = __uint_as_float(gb.y << 16) - __uint_as_float(xb2.y << 16);
+                            d3 = __uint_as_float(gb.y & 0xffff0000u) - __uint_as_float(xb2.y & 0xffff0000u);
+                        } else {
+                            if (a.q_out && rr < a.N) *(f32x4 *)((float *)a.q_out + rr * a.ldq + c0 + lane * 4) = g[u];
+                            if (a.resid_out && rr < a.N) *(f32x4 *)((float *)a.resid_out + rr * a.ldr + c0 + lane * 4) = xv[u] - g[u];
+                            d0 = g[u].x - xv[u].x; d1 = g[u].y - xv[u].y; d2 = g[u].z - xv[u].z; d3 = g[u].w - xv[u].w;
+                        }
+                        if (want_sq && ((cmask >> (r0 + u)) & 1ull)) ds += (double)(((d0 * d0 + d1 * d1) + d2 * d2) + d3 * d3);
                     }
                 }
             }
@@ -1613,7 +1692,7 @@ extern "C" size_t vqhip_screen_workspace_bytes(int64_t N)
 
 extern "C" int vqhip_screen_supported(int64_t N, int D, int C)
 {
-    return (D == 32 || D == 64 || D == 128 || D == 256) && N > 0 && N < ((int64_t)1 << 31) - 512 && C >= 2;
+    return (D == 32 || D == 64 || D == 128 || D == 256 || D == 512) && N > 0 && N < ((int64_t)1 << 31) - 512 && C >= 2;
 }
 
 // VQHIP_SCREEN_BF16X2=1 selects the two-pass bf16 hi/lo kernel for bf16 rows (A/B runs against vq_screen16_kernel)
@@ -1627,28 +1706,40 @@ static bool screen_bf16x2()
 template <int DT, int METRIC>
 static int launch_screen(const ScreenArgs &a, int x_dtype, hipStream_t st)
 {
-    constexpr int SMEM = 2 * (128 * DT + 1024);
-    static VqAttrOnce once_b, once_f, once_h;
     const unsigned blocks = (unsigned)vqhip_screen_blocks(a.N, x_dtype);
-    if (x_dtype == VQHIP_BF16 && !screen_bf16x2()) {
-        constexpr int SMEM16 = Screen16Cfg<DT>::SMEM;
-        if (int rc = vq_set_max_smem(once_h, (const void *)vq_screen16_kernel<DT, METRIC>, SMEM16, "vq_screen16_kernel")) return rc;
-        hipLaunchKernelGGL((vq_screen16_kernel<DT, METRIC>), dim3(blocks), dim3(VQS_WAVES * 64), SMEM16, st, a);
-        return vq_launch_status("vq_screen16_kernel");
+    if (!screen_bf16x2() || DT > 256) {
+        // fp16 single-codebook-part kernels: bf16 rows with D <= 256 keep two row blocks per wave, everything else one
+        if (x_dtype == VQHIP_BF16) {
+            if constexpr (DT <= 256) {
+                static VqAttrOnce once;
+                constexpr int SMEM16 = Screen16Cfg<DT>::SMEM;
+                if (int rc = vq_set_max_smem(once, (const void *)vq_screen16_kernel<DT, METRIC>, SMEM16, "vq_screen16_kernel")) return rc;
+                hipLaunchKernelGGL((vq_screen16_kernel<DT, METRIC>), dim3(blocks), dim3(VQS_WAVES * 64), SMEM16, st, a);
+            } else {
+                static VqAttrOnce once;
+                constexpr int SMEM16 = Screen16F32Cfg<DT>::SMEM;
+                if (int rc = vq_set_max_smem(once, (const void *)vq_screen16_1rb_kernel<DT, METRIC, true, 1>, SMEM16, "vq_screen16_1rb_kernel")) return rc;
+                hipLaunchKernelGGL((vq_screen16_1rb_kernel<DT, METRIC, true, 1>), dim3(blocks), dim3(VQS_F32_WAVES * 64), SMEM16, st, a);
+            }
+        } else {
+            static VqAttrOnce once;
+            constexpr int SMEM16 = Screen16F32Cfg<DT>::SMEM;
+            constexpr int NPART = DT <= 256 ? 2 : 1;
+            if (int rc = vq_set_max_smem(once, (const void *)vq_screen16_1rb_kernel<DT, METRIC, false, NPART>, SMEM16, "vq_screen16_1rb_kernel")) return rc;
+            hipLaunchKernelGGL((vq_screen16_1rb_kernel<DT, METRIC, false, NPART>), dim3(blocks), dim3(VQS_F32_WAVES * 64), SMEM16, st, a);
+        }
+        return vq_launch_status("vq_screen16 kernels");
     }
-    if (x_dtype == VQHIP_F32 && !screen_bf16x2()) {
-        static VqAttrOnce once_hf;
-        constexpr int SMEM16 = Screen16F32Cfg<DT>::SMEM;
-        if (int rc = vq_set_max_smem(once_hf, (const void *)vq_screen16_f32_kernel<DT, METRIC>, SMEM16, "vq_screen16_f32_kernel")) return rc;
-        hipLaunchKernelGGL((vq_screen16_f32_kernel<DT, METRIC>), dim3(blocks), dim3(VQS_F32_WAVES * 64), SMEM16, st, a);
-        return vq_launch_status("vq_screen16_f32_kernel");
+    if constexpr (DT <= 256) {   // VQHIP_SCREEN_BF16X2=1: the two-pass bf16 hi/lo kernels (A/B runs)
+        constexpr int SMEM = 2 * (128 * DT + 1024);
+        static VqAttrOnce once_b, once_f;
+        if (int rc = vq_set_max_smem(once_b, (const void *)vq_screen_kernel<DT, METRIC>, SMEM, "vq_screen_kernel")) return rc;
+        if (int rc = vq_set_max_smem(once_f, (const void *)vq_screen_f32_kernel<DT, METRIC>, SMEM, "vq_screen_f32_kernel")) return rc;
+        if (x_dtype == VQHIP_BF16)
+            hipLaunchKernelGGL((vq_screen_kernel<DT, METRIC>), dim3(blocks), dim3(VQS_WAVES * 64), SMEM, st, a);
+        else
+            hipLaunchKernelGGL((vq_screen_f32_kernel<DT, METRIC>), dim3(blocks), dim3(VQS_F32_WAVES * 64), SMEM, st, a);
     }
-    if (int rc = vq_set_max_smem(once_b, (const void *)vq_screen_kernel<DT, METRIC>, SMEM, "vq_screen_kernel")) return rc;
-    if (int rc = vq_set_max_smem(once_f, (const void *)vq_screen_f32_kernel<DT, METRIC>, SMEM, "vq_screen_f32_kernel")) return rc;
-    if (x_dtype == VQHIP_BF16)
-        hipLaunchKernelGGL((vq_screen_kernel<DT, METRIC>), dim3(blocks), dim3(VQS_WAVES * 64), SMEM, st, a);
-    else
-        hipLaunchKernelGGL((vq_screen_f32_kernel<DT, METRIC>), dim3(blocks), dim3(VQS_F32_WAVES * 64), SMEM, st, a);
     return vq_launch_status("vq_screen_kernel");
 }
 
@@ -1669,7 +1760,7 @@ extern "C" int vqhip_assign_screened(const void *x, int x_dtype, int64_t N, int 
     if (x_dtype != VQHIP_F32 && x_dtype != VQHIP_BF16) VQ_FAIL(VQHIP_EINVAL, "assign_screened: unknown x dtype %d", x_dtype);
     if (metric != VQHIP_EUCLID && metric != VQHIP_COSINE_PRENORM)
         VQ_FAIL(VQHIP_EINVAL, "assign_screened: metric %d (VQHIP_EUCLID, or VQHIP_COSINE_PRENORM on rows normalised by vqhip_l2norm_rows)", metric);
-    if (!vqhip_screen_supported(N, D, C)) VQ_FAIL(VQHIP_EDIM, "assign_screened: N=%lld D=%d C=%d outside the screened path (D in {32,64,128,256}, C >= 2)", (long long)N, D, C);
+    if (!vqhip_screen_supported(N, D, C)) VQ_FAIL(VQHIP_EDIM, "assign_screened: N=%lld D=%d C=%d outside the screened path (D in {32,64,128,256,512}, C >= 2)", (long long)N, D, C);
     if (workspace_bytes < vqhip_screen_workspace_bytes(N)) VQ_FAIL(VQHIP_EINVAL, "assign_screened: workspace too small");
     if (ldx < D || (q_out && ldq < D) || (resid_out && ldr < D)) VQ_FAIL(VQHIP_EINVAL, "assign_screened: row stride smaller than D");
     const int es = (x_dtype == VQHIP_BF16) ? 2 : 4;
@@ -1707,10 +1798,11 @@ extern "C" int vqhip_assign_screened(const void *x, int x_dtype, int64_t N, int 
         case 32: rc = dispatch_screen<32>(a, x_dtype, metric, st); break;
         case 64: rc = dispatch_screen<64>(a, x_dtype, metric, st); break;
         case 128: rc = dispatch_screen<128>(a, x_dtype, metric, st); break;
-        default: rc = dispatch_screen<256>(a, x_dtype, metric, st); break;
+        case 256: rc = dispatch_screen<256>(a, x_dtype, metric, st); break;
+        default: rc = dispatch_screen<512>(a, x_dtype, metric, st); break;
     }
     if (rc) return rc;
-    const int with_pairs = screen_bf16x2() ? 0 : 1;   // the fp16 screening kernels also build the pair list
+    const int with_pairs = (screen_bf16x2() && D <= 256) ? 0 : 1;   // the fp16 screening kernels also build the pair list
     return vq_assign_listed(x, x_dtype, metric, N, D, ldx, packed, embed, C, idx_out, q_out, ldq, resid_out, ldr,
                             sqerr_partial ? sqerr_partial + vqhip_screen_blocks(N, x_dtype) : nullptr, row_mask, rows, count, keys,
                             with_pairs, st);

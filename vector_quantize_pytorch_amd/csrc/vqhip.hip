@@ -796,6 +796,62 @@ __global__ void __launch_bounds__(256) vq_row_sumsq_kernel(const void *x, int64_
     out[n] = aten_sumsq_seq([&](int e) { return load_elem<XBF16>(x, n * ldx + e); }, D);
 }
 
+// Score of ONE given code per row in the reference's arithmetic: the Euclidean distance cdist(x_n, c_idx) (vqp.py:58-62: ATen-order
+// norms, x.c as one ascending fp32 FMA chain, (x2 + y2) + (-2 xy), clamp, correctly rounded sqrt) or, for unit-norm rows, the
+// cosine similarity x_n . c_idx (vqp.py:741) -- bit for bit what vq_assign_kernel reports as the winner's score.  The screened
+// search does not produce scores; a codebook-sharded argmin needs the winner's exact score to merge shards (one chain per row).
+template <bool XBF16, int METRIC>
+__global__ void __launch_bounds__(256) vq_score_idx_kernel(const void *x, int64_t N, int D, int64_t ldx, const float *embed,
+                                                           const float *packed, int DT, const int64_t *idx, float *out)
+{
+    const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    const int64_t c = idx[n];
+    const float *e = embed + (size_t)c * D;
+    float xy = 0.f;
+    for (int k = 0; k < D; k += 4) {
+        float xv[4];
+        if (XBF16) {
+            const uint2 w = *(const uint2 *)((const unsigned short *)x + n * ldx + k);
+            xv[0] = __uint_as_float(w.x << 16); xv[1] = __uint_as_float(w.x & 0xffff0000u);
+            xv[2] = __uint_as_float(w.y << 16); xv[3] = __uint_as_float(w.y & 0xffff0000u);
+        } else {
+            const f32x4 w = *(const f32x4 *)((const float *)x + n * ldx + k);
+            xv[0] = w.x; xv[1] = w.y; xv[2] = w.z; xv[3] = w.w;
+        }
+        const f32x4 u = *(const f32x4 *)(e + k);
+        xy = __builtin_fmaf(xv[0], u.x, xy); xy = __builtin_fmaf(xv[1], u.y, xy);
+        xy = __builtin_fmaf(xv[2], u.z, xy); xy = __builtin_fmaf(xv[3], u.w, xy);
+    }
+    if (METRIC == 0) {
+        const float x2 = aten_sumsq_seq([&](int i) { return load_elem<XBF16>(x, n * ldx + i); }, D);
+        const float y2 = packed[(size_t)(c >> 5) * (32 * DT + 256) + 32 * DT + (c & 31)];
+        out[n] = sqrtf(fmaxf(__builtin_fmaf(-2.f, xy, x2 + y2), 1e-8f));
+    } else {
+        out[n] = xy;
+    }
+}
+
+extern "C" int vqhip_score_indices(const void *x, int x_dtype, int64_t N, int D, int64_t ldx, const float *packed, const float *embed,
+                                   int C, int metric, const int64_t *idx, float *out, void *stream)
+{
+    if (!x || !packed || !embed || !idx || !out || N < 0 || C <= 0) VQ_FAIL(VQHIP_EINVAL, "score_indices: bad argument");
+    if (x_dtype != VQHIP_F32 && x_dtype != VQHIP_BF16) VQ_FAIL(VQHIP_EINVAL, "score_indices: unknown dtype %d", x_dtype);
+    if (metric != VQHIP_EUCLID && metric != VQHIP_COSINE_PRENORM) VQ_FAIL(VQHIP_EINVAL, "score_indices: metric %d (VQHIP_EUCLID or VQHIP_COSINE_PRENORM)", metric);
+    const int DT = pick_dt(D);
+    if (DT == 0 || (D & 3)) VQ_FAIL(VQHIP_EDIM, "score_indices: D=%d unsupported (multiple of 4, <= 512)", D);
+    const int es = (x_dtype == VQHIP_BF16) ? 2 : 4;
+    if ((((uintptr_t)x) % (4 * es)) || ((ldx * es) % (4 * es)) || (((uintptr_t)embed) & 15)) VQ_FAIL(VQHIP_EALIGN, "score_indices: rows must be aligned to 4 elements");
+    if (N == 0) return 0;
+    const unsigned blocks = (unsigned)((N + 255) / 256);
+    hipStream_t st = (hipStream_t)stream;
+#define VQ_SI(B, M) hipLaunchKernelGGL((vq_score_idx_kernel<B, M>), dim3(blocks), dim3(256), 0, st, x, N, D, ldx, embed, packed, DT, idx, out)
+    if (metric == VQHIP_EUCLID) { if (x_dtype == VQHIP_BF16) VQ_SI(true, 0); else VQ_SI(false, 0); }
+    else                        { if (x_dtype == VQHIP_BF16) VQ_SI(true, 1); else VQ_SI(false, 1); }
+#undef VQ_SI
+    return launch_status("vq_score_idx_kernel");
+}
+
 extern "C" int vqhip_row_sumsq(const void *x, int x_dtype, int64_t N, int D, int64_t ldx, float *out, void *stream)
 {
     if (!x || !out || N < 0) VQ_FAIL(VQHIP_EINVAL, "row_sumsq: bad argument");
@@ -955,7 +1011,7 @@ extern "C" int vqhip_l2norm_rows(const void *x, int x_dtype, int64_t N, int D, i
     if (N == 0) return 0;
     if (!x || !out) VQ_FAIL(VQHIP_EINVAL, "l2norm_rows: null pointer");
     if (x_dtype != VQHIP_F32 && x_dtype != VQHIP_BF16) VQ_FAIL(VQHIP_EINVAL, "l2norm_rows: unknown dtype %d", x_dtype);
-    if (D != 32 && D != 64 && D != 128 && D != 256) VQ_FAIL(VQHIP_EDIM, "l2norm_rows: D=%d unsupported (32, 64, 128, 256)", D);
+    if (D != 32 && D != 64 && D != 128 && D != 256 && D != 512) VQ_FAIL(VQHIP_EDIM, "l2norm_rows: D=%d unsupported (32, 64, 128, 256, 512)", D);
     const int es = (x_dtype == VQHIP_BF16) ? 2 : 4;
     if (ldx < D || ldo < D) VQ_FAIL(VQHIP_EINVAL, "l2norm_rows: row stride smaller than D");
     if ((((uintptr_t)x) % (4 * es)) || ((ldx * es) % (4 * es)) || (((uintptr_t)out) % (4 * es)) || ((ldo * es) % (4 * es)))
@@ -971,7 +1027,8 @@ extern "C" int vqhip_l2norm_rows(const void *x, int x_dtype, int64_t N, int D, i
         case 32: VQ_L2N(32); break;
         case 64: VQ_L2N(64); break;
         case 128: VQ_L2N(128); break;
-        default: VQ_L2N(256); break;
+        case 256: VQ_L2N(256); break;
+        default: VQ_L2N(512); break;
     }
 #undef VQ_L2N
     return launch_status("vq_l2norm_kernel");
@@ -1000,7 +1057,7 @@ struct RefineArgs {
 };
 
 template <int DT, bool XBF16, int METRIC>
-__global__ void __launch_bounds__(256, 2) vq_refine_kernel(const RefineArgs a)
+__global__ void __launch_bounds__(256, (DT <= 256 ? 2 : 1)) vq_refine_kernel(const RefineArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int TILE_F = 32 * DT + 256;
@@ -1132,25 +1189,25 @@ __global__ void __launch_bounds__(256) vq_finish_listed_kernel(const FinishArgs 
         const int idx = (int)(unsigned)(a.keys[pos] & 0xffffffffull);
         if (lane == 0) a.idx_out[row] = (int64_t)idx;
         float ls = 0.f;
-        if (lane * 4 < a.D) {
+        for (int c0 = lane * 4; c0 < a.D; c0 += 256) {
             float d0, d1, d2, d3;
             if (XBF16) {
-                const uint2 g = *(const uint2 *)((const unsigned short *)a.codes + (size_t)idx * a.D + lane * 4);
-                const uint2 xv = *(const uint2 *)((const unsigned short *)a.x + row * a.ldx + lane * 4);
-                if (a.q_out) *(uint2 *)((unsigned short *)a.q_out + row * a.ldq + lane * 4) = g;
-                if (a.resid_out) *(uint2 *)((unsigned short *)a.resid_out + row * a.ldr + lane * 4) = vq_bf16x4_sub(xv, g);
+                const uint2 g = *(const uint2 *)((const unsigned short *)a.codes + (size_t)idx * a.D + c0);
+                const uint2 xv = *(const uint2 *)((const unsigned short *)a.x + row * a.ldx + c0);
+                if (a.q_out) *(uint2 *)((unsigned short *)a.q_out + row * a.ldq + c0) = g;
+                if (a.resid_out) *(uint2 *)((unsigned short *)a.resid_out + row * a.ldr + c0) = vq_bf16x4_sub(xv, g);
                 d0 = __uint_as_float(g.x << 16) - __uint_as_float(xv.x << 16);
                 d1 = __uint_as_float(g.x & 0xffff0000u) - __uint_as_float(xv.x & 0xffff0000u);
                 d2 = __uint_as_float(g.y << 16) - __uint_as_float(xv.y << 16);
                 d3 = __uint_as_float(g.y & 0xffff0000u) - __uint_as_float(xv.y & 0xffff0000u);
             } else {
-                const f32x4 g = *(const f32x4 *)((const float *)a.codes + (size_t)idx * a.D + lane * 4);
-                const f32x4 xv = *(const f32x4 *)((const float *)a.x + row * a.ldx + lane * 4);
-                if (a.q_out) *(f32x4 *)((float *)a.q_out + row * a.ldq + lane * 4) = g;
-                if (a.resid_out) *(f32x4 *)((float *)a.resid_out + row * a.ldr + lane * 4) = xv - g;
+                const f32x4 g = *(const f32x4 *)((const float *)a.codes + (size_t)idx * a.D + c0);
+                const f32x4 xv = *(const f32x4 *)((const float *)a.x + row * a.ldx + c0);
+                if (a.q_out) *(f32x4 *)((float *)a.q_out + row * a.ldq + c0) = g;
+                if (a.resid_out) *(f32x4 *)((float *)a.resid_out + row * a.ldr + c0) = xv - g;
                 d0 = g.x - xv.x; d1 = g.y - xv.y; d2 = g.z - xv.z; d3 = g.w - xv.w;
             }
-            ls = ((d0 * d0 + d1 * d1) + d2 * d2) + d3 * d3;
+            ls += ((d0 * d0 + d1 * d1) + d2 * d2) + d3 * d3;
         }
         double ds = (double)ls;
 #pragma unroll
@@ -1289,6 +1346,7 @@ int vq_assign_listed(const void *x, int x_dtype, int metric, int64_t N, int D, i
         case 64: rc = dispatch_refine<64>(r, x_dtype, metric, gx, st); break;
         case 128: rc = dispatch_refine<128>(r, x_dtype, metric, gx, st); break;
         case 256: rc = dispatch_refine<256>(r, x_dtype, metric, gx, st); break;
+        case 512: rc = dispatch_refine<512>(r, x_dtype, metric, gx, st); break;
         default: VQ_FAIL(VQHIP_EDIM, "assign_listed: D=%d unsupported", D);
     }
     if (rc) return rc;
@@ -1302,7 +1360,8 @@ int vq_assign_listed(const void *x, int x_dtype, int metric, int64_t N, int D, i
             case 32: rc = dispatch_pair<32>(pa, x_dtype, metric, blocks, st); break;
             case 64: rc = dispatch_pair<64>(pa, x_dtype, metric, blocks, st); break;
             case 128: rc = dispatch_pair<128>(pa, x_dtype, metric, blocks, st); break;
-            default: rc = dispatch_pair<256>(pa, x_dtype, metric, blocks, st); break;
+            case 256: rc = dispatch_pair<256>(pa, x_dtype, metric, blocks, st); break;
+            default: rc = dispatch_pair<512>(pa, x_dtype, metric, blocks, st); break;
         }
         if (rc) return rc;
     }

@@ -78,7 +78,7 @@ class ShardedVectorQuantize(torch.nn.Module):
     Returns (quantized [b, n, d], global indices [b, n], commit_loss) like VectorQuantize."""
 
     def __init__(self, dim, codebook_size, *, use_cosine_sim=False, decay=0.8, eps=1e-5, commitment_weight=1.,
-                 group=None, gather_input=True, emulate=None):
+                 group=None, gather_input=True, emulate=None, rotation_trick=True, route_gradients_to_input=True, init_embed=None):
         super().__init__()
         from .codebook import Codebook
         self.group = group
@@ -93,42 +93,55 @@ class ShardedVectorQuantize(torch.nn.Module):
         self.use_cosine_sim, self.decay, self.eps = use_cosine_sim, decay, eps
         self.commitment_weight = commitment_weight
         self.gather_input = gather_input
-        # identical RNG consumption on every rank: build the full codebook, keep the shard
-        full = Codebook(dim=dim, codebook_size=codebook_size, use_cosine_sim=use_cosine_sim, decay=decay, eps=eps,
-                        threshold_ema_dead_code=0, manual_ema_update=True)
+        self.rotation_trick = rotation_trick
+        self.route_gradients_to_input = route_gradients_to_input
+        # identical RNG consumption on every rank: build (or be handed) the full codebook [1, C, d], keep the shard
+        if init_embed is None:
+            init_embed = Codebook(dim=dim, codebook_size=codebook_size, use_cosine_sim=use_cosine_sim, decay=decay, eps=eps,
+                                  threshold_ema_dead_code=0, manual_ema_update=True).embed
+        state = torch.random.get_rng_state()
         self._codebook = Codebook(dim=dim, codebook_size=self.hi - self.lo, use_cosine_sim=use_cosine_sim, decay=decay,
                                   eps=eps, threshold_ema_dead_code=0, manual_ema_update=True)
+        torch.random.set_rng_state(state)             # the shard's own (discarded) init does not advance the generator
         with torch.no_grad():
-            self._codebook.embed.copy_(full.embed[:, self.lo:self.hi])
-            self._codebook.embed_avg.copy_(full.embed_avg[:, self.lo:self.hi])
+            self._codebook.embed.copy_(init_embed.detach()[:, self.lo:self.hi])
+            self._codebook.embed_avg.copy_(init_embed.detach()[:, self.lo:self.hi])
 
     def _collectives_on(self):
         return self.world > 1 and not self._emulated
 
     @torch.no_grad()
-    def forward(self, x):
+    def _search_and_update(self, xin):
+        """xin [n_local, d]: this rank's rows, already unit-norm for the cosine metric.  -> (q rows fp32 [n_local, d], global indices)."""
         from . import _lib as L
         cb = self._codebook
-        b, n, d = x.shape
-        rows = x.reshape(-1, d)
+        d = xin.shape[-1]
+        cos = self.use_cosine_sim
         if self._collectives_on() and self.gather_input:
-            allrows = torch.empty(self.world * rows.shape[0], d, dtype=x.dtype, device=x.device)
-            dist.all_gather_into_tensor(allrows, rows.contiguous(), group=self.group)
+            allrows = torch.empty(self.world * xin.shape[0], d, dtype=xin.dtype, device=xin.device)
+            dist.all_gather_into_tensor(allrows, xin.contiguous(), group=self.group)
         else:
-            allrows = rows
+            allrows = xin
         e = cb.embed[0]
-        r = L.assign(allrows, L.pack_codebook(e), e, cosine=self.use_cosine_sim, want_q=False, want_best=True,
-                     want_rnorm=self.use_cosine_sim)
-        gidx, _ = merge_sharded_argmin(r["best"], r["idx"], self.lo, euclid=not self.use_cosine_sim, group=self.group)
+        packed = L.pack_codebook(e)
+        if L.screen_supported(allrows, e.shape[0]):
+            # MFMA-screened search of the shard (csrc/vq_screen.hip) + the winner's score in the reference's arithmetic
+            # (vqhip_score_indices): the cross-shard merge needs exact scores, the screen only certifies indices
+            r = L.assign(allrows, packed, e, cosine=cos, skip_l2norm=True, want_q=False)
+            best = L.score_indices(allrows, packed, e, r["idx"], cosine=cos)
+        else:
+            r = L.assign(allrows, packed, e, cosine=cos, skip_l2norm=True, want_q=False, want_best=True)
+            best = r["best"]
+        gidx, _ = merge_sharded_argmin(best, r["idx"], self.lo, euclid=not cos, group=self.group if self._collectives_on() else None)
         mine = (gidx >= self.lo) & (gidx < self.hi)
         local = torch.where(mine, gidx - self.lo, torch.full_like(gidx, -1))
         q_part = L.decode_sum(local[:, None].contiguous(), e, out_dtype=torch.float32)      # zeros where another rank owns the winner
-        n_local = rows.shape[0]
+        n_local = xin.shape[0]
         if self._collectives_on():
             if self.gather_input:
                 backend = dist.get_backend(self.group)
                 if backend == "nccl":
-                    q_rows = torch.empty(n_local, d, dtype=torch.float32, device=x.device)
+                    q_rows = torch.empty(n_local, d, dtype=torch.float32, device=xin.device)
                     dist.reduce_scatter_tensor(q_rows, q_part, group=self.group)
                 else:       # gloo (CPU-side tests): no reduce-scatter
                     dist.all_reduce(q_part, group=self.group)
@@ -139,22 +152,40 @@ class ShardedVectorQuantize(torch.nn.Module):
                 q_rows, idx_rows = q_part, gidx
         else:
             q_rows, idx_rows = q_part, gidx
-        q_rows = q_rows.to(x.dtype)
 
-        loss = torch.zeros((), device=x.device)
         if self.training:
-            xin = torch.nn.functional.normalize(rows.float(), dim=-1, eps=1e-6) if self.use_cosine_sim else rows.float()
-            loss = ((q_rows.float() - xin) ** 2).mean() * self.commitment_weight
             # EMA on the owner: all rows, indices of foreign winners masked to -1 (skipped by the kernel)
             C = self.hi - self.lo
-            count, esum = L.ema_accumulate(allrows, local.contiguous(), C, cosine=self.use_cosine_sim, rnorm=r["rnorm"])
+            count, esum = L.ema_accumulate(allrows, local.contiguous(), C)
             cb._fold_stats(0, count, esum, None, False, True)        # lerp only (manual_ema_update)
             total = cb.cluster_size.sum()
             if self._collectives_on():
                 dist.all_reduce(total, group=self.group)
             smoothed = (cb.cluster_size + self.eps) / (total + self.codebook_size * self.eps) * total
             new = cb.embed_avg / smoothed[..., None]
-            if self.use_cosine_sim:
+            if cos:
                 new = torch.nn.functional.normalize(new, dim=-1, eps=1e-6)
             cb.embed.copy_(new)
-        return q_rows.reshape(b, n, d), idx_rows.reshape(b, n), loss
+        return q_rows, idx_rows
+
+    def forward(self, x):
+        from . import _lib as L
+        b, n, d = x.shape
+        needs_grad = self.training and x.requires_grad and torch.is_grad_enabled()
+        rows = x.reshape(-1, d)
+        if self.use_cosine_sim:
+            # gradients flow through the l2norm (vqp.py:1159); without them the HIP kernel normalises in the reference's arithmetic
+            xin = torch.nn.functional.normalize(rows, p=2, dim=-1, eps=1e-6) if needs_grad or not L.screen_supported(rows, 2) \
+                else L.l2norm_rows(rows)
+        else:
+            xin = rows
+        q_rows, idx_rows = self._search_and_update(xin.detach())
+        q_rows = q_rows.to(x.dtype)
+        quantize = q_rows
+        loss = torch.zeros((), device=x.device)
+        if self.training:
+            if needs_grad and self.route_gradients_to_input:
+                from .vector_quantize import _RouteFn
+                quantize = _RouteFn.apply(xin.contiguous(), q_rows.contiguous(), L.ROTATION if self.rotation_trick else L.STRAIGHT_THROUGH)
+            loss = torch.nn.functional.mse_loss(q_rows.detach().float(), xin.float()) * self.commitment_weight   # vqp.py:1327
+        return quantize.reshape(b, n, d), idx_rows.reshape(b, n), loss

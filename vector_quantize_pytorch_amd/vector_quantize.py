@@ -164,7 +164,12 @@ class VectorQuantize(nn.Module):
         sync_update_v=0.,
         return_zeros_for_masked_padding=True,
         route_gradients_to_input=True,
+        shard_codebook=False,
     ):
+        """Constructor keywords = the reference's (vqp.py:803-849) plus ONE extension: `shard_codebook=True` partitions the
+        codebook over the ranks of the default process group (rank p owns codes [p C/P, (p+1) C/P), BASELINE config 4): every
+        rank searches its shard with the HIP kernels and ONE RCCL all-reduce(MAX) of packed (score, index) keys picks the
+        global winner with the reference's tie rule (parallel.ShardedVectorQuantize).  EMA codebooks with heads == 1 only."""
         super().__init__()
 
         # derived defaults, as vqp.py:854-856
@@ -266,6 +271,22 @@ class VectorQuantize(nn.Module):
             affine_param_batch_decay=affine_param_batch_decay,
             affine_param_codebook_decay=affine_param_codebook_decay,
         )
+        self._sharded = None
+        if shard_codebook:
+            bad = [n for n, v in dict(heads=heads > 1, kmeans_init=kmeans_init, learnable_codebook=learnable_codebook or has_orth,
+                                      affine_param=affine_param, vq_bridge=vq_bridge is not None,
+                                      threshold_ema_dead_code=threshold_ema_dead_code > 0, dense_options=dense_options,
+                                      directional_reparam=directional_reparam, accept_fmap=accept_image_fmap or accept_3d_fmap,
+                                      in_place_codebook_optimizer=in_place_codebook_optimizer is not None,
+                                      ema_update_off=not ema_update).items() if v]
+            if bad:
+                raise NotImplementedError(f"shard_codebook=True supports plain EMA codebooks only (unsupported here: {', '.join(bad)})")
+            from .parallel import ShardedVectorQuantize
+            self._sharded = ShardedVectorQuantize(codebook_dim, codebook_size, use_cosine_sim=use_cosine_sim, decay=decay, eps=eps,
+                                                  commitment_weight=commitment_weight, rotation_trick=rotation_trick,
+                                                  route_gradients_to_input=route_gradients_to_input,
+                                                  init_embed=self._codebook.embed)     # same init as the unsharded module
+            self._codebook = self._sharded._codebook          # this rank's shard: state_dict keys as usual, one shard per rank
         self.in_place_codebook_optimizer = in_place_codebook_optimizer(self._codebook.parameters()) \
             if in_place_codebook_optimizer is not None else None
         self.manual_in_place_optimizer_update = manual_in_place_optimizer_update
@@ -448,6 +469,15 @@ class VectorQuantize(nn.Module):
     ):
         if codebook_transform_fn is not None:
             raise NotImplementedError("codebook_transform_fn (QINCo implicit codebooks) is not on the MI355X hot path (SURVEY.md §8f)")
+        if self._sharded is not None:
+            if any(v is not None for v in (indices, mask, lens, topk, sample_codebook_temp, ema_update_weight, ema_update)) or accum_ema_update \
+                    or return_loss_breakdown or x.ndim != 3:
+                raise NotImplementedError("shard_codebook=True: forward(x [b, n, d]) only")
+            L._need_gpu(x)
+            xs = x if self.channel_last else x.transpose(1, 2)
+            q, ind, loss = self._sharded(self.project_in(xs))
+            q = self.project_out(q)
+            return (q if self.channel_last else q.transpose(1, 2)), ind, loss
         if (indices is not None or topk is not None) and self.heads > 1:
             raise NotImplementedError("forward(indices= / topk=) is implemented for heads == 1 only")
         L._need_gpu(x)
