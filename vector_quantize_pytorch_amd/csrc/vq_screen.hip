@@ -497,7 +497,11 @@ template <int DT> struct Screen16Cfg {
     static constexpr int SMEM = 2 * BUF_B;
 };
 
-template <int DT, int METRIC>
+// XF32: fp32 rows with ONE fp16 operand set per row, x_h = fp16_rne(x 2^SX) -- the same sweep as for bf16 rows (two row blocks per
+// wave, half the MFMAs and LDS reads per row of the two-set kernel further down).  The certificate charges the MEASURED residual
+// ||x' - x_h|| Y per code.  The scale is chosen per row block (rows of different blocks are never compared), so that a row block's
+// raw fp32 values (128 registers at D = 256) are converted before the next one is loaded.
+template <int DT, int METRIC, bool XF32 = false>
 __global__ void __launch_bounds__(VQS_WAVES * 64, 8 / VQS_WAVES) vq_screen16_kernel(const ScreenArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -532,18 +536,46 @@ __global__ void __launch_bounds__(VQS_WAVES * 64, 8 / VQS_WAVES) vq_screen16_ker
     const int piece_off = wave * 1024 + lane * 16;
     const char *tiles = a.tiles16;
 
-    // ---- x rows (bf16), requested first: lane (j, half) holds x[row][16 ks + 8 half + 0..7] for every k-step ----
+    // ---- x rows, requested first: lane (j, half) holds x[row][16 ks + 8 half + 0..7] for every k-step ----
     uint4 xb[2][NK];
     int64_t rows[2];
     bool row_ok[2];
+    float xs2[2], rxn[2] = {0.f, 0.f};     // ||x||^2 (x 1.001) and, for fp32 rows, ||x' - x_h|| in unscaled units
+    int SXv[2];
+    const int sc = (int)a.scalars[2];
+    // scale exponent from the largest FINITE squared row norm `mx` (float bits) of the rows sharing it.  Every element is <= ||x||, so
+    // bringing that norm below 2^14 keeps every element below fp16's 65504 (rows with a non-finite norm can never be certified
+    // anyway); elements then sit around 2^14 / sqrt(D), far above fp16's 2^-14.  sc is the codebook's (scalars[2]); SX + sc stays
+    // inside fp32's exponent range so that every power of two below is exact, and SX - sc <= 90 keeps -||c||^2/2 * 2^(SX+sc) finite
+    // (rows that tiny against the codebook lose bits in the conversion, which `conv` charges).
+    auto pick_sx = [&](unsigned mx) {
+        const int e2 = (int)(mx >> 23) - 127;          // largest ||x||^2 in [2^e2, 2^(e2+1))  =>  ||x|| < 2^((e2 >> 1) + 1)
+        int SX = (mx == 0u) ? 0 : 14 - ((e2 >> 1) + 1);
+        SX = SX > 120 - sc ? 120 - sc : SX;
+        SX = SX < -120 - sc ? -120 - sc : SX;
+        SX = SX > sc + 90 ? sc + 90 : SX;
+        return SX > 126 ? 126 : (SX < -126 ? -126 : SX);
+    };
+    auto wave_max_finite = [&](float v) {
+        const unsigned bits = __float_as_uint(v);
+        unsigned mx = (bits & 0x7f800000u) == 0x7f800000u ? 0u : (bits & 0x7fffffffu);
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) { const unsigned t = (unsigned)__shfl_xor((int)mx, o, 64); mx = t > mx ? t : mx; }
+        return (unsigned)__builtin_amdgcn_readfirstlane((int)mx);
+    };
 #pragma unroll
     for (int rb = 0; rb < 2; ++rb) {
         rows[rb] = wrow0 + rb * 32 + j;
         row_ok[rb] = rows[rb] < a.N;
-        const int64_t rc = row_ok[rb] ? rows[rb] : (a.N - 1);
-        const unsigned short *p = (const unsigned short *)a.x + rc * a.ldx + 8 * half;
+    }
+    if (!XF32) {
 #pragma unroll
-        for (int ks = 0; ks < NK; ++ks) xb[rb][ks] = *(const uint4 *)(p + ks * 16);
+        for (int rb = 0; rb < 2; ++rb) {
+            const int64_t rc = row_ok[rb] ? rows[rb] : (a.N - 1);
+            const unsigned short *p = (const unsigned short *)a.x + rc * a.ldx + 8 * half;
+#pragma unroll
+            for (int ks = 0; ks < NK; ++ks) xb[rb][ks] = *(const uint4 *)(p + ks * 16);
+        }
     }
     // ---- first buffer: wave w copies the 1-KiB pieces w, w + WAVES, ... (PMAX of them: a piece past the buffer's end reads
     //      the next tiles / the tail pad and lands in the LDS pad) ----
@@ -551,46 +583,85 @@ __global__ void __launch_bounds__(VQS_WAVES * 64, 8 / VQS_WAVES) vq_screen16_ker
     for (int k = 0; k < PMAX; ++k)
         *(f32x4 *)(smem + piece_off + k * PSTRIDE) = *(const f32x4 *)(tiles + piece_off + (size_t)k * PSTRIDE);
 
-    // ---- ||x||^2 per row (any order: it only scales the bound) ----
-    float xs2[2];
+    if (!XF32) {
+        // ---- bf16 rows: ||x||^2 per row (any order: it only scales the bound), one scale for the wave, exact conversion ----
 #pragma unroll
-    for (int rb = 0; rb < 2; ++rb) {
-        float xs = 0.f;
+        for (int rb = 0; rb < 2; ++rb) {
+            float xs = 0.f;
 #pragma unroll
-        for (int ks = 0; ks < NK; ++ks) {
-            const unsigned w[4] = {xb[rb][ks].x, xb[rb][ks].y, xb[rb][ks].z, xb[rb][ks].w};
+            for (int ks = 0; ks < NK; ++ks) {
+                const unsigned w[4] = {xb[rb][ks].x, xb[rb][ks].y, xb[rb][ks].z, xb[rb][ks].w};
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
-                xs = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, w[q]), __builtin_bit_cast(bf16x2, w[q]), xs, false);
+                for (int q = 0; q < 4; ++q)
+                    xs = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, w[q]), __builtin_bit_cast(bf16x2, w[q]), xs, false);
+            }
+            xs += __shfl_xor(xs, 32, 64);
+            xs2[rb] = xs * 1.001f;
         }
-        xs += __shfl_xor(xs, 32, 64);
-        xs2[rb] = xs * 1.001f;
+        const unsigned m0 = wave_max_finite(xs2[0]), m1b = wave_max_finite(xs2[1]);
+        SXv[0] = SXv[1] = pick_sx(m0 > m1b ? m0 : m1b);
+        const float S = __uint_as_float((unsigned)(SXv[0] + 127) << 23);
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+            for (int ks = 0; ks < NK; ++ks) {
+                unsigned w[4] = {xb[rb][ks].x, xb[rb][ks].y, xb[rb][ks].z, xb[rb][ks].w};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float lo = __uint_as_float(w[q] << 16) * S, hi = __uint_as_float(w[q] & 0xffff0000u) * S;
+                    w[q] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(lo, hi));   // exact above 2^-14, truncated below (conv)
+                }
+                xb[rb][ks] = make_uint4(w[0], w[1], w[2], w[3]);
+            }
+    } else {
+        // ---- fp32 rows, one row block at a time: raw values -> ||x||^2 -> the block's scale -> x_h = fp16_rne(x') and the residual ----
+        typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) {
+            const float *p = (const float *)a.x + (row_ok[rb] ? rows[rb] : (a.N - 1)) * a.ldx + 8 * half;
+            f32x4 xr[NK][2];
+#pragma unroll
+            for (int ks = 0; ks < NK; ++ks) { xr[ks][0] = *(const f32x4 *)(p + ks * 16); xr[ks][1] = *(const f32x4 *)(p + ks * 16 + 4); }
+            float xs = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < NK; ++ks)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const f32x4 v = xr[ks][q];
+                    xs = __builtin_fmaf(v.x, v.x, xs); xs = __builtin_fmaf(v.y, v.y, xs);
+                    xs = __builtin_fmaf(v.z, v.z, xs); xs = __builtin_fmaf(v.w, v.w, xs);
+                }
+            xs += __shfl_xor(xs, 32, 64);
+            xs2[rb] = xs * 1.001f;
+            SXv[rb] = pick_sx(wave_max_finite(xs2[rb]));
+            const float S = __uint_as_float((unsigned)(SXv[rb] + 127) << 23);
+            float r2 = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < NK; ++ks) {
+                const float v[8] = {xr[ks][0].x * S, xr[ks][0].y * S, xr[ks][0].z * S, xr[ks][0].w * S,
+                                    xr[ks][1].x * S, xr[ks][1].y * S, xr[ks][1].z * S, xr[ks][1].w * S};
+                unsigned hw[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    f16x2 h;
+                    h[0] = (_Float16)v[2 * q]; h[1] = (_Float16)v[2 * q + 1];
+                    const float r0 = v[2 * q] - (float)h[0], r1 = v[2 * q + 1] - (float)h[1];   // exact
+                    r2 = __builtin_fmaf(r0, r0, r2); r2 = __builtin_fmaf(r1, r1, r2);
+                    hw[q] = __builtin_bit_cast(unsigned, h);
+                }
+                xb[rb][ks] = make_uint4(hw[0], hw[1], hw[2], hw[3]);
+            }
+            r2 += __shfl_xor(r2, 32, 64);
+            rxn[rb] = sqrtf(r2 * 1.001f) * 1.001f * __uint_as_float((unsigned)(127 - SXv[rb]) << 23);
+            __builtin_amdgcn_sched_barrier(0);   // finish this block before the next block's 128 raw registers are requested
+        }
     }
-    // scale exponents.  SX: every element is <= ||x||, so bringing the largest FINITE row norm of the wave below 2^14 keeps
-    // every element of those rows below fp16's 65504 (rows with a non-finite norm can never be certified anyway); elements
-    // then sit around 2^14 / sqrt(D), far above fp16's 2^-14.  sc is the codebook's (scalars[2]); the sum SX + sc is kept
-    // inside fp32's exponent range so that every power of two below is exact.
-    unsigned mx = 0;
+    float SSv[2], iSSv[2];
 #pragma unroll
     for (int rb = 0; rb < 2; ++rb) {
-        const unsigned bits = __float_as_uint(xs2[rb]);
-        const unsigned fin = (bits & 0x7f800000u) == 0x7f800000u ? 0u : (bits & 0x7fffffffu);
-        mx = fin > mx ? fin : mx;
+        SSv[rb] = __uint_as_float((unsigned)(SXv[rb] + sc + 127) << 23);
+        iSSv[rb] = __uint_as_float((unsigned)(127 - SXv[rb] - sc) << 23);
     }
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) { const unsigned t = (unsigned)__shfl_xor((int)mx, o, 64); mx = t > mx ? t : mx; }
-    mx = (unsigned)__builtin_amdgcn_readfirstlane((int)mx);
-    const int sc = (int)a.scalars[2];
-    const int e2 = (int)(mx >> 23) - 127;          // largest ||x||^2 in [2^e2, 2^(e2+1))  =>  ||x|| < 2^((e2 >> 1) + 1)
-    int SX = (mx == 0u) ? 0 : 14 - ((e2 >> 1) + 1);
-    SX = SX > 120 - sc ? 120 - sc : SX;
-    SX = SX < -120 - sc ? -120 - sc : SX;
-    SX = SX > sc + 90 ? sc + 90 : SX;      // -||c||^2/2 * 2^(SX+sc) < 2^27 * 2^(SX-sc) stays finite (rows that tiny against the codebook
-                                           // lose bits in the conversion, which `conv` below charges)
-    SX = SX > 126 ? 126 : (SX < -126 ? -126 : SX);
-    const float S = __uint_as_float((unsigned)(SX + 127) << 23);
-    const float SS = __uint_as_float((unsigned)(SX + sc + 127) << 23);
-    const float iSS = __uint_as_float((unsigned)(127 - SX - sc) << 23);
 
     // ---- threshold (unscaled units; see the file header for the terms that did not change) ----
     float eps[2];
@@ -599,32 +670,19 @@ __global__ void __launch_bounds__(VQS_WAVES * 64, 8 / VQS_WAVES) vq_screen16_ker
         const float rmax = __uint_as_float(a.scalars[1]);
         const float ymax = sqrtf(y2max) * 1.0001f;
         const float u = 5.9604645e-8f;   // 2^-24
-        // truncated elements: |dx_k| <= 2^-24 / S each, sum_k |dx_k| |c1_k - c2_k| <= 2^-24 / S * sqrt(D) * 2 Y
-        const float conv = 2.f * 5.9604645e-8f * sqrtf((float)DT) * ymax * __uint_as_float((unsigned)(127 - SX) << 23);
 #pragma unroll
         for (int rb = 0; rb < 2; ++rb) {
+            // truncated elements: |dx_k| <= 2^-24 / S each, sum_k |dx_k| |c1_k - c2_k| <= 2^-24 / S * sqrt(D) * 2 Y
+            const float conv = 2.f * 5.9604645e-8f * sqrtf((float)DT) * ymax * __uint_as_float((unsigned)(127 - SXv[rb]) << 23);
             const float xs = xs2[rb];
             const float xn = sqrtf(xs) * 1.0001f;
             const float xy = xn * ymax;
+            const float drop = XF32 ? 2.f * rxn[rb] * ymax : 0.f;     // |(x' - x_h).c| <= ||x' - x_h|| Y, both codes of the margin
             if (METRIC == 0) eps[rb] = u * (10.f * (xs + y2max + 2.f * xy) + 2.f * DT * xy + 4.f * (DT + 1) * 1.001f * (xy + 0.5f * y2max))
-                                       + 2.f * xn * rmax + conv + 4e-8f;
-            else             eps[rb] = 2.f * (u * 3.f * DT * 1.001f * xy + xn * rmax) + conv + 1e-30f;
+                                       + 2.f * xn * rmax + drop + conv + 4e-8f;
+            else             eps[rb] = 2.f * (u * 3.f * DT * 1.001f * xy + xn * rmax) + drop + conv + 1e-30f;
         }
     }
-
-    // ---- bf16 -> scaled fp16, in place ----
-#pragma unroll
-    for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-        for (int ks = 0; ks < NK; ++ks) {
-            unsigned w[4] = {xb[rb][ks].x, xb[rb][ks].y, xb[rb][ks].z, xb[rb][ks].w};
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float lo = __uint_as_float(w[q] << 16) * S, hi = __uint_as_float(w[q] & 0xffff0000u) * S;
-                w[q] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(lo, hi));
-            }
-            xb[rb][ks] = make_uint4(w[0], w[1], w[2], w[3]);
-        }
 
     float m1[2] = {-__builtin_inff(), -__builtin_inff()};
     float m2[2] = {-__builtin_inff(), -__builtin_inff()};
@@ -686,11 +744,7 @@ __global__ void __launch_bounds__(VQS_WAVES * 64, 8 / VQS_WAVES) vq_screen16_ker
             for (int s = 0; s < 2 * NK; ++s) {
                 const int ph = s / NK, ks = s % NK;
                 const f16x8 av = __builtin_bit_cast(f16x8, af[s % VQS16_PF]);
-#ifdef VQS16_INIT2
-                if (ks == 0) {
-#else
-                if (s == 0) {
-#endif
+                if (XF32 ? (ks == 0) : (s == 0)) {   // fp32 rows: the two row blocks have their own scales, hence their own start values
                     // start value -||c||^2 / 2 (scaled); register e <-> code 8 (e >> 2) + 4 half + (e & 3) of the tile.  Tiles with
                     // padding codes clamp it to a finite -3e38 (scaled, the padding's -3e38 overflows to -inf, and -inf with the
                     // code number in its mantissa is a NaN key that v_med3_f32 must never see).
@@ -700,7 +754,7 @@ __global__ void __launch_bounds__(VQS_WAVES * 64, 8 / VQS_WAVES) vq_screen16_ker
                             f32x4 v = *(const f32x4 *)(nh + 8 * q + 4 * half);
                             if (METRIC != 0) { v.x = v.x < -1e38f ? v.x : 0.f; v.y = v.y < -1e38f ? v.y : 0.f;
                                                v.z = v.z < -1e38f ? v.z : 0.f; v.w = v.w < -1e38f ? v.w : 0.f; }
-                            init[4 * q + 0] = v.x * SS; init[4 * q + 1] = v.y * SS; init[4 * q + 2] = v.z * SS; init[4 * q + 3] = v.w * SS;
+                            init[4 * q + 0] = v.x * SSv[ph]; init[4 * q + 1] = v.y * SSv[ph]; init[4 * q + 2] = v.z * SSv[ph]; init[4 * q + 3] = v.w * SSv[ph];
                         }
                         if (has_pad) {
 #pragma unroll
@@ -802,7 +856,7 @@ __global__ void __launch_bounds__(VQS_WAVES * 64, 8 / VQS_WAVES) vq_screen16_ker
                     f32x4 v = *(const f32x4 *)(nh + 8 * q + 4 * half);
                     if (METRIC != 0) { v.x = v.x < -1e38f ? v.x : 0.f; v.y = v.y < -1e38f ? v.y : 0.f;
                                        v.z = v.z < -1e38f ? v.z : 0.f; v.w = v.w < -1e38f ? v.w : 0.f; }
-                    init[4 * q + 0] = v.x * SS; init[4 * q + 1] = v.y * SS; init[4 * q + 2] = v.z * SS; init[4 * q + 3] = v.w * SS;
+                    init[4 * q + 0] = v.x * SSv[0]; init[4 * q + 1] = v.y * SSv[0]; init[4 * q + 2] = v.z * SSv[0]; init[4 * q + 3] = v.w * SSv[0];
                 }
                 if (has_pad) {
 #pragma unroll
@@ -895,7 +949,7 @@ __global__ void __launch_bounds__(VQS_WAVES * 64, 8 / VQS_WAVES) vq_screen16_ker
         const int id2 = second_low ? il1 : ih2;
         const float b3 = second_low ? fmaxf(h2, l2) : fmaxf(h3, l1);
         code[rb] = ih1;
-        const float thr = eps[rb] * SS + 8e-6f * fabsf(b1);
+        const float thr = eps[rb] * SSv[rb] + 8e-6f * fabsf(b1);
         const bool certified = ((b1 - b2) > thr) && code[rb] < a.C;
         const bool pair = !certified && ((b1 - b3) > thr) && code[rb] < a.C && id2 < a.C;
         flagged[rb] = !certified;
@@ -903,7 +957,7 @@ __global__ void __launch_bounds__(VQS_WAVES * 64, 8 / VQS_WAVES) vq_screen16_ker
             a.idx_out[rows[rb]] = (int64_t)(code[rb] < a.C ? code[rb] : 0);
             if (a.dbg) {
                 float *d = a.dbg + rows[rb] * 4;
-                d[0] = b1 * iSS; d[1] = b2 * iSS; d[2] = thr * iSS; d[3] = certified ? 0.f : (pair ? 2.f : 1.f);
+                d[0] = b1 * iSSv[rb]; d[1] = b2 * iSSv[rb]; d[2] = thr * iSSv[rb]; d[3] = certified ? 0.f : (pair ? 2.f : 1.f);
             }
         }
         if (code[rb] >= a.C) code[rb] = 0;
@@ -925,10 +979,10 @@ __global__ void __launch_bounds__(VQS_WAVES * 64, 8 / VQS_WAVES) vq_screen16_ker
 
     VQ_PHASE(3);   // idx + list written
     // ---- outputs: whole rows per wave instruction (lane l moves elements 4 l .. 4 l + 3), RU rows in flight; x is re-read
-    //      (coalesced) for the squared error and the residual.  Rows of the exact pass are skipped in the loss here. ----
+    //      (coalesced) for the squared error and the residual.  Rows of the exact passes are skipped in the loss here. ----
     double ds = 0.0;
     if (a.q_out || a.resid_out || a.sqerr_partial) {
-        constexpr int RU = 16;
+        constexpr int RU = XF32 ? 8 : 16;
         const bool want_x = a.sqerr_partial != nullptr || a.resid_out != nullptr;
         const bool lane_on = lane * 4 < DT;
 #pragma unroll
@@ -937,29 +991,54 @@ __global__ void __launch_bounds__(VQS_WAVES * 64, 8 / VQS_WAVES) vq_screen16_ker
             const unsigned long long cmask = __ballot(counted && half == 0);
 #pragma unroll
             for (int r0 = 0; r0 < 32; r0 += RU) {
-                uint2 g[RU], xv[RU];
+                if (!XF32) {
+                    uint2 g[RU], xv[RU];
 #pragma unroll
-                for (int u = 0; u < RU; ++u) {
-                    const int c = __builtin_amdgcn_readlane(code[rb], r0 + u);
-                    const int64_t rr = wrow0 + rb * 32 + r0 + u;
-                    if (lane_on) {
-                        g[u] = *(const uint2 *)(a.embed_bf16 + (size_t)c * DT + lane * 4);
-                        if (want_x) xv[u] = *(const uint2 *)((const unsigned short *)a.x + (rr < a.N ? rr : a.N - 1) * a.ldx + lane * 4);
+                    for (int u = 0; u < RU; ++u) {
+                        const int c = __builtin_amdgcn_readlane(code[rb], r0 + u);
+                        const int64_t rr = wrow0 + rb * 32 + r0 + u;
+                        if (lane_on) {
+                            g[u] = *(const uint2 *)(a.embed_bf16 + (size_t)c * DT + lane * 4);
+                            if (want_x) xv[u] = *(const uint2 *)((const unsigned short *)a.x + (rr < a.N ? rr : a.N - 1) * a.ldx + lane * 4);
+                        }
                     }
-                }
 #pragma unroll
-                for (int u = 0; u < RU; ++u) {
-                    const int64_t rr = wrow0 + rb * 32 + r0 + u;
-                    if (rr < a.N && lane_on) {
-                        if (a.q_out) *(uint2 *)((unsigned short *)a.q_out + rr * a.ldq + lane * 4) = g[u];
-                        if (a.resid_out) *(uint2 *)((unsigned short *)a.resid_out + rr * a.ldr + lane * 4) = vq_bf16x4_sub(xv[u], g[u]);
+                    for (int u = 0; u < RU; ++u) {
+                        const int64_t rr = wrow0 + rb * 32 + r0 + u;
+                        if (rr < a.N && lane_on) {
+                            if (a.q_out) *(uint2 *)((unsigned short *)a.q_out + rr * a.ldq + lane * 4) = g[u];
+                            if (a.resid_out) *(uint2 *)((unsigned short *)a.resid_out + rr * a.ldr + lane * 4) = vq_bf16x4_sub(xv[u], g[u]);
+                        }
+                        if (a.sqerr_partial && lane_on && ((cmask >> (r0 + u)) & 1ull)) {
+                            const float d0 = __uint_as_float(g[u].x << 16) - __uint_as_float(xv[u].x << 16);
+                            const float d1 = __uint_as_float(g[u].x & 0xffff0000u) - __uint_as_float(xv[u].x & 0xffff0000u);
+                            const float d2 = __uint_as_float(g[u].y << 16) - __uint_as_float(xv[u].y << 16);
+                            const float d3 = __uint_as_float(g[u].y & 0xffff0000u) - __uint_as_float(xv[u].y & 0xffff0000u);
+                            ds += (double)(((d0 * d0 + d1 * d1) + d2 * d2) + d3 * d3);
+                        }
                     }
-                    if (a.sqerr_partial && lane_on && ((cmask >> (r0 + u)) & 1ull)) {
-                        const float d0 = __uint_as_float(g[u].x << 16) - __uint_as_float(xv[u].x << 16);
-                        const float d1 = __uint_as_float(g[u].x & 0xffff0000u) - __uint_as_float(xv[u].x & 0xffff0000u);
-                        const float d2 = __uint_as_float(g[u].y << 16) - __uint_as_float(xv[u].y << 16);
-                        const float d3 = __uint_as_float(g[u].y & 0xffff0000u) - __uint_as_float(xv[u].y & 0xffff0000u);
-                        ds += (double)(((d0 * d0 + d1 * d1) + d2 * d2) + d3 * d3);
+                } else {
+                    f32x4 g[RU], xv[RU];
+#pragma unroll
+                    for (int u = 0; u < RU; ++u) {
+                        const int c = __builtin_amdgcn_readlane(code[rb], r0 + u);
+                        const int64_t rr = wrow0 + rb * 32 + r0 + u;
+                        if (lane_on) {
+                            g[u] = *(const f32x4 *)(a.embed + (size_t)c * DT + lane * 4);
+                            if (want_x) xv[u] = *(const f32x4 *)((const float *)a.x + (rr < a.N ? rr : a.N - 1) * a.ldx + lane * 4);
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < RU; ++u) {
+                        const int64_t rr = wrow0 + rb * 32 + r0 + u;
+                        if (rr < a.N && lane_on) {
+                            if (a.q_out) *(f32x4 *)((float *)a.q_out + rr * a.ldq + lane * 4) = g[u];
+                            if (a.resid_out) *(f32x4 *)((float *)a.resid_out + rr * a.ldr + lane * 4) = xv[u] - g[u];
+                        }
+                        if (a.sqerr_partial && lane_on && ((cmask >> (r0 + u)) & 1ull)) {
+                            const float d0 = g[u].x - xv[u].x, d1 = g[u].y - xv[u].y, d2 = g[u].z - xv[u].z, d3 = g[u].w - xv[u].w;
+                            ds += (double)(((d0 * d0 + d1 * d1) + d2 * d2) + d3 * d3);
+                        }
                     }
                 }
             }
@@ -1722,6 +1801,18 @@ static int launch_screen(const ScreenArgs &a, int x_dtype, hipStream_t st)
                 hipLaunchKernelGGL((vq_screen16_1rb_kernel<DT, METRIC, true, 1>), dim3(blocks), dim3(VQS_F32_WAVES * 64), SMEM16, st, a);
             }
         } else {
+            // fp32 rows, D <= 256: one fp16 operand set, two row blocks per wave (VQHIP_SCREEN_F32_2PART=1: the two-set kernel, A/B)
+            static int two_part = -1;
+            if (two_part < 0) { const char *e = getenv("VQHIP_SCREEN_F32_2PART"); two_part = (e && e[0] == '1') ? 1 : 0; }
+            if constexpr (DT <= 256) {
+                if (!two_part) {
+                    static VqAttrOnce once;
+                    constexpr int SMEM16 = Screen16Cfg<DT>::SMEM;
+                    if (int rc = vq_set_max_smem(once, (const void *)vq_screen16_kernel<DT, METRIC, true>, SMEM16, "vq_screen16_kernel (fp32 rows)")) return rc;
+                    hipLaunchKernelGGL((vq_screen16_kernel<DT, METRIC, true>), dim3(blocks), dim3(VQS_WAVES * 64), SMEM16, st, a);
+                    return vq_launch_status("vq_screen16_kernel (fp32 rows)");
+                }
+            }
             static VqAttrOnce once;
             constexpr int SMEM16 = Screen16F32Cfg<DT>::SMEM;
             constexpr int NPART = DT <= 256 ? 2 : 1;
