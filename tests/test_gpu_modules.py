@@ -566,3 +566,106 @@ def test_shard_codebook_single_rank_equals_plain_module(dev, cosine, dim, dtype)
         ((qb.float() * w).sum() + lb).backward()
         assert (xa.grad.float() - xb.grad.float()).abs().max().item() <= 10 * tol * max(xa.grad.float().abs().max().item(), 1e-6)
         assert (a._codebook.embed - b._codebook.embed).abs().max().item() <= 1e-5 * a._codebook.embed.abs().max().item()
+
+
+def _dp_rvq_worker(rank, world, port, out_path, shared):
+    import os
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)       # 2 ranks sharing the one test GPU
+    from vector_quantize_pytorch_amd import ResidualVQ
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    rvq = ResidualVQ(dim=64, num_quantizers=3, codebook_size=96, shared_codebook=shared, sync_codebook=True).to(dev).train()
+    x = torch.randn(2, 400, 64, generator=torch.Generator().manual_seed(300 + rank)).to(dev)
+    for _ in range(2):
+        q, idx, loss = rvq(x)
+    torch.save(dict(idx=idx.cpu(), embed=torch.stack([l._codebook.embed.cpu() for l in rvq.layers])), f"{out_path}.{rank}")
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("shared", [True, False])
+def test_data_parallel_residual_vq_one_allreduce_equals_single_process(dev, tmp_path, shared):
+    """ResidualVQ under data parallelism: the statistics of all Q stages travel in ONE [Q, C D + C] all-reduce per forward
+    (SURVEY §8e); 2 ranks == one process on the concatenated batch."""
+    import socket
+    import torch.multiprocessing as mp
+    from vector_quantize_pytorch_amd import ResidualVQ
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    out = str(tmp_path / "dprvq")
+    mp.spawn(_dp_rvq_worker, args=(2, port, out, shared), nprocs=2, join=True)
+    r = [torch.load(f"{out}.{k}") for k in range(2)]
+    torch.manual_seed(0)
+    rvq = ResidualVQ(dim=64, num_quantizers=3, codebook_size=96, shared_codebook=shared, sync_codebook=False).to(dev).train()
+    x = torch.cat([torch.randn(2, 400, 64, generator=torch.Generator().manual_seed(300 + k)) for k in range(2)], 0).to(dev)
+    for _ in range(2):
+        q, idx, loss = rvq(x)
+    assert torch.equal(r[0]["embed"], r[1]["embed"])
+    assert torch.equal(torch.cat([r[0]["idx"], r[1]["idx"]], 0), idx.cpu())
+    _close(r[0]["embed"], torch.stack([l._codebook.embed for l in rvq.layers]), 1e-5, "embed")
+
+
+# ---- ADVICE (round 1): the fused residual loop must not be taken by layers whose options change the search or need autograd ----
+@pytest.mark.parametrize("opt", [dict(affine_param=True), dict(stochastic_sample_codes=True, sample_codebook_temp=0.5),
+                                 dict(learnable_codebook=True, ema_update=False), dict(codebook_diversity_loss_weight=0.1),
+                                 dict(orthogonal_reg_weight=0.1)])
+@pytest.mark.parametrize("train", [False, True])
+def test_residual_vq_options_outside_the_fused_loop_take_the_staged_path(dev, opt, train):
+    from vector_quantize_pytorch_amd import ResidualVQ
+    torch.manual_seed(1)
+    rvq = ResidualVQ(dim=64, num_quantizers=3, codebook_size=64, **opt).to(dev)
+    rvq = rvq.train() if train else rvq.eval()
+    x = torch.randn(2, 300, 64, device=dev)            # no grad on the input: the case that used to slip into the fused loop
+    assert not rvq._fused_eligible(x, None)
+    torch.manual_seed(7); q1, i1, l1 = rvq._forward_staged(x, None, None, False, None) if not train else (None, None, None)
+    if not train and not opt.get("affine_param"):       # eval mode is deterministic: forward() must equal the staged path
+        torch.manual_seed(7); q0, i0, l0 = rvq(x)        # (affine_param keeps updating its batch statistics in eval: stateful)
+        assert torch.equal(i0, i1) and torch.equal(q0, q1)
+    elif not train:
+        q0, i0, l0 = rvq(x)
+        assert i0.shape == (2, 300, 3)
+    else:
+        q0, i0, l0 = rvq(x)
+        assert i0.shape == (2, 300, 3) and bool(torch.isfinite(l0).all())
+        if opt.get("learnable_codebook"):
+            l0.sum().backward()
+            assert rvq.layers[0]._codebook.embed.grad is not None    # the codebook receives its gradient (it did not through the fused loop)
+
+
+def test_accum_ema_update_statistics_are_folded_exactly_once(dev):
+    """vqp.py:80-82: parked statistics are added to the next fold and then dropped ("old.grad = None")."""
+    from vector_quantize_pytorch_amd import VectorQuantize
+    torch.manual_seed(0)
+    a = VectorQuantize(dim=32, codebook_size=64).to(dev).train()
+    b = VectorQuantize(dim=32, codebook_size=64).to(dev).train()
+    b.load_state_dict(a.state_dict())
+    g = torch.Generator().manual_seed(1)
+    xs = [torch.randn(2, 200, 32, generator=g).to(dev) for _ in range(4)]
+    a(xs[0], accum_ema_update=True)               # parked
+    a(xs[1])                                      # folds xs[0] + xs[1] statistics, clears the parked ones
+    assert a._codebook.cluster_size.grad is None and a._codebook.embed_avg.grad is None
+    # from here on `a` must behave like a module that never parked anything
+    b._codebook.load_state_dict(a._codebook.state_dict())
+    for x in xs[2:]:
+        qa, ia, la = a(x)
+        qb, ib, lb = b(x)
+        assert torch.equal(ia, ib)
+    # (the segmented sums meet in fp32 atomics: the last bits depend on arrival order)
+    _close(a._codebook.embed, b._codebook.embed, 1e-5, "embed")
+    _close(a._codebook.cluster_size, b._codebook.cluster_size, 1e-6, "cluster_size")
+
+
+def test_fused_residual_loop_expiry_samples_only_unmasked_rows(dev):
+    """separate codebooks + dead-code replacement + mask through the fused loop: replacement rows must come from rows with
+    mask == True (vqp.py:641 passes seq_mask)."""
+    from vector_quantize_pytorch_amd import ResidualVQ
+    torch.manual_seed(0)
+    rvq = ResidualVQ(dim=32, num_quantizers=2, codebook_size=64, threshold_ema_dead_code=2).to(dev).train()
+    x = torch.randn(2, 300, 32, device=dev)
+    x[:, 150:] = 1000.0                                   # padded positions carry a sentinel value
+    mask = torch.zeros(2, 300, dtype=torch.bool, device=dev); mask[:, :150] = True
+    assert rvq._fused_eligible(x, mask)
+    for _ in range(3):
+        rvq(x, mask=mask)
+    for layer in rvq.layers:
+        assert float(layer._codebook.embed.abs().max()) < 100.0, "a code was re-seeded from a masked row"

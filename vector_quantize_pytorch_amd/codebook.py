@@ -408,10 +408,11 @@ class Codebook(nn.Module):
         ind = ind.masked_fill(ind == -1, 0).reshape(H, -1).contiguous()
         rmask = None if mask is None else mask.reshape(-1)
         for h in range(H):
-            count, esum = L.ema_accumulate(xs[h], ind[h], C, row_mask=rmask)
+            buf = torch.zeros(C * self.dim + C, dtype=torch.float32, device=xs.device)
+            esum, count = buf[: C * self.dim].view(C, self.dim), buf[C * self.dim:]
+            L.ema_accumulate(xs[h], ind[h], C, row_mask=rmask, count=count, embed_sum=esum)
             if self.use_ddp:
-                dist.all_reduce(count)
-                dist.all_reduce(esum)
+                dist.all_reduce(buf)              # ONE collective for count || embed_sum
             self._fold_stats(h, count, esum, ema_update_weight, accum_ema_update, ema_update)
         if not accum_ema_update:
             self.expire_codes_(xs.reshape(H, -1, self.dim), seq_mask=None if rmask is None else rmask[None].expand(H, -1).bool())

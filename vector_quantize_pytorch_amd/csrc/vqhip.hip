@@ -24,6 +24,7 @@
 // follows the reference's CPU arithmetic; the dot product itself is ONE fp32 FMA chain in ascending
 // k (what the f32 MFMA computes), which oracle/vq_oracle.c restates.  BUILD WITH -ffp-contract=off.
 
+#include <stdlib.h>
 #include <string.h>
 #include <math.h>
 
@@ -130,10 +131,13 @@ extern "C" size_t vqhip_packed_bytes(int C, int D)
 
 __global__ void __launch_bounds__(256) vq_pack_kernel(const float *__restrict__ embed, int C, int D, int DT,
                                                       float *__restrict__ packed, unsigned short *__restrict__ ebf,
-                                                      char *__restrict__ screen, unsigned *__restrict__ scalars)
+                                                      char *__restrict__ screen, unsigned *__restrict__ scalars, int legacy_screen)
 {
     __shared__ float y2sh[32];
     const int t = blockIdx.x;
+    // blockIdx.y splits a tile's work over two workgroups (a 1024-code codebook is only 32 tiles): y = 1 writes the bf16 copy,
+    // y = 0 the fp32 tile, the norms and (legacy_screen: VQHIP_SCREEN_BF16X2=1 A/B runs only) the bf16 hi/lo screening tile
+    if (blockIdx.y == 1) {
     if ((D & 3) == 0) {   // RNE-rounded bf16 copy of this tile's 32 code rows, 4 elements per store
         for (int p = threadIdx.x; p < 8 * D; p += 256) {
             const size_t o = (size_t)t * 32 * D + 4 * (size_t)p;
@@ -150,6 +154,8 @@ __global__ void __launch_bounds__(256) vq_pack_kernel(const float *__restrict__ 
             const size_t o = (size_t)t * 32 * D + p;
             if (o < (size_t)C * D) ebf[o] = f32_to_bf16_rne(embed[o]);
         }
+    }
+    return;
     }
     const int tile_f = 32 * DT + 256;
     float *out = packed + (size_t)t * tile_f;
@@ -181,7 +187,7 @@ __global__ void __launch_bounds__(256) vq_pack_kernel(const float *__restrict__ 
     //      v_mfma_f32_32x32x16_bf16: 16 bytes per lane and (k-step, part); lane l = code (l & 31), k-slot 8 * (l >> 5) + e.
     //      Then 32 floats -||c||^2 / 2 (the accumulator's initial value; -3e38 for padding codes).
     unsigned short *st = (unsigned short *)(screen + (size_t)t * vq_tile_bytes(DT));
-    for (int p = threadIdx.x; p < 4 * DT; p += 256) {   // one (k-step, lane) per iteration: 8 features -> hi and lo fragment
+    for (int p = threadIdx.x; legacy_screen && p < 4 * DT; p += 256) {   // one (k-step, lane) per iteration: 8 features -> hi and lo fragment
         const int l = p & 63;
         const int ks = p >> 6;
         const int code = t * 32 + (l & 31);
@@ -293,8 +299,10 @@ extern "C" int vqhip_pack_codebook(const float *embed, int C, int D, float *pack
     unsigned *scalars = (unsigned *)(base + vq_packed_scalars_offset(C, D));
     hipError_t e = hipMemsetAsync(scalars, 0, VQ_PACKED_SCALARS_BYTES, (hipStream_t)stream);
     if (e != hipSuccess) VQ_FAIL((int)e, "pack_codebook: hipMemsetAsync: %s", hipGetErrorString(e));
-    hipLaunchKernelGGL(vq_pack_kernel, dim3(tiles), dim3(256), 0, (hipStream_t)stream, embed, C, D, DT, packed,
-                       (unsigned short *)(base + packed_bf16_offset(C, D)), base + vq_packed_screen_offset(C, D), scalars);
+    static int legacy = -1;      // the bf16 hi/lo tiles are only read by the VQHIP_SCREEN_BF16X2=1 kernels
+    if (legacy < 0) { const char *ev = getenv("VQHIP_SCREEN_BF16X2"); legacy = (ev && ev[0] == '1') ? 1 : 0; }
+    hipLaunchKernelGGL(vq_pack_kernel, dim3(tiles, 2), dim3(256), 0, (hipStream_t)stream, embed, C, D, DT, packed,
+                       (unsigned short *)(base + packed_bf16_offset(C, D)), base + vq_packed_screen_offset(C, D), scalars, legacy);
     if (int rc = launch_status("vq_pack_kernel")) return rc;
     hipLaunchKernelGGL(vq_pack16_kernel, dim3((unsigned)vq_tiles16(C)), dim3(256), 0, (hipStream_t)stream, embed, C, D, DT, tiles,
                        (const float *)packed, base + vq_packed_f16_offset(C, D), scalars);

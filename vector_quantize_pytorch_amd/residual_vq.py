@@ -254,15 +254,18 @@ class ResidualVQ(nn.Module):
         if update:
             resid = r["resid"]
             stage_in = (lambda q: r["inputs"][q]) if r.get("inputs") is not None else (lambda q: resid[..., q, :])
+            # statistics of ALL stages in one buffer [Q, C D + C] (embed_sum || count per stage): under data parallelism ONE
+            # all-reduce per forward (the reference issues two per stage, vqp.py:603, 607); the per-stage folds stay sequential
+            # (a shared codebook is lerp-ed Q times, rvq.py:213-217 + vqp.py:616-617)
+            buf = torch.zeros(Q, (C * D + C + 3) // 4 * 4, dtype=torch.float32, device=x.device)   # stage slices stay 16-byte aligned
+            for q in range(Q):
+                L.ema_accumulate(stage_in(q), idx, C, row_mask=mask, count=buf[q, C * D: C * D + C], embed_sum=buf[q, : C * D].view(C, D),
+                                 idx_offset=q, idx_stride=Q)
+            if vq0._codebook.use_ddp:
+                dist.all_reduce(buf)
             for q in range(Q):
                 cb = self.layers[q]._codebook
-                buf = torch.zeros(C * D + C, dtype=torch.float32, device=x.device)
-                esum, count = buf[: C * D].view(C, D), buf[C * D:]
-                L.ema_accumulate(stage_in(q), idx, C, row_mask=mask, count=count, embed_sum=esum,
-                                 idx_offset=q, idx_stride=Q)
-                if cb.use_ddp:
-                    dist.all_reduce(buf)
-                cb._fold_stats(0, count, esum, None, False, cb.ema_update)
+                cb._fold_stats(0, buf[q, C * D: C * D + C], buf[q, : C * D].view(C, D), None, False, cb.ema_update)
                 if not self.shared_codebook:                        # vqp.py:641: expire_codes_(flatten, seq_mask = mask)
                     cb.expire_codes_(stage_in(q).reshape(1, -1, D),
                                      seq_mask=None if mask is None else mask.reshape(1, -1).bool())

@@ -37,13 +37,16 @@ class _QuantizeFn(torch.autograd.Function):
     Only x and q are saved; u, qh, w, s are recomputed in the backward kernel."""
 
     @staticmethod
-    def forward(ctx, x, vq, mask, kw):
+    def forward(ctx, x, vq, mask, kw, loss_scale=1.0):
+        """loss_scale: constant folded into the squared-error reduction (1 / numel for the unmasked commit loss), so that the
+        third output IS mean((q - x)^2) without further elementwise kernels"""
         cb = vq._codebook
         r = cb.quantize(x, mask=mask, want_sqerr=vq.training and vq.has_commitment_loss, **kw)
         q, idx = r["q"], r["idx"]
         loss_sum = None
+        ctx.loss_scale = float(loss_scale)
         if vq.training and vq.has_commitment_loss:
-            loss_sum = L.reduce_partials(r["sqerr_partials"], r["nblk"], 1.0)
+            loss_sum = L.reduce_partials(r["sqerr_partials"], r["nblk"], float(loss_scale))
         out = q
         mode = 0
         if vq.training and x.requires_grad and vq.route_gradients_to_input:
@@ -64,9 +67,11 @@ class _QuantizeFn(torch.autograd.Function):
         mask = tensors[2] if ctx.has_mask else None
         use_g = ctx.mode != 0 and g_out is not None
         if not use_g and g_loss is None:
-            return None, None, None, None
+            return None, None, None, None, None
+        if g_loss is not None and ctx.loss_scale != 1.0:
+            g_loss = g_loss * ctx.loss_scale
         gx = L.route_bwd(x, q, g_out.contiguous() if use_g else None, g_loss, mask, ctx.mode if use_g else 0)
-        return gx, None, None, None
+        return gx, None, None, None, None
 
 
 class _RouteFn(torch.autograd.Function):
@@ -526,10 +531,20 @@ class VectorQuantize(nn.Module):
             quantize, embed_ind, commit_quantize, inplace_loss, distances = self._forward_general(
                 xs, rmask, freeze_codebook, kw, dense=dense, topk=topk, temp=sample_codebook_temp)
         else:
-            quantize, embed_ind, sq_sum = _QuantizeFn.apply(xs, self, rmask, kw)
+            fold = (mask is None and self.training and self.has_commitment_loss)     # sq_sum then already is the mean
+            quantize, embed_ind, sq_sum = _QuantizeFn.apply(xs, self, rmask, kw, 1.0 / float(max(xs.numel(), 1)) if fold else 1.0)
 
         # ---- loss (vqp.py:1282-1348) --------------------------------------------------------------
-        loss = torch.zeros((), device=x.device, dtype=torch.float32, requires_grad=self.training)
+        # the reference's loss starts as a leaf that requires grad in training (vqp.py:1282); one cached leaf per device instead of
+        # a fill kernel per forward
+        if self.training:
+            anchor = self.__dict__.get("_loss_anchor")
+            if anchor is None or anchor.device != x.device:
+                anchor = torch.zeros((), device=x.device, dtype=torch.float32, requires_grad=True)
+                self.__dict__["_loss_anchor"] = anchor
+            loss = anchor
+        else:
+            loss = torch.zeros((), device=x.device, dtype=torch.float32)
         commit_loss = self.zero
         def ce_loss(codes):                                                          # vqp.py:1242-1256, heads == 1
             return F.cross_entropy(distances.permute(0, 2, 1), codes, ignore_index=-1)
@@ -574,7 +589,7 @@ class VectorQuantize(nn.Module):
         elif self.training and self.has_commitment_loss:
             d = xs.shape[-1]
             if mask is None:
-                commit_loss = sq_sum / float(xs.numel())
+                commit_loss = sq_sum                                  # mean((q - x)^2): the 1 / numel is folded into the reduction
             elif not self.use_cosine_sim:
                 denom = (rmask.sum() * d).to(torch.float32) * (xs.shape[0] if xs.ndim == 4 else 1)
                 commit_loss = sq_sum / denom
@@ -582,7 +597,10 @@ class VectorQuantize(nn.Module):
                 # reference quirk (vqp.py:1319): the masked loss compares against the ORIGINAL (un-normalised) input
                 diff = (quantize.detach().float() - orig_input.float()) ** 2
                 commit_loss = diff[mask].mean()
-            loss = loss + commit_loss * self.commitment_weight
+            loss = loss + (commit_loss if self.commitment_weight == 1. else commit_loss * self.commitment_weight)
+
+        if self.training and loss is self.__dict__.get("_loss_anchor"):
+            loss = loss.clone()                      # no loss term was added: hand out a fresh tensor, not the cached leaf
 
         # ---- indices / quantized back to the caller's layout (vqp.py:1265-1396) -------------------
         if self.heads > 1:
