@@ -16,7 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PMC_PASSES = [["FETCH_SIZE"], ["WRITE_SIZE"],
               ["SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CU_CYCLES", "SQ_WAVE_CYCLES", "GRBM_GUI_ACTIVE"],
               ["SQ_INSTS_VALU", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_VALU"],
-              ["SQ_INSTS_VALU_MFMA_MOPS_BF16", "SQ_INSTS_VALU_MFMA_MOPS_F32"],
+              ["SQ_INSTS_VALU_MFMA_MOPS_BF16", "SQ_INSTS_VALU_MFMA_MOPS_F16", "SQ_INSTS_VALU_MFMA_MOPS_F32"],
               ["SQ_LDS_BANK_CONFLICT", "SQ_ACTIVE_INST_LDS"]]
 
 
@@ -26,7 +26,7 @@ def run(cmd, **kw):
 
 def main():
     tag = sys.argv[1]
-    bargs = sys.argv[2:] or ["--steps", "5", "--warmup", "2", "--no-cpu-baseline"]
+    bargs = sys.argv[2:] or ["--steps", "5", "--warmup", "2", "--no-cpu-baseline", "--no-adversarial"]
     out = os.path.join(ROOT, "gpurun_out", tag)
     os.makedirs(out, exist_ok=True)
     bench = [sys.executable, os.path.join(ROOT, "bench.py")] + bargs

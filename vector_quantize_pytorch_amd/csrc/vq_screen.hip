@@ -521,7 +521,11 @@ __global__ void __launch_bounds__(VQS_WAVES * 64, 8 / VQS_WAVES) vq_screen16_ker
     static_assert(VQ_F16_TILE_GROUP % SUB == 0, "tile padding must cover the tiles of one barrier");
     static_assert(LAG >= 1 && (NBS - 1) * SPAN + LAG < NK, "staging schedule");
     constexpr int BS2 = (PPS + 1) / 2;              // skewed sweep: two staging batches per tile, one per row-block phase
+#ifdef VQS16_LAG2
+    constexpr int LAG2 = (NK > VQS16_LAG2 + 1) ? VQS16_LAG2 : NK - 1;
+#else
     constexpr int LAG2 = (NK >= 8) ? NK - 2 : NK - 1;
+#endif
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
