@@ -181,6 +181,18 @@ int vqhip_decode_sum(const int64_t *idx, int64_t N, int Q, const float *embed, i
                      int C, int D, void *out, int out_dtype, int64_t ldo, void *stream);
 
 /* ---- ATen-order row sum of squares (vqp.py:59) -- exposed for tests / odd D -------------------- */
+/* Dead-code replacement without a host round trip (reference: Codebook.expire_codes_ / replace,
+ * vector_quantize_pytorch.py:544-574, which reads `torch.any(expired)` and `mask.sum().item()` on the host).  The j-th code
+ * with cluster_size < threshold (ascending code order) takes candidates[j]: embed[c] = cand[j], cluster_size[c] = reset,
+ * embed_avg[c] = cand[j] * reset.  candidates [C, D] fp32: rows the caller drew from torch's generator (randperm(n)[:C],
+ * l2-normalised for the cosine metric).  n_expired_out (nullable, device int) receives the number of replaced codes. */
+int vqhip_expire_scatter(float *cluster_size, float *embed_avg, float *embed, const float *candidates, int C, int D,
+                         float threshold, float reset, int *n_expired_out, void *stream);
+
+/* k-means centroid update of one iteration (reference: kmeans, vector_quantize_pytorch.py:262-276): in place,
+ * means[c] = embed_sum[c] / count[c] where count[c] > 0 (l2-normalised if cosine), unchanged for empty bins. */
+int vqhip_kmeans_update(float *means, const float *embed_sum, const float *count, int C, int D, int cosine, void *stream);
+
 /* Score of ONE given code per row in the reference's arithmetic: cdist(x_n, embed[idx_n]) (vector_quantize_pytorch.py:58-62)
  * for VQHIP_EUCLID, the similarity x_n . embed[idx_n] (:741) for VQHIP_COSINE_PRENORM (rows already unit-norm) -- bit for bit
  * the winner's score vqhip_assign reports through best_out.  Replaces nothing in the reference (it always has the whole

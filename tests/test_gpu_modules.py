@@ -669,3 +669,51 @@ def test_fused_residual_loop_expiry_samples_only_unmasked_rows(dev):
         rvq(x, mask=mask)
     for layer in rvq.layers:
         assert float(layer._codebook.embed.abs().max()) < 100.0, "a code was re-seeded from a masked row"
+
+
+def test_train_step_with_dead_code_replacement_is_graph_capturable(dev):
+    """threshold_ema_dead_code > 0 inside a HIP graph: while capturing, expiry takes the device-side path (candidates drawn every
+    step, vqhip_expire_scatter), so no host round trip is needed; replays keep replacing dead codes and every code stays alive."""
+    from vector_quantize_pytorch_amd import VectorQuantize
+    torch.manual_seed(0)
+    vq = VectorQuantize(dim=64, codebook_size=256, threshold_ema_dead_code=2).to(dev).train()
+    static_x = (torch.randn(4, 1024, 64, device=dev) * 0.05 + 3.0)     # a tight blob far from the initial codes: most codes die
+    with torch.no_grad():
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            vq(static_x)
+        torch.cuda.current_stream().wait_stream(s)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            out = vq(static_x)
+        for step in range(6):
+            static_x.copy_(torch.randn(4, 1024, 64, device=dev) * 0.05 + 3.0)
+            g.replay()
+        torch.cuda.synchronize()
+    cb = vq._codebook
+    # replaced codes sit inside the data blob (|c - 3| small); with expiry working, (nearly) all codes have been re-seeded
+    near = ((cb.embed[0] - 3.0).abs().max(dim=-1).values < 1.0).float().mean().item()
+    assert near > 0.9, f"only {near:.2f} of the codes were re-seeded from the data"
+    assert bool(torch.isfinite(out[2])) and int(out[1].max()) < 256
+
+
+def test_device_side_expiry_matches_reference_semantics(dev):
+    """expire_without_host_sync: same update rule as the host-synchronised path (expired codes <- rows of the batch, cluster_size and
+    embed_avg reset), only the draw differs."""
+    from vector_quantize_pytorch_amd import VectorQuantize
+    torch.manual_seed(0)
+    vq = VectorQuantize(dim=32, codebook_size=128, threshold_ema_dead_code=2).to(dev).train()
+    vq._codebook.expire_without_host_sync = True
+    x = torch.randn(2, 512, 32, device=dev)
+    with torch.no_grad():
+        vq._codebook.cluster_size[0, :40] = 0.5                        # 40 dead codes
+        before = vq._codebook.embed[0].clone()
+        vq._codebook.expire_codes_(x.reshape(1, -1, 32))
+    e = vq._codebook.embed[0]
+    rows = x.reshape(-1, 32)
+    # every replaced code is a row of the batch; live codes untouched; bookkeeping reset
+    assert bool((rows[None, :, :] == e[:40, None, :]).all(-1).any(-1).all())
+    assert torch.equal(e[40:], before[40:])
+    assert torch.equal(vq._codebook.cluster_size[0, :40], torch.full((40,), 2.0, device=dev))
+    assert torch.equal(vq._codebook.embed_avg[0, :40], e[:40] * 2.0)

@@ -532,3 +532,40 @@ def test_score_indices_equals_exact_kernels_winner_score(dev, N, C, D, dtype, co
     assert r1.get("n_exact") is not None and torch.equal(r0["idx"], r1["idx"])
     s = L.score_indices(xd, packed, ed, r1["idx"], cosine=cos)
     assert torch.equal(s, r0["best"])
+
+
+@pytest.mark.parametrize("C,D,frac", [(1024, 256, 0.1), (37, 8, 0.5), (5000, 32, 0.01), (64, 128, 0.0), (300, 100, 1.0)])
+def test_expire_scatter_matches_masked_assignment(dev, C, D, frac):
+    """vqhip_expire_scatter == the reference's `embed[mask] = sampled; cluster_size[mask] = reset; embed_avg[mask] = sampled * reset`
+    (vqp.py:559-562) with sampled[j] going to the j-th expired code in ascending order."""
+    from vector_quantize_pytorch_amd import _lib as L
+    g = torch.Generator().manual_seed(C + D)
+    cs = torch.rand(C, generator=g) * 4 + 2.0
+    dead = torch.rand(C, generator=g) < frac
+    cs[dead] = torch.rand(int(dead.sum()), generator=g) * 1.9          # below the threshold 2
+    e, ea, cand = torch.randn(C, D, generator=g), torch.randn(C, D, generator=g), torch.randn(C, D, generator=g)
+    cs_d, e_d, ea_d = cs.to(dev), e.to(dev), ea.to(dev)
+    n = torch.zeros(1, dtype=torch.int32, device=dev)
+    L.expire_scatter(cs_d, ea_d, e_d, cand.to(dev), 2.0, 2.0, n)
+    k = int(dead.sum())
+    e[dead] = cand[:k]; ea[dead] = cand[:k] * 2.0; cs[dead] = 2.0
+    assert int(n.item()) == k
+    assert torch.equal(e_d.cpu(), e) and torch.equal(ea_d.cpu(), ea) and torch.equal(cs_d.cpu(), cs)
+
+
+@pytest.mark.parametrize("C,D,cos", [(512, 256, False), (100, 40, True), (4096, 128, False)])
+def test_kmeans_update_kernel(dev, C, D, cos):
+    from vector_quantize_pytorch_amd import _lib as L
+    g = torch.Generator().manual_seed(3)
+    means, esum = torch.randn(C, D, generator=g), torch.randn(C, D, generator=g) * 5
+    cnt = torch.randint(0, 6, (C,), generator=g).float()
+    md = means.to(dev)
+    L.kmeans_update(md, esum.to(dev), cnt.to(dev), cosine=cos)
+    nm = esum / cnt.clamp(min=1)[:, None]
+    if cos:
+        nm = torch.nn.functional.normalize(nm, dim=-1, eps=1e-6)
+    want = torch.where((cnt == 0)[:, None], means, nm)
+    if cos:
+        assert (md.cpu() - want).abs().max().item() <= 1e-6
+    else:
+        assert torch.equal(md.cpu(), want)

@@ -74,8 +74,12 @@ def lib():
     L.vqhip_row_sumsq.argtypes = [vp, i32, i64, i32, i64, vp, vp]
     L.vqhip_score_indices.argtypes = [vp, i32, i64, i32, i64, vp, vp, i32, i32, vp, vp, vp]
     L.vqhip_score_indices.restype = i32
+    L.vqhip_expire_scatter.argtypes = [vp, vp, vp, vp, i32, i32, f32, f32, vp, vp]
+    L.vqhip_expire_scatter.restype = i32
+    L.vqhip_kmeans_update.argtypes = [vp, vp, vp, i32, i32, i32, vp]
+    L.vqhip_kmeans_update.restype = i32
     for name in ("vqhip_pack_codebook", "vqhip_assign", "vqhip_reduce_partials", "vqhip_ema_accumulate",
-                 "vqhip_ema_finalize", "vqhip_decode_sum", "vqhip_row_sumsq", "vqhip_score_indices", "vqhip_route_fwd", "vqhip_route_bwd"):
+                 "vqhip_ema_finalize", "vqhip_decode_sum", "vqhip_row_sumsq", "vqhip_score_indices", "vqhip_expire_scatter", "vqhip_kmeans_update", "vqhip_route_fwd", "vqhip_route_bwd"):
         getattr(L, name).restype = i32
     _lib = L
     return L
@@ -84,7 +88,7 @@ def lib():
 EXPORTS = ("vqhip_version", "vqhip_last_error", "vqhip_packed_bytes", "vqhip_pack_codebook",
            "vqhip_assign_blocks", "vqhip_assign", "vqhip_screen_supported", "vqhip_screen_workspace_bytes",
            "vqhip_screen_blocks", "vqhip_screen_partials", "vqhip_assign_screened", "vqhip_l2norm_rows", "vqhip_scores", "vqhip_rvq_forward", "vqhip_reduce_partials", "vqhip_ema_workspace_bytes", "vqhip_ema_accumulate",
-           "vqhip_ema_finalize", "vqhip_decode_sum", "vqhip_row_sumsq", "vqhip_score_indices", "vqhip_route_fwd", "vqhip_route_bwd")
+           "vqhip_ema_finalize", "vqhip_decode_sum", "vqhip_row_sumsq", "vqhip_score_indices", "vqhip_expire_scatter", "vqhip_kmeans_update", "vqhip_route_fwd", "vqhip_route_bwd")
 
 
 def _check(rc, what):
@@ -468,6 +472,29 @@ def score_indices(x: torch.Tensor, packed: torch.Tensor, embed2d: torch.Tensor, 
         _check(lib().vqhip_score_indices(_ptr(xk), _dtype_code(xk), N, D, ldx, _ptr(packed), _ptr(embed2d), embed2d.shape[0],
                                          COSINE_PRENORM if cosine else EUCLID, _ptr(idx), _ptr(out), _stream()), "vqhip_score_indices")
     return out
+
+
+@_on_device
+def expire_scatter(cluster_size: torch.Tensor, embed_avg: torch.Tensor, embed: torch.Tensor, candidates: torch.Tensor, threshold: float,
+                   reset: float, n_expired: torch.Tensor | None = None):
+    """In place on one codebook's (cluster_size [C], embed_avg [C, D], embed [C, D]): the j-th expired code takes candidates[j]."""
+    _need_gpu(cluster_size, embed_avg, embed, candidates)
+    C, D = embed.shape
+    assert candidates.shape == (C, D) and candidates.dtype == torch.float32 and candidates.is_contiguous()
+    for t in (cluster_size, embed_avg, embed):
+        assert t.is_contiguous() and t.dtype == torch.float32
+    _check(lib().vqhip_expire_scatter(_ptr(cluster_size), _ptr(embed_avg), _ptr(embed), _ptr(candidates), C, D, float(threshold),
+                                      float(reset), _ptr(n_expired), _stream()), "vqhip_expire_scatter")
+
+
+@_on_device
+def kmeans_update(means: torch.Tensor, embed_sum: torch.Tensor, count: torch.Tensor, *, cosine=False):
+    """In place: means[c] = embed_sum[c] / count[c] for non-empty bins (l2-normalised if cosine)."""
+    _need_gpu(means, embed_sum, count)
+    C, D = means.shape
+    for t in (means, embed_sum, count):
+        assert t.is_contiguous() and t.dtype == torch.float32
+    _check(lib().vqhip_kmeans_update(_ptr(means), _ptr(embed_sum), _ptr(count), C, D, int(cosine), _stream()), "vqhip_kmeans_update")
 
 
 @_on_device

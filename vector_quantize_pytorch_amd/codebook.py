@@ -249,6 +249,11 @@ class Codebook(nn.Module):
                 r = L.assign(data[h], L.pack_codebook(m), m, cosine=self.use_cosine_sim, want_q=False,
                              skip_l2norm=True)
                 cnt, esum = L.ema_accumulate(data[h], r["idx"], C)
+                if not self.sync_kmeans_stats and not self.use_cosine_sim:
+                    L.kmeans_update(m, esum, cnt)             # m <- esum / cnt where cnt > 0 (vqhip_kmeans_update), in place
+                    new_means.append(m)
+                    bins.append(cnt)
+                    continue
                 if self.sync_kmeans_stats:
                     dist.all_reduce(cnt)
                     # the reference divides by the all-reduced bins *before* all-reducing the means
@@ -294,17 +299,40 @@ class Codebook(nn.Module):
             self.cluster_size[h][m] = self.reset_cluster_size
             self.embed_avg[h][m] = picked * self.reset_cluster_size
 
+    expire_without_host_sync = False     # class default; set True (or capture the step in a HIP graph) for the device-side path
+
     @torch.no_grad()
     def expire_codes_(self, batch_samples: Tensor, seq_mask: Optional[Tensor] = None):
-        """vqp.py:564-574.  The `any()` below is the only host sync and only exists when
-        threshold_ema_dead_code > 0 (0 is VectorQuantize's default, vqp.py:818)."""
+        """vqp.py:564-574.  Default path: the reference's control flow -- `any(expired)` and the number of expired codes are read
+        on the host (two syncs, only when threshold_ema_dead_code > 0; 0 is VectorQuantize's default, vqp.py:818), which keeps
+        torch's generator in lock-step with the reference (no draw when nothing expired).  Device-side path
+        (`expire_without_host_sync`, or automatically while the stream is being captured into a graph): candidates are drawn
+        every step and vqhip_expire_scatter hands the j-th expired code the j-th candidate -- same distribution, no host round
+        trip, but the generator advances on steps without expired codes too."""
         if not self.has_dead_code_replacement or not self.training:
+            return
+        H = batch_samples.shape[0]
+        samples = batch_samples.reshape(H, -1, batch_samples.shape[-1])
+        nosync = (self.expire_without_host_sync or torch.cuda.is_current_stream_capturing()) and seq_mask is None \
+            and self.replace_sample_fn is batched_sample_rows
+        if nosync:
+            C = self.codebook_size
+            for h in range(H):
+                rows = samples[h]
+                n = rows.shape[0]
+                pick = torch.randperm(n, device=rows.device)[:C] if n >= C else torch.randint(0, n, (C,), device=rows.device)
+                cand = rows.index_select(0, pick).float()
+                if cand.shape[0] < C:                       # (n >= C but fewer than C rows: cannot happen; keeps shapes static)
+                    cand = torch.cat([cand, cand[: C - cand.shape[0]]], 0)
+                if self.use_cosine_sim:
+                    cand = _l2norm(cand)
+                cs, ea, e = self._views(h)
+                L.expire_scatter(cs, ea, e, cand.contiguous(), self.threshold_ema_dead_code, self.reset_cluster_size)
             return
         expired = self.cluster_size < self.threshold_ema_dead_code
         if not bool(expired.any()):
             return
-        H = batch_samples.shape[0]
-        self.replace(batch_samples.reshape(H, -1, batch_samples.shape[-1]).float(), expired, seq_mask)
+        self.replace(samples.float(), expired, seq_mask)
 
     def _fold_stats(self, h, count, esum, ema_update_weight, accum_ema_update, ema_update):
         cs, ea, e = self._views(h)

@@ -2303,6 +2303,94 @@ extern "C" int vqhip_ema_finalize(float *cluster_size, float *embed_avg, float *
 }
 
 // ------------------------------------------------------------------------------------------------
+// dead-code replacement on the device (vqp.py:544-574) and the k-means centroid update (vqp.py:262-276)
+// ------------------------------------------------------------------------------------------------
+// expire: the j-th expired code (cluster_size < threshold, ascending code order -- the order in which the reference's boolean-mask
+// assignment `embed[mask] = sampled` consumes `sampled`) takes candidate row j: embed[c] = cand[j], cluster_size[c] = reset,
+// embed_avg[c] = cand[j] * reset.  The candidates are rows drawn by the caller from torch's generator (randperm(n)[:C] like
+// vqp.py:156-163, l2-normalised for the cosine metric); nothing returns to the host, so the whole step can be captured in a HIP
+// graph.  One workgroup of 1024 threads: the rank of a code among the expired ones is a block-wide prefix count.
+__global__ void __launch_bounds__(1024) vq_expire_kernel(float *__restrict__ cluster_size, float *__restrict__ embed_avg,
+                                                         float *__restrict__ embed, const float *__restrict__ cand, int C, int D,
+                                                         float threshold, float reset, int *__restrict__ n_expired_out)
+{
+    __shared__ int wsum[16];
+    __shared__ int base_sh, n_chunk;
+    __shared__ int ex_code[1024], ex_rank[1024];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) base_sh = 0;
+    __syncthreads();
+    for (int c0 = 0; c0 < C; c0 += 1024) {
+        const int c = c0 + tid;
+        const bool ex = c < C && cluster_size[c] < threshold;
+        const unsigned long long bal = __ballot(ex);
+        const int within = (int)__popcll(bal & ((1ull << lane) - 1ull));
+        if (lane == 0) wsum[wave] = (int)__popcll(bal);
+        __syncthreads();
+        int before = base_sh;
+        for (int w = 0; w < wave; ++w) before += wsum[w];
+        const int rank = before + within;
+        __syncthreads();
+        if (tid == 0) { int t = 0; for (int w = 0; w < 16; ++w) t += wsum[w]; base_sh += t; }
+        if (ex) cluster_size[c] = reset;
+        // the row copies: every expired code of this chunk, D floats each, spread over the block below
+        if (tid == 0) n_chunk = 0;
+        __syncthreads();
+        if (ex) { const int s = atomicAdd(&n_chunk, 1); ex_code[s] = c; ex_rank[s] = rank; }
+        __syncthreads();
+        const int nc = n_chunk;
+        for (int p = tid; p < nc * D; p += 1024) {
+            const int s = p / D, k = p - s * D;
+            const float v = cand[(size_t)ex_rank[s] * D + k];
+            embed[(size_t)ex_code[s] * D + k] = v;
+            embed_avg[(size_t)ex_code[s] * D + k] = v * reset;
+        }
+        __syncthreads();
+    }
+    if (tid == 0 && n_expired_out) *n_expired_out = base_sh;
+}
+
+extern "C" int vqhip_expire_scatter(float *cluster_size, float *embed_avg, float *embed, const float *candidates, int C, int D,
+                                    float threshold, float reset, int *n_expired_out, void *stream)
+{
+    if (!cluster_size || !embed_avg || !embed || !candidates || C <= 0 || D <= 0) VQ_FAIL(VQHIP_EINVAL, "expire_scatter: bad argument");
+    hipLaunchKernelGGL(vq_expire_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, cluster_size, embed_avg, embed, candidates, C, D,
+                       threshold, reset, n_expired_out);
+    return launch_status("vq_expire_kernel");
+}
+
+// k-means centroid update of one iteration (vqp.py:262-276): means[c] = embed_sum[c] / count[c] where count[c] > 0 (l2-normalised for
+// the cosine metric, eps 1e-6 as vqp.py:37-38), unchanged where the bin is empty.  In place on `means`.
+__global__ void __launch_bounds__(256) vq_kmeans_update_kernel(float *__restrict__ means, const float *__restrict__ embed_sum,
+                                                               const float *__restrict__ count, int C, int D, int cosine)
+{
+    const int lane = threadIdx.x & 63;
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (c >= C) return;
+    const float n = count[c];
+    if (n == 0.f) return;
+    float ss = 0.f;
+    for (int k = lane; k < D; k += 64) { const float v = embed_sum[(size_t)c * D + k] / n; ss += v * v; }
+    float inv = 1.f;
+    if (cosine) {
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) ss += __shfl_xor(ss, o, 64);
+        inv = 1.f / fmaxf(sqrtf(ss), 1e-6f);
+    }
+    for (int k = lane; k < D; k += 64) {
+        const float v = embed_sum[(size_t)c * D + k] / n;
+        means[(size_t)c * D + k] = cosine ? v * inv : v;
+    }
+}
+
+extern "C" int vqhip_kmeans_update(float *means, const float *embed_sum, const float *count, int C, int D, int cosine, void *stream)
+{
+    if (!means || !embed_sum || !count || C <= 0 || D <= 0) VQ_FAIL(VQHIP_EINVAL, "kmeans_update: bad argument");
+    hipLaunchKernelGGL(vq_kmeans_update_kernel, dim3((unsigned)((C + 3) / 4)), dim3(256), 0, (hipStream_t)stream, means, embed_sum, count, C, D, cosine);
+    return launch_status("vq_kmeans_update_kernel");
+}
+
+// ------------------------------------------------------------------------------------------------
 // decode: out[n,:] = sum_q embed_q[idx[n,q],:]   (sequential in q, like the reference's running sum)
 // ------------------------------------------------------------------------------------------------
 // one wave per output row.  The Q indices of a row are fetched first, then the code rows of 8 stages at a time are all
