@@ -161,7 +161,27 @@ def other_workload(args, world, rank, dev):
             dist.barrier()
         torch.cuda.synchronize()
 
+    # rows the screen could not certify, per search (stage): device-side counters collected without synchronising
+    counts = []
+    orig_assign = _lib.assign
+
+    def counting_assign(*a, **k):
+        r = orig_assign(*a, **k)
+        if r.get("n_exact") is not None:
+            counts.append((r["n_exact"], r["n_pair"], r["idx"].numel()))
+        return r
+
+    _lib.assign = counting_assign
+    import vector_quantize_pytorch_amd.codebook as cbmod
+    cbmod.L.assign = counting_assign
     dt, first, _ = _time_module(mod, batches, args.steps, args.warmup, sync)
+    _lib.assign = orig_assign
+    per_stage = None
+    if counts:
+        n_last = stages if len(counts) >= stages else len(counts)
+        last = counts[-n_last:]                          # the searches of the last forward, in call order (group-major, then stage)
+        per_stage = {"open_frac": [round(float(c[0].item()) / c[2], 5) for c in last],
+                     "pair_frac": [round(float(c[1].item()) / c[2], 5) for c in last]}
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -178,7 +198,7 @@ def other_workload(args, world, rank, dev):
                       "scaling": "strong" if strong else "weak", "vs_baseline": None,
                       "dtype": "bf16x3+f32" if screened else "f32", "data": "synthetic",
                       "config": {"workload": name, "parallelism": par, "vector_stages_per_s": n * stages * args.steps / dt,
-                                 "first_forward_ms": first * 1e3},
+                                 "first_forward_ms": first * 1e3, "uncertified_rows_per_search": per_stage},
                       "roofline": {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
                                    "traffic": None, "achieved_vs_fp32_mfma_peak": ach / PEAK_FP32_MFMA_TFLOPS,
                                    "note": "whole step (all kernels) PER GPU, not one kernel; algorithmic flops (2*C*D per vector and stage); "

@@ -454,6 +454,18 @@ def test_cfg5_full_size_grouped_rvq_with_kmeans(dev):
     assert torch.allclose(q, out, atol=1e-5)
     # k-means lowered the quantisation error well below that of a random codebook
     assert ((q - x) ** 2).mean().item() < 0.75
+    # oracle, stage by stage, on one batch row of every group (8192 vectors x 8 stages x 4 groups): indices bit-exact against the
+    # chain oracle on the residual the reference's arithmetic produces (fp32 x - q per stage, rvq.py:524)
+    for g, rvq in enumerate(m.rvqs):
+        r = x[7, :, g * 128:(g + 1) * 128].cpu().contiguous()
+        for s_ in range(8):
+            e = rvq.layers[s_]._codebook.embed[0].cpu()
+            io, _ = O.c_assign(r, e)
+            assert torch.equal(idx[g, 7, :, s_].cpu(), io), f"group {g} stage {s_}"
+            r = r - e[io]
+    # and the quantised output is the sum of the chosen codes in stage order
+    want = torch.cat([sum(m.rvqs[g].layers[s_]._codebook.embed[0][idx[g, ..., s_]] for s_ in range(8)) for g in range(4)], -1)
+    assert torch.allclose(q, want, atol=1e-5)
 
 
 def test_topk_and_manual_ema_update(dev):                                     # reference tests/test_beam.py:7-47
@@ -707,6 +719,7 @@ def test_device_side_expiry_matches_reference_semantics(dev):
     vq._codebook.expire_without_host_sync = True
     x = torch.randn(2, 512, 32, device=dev)
     with torch.no_grad():
+        vq._codebook.cluster_size.fill_(3.0)                           # (a fresh module starts at 1.0: everything would count as dead)
         vq._codebook.cluster_size[0, :40] = 0.5                        # 40 dead codes
         before = vq._codebook.embed[0].clone()
         vq._codebook.expire_codes_(x.reshape(1, -1, 32))
