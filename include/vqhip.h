@@ -181,6 +181,13 @@ int vqhip_decode_sum(const int64_t *idx, int64_t N, int Q, const float *embed, i
                      int C, int D, void *out, int out_dtype, int64_t ldo, void *stream);
 
 /* ---- ATen-order row sum of squares (vqp.py:59) -- exposed for tests / odd D -------------------- */
+/* The K best codes per row, K <= 8 (reference: `logits.topk(topk)` on the N x C `dist` tensor, vector_quantize_pytorch.py:137-138,
+ * used by forward(topk=) and ResidualVQ's beam search): scores in the reference's arithmetic (-cdist with correctly rounded sqrt, or
+ * cosine similarity), order = (score descending, code ascending); `dist` is never materialised.  idx_out [N, K] int64,
+ * val_out nullable [N, K] fp32.  D in {32, 64, 128, 256, 512}; metric VQHIP_EUCLID / VQHIP_COSINE / VQHIP_COSINE_PRENORM. */
+int vqhip_topk(const void *x, int x_dtype, int64_t N, int D, int64_t ldx, const float *packed, int C, int metric, int K,
+               int64_t *idx_out, float *val_out, void *stream);
+
 /* Dead-code replacement without a host round trip (reference: Codebook.expire_codes_ / replace,
  * vector_quantize_pytorch.py:544-574, which reads `torch.any(expired)` and `mask.sum().item()` on the host).  The j-th code
  * with cluster_size < threshold (ascending code order) takes candidates[j]: embed[c] = cand[j], cluster_size[c] = reset,

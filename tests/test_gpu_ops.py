@@ -569,3 +569,25 @@ def test_kmeans_update_kernel(dev, C, D, cos):
         assert (md.cpu() - want).abs().max().item() <= 1e-6
     else:
         assert torch.equal(md.cpu(), want)
+
+
+@pytest.mark.parametrize("N,C,D,K,dtype,cos", [(1000, 64, 32, 3, torch.float32, False), (777, 1000, 256, 8, torch.float32, False),
+                                               (2048, 512, 128, 4, torch.bfloat16, False), (500, 300, 64, 2, torch.float32, True),
+                                               (300, 4096, 512, 5, torch.float32, True), (100, 5, 32, 5, torch.float32, False)])
+def test_fused_topk_equals_topk_of_the_dense_scores(dev, N, C, D, K, dtype, cos):
+    """vqhip_topk (no N x C tensor) == topk of vqhip_scores (the reference's `dist`, bit-exact vs the oracle), values and order;
+    ties are ordered by ascending code (checked with duplicated codes)."""
+    from vector_quantize_pytorch_amd import _lib as L
+    x, e = _mk(N, C, D, dtype, unit=True, seed=31)
+    if C >= 8:
+        e[C // 2] = e[1]                                    # an exact duplicate: equal scores, the lower code must come first
+    xd, ed = x.to(dev), e.to(dev)
+    if cos:
+        ed = torch.nn.functional.normalize(ed, dim=-1).contiguous()
+    packed = L.pack_codebook(ed)
+    idx, val = L.topk(xd, packed, C, K, cosine=cos, want_values=True)
+    dist, _, _ = L.scores(xd, packed, ed, cosine=cos)
+    # reference order: value descending, then code ascending (stable sort of the dense row)
+    order = torch.sort(dist, dim=-1, descending=True, stable=True)
+    assert torch.equal(val, order.values[:, :K])
+    assert torch.equal(idx, order.indices[:, :K])

@@ -74,12 +74,14 @@ def lib():
     L.vqhip_row_sumsq.argtypes = [vp, i32, i64, i32, i64, vp, vp]
     L.vqhip_score_indices.argtypes = [vp, i32, i64, i32, i64, vp, vp, i32, i32, vp, vp, vp]
     L.vqhip_score_indices.restype = i32
+    L.vqhip_topk.argtypes = [vp, i32, i64, i32, i64, vp, i32, i32, i32, vp, vp, vp]
+    L.vqhip_topk.restype = i32
     L.vqhip_expire_scatter.argtypes = [vp, vp, vp, vp, i32, i32, f32, f32, vp, vp]
     L.vqhip_expire_scatter.restype = i32
     L.vqhip_kmeans_update.argtypes = [vp, vp, vp, i32, i32, i32, vp]
     L.vqhip_kmeans_update.restype = i32
     for name in ("vqhip_pack_codebook", "vqhip_assign", "vqhip_reduce_partials", "vqhip_ema_accumulate",
-                 "vqhip_ema_finalize", "vqhip_decode_sum", "vqhip_row_sumsq", "vqhip_score_indices", "vqhip_expire_scatter", "vqhip_kmeans_update", "vqhip_route_fwd", "vqhip_route_bwd"):
+                 "vqhip_ema_finalize", "vqhip_decode_sum", "vqhip_row_sumsq", "vqhip_score_indices", "vqhip_topk", "vqhip_expire_scatter", "vqhip_kmeans_update", "vqhip_route_fwd", "vqhip_route_bwd"):
         getattr(L, name).restype = i32
     _lib = L
     return L
@@ -88,7 +90,7 @@ def lib():
 EXPORTS = ("vqhip_version", "vqhip_last_error", "vqhip_packed_bytes", "vqhip_pack_codebook",
            "vqhip_assign_blocks", "vqhip_assign", "vqhip_screen_supported", "vqhip_screen_workspace_bytes",
            "vqhip_screen_blocks", "vqhip_screen_partials", "vqhip_assign_screened", "vqhip_l2norm_rows", "vqhip_scores", "vqhip_rvq_forward", "vqhip_reduce_partials", "vqhip_ema_workspace_bytes", "vqhip_ema_accumulate",
-           "vqhip_ema_finalize", "vqhip_decode_sum", "vqhip_row_sumsq", "vqhip_score_indices", "vqhip_expire_scatter", "vqhip_kmeans_update", "vqhip_route_fwd", "vqhip_route_bwd")
+           "vqhip_ema_finalize", "vqhip_decode_sum", "vqhip_row_sumsq", "vqhip_score_indices", "vqhip_topk", "vqhip_expire_scatter", "vqhip_kmeans_update", "vqhip_route_fwd", "vqhip_route_bwd")
 
 
 def _check(rc, what):
@@ -472,6 +474,28 @@ def score_indices(x: torch.Tensor, packed: torch.Tensor, embed2d: torch.Tensor, 
         _check(lib().vqhip_score_indices(_ptr(xk), _dtype_code(xk), N, D, ldx, _ptr(packed), _ptr(embed2d), embed2d.shape[0],
                                          COSINE_PRENORM if cosine else EUCLID, _ptr(idx), _ptr(out), _stream()), "vqhip_score_indices")
     return out
+
+
+TOPK_MAX = 8
+
+
+def topk_supported(x: torch.Tensor, k: int, C: int) -> bool:
+    xk, N, D, ldx = as_rows(x)
+    return (1 <= k <= min(TOPK_MAX, C) and D in (32, 64, 128, 256, 512) and xk.dtype in (torch.float32, torch.bfloat16)
+            and xk.data_ptr() % 16 == 0 and (ldx * xk.element_size()) % 16 == 0)
+
+
+@_on_device
+def topk(x: torch.Tensor, packed: torch.Tensor, C: int, k: int, *, cosine=False, skip_l2norm=False, want_values=False):
+    """x [..., D] -> indices [..., k] (and values) of the k best codes in the reference's arithmetic, without the N x C tensor."""
+    _need_gpu(x, packed)
+    xk, N, D, ldx = as_rows(x)
+    idx = torch.empty(*x.shape[:-1], k, dtype=torch.int64, device=x.device)
+    val = torch.empty(*x.shape[:-1], k, dtype=torch.float32, device=x.device) if want_values else None
+    if N > 0:
+        metric = (COSINE_PRENORM if skip_l2norm else COSINE) if cosine else EUCLID
+        _check(lib().vqhip_topk(_ptr(xk), _dtype_code(xk), N, D, ldx, _ptr(packed), C, metric, k, _ptr(idx), _ptr(val), _stream()), "vqhip_topk")
+    return (idx, val) if want_values else idx
 
 
 @_on_device

@@ -795,6 +795,198 @@ static int dispatch_assign(const AssignArgs &a, int x_dtype, int metric, hipStre
     return metric ? launch_assign<DT, false, 1>(a, st) : launch_assign<DT, false, 0>(a, st);
 }
 
+// ------------------------------------------------------------------------------------------------
+// exact top-K codes per row (vqp.py:137-138: `logits.topk(topk)` of dist = -cdist or the cosine similarity) without the N x C
+// `dist` tensor: the sweep of vq_assign_kernel with a per-lane sorted list of the K best (score, code) instead of the running
+// argmin.  Scores are the reference's values (correctly rounded sqrt per element), order = (score descending, code ascending).
+// Cold path (forward(topk=), ResidualVQ beam search): K <= 8, D in {32, 64, 128, 256, 512}, vector-aligned rows.
+// ------------------------------------------------------------------------------------------------
+#define VQ_TOPK_MAX 8
+struct TopkArgs {
+    const void *x;
+    int64_t N;
+    int64_t ldx;
+    const float *packed;
+    int C;
+    int n_tiles;
+    int K;
+    int skip_norm;
+    int64_t *idx_out;   // [N, K]
+    float *val_out;     // nullable [N, K]
+};
+
+__device__ __forceinline__ bool topk_better(float v, int c, float lv, int lc) { return v > lv || (v == lv && c < lc); }
+
+// bubble one item down a list sorted by (score descending, code ascending): K compare-swaps, branch-free; entries past K stay unused
+__device__ __noinline__ void topk_insert(float (&lv)[VQ_TOPK_MAX], int (&lc)[VQ_TOPK_MAX], int K, float v, int c)
+{
+#pragma unroll
+    for (int k = 0; k < VQ_TOPK_MAX; ++k) {
+        const bool b = (k < K) && topk_better(v, c, lv[k], lc[k]);
+        const float tv = lv[k]; const int tc = lc[k];
+        lv[k] = b ? v : tv; lc[k] = b ? c : tc;
+        v = b ? tv : v; c = b ? tc : c;
+    }
+}
+
+template <int DT, bool XBF16, int METRIC>
+__global__ void __launch_bounds__(256, (DT <= 256 ? 2 : 1)) vq_topk_kernel(const TopkArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int TILE_F = 32 * DT + 256;
+    constexpr int TILE_B = TILE_F * 4;
+    constexpr int NCHUNK = TILE_B / 1024;
+    constexpr int NG = DT / 8;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 31;
+    const int hi = lane >> 5;
+    const int64_t row = (int64_t)blockIdx.x * VQHIP_ASSIGN_ROWS_PER_BLOCK + wave * 32 + j;
+    const bool row_ok = row < a.N;
+    const int64_t rowc = row_ok ? row : (a.N - 1);
+    const int my_pieces = (NCHUNK - wave + 3) / 4;
+    const int piece_off = wave * 1024 + lane * 16;
+    for (int k = 0; k < my_pieces; ++k)
+        *(f32x4 *)(smem + piece_off + k * 4096) = *(const f32x4 *)((const char *)a.packed + piece_off + (size_t)k * 4096);
+
+    float xr[DT / 2];   // load layout, as in vq_assign_kernel
+    if (XBF16) {
+        const uint2 *p = (const uint2 *)((const unsigned short *)a.x + rowc * a.ldx + 4 * hi);
+#pragma unroll
+        for (int m = 0; m < NG; ++m) {
+            const uint2 w = p[m * 2];
+            xr[4 * m + 0] = __uint_as_float(w.x << 16); xr[4 * m + 1] = __uint_as_float(w.x & 0xffff0000u);
+            xr[4 * m + 2] = __uint_as_float(w.y << 16); xr[4 * m + 3] = __uint_as_float(w.y & 0xffff0000u);
+        }
+    } else {
+        const f32x4 *p = (const f32x4 *)((const float *)a.x + rowc * a.ldx + 4 * hi);
+#pragma unroll
+        for (int m = 0; m < NG; ++m) {
+            const f32x4 w = p[m * 2];
+            xr[4 * m + 0] = w.x; xr[4 * m + 1] = w.y; xr[4 * m + 2] = w.z; xr[4 * m + 3] = w.w;
+        }
+    }
+    const float x2 = x2_aten_order<DT>(xr, j);
+    if (METRIC == 1 && !a.skip_norm) {
+        float nrm = sqrtf(x2);
+        if (XBF16) nrm = round_to_bf16(nrm);
+        nrm = fmaxf(nrm, XBF16 ? round_to_bf16(1e-6f) : 1e-6f);
+#pragma unroll
+        for (int q = 0; q < DT / 2; ++q) { const float v = xr[q] / nrm; xr[q] = XBF16 ? round_to_bf16(v) : v; }
+    }
+#pragma unroll
+    for (int m = 0; m < NG; ++m) { swap32(xr[4 * m + 0], xr[4 * m + 1]); swap32(xr[4 * m + 2], xr[4 * m + 3]); }
+
+    float lv[VQ_TOPK_MAX];
+    int lc[VQ_TOPK_MAX];
+#pragma unroll
+    for (int k = 0; k < VQ_TOPK_MAX; ++k) { lv[k] = -INFINITY; lc[k] = 0x7fffffff; }
+    const int K = a.K;
+
+    const int nt = a.n_tiles;
+    for (int ct = 0; ct < nt; ++ct) {
+        const int buf = ct & 1;
+        __syncthreads();
+        const char *tile = smem + buf * TILE_B;
+        const f32x4 *ap = (const f32x4 *)tile + (hi * 32 + j);
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        const bool more = ct + 1 < nt;
+        mfma_sweep_tile<DT>(ap, xr, acc, (const char *)a.packed + (size_t)(more ? ct + 1 : ct) * TILE_B + piece_off,
+                            smem + (buf ^ 1) * TILE_B + piece_off, more ? my_pieces : 0);
+        // the 16 scores of this lane go through LDS-free scratch-free insertion one by one; the (cold-path) loop over the
+        // elements is a real loop -- the scores are staged in this lane's slice of a small LDS array so that it can be
+        // indexed at run time (a register array cannot)
+        const float *y2s = (const float *)tile + 32 * DT;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int code = ct * 32 + 8 * (e >> 2) + 4 * hi + (e & 3);
+            float t = acc[e];
+            if (METRIC == 0) t = -sqrtf(fmaxf(__builtin_fmaf(-2.0f, t, x2 + y2s[8 * (e >> 2) + 4 * hi + (e & 3)]), 1e-8f));
+            acc[e] = (code < a.C) ? t : -INFINITY;
+        }
+        float vmax = acc[0];
+#pragma unroll
+        for (int e = 1; e < 16; ++e) vmax = fmaxf(vmax, acc[e]);
+        // skip the insertions when no lane can improve its list (a tie would need a lower code: tiles ascend, so never)
+        float worst = lv[0];
+#pragma unroll
+        for (int k = 1; k < VQ_TOPK_MAX; ++k) worst = (k == K - 1) ? lv[k] : worst;
+        if (__any(vmax > worst)) {
+            float *sv = (float *)(smem + 2 * TILE_B) + tid * 16;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) sv[e] = acc[e];
+#pragma unroll 1
+            for (int e = 0; e < 16; ++e)
+                topk_insert(lv, lc, K, sv[e], ct * 32 + 8 * (e >> 2) + 4 * hi + (e & 3));
+        }
+    }
+    // merge the two half-waves (same row, disjoint code subsets): the partner's list goes into this lane's
+    float pv[VQ_TOPK_MAX];
+    int pc[VQ_TOPK_MAX];
+#pragma unroll
+    for (int k = 0; k < VQ_TOPK_MAX; ++k) { pv[k] = __shfl_xor(lv[k], 32, 64); pc[k] = __shfl_xor(lc[k], 32, 64); }
+#pragma unroll 1
+    for (int k = 0; k < VQ_TOPK_MAX; ++k) {
+        float v = pv[0]; int c = pc[0];
+#pragma unroll
+        for (int q = 1; q < VQ_TOPK_MAX; ++q) { v = (q == k) ? pv[q] : v; c = (q == k) ? pc[q] : c; }
+        topk_insert(lv, lc, K, v, c);
+    }
+    if (row_ok && hi == 0) {
+#pragma unroll
+        for (int k = 0; k < VQ_TOPK_MAX; ++k)
+            if (k < K) {
+                a.idx_out[row * K + k] = (int64_t)lc[k];
+                if (a.val_out) a.val_out[row * K + k] = lv[k];
+            }
+    }
+}
+
+template <int DT>
+static int dispatch_topk(const TopkArgs &a, int x_dtype, int metric, hipStream_t st)
+{
+    constexpr int SMEM = 2 * (32 * DT + 256) * 4 + 256 * 16 * 4;   // two tiles + the per-lane score staging of the insertion loop
+    const unsigned blocks = (unsigned)vqhip_assign_blocks(a.N);
+#define VQ_TK(B, M)                                                                                                        \
+    do {                                                                                                                   \
+        static VqAttrOnce once;                                                                                            \
+        if (int rc = vq_set_max_smem(once, (const void *)vq_topk_kernel<DT, B, M>, SMEM, "vq_topk_kernel")) return rc;     \
+        hipLaunchKernelGGL((vq_topk_kernel<DT, B, M>), dim3(blocks), dim3(256), SMEM, st, a);                              \
+    } while (0)
+    if (metric == VQHIP_EUCLID) { if (x_dtype == VQHIP_BF16) VQ_TK(true, 0); else VQ_TK(false, 0); }
+    else                        { if (x_dtype == VQHIP_BF16) VQ_TK(true, 1); else VQ_TK(false, 1); }
+#undef VQ_TK
+    return launch_status("vq_topk_kernel");
+}
+
+extern "C" int vqhip_topk(const void *x, int x_dtype, int64_t N, int D, int64_t ldx, const float *packed, int C, int metric, int K,
+                          int64_t *idx_out, float *val_out, void *stream)
+{
+    if (!x || !packed || !idx_out || N < 0 || C <= 0) VQ_FAIL(VQHIP_EINVAL, "topk: bad argument");
+    if (K < 1 || K > VQ_TOPK_MAX || K > C) VQ_FAIL(VQHIP_EINVAL, "topk: K=%d outside 1..min(%d, C)", K, VQ_TOPK_MAX);
+    if (x_dtype != VQHIP_F32 && x_dtype != VQHIP_BF16) VQ_FAIL(VQHIP_EINVAL, "topk: unknown dtype %d", x_dtype);
+    if (metric != VQHIP_EUCLID && metric != VQHIP_COSINE && metric != VQHIP_COSINE_PRENORM) VQ_FAIL(VQHIP_EINVAL, "topk: unknown metric %d", metric);
+    if (D != 32 && D != 64 && D != 128 && D != 256 && D != 512) VQ_FAIL(VQHIP_EDIM, "topk: D=%d unsupported (32, 64, 128, 256, 512)", D);
+    const int es = (x_dtype == VQHIP_BF16) ? 2 : 4;
+    if ((((uintptr_t)x) % (4 * es)) || ((ldx * es) % (4 * es)) || ldx < D) VQ_FAIL(VQHIP_EALIGN, "topk: rows must be aligned to 4 elements");
+    if (N == 0) return 0;
+    TopkArgs a;
+    a.x = x; a.N = N; a.ldx = ldx; a.packed = packed; a.C = C; a.n_tiles = (C + 31) / 32; a.K = K;
+    a.skip_norm = metric == VQHIP_COSINE_PRENORM; a.idx_out = idx_out; a.val_out = val_out;
+    const int m = metric == VQHIP_EUCLID ? VQHIP_EUCLID : VQHIP_COSINE;
+    hipStream_t st = (hipStream_t)stream;
+    switch (D) {
+        case 32: return dispatch_topk<32>(a, x_dtype, m, st);
+        case 64: return dispatch_topk<64>(a, x_dtype, m, st);
+        case 128: return dispatch_topk<128>(a, x_dtype, m, st);
+        case 256: return dispatch_topk<256>(a, x_dtype, m, st);
+        default: return dispatch_topk<512>(a, x_dtype, m, st);
+    }
+}
+
 // thread-per-row exact ATen-order sum of squares (any D <= 512)
 template <bool XBF16>
 __global__ void __launch_bounds__(256) vq_row_sumsq_kernel(const void *x, int64_t N, int D, int64_t ldx, float *out)

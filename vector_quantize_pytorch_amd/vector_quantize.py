@@ -350,13 +350,16 @@ class VectorQuantize(nn.Module):
     # The nearest-code search still runs on the HIP kernel (no gradient flows through an argmin); what changes is
     # that `quantize` is a differentiable gather of the (possibly bridged) codebook parameter and that the losses
     # are built from autograd ops.  Reference: vqp.py:710-717 (learnable embed / bridge), :1186-1237.
-    def _forward_general(self, xs, rmask, freeze_codebook, kw, *, dense, topk, temp):
+    def _forward_general(self, xs, rmask, freeze_codebook, kw, *, dense, topk, temp, need_dist=False):
         """everything that is not the fused hot path: codebooks with gradients and/or options that read the full score row"""
         cb = self._codebook
         embed_eff = cb.embed if cb.vq_bridge is None else cb.vq_bridge(cb.embed)      # [1, C, D]
         if not cb.learnable_codebook:
             embed_eff = embed_eff.detach()
         temp = cb.sample_codebook_temp if temp is None else temp
+        topk_only = (topk is not None and not self.commitment_use_cross_entropy_loss and not self.has_codebook_diversity_loss
+                     and not self.gumbel_straight_through and not (self.training and self.stochastic_sample_codes and temp > 0)
+                     and not need_dist)
 
         def search(update_usage=True):
             if not dense:
@@ -368,6 +371,12 @@ class VectorQuantize(nn.Module):
                 return q, r["idx"], None
             if not cb._is_initted():
                 cb.init_embed_(xs.detach().reshape(1, -1, xs.shape[-1]).float(), None if rmask is None else rmask.reshape(1, -1))
+            if topk_only and L.topk_supported(xs, topk, embed_eff.shape[-2]):
+                # top-k is the only consumer of the score row: the K best codes straight from the sweep (vqhip_topk), no N x C tensor
+                e2 = embed_eff[0].detach().float().contiguous()
+                ind = L.topk(xs.detach(), L.pack_codebook(e2), e2.shape[0], topk, cosine=cb.use_cosine_sim, skip_l2norm=True)
+                q = F.embedding(ind, embed_eff[0])
+                return q.to(xs.dtype), ind, None
             dist = _ScoresFn.apply(xs, embed_eff[0], cb.use_cosine_sim)               # vqp.py:740-743, [b, n, C]
             logits = dist
             if self.training and self.stochastic_sample_codes and temp > 0:           # vqp.py:117-119, 132-133
@@ -529,7 +538,7 @@ class VectorQuantize(nn.Module):
         distances = None
         if param_path:
             quantize, embed_ind, commit_quantize, inplace_loss, distances = self._forward_general(
-                xs, rmask, freeze_codebook, kw, dense=dense, topk=topk, temp=sample_codebook_temp)
+                xs, rmask, freeze_codebook, kw, dense=dense, topk=topk, temp=sample_codebook_temp, need_dist=return_loss)
         else:
             fold = (mask is None and self.training and self.has_commitment_loss)     # sq_sum then already is the mean
             quantize, embed_ind, sq_sum = _QuantizeFn.apply(xs, self, rmask, kw, 1.0 / float(max(xs.numel(), 1)) if fold else 1.0)
