@@ -1119,7 +1119,7 @@ template <int DT> struct Screen16F32Cfg {
 //                              charges the measured residual, |(x' - x_h).c| <= ||x' - x_h|| Y per code (computed per row)
 //   XBF16 = true,  NPART = 1 : bf16 rows, D = 512 -- exact operands like vq_screen16_kernel, half its rows per wave
 template <int DT, int METRIC, bool XBF16, int NPART>
-__global__ void __launch_bounds__(VQS_F32_WAVES * 64, 8 / VQS_F32_WAVES) vq_screen16_1rb_kernel(const ScreenArgs a)
+__global__ void __launch_bounds__(VQS_F32_WAVES * 64, (XBF16 && NPART == 1 && DT <= 256) ? 4 : 8 / VQS_F32_WAVES) vq_screen16_1rb_kernel(const ScreenArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using Cfg = Screen16F32Cfg<DT>;
@@ -1133,8 +1133,9 @@ __global__ void __launch_bounds__(VQS_F32_WAVES * 64, 8 / VQS_F32_WAVES) vq_scre
     constexpr int TS = NPART * NK;                  // MFMAs (steps) per tile
     constexpr int PMAX = (NCHUNK + W - 1) / W;      // pieces per wave and buffer
     constexpr int PPS = (PMAX + SUB - 1) / SUB;     // pieces a wave copies during one tile
-    constexpr int BS2 = (PPS + 1) / 2;
-    constexpr int HALF = TS / 2;                    // second staging batch starts here
+    constexpr int NBATCH = (TS >= 4) ? 2 : 1;       // staging batches per tile
+    constexpr int BS2 = (PPS + NBATCH - 1) / NBATCH;
+    constexpr int HALF = TS / NBATCH;               // steps between batch starts
     constexpr int LAG2 = (HALF >= 8) ? HALF - 2 : HALF - 1;
     constexpr int PSTRIDE = W * 1024;
     constexpr int ES = XBF16 ? 2 : 4;               // element size of x / q
@@ -1353,7 +1354,7 @@ __global__ void __launch_bounds__(VQS_F32_WAVES * 64, 8 / VQS_F32_WAVES) vq_scre
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int bt = 0; bt < 2; ++bt) {
+                for (int bt = 0; bt < NBATCH; ++bt) {
                     if (s == bt * HALF) {
 #pragma unroll
                         for (int i = 0; i < BS2; ++i)
@@ -1793,7 +1794,16 @@ static int launch_screen(const ScreenArgs &a, int x_dtype, hipStream_t st)
     if (!screen_bf16x2() || DT > 256) {
         // fp16 single-codebook-part kernels: bf16 rows with D <= 256 keep two row blocks per wave, everything else one
         if (x_dtype == VQHIP_BF16) {
+            static int one_rb = -1;      // VQHIP_SCREEN_1RB=1: bf16 rows through the one-row-block kernel (4 waves per SIMD), A/B
+            if (one_rb < 0) { const char *e = getenv("VQHIP_SCREEN_1RB"); one_rb = (e && e[0] == '1') ? 1 : 0; }
             if constexpr (DT <= 256) {
+                if (one_rb) {
+                    static VqAttrOnce once1;
+                    constexpr int SMEM1 = Screen16F32Cfg<DT>::SMEM;
+                    if (int rc = vq_set_max_smem(once1, (const void *)vq_screen16_1rb_kernel<DT, METRIC, true, 1>, SMEM1, "vq_screen16_1rb_kernel")) return rc;
+                    hipLaunchKernelGGL((vq_screen16_1rb_kernel<DT, METRIC, true, 1>), dim3(blocks), dim3(VQS_F32_WAVES * 64), SMEM1, st, a);
+                    return vq_launch_status("vq_screen16_1rb_kernel (bf16)");
+                }
                 static VqAttrOnce once;
                 constexpr int SMEM16 = Screen16Cfg<DT>::SMEM;
                 if (int rc = vq_set_max_smem(once, (const void *)vq_screen16_kernel<DT, METRIC>, SMEM16, "vq_screen16_kernel")) return rc;
