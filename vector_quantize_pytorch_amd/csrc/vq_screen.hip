@@ -501,7 +501,10 @@ template <int DT> struct Screen16Cfg {
 // wave, half the MFMAs and LDS reads per row of the two-set kernel further down).  The certificate charges the MEASURED residual
 // ||x' - x_h|| Y per code.  The scale is chosen per row block (rows of different blocks are never compared), so that a row block's
 // raw fp32 values (128 registers at D = 256) are converted before the next one is loaded.
-template <int DT, int METRIC, bool XF32 = false>
+// NPART = 2 (fp32 rows, D <= 128, where two operand sets per row block still fit the registers): x' = x_h + x_m, both truncated
+// fp16 parts (|x' - x_h - x_m| <= 2^-20 |x'|), two MFMAs per k-step on one A fragment -- the x side then costs the certificate
+// 2^-20 X Y instead of the measured 2^-11-level residual, which brings the uncertified fraction of fp32 rows down to bf16 levels.
+template <int DT, int METRIC, bool XF32 = false, int NPART = 1>
 __global__ void __launch_bounds__(VQS_WAVES * 64, 8 / VQS_WAVES) vq_screen16_kernel(const ScreenArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -542,7 +545,9 @@ __global__ void __launch_bounds__(VQS_WAVES * 64, 8 / VQS_WAVES) vq_screen16_ker
 
     // ---- x rows, requested first: lane (j, half) holds x[row][16 ks + 8 half + 0..7] for every k-step ----
     uint4 xb[2][NK];
+    uint4 xm[2][NPART == 2 ? NK : 1];   // second operand set (NPART == 2)
     int64_t rows[2];
+    static_assert(NPART == 1 || XF32, "only fp32 rows need a second operand set");
     bool row_ok[2];
     float xs2[2], rxn[2] = {0.f, 0.f};     // ||x||^2 (x 1.001) and, for fp32 rows, ||x' - x_h|| in unscaled units
     int SXv[2];
@@ -644,16 +649,24 @@ __global__ void __launch_bounds__(VQS_WAVES * 64, 8 / VQS_WAVES) vq_screen16_ker
             for (int ks = 0; ks < NK; ++ks) {
                 const float v[8] = {xr[ks][0].x * S, xr[ks][0].y * S, xr[ks][0].z * S, xr[ks][0].w * S,
                                     xr[ks][1].x * S, xr[ks][1].y * S, xr[ks][1].z * S, xr[ks][1].w * S};
-                unsigned hw[4];
+                unsigned hw[4], mw[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    f16x2 h;
-                    h[0] = (_Float16)v[2 * q]; h[1] = (_Float16)v[2 * q + 1];
-                    const float r0 = v[2 * q] - (float)h[0], r1 = v[2 * q + 1] - (float)h[1];   // exact
-                    r2 = __builtin_fmaf(r0, r0, r2); r2 = __builtin_fmaf(r1, r1, r2);
-                    hw[q] = __builtin_bit_cast(unsigned, h);
+                    if (NPART == 1) {
+                        f16x2 h;
+                        h[0] = (_Float16)v[2 * q]; h[1] = (_Float16)v[2 * q + 1];
+                        const float r0 = v[2 * q] - (float)h[0], r1 = v[2 * q + 1] - (float)h[1];   // exact
+                        r2 = __builtin_fmaf(r0, r0, r2); r2 = __builtin_fmaf(r1, r1, r2);
+                        hw[q] = __builtin_bit_cast(unsigned, h);
+                    } else {               // x_h: truncated x', x_m: truncated exact remainder
+                        const f16x2 h = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(v[2 * q], v[2 * q + 1]));
+                        const float r0 = v[2 * q] - (float)h[0], r1 = v[2 * q + 1] - (float)h[1];
+                        hw[q] = __builtin_bit_cast(unsigned, h);
+                        mw[q] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(r0, r1));
+                    }
                 }
                 xb[rb][ks] = make_uint4(hw[0], hw[1], hw[2], hw[3]);
+                if (NPART == 2) xm[rb][ks] = make_uint4(mw[0], mw[1], mw[2], mw[3]);
             }
             r2 += __shfl_xor(r2, 32, 64);
             rxn[rb] = sqrtf(r2 * 1.001f) * 1.001f * __uint_as_float((unsigned)(127 - SXv[rb]) << 23);
@@ -677,14 +690,17 @@ __global__ void __launch_bounds__(VQS_WAVES * 64, 8 / VQS_WAVES) vq_screen16_ker
 #pragma unroll
         for (int rb = 0; rb < 2; ++rb) {
             // truncated elements: |dx_k| <= 2^-24 / S each, sum_k |dx_k| |c1_k - c2_k| <= 2^-24 / S * sqrt(D) * 2 Y
-            const float conv = 2.f * 5.9604645e-8f * sqrtf((float)DT) * ymax * __uint_as_float((unsigned)(127 - SXv[rb]) << 23);
+            const float conv = NPART * 2.f * 5.9604645e-8f * sqrtf((float)DT) * ymax * __uint_as_float((unsigned)(127 - SXv[rb]) << 23);
             const float xs = xs2[rb];
             const float xn = sqrtf(xs) * 1.0001f;
             const float xy = xn * ymax;
-            const float drop = XF32 ? 2.f * rxn[rb] * ymax : 0.f;     // |(x' - x_h).c| <= ||x' - x_h|| Y, both codes of the margin
-            if (METRIC == 0) eps[rb] = u * (10.f * (xs + y2max + 2.f * xy) + 2.f * DT * xy + 4.f * (DT + 1) * 1.001f * (xy + 0.5f * y2max))
+            // the part of x' the operand set(s) do not carry, for both codes of the margin: one set -- the measured ||x' - x_h|| Y;
+            // two sets -- 2^-20 X Y
+            const float drop = !XF32 ? 0.f : (NPART == 1 ? 2.f * rxn[rb] * ymax : 2.f * 9.5367432e-7f * 1.01f * xy);
+            const float nacc = (float)(NPART * DT + 1);
+            if (METRIC == 0) eps[rb] = u * (10.f * (xs + y2max + 2.f * xy) + 2.f * DT * xy + 4.f * nacc * 1.001f * (xy + 0.5f * y2max))
                                        + 2.f * xn * rmax + drop + conv + 4e-8f;
-            else             eps[rb] = 2.f * (u * 3.f * DT * 1.001f * xy + xn * rmax) + drop + conv + 1e-30f;
+            else             eps[rb] = 2.f * (u * (DT + 2.f * NPART * DT) * 1.001f * xy + xn * rmax) + drop + conv + 1e-30f;
         }
     }
 
@@ -775,6 +791,10 @@ __global__ void __launch_bounds__(VQS_WAVES * 64, 8 / VQS_WAVES) vq_screen16_ker
                 } else {
                     if (ph == 0) acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, __builtin_bit_cast(f16x8, xb[0][ks]), acc0, 0, 0, 0);
                     else         acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, __builtin_bit_cast(f16x8, xb[1][ks]), acc1, 0, 0, 0);
+                }
+                if (NPART == 2) {   // the low part of the rows against the same A fragment
+                    if (ph == 0) acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, __builtin_bit_cast(f16x8, xm[0][NPART == 2 ? ks : 0]), acc0, 0, 0, 0);
+                    else         acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, __builtin_bit_cast(f16x8, xm[1][NPART == 2 ? ks : 0]), acc1, 0, 0, 0);
                 }
                 if (s + VQS16_PF < 2 * NK) af[s % VQS16_PF] = ap[((s + VQS16_PF) % NK) * 64];
 #ifndef VQS16_NO_EPI
@@ -1822,8 +1842,11 @@ static int launch_screen(const ScreenArgs &a, int x_dtype, hipStream_t st)
                 if (!two_part) {
                     static VqAttrOnce once;
                     constexpr int SMEM16 = Screen16Cfg<DT>::SMEM;
-                    if (int rc = vq_set_max_smem(once, (const void *)vq_screen16_kernel<DT, METRIC, true>, SMEM16, "vq_screen16_kernel (fp32 rows)")) return rc;
-                    hipLaunchKernelGGL((vq_screen16_kernel<DT, METRIC, true>), dim3(blocks), dim3(VQS_WAVES * 64), SMEM16, st, a);
+                    // (NPART = 2 fits the registers for D <= 128 and halves the uncertified rows of fp32 inputs, but its second MFMA per
+                    //  k-step costs more than the exact passes it saves: cfg 5 26.0 vs 23.5 ms -- measured, not adopted)
+                    constexpr int NP = 1;
+                    if (int rc = vq_set_max_smem(once, (const void *)vq_screen16_kernel<DT, METRIC, true, NP>, SMEM16, "vq_screen16_kernel (fp32 rows)")) return rc;
+                    hipLaunchKernelGGL((vq_screen16_kernel<DT, METRIC, true, NP>), dim3(blocks), dim3(VQS_WAVES * 64), SMEM16, st, a);
                     return vq_launch_status("vq_screen16_kernel (fp32 rows)");
                 }
             }
