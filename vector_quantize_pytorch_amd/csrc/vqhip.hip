@@ -2386,11 +2386,19 @@ __global__ void __launch_bounds__(256) vq_ema_cs_lerp_kernel(float *cs, const fl
 
 // total = cluster_size.sum() in ATen's cascade order (8 lanes x 4 ILP chains, 4 cascade levels);
 // denom[c] = (cs + eps) / (total + C eps) * total        (vqp.py:152-154, 577)
-__global__ void __launch_bounds__(256) vq_ema_denom_kernel(const float *cs, int C, float eps, float ceps, float *denom)
+__global__ void __launch_bounds__(256) vq_ema_denom_kernel(const float *cs_g, int C, float eps, float ceps, float *denom)
 {
     __shared__ float part[32];
     __shared__ float total_s;
+    extern __shared__ float cs_lds[];      // C floats when the launch provides them (C <= 16384), else unused
     const int tid = threadIdx.x;
+    // the 32 summation chains below are latency-bound on dependent global loads (33 us at C = 4096): stage cluster_size in LDS first
+    const float *cs = cs_g;
+    if (C <= 16384) {
+        for (int c = tid; c < C; c += 256) cs_lds[c] = cs_g[c];
+        __syncthreads();
+        cs = cs_lds;
+    }
     if (tid < 32) {
         const int V = C >> 3;
         const int size = V >> 2;
@@ -2486,7 +2494,7 @@ extern "C" int vqhip_ema_finalize(float *cluster_size, float *embed_avg, float *
         hipLaunchKernelGGL(vq_ema_cs_lerp_kernel, dim3((C + 255) / 256), dim3(256), 0, st, cluster_size, count, weight, C, one_minus_decay);
     if (do_update_ema) {
         const float ceps = (float)((double)C * (double)eps);
-        hipLaunchKernelGGL(vq_ema_denom_kernel, dim3(1), dim3(256), 0, st, cluster_size, C, eps, ceps, denom_ws);
+        hipLaunchKernelGGL(vq_ema_denom_kernel, dim3(1), dim3(256), (C <= 16384 ? (size_t)C * 4 : 0), st, cluster_size, C, eps, ceps, denom_ws);
     }
     if (do_lerp || do_update_ema)
         hipLaunchKernelGGL(vq_ema_embed_kernel, dim3((C + 3) / 4), dim3(256), 0, st, embed_avg, embed, embed_sum, weight,
