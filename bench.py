@@ -145,7 +145,8 @@ def other_workload(args, world, rank, dev):
         mod = ShardedVectorQuantize(512, 65536, use_cosine_sim=True, emulate=(0, 8)).to(dev).train()
         shape, stages, flops = (16, 16384, 512), 1, 2.0 * 16 * 16384 * 8192 * 512
         name = ("VectorQuantize(dim=512, codebook_size=65536, use_cosine_sim=True) sharded over 8 ranks: ONE rank's work "
-                "(all 262144 rows x its 8192 codes, search + decode + EMA; collectives excluded), x=(16,16384,512) fp32")
+                "(all 262144 gathered rows x its 8192 codes: search, exact winner scores, decode + EMA of the codes it owns; l2norm, "
+                "outputs and loss for its own 32768 rows; collectives excluded), x=(16,16384,512) fp32")
     else:   # vq_cfg4_sharded: the whole of config 4 over the `world` ranks
         mod = ShardedVectorQuantize(512, 65536, use_cosine_sim=True).to(dev).train()
         assert 16 % world == 0
@@ -155,6 +156,8 @@ def other_workload(args, world, rank, dev):
         par = f"codebook sharded x{world} (rows all-gathered, one int64 MAX all-reduce, reduce-scatter of q)"
     nb = 2
     batches = [torch.randn(*shape, generator=gen, device=dev) for _ in range(nb)]
+    if args.workload == "vq_cfg4_shard":     # what the all-gather hands a rank: rows its peers have already normalised
+        batches = [torch.nn.functional.normalize(b, dim=-1) for b in batches]
 
     def sync():
         if world > 1:
@@ -196,13 +199,13 @@ def other_workload(args, world, rank, dev):
     print(json.dumps({"metric": "vectors quantized/sec", "value": n * args.steps / dt, "unit": "vectors/s", "n_gpus": world,
                       "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
                       "scaling": "strong" if strong else "weak", "vs_baseline": None,
-                      "dtype": "bf16x3+f32" if screened else "f32", "data": "synthetic",
+                      "dtype": "f16+f32" if screened else "f32", "data": "synthetic",
                       "config": {"workload": name, "parallelism": par, "vector_stages_per_s": n * stages * args.steps / dt,
                                  "first_forward_ms": first * 1e3, "uncertified_rows_per_search": per_stage},
                       "roofline": {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
                                    "traffic": None, "achieved_vs_fp32_mfma_peak": ach / PEAK_FP32_MFMA_TFLOPS,
                                    "note": "whole step (all kernels) PER GPU, not one kernel; algorithmic flops (2*C*D per vector and stage); "
-                                           "peak = bf16 MFMA when the search runs screened (VQHIP_SCREEN != 0), fp32 MFMA otherwise"}}), flush=True)
+                                           "peak = dense f16 MFMA when the search runs screened (VQHIP_SCREEN != 0), fp32 MFMA otherwise"}}), flush=True)
 
 
 # ----------------------------------------------------------------------------------------------------------------------

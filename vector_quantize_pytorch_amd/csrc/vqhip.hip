@@ -1001,32 +1001,65 @@ __global__ void __launch_bounds__(256) vq_row_sumsq_kernel(const void *x, int64_
 // cosine similarity x_n . c_idx (vqp.py:741) -- bit for bit what vq_assign_kernel reports as the winner's score.  The screened
 // search does not produce scores; a codebook-sharded argmin needs the winner's exact score to merge shards (one chain per row).
 template <bool XBF16, int METRIC>
-__global__ void __launch_bounds__(256) vq_score_idx_kernel(const void *x, int64_t N, int D, int64_t ldx, const float *embed,
+__global__ void __launch_bounds__(128) vq_score_idx_kernel(const void *x, int64_t N, int D, int64_t ldx, const float *embed,
                                                            const float *packed, int DT, const int64_t *idx, float *out)
 {
-    const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (n >= N) return;
-    const int64_t c = idx[n];
-    const float *e = embed + (size_t)c * D;
-    float xy = 0.f;
-    for (int k = 0; k < D; k += 4) {
-        float xv[4];
-        if (XBF16) {
-            const uint2 w = *(const uint2 *)((const unsigned short *)x + n * ldx + k);
-            xv[0] = __uint_as_float(w.x << 16); xv[1] = __uint_as_float(w.x & 0xffff0000u);
-            xv[2] = __uint_as_float(w.y << 16); xv[3] = __uint_as_float(w.y & 0xffff0000u);
-        } else {
-            const f32x4 w = *(const f32x4 *)((const float *)x + n * ldx + k);
-            xv[0] = w.x; xv[1] = w.y; xv[2] = w.z; xv[3] = w.w;
+    // One row per lane keeps the reference's sequential k order; the row and its code are staged through LDS 32 elements at a
+    // time so that the global reads are 128-byte row segments instead of one strided 16-byte read per lane.
+    __shared__ float xs[128][33], es[128][33];
+    __shared__ int64_t cs[128];
+    const int t = threadIdx.x;
+    const int64_t n0 = (int64_t)blockIdx.x * 128, n = n0 + t;
+    cs[t] = idx[n < N ? n : N - 1];
+    __syncthreads();
+    float xy = 0.f, ch[32];
+#pragma unroll
+    for (int c = 0; c < 32; ++c) ch[c] = 0.f;
+    float fin = 0.f;                       // elements past the last whole group of 8 (aten_sumsq_seq's tail)
+    const int V8 = (D >> 3) << 3, V32 = (D >> 5) << 5;
+    for (int k0 = 0; k0 < D; k0 += 32) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int f = t + 128 * i, row = f >> 3, k = k0 + 4 * (f & 7);
+            const int64_t rn = (n0 + row < N) ? n0 + row : N - 1;
+            f32x4 xv = {0.f, 0.f, 0.f, 0.f}, ev = {0.f, 0.f, 0.f, 0.f};
+            if (k < D) {
+                if (XBF16) {
+                    const uint2 w = *(const uint2 *)((const unsigned short *)x + rn * ldx + k);
+                    xv.x = __uint_as_float(w.x << 16); xv.y = __uint_as_float(w.x & 0xffff0000u);
+                    xv.z = __uint_as_float(w.y << 16); xv.w = __uint_as_float(w.y & 0xffff0000u);
+                } else {
+                    xv = *(const f32x4 *)((const float *)x + rn * ldx + k);
+                }
+                ev = *(const f32x4 *)(embed + (size_t)cs[row] * D + k);
+            }
+            float *px = &xs[row][4 * (f & 7)], *pe = &es[row][4 * (f & 7)];
+            px[0] = xv.x; px[1] = xv.y; px[2] = xv.z; px[3] = xv.w;
+            pe[0] = ev.x; pe[1] = ev.y; pe[2] = ev.z; pe[3] = ev.w;
         }
-        const f32x4 u = *(const f32x4 *)(e + k);
-        xy = __builtin_fmaf(xv[0], u.x, xy); xy = __builtin_fmaf(xv[1], u.y, xy);
-        xy = __builtin_fmaf(xv[2], u.z, xy); xy = __builtin_fmaf(xv[3], u.w, xy);
+        __syncthreads();
+        const int lim = (D - k0 < 32) ? D - k0 : 32;
+#pragma unroll
+        for (int j = 0; j < 32; ++j) {
+            const float xv = xs[t][j];
+            if (j < lim) xy = __builtin_fmaf(xv, es[t][j], xy);
+            if (METRIC == 0) {
+                const int e = k0 + j;                 // chain assignment of aten_sumsq_seq
+                const float sq = xv * xv;
+                if (e < V32) ch[j] += sq;
+                else if (e < V8) ch[j & 7] += sq;
+                else if (e < D) fin += sq;
+            }
+        }
+        __syncthreads();
     }
+    if (n >= N) return;
     if (METRIC == 0) {
-        const float x2 = aten_sumsq_seq([&](int i) { return load_elem<XBF16>(x, n * ldx + i); }, D);
+#pragma unroll
+        for (int l = 0; l < 8; ++l) fin += ((ch[l] + ch[8 + l]) + ch[16 + l]) + ch[24 + l];
+        const int64_t c = cs[t];
         const float y2 = packed[(size_t)(c >> 5) * (32 * DT + 256) + 32 * DT + (c & 31)];
-        out[n] = sqrtf(fmaxf(__builtin_fmaf(-2.f, xy, x2 + y2), 1e-8f));
+        out[n] = sqrtf(fmaxf(__builtin_fmaf(-2.f, xy, fin + y2), 1e-8f));
     } else {
         out[n] = xy;
     }
@@ -1043,9 +1076,9 @@ extern "C" int vqhip_score_indices(const void *x, int x_dtype, int64_t N, int D,
     const int es = (x_dtype == VQHIP_BF16) ? 2 : 4;
     if ((((uintptr_t)x) % (4 * es)) || ((ldx * es) % (4 * es)) || (((uintptr_t)embed) & 15)) VQ_FAIL(VQHIP_EALIGN, "score_indices: rows must be aligned to 4 elements");
     if (N == 0) return 0;
-    const unsigned blocks = (unsigned)((N + 255) / 256);
+    const unsigned blocks = (unsigned)((N + 127) / 128);
     hipStream_t st = (hipStream_t)stream;
-#define VQ_SI(B, M) hipLaunchKernelGGL((vq_score_idx_kernel<B, M>), dim3(blocks), dim3(256), 0, st, x, N, D, ldx, embed, packed, DT, idx, out)
+#define VQ_SI(B, M) hipLaunchKernelGGL((vq_score_idx_kernel<B, M>), dim3(blocks), dim3(128), 0, st, x, N, D, ldx, embed, packed, DT, idx, out)
     if (metric == VQHIP_EUCLID) { if (x_dtype == VQHIP_BF16) VQ_SI(true, 0); else VQ_SI(false, 0); }
     else                        { if (x_dtype == VQHIP_BF16) VQ_SI(true, 1); else VQ_SI(false, 1); }
 #undef VQ_SI
@@ -2259,9 +2292,6 @@ __global__ void __launch_bounds__(256) vq_segsum_fast_kernel(const SegArgs a)
     const int j = w - a.chunk_off[c];
     const int beg = a.seg_off[c] + j * VQ_SEG_CH;
     const int end = min(a.seg_off[c + 1], beg + VQ_SEG_CH);
-    const int d = lane * 4;
-    const bool act = d < a.D;
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
 #ifndef VQ_SEG_U_BF
 #define VQ_SEG_U_BF 16
 #endif
@@ -2269,35 +2299,40 @@ __global__ void __launch_bounds__(256) vq_segsum_fast_kernel(const SegArgs a)
 #define VQ_SEG_U_F32 32
 #endif
     constexpr int U = XBF16 ? VQ_SEG_U_BF : VQ_SEG_U_F32;   // rows in flight per wave
-    for (int r = beg; r < end; r += U) {
-        int rows[U];
+    for (int d0 = 0; d0 < a.D; d0 += 256) {                 // D <= 512: one or two 256-element column blocks
+        const int d = d0 + lane * 4;
+        const bool act = d < a.D;
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int r = beg; r < end; r += U) {
+            int rows[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) rows[u] = a.perm[min(r + u, end - 1)];   // wave-uniform
-        if (XBF16) {
-            uint2 v[U];
+            for (int u = 0; u < U; ++u) rows[u] = a.perm[min(r + u, end - 1)];   // wave-uniform
+            if (XBF16) {
+                uint2 v[U];
 #pragma unroll
-            for (int u = 0; u < U; ++u)
-                if (act) v[u] = *(const uint2 *)((const unsigned short *)a.x + (int64_t)rows[u] * a.ldx + d);
+                for (int u = 0; u < U; ++u)
+                    if (act) v[u] = *(const uint2 *)((const unsigned short *)a.x + (int64_t)rows[u] * a.ldx + d);
 #pragma unroll
-            for (int u = 0; u < U; ++u)
-                if (act && r + u < end) {
-                    acc[0] += __uint_as_float(v[u].x << 16); acc[1] += __uint_as_float(v[u].x & 0xffff0000u);
-                    acc[2] += __uint_as_float(v[u].y << 16); acc[3] += __uint_as_float(v[u].y & 0xffff0000u);
-                }
-        } else {
-            f32x4 v[U];
+                for (int u = 0; u < U; ++u)
+                    if (act && r + u < end) {
+                        acc[0] += __uint_as_float(v[u].x << 16); acc[1] += __uint_as_float(v[u].x & 0xffff0000u);
+                        acc[2] += __uint_as_float(v[u].y << 16); acc[3] += __uint_as_float(v[u].y & 0xffff0000u);
+                    }
+            } else {
+                f32x4 v[U];
 #pragma unroll
-            for (int u = 0; u < U; ++u)
-                if (act) v[u] = *(const f32x4 *)((const float *)a.x + (int64_t)rows[u] * a.ldx + d);
+                for (int u = 0; u < U; ++u)
+                    if (act) v[u] = *(const f32x4 *)((const float *)a.x + (int64_t)rows[u] * a.ldx + d);
 #pragma unroll
-            for (int u = 0; u < U; ++u)
-                if (act && r + u < end) { acc[0] += v[u].x; acc[1] += v[u].y; acc[2] += v[u].z; acc[3] += v[u].w; }
+                for (int u = 0; u < U; ++u)
+                    if (act && r + u < end) { acc[0] += v[u].x; acc[1] += v[u].y; acc[2] += v[u].z; acc[3] += v[u].w; }
+            }
         }
-    }
-    if (act)
+        if (act)
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-            if (acc[e] != 0.f) unsafeAtomicAdd(&a.embed_sum[(size_t)c * a.D + d + e], acc[e]);
+            for (int e = 0; e < 4; ++e)
+                if (acc[e] != 0.f) unsafeAtomicAdd(&a.embed_sum[(size_t)c * a.D + d + e], acc[e]);
+    }
 }
 
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -2353,7 +2388,7 @@ extern "C" int vqhip_ema_accumulate(const void *x, int x_dtype, int64_t N, int D
     const bool vec = (D % 4 == 0) && (((uintptr_t)x) % (4 * es) == 0) && ((ldx * es) % (4 * es) == 0);
     const bool bf = (x_dtype == VQHIP_BF16);
 #ifndef VQ_SEG_SLOW
-    if (vec && D <= 256 && !g.cosine) {
+    if (vec && D <= 512 && !g.cosine) {
         if (bf) hipLaunchKernelGGL((vq_segsum_fast_kernel<true>), dim3(seg_blocks), dim3(256), 0, st, g);
         else hipLaunchKernelGGL((vq_segsum_fast_kernel<false>), dim3(seg_blocks), dim3(256), 0, st, g);
         return launch_status("vq_ema_accumulate");

@@ -87,7 +87,8 @@ class ShardedVectorQuantize(torch.nn.Module):
         self.rank = dist.get_rank(group) if on else 0
         self._emulated = emulate is not None
         if emulate is not None:        # (rank, world): this process plays ONE rank of a larger job, collectives skipped --
-            self.rank, self.world = emulate    # the per-rank work of a sharded configuration on a single GPU (bench.py vq_cfg4_shard)
+            self.rank, self.world = emulate    # the per-rank work of a sharded configuration on a single GPU (bench.py vq_cfg4_shard):
+                                               # forward(x) then takes the gathered rows of all ranks and returns this rank's share
         self.dim, self.codebook_size = dim, codebook_size
         self.lo, self.hi = shard_bounds(codebook_size, self.world, self.rank)
         self.use_cosine_sim, self.decay, self.eps = use_cosine_sim, decay, eps
@@ -150,6 +151,9 @@ class ShardedVectorQuantize(torch.nn.Module):
             else:
                 dist.all_reduce(q_part, group=self.group)
                 q_rows, idx_rows = q_part, gidx
+        elif self._emulated:          # one rank of a larger job on its own: it keeps the rows it contributed to the gather
+            sl = slice(self.rank * (n_local // self.world), (self.rank + 1) * (n_local // self.world))
+            q_rows, idx_rows = q_part[sl], gidx[sl]
         else:
             q_rows, idx_rows = q_part, gidx
 
@@ -173,13 +177,21 @@ class ShardedVectorQuantize(torch.nn.Module):
         b, n, d = x.shape
         needs_grad = self.training and x.requires_grad and torch.is_grad_enabled()
         rows = x.reshape(-1, d)
-        if self.use_cosine_sim:
-            # gradients flow through the l2norm (vqp.py:1159); without them the HIP kernel normalises in the reference's arithmetic
-            xin = torch.nn.functional.normalize(rows, p=2, dim=-1, eps=1e-6) if needs_grad or not L.screen_supported(rows, 2) \
-                else L.l2norm_rows(rows)
+        if self._emulated:
+            # x stands for the gathered rows of ALL ranks (unit-norm already for the cosine metric, as the all-gather delivers
+            # them); this rank normalises, and gets outputs for, its own share only -- the work one rank of the real job does
+            per = rows.shape[0] // self.world
+            own = rows[self.rank * per:(self.rank + 1) * per]
+            xin = L.l2norm_rows(own) if self.use_cosine_sim else own
+            q_rows, idx_rows = self._search_and_update(rows.detach())
         else:
-            xin = rows
-        q_rows, idx_rows = self._search_and_update(xin.detach())
+            if self.use_cosine_sim:
+                # gradients flow through the l2norm (vqp.py:1159); without them the HIP kernel normalises in the reference's arithmetic
+                xin = torch.nn.functional.normalize(rows, p=2, dim=-1, eps=1e-6) if needs_grad or not L.screen_supported(rows, 2) \
+                    else L.l2norm_rows(rows)
+            else:
+                xin = rows
+            q_rows, idx_rows = self._search_and_update(xin.detach())
         q_rows = q_rows.to(x.dtype)
         quantize = q_rows
         loss = torch.zeros((), device=x.device)
@@ -188,4 +200,6 @@ class ShardedVectorQuantize(torch.nn.Module):
                 from .vector_quantize import _RouteFn
                 quantize = _RouteFn.apply(xin.contiguous(), q_rows.contiguous(), L.ROTATION if self.rotation_trick else L.STRAIGHT_THROUGH)
             loss = torch.nn.functional.mse_loss(q_rows.detach().float(), xin.float()) * self.commitment_weight   # vqp.py:1327
+        if self._emulated:
+            return quantize, idx_rows, loss
         return quantize.reshape(b, n, d), idx_rows.reshape(b, n), loss
