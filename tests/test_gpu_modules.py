@@ -157,6 +157,38 @@ def test_grouped_residual_vq(dev):                                            # 
     assert quantized.shape == x.shape and indices.shape == (2, 1, 1024, 8) and commit_loss.shape == (2, 8)
 
 
+def test_grouped_residual_vq_group_streams_match_serial(dev):
+    """GroupedResidualVQ runs its groups on side streams (concurrent_groups): same outputs, codebooks and gradients as the
+    serial order over several train steps, including under a caller-chosen non-default stream."""
+    import copy
+    from vector_quantize_pytorch_amd import GroupedResidualVQ
+    torch.manual_seed(3)
+    a = GroupedResidualVQ(dim=256, num_quantizers=4, groups=4, codebook_size=256, threshold_ema_dead_code=2).to(dev).train()
+    b = copy.deepcopy(a)
+    b.concurrent_groups = False
+    s = torch.cuda.Stream(device=dev)
+    for step in range(3):
+        x = torch.randn(4, 2048, 256, device=dev)
+        xa, xb = x.clone().requires_grad_(), x.clone().requires_grad_()
+        state = torch.cuda.get_rng_state(dev)
+        if step == 2:
+            s.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(s):
+                qa, ia, la = a(xa)
+                (qa.sum() + la.sum()).backward()
+            torch.cuda.current_stream(dev).wait_stream(s)
+        else:
+            qa, ia, la = a(xa)
+            (qa.sum() + la.sum()).backward()
+        torch.cuda.set_rng_state(state, dev)
+        qb, ib, lb = b(xb)
+        (qb.sum() + lb.sum()).backward()
+        torch.cuda.synchronize()
+        assert torch.equal(ia, ib) and torch.equal(qa, qb) and torch.equal(la, lb), step
+        assert torch.equal(xa.grad, xb.grad), step
+    assert torch.equal(a.codebooks, b.codebooks)
+
+
 def test_accum_ema_update(dev):                                               # tests/test_readme.py:467-492
     from vector_quantize_pytorch_amd import VectorQuantize
     vq = VectorQuantize(dim=64, codebook_size=128).to(dev)

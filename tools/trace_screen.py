@@ -11,16 +11,20 @@ g = torch.Generator(device=dev).manual_seed(0)
 e = torch.empty(C, D, device=dev)
 torch.nn.init.kaiming_uniform_(e, generator=g)
 pk = L.pack_codebook(e)
-xf = torch.randn(1 << 20, D, device=dev, generator=g).bfloat16()
+F32 = len(sys.argv) > 1 and sys.argv[1] == 'f32'      # fp32 rows with a residual output: one stage of the cfg-3 loop
+xf = torch.randn(1 << 20, D, device=dev, generator=g)
+if not F32: xf = xf.bfloat16()
+resid = torch.empty_like(xf) if F32 else None
+kw = (lambda x: dict(want_q=False, want_sqerr=True, resid_out=resid[: x.shape[0]])) if F32 else (lambda x: dict(want_q=True, want_sqerr=True))
 lib = L.lib()
 lib.vqhip_set_trace.argtypes = [ctypes.c_void_p]
 NI = 16   # barrier intervals at C = 1024, SUB = 2
 for blocks in (256, 512, 4096):
     x = xf[: blocks * 256]
-    L.assign(x, pk, e, want_q=True, want_sqerr=True); torch.cuda.synchronize()
+    L.assign(x, pk, e, **kw(x)); torch.cuda.synchronize()
     tr = torch.zeros(16 * 4 * 64 * 4 + 16 * 4 * 8, dtype=torch.int64, device=dev)
     lib.vqhip_set_trace(ctypes.c_void_p(tr.data_ptr()))
-    L.assign(x, pk, e, want_q=True, want_sqerr=True); torch.cuda.synchronize()
+    L.assign(x, pk, e, **kw(x)); torch.cuda.synchronize()
     lib.vqhip_set_trace(ctypes.c_void_p(0))
     ph = tr.cpu()[16 * 4 * 64 * 4:].reshape(16, 4, 8).double()
     d = [(ph[:, :, i + 1] - ph[:, :, i]).mean().item() for i in range(4)]

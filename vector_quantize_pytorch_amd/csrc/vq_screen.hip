@@ -625,10 +625,104 @@ __global__ void __launch_bounds__(VQS_WAVES * 64, 8 / VQS_WAVES) vq_screen16_ker
     } else {
         // ---- fp32 rows, one row block at a time: raw values -> ||x||^2 -> the block's scale -> x_h = fp16_rne(x') and the residual ----
         typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+#ifndef VQS16_F32_DIRECT
+        if constexpr (NPART == 1) {
+            // Whole rows per wave instruction (LPR lanes x 16 bytes per row; one row per lane, the operand layout's pattern, touches
+            // 64 cache lines per instruction and ran this load at 1.6 TB/s).  Norms, scale, conversion and the measured residual
+            // all happen in that row-cooperative layout; only the fp16 operands are transposed into the operand layout, through
+            // this wave's quarter of the SECOND codebook buffer, which nothing stages before the barrier that ends the prologue.
+            constexpr int CH = DT < 64 ? DT : 64, LPR = CH / 4, RPI = 64 / LPR, NI = 32 / RPI, NSTEP = DT / CH;
+            constexpr int COLS = DT < 128 ? DT : 128, NPASS = DT / COLS, SPP = COLS / CH, PITCH = COLS * 2 + 16;
+            static_assert(32 * PITCH + 256 <= Cfg::BUF_B / VQS_WAVES, "transposition scratch");
+            char *scr = smem + Cfg::BUF_B + wave * (Cfg::BUF_B / VQS_WAVES);
+            float *nrm = (float *)(scr + 32 * PITCH);          // [2][32]: ||x||^2 and ||x' - x_h||^2 per row of the block
+            const int lr = lane / LPR, lc = lane % LPR;
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb) {
+                f32x4 g[NSTEP][NI];
+#pragma unroll
+                for (int i = 0; i < NI; ++i) {
+                    const int64_t r = wrow0 + rb * 32 + i * RPI + lr;
+                    const float *pr = (const float *)a.x + (r < a.N ? r : a.N - 1) * a.ldx + lc * 4;
+#pragma unroll
+                    for (int st = 0; st < NSTEP; ++st) g[st][i] = *(const f32x4 *)(pr + st * CH);
+                }
+                float ps[NI];
+                unsigned mxb = 0u;
+#pragma unroll
+                for (int i = 0; i < NI; ++i) {
+                    float xs = 0.f;
+#pragma unroll
+                    for (int st = 0; st < NSTEP; ++st) {
+                        const f32x4 v = g[st][i];
+                        xs = __builtin_fmaf(v.x, v.x, xs); xs = __builtin_fmaf(v.y, v.y, xs);
+                        xs = __builtin_fmaf(v.z, v.z, xs); xs = __builtin_fmaf(v.w, v.w, xs);
+                    }
+#pragma unroll
+                    for (int o = 1; o < LPR; o <<= 1) xs += __shfl_xor(xs, o, 64);
+                    ps[i] = xs * 1.001f;
+                    const unsigned bits = __float_as_uint(ps[i]);
+                    const unsigned fin = (bits & 0x7f800000u) == 0x7f800000u ? 0u : (bits & 0x7fffffffu);
+                    mxb = fin > mxb ? fin : mxb;
+                }
+#pragma unroll
+                for (int o = 32; o >= 1; o >>= 1) { const unsigned t = (unsigned)__shfl_xor((int)mxb, o, 64); mxb = t > mxb ? t : mxb; }
+                SXv[rb] = pick_sx((unsigned)__builtin_amdgcn_readfirstlane((int)mxb));
+                const float S = __uint_as_float((unsigned)(SXv[rb] + 127) << 23);
+                uint2 hq[NSTEP][NI];
+                float pr2[NI];
+#pragma unroll
+                for (int i = 0; i < NI; ++i) {
+                    float r2 = 0.f;
+#pragma unroll
+                    for (int st = 0; st < NSTEP; ++st) {
+                        const float v[4] = {g[st][i].x * S, g[st][i].y * S, g[st][i].z * S, g[st][i].w * S};
+                        unsigned hw[2];
+#pragma unroll
+                        for (int q = 0; q < 2; ++q) {
+                            f16x2 h;
+                            h[0] = (_Float16)v[2 * q]; h[1] = (_Float16)v[2 * q + 1];
+                            const float r0 = v[2 * q] - (float)h[0], r1 = v[2 * q + 1] - (float)h[1];   // exact
+                            r2 = __builtin_fmaf(r0, r0, r2); r2 = __builtin_fmaf(r1, r1, r2);
+                            hw[q] = __builtin_bit_cast(unsigned, h);
+                        }
+                        hq[st][i] = make_uint2(hw[0], hw[1]);
+                    }
+#pragma unroll
+                    for (int o = 1; o < LPR; o <<= 1) r2 += __shfl_xor(r2, o, 64);
+                    pr2[i] = r2;
+                }
+                if (lc == 0) {
+#pragma unroll
+                    for (int i = 0; i < NI; ++i) { nrm[i * RPI + lr] = ps[i]; nrm[32 + i * RPI + lr] = pr2[i]; }
+                }
+#pragma unroll
+                for (int ps_ = 0; ps_ < NPASS; ++ps_) {
+#pragma unroll
+                    for (int sl = 0; sl < SPP; ++sl)
+#pragma unroll
+                        for (int i = 0; i < NI; ++i)
+                            *(uint2 *)(scr + (i * RPI + lr) * PITCH + (sl * CH + lc * 4) * 2) = hq[ps_ * SPP + sl][i];
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                    for (int kk = 0; kk < COLS / 16; ++kk)
+                        xb[rb][ps_ * (COLS / 16) + kk] = *(const uint4 *)(scr + j * PITCH + (16 * kk + 8 * half) * 2);
+                    if (ps_ == NPASS - 1) {
+                        xs2[rb] = nrm[j];
+                        rxn[rb] = sqrtf(nrm[32 + j] * 1.001f) * 1.001f * __uint_as_float((unsigned)(127 - SXv[rb]) << 23);
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                }
+            }
+        } else
+#endif
+        {
 #pragma unroll
         for (int rb = 0; rb < 2; ++rb) {
-            const float *p = (const float *)a.x + (row_ok[rb] ? rows[rb] : (a.N - 1)) * a.ldx + 8 * half;
             f32x4 xr[NK][2];
+            const float *p = (const float *)a.x + (row_ok[rb] ? rows[rb] : (a.N - 1)) * a.ldx + 8 * half;
 #pragma unroll
             for (int ks = 0; ks < NK; ++ks) { xr[ks][0] = *(const f32x4 *)(p + ks * 16); xr[ks][1] = *(const f32x4 *)(p + ks * 16 + 4); }
             float xs = 0.f;
@@ -672,6 +766,7 @@ __global__ void __launch_bounds__(VQS_WAVES * 64, 8 / VQS_WAVES) vq_screen16_ker
             rxn[rb] = sqrtf(r2 * 1.001f) * 1.001f * __uint_as_float((unsigned)(127 - SXv[rb]) << 23);
             __builtin_amdgcn_sched_barrier(0);   // finish this block before the next block's 128 raw registers are requested
         }
+    }
     }
     float SSv[2], iSSv[2];
 #pragma unroll
@@ -1006,7 +1101,10 @@ __global__ void __launch_bounds__(VQS_WAVES * 64, 8 / VQS_WAVES) vq_screen16_ker
     //      (coalesced) for the squared error and the residual.  Rows of the exact passes are skipped in the loss here. ----
     double ds = 0.0;
     if (a.q_out || a.resid_out || a.sqerr_partial) {
-        constexpr int RU = XF32 ? 8 : 16;
+#ifndef VQS16_RU_F32
+#define VQS16_RU_F32 8
+#endif
+        constexpr int RU = XF32 ? VQS16_RU_F32 : 16;
         const bool want_x = a.sqerr_partial != nullptr || a.resid_out != nullptr;
         const bool lane_on = lane * 4 < DT;
 #pragma unroll

@@ -371,6 +371,9 @@ class ResidualVQ(nn.Module):
         return quantized_out, torch.stack(all_idx, -1), torch.stack(all_loss)
 
 
+_SIDE_STREAMS = {}
+
+
 class GroupedResidualVQ(nn.Module):
     """G independent ResidualVQs on feature chunks (rvq.py:634-724).  Chunks are passed to the kernels as
     strided row views -- no per-group copy of the input."""
@@ -383,6 +386,14 @@ class GroupedResidualVQ(nn.Module):
         self.accept_image_fmap = accept_image_fmap
         self.rvqs = nn.ModuleList([ResidualVQ(dim=dim // groups, accept_image_fmap=accept_image_fmap, **kwargs)
                                    for _ in range(groups)])
+
+    concurrent_groups = True      # one HIP stream per group in forward (class attribute: set False to serialise on the caller's stream)
+
+    def _side_streams(self, device):
+        pool = _SIDE_STREAMS.setdefault(torch.device(device).index, [])      # per device, shared by every module: no stream in module state
+        while len(pool) < self.groups - 1:
+            pool.append(torch.cuda.Stream(device=device))
+        return pool
 
     @property
     def codebooks(self):
@@ -406,9 +417,31 @@ class GroupedResidualVQ(nn.Module):
         seed = None
         if self.training:   # same RNG consumption as rvq.py:701; the value (host sync) only if dropout needs it
             seed = _draw_seed(x.device, need_value=any(r.quantize_dropout for r in self.rvqs))
-        outs = [r(c, return_all_codes=return_all_codes, sample_codebook_temp=sample_codebook_temp, mask=mask,
+        kw = dict(return_all_codes=return_all_codes, sample_codebook_temp=sample_codebook_temp, mask=mask,
                   freeze_codebook=freeze_codebook, rand_quantize_dropout_fixed_seed=seed)
-                for r, c in zip(self.rvqs, chunks)]
+        if x.is_cuda and self.groups > 1 and self.concurrent_groups:
+            # The groups share nothing (own codebooks, own feature chunk): each runs on its own HIP stream, forked from and
+            # joined back into the caller's stream, so that one group's short exact-pass / statistics kernels run beside another
+            # group's search instead of leaving the chip mostly idle.  Host code order (and with it RNG consumption) is unchanged.
+            cur = torch.cuda.current_stream(x.device)
+            side = self._side_streams(x.device)
+            fork = torch.cuda.Event()
+            fork.record(cur)
+            outs = []
+            for g, (r, c) in enumerate(zip(self.rvqs, chunks)):
+                if g == 0:
+                    outs.append(r(c, **kw))
+                    continue
+                side[g - 1].wait_event(fork)
+                with torch.cuda.stream(side[g - 1]):
+                    outs.append(r(c, **kw))
+            for g in range(1, self.groups):
+                cur.wait_stream(side[g - 1])
+                for t in outs[g]:
+                    if torch.is_tensor(t):
+                        t.record_stream(cur)          # allocated on the side stream, consumed (and freed) on the caller's
+        else:
+            outs = [r(c, **kw) for r, c in zip(self.rvqs, chunks)]
         quantized, all_idx, losses, *codes = zip(*outs)
         ret = (torch.cat(quantized, dim=self.split_dim), torch.stack(all_idx), torch.stack(losses))
         if codes:
