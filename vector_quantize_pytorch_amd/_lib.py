@@ -299,11 +299,11 @@ def l2norm_rows(x: torch.Tensor) -> torch.Tensor:
 
 @_on_device
 def rvq_forward_screened(x: torch.Tensor, packed: torch.Tensor, embed: torch.Tensor, Q: int, *, want_resid=False,
-                         want_sqerr=False, row_mask=None):
+                         want_sqerr=False, row_mask=None, stage_hook=None):
     """The residual loop (rvq.py:469-568) as Q screened assignments: each stage's search runs on the bf16 MFMA pipe
     (csrc/vq_screen.hip) and writes the next stage's input x - q itself, so no N x D tensor op runs between stages.
-    Same arguments as rvq_forward; -> dict(idx [..., Q], inputs = the Q stage inputs (inputs[0] is x) | None,
-    sqerr_partials [Q, P] | None)."""
+    Same arguments as rvq_forward (+ stage_hook(q, stage_input, idx), called after stage q's launches);
+    -> dict(idx [..., Q], inputs = the Q stage inputs (inputs[0] is x) | None, sqerr_partials [Q, P] | None)."""
     _need_gpu(x, packed, embed, row_mask)
     shared = embed.ndim == 2
     lead, D, dev = x.shape[:-1], x.shape[-1], x.device
@@ -319,6 +319,8 @@ def rvq_forward_screened(x: torch.Tensor, packed: torch.Tensor, embed: torch.Ten
         if want_sqerr:
             parts.append(r["sqerr_partials"][: r["nblk"]])
         inputs.append(cur)
+        if stage_hook is not None:      # stage q's input and indices are final (in stream order): the caller's per-stage work
+            stage_hook(q, cur, idx)
         cur = nxt
     if row_mask is not None:      # as the fused kernel: masked rows carry index -1 (decode contributes nothing)
         idx.masked_fill_(~row_mask.reshape(*lead, 1).bool(), -1)

@@ -34,6 +34,8 @@ def _draw_seed(device, need_value: bool, max_size=10_000):
 
 
 class ResidualVQ(nn.Module):
+    concurrent_stats = True       # fused loop: stage statistics on a side HIP stream beside the later searches (class attribute)
+
     def __init__(
         self,
         *,
@@ -234,10 +236,39 @@ class ResidualVQ(nn.Module):
         update = train and not (freeze_codebook or vq0.freeze_codebook) and \
             (vq0._codebook.ema_update or vq0._codebook.has_dead_code_replacement)
         want_loss = train and vq0.has_commitment_loss
+        buf = side = None
+        if update:
+            # statistics of ALL stages in one buffer [Q, C D + C] (embed_sum || count per stage): under data parallelism ONE
+            # all-reduce per forward (the reference issues two per stage, vqp.py:603, 607); the per-stage folds stay sequential
+            # (a shared codebook is lerp-ed Q times, rvq.py:213-217 + vqp.py:616-617)
+            buf = torch.zeros(Q, (C * D + C + 3) // 4 * 4, dtype=torch.float32, device=x.device)   # stage slices stay 16-byte aligned
+
+        def accumulate(q, stage_input, idx_all):
+            L.ema_accumulate(stage_input, idx_all, C, row_mask=mask, count=buf[q, C * D: C * D + C], embed_sum=buf[q, : C * D].view(C, D),
+                             idx_offset=q, idx_stride=Q)
+
         if L.screening_enabled() and D in (32, 64, 128, 256) and x.data_ptr() % 16 == 0:
-            # Q screened searches on the bf16 MFMA pipe (csrc/vq_screen.hip), each writing the next stage's input; beats
+            # Q screened searches on the f16 MFMA pipe (csrc/vq_screen.hip), each writing the next stage's input; beats
             # the fused exact-fp32 kernel, which keeps the dims the screen does not cover (96, 160, ..., 512)
-            r = L.rvq_forward_screened(x, packed, embed, Q, want_resid=update, want_sqerr=want_loss, row_mask=mask)
+            hook = None
+            if update and x.is_cuda and self.concurrent_stats and not torch.cuda.is_current_stream_capturing():
+                # no search reads a codebook this forward changes (shared or not, embed is only rewritten after the loop), so
+                # stage q's statistics pass runs on a side stream beside the searches of the later stages.  (Not while a HIP graph
+                # is being captured: a fork nested inside GroupedResidualVQ's per-group fork crashed hipStreamEndCapture on
+                # ROCm 7.2; either fork alone captures fine, the group fork is the one kept.)
+                main = torch.cuda.current_stream(x.device)
+                side = _stats_stream(x.device, main)
+                side.wait_stream(main)
+
+                def hook(q, stage_input, idx_all):
+                    ev = torch.cuda.Event()
+                    ev.record(main)
+                    side.wait_event(ev)
+                    with torch.cuda.stream(side):
+                        accumulate(q, stage_input, idx_all)
+            r = L.rvq_forward_screened(x, packed, embed, Q, want_resid=update, want_sqerr=want_loss, row_mask=mask, stage_hook=hook)
+            if hook is None:
+                side = None
         else:
             r = L.rvq_forward(x, packed, embed, Q, want_resid=update, want_sqerr=want_loss, row_mask=mask)
         idx = r["idx"]
@@ -254,13 +285,11 @@ class ResidualVQ(nn.Module):
         if update:
             resid = r["resid"]
             stage_in = (lambda q: r["inputs"][q]) if r.get("inputs") is not None else (lambda q: resid[..., q, :])
-            # statistics of ALL stages in one buffer [Q, C D + C] (embed_sum || count per stage): under data parallelism ONE
-            # all-reduce per forward (the reference issues two per stage, vqp.py:603, 607); the per-stage folds stay sequential
-            # (a shared codebook is lerp-ed Q times, rvq.py:213-217 + vqp.py:616-617)
-            buf = torch.zeros(Q, (C * D + C + 3) // 4 * 4, dtype=torch.float32, device=x.device)   # stage slices stay 16-byte aligned
-            for q in range(Q):
-                L.ema_accumulate(stage_in(q), idx, C, row_mask=mask, count=buf[q, C * D: C * D + C], embed_sum=buf[q, : C * D].view(C, D),
-                                 idx_offset=q, idx_stride=Q)
+            if side is not None:
+                torch.cuda.current_stream(x.device).wait_stream(side)
+            else:
+                for q in range(Q):
+                    accumulate(q, stage_in(q), idx)
             if vq0._codebook.use_ddp:
                 dist.all_reduce(buf)
             for q in range(Q):
@@ -372,6 +401,15 @@ class ResidualVQ(nn.Module):
 
 
 _SIDE_STREAMS = {}
+_STATS_STREAMS = {}
+
+
+def _stats_stream(device, main):
+    """The statistics stream that pairs with `main` (one per caller stream, so concurrent groups do not share one)."""
+    key = (torch.device(device).index, main.cuda_stream)
+    if key not in _STATS_STREAMS:
+        _STATS_STREAMS[key] = torch.cuda.Stream(device=device)
+    return _STATS_STREAMS[key]
 
 
 class GroupedResidualVQ(nn.Module):
