@@ -16,6 +16,9 @@ def t(**kw):
     a.record()
     for _ in range(10): r = L.assign(x, pk, e, **kw)
     b.record(); torch.cuda.synchronize()
+    global last
+    last = r
     return a.elapsed_time(b) / 10 * 1e3
 q = torch.empty(N, D, device=dev, dtype=dt)
 print(f"{dt}: idx only {t(want_q=False):.0f} us | +q {t(want_q=True, q_out=q):.0f} | +q+sqerr {t(want_q=True, q_out=q, want_sqerr=True):.0f} | sqerr only {t(want_q=False, want_sqerr=True):.0f}")
+if last.get("n_exact") is not None: print("   open rows", int(last["n_exact"][0]), "pair rows", int(last["n_pair"][0]))

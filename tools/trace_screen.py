@@ -2,7 +2,7 @@
 Phases per workgroup (load x + scale + convert | sweep | merge / idx / list | output rows) and, inside the sweep, per barrier
 interval (SUB tiles): wait at the barrier, MFMA + staging + top-2 of the interval."""
 import sys, os, ctypes, torch
-os.environ["VQHIP_SO"] = os.path.join(os.path.dirname(os.path.abspath(__file__)), "variants", "libvqhip_trace.so")
+os.environ.setdefault("VQHIP_SO", os.path.join(os.path.dirname(os.path.abspath(__file__)), "variants", "libvqhip_trace.so"))
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from vector_quantize_pytorch_amd import _lib as L
 dev = torch.device('cuda:0')
@@ -19,7 +19,7 @@ kw = (lambda x: dict(want_q=False, want_sqerr=True, resid_out=resid[: x.shape[0]
 lib = L.lib()
 lib.vqhip_set_trace.argtypes = [ctypes.c_void_p]
 NI = 16   # barrier intervals at C = 1024, SUB = 2
-for blocks in (256, 512, 4096):
+for blocks in [int(b) for b in os.environ.get('TRACE_BLOCKS', '256,512,4096').split(',')]:
     x = xf[: blocks * 256]
     L.assign(x, pk, e, **kw(x)); torch.cuda.synchronize()
     tr = torch.zeros(16 * 4 * 64 * 4 + 16 * 4 * 8, dtype=torch.int64, device=dev)

@@ -536,6 +536,18 @@ __global__ void __launch_bounds__(VQS_WAVES * 64, 8 / VQS_WAVES) vq_screen16_ker
     const int j = lane & 31;
     const int half = lane >> 5;
     const int64_t wrow0 = (int64_t)blockIdx.x * VQ_SCREEN_ROWS + wave * 64;
+#ifdef VQS16_STAGGER
+    // A/B: the second workgroup of every CU (blocks 256 .. 511 of the first round) starts late, so that the two workgroups of a CU
+    // are not in their memory phases (row load, outputs) at the same time for the rest of the kernel
+#ifdef VQS16_STAGGER_LDSBASE
+    // the workgroup whose LDS allocation does not start at 0 is the second one on its CU (HW_REG_LDS_ALLOC, LDS_BASE field)
+    const bool second_wg = (__builtin_amdgcn_s_getreg((11 << 11) | (0 << 6) | 6) & 0xfff) != 0;
+    if (second_wg && blockIdx.x < 512)
+#else
+    if (blockIdx.x >= 256 && blockIdx.x < 512)
+#endif
+        for (int i = 0; i < VQS16_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
+#endif
     VQ_PHASE(0);
 
     // ---- first buffer: wave w copies the 1-KiB pieces w, w + WAVES, ... ----
@@ -583,7 +595,11 @@ __global__ void __launch_bounds__(VQS_WAVES * 64, 8 / VQS_WAVES) vq_screen16_ker
             const int64_t rc = row_ok[rb] ? rows[rb] : (a.N - 1);
             const unsigned short *p = (const unsigned short *)a.x + rc * a.ldx + 8 * half;
 #pragma unroll
+#ifdef VQS16_NO_XLOAD      // A/B: no row traffic in the prologue (one 16-byte piece per lane, replicated)
+            for (int ks = 0; ks < NK; ++ks) xb[rb][ks] = *(const uint4 *)(p);
+#else
             for (int ks = 0; ks < NK; ++ks) xb[rb][ks] = *(const uint4 *)(p + ks * 16);
+#endif
         }
     }
     // ---- first buffer: wave w copies the 1-KiB pieces w, w + WAVES, ... (PMAX of them: a piece past the buffer's end reads
@@ -805,8 +821,161 @@ __global__ void __launch_bounds__(VQS_WAVES * 64, 8 / VQS_WAVES) vq_screen16_ker
     int tix[2] = {0, 0}, tix2[2] = {0, 0};
     VQ_PHASE(1);
 
+#ifdef VQS16_NO_SWEEP      // A/B: prologue and output phases only
+    const int nst = 0;
+#else
     const int nst = a.n_tiles16 / SUB;   // barriers
-#ifndef VQS16_FLAT
+#endif
+#if !defined(VQS16_SKEWED) && !defined(VQS16_FLAT)
+    // ---- paired sweep: every A fragment is read from LDS ONCE and multiplied with both row blocks (two MFMAs on DIFFERENT
+    //      accumulators back to back: no dependent-accumulator stall between them), and the top-3 epilogue of the PREVIOUS tile's
+    //      two accumulators is issued in slices between this tile's MFMAs.  Tiles are processed in pairs with the accumulator
+    //      sets swapping roles (A accumulates while B is folded, then B accumulates while A is folded), so no accumulator is
+    //      ever copied.  Against the skewed sweep below: half the LDS reads, and a wave's MFMA stream alternates accumulators
+    //      (a same-accumulator chain with VALU between its MFMAs pays the write-back latency at every step). ----
+    static_assert(SUB % 2 == 0, "tiles are swept in pairs");
+#ifndef VQS16_PF2
+#define VQS16_PF2 3
+#endif
+    constexpr int PF2 = VQS16_PF2 < NK ? VQS16_PF2 : NK;
+    constexpr int FPS = 16 / NK;                        // folds per accumulator and step
+    static_assert(FPS * NK == 16, "16 scores per accumulator spread evenly over the k-steps");
+    constexpr bool TWO_B = NK >= 8;                     // staging batches per tile
+    constexpr int BSF = TWO_B ? (PPS + 1) / 2 : PPS;
+    constexpr int LAGF = TWO_B ? NK / 2 - 1 : NK - 1;   // steps (of two MFMAs) between a batch's loads and its LDS stores
+    auto fold = [&](const f32x16 &acc, int e, float &b1, float &b2, float &b3) __attribute__((always_inline)) {
+        const float k = __uint_as_float((__float_as_uint(acc[e]) & 0xfffffff0u) | (unsigned)e);
+        asm volatile("v_med3_f32 %2, %1, %2, %3\n\tv_med3_f32 %1, %0, %1, %3\n\tv_max_f32 %0, %0, %3"
+                     : "+v"(b1), "+v"(b2), "+v"(b3) : "v"(k));
+    };
+    auto book = [&](float om1, float om2, float n1, float n2, int &t1, int &t2, int tile_id) __attribute__((always_inline)) {
+        const bool c1 = n1 != om1;
+        const int from_old_best = (c1 && n2 == om1) ? t1 : tile_id;
+        t2 = (n2 != om2) ? from_old_best : t2;
+        t1 = c1 ? tile_id : t1;
+    };
+    int ptile = 0;
+    // one tile: accumulate into (C0, C1), fold the previous tile's (P0, P1).  lane16 = 16 * lane, re-derived once per barrier
+    // interval (two instructions) instead of living in a register across the sweep: every lane-dependent address of the loop
+    // (A fragments, start values, staging source and destination) is that one value plus something wave-uniform.
+    auto tile_body = [&](const char *sbase, int sub, int st, const char *gsrc, char *ldst, unsigned lane16,
+                         f32x16 &C0, f32x16 &C1, const f32x16 &P0, const f32x16 &P1) __attribute__((always_inline)) {
+        const char *tile = sbase + sub * TILE_B;
+        const float *nh = (const float *)(tile + 64 * DT + ((lane16 >> 9) << 4)) ;   // + 4 * half floats
+        const int tile_id = st * SUB + sub;
+        const bool has_pad = (tile_id + 1) * 32 > a.C;
+        const uint4 *ap = (const uint4 *)(tile + lane16);
+        uint4 af[PF2];
+        f32x4 stg[BSF];
+        const int p0 = sub * PPS;
+        const float o10 = m1[0], o20 = m2[0], o11 = m1[1], o21 = m2[1];
+#pragma unroll
+        for (int p = 0; p < PF2; ++p) af[p] = ap[p * 64];
+        // start value -||c||^2 / 2 (scaled); register e <-> code 8 (e >> 2) + 4 half + (e & 3) of the tile.  Tiles with padding
+        // codes clamp it to a finite -3e38 (see the skewed sweep).  fp32 rows: each row block has its own scale.
+        f32x16 init0, init1;
+        if (METRIC == 0 || has_pad) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                f32x4 v = *(const f32x4 *)(nh + 8 * q);
+                if (METRIC != 0) { v.x = v.x < -1e38f ? v.x : 0.f; v.y = v.y < -1e38f ? v.y : 0.f;
+                                   v.z = v.z < -1e38f ? v.z : 0.f; v.w = v.w < -1e38f ? v.w : 0.f; }
+                init0[4 * q + 0] = v.x * SSv[0]; init0[4 * q + 1] = v.y * SSv[0]; init0[4 * q + 2] = v.z * SSv[0]; init0[4 * q + 3] = v.w * SSv[0];
+                if (XF32) { init1[4 * q + 0] = v.x * SSv[1]; init1[4 * q + 1] = v.y * SSv[1]; init1[4 * q + 2] = v.z * SSv[1]; init1[4 * q + 3] = v.w * SSv[1]; }
+            }
+            if (has_pad) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { init0[r] = fmaxf(init0[r], -3.0e38f); if (XF32) init1[r] = fmaxf(init1[r], -3.0e38f); }
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { init0[r] = 0.f; if (XF32) init1[r] = 0.f; }
+        }
+#pragma unroll
+        for (int s = 0; s < NK; ++s) {
+            const f16x8 av = __builtin_bit_cast(f16x8, af[s % PF2]);
+            if (s == 0) {
+                C0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, __builtin_bit_cast(f16x8, xb[0][s]), init0, 0, 0, 0);
+                C1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, __builtin_bit_cast(f16x8, xb[1][s]), XF32 ? init1 : init0, 0, 0, 0);
+            } else {
+                C0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, __builtin_bit_cast(f16x8, xb[0][s]), C0, 0, 0, 0);
+                C1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, __builtin_bit_cast(f16x8, xb[1][s]), C1, 0, 0, 0);
+            }
+            if (NPART == 2) {   // the low part of the rows against the same A fragment
+                C0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, __builtin_bit_cast(f16x8, xm[0][NPART == 2 ? s : 0]), C0, 0, 0, 0);
+                C1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, __builtin_bit_cast(f16x8, xm[1][NPART == 2 ? s : 0]), C1, 0, 0, 0);
+            }
+            if (s + PF2 < NK) af[s % PF2] = ap[(s + PF2) * 64];
+#ifndef VQS16_NO_EPI
+#pragma unroll
+            for (int f = 0; f < FPS; ++f) {
+                fold(P0, s * FPS + f, m1[0], m2[0], m3[0]);
+                fold(P1, s * FPS + f, m1[1], m2[1], m3[1]);
+            }
+#endif
+            __builtin_amdgcn_sched_barrier(0);   // pins the slice and the prefetch distance between the MFMAs
+#ifndef VQS16_NO_STAGE
+#pragma unroll
+            for (int bt = 0; bt < (TWO_B ? 2 : 1); ++bt) {
+                const int s0 = bt * (NK / 2);
+                if (s == s0) {
+#pragma unroll
+                    for (int i = 0; i < BSF; ++i)   // unconditional: a piece past this wave's share repeats its last one
+                        if (bt * BSF + i < PPS) {
+                            const int pc = min(p0 + bt * BSF + i, PMAX - 1);
+                            stg[i] = *(const f32x4 *)(gsrc + (size_t)pc * PSTRIDE + lane16);   // uniform base + 32-bit lane offset
+                        }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (s == s0 + LAGF) {
+#pragma unroll
+                    for (int i = 0; i < BSF; ++i)
+                        if (bt * BSF + i < PPS) *(f32x4 *)(ldst + min(p0 + bt * BSF + i, PMAX - 1) * PSTRIDE + lane16) = stg[i];
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+#endif
+        }
+#ifndef VQS16_NO_EPI
+        book(o10, o20, m1[0], m2[0], tix[0], tix2[0], ptile);
+        book(o11, o21, m1[1], m2[1], tix[1], tix2[1], ptile);
+#else
+        m1[0] = fmaxf(m1[0], P0[0]); m1[1] = fmaxf(m1[1], P1[0]);
+#endif
+        ptile = tile_id;
+    };
+    f32x16 accA0, accA1, accB0, accB1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accB0[r] = accB1[r] = -3.0e38f;      // "padding codes": never win against a real one
+    for (int st = 0; st < nst; ++st) {
+        const int buf = st & 1;
+        const int ct = st;   // trace index
+        VQ_STAMP(0);
+        __syncthreads();     // buffer `buf` has landed for every wave; the other buffer is free
+        VQ_STAMP(1);
+        const char *sbase = smem + buf * BUF_B;
+        const bool more = st + 1 < nst;
+        const char *gsrc = tiles + (size_t)(more ? st + 1 : st) * SUPER_B + wave * 1024;   // wave-uniform part of the source address
+        char *ldst = smem + (buf ^ 1) * BUF_B + wave * 1024;   // (the last interval re-copies its own buffer into the idle one: no branch)
+        unsigned lane16;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0\n\tv_lshlrev_b32 %0, 4, %0" : "=v"(lane16));
+#pragma unroll 1
+        for (int sub = 0; sub < SUB; sub += 2) {
+            tile_body(sbase, sub, st, gsrc, ldst, lane16, accA0, accA1, accB0, accB1);
+            tile_body(sbase, sub + 1, st, gsrc, ldst, lane16, accB0, accB1, accA0, accA1);
+        }
+        VQ_STAMP(2);
+    }
+    {   // both row blocks of the last tile
+        const float o10 = m1[0], o20 = m2[0], o11 = m1[1], o21 = m2[1];
+#ifndef VQS16_NO_EPI
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { fold(accB0, e, m1[0], m2[0], m3[0]); fold(accB1, e, m1[1], m2[1], m3[1]); }
+#endif
+        book(o10, o20, m1[0], m2[0], tix[0], tix2[0], ptile);
+        book(o11, o21, m1[1], m2[1], tix[1], tix2[1], ptile);
+    }
+#elif !defined(VQS16_FLAT)
     // ---- skewed sweep: a tile is swept for row block 0 (NK MFMAs into acc0), then for row block 1 (NK MFMAs into acc1).
     //      The top-3 epilogue of a finished accumulator is issued in slices BETWEEN the MFMAs of the other row block -- acc1 of
     //      the previous tile beside this tile's row-block-0 MFMAs, acc0 beside the row-block-1 MFMAs -- so a wave's VALU work
@@ -1069,7 +1238,11 @@ __global__ void __launch_bounds__(VQS_WAVES * 64, 8 / VQS_WAVES) vq_screen16_ker
         const float b3 = second_low ? fmaxf(h2, l2) : fmaxf(h3, l1);
         code[rb] = ih1;
         const float thr = eps[rb] * SSv[rb] + 8e-6f * fabsf(b1);
+#ifdef VQS16_NO_SWEEP
+        const bool certified = true;
+#else
         const bool certified = ((b1 - b2) > thr) && code[rb] < a.C;
+#endif
         const bool pair = !certified && ((b1 - b3) > thr) && code[rb] < a.C && id2 < a.C;
         flagged[rb] = !certified;
         if (row_ok[rb] && half == 0) {
@@ -1104,7 +1277,10 @@ __global__ void __launch_bounds__(VQS_WAVES * 64, 8 / VQS_WAVES) vq_screen16_ker
 #ifndef VQS16_RU_F32
 #define VQS16_RU_F32 8
 #endif
-        constexpr int RU = XF32 ? VQS16_RU_F32 : 16;
+#ifndef VQS16_RU_BF16
+#define VQS16_RU_BF16 16
+#endif
+        constexpr int RU = XF32 ? VQS16_RU_F32 : VQS16_RU_BF16;
         const bool want_x = a.sqerr_partial != nullptr || a.resid_out != nullptr;
         const bool lane_on = lane * 4 < DT;
 #pragma unroll
@@ -1923,7 +2099,10 @@ static int launch_screen(const ScreenArgs &a, int x_dtype, hipStream_t st)
                     return vq_launch_status("vq_screen16_1rb_kernel (bf16)");
                 }
                 static VqAttrOnce once;
-                constexpr int SMEM16 = Screen16Cfg<DT>::SMEM;
+#ifndef VQS16_LDS_PAD
+#define VQS16_LDS_PAD 0      // A/B: extra dynamic LDS (> 8 KiB at D = 256: one workgroup per CU, i.e. one wave per SIMD)
+#endif
+                constexpr int SMEM16 = Screen16Cfg<DT>::SMEM + VQS16_LDS_PAD;
                 if (int rc = vq_set_max_smem(once, (const void *)vq_screen16_kernel<DT, METRIC>, SMEM16, "vq_screen16_kernel")) return rc;
                 hipLaunchKernelGGL((vq_screen16_kernel<DT, METRIC>), dim3(blocks), dim3(VQS_WAVES * 64), SMEM16, st, a);
             } else {
