@@ -161,6 +161,18 @@ int vqhip_ema_accumulate(const void *x, int x_dtype, int64_t N, int D, int64_t l
                          float *count, float *embed_sum, void *workspace, size_t workspace_bytes,
                          void *stream);
 
+/* The same pass, which reads every unmasked row next to its code, also summing the commitment loss' squared error
+ * (reference: F.mse_loss(quantize.detach(), x), vector_quantize_pytorch.py:1327) -- so that the search does not have to re-read
+ * x for it.  sqerr_partial[i], i < vqhip_ema_sqerr_partials(N, C): sum over the rows of work item i of ||q - x||^2 with q the
+ * row's code in x's dtype (fp32 rows: embed; bf16 rows: the bf16 copy inside `packed`) -- per 4 elements
+ * ((d0^2 + d1^2) + d2^2) + d3^2 in fp32, then in double: what vqhip_assign / vqhip_assign_screened sum into their own
+ * sqerr_partial for the same rows.  Euclidean metric, D % 4 == 0, D <= 512, 16-byte aligned rows (VQHIP_EINVAL otherwise). */
+int64_t vqhip_ema_sqerr_partials(int64_t N, int C);
+int vqhip_ema_accumulate_sqerr(const void *x, int x_dtype, int64_t N, int D, int64_t ldx,
+                               const int64_t *idx, int64_t idx_stride, const uint8_t *row_mask, int C,
+                               float *count, float *embed_sum, void *workspace, size_t workspace_bytes,
+                               const float *packed, const float *embed, double *sqerr_partial, void *stream);
+
 /* ---- EMA fold + codebook renormalisation ------------------------------------------------------
  * Replaces ema_inplace x2 (vqp.py:76-97, ATen lerp_ semantics), laplace_smoothing + update_ema
  * (:152-154, :576-584).  In place on cluster_size [C], embed_avg [C, D], embed [C, D].

@@ -797,3 +797,29 @@ def test_device_side_expiry_matches_reference_semantics(dev):
     assert torch.equal(e[40:], before[40:])
     assert torch.equal(vq._codebook.cluster_size[0, :40], torch.full((40,), 2.0, device=dev))
     assert torch.equal(vq._codebook.embed_avg[0, :40], e[:40] * 2.0)
+
+
+@pytest.mark.parametrize("dtype,kw", [(torch.bfloat16, dict(dim=256, codebook_size=1024)), (torch.float32, dict(dim=256, codebook_size=512)),
+                                      (torch.float32, dict(dim=128, codebook_size=256, heads=2, separate_codebook_per_head=True)),
+                                      (torch.float32, dict(dim=512, codebook_size=300, threshold_ema_dead_code=2))])
+def test_commit_loss_from_the_statistics_pass_equals_the_search_kernels(dev, monkeypatch, dtype, kw):
+    """Training with EMA: the squared error of the commitment loss comes from the statistics pass (Codebook.quantize,
+    vqhip_ema_accumulate_sqerr) instead of the search kernel re-reading x.  Same module, same batches, VQHIP_STATS_SQERR=0
+    (search kernel sums it) vs default: indices and outputs identical, loss and codebooks equal to fp32 rounding; with a mask too."""
+    from vector_quantize_pytorch_amd import VectorQuantize
+    torch.manual_seed(0)
+    a, b = VectorQuantize(**kw).to(dev).train(), VectorQuantize(**kw).to(dev).train()
+    b.load_state_dict(a.state_dict())
+    for step in range(3):
+        x = torch.randn(4, 1500, kw["dim"], device=dev).to(dtype)
+        lens = torch.tensor([1500, 900, 1, 1200], device=dev) if step == 2 else None
+        rng = torch.cuda.get_rng_state(dev)
+        monkeypatch.setenv("VQHIP_STATS_SQERR", "1")
+        qa, ia, la = a(x, lens=lens)
+        torch.cuda.set_rng_state(rng, dev)
+        monkeypatch.setenv("VQHIP_STATS_SQERR", "0")
+        qb, ib, lb = b(x, lens=lens)
+        assert torch.equal(ia, ib) and torch.equal(qa, qb)
+        assert torch.allclose(la, lb, rtol=2e-6, atol=0)
+        assert torch.allclose(a._codebook.embed, b._codebook.embed, rtol=1e-5, atol=1e-7)    # (embed_sum: fp32 atomics over a code's row chunks)
+        b.load_state_dict(a.state_dict())                                                     # same start for the next step

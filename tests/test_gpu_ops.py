@@ -144,6 +144,37 @@ def test_ema_accumulate(dev, N, C, D, dtype, cos):
     assert (es.cpu() - es_o).abs().max().item() <= 1e-5 * scale
 
 
+@pytest.mark.parametrize("N,C,D,dtype", [(20000, 1024, 256, torch.bfloat16), (20000, 512, 256, torch.float32),
+                                         (5000, 300, 512, torch.float32), (5000, 64, 32, torch.bfloat16), (777, 1000, 128, torch.bfloat16)])
+def test_ema_accumulate_sqerr_equals_the_search_kernels_loss(dev, N, C, D, dtype):
+    """vqhip_ema_accumulate_sqerr: the statistics pass also sums ||q - x||^2 (reference: F.mse_loss numerator, vqp.py:1327).  Against
+    (a) the oracle formula on the CPU in double, (b) the sum the exact search kernel produces for the same rows and indices;
+    count / embed_sum must be what the plain entry point gives; masked rows (mask, idx < 0) contribute nothing."""
+    from vector_quantize_pytorch_amd import _lib as L
+    x, e = _mk(N, C, D, dtype)
+    xd, ed = x.to(dev), e.to(dev).contiguous()
+    packed = L.pack_codebook(ed)
+    mask = torch.rand(N) > 0.1
+    r = L.assign(xd, packed, ed, want_q=True, want_sqerr=True, row_mask=mask.to(dev))
+    idx = r["idx"]
+    assert L.stats_sqerr_supported(xd)
+    cnt, es, parts = L.ema_accumulate(xd, idx, C, row_mask=mask.to(dev), sqerr_from=(packed, ed))
+    cnt0, es0 = L.ema_accumulate(xd, idx, C, row_mask=mask.to(dev))
+    assert torch.equal(cnt, cnt0) and (es - es0).abs().max().item() <= 1e-5 * es0.abs().max().item()   # (fp32 atomics over a code's chunks)
+    got = parts.sum().item()
+    q = (ed.to(dtype) if dtype == torch.bfloat16 else ed)[idx].double().cpu()         # the q rows of this dtype
+    want = ((q - x.double()) ** 2).sum(-1)[mask].sum().item()
+    assert abs(got - want) <= 1e-6 * want
+    from_search = r["sqerr_partials"][: r["nblk"]].sum().item()
+    assert abs(got - from_search) <= 1e-9 * from_search                                  # same fp32 4-element terms, summed in double
+    # rows dropped through idx < 0 are skipped by both the statistics and the loss
+    idx2 = idx.clone(); idx2[::5] = -1
+    _, _, parts2 = L.ema_accumulate(xd, idx2, C, sqerr_from=(packed, ed))
+    keep = torch.ones(N, dtype=torch.bool); keep[::5] = False
+    want2 = ((q - x.double()) ** 2).sum(-1)[keep].sum().item()
+    assert abs(parts2.sum().item() - want2) <= 1e-6 * want2
+
+
 @pytest.mark.parametrize("C,D,cos", [(512, 256, False), (1024, 256, False), (1000, 100, False), (4096, 128, True), (37, 2, False)])
 def test_ema_finalize(dev, C, D, cos):
     from vector_quantize_pytorch_amd import _lib as L

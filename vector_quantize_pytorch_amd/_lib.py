@@ -69,6 +69,10 @@ def lib():
     L.vqhip_ema_workspace_bytes.restype = ctypes.c_size_t
     L.vqhip_ema_workspace_bytes.argtypes = [i64, i32]
     L.vqhip_ema_accumulate.argtypes = [vp, i32, i64, i32, i64, vp, i64, vp, i32, vp, i32, vp, vp, vp, ctypes.c_size_t, vp]
+    L.vqhip_ema_sqerr_partials.argtypes = [i64, i32]
+    L.vqhip_ema_sqerr_partials.restype = i64
+    L.vqhip_ema_accumulate_sqerr.argtypes = [vp, i32, i64, i32, i64, vp, i64, vp, i32, vp, vp, vp, ctypes.c_size_t, vp, vp, vp, vp]
+    L.vqhip_ema_accumulate_sqerr.restype = i32
     L.vqhip_ema_finalize.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, f32, f32, i32, i32, i32, vp, vp]
     L.vqhip_decode_sum.argtypes = [vp, i64, i32, vp, i64, i32, i32, vp, i32, i64, vp]
     L.vqhip_row_sumsq.argtypes = [vp, i32, i64, i32, i64, vp, vp]
@@ -89,7 +93,7 @@ def lib():
 
 EXPORTS = ("vqhip_version", "vqhip_last_error", "vqhip_packed_bytes", "vqhip_pack_codebook",
            "vqhip_assign_blocks", "vqhip_assign", "vqhip_screen_supported", "vqhip_screen_workspace_bytes",
-           "vqhip_screen_blocks", "vqhip_screen_partials", "vqhip_assign_screened", "vqhip_l2norm_rows", "vqhip_scores", "vqhip_rvq_forward", "vqhip_reduce_partials", "vqhip_ema_workspace_bytes", "vqhip_ema_accumulate",
+           "vqhip_screen_blocks", "vqhip_screen_partials", "vqhip_assign_screened", "vqhip_l2norm_rows", "vqhip_scores", "vqhip_rvq_forward", "vqhip_reduce_partials", "vqhip_ema_workspace_bytes", "vqhip_ema_accumulate", "vqhip_ema_sqerr_partials", "vqhip_ema_accumulate_sqerr",
            "vqhip_ema_finalize", "vqhip_decode_sum", "vqhip_row_sumsq", "vqhip_score_indices", "vqhip_topk", "vqhip_expire_scatter", "vqhip_kmeans_update", "vqhip_route_fwd", "vqhip_route_bwd")
 
 
@@ -402,9 +406,21 @@ def reduce_partials(partials: torch.Tensor, n: int, scale: float, out: torch.Ten
 
 
 @_on_device
+def stats_sqerr_supported(x: torch.Tensor, cosine=False) -> bool:
+    """can the statistics pass also sum the commitment loss' squared error for these rows (vqhip_ema_accumulate_sqerr)?"""
+    if cosine or not x.is_cuda or x.dtype not in (torch.float32, torch.bfloat16) or os.environ.get("VQHIP_STATS_SQERR", "1") == "0":
+        return False
+    xk, N, D, ldx = as_rows(x)
+    es = xk.element_size()
+    return D % 4 == 0 and D <= 512 and xk.data_ptr() % (4 * es) == 0 and (ldx * es) % (4 * es) == 0
+
+
+@_on_device
 def ema_accumulate(x: torch.Tensor, idx: torch.Tensor, C: int, *, cosine=False, rnorm=None, row_mask=None,
-                   count=None, embed_sum=None, idx_stride=1, idx_offset=0):
-    """Accumulates into (count [C], embed_sum [C, D]); allocates zeroed ones if not given."""
+                   count=None, embed_sum=None, idx_stride=1, idx_offset=0, sqerr_from=None):
+    """Accumulates into (count [C], embed_sum [C, D]); allocates zeroed ones if not given.
+    sqerr_from = (packed, embed): also returns the squared-error partials of the commitment loss, summed by the same pass
+    (-> count, embed_sum, partials [P] float64); requires stats_sqerr_supported(x)."""
     _need_gpu(x, idx, rnorm, row_mask)
     xk, N, D, ldx = as_rows(x)
     dev = x.device
@@ -419,9 +435,19 @@ def ema_accumulate(x: torch.Tensor, idx: torch.Tensor, C: int, *, cosine=False, 
         nbytes = lib().vqhip_ema_workspace_bytes(N, C)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)     # caching allocator: 512-byte aligned
         idx_ptr = ctypes.c_void_p(idx.data_ptr() + 8 * idx_offset)     # e.g. column q of an [N, Q] index tensor
+        if sqerr_from is not None:
+            packed, embed = sqerr_from
+            assert not cosine and embed.dtype == torch.float32 and embed.is_contiguous() and tuple(embed.shape) == (C, D)
+            partials = torch.empty(lib().vqhip_ema_sqerr_partials(N, C), dtype=torch.float64, device=dev)
+            _check(lib().vqhip_ema_accumulate_sqerr(_ptr(xk), _dtype_code(xk), N, D, ldx, idx_ptr, idx_stride, _ptr(row_mask), C,
+                                                    _ptr(count), _ptr(embed_sum), _ptr(ws), nbytes, _ptr(packed), _ptr(embed),
+                                                    _ptr(partials), _stream()), "vqhip_ema_accumulate_sqerr")
+            return count, embed_sum, partials
         _check(lib().vqhip_ema_accumulate(_ptr(xk), _dtype_code(xk), N, D, ldx, idx_ptr, idx_stride, _ptr(rnorm),
                                           COSINE if cosine else EUCLID, _ptr(row_mask), C, _ptr(count),
                                           _ptr(embed_sum), _ptr(ws), nbytes, _stream()), "vqhip_ema_accumulate")
+    if sqerr_from is not None:
+        return count, embed_sum, torch.zeros(1, dtype=torch.float64, device=dev)
     return count, embed_sum
 
 

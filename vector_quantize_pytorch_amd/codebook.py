@@ -402,14 +402,22 @@ class Codebook(nn.Module):
                 # the arithmetic the exact kernel applies internally (vqp.py:37-38 at :1159), then search / sum those rows
                 xh = xst = L.l2norm_rows(xh)
                 prenorm = True
-            r = L.assign(xh, packed, e, cosine=self.use_cosine_sim, want_q=want_q, want_sqerr=want_sqerr,
+            # the statistics pass below reads every row next to its code: when it runs on the rows that were searched, it also
+            # sums the commitment loss' squared error, and the search does not re-read x for it (csrc: vq_segsum_fast_kernel)
+            sq_in_stats = (want_sqerr and do_update and x_stats is xs and not self.use_cosine_sim and L.stats_sqerr_supported(xh))
+            r = L.assign(xh, packed, e, cosine=self.use_cosine_sim, want_q=want_q, want_sqerr=want_sqerr and not sq_in_stats,
                          row_mask=rmask, skip_l2norm=prenorm, want_rnorm=self.use_cosine_sim and not prenorm,
                          q_out=q_out if H == 1 else None)
             if do_update:
                 buf = torch.zeros(C * self.dim + C, dtype=torch.float32, device=x.device)
                 esum, count = buf[: C * self.dim].view(C, self.dim), buf[C * self.dim:]
-                L.ema_accumulate(xst, r["idx"].reshape(-1), C, cosine=self.use_cosine_sim and not prenorm,
-                                 rnorm=r["rnorm"], row_mask=rmask, count=count, embed_sum=esum)
+                if sq_in_stats:
+                    _, _, parts = L.ema_accumulate(xst, r["idx"].reshape(-1), C, row_mask=rmask, count=count, embed_sum=esum,
+                                                   sqerr_from=(packed, e))
+                    r["sqerr_partials"], r["nblk"] = parts, parts.numel()
+                else:
+                    L.ema_accumulate(xst, r["idx"].reshape(-1), C, cosine=self.use_cosine_sim and not prenorm,
+                                     rnorm=r["rnorm"], row_mask=rmask, count=count, embed_sum=esum)
                 if self.use_ddp:
                     dist.all_reduce(buf)          # ONE collective for count || embed_sum (RCCL over xGMI)
                 self._fold_stats(h, count, esum, ema_update_weight, accum_ema_update, ema_update)

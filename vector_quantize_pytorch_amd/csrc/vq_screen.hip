@@ -865,10 +865,10 @@ __global__ void __launch_bounds__(VQS_WAVES * 64, 8 / VQS_WAVES) vq_screen16_ker
         const int tile_id = st * SUB + sub;
         const bool has_pad = (tile_id + 1) * 32 > a.C;
         const uint4 *ap = (const uint4 *)(tile + lane16);
-        uint4 af[PF2];
         f32x4 stg[BSF];
         const int p0 = sub * PPS;
         const float o10 = m1[0], o20 = m2[0], o11 = m1[1], o21 = m2[1];
+        uint4 af[PF2];
 #pragma unroll
         for (int p = 0; p < PF2; ++p) af[p] = ap[p * 64];
         // start value -||c||^2 / 2 (scaled); register e <-> code 8 (e >> 2) + 4 half + (e & 3) of the tile.  Tiles with padding

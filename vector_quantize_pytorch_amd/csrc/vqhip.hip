@@ -2187,6 +2187,9 @@ struct SegArgs {
     const int *chunk_off;
     const int *perm;
     float *embed_sum;
+    const void *qsrc;          // nullable: codebook rows in x's dtype, [C, D] -- the q of the commitment loss
+    double *sqerr_partial;     // nullable: one entry per work item (n_partial of them)
+    int64_t n_partial;
 };
 
 // EPL = elements per lane (vector path: D == 64 * EPL * nvec ... handled by the h loop)
@@ -2276,13 +2279,19 @@ __global__ void __launch_bounds__(256) vq_segsum_kernel(const SegArgs a)
 
 // Common case (D <= 256, vector-aligned rows, no per-row normalisation): the rows stay packed in their load registers
 // (2 VGPRs per bf16 row, 4 per fp32 row), so 16 rows are in flight per wave instead of 8.
-template <bool XBF16>
+// SQ: this pass reads every (unmasked) row next to its code, which is all the commitment loss needs (F.mse_loss(quantize, x),
+// vqp.py:1327): the wave also sums ||q_c - x||^2 over its rows -- per 4 elements ((d0^2 + d1^2) + d2^2) + d3^2 in fp32, then in
+// double, the arithmetic of the search kernels' own loss partials -- so the search does not have to re-read x for it.
+template <bool XBF16, bool SQ>
 __global__ void __launch_bounds__(256) vq_segsum_fast_kernel(const SegArgs a)
 {
     const int lane = threadIdx.x & 63;
     const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int total = a.chunk_off[a.C];
-    if (w >= total) return;
+    if (w >= total) {
+        if (SQ && lane == 0 && w < a.n_partial) a.sqerr_partial[w] = 0.0;
+        return;
+    }
     int lo = 0, hi = a.C;
     while (hi - lo > 1) {
         const int mid = (lo + hi) >> 1;
@@ -2299,10 +2308,22 @@ __global__ void __launch_bounds__(256) vq_segsum_fast_kernel(const SegArgs a)
 #define VQ_SEG_U_F32 32
 #endif
     constexpr int U = XBF16 ? VQ_SEG_U_BF : VQ_SEG_U_F32;   // rows in flight per wave
+    double sq = 0.0;
     for (int d0 = 0; d0 < a.D; d0 += 256) {                 // D <= 512: one or two 256-element column blocks
         const int d = d0 + lane * 4;
         const bool act = d < a.D;
         float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        float g[4] = {0.f, 0.f, 0.f, 0.f};                  // this lane's 4 elements of the code's row (the loss' q)
+        if (SQ && act) {
+            if (XBF16) {
+                const uint2 gw = *(const uint2 *)((const unsigned short *)a.qsrc + (size_t)c * a.D + d);
+                g[0] = __uint_as_float(gw.x << 16); g[1] = __uint_as_float(gw.x & 0xffff0000u);
+                g[2] = __uint_as_float(gw.y << 16); g[3] = __uint_as_float(gw.y & 0xffff0000u);
+            } else {
+                const f32x4 gw = *(const f32x4 *)((const float *)a.qsrc + (size_t)c * a.D + d);
+                g[0] = gw.x; g[1] = gw.y; g[2] = gw.z; g[3] = gw.w;
+            }
+        }
         for (int r = beg; r < end; r += U) {
             int rows[U];
 #pragma unroll
@@ -2315,8 +2336,13 @@ __global__ void __launch_bounds__(256) vq_segsum_fast_kernel(const SegArgs a)
 #pragma unroll
                 for (int u = 0; u < U; ++u)
                     if (act && r + u < end) {
-                        acc[0] += __uint_as_float(v[u].x << 16); acc[1] += __uint_as_float(v[u].x & 0xffff0000u);
-                        acc[2] += __uint_as_float(v[u].y << 16); acc[3] += __uint_as_float(v[u].y & 0xffff0000u);
+                        const float x0 = __uint_as_float(v[u].x << 16), x1 = __uint_as_float(v[u].x & 0xffff0000u);
+                        const float x2 = __uint_as_float(v[u].y << 16), x3 = __uint_as_float(v[u].y & 0xffff0000u);
+                        acc[0] += x0; acc[1] += x1; acc[2] += x2; acc[3] += x3;
+                        if (SQ) {
+                            const float e0 = g[0] - x0, e1 = g[1] - x1, e2 = g[2] - x2, e3 = g[3] - x3;
+                            sq += (double)(((e0 * e0 + e1 * e1) + e2 * e2) + e3 * e3);
+                        }
                     }
             } else {
                 f32x4 v[U];
@@ -2325,13 +2351,24 @@ __global__ void __launch_bounds__(256) vq_segsum_fast_kernel(const SegArgs a)
                     if (act) v[u] = *(const f32x4 *)((const float *)a.x + (int64_t)rows[u] * a.ldx + d);
 #pragma unroll
                 for (int u = 0; u < U; ++u)
-                    if (act && r + u < end) { acc[0] += v[u].x; acc[1] += v[u].y; acc[2] += v[u].z; acc[3] += v[u].w; }
+                    if (act && r + u < end) {
+                        acc[0] += v[u].x; acc[1] += v[u].y; acc[2] += v[u].z; acc[3] += v[u].w;
+                        if (SQ) {
+                            const float e0 = g[0] - v[u].x, e1 = g[1] - v[u].y, e2 = g[2] - v[u].z, e3 = g[3] - v[u].w;
+                            sq += (double)(((e0 * e0 + e1 * e1) + e2 * e2) + e3 * e3);
+                        }
+                    }
             }
         }
         if (act)
 #pragma unroll
             for (int e = 0; e < 4; ++e)
                 if (acc[e] != 0.f) unsafeAtomicAdd(&a.embed_sum[(size_t)c * a.D + d + e], acc[e]);
+    }
+    if (SQ) {
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) sq += __shfl_xor(sq, o, 64);
+        if (lane == 0) a.sqerr_partial[w] = sq;
     }
 }
 
@@ -2345,14 +2382,28 @@ extern "C" size_t vqhip_ema_workspace_bytes(int64_t N, int C)
            align_up((size_t)(N > 0 ? N : 1) * 4, 256);
 }
 
-extern "C" int vqhip_ema_accumulate(const void *x, int x_dtype, int64_t N, int D, int64_t ldx,
-                                    const int64_t *idx, int64_t idx_stride, const float *rnorm, int metric,
-                                    const uint8_t *row_mask, int C,
-                                    float *count, float *embed_sum, void *workspace, size_t workspace_bytes,
-                                    void *stream)
+static inline int64_t seg_work_items(int64_t N, int C)
+{
+    const int64_t max_items = N / VQ_SEG_CH + C + 1;       // sum_c ceil(n_c / CH) <= N / CH + C
+    return (max_items + 3) / 4 * 4;                        // whole workgroups of 4 waves
+}
+
+extern "C" int64_t vqhip_ema_sqerr_partials(int64_t N, int C) { return (N < 0 || C <= 0) ? 0 : seg_work_items(N, C); }
+
+static int ema_accumulate_impl(const void *x, int x_dtype, int64_t N, int D, int64_t ldx,
+                               const int64_t *idx, int64_t idx_stride, const float *rnorm, int metric,
+                               const uint8_t *row_mask, int C,
+                               float *count, float *embed_sum, void *workspace, size_t workspace_bytes,
+                               const void *qsrc, double *sqerr_partial, void *stream)
 {
     if (N < 0 || C <= 0 || D < 1) VQ_FAIL(VQHIP_EINVAL, "ema_accumulate: bad size");
-    if (N == 0) return 0;
+    if (N == 0) {
+        if (sqerr_partial) {
+            hipError_t e0 = hipMemsetAsync(sqerr_partial, 0, (size_t)seg_work_items(0, C) * sizeof(double), (hipStream_t)stream);
+            if (e0 != hipSuccess) VQ_FAIL((int)e0, "hipMemsetAsync(sqerr_partial): %s", hipGetErrorString(e0));
+        }
+        return 0;
+    }
     if (!x || !idx || !count || !embed_sum || !workspace) VQ_FAIL(VQHIP_EINVAL, "ema_accumulate: null pointer");
     if (D > 512) VQ_FAIL(VQHIP_EDIM, "ema_accumulate: D=%d unsupported (1..512)", D);
     if (N >= ((int64_t)1 << 31)) VQ_FAIL(VQHIP_EINVAL, "ema_accumulate: N must be < 2^31");
@@ -2382,23 +2433,54 @@ extern "C" int vqhip_ema_accumulate(const void *x, int x_dtype, int64_t N, int D
     SegArgs g;
     g.x = x; g.D = D; g.ldx = ldx; g.rnorm = rnorm; g.cosine = (metric == VQHIP_COSINE); g.C = C;
     g.seg_off = s.seg_off; g.chunk_off = s.chunk_off; g.perm = s.perm; g.embed_sum = embed_sum;
-    const int64_t max_items = N / VQ_SEG_CH + C + 1;       // sum_c ceil(n_c / CH) <= N / CH + C
-    const unsigned seg_blocks = (unsigned)((max_items + 3) / 4);
+    g.qsrc = qsrc; g.sqerr_partial = sqerr_partial; g.n_partial = seg_work_items(N, C);
+    const unsigned seg_blocks = (unsigned)(seg_work_items(N, C) / 4);
     const int es = (x_dtype == VQHIP_BF16) ? 2 : 4;
     const bool vec = (D % 4 == 0) && (((uintptr_t)x) % (4 * es) == 0) && ((ldx * es) % (4 * es) == 0);
     const bool bf = (x_dtype == VQHIP_BF16);
+    if (sqerr_partial && !(vec && D <= 512 && !g.cosine && qsrc && ((uintptr_t)qsrc) % (4 * es) == 0))
+        VQ_FAIL(VQHIP_EINVAL, "ema_accumulate_sqerr: needs the Euclidean metric, D %% 4 == 0, D <= 512 and 16-byte aligned rows");
 #ifndef VQ_SEG_SLOW
     if (vec && D <= 512 && !g.cosine) {
-        if (bf) hipLaunchKernelGGL((vq_segsum_fast_kernel<true>), dim3(seg_blocks), dim3(256), 0, st, g);
-        else hipLaunchKernelGGL((vq_segsum_fast_kernel<false>), dim3(seg_blocks), dim3(256), 0, st, g);
+        if (sqerr_partial) {
+            if (bf) hipLaunchKernelGGL((vq_segsum_fast_kernel<true, true>), dim3(seg_blocks), dim3(256), 0, st, g);
+            else hipLaunchKernelGGL((vq_segsum_fast_kernel<false, true>), dim3(seg_blocks), dim3(256), 0, st, g);
+        } else {
+            if (bf) hipLaunchKernelGGL((vq_segsum_fast_kernel<true, false>), dim3(seg_blocks), dim3(256), 0, st, g);
+            else hipLaunchKernelGGL((vq_segsum_fast_kernel<false, false>), dim3(seg_blocks), dim3(256), 0, st, g);
+        }
         return launch_status("vq_ema_accumulate");
     }
 #endif
+    if (sqerr_partial) VQ_FAIL(VQHIP_EINVAL, "ema_accumulate_sqerr: built without the fast segment-sum kernel");
     if (bf && vec) hipLaunchKernelGGL((vq_segsum_kernel<true, true>), dim3(seg_blocks), dim3(256), 0, st, g);
     else if (bf) hipLaunchKernelGGL((vq_segsum_kernel<true, false>), dim3(seg_blocks), dim3(256), 0, st, g);
     else if (vec) hipLaunchKernelGGL((vq_segsum_kernel<false, true>), dim3(seg_blocks), dim3(256), 0, st, g);
     else hipLaunchKernelGGL((vq_segsum_kernel<false, false>), dim3(seg_blocks), dim3(256), 0, st, g);
     return launch_status("vq_ema_accumulate");
+}
+
+extern "C" int vqhip_ema_accumulate(const void *x, int x_dtype, int64_t N, int D, int64_t ldx,
+                                    const int64_t *idx, int64_t idx_stride, const float *rnorm, int metric,
+                                    const uint8_t *row_mask, int C,
+                                    float *count, float *embed_sum, void *workspace, size_t workspace_bytes,
+                                    void *stream)
+{
+    return ema_accumulate_impl(x, x_dtype, N, D, ldx, idx, idx_stride, rnorm, metric, row_mask, C, count, embed_sum, workspace,
+                               workspace_bytes, nullptr, nullptr, stream);
+}
+
+extern "C" int vqhip_ema_accumulate_sqerr(const void *x, int x_dtype, int64_t N, int D, int64_t ldx,
+                                          const int64_t *idx, int64_t idx_stride, const uint8_t *row_mask, int C,
+                                          float *count, float *embed_sum, void *workspace, size_t workspace_bytes,
+                                          const float *packed, const float *embed, double *sqerr_partial, void *stream)
+{
+    if (!sqerr_partial || !packed || !embed) VQ_FAIL(VQHIP_EINVAL, "ema_accumulate_sqerr: null pointer");
+    if (D < 1 || D > 512 || C <= 0) VQ_FAIL(VQHIP_EINVAL, "ema_accumulate_sqerr: bad size");
+    // the loss' q rows: what the search writes for this dtype -- fp32 rows: embed; bf16 rows: the packed codebook's bf16 copy
+    const void *qsrc = (x_dtype == VQHIP_BF16) ? (const void *)((const char *)packed + vq_packed_bf16_offset(C, D)) : (const void *)embed;
+    return ema_accumulate_impl(x, x_dtype, N, D, ldx, idx, idx_stride, nullptr, VQHIP_EUCLID, row_mask, C, count, embed_sum, workspace,
+                               workspace_bytes, qsrc, sqerr_partial, stream);
 }
 
 // ------------------------------------------------------------------------------------------------
