@@ -1406,17 +1406,19 @@ struct FinishArgs {
     const uint8_t *row_mask;
 };
 
-// one wave per listed row: idx, q row, sum (q - x)^2
+// one wave per listed row: idx, q row, sum (q - x)^2.  A row is a chain of dependent loads (list -> key -> code row): the kernel is
+// latency bound, so VQ_FINISH_WAVES waves per workgroup (8192 waves in the grid) keep the rows per wave at a handful
+#define VQ_FINISH_WAVES 16
 template <bool XBF16>
-__global__ void __launch_bounds__(256) vq_finish_listed_kernel(const FinishArgs a)
+__global__ void __launch_bounds__(VQ_FINISH_WAVES * 64) vq_finish_listed_kernel(const FinishArgs a)
 {
-    __shared__ double red[4];
+    __shared__ double red[VQ_FINISH_WAVES];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int n_full = a.row_count[0];
     const int n = n_full + a.row_count[1];
     double acc = 0.0;
-    for (int64_t v = (int64_t)blockIdx.x * 4 + wave; v < n; v += (int64_t)gridDim.x * 4) {
+    for (int64_t v = (int64_t)blockIdx.x * VQ_FINISH_WAVES + wave; v < n; v += (int64_t)gridDim.x * VQ_FINISH_WAVES) {
         const int64_t pos = v < n_full ? v : a.cap - 1 - (v - n_full);
         const int64_t row = a.row_list[pos];
         const int idx = (int)(unsigned)(a.keys[pos] & 0xffffffffull);
@@ -1450,7 +1452,12 @@ __global__ void __launch_bounds__(256) vq_finish_listed_kernel(const FinishArgs 
     if (a.sqerr_partial) {
         if (lane == 0) red[wave] = acc;
         __syncthreads();
-        if (threadIdx.x == 0) a.sqerr_partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+        if (threadIdx.x == 0) {
+            double t = 0.0;
+#pragma unroll
+            for (int w = 0; w < VQ_FINISH_WAVES; ++w) t += red[w];
+            a.sqerr_partial[blockIdx.x] = t;
+        }
     }
 }
 
@@ -1489,40 +1496,86 @@ struct PairArgs {
     unsigned long long *keys;
 };
 
+// The 16-byte pieces a lane streams from its OWN row and its two code rows would touch 64 different cache lines per wave
+// instruction and thrash the 16 KiB vector L1 (every piece re-fetched from L2: the first version ran at 30-38 us for ~30k rows).
+// So the wave loads 32-element pieces of its 64 rows COOPERATIVELY (8 lanes per fp32 piece: whole 128-byte lines), parks them
+// in LDS (row pitch + 16 bytes: conflict-free b128 reads), and every lane then reads its own row's piece back.  The next
+// piece's global loads are in flight while the current one is multiplied.  Arithmetic unchanged: one ascending FMA chain per code.
+#define VQ_PAIR_WAVES 2
 template <int DT, bool XBF16, int METRIC>
-__global__ void __launch_bounds__(256) vq_pair_kernel(const PairArgs a)
+__global__ void __launch_bounds__(VQ_PAIR_WAVES * 64) vq_pair_kernel(const PairArgs a)
 {
+    constexpr int KC = 32, NCH = DT / KC;
+    constexpr int EP = KC * 4 + 16;                          // LDS row pitch of a code piece (bytes)
+    constexpr int XP = (XBF16 ? KC * 2 : KC * 4) + 16;       // ... of a row piece
+    constexpr int NXL = XBF16 ? 4 : 8;                       // wave loads per row piece of the 64 rows
+    constexpr int XLPR = 64 / (64 / NXL) ;                   // lanes per row piece: 4 (bf16: 64 B) or 8 (fp32: 128 B)
+    constexpr int WAVE_B = 64 * (2 * EP + XP);
+    __shared__ __attribute__((aligned(16))) char smem[VQ_PAIR_WAVES * WAVE_B];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    char *se1 = smem + wave * WAVE_B, *se2 = se1 + 64 * EP, *sx = se2 + 64 * EP;
     const int n = a.row_count[1];
-    for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < n; p += (int64_t)gridDim.x * 256) {
+    for (int64_t base = ((int64_t)blockIdx.x * VQ_PAIR_WAVES + wave) * 64; base < n; base += (int64_t)gridDim.x * VQ_PAIR_WAVES * 64) {
+        const int64_t p = (base + lane < n) ? base + lane : (int64_t)n - 1;
         const int64_t pos = a.cap - 1 - p;
         const int64_t row = a.row_list[pos];
         const unsigned long long cand = a.keys[pos];
         const int c1 = (int)(unsigned)(cand & 0xffffffffull), c2 = (int)(unsigned)(cand >> 32);
-        const float *e1 = a.embed + (size_t)c1 * DT, *e2 = a.embed + (size_t)c2 * DT;
+        // cooperative pieces: wave load i of a code stream covers the rows 8 i .. 8 i + 7 (8 lanes x 16 bytes each)
+        const float *pe1[8], *pe2[8];
+        const char *px[NXL];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int r = i * 8 + (lane >> 3);
+            pe1[i] = a.embed + (size_t)__shfl(c1, r, 64) * DT + (lane & 7) * 4;
+            pe2[i] = a.embed + (size_t)__shfl(c2, r, 64) * DT + (lane & 7) * 4;
+        }
+#pragma unroll
+        for (int i = 0; i < NXL; ++i) {
+            const int r = i * (64 / XLPR) + lane / XLPR;
+            const int64_t rr = ((int64_t)__shfl((int)(row >> 32), r, 64) << 32) | (int64_t)(unsigned)__shfl((int)(row & 0xffffffffll), r, 64);
+            px[i] = (const char *)a.x + (rr * a.ldx) * (XBF16 ? 2 : 4) + (lane % XLPR) * 16;
+        }
+        f32x4 g1[8], g2[8], gx[NXL];
+        auto issue = [&](int k0) __attribute__((always_inline)) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { g1[i] = *(const f32x4 *)(pe1[i] + k0); g2[i] = *(const f32x4 *)(pe2[i] + k0); }
+#pragma unroll
+            for (int i = 0; i < NXL; ++i) gx[i] = *(const f32x4 *)(px[i] + (size_t)k0 * (XBF16 ? 2 : 4));
+        };
+        issue(0);
         float xy1 = 0.f, xy2 = 0.f;
         float ch[32];                      // ATen-order ||x||^2: 32 interleaved chains, combined below (aten_sumsq_seq's order)
 #pragma unroll
         for (int c = 0; c < 32; ++c) ch[c] = 0.f;
-#pragma unroll 2
-        for (int k0 = 0; k0 < DT; k0 += 32) {
+#pragma unroll 1
+        for (int k = 0; k < NCH; ++k) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                *(f32x4 *)(se1 + (i * 8 + (lane >> 3)) * EP + (lane & 7) * 16) = g1[i];
+                *(f32x4 *)(se2 + (i * 8 + (lane >> 3)) * EP + (lane & 7) * 16) = g2[i];
+            }
+#pragma unroll
+            for (int i = 0; i < NXL; ++i) *(f32x4 *)(sx + (i * (64 / XLPR) + lane / XLPR) * XP + (lane % XLPR) * 16) = gx[i];
+            if (k + 1 < NCH) issue((k + 1) * KC);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
             float xv[32];
             if (XBF16) {
-                const uint4 *px = (const uint4 *)((const unsigned short *)a.x + row * a.ldx + k0);
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const uint4 w = px[q];
+                    const uint4 w = *(const uint4 *)(sx + lane * XP + q * 16);
                     const unsigned ww[4] = {w.x, w.y, w.z, w.w};
 #pragma unroll
                     for (int r = 0; r < 4; ++r) { xv[8 * q + 2 * r] = __uint_as_float(ww[r] << 16); xv[8 * q + 2 * r + 1] = __uint_as_float(ww[r] & 0xffff0000u); }
                 }
             } else {
-                const f32x4 *px = (const f32x4 *)((const float *)a.x + row * a.ldx + k0);
 #pragma unroll
-                for (int q = 0; q < 8; ++q) { const f32x4 w = px[q]; xv[4 * q] = w.x; xv[4 * q + 1] = w.y; xv[4 * q + 2] = w.z; xv[4 * q + 3] = w.w; }
+                for (int q = 0; q < 8; ++q) { const f32x4 w = *(const f32x4 *)(sx + lane * XP + q * 16); xv[4 * q] = w.x; xv[4 * q + 1] = w.y; xv[4 * q + 2] = w.z; xv[4 * q + 3] = w.w; }
             }
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
-                const f32x4 u1 = *(const f32x4 *)(e1 + k0 + 4 * q), u2 = *(const f32x4 *)(e2 + k0 + 4 * q);
+                const f32x4 u1 = *(const f32x4 *)(se1 + lane * EP + q * 16), u2 = *(const f32x4 *)(se2 + lane * EP + q * 16);
                 xy1 = __builtin_fmaf(xv[4 * q + 0], u1.x, xy1); xy1 = __builtin_fmaf(xv[4 * q + 1], u1.y, xy1);
                 xy1 = __builtin_fmaf(xv[4 * q + 2], u1.z, xy1); xy1 = __builtin_fmaf(xv[4 * q + 3], u1.w, xy1);
                 xy2 = __builtin_fmaf(xv[4 * q + 0], u2.x, xy2); xy2 = __builtin_fmaf(xv[4 * q + 1], u2.y, xy2);
@@ -1532,6 +1585,8 @@ __global__ void __launch_bounds__(256) vq_pair_kernel(const PairArgs a)
 #pragma unroll
                 for (int c = 0; c < 32; ++c) ch[c] += xv[c] * xv[c];
             }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   // this piece has been read before the next one is parked
+            __builtin_amdgcn_wave_barrier();
         }
         int win;
         if (METRIC == 0) {
@@ -1546,14 +1601,14 @@ __global__ void __launch_bounds__(256) vq_pair_kernel(const PairArgs a)
         } else {
             win = (xy2 > xy1 || (xy2 == xy1 && c2 < c1)) ? c2 : c1;
         }
-        a.keys[pos] = (unsigned long long)(unsigned)win;
+        if (base + lane < n) a.keys[pos] = (unsigned long long)(unsigned)win;
     }
 }
 
 template <int DT>
 static int dispatch_pair(const PairArgs &a, int x_dtype, int metric, unsigned blocks, hipStream_t st)
 {
-#define VQ_PAIR(B, M) hipLaunchKernelGGL((vq_pair_kernel<DT, B, M>), dim3(blocks), dim3(256), 0, st, a)
+#define VQ_PAIR(B, M) hipLaunchKernelGGL((vq_pair_kernel<DT, B, M>), dim3(blocks), dim3(VQ_PAIR_WAVES * 64), 0, st, a)
     if (metric == VQHIP_EUCLID) { if (x_dtype == VQHIP_BF16) VQ_PAIR(true, 0); else VQ_PAIR(false, 0); }
     else                        { if (x_dtype == VQHIP_BF16) VQ_PAIR(true, 1); else VQ_PAIR(false, 1); }
 #undef VQ_PAIR
@@ -1587,8 +1642,8 @@ int vq_assign_listed(const void *x, int x_dtype, int metric, int64_t N, int D, i
         PairArgs pa;
         pa.x = x; pa.ldx = ldx; pa.embed = embed; pa.packed = packed; pa.D = D;
         pa.row_list = row_list; pa.row_count = row_count; pa.cap = N; pa.keys = keys;
-        const int64_t pb = (N + 255) / 256;
-        const unsigned blocks = (unsigned)(pb < 512 ? pb : 512);
+        const int64_t pb = (N + VQ_PAIR_WAVES * 64 - 1) / (VQ_PAIR_WAVES * 64);
+        const unsigned blocks = (unsigned)(pb < 1024 ? pb : 1024);
         switch (pick_dt(D)) {
             case 32: rc = dispatch_pair<32>(pa, x_dtype, metric, blocks, st); break;
             case 64: rc = dispatch_pair<64>(pa, x_dtype, metric, blocks, st); break;
@@ -1604,9 +1659,9 @@ int vq_assign_listed(const void *x, int x_dtype, int metric, int64_t N, int D, i
     f.D = D; f.row_list = row_list; f.row_count = row_count; f.cap = N; f.keys = keys;
     f.idx_out = idx_out; f.q_out = q_out; f.ldq = ldq; f.resid_out = resid_out; f.ldr = ldr; f.sqerr_partial = sqerr_partial; f.row_mask = row_mask;
     if (x_dtype == VQHIP_BF16)
-        hipLaunchKernelGGL(vq_finish_listed_kernel<true>, dim3(VQ_FINISH_BLOCKS), dim3(256), 0, st, f);
+        hipLaunchKernelGGL(vq_finish_listed_kernel<true>, dim3(VQ_FINISH_BLOCKS), dim3(VQ_FINISH_WAVES * 64), 0, st, f);
     else
-        hipLaunchKernelGGL(vq_finish_listed_kernel<false>, dim3(VQ_FINISH_BLOCKS), dim3(256), 0, st, f);
+        hipLaunchKernelGGL(vq_finish_listed_kernel<false>, dim3(VQ_FINISH_BLOCKS), dim3(VQ_FINISH_WAVES * 64), 0, st, f);
     return launch_status("vq_finish_listed_kernel");
 }
 
