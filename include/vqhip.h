@@ -164,9 +164,9 @@ int vqhip_ema_accumulate(const void *x, int x_dtype, int64_t N, int D, int64_t l
 /* The same pass, which reads every unmasked row next to its code, also summing the commitment loss' squared error
  * (reference: F.mse_loss(quantize.detach(), x), vector_quantize_pytorch.py:1327) -- so that the search does not have to re-read
  * x for it.  sqerr_partial[i], i < vqhip_ema_sqerr_partials(N, C): sum over the rows of work item i of ||q - x||^2 with q the
- * row's code in x's dtype (fp32 rows: embed; bf16 rows: the bf16 copy inside `packed`) -- per 4 elements
- * ((d0^2 + d1^2) + d2^2) + d3^2 in fp32, then in double: what vqhip_assign / vqhip_assign_screened sum into their own
- * sqerr_partial for the same rows.  Euclidean metric, D % 4 == 0, D <= 512, 16-byte aligned rows (VQHIP_EINVAL otherwise). */
+ * row's code in x's dtype (fp32 rows: embed; bf16 rows: the bf16 copy inside `packed`) -- fp32 FMA chains over a few rows'
+ * elements, then double: equal to what vqhip_assign / vqhip_assign_screened sum into their own sqerr_partial for the same rows
+ * to ~1e-8 relative.  Euclidean metric, D % 4 == 0, D <= 512, 16-byte aligned rows (VQHIP_EINVAL otherwise). */
 int64_t vqhip_ema_sqerr_partials(int64_t N, int C);
 int vqhip_ema_accumulate_sqerr(const void *x, int x_dtype, int64_t N, int D, int64_t ldx,
                                const int64_t *idx, int64_t idx_stride, const uint8_t *row_mask, int C,
@@ -219,6 +219,14 @@ int vqhip_kmeans_update(float *means, const float *embed_sum, const float *count
  * shards' winners by (score, index) after a screened search that does not produce scores.  D % 4 == 0, D <= 512. */
 int vqhip_score_indices(const void *x, int x_dtype, int64_t N, int D, int64_t ldx, const float *packed, const float *embed,
                         int C, int metric, const int64_t *idx, float *out, void *stream);
+
+/* A separate codebook per row (QINCo's implicit neural codebook; reference: Codebook.forward(codebook_transform_fn=),
+ * vector_quantize_pytorch.py:729-738: dist = -F.pairwise_distance(x[..., None, :], transformed) or the cosine einsum, then argmax).
+ * x [N, D] fp32 at row stride ldx, codes [N, C, D] fp32 contiguous: idx_out[n] = argmin_c ||x_n - codes[n, c] + 1e-6||_2
+ * (VQHIP_EUCLID) or argmax_c x_n . codes[n, c] (VQHIP_COSINE_PRENORM: both sides already unit-norm); first extremum in
+ * ascending c.  Streams N * C * D floats once. */
+int vqhip_assign_rowwise(const float *x, int64_t N, int D, int64_t ldx, const float *codes, int C, int metric,
+                         int64_t *idx_out, void *stream);
 
 int vqhip_row_sumsq(const void *x, int x_dtype, int64_t N, int D, int64_t ldx, float *out, void *stream);
 

@@ -54,8 +54,13 @@ def inject(mod):
             m.replace_sample_fn = first_rows
 
 
+ONLY = set(sys.argv[1:])       # python tests/golden/make_golden.py [name ...]: (re)generate just these fixtures
+
+
 def run_case(name, cls, kwargs, xs, *, train=True, fwd_kwargs=None, grad=False, unit_codebook=False, deterministic_sampling=False,
              build=None, param_grad=False):
+    if ONLY and name not in ONLY:
+        return
     torch.manual_seed(1234)
     mod = cls(**kwargs) if build is None else build()
     if unit_codebook:
@@ -218,3 +223,8 @@ if __name__ == "__main__":
     run_case("grvq", GroupedResidualVQ, dict(dim=128, groups=2, num_quantizers=3, codebook_size=64), [randn(2, 100, 128, seed=22)], unit_codebook=True)
     run_case("grvq_kmeans", GroupedResidualVQ, dict(dim=64, groups=2, num_quantizers=2, codebook_size=32, kmeans_init=True, kmeans_iters=3),
              [randn(1, 1024, 64, seed=23)], deterministic_sampling=True)
+    # QINCo (rvq.py:107-162, 288-289, 460-499): implicit neural codebooks -- every quantizer after the first searches a codebook
+    # that an MLP derives per row from the sum so far; learnable codebooks, gradients to the codes, the MLPs and the input
+    qinco = dict(dim=32, num_quantizers=3, codebook_size=64, implicit_neural_codebook=True, mlp_kwargs=dict(depth=2))
+    run_case("rvq_qinco", ResidualVQ, qinco, [randn(2, 50, 32, seed=100)], grad=True, param_grad=True, unit_codebook=True)
+    run_case("rvq_qinco_eval", ResidualVQ, qinco, [randn(2, 40, 32, seed=101)], train=False, unit_codebook=True)

@@ -823,3 +823,37 @@ def test_commit_loss_from_the_statistics_pass_equals_the_search_kernels(dev, mon
         assert torch.allclose(la, lb, rtol=2e-6, atol=0)
         assert torch.allclose(a._codebook.embed, b._codebook.embed, rtol=1e-5, atol=1e-7)    # (embed_sum: fp32 atomics over a code's row chunks)
         b.load_state_dict(a.state_dict())                                                     # same start for the next step
+
+
+def test_qinco_implicit_neural_codebook_round_trip(dev):
+    """ResidualVQ(implicit_neural_codebook=True) (rvq.py:107-162, 460-499): same parameter names as the reference (goldens rvq_qinco*
+    pin values and gradients); here: decode from indices reproduces the forward's output, dropped quantizers decode to zero,
+    the MLPs and the codebooks receive gradients, a VectorQuantize with an EMA codebook accepts a transform and still updates."""
+    from vector_quantize_pytorch_amd import ResidualVQ, VectorQuantize
+    torch.manual_seed(0)
+    m = ResidualVQ(dim=32, num_quantizers=3, codebook_size=48, implicit_neural_codebook=True, mlp_kwargs=dict(depth=1)).to(dev)
+    assert sorted(k for k in m.state_dict() if k.startswith("mlps.0.")) == [
+        "mlps.0.layers.0.0.bias", "mlps.0.layers.0.0.weight", "mlps.0.layers.0.2.bias", "mlps.0.layers.0.2.weight",
+        "mlps.0.proj_in.bias", "mlps.0.proj_in.weight"]
+    x = torch.randn(2, 70, 32, device=dev, requires_grad=True)
+    q, idx, loss = m(x)
+    assert q.shape == x.shape and idx.shape == (2, 70, 3) and loss.shape == (3,)
+    (q.sum() + loss.sum()).backward()
+    assert x.grad is not None and all(p.grad is not None for p in m.parameters())
+    m.eval()
+    with torch.no_grad():
+        q2, idx2, _, codes = m(x.detach(), return_all_codes=True)
+        assert torch.allclose(codes.sum(0), q2, rtol=1e-5, atol=1e-6)
+        assert torch.allclose(m.get_output_from_indices(idx2), q2, rtol=1e-5, atol=1e-6)
+        dropped = idx2.clone(); dropped[..., 2] = -1
+        c3 = m.get_codes_from_indices(dropped)
+        assert (c3[2] == 0).all() and torch.allclose(c3[:2], codes[:2], rtol=1e-5, atol=1e-6)
+    # a plain EMA VectorQuantize with a transform: the base codebook still gets its EMA update from the chosen indices
+    vq = VectorQuantize(dim=16, codebook_size=32).to(dev).train()
+    before = vq._codebook.embed.clone()
+    fn = lambda e: e[:, None, None].expand(1, 2, 40, 32, 16) * 1.5
+    xq = torch.randn(2, 40, 16, device=dev)
+    qv, iv, _ = vq(xq, codebook_transform_fn=fn)
+    want = (-torch.nn.functional.pairwise_distance(xq[:, :, None, :], (before * 1.5)[0][None, None])).argmax(-1)
+    assert (iv != want).sum().item() <= 1 and not torch.equal(vq._codebook.embed, before)
+    assert torch.allclose(qv, (before[0] * 1.5)[iv], rtol=1e-6, atol=1e-6)

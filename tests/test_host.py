@@ -97,7 +97,9 @@ def test_unsupported_options_fail_loudly_and_cpu_is_refused():
         with pytest.raises(NotImplementedError):
             VectorQuantize(dim=32, codebook_size=16, **kw)
     with pytest.raises(NotImplementedError):
-        ResidualVQ(dim=32, num_quantizers=2, codebook_size=16, implicit_neural_codebook=True)
+        ResidualVQ(dim=32, num_quantizers=2, codebook_size=16, implicit_neural_codebook=True, beam_size=2)
+    qinco = ResidualVQ(dim=32, num_quantizers=3, codebook_size=16, implicit_neural_codebook=True, mlp_kwargs=dict(depth=1))
+    assert len(qinco.mlps) == 2 and "mlps.1.proj_in.weight" in qinco.state_dict() and qinco.layers[0].learnable_codebook   # rvq.py:207-211, 288-289
     with pytest.raises(AssertionError):
         ResidualVQ(dim=32, num_quantizers=2, codebook_size=16, heads=2)
     for kw in (dict(learnable_codebook=True), dict(learnable_codebook=True, ema_update=False, use_cosine_sim=True),
@@ -109,8 +111,10 @@ def test_unsupported_options_fail_loudly_and_cpu_is_refused():
     vq = VectorQuantize(dim=32, codebook_size=16)
     with pytest.raises(VQHipError, match="no CPU fallback"):
         vq(torch.randn(1, 4, 32))
-    with pytest.raises(NotImplementedError):
-        vq(torch.randn(1, 4, 32), codebook_transform_fn=lambda e: e)
+    with pytest.raises(NotImplementedError):                    # a per-row codebook together with an option that reads the score row
+        vq(torch.randn(1, 4, 32), codebook_transform_fn=lambda e: e, topk=2)
+    with pytest.raises(VQHipError, match="no CPU fallback"):
+        vq(torch.randn(1, 4, 32), codebook_transform_fn=lambda e: e[:, None, None].expand(1, 1, 4, 16, 32))
 
 
 def test_product_never_imports_the_oracle():

@@ -76,6 +76,8 @@ def lib():
     L.vqhip_ema_finalize.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, f32, f32, i32, i32, i32, vp, vp]
     L.vqhip_decode_sum.argtypes = [vp, i64, i32, vp, i64, i32, i32, vp, i32, i64, vp]
     L.vqhip_row_sumsq.argtypes = [vp, i32, i64, i32, i64, vp, vp]
+    L.vqhip_assign_rowwise.argtypes = [vp, i64, i32, i64, vp, i32, i32, vp, vp]
+    L.vqhip_assign_rowwise.restype = i32
     L.vqhip_score_indices.argtypes = [vp, i32, i64, i32, i64, vp, vp, i32, i32, vp, vp, vp]
     L.vqhip_score_indices.restype = i32
     L.vqhip_topk.argtypes = [vp, i32, i64, i32, i64, vp, i32, i32, i32, vp, vp, vp]
@@ -85,7 +87,7 @@ def lib():
     L.vqhip_kmeans_update.argtypes = [vp, vp, vp, i32, i32, i32, vp]
     L.vqhip_kmeans_update.restype = i32
     for name in ("vqhip_pack_codebook", "vqhip_assign", "vqhip_reduce_partials", "vqhip_ema_accumulate",
-                 "vqhip_ema_finalize", "vqhip_decode_sum", "vqhip_row_sumsq", "vqhip_score_indices", "vqhip_topk", "vqhip_expire_scatter", "vqhip_kmeans_update", "vqhip_route_fwd", "vqhip_route_bwd"):
+                 "vqhip_ema_finalize", "vqhip_decode_sum", "vqhip_row_sumsq", "vqhip_assign_rowwise", "vqhip_score_indices", "vqhip_topk", "vqhip_expire_scatter", "vqhip_kmeans_update", "vqhip_route_fwd", "vqhip_route_bwd"):
         getattr(L, name).restype = i32
     _lib = L
     return L
@@ -94,7 +96,7 @@ def lib():
 EXPORTS = ("vqhip_version", "vqhip_last_error", "vqhip_packed_bytes", "vqhip_pack_codebook",
            "vqhip_assign_blocks", "vqhip_assign", "vqhip_screen_supported", "vqhip_screen_workspace_bytes",
            "vqhip_screen_blocks", "vqhip_screen_partials", "vqhip_assign_screened", "vqhip_l2norm_rows", "vqhip_scores", "vqhip_rvq_forward", "vqhip_reduce_partials", "vqhip_ema_workspace_bytes", "vqhip_ema_accumulate", "vqhip_ema_sqerr_partials", "vqhip_ema_accumulate_sqerr",
-           "vqhip_ema_finalize", "vqhip_decode_sum", "vqhip_row_sumsq", "vqhip_score_indices", "vqhip_topk", "vqhip_expire_scatter", "vqhip_kmeans_update", "vqhip_route_fwd", "vqhip_route_bwd")
+           "vqhip_ema_finalize", "vqhip_decode_sum", "vqhip_row_sumsq", "vqhip_assign_rowwise", "vqhip_score_indices", "vqhip_topk", "vqhip_expire_scatter", "vqhip_kmeans_update", "vqhip_route_fwd", "vqhip_route_bwd")
 
 
 def _check(rc, what):
@@ -466,6 +468,21 @@ def ema_finalize(cluster_size, embed_avg, embed, count, embed_sum, *, decay, eps
     _check(lib().vqhip_ema_finalize(_ptr(cluster_size), _ptr(embed_avg), _ptr(embed), _ptr(count), _ptr(embed_sum),
                                     _ptr(weight), C, D, omd, float(eps), int(cosine), int(do_lerp),
                                     int(do_update_ema), _ptr(denom_ws), _stream()), "vqhip_ema_finalize")
+
+
+@_on_device
+def assign_rowwise(x: torch.Tensor, codes: torch.Tensor, cosine=False) -> torch.Tensor:
+    """x [..., D], codes [..., C, D] (one codebook per row, QINCo) -> idx [...]: nearest code of each row's own codebook
+    (F.pairwise_distance arithmetic incl. its eps; cosine: dot products of unit-norm rows and codes)."""
+    _need_gpu(x, codes)
+    lead, D, C = x.shape[:-1], x.shape[-1], codes.shape[-2]
+    assert codes.shape[:-2] == lead and codes.shape[-1] == D
+    xf = x.detach().reshape(-1, D).float().contiguous()
+    cf = codes.detach().reshape(-1, C, D).float().contiguous()
+    idx = torch.empty(xf.shape[0], dtype=torch.int64, device=x.device)
+    _check(lib().vqhip_assign_rowwise(_ptr(xf), xf.shape[0], D, D, _ptr(cf), C, COSINE_PRENORM if cosine else EUCLID, _ptr(idx), _stream()),
+           "vqhip_assign_rowwise")
+    return idx.reshape(lead)
 
 
 @_on_device

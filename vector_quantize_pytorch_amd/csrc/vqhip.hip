@@ -1085,6 +1085,86 @@ extern "C" int vqhip_score_indices(const void *x, int x_dtype, int64_t N, int D,
     return launch_status("vq_score_idx_kernel");
 }
 
+// ------------------------------------------------------------------------------------------------
+// A separate codebook PER ROW (QINCo's implicit neural codebook: the reference hands Codebook.forward a codebook_transform_fn,
+// vqp.py:729-738, whose output is [h, b, n, c, d]): idx[n] = argmin_c ||x_n - e_{n,c} + 1e-6||_2 (F.pairwise_distance's eps)
+// or, for the cosine metric, argmax_c x_n . e_{n,c}; first extremum in ascending c, like ATen's argmax of -dist.  There is no
+// codebook to keep resident: the kernel streams N * C * D floats once (HBM bound).  One wave per row, 4 codes per step so that
+// the cross-lane sums of one step overlap; lanes take the features in 4-element slices (D % 4 == 0) or one by one.
+// ------------------------------------------------------------------------------------------------
+template <int METRIC, bool VEC>
+__global__ void __launch_bounds__(256) vq_rowwise_kernel(const float *x, int64_t N, int D, int64_t ldx, const float *codes, int C, int64_t *idx_out)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t n = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= N) return;
+    const float *xr = x + n * ldx;
+    const float *er = codes + (size_t)n * C * D;
+    float best = METRIC == 0 ? INFINITY : -INFINITY;
+    int bi = 0;
+    for (int c0 = 0; c0 < C; c0 += 4) {
+        float s[4] = {0.f, 0.f, 0.f, 0.f};
+        if (VEC) {
+            for (int d = lane * 4; d < D; d += 256) {
+                const f32x4 xv = *(const f32x4 *)(xr + d);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const f32x4 ev = *(const f32x4 *)(er + (size_t)min(c0 + u, C - 1) * D + d);
+                    if (METRIC == 0) {
+                        const float t0 = (xv.x - ev.x) + 1e-6f, t1 = (xv.y - ev.y) + 1e-6f, t2 = (xv.z - ev.z) + 1e-6f, t3 = (xv.w - ev.w) + 1e-6f;
+                        s[u] = __builtin_fmaf(t0, t0, s[u]); s[u] = __builtin_fmaf(t1, t1, s[u]);
+                        s[u] = __builtin_fmaf(t2, t2, s[u]); s[u] = __builtin_fmaf(t3, t3, s[u]);
+                    } else {
+                        s[u] = __builtin_fmaf(xv.x, ev.x, s[u]); s[u] = __builtin_fmaf(xv.y, ev.y, s[u]);
+                        s[u] = __builtin_fmaf(xv.z, ev.z, s[u]); s[u] = __builtin_fmaf(xv.w, ev.w, s[u]);
+                    }
+                }
+            }
+        } else {
+            for (int d = lane; d < D; d += 64) {
+                const float xv = xr[d];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float ev = er[(size_t)min(c0 + u, C - 1) * D + d];
+                    if (METRIC == 0) { const float t = (xv - ev) + 1e-6f; s[u] = __builtin_fmaf(t, t, s[u]); }
+                    else s[u] = __builtin_fmaf(xv, ev, s[u]);
+                }
+            }
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) s[u] += __shfl_xor(s[u], o, 64);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (c0 + u < C) {
+                const float v = METRIC == 0 ? sqrtf(s[u]) : s[u];
+                if (METRIC == 0 ? (v < best) : (v > best)) { best = v; bi = c0 + u; }
+            }
+        }
+    }
+    if (lane == 0) idx_out[n] = (int64_t)bi;
+}
+
+extern "C" int vqhip_assign_rowwise(const float *x, int64_t N, int D, int64_t ldx, const float *codes, int C, int metric,
+                                    int64_t *idx_out, void *stream)
+{
+    if (!x || !codes || !idx_out || N < 0 || C <= 0 || D < 1) VQ_FAIL(VQHIP_EINVAL, "assign_rowwise: bad argument");
+    if (metric != VQHIP_EUCLID && metric != VQHIP_COSINE_PRENORM) VQ_FAIL(VQHIP_EINVAL, "assign_rowwise: metric must be VQHIP_EUCLID or VQHIP_COSINE_PRENORM");
+    if (N == 0) return 0;
+    const bool vec = (D % 4 == 0) && (ldx % 4 == 0) && (((uintptr_t)x) % 16 == 0) && (((uintptr_t)codes) % 16 == 0);
+    const unsigned blocks = (unsigned)((N + 3) / 4);
+    hipStream_t st = (hipStream_t)stream;
+    if (metric == VQHIP_EUCLID) {
+        if (vec) hipLaunchKernelGGL((vq_rowwise_kernel<0, true>), dim3(blocks), dim3(256), 0, st, x, N, D, ldx, codes, C, idx_out);
+        else hipLaunchKernelGGL((vq_rowwise_kernel<0, false>), dim3(blocks), dim3(256), 0, st, x, N, D, ldx, codes, C, idx_out);
+    } else {
+        if (vec) hipLaunchKernelGGL((vq_rowwise_kernel<1, true>), dim3(blocks), dim3(256), 0, st, x, N, D, ldx, codes, C, idx_out);
+        else hipLaunchKernelGGL((vq_rowwise_kernel<1, false>), dim3(blocks), dim3(256), 0, st, x, N, D, ldx, codes, C, idx_out);
+    }
+    return launch_status("vq_rowwise_kernel");
+}
+
 extern "C" int vqhip_row_sumsq(const void *x, int x_dtype, int64_t N, int D, int64_t ldx, float *out, void *stream)
 {
     if (!x || !out || N < 0) VQ_FAIL(VQHIP_EINVAL, "row_sumsq: bad argument");
@@ -2335,8 +2415,9 @@ __global__ void __launch_bounds__(256) vq_segsum_kernel(const SegArgs a)
 // Common case (D <= 256, vector-aligned rows, no per-row normalisation): the rows stay packed in their load registers
 // (2 VGPRs per bf16 row, 4 per fp32 row), so 16 rows are in flight per wave instead of 8.
 // SQ: this pass reads every (unmasked) row next to its code, which is all the commitment loss needs (F.mse_loss(quantize, x),
-// vqp.py:1327): the wave also sums ||q_c - x||^2 over its rows -- per 4 elements ((d0^2 + d1^2) + d2^2) + d3^2 in fp32, then in
-// double, the arithmetic of the search kernels' own loss partials -- so the search does not have to re-read x for it.
+// vqp.py:1327): the wave also sums ||q_c - x||^2 over its rows -- an fp32 FMA chain over the batch's elements of a lane, then in
+// double per batch of rows in flight (relative error of the total ~1e-8; the loss is held to 1e-5) -- so the search does not have to
+// re-read x for it.
 template <bool XBF16, bool SQ>
 __global__ void __launch_bounds__(256) vq_segsum_fast_kernel(const SegArgs a)
 {
@@ -2388,6 +2469,7 @@ __global__ void __launch_bounds__(256) vq_segsum_fast_kernel(const SegArgs a)
 #pragma unroll
                 for (int u = 0; u < U; ++u)
                     if (act) v[u] = *(const uint2 *)((const unsigned short *)a.x + (int64_t)rows[u] * a.ldx + d);
+                float bsq = 0.f;            // this batch's squared error in fp32 (64 terms), folded into the double once per batch
 #pragma unroll
                 for (int u = 0; u < U; ++u)
                     if (act && r + u < end) {
@@ -2396,23 +2478,28 @@ __global__ void __launch_bounds__(256) vq_segsum_fast_kernel(const SegArgs a)
                         acc[0] += x0; acc[1] += x1; acc[2] += x2; acc[3] += x3;
                         if (SQ) {
                             const float e0 = g[0] - x0, e1 = g[1] - x1, e2 = g[2] - x2, e3 = g[3] - x3;
-                            sq += (double)(((e0 * e0 + e1 * e1) + e2 * e2) + e3 * e3);
+                            bsq = __builtin_fmaf(e0, e0, bsq); bsq = __builtin_fmaf(e1, e1, bsq);
+                            bsq = __builtin_fmaf(e2, e2, bsq); bsq = __builtin_fmaf(e3, e3, bsq);
                         }
                     }
+                if (SQ) sq += (double)bsq;
             } else {
                 f32x4 v[U];
 #pragma unroll
                 for (int u = 0; u < U; ++u)
                     if (act) v[u] = *(const f32x4 *)((const float *)a.x + (int64_t)rows[u] * a.ldx + d);
+                float bsq = 0.f;
 #pragma unroll
                 for (int u = 0; u < U; ++u)
                     if (act && r + u < end) {
                         acc[0] += v[u].x; acc[1] += v[u].y; acc[2] += v[u].z; acc[3] += v[u].w;
                         if (SQ) {
                             const float e0 = g[0] - v[u].x, e1 = g[1] - v[u].y, e2 = g[2] - v[u].z, e3 = g[3] - v[u].w;
-                            sq += (double)(((e0 * e0 + e1 * e1) + e2 * e2) + e3 * e3);
+                            bsq = __builtin_fmaf(e0, e0, bsq); bsq = __builtin_fmaf(e1, e1, bsq);
+                            bsq = __builtin_fmaf(e2, e2, bsq); bsq = __builtin_fmaf(e3, e3, bsq);
                         }
                     }
+                if (SQ) sq += (double)bsq;
             }
         }
         if (act)

@@ -33,6 +33,34 @@ def _draw_seed(device, need_value: bool, max_size=10_000):
     return int(r.item())
 
 
+class MLP(nn.Module):
+    """QINCo's code transform (rvq.py:107-162; Huijben et al., arXiv 2401.14732): every code of a quantizer's codebook is
+    rewritten as a function of the reconstruction so far.  codes [c, d] (or [h, c, d]), condition [b, n, d] (or [b, d]) ->
+    [b, n, c, d] ([h, b, n, c, d]).  Same parameter names as the reference (`proj_in`, `layers.{i}.0/2`): state_dicts load.
+    Plain PyTorch: this is the user-side network, not the search; the search over its output is vqhip_assign_rowwise."""
+
+    def __init__(self, dim, dim_hidden=None, depth=4, l2norm_output=False):
+        super().__init__()
+        dim_hidden = dim if dim_hidden is None else dim_hidden
+        self.proj_in = nn.Linear(2 * dim, dim)
+        self.layers = nn.ModuleList([nn.Sequential(nn.Linear(dim, dim_hidden), nn.SiLU(), nn.Linear(dim_hidden, dim)) for _ in range(depth)])
+        self.l2norm_output = l2norm_output
+
+    def forward(self, codes, *, condition):
+        one_headed = codes.ndim == 2
+        if one_headed:
+            codes = codes[None]
+        cond = condition.reshape(condition.shape[0], -1, condition.shape[-1])                  # [b, n, d] ([b, d] -> n = 1)
+        h, c, b, n = codes.shape[0], codes.shape[-2], cond.shape[0], cond.shape[1]
+        both = torch.cat((cond[None, :, :, None, :].expand(h, b, n, c, -1), codes[:, None, None].expand(h, b, n, c, -1)), dim=-1)
+        x = self.proj_in(both)
+        for layer in self.layers:
+            x = layer(x) + x
+        if self.l2norm_output:
+            x = torch.nn.functional.normalize(x, dim=-1)
+        return x[0] if one_headed else x
+
+
 class ResidualVQ(nn.Module):
     concurrent_stats = True       # fused loop: stage statistics on a side HIP stream beside the later searches (class attribute)
 
@@ -61,10 +89,9 @@ class ResidualVQ(nn.Module):
         super().__init__()
         assert heads == 1, 'residual vq is not compatible with multi-headed codes'
         assert num_quantizers is not None or isinstance(codebook_size, tuple)
-        if implicit_neural_codebook:
-            raise NotImplementedError("implicit_neural_codebook (QINCo: a separate codebook per row) is outside the MI355X hot path "
-                                      "(SURVEY.md §2.1, §8f); no fallback is provided")
         assert not (eval_beam_size is not None and beam_size is None)
+        if implicit_neural_codebook and (beam_size is not None):
+            raise NotImplementedError("implicit_neural_codebook with beam search")
 
         codebook_dim = dim if codebook_dim is None else codebook_dim
         self.codebook_dim = codebook_dim
@@ -73,7 +100,9 @@ class ResidualVQ(nn.Module):
         self.project_out = nn.Linear(codebook_dim, dim) if requires_projection else nn.Identity()
         self.has_projections = requires_projection
         self.accept_image_fmap = accept_image_fmap
-        self.implicit_neural_codebook = False
+        self.implicit_neural_codebook = implicit_neural_codebook
+        if implicit_neural_codebook:                          # rvq.py:207-211
+            vq_kwargs.update(learnable_codebook=True, ema_update=False)
         self.diveq = diveq
         if diveq:                                             # rvq.py:226-232: DiVeQ learns the codebook through the reparametrised output
             vq_kwargs.update(ema_update=False, learnable_codebook=True, route_gradients_to_input=False, commitment_weight=0.)
@@ -105,7 +134,11 @@ class ResidualVQ(nn.Module):
         weights = [1.] * num_quantizers if beam_score_quantizer_weights is None else beam_score_quantizer_weights
         assert len(weights) == num_quantizers
         self.register_buffer('beam_score_weights', torch.tensor(weights), persistent=False)
-        self.mlps = (None,) * (num_quantizers - 1)
+        if implicit_neural_codebook:                          # rvq.py:288-289: one transform per quantizer after the first
+            self.mlps = nn.ModuleList([MLP(dim=codebook_dim, l2norm_output=self.layers[0].use_cosine_sim, **mlp_kwargs)
+                                       for _ in range(num_quantizers - 1)])
+        else:
+            self.mlps = (None,) * (num_quantizers - 1)
 
         self.shared_codebook = shared_codebook
         if shared_codebook:                                   # rvq.py:300-306: every layer aliases layer 0's codebook
@@ -130,6 +163,21 @@ class ResidualVQ(nn.Module):
             assert self.quantize_dropout > 0., 'quantize dropout must be greater than 0 if you wish to reconstruct from a signal with less fine quantizations'
             indices = torch.nn.functional.pad(indices, (0, self.num_quantizers - qdim), value=-1)
         cbs = self.codebooks
+        if self.implicit_neural_codebook:                     # rvq.py:347-366: layer by layer, every transform sees the sum so far
+            out, so_far = [], 0.
+            for q, mlp in enumerate((None, *self.mlps)):
+                ind = indices[..., q]
+                safe = ind.clamp(min=0)
+                if mlp is None:
+                    codes = cbs[q][safe]
+                else:
+                    te = mlp(cbs[q], condition=so_far)                                        # [b, n, c, d]
+                    te = te.reshape(*ind.shape, te.shape[-2], te.shape[-1])
+                    codes = te.gather(-2, safe[..., None, None].expand(*ind.shape, 1, te.shape[-1]))[..., 0, :]
+                out.append(codes)
+                so_far = so_far + codes                       # (the reference adds the un-masked code as well, rvq.py:364)
+            allc = torch.stack(out)
+            return allc.masked_fill((indices == -1).movedim(-1, 0)[..., None], 0.)
         out = [L.decode_sum(indices[..., q:q + 1].contiguous(), cbs[q].contiguous()) for q in range(self.num_quantizers)]
         return torch.stack(out)
 
@@ -138,7 +186,7 @@ class ResidualVQ(nn.Module):
         if qdim < self.num_quantizers:
             assert self.quantize_dropout > 0., 'quantize dropout must be greater than 0 if you wish to reconstruct from a signal with less fine quantizations'
             indices = torch.nn.functional.pad(indices, (0, self.num_quantizers - qdim), value=-1)
-        if self.uniform_codebook_size:
+        if self.uniform_codebook_size and not self.implicit_neural_codebook:
             cb = self.layers[0]._codebook.embed[0] if self.shared_codebook else self.codebooks.contiguous()
             summed = L.decode_sum(indices.contiguous(), cb.contiguous())           # one fused gather + sum over q
         else:
@@ -372,6 +420,7 @@ class ResidualVQ(nn.Module):
         all_idx, all_loss, stage_inputs = [], [], []
         idx_shape = x.shape[:-1] if not self.accept_image_fmap else (x.shape[0], *x.shape[2:])
 
+        transforms = (None, *self.mlps)                             # rvq.py:460-465
         for qi, vq in enumerate(self.layers):                      # rvq.py:469-568
             if drop_at is not None and qi > drop_at:
                 all_idx.append(torch.full(idx_shape, -1, device=x.device, dtype=torch.long))
@@ -379,8 +428,11 @@ class ResidualVQ(nn.Module):
                 continue
             if self.shared_codebook and self.training:
                 stage_inputs.append(residual.detach())
+            fn = None
+            if transforms[qi] is not None:                          # QINCo: this stage's codes are a function of the sum so far
+                fn = (lambda codes, _m=transforms[qi], _c=quantized_out: _m(codes, condition=_c))
             quantized, ind, loss = vq(residual, mask=mask, sample_codebook_temp=sample_codebook_temp,
-                                      freeze_codebook=freeze_codebook)
+                                      freeze_codebook=freeze_codebook, codebook_transform_fn=fn)
             step = quantized.detach() if self.quant_grad_frac <= 0 else (
                 self.quant_grad_frac * quantized + (1. - self.quant_grad_frac) * quantized.detach())
             residual = residual - step

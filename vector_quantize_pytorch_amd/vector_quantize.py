@@ -350,7 +350,7 @@ class VectorQuantize(nn.Module):
     # The nearest-code search still runs on the HIP kernel (no gradient flows through an argmin); what changes is
     # that `quantize` is a differentiable gather of the (possibly bridged) codebook parameter and that the losses
     # are built from autograd ops.  Reference: vqp.py:710-717 (learnable embed / bridge), :1186-1237.
-    def _forward_general(self, xs, rmask, freeze_codebook, kw, *, dense, topk, temp, need_dist=False):
+    def _forward_general(self, xs, rmask, freeze_codebook, kw, *, dense, topk, temp, need_dist=False, transform_fn=None):
         """everything that is not the fused hot path: codebooks with gradients and/or options that read the full score row"""
         cb = self._codebook
         embed_eff = cb.embed if cb.vq_bridge is None else cb.vq_bridge(cb.embed)      # [1, C, D]
@@ -362,6 +362,23 @@ class VectorQuantize(nn.Module):
                      and not need_dist)
 
         def search(update_usage=True):
+            if transform_fn is not None:
+                # QINCo (vqp.py:729-738, 754-776): the callable turns the codebook [h, c, d] into one codebook per row,
+                # [h, b, n, c, d]; the search runs on the HIP row-wise kernel (nothing to keep resident: it streams the N x C x D
+                # codes once), `quantize` is a differentiable gather from the transformed codes, and an EMA codebook is updated
+                # from the chosen indices as usual (vqp.py:783-784)
+                if not cb._is_initted():
+                    cb.init_embed_(xs.detach().reshape(1, -1, xs.shape[-1]).float(), None if rmask is None else rmask.reshape(1, -1))
+                te = transform_fn(embed_eff.to(xs.dtype))                                  # [1, b, n, c, d]
+                te = te.reshape(*xs.shape[:-1], te.shape[-2], te.shape[-1])
+                if cb.use_cosine_sim:
+                    te = F.normalize(te, p=2, dim=-1, eps=1e-6)                            # l2norm (vqp.py:37-38)
+                ind = L.assign_rowwise(xs, te, cosine=cb.use_cosine_sim)
+                q = te.gather(-2, ind[..., None, None].expand(*ind.shape, 1, te.shape[-1]))[..., 0, :]
+                if self.training and update_usage and not freeze_codebook:
+                    cb.update_indices(xs.detach(), ind, mask=rmask, ema_update_weight=kw.get("ema_update_weight"),
+                                      accum_ema_update=kw.get("accum_ema_update", False), ema_update=kw.get("ema_update"))
+                return q.to(xs.dtype), ind, None
             if not dense:
                 r = cb.quantize(xs.detach(), mask=rmask, embed_override=embed_eff, update_usage=update_usage, **kw)
                 # value: the rows of the PRE-update codebook (the EMA fold inside quantize() runs after the gather, like
@@ -482,7 +499,12 @@ class VectorQuantize(nn.Module):
         ema_update=None,
     ):
         if codebook_transform_fn is not None:
-            raise NotImplementedError("codebook_transform_fn (QINCo implicit codebooks) is not on the MI355X hot path (SURVEY.md §8f)")
+            if self.heads > 1 or self._sharded is not None or self._codebook.affine_param:
+                raise NotImplementedError("codebook_transform_fn: heads == 1, unsharded, no affine_param")
+            if (indices is not None or topk is not None or self.commitment_use_cross_entropy_loss or self.has_codebook_diversity_loss
+                    or self.stochastic_sample_codes or self.gumbel_straight_through or self.in_place_codebook_optimizer is not None):
+                raise NotImplementedError("codebook_transform_fn cannot be combined with options that read the whole score row "
+                                          "(indices=, topk=, cross-entropy / diversity losses, gumbel sampling) or the in-place optimizer")
         if self._sharded is not None:
             if any(v is not None for v in (indices, mask, lens, topk, sample_codebook_temp, ema_update_weight, ema_update)) or accum_ema_update \
                     or return_loss_breakdown or x.ndim != 3:
@@ -533,12 +555,14 @@ class VectorQuantize(nn.Module):
         kw = dict(freeze_codebook=freeze_codebook, ema_update_weight=ema_update_weight,
                   accum_ema_update=accum_ema_update, ema_update=(ema_update if topk is None else False),
                   input_normalized=pre_normalized)
-        param_path = (self._codebook.learnable_codebook or self._codebook.vq_bridge is not None or self.directional_reparam or dense)
+        param_path = (self._codebook.learnable_codebook or self._codebook.vq_bridge is not None or self.directional_reparam or dense
+                      or codebook_transform_fn is not None)
         inplace_loss = orth_loss = diversity_loss = self.zero
         distances = None
         if param_path:
             quantize, embed_ind, commit_quantize, inplace_loss, distances = self._forward_general(
-                xs, rmask, freeze_codebook, kw, dense=dense, topk=topk, temp=sample_codebook_temp, need_dist=return_loss)
+                xs, rmask, freeze_codebook, kw, dense=dense, topk=topk, temp=sample_codebook_temp, need_dist=return_loss,
+                transform_fn=codebook_transform_fn)
         else:
             fold = (mask is None and self.training and self.has_commitment_loss)     # sq_sum then already is the mean
             quantize, embed_ind, sq_sum = _QuantizeFn.apply(xs, self, rmask, kw, 1.0 / float(max(xs.numel(), 1)) if fold else 1.0)
