@@ -104,6 +104,26 @@ int vqhip_assign_screened(const void *x, int x_dtype, int64_t N, int D, int64_t 
                           void *resid_out, int64_t ldr, double *sqerr_partial, const uint8_t *row_mask,
                           void *workspace, size_t workspace_bytes, float *debug_out, void *stream);
 
+/* Residual chain for the stages of a residual VQ (reference: the loop body of ResidualVQ.forward, residual_vq.py:469-568, with
+ * `residual = residual - quantized.detach()` at :524).  A stage's screening kernel forms its own input in its prologue,
+ * x - prev_embed[prev_idx] in fp32 (exactly the x - q the previous stage would have written), from the PREVIOUS stage's input x
+ * and indices, and stores it to x_out, where the exact passes of this stage (and the caller's statistics pass) read it -- so no
+ * stage re-reads its input to write a residual.  prev_idx == NULL: plain search of x (first stage); idx_stride lets every stage
+ * write its column of an [N, Q] index tensor.  fp32 rows, D in {32, 64, 128, 256}, Euclidean (vqhip_screen_chain_supported);
+ * no q / residual / squared-error outputs (the statistics pass sums the loss: vqhip_ema_accumulate_sqerr). */
+typedef struct {
+    int64_t idx_stride;            /* idx_out[n * idx_stride] */
+    const int64_t *prev_idx;       /* nullable: previous stage's indices, prev_idx[n * prev_idx_stride] */
+    int64_t prev_idx_stride;
+    const float *prev_embed;       /* previous stage's codebook [C_prev, D] fp32 */
+    void *x_out;                   /* [N, D] fp32 at row stride ldxo: receives this stage's input */
+    int64_t ldxo;
+} vqhip_chain_t;
+int vqhip_screen_chain_supported(int x_dtype, int D);
+int vqhip_assign_screened_chain(const void *x, int x_dtype, int64_t N, int D, int64_t ldx, const float *packed,
+                                const float *embed, int C, int metric, int64_t *idx_out, const uint8_t *row_mask,
+                                void *workspace, size_t workspace_bytes, const vqhip_chain_t *chain, void *stream);
+
 /* ---- dense scores (rare options only) ------------------------------------------------------------
  * Materialises the tensor the reference calls `dist` (vqp.py:741-743): scores_out[n, c] = -cdist(x_n, c) for the
  * Euclidean metric (same rounding sequence as vqhip_assign), x^_n . c for cosine.  Needed by the options that read

@@ -857,3 +857,29 @@ def test_qinco_implicit_neural_codebook_round_trip(dev):
     want = (-torch.nn.functional.pairwise_distance(xq[:, :, None, :], (before * 1.5)[0][None, None])).argmax(-1)
     assert (iv != want).sum().item() <= 1 and not torch.equal(vq._codebook.embed, before)
     assert torch.allclose(qv, (before[0] * 1.5)[iv], rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("kw", [dict(dim=256, num_quantizers=4, codebook_size=256, shared_codebook=True), dict(dim=128, num_quantizers=3, codebook_size=512),
+                                dict(dim=64, num_quantizers=5, codebook_size=64, commitment_weight=0.25), dict(dim=32, num_quantizers=2, codebook_size=1000)])
+def test_residual_chain_equals_the_stage_by_stage_loop(dev, monkeypatch, kw):
+    """vqhip_assign_screened_chain (every stage forms x_prev - code in its own prologue, the loss comes from the statistics pass) vs
+    VQHIP_RVQ_CHAIN=0 (every stage writes the next stage's input in its output phase and sums its own loss): same module, same
+    batches -- train steps with and without a mask, then eval: indices and outputs identical, losses / codebooks to fp32 rounding."""
+    from vector_quantize_pytorch_amd import ResidualVQ
+    torch.manual_seed(0)
+    a, b = ResidualVQ(**kw).to(dev).train(), ResidualVQ(**kw).to(dev).train()
+    b.load_state_dict(a.state_dict())
+    for step in range(4):
+        if step == 3:
+            a.eval(); b.eval()
+        x = torch.randn(3, 700, kw["dim"], device=dev) * (1.0 + step)
+        mask = (torch.rand(3, 700, device=dev) > 0.2) if step == 1 else None
+        with torch.no_grad():
+            monkeypatch.setenv("VQHIP_RVQ_CHAIN", "1")
+            qa, ia, la = a(x, mask=mask)
+            monkeypatch.setenv("VQHIP_RVQ_CHAIN", "0")
+            qb, ib, lb = b(x, mask=mask)
+        assert torch.equal(ia, ib) and torch.equal(qa, qb)
+        assert torch.allclose(la, lb, rtol=2e-6, atol=1e-12)
+        assert torch.allclose(a.codebooks, b.codebooks, rtol=1e-5, atol=1e-7)
+        b.load_state_dict(a.state_dict())

@@ -159,3 +159,18 @@ def test_key_packing_orders_like_argmax():
     assert (ss[:-1] >= ss[1:]).all()
     same = ss[:-1] == ss[1:]
     assert (ii[:-1][same] < ii[1:][same]).all()     # among equal scores the lowest index has the largest key
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/vector_quantize_pytorch"), reason="the live reference only exists in the build container")
+def test_reference_residual_vq_forward_indices_is_broken_upstream():
+    """Why ResidualVQ.forward(indices=) raises here instead of mirroring the reference: the reference's own path cannot run --
+    rvq.py:493 unpacks three values from the (quantize, ce_loss) pair that VectorQuantize.forward returns for indices= (vqp.py:1261)."""
+    import sys
+    sys.path[:0] = [os.path.join(ROOT, "oracle", "refshim"), "/root/reference"]
+    try:
+        from vector_quantize_pytorch import ResidualVQ as RefRVQ
+        m = RefRVQ(dim=16, num_quantizers=2, codebook_size=8)
+        with pytest.raises(ValueError, match="not enough values to unpack"):
+            m(torch.randn(1, 4, 16), indices=torch.zeros(1, 4, 2, dtype=torch.long))
+    finally:
+        del sys.path[:2]

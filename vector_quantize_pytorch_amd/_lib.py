@@ -60,6 +60,10 @@ def lib():
     L.vqhip_screen_partials.restype = i64
     L.vqhip_assign_screened.argtypes = [vp, i32, i64, i32, i64, vp, vp, i32, i32, vp, vp, i64, vp, i64, vp, vp, vp, ctypes.c_size_t, vp, vp]
     L.vqhip_l2norm_rows.argtypes = [vp, i32, i64, i32, i64, vp, i64, vp]
+    L.vqhip_screen_chain_supported.argtypes = [i32, i32]
+    L.vqhip_screen_chain_supported.restype = i32
+    L.vqhip_assign_screened_chain.argtypes = [vp, i32, i64, i32, i64, vp, vp, i32, i32, vp, vp, vp, ctypes.c_size_t, vp, vp]
+    L.vqhip_assign_screened_chain.restype = i32
     L.vqhip_l2norm_rows.restype = i32
     L.vqhip_assign_screened.restype = i32
     L.vqhip_route_fwd.argtypes = [vp, vp, i32, i64, i32, i64, i64, vp, i64, i32, vp]
@@ -95,7 +99,7 @@ def lib():
 
 EXPORTS = ("vqhip_version", "vqhip_last_error", "vqhip_packed_bytes", "vqhip_pack_codebook",
            "vqhip_assign_blocks", "vqhip_assign", "vqhip_screen_supported", "vqhip_screen_workspace_bytes",
-           "vqhip_screen_blocks", "vqhip_screen_partials", "vqhip_assign_screened", "vqhip_l2norm_rows", "vqhip_scores", "vqhip_rvq_forward", "vqhip_reduce_partials", "vqhip_ema_workspace_bytes", "vqhip_ema_accumulate", "vqhip_ema_sqerr_partials", "vqhip_ema_accumulate_sqerr",
+           "vqhip_screen_blocks", "vqhip_screen_partials", "vqhip_assign_screened", "vqhip_screen_chain_supported", "vqhip_assign_screened_chain", "vqhip_l2norm_rows", "vqhip_scores", "vqhip_rvq_forward", "vqhip_reduce_partials", "vqhip_ema_workspace_bytes", "vqhip_ema_accumulate", "vqhip_ema_sqerr_partials", "vqhip_ema_accumulate_sqerr",
            "vqhip_ema_finalize", "vqhip_decode_sum", "vqhip_row_sumsq", "vqhip_assign_rowwise", "vqhip_score_indices", "vqhip_topk", "vqhip_expire_scatter", "vqhip_kmeans_update", "vqhip_route_fwd", "vqhip_route_bwd")
 
 
@@ -301,6 +305,64 @@ def l2norm_rows(x: torch.Tensor) -> torch.Tensor:
     if N > 0:
         _check(lib().vqhip_l2norm_rows(_ptr(xk), _dtype_code(xk), N, D, ldx, _ptr(out), D, _stream()), "vqhip_l2norm_rows")
     return out
+
+
+class _Chain(ctypes.Structure):          # vqhip_chain_t (include/vqhip.h)
+    _fields_ = [("idx_stride", ctypes.c_int64), ("prev_idx", ctypes.c_void_p), ("prev_idx_stride", ctypes.c_int64),
+                ("prev_embed", ctypes.c_void_p), ("x_out", ctypes.c_void_p), ("ldxo", ctypes.c_int64)]
+
+
+def rvq_chain_supported(x: torch.Tensor, C: int) -> bool:
+    """can the residual loop run as a chain (every stage forms its input in its own prologue: vqhip_assign_screened_chain)?"""
+    if not (x.is_cuda and x.dtype == torch.float32 and screening_enabled() and os.environ.get("VQHIP_RVQ_CHAIN", "1") != "0"):
+        return False
+    xk, N, D, ldx = as_rows(x)
+    return bool(N > 0 and lib().vqhip_screen_chain_supported(_dtype_code(xk), D) and lib().vqhip_screen_supported(N, D, C)
+                and xk.data_ptr() % 16 == 0 and (ldx * 4) % 16 == 0)
+
+
+@_on_device
+def rvq_forward_chained(x: torch.Tensor, packed: torch.Tensor, embed: torch.Tensor, Q: int, *, row_mask=None, stage_hook=None):
+    """The residual loop (rvq.py:469-568) as Q chained screened searches: stage q's kernel forms its input
+    inputs[q-1] - embed[idx[:, q-1]] in its prologue and stores it as inputs[q]; no stage re-reads its input to write a residual,
+    and every stage writes its column of idx directly.  No q / squared-error outputs: the caller's statistics pass sums the loss
+    (ema_accumulate(sqerr_from=...)).  -> dict(idx [..., Q], inputs [Q tensors], n_exact / n_pair per stage)."""
+    _need_gpu(x, packed, embed, row_mask)
+    shared = embed.ndim == 2
+    xk, N, D, ldx = as_rows(x)
+    lead, dev = x.shape[:-1], x.device
+    C = embed.shape[-2]
+    assert embed.dtype == torch.float32 and embed.is_contiguous() and xk.dtype == torch.float32
+    idx = torch.empty(N, Q, dtype=torch.int64, device=dev)
+    bufs = torch.empty(max(Q - 1, 1), N, D, dtype=torch.float32, device=dev)
+    if row_mask is not None:
+        row_mask = row_mask.reshape(-1).to(torch.uint8).contiguous()
+    nws = lib().vqhip_screen_workspace_bytes(N)
+    inputs, counts = [x], []
+    for q in range(Q):
+        ws = torch.empty((nws + 3) // 4, dtype=torch.int32, device=dev)
+        ch = _Chain(idx_stride=Q, prev_idx=None, prev_idx_stride=Q, prev_embed=None, x_out=None, ldxo=D)
+        src, lds = xk, ldx
+        if q > 0:
+            prev_e = embed if shared else embed[q - 1]
+            ch.prev_idx = idx.data_ptr() + 8 * (q - 1)
+            ch.prev_embed = prev_e.data_ptr()
+            ch.x_out = bufs[q - 1].data_ptr()
+            if q > 1:
+                src, lds = bufs[q - 2], D
+        _check(lib().vqhip_assign_screened_chain(_ptr(src), F32, N, D, lds, _ptr(packed if shared else packed[q]),
+                                                 _ptr(embed if shared else embed[q]), C, EUCLID,
+                                                 ctypes.c_void_p(idx.data_ptr() + 8 * q), _ptr(row_mask), _ptr(ws), nws,
+                                                 ctypes.byref(ch), _stream()), "vqhip_assign_screened_chain")
+        if q > 0:
+            inputs.append(bufs[q - 1].view(*lead, D))
+        counts.append((ws[:1], ws[1:2]))
+        if stage_hook is not None:      # stage q's input and indices are final (in stream order): the caller's per-stage work
+            stage_hook(q, inputs[q], idx.view(*lead, Q))
+    idx = idx.view(*lead, Q)
+    if row_mask is not None:      # as the fused kernel: masked rows carry index -1 (decode contributes nothing)
+        idx.masked_fill_(~row_mask.reshape(*lead, 1).bool(), -1)
+    return dict(idx=idx, inputs=inputs, counts=counts)
 
 
 @_on_device

@@ -73,6 +73,14 @@ struct ScreenArgs {
     int *flag_rows;
     unsigned long long *flag_keys;     // [N] keys of the exact pass, preset to ~0 for every appended row
     float *dbg;                        // nullable [N, 4]: t_best, t_second, eps_t, flagged
+    // residual chain (vq_screen16_kernel, fp32 rows): this stage's rows are x - prev_embed[prev_idx], formed in the prologue from
+    // the PREVIOUS stage's input and indices and written to x_out (the exact passes and the statistics read them there)
+    int64_t idx_stride;                // idx_out[row * idx_stride] (a column of an [N, Q] index tensor)
+    const int64_t *prev_idx;           // nullable
+    int64_t prev_idx_stride;
+    const float *prev_embed;           // [C_prev, D] fp32
+    float *x_out;
+    int64_t ldxo;
 #ifdef VQ_TRACE
     long long *trace;
 #endif
@@ -663,6 +671,26 @@ __global__ void __launch_bounds__(VQS_WAVES * 64, 8 / VQS_WAVES) vq_screen16_ker
 #pragma unroll
                     for (int st = 0; st < NSTEP; ++st) g[st][i] = *(const f32x4 *)(pr + st * CH);
                 }
+                if (a.prev_idx) {
+                    // residual chain (rvq.py:524: residual = residual - quantized.detach()): the loaded rows are the PREVIOUS stage's
+                    // input; its code rows (fp32, from L2) are subtracted here -- the same fp32 x - q the output phase of that stage
+                    // would have written -- and the result is both this stage's input and, stored to x_out, the tensor the exact
+                    // passes and the statistics pass of this stage read.  Saves the previous stage's re-read of x for the residual.
+#pragma unroll
+                    for (int i = 0; i < NI; ++i) {
+                        const int64_t r = wrow0 + rb * 32 + i * RPI + lr;
+                        const int64_t rc = r < a.N ? r : a.N - 1;
+                        const float *pe = a.prev_embed + (size_t)a.prev_idx[rc * a.prev_idx_stride] * DT + lc * 4;
+                        f32x4 e[NSTEP];
+#pragma unroll
+                        for (int st = 0; st < NSTEP; ++st) e[st] = *(const f32x4 *)(pe + st * CH);
+#pragma unroll
+                        for (int st = 0; st < NSTEP; ++st) {
+                            g[st][i] = g[st][i] - e[st];
+                            if (r < a.N) *(f32x4 *)(a.x_out + r * a.ldxo + lc * 4 + st * CH) = g[st][i];
+                        }
+                    }
+                }
                 float ps[NI];
                 unsigned mxb = 0u;
 #pragma unroll
@@ -1246,7 +1274,7 @@ __global__ void __launch_bounds__(VQS_WAVES * 64, 8 / VQS_WAVES) vq_screen16_ker
         const bool pair = !certified && ((b1 - b3) > thr) && code[rb] < a.C && id2 < a.C;
         flagged[rb] = !certified;
         if (row_ok[rb] && half == 0) {
-            a.idx_out[rows[rb]] = (int64_t)(code[rb] < a.C ? code[rb] : 0);
+            a.idx_out[rows[rb] * a.idx_stride] = (int64_t)(code[rb] < a.C ? code[rb] : 0);
             if (a.dbg) {
                 float *d = a.dbg + rows[rb] * 4;
                 d[0] = b1 * iSSv[rb]; d[1] = b2 * iSSv[rb]; d[2] = thr * iSSv[rb]; d[3] = certified ? 0.f : (pair ? 2.f : 1.f);
@@ -2081,6 +2109,13 @@ static bool screen_bf16x2()
     return v == 1;
 }
 
+static bool screen_f32_two_part()     // VQHIP_SCREEN_F32_2PART=1: fp32 rows through the two-operand-set kernel (A/B runs)
+{
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("VQHIP_SCREEN_F32_2PART"); v = (e && e[0] == '1') ? 1 : 0; }
+    return v != 0;
+}
+
 template <int DT, int METRIC>
 static int launch_screen(const ScreenArgs &a, int x_dtype, hipStream_t st)
 {
@@ -2113,8 +2148,7 @@ static int launch_screen(const ScreenArgs &a, int x_dtype, hipStream_t st)
             }
         } else {
             // fp32 rows, D <= 256: one fp16 operand set, two row blocks per wave (VQHIP_SCREEN_F32_2PART=1: the two-set kernel, A/B)
-            static int two_part = -1;
-            if (two_part < 0) { const char *e = getenv("VQHIP_SCREEN_F32_2PART"); two_part = (e && e[0] == '1') ? 1 : 0; }
+            const int two_part = screen_f32_two_part() ? 1 : 0;
             if constexpr (DT <= 256) {
                 if (!two_part) {
                     static VqAttrOnce once;
@@ -2154,10 +2188,47 @@ static int dispatch_screen(const ScreenArgs &a, int x_dtype, int metric, hipStre
     return metric == VQHIP_EUCLID ? launch_screen<DT, 0>(a, x_dtype, st) : launch_screen<DT, 1>(a, x_dtype, st);
 }
 
+static int assign_screened_impl(const void *x, int x_dtype, int64_t N, int D, int64_t ldx, const float *packed,
+                                const float *embed, int C, int metric, int64_t *idx_out, void *q_out, int64_t ldq,
+                                void *resid_out, int64_t ldr, double *sqerr_partial, const uint8_t *row_mask,
+                                void *workspace, size_t workspace_bytes, float *debug_out, const vqhip_chain_t *chain, void *stream);
+
 extern "C" int vqhip_assign_screened(const void *x, int x_dtype, int64_t N, int D, int64_t ldx, const float *packed,
                                      const float *embed, int C, int metric, int64_t *idx_out, void *q_out, int64_t ldq,
                                      void *resid_out, int64_t ldr, double *sqerr_partial, const uint8_t *row_mask,
                                      void *workspace, size_t workspace_bytes, float *debug_out, void *stream)
+{
+    return assign_screened_impl(x, x_dtype, N, D, ldx, packed, embed, C, metric, idx_out, q_out, ldq, resid_out, ldr, sqerr_partial,
+                                row_mask, workspace, workspace_bytes, debug_out, nullptr, stream);
+}
+
+extern "C" int vqhip_screen_chain_supported(int x_dtype, int D)
+{
+    return (x_dtype == VQHIP_F32 && (D == 32 || D == 64 || D == 128 || D == 256) && !screen_bf16x2() && !screen_f32_two_part()) ? 1 : 0;
+}
+
+extern "C" int vqhip_assign_screened_chain(const void *x, int x_dtype, int64_t N, int D, int64_t ldx, const float *packed,
+                                           const float *embed, int C, int metric, int64_t *idx_out, const uint8_t *row_mask,
+                                           void *workspace, size_t workspace_bytes, const vqhip_chain_t *chain, void *stream)
+{
+    if (!chain) VQ_FAIL(VQHIP_EINVAL, "assign_screened_chain: chain is null");
+    if (!vqhip_screen_chain_supported(x_dtype, D)) VQ_FAIL(VQHIP_EINVAL, "assign_screened_chain: fp32 rows, D in {32, 64, 128, 256} only");
+    if (metric != VQHIP_EUCLID) VQ_FAIL(VQHIP_EINVAL, "assign_screened_chain: Euclidean metric only");
+    if (chain->idx_stride < 1) VQ_FAIL(VQHIP_EINVAL, "assign_screened_chain: idx_stride < 1");
+    if (chain->prev_idx) {
+        if (!chain->prev_embed || !chain->x_out || chain->prev_idx_stride < 1 || chain->ldxo < D)
+            VQ_FAIL(VQHIP_EINVAL, "assign_screened_chain: prev_idx needs prev_embed, x_out and valid strides");
+        if ((((uintptr_t)chain->prev_embed) & 15) || (((uintptr_t)chain->x_out) & 15) || ((chain->ldxo * 4) & 15))
+            VQ_FAIL(VQHIP_EALIGN, "assign_screened_chain: prev_embed / x_out rows must be 16-byte aligned");
+    }
+    return assign_screened_impl(x, x_dtype, N, D, ldx, packed, embed, C, metric, idx_out, nullptr, D, nullptr, D, nullptr, row_mask,
+                                workspace, workspace_bytes, nullptr, chain, stream);
+}
+
+static int assign_screened_impl(const void *x, int x_dtype, int64_t N, int D, int64_t ldx, const float *packed,
+                                const float *embed, int C, int metric, int64_t *idx_out, void *q_out, int64_t ldq,
+                                void *resid_out, int64_t ldr, double *sqerr_partial, const uint8_t *row_mask,
+                                void *workspace, size_t workspace_bytes, float *debug_out, const vqhip_chain_t *chain, void *stream)
 {
     if (N < 0 || C <= 0) VQ_FAIL(VQHIP_EINVAL, "assign_screened: N < 0 or C <= 0");
     if (N == 0) return 0;
@@ -2195,6 +2266,12 @@ extern "C" int vqhip_assign_screened(const void *x, int x_dtype, int64_t N, int 
     a.sqerr_partial = sqerr_partial; a.row_mask = row_mask;
     unsigned long long *keys = (unsigned long long *)((char *)workspace + 16 + (((size_t)N * sizeof(int) + 7) & ~(size_t)7));
     a.flag_count = count; a.flag_rows = rows; a.flag_keys = keys; a.dbg = debug_out;
+    a.idx_stride = chain ? chain->idx_stride : 1;
+    a.prev_idx = chain ? chain->prev_idx : nullptr;
+    a.prev_idx_stride = chain ? chain->prev_idx_stride : 1;
+    a.prev_embed = chain ? chain->prev_embed : nullptr;
+    a.x_out = chain ? (float *)chain->x_out : nullptr;
+    a.ldxo = chain ? chain->ldxo : 0;
 #ifdef VQ_TRACE
     a.trace = vq_g_trace;
 #endif
@@ -2208,7 +2285,10 @@ extern "C" int vqhip_assign_screened(const void *x, int x_dtype, int64_t N, int 
     }
     if (rc) return rc;
     const int with_pairs = (screen_bf16x2() && D <= 256) ? 0 : 1;   // the fp16 screening kernels also build the pair list
-    return vq_assign_listed(x, x_dtype, metric, N, D, ldx, packed, embed, C, idx_out, q_out, ldq, resid_out, ldr,
+    // a chained stage's rows were materialised by its screening kernel: the exact passes read them there
+    const void *xl = (chain && chain->prev_idx) ? (const void *)chain->x_out : x;
+    const int64_t ldl = (chain && chain->prev_idx) ? chain->ldxo : ldx;
+    return vq_assign_listed(xl, x_dtype, metric, N, D, ldl, packed, embed, C, idx_out, a.idx_stride, q_out, ldq, resid_out, ldr,
                             sqerr_partial ? sqerr_partial + vqhip_screen_blocks(N, x_dtype) : nullptr, row_mask, rows, count, keys,
                             with_pairs, st);
 }

@@ -1478,6 +1478,7 @@ struct FinishArgs {
     int64_t cap;             // list capacity (N)
     const unsigned long long *keys;
     int64_t *idx_out;
+    int64_t idx_stride;      // idx_out[row * idx_stride]
     void *q_out;             // nullable, x's dtype
     int64_t ldq;
     void *resid_out;         // nullable, x's dtype: x - q
@@ -1502,7 +1503,7 @@ __global__ void __launch_bounds__(VQ_FINISH_WAVES * 64) vq_finish_listed_kernel(
         const int64_t pos = v < n_full ? v : a.cap - 1 - (v - n_full);
         const int64_t row = a.row_list[pos];
         const int idx = (int)(unsigned)(a.keys[pos] & 0xffffffffull);
-        if (lane == 0) a.idx_out[row] = (int64_t)idx;
+        if (lane == 0) a.idx_out[row * a.idx_stride] = (int64_t)idx;
         float ls = 0.f;
         for (int c0 = lane * 4; c0 < a.D; c0 += 256) {
             float d0, d1, d2, d3;
@@ -1696,7 +1697,7 @@ static int dispatch_pair(const PairArgs &a, int x_dtype, int metric, unsigned bl
 }
 
 int vq_assign_listed(const void *x, int x_dtype, int metric, int64_t N, int D, int64_t ldx, const float *packed, const float *embed, int C,
-                     int64_t *idx_out, void *q_out, int64_t ldq, void *resid_out, int64_t ldr, double *sqerr_partial,
+                     int64_t *idx_out, int64_t idx_stride, void *q_out, int64_t ldq, void *resid_out, int64_t ldr, double *sqerr_partial,
                      const uint8_t *row_mask, const int *row_list, const int *row_count, unsigned long long *keys, int with_pairs,
                      hipStream_t st)
 {
@@ -1737,7 +1738,7 @@ int vq_assign_listed(const void *x, int x_dtype, int metric, int64_t N, int D, i
     f.x = x; f.ldx = ldx;
     f.codes = (x_dtype == VQHIP_BF16) ? (const void *)((const char *)packed + packed_bf16_offset(C, D)) : (const void *)embed;
     f.D = D; f.row_list = row_list; f.row_count = row_count; f.cap = N; f.keys = keys;
-    f.idx_out = idx_out; f.q_out = q_out; f.ldq = ldq; f.resid_out = resid_out; f.ldr = ldr; f.sqerr_partial = sqerr_partial; f.row_mask = row_mask;
+    f.idx_out = idx_out; f.idx_stride = idx_stride; f.q_out = q_out; f.ldq = ldq; f.resid_out = resid_out; f.ldr = ldr; f.sqerr_partial = sqerr_partial; f.row_mask = row_mask;
     if (x_dtype == VQHIP_BF16)
         hipLaunchKernelGGL(vq_finish_listed_kernel<true>, dim3(VQ_FINISH_BLOCKS), dim3(VQ_FINISH_WAVES * 64), 0, st, f);
     else

@@ -110,6 +110,6 @@ static inline size_t vq_packed_total_bytes(int C, int D)
 // sqerr_partial (nullable) receives VQ_FINISH_BLOCKS entries.
 #define VQ_FINISH_BLOCKS 512
 int vq_assign_listed(const void *x, int x_dtype, int metric, int64_t N, int D, int64_t ldx, const float *packed, const float *embed, int C,
-                     int64_t *idx_out, void *q_out, int64_t ldq, void *resid_out, int64_t ldr, double *sqerr_partial,
+                     int64_t *idx_out, int64_t idx_stride, void *q_out, int64_t ldq, void *resid_out, int64_t ldr, double *sqerr_partial,
                      const uint8_t *row_mask, const int *row_list, const int *row_count, unsigned long long *keys, int with_pairs,
                      hipStream_t st);

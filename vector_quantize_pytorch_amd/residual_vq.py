@@ -291,9 +291,19 @@ class ResidualVQ(nn.Module):
             # (a shared codebook is lerp-ed Q times, rvq.py:213-217 + vqp.py:616-617)
             buf = torch.zeros(Q, (C * D + C + 3) // 4 * 4, dtype=torch.float32, device=x.device)   # stage slices stay 16-byte aligned
 
+        # Residual chain (csrc: vqhip_assign_screened_chain): every stage forms its input x_prev - code in its own prologue, so no
+        # stage re-reads its input to write a residual; the commitment loss' squared error then comes from the per-stage
+        # statistics pass, which reads every row next to its code anyway (needs `update`; without a loss nothing is needed)
+        chain = (L.screening_enabled() and D in (32, 64, 128, 256) and L.rvq_chain_supported(x, C) and (update or not want_loss))
+        sq_parts = [None] * Q
+
         def accumulate(q, stage_input, idx_all):
-            L.ema_accumulate(stage_input, idx_all, C, row_mask=mask, count=buf[q, C * D: C * D + C], embed_sum=buf[q, : C * D].view(C, D),
-                             idx_offset=q, idx_stride=Q)
+            kw = dict(row_mask=mask, count=buf[q, C * D: C * D + C], embed_sum=buf[q, : C * D].view(C, D), idx_offset=q, idx_stride=Q)
+            if chain and want_loss:
+                e_q = embed if self.shared_codebook else embed[q]
+                sq_parts[q] = L.ema_accumulate(stage_input, idx_all, C, sqerr_from=(packed if self.shared_codebook else packed[q], e_q), **kw)[2]
+            else:
+                L.ema_accumulate(stage_input, idx_all, C, **kw)
 
         if L.screening_enabled() and D in (32, 64, 128, 256) and x.data_ptr() % 16 == 0:
             # Q screened searches on the f16 MFMA pipe (csrc/vq_screen.hip), each writing the next stage's input; beats
@@ -314,7 +324,10 @@ class ResidualVQ(nn.Module):
                     side.wait_event(ev)
                     with torch.cuda.stream(side):
                         accumulate(q, stage_input, idx_all)
-            r = L.rvq_forward_screened(x, packed, embed, Q, want_resid=update, want_sqerr=want_loss, row_mask=mask, stage_hook=hook)
+            if chain:
+                r = L.rvq_forward_chained(x, packed, embed, Q, row_mask=mask, stage_hook=hook)
+            else:
+                r = L.rvq_forward_screened(x, packed, embed, Q, want_resid=update, want_sqerr=want_loss, row_mask=mask, stage_hook=hook)
             if hook is None:
                 side = None
         else:
@@ -322,22 +335,31 @@ class ResidualVQ(nn.Module):
         idx = r["idx"]
         quantized_out = L.decode_sum(idx, embed, out_dtype=x.dtype)
 
+        stage_in = None
+        if update:
+            resid = r.get("resid")
+            stage_in = (lambda q: r["inputs"][q]) if r.get("inputs") is not None else (lambda q: resid[..., q, :])
+            if side is not None:
+                torch.cuda.current_stream(x.device).wait_stream(side)
+                for p_ in sq_parts:
+                    if p_ is not None:
+                        p_.record_stream(torch.cuda.current_stream(x.device))   # allocated on the statistics stream, reduced here
+            else:
+                for q in range(Q):
+                    accumulate(q, stage_in(q), idx)
+
         losses = torch.zeros(self.num_quantizers, device=x.device, dtype=torch.float32)
         if want_loss:
-            sums = torch.stack([L.reduce_partials(r["sqerr_partials"][q], r["sqerr_partials"].shape[1], 1.0) for q in range(Q)])
+            if chain:
+                sums = torch.stack([L.reduce_partials(sq_parts[q], sq_parts[q].numel(), 1.0) for q in range(Q)])
+            else:
+                sums = torch.stack([L.reduce_partials(r["sqerr_partials"][q], r["sqerr_partials"].shape[1], 1.0) for q in range(Q)])
             denom = float(x.numel()) if mask is None else (mask.sum() * D).to(torch.float32)
             losses[:Q] = sums / denom * vq0.commitment_weight
         if train:
             losses = torch.zeros(self.num_quantizers, device=x.device, requires_grad=True) + losses   # as vqp.py:1282
 
         if update:
-            resid = r["resid"]
-            stage_in = (lambda q: r["inputs"][q]) if r.get("inputs") is not None else (lambda q: resid[..., q, :])
-            if side is not None:
-                torch.cuda.current_stream(x.device).wait_stream(side)
-            else:
-                for q in range(Q):
-                    accumulate(q, stage_in(q), idx)
             if vq0._codebook.use_ddp:
                 dist.all_reduce(buf)
             for q in range(Q):
