@@ -174,11 +174,21 @@ def other_workload(args, world, rank, dev):
             counts.append((r["n_exact"], r["n_pair"], r["idx"].numel()))
         return r
 
+    orig_chained = _lib.rvq_forward_chained
+
+    def counting_chained(*a, **k):          # the chained residual loop reports its per-stage counters itself
+        r = orig_chained(*a, **k)
+        n = r["idx"].numel() // len(r["counts"])
+        counts.extend((c[0], c[1], n) for c in r["counts"])
+        return r
+
     _lib.assign = counting_assign
+    _lib.rvq_forward_chained = counting_chained
     import vector_quantize_pytorch_amd.codebook as cbmod
     cbmod.L.assign = counting_assign
     dt, first, _ = _time_module(mod, batches, args.steps, args.warmup, sync)
     _lib.assign = orig_assign
+    _lib.rvq_forward_chained = orig_chained
     per_stage = None
     if counts:
         n_last = stages if len(counts) >= stages else len(counts)
