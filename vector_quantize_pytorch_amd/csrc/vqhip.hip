@@ -1369,10 +1369,11 @@ struct RefineArgs {
     unsigned long long *keys;   // [list capacity], preset to ~0
 };
 
+// (bid, nblk): this workgroup's number and the number of workgroups doing this work -- the kernel's own grid, or its share of
+// the merged launch vq_listed_kernel further down
 template <int DT, bool XBF16, int METRIC>
-__global__ void __launch_bounds__(256, (DT <= 256 ? 2 : 1)) vq_refine_kernel(const RefineArgs a)
+__device__ __forceinline__ void vq_refine_body(const RefineArgs &a, char *smem, const unsigned bid, const unsigned nblk)
 {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int TILE_F = 32 * DT + 256;
     constexpr int TILE_B = TILE_F * 4;
     constexpr int NCHUNK = TILE_B / 1024;
@@ -1389,14 +1390,14 @@ __global__ void __launch_bounds__(256, (DT <= 256 ? 2 : 1)) vq_refine_kernel(con
     // as many workgroups as the grid has to spare (a short list would otherwise keep a handful of workgroups busy for a whole
     // sweep each: 70 us for a few hundred rows); the partial winners meet in the atomicMin below
     const int n_chunks = (list_n + VQHIP_ASSIGN_ROWS_PER_BLOCK - 1) / VQHIP_ASSIGN_ROWS_PER_BLOCK;
-    int splits = (int)gridDim.x / n_chunks;
+    int splits = (int)nblk / n_chunks;
     splits = splits < 1 ? 1 : (splits > a.n_tiles ? a.n_tiles : splits);
     const int tps = (a.n_tiles + splits - 1) / splits;   // tiles per split
     splits = (a.n_tiles + tps - 1) / tps;
     const int my_pieces = (NCHUNK - wave + 3) / 4;
     const int piece_off = wave * 1024 + lane * 16;
 
-    for (int64_t w = blockIdx.x; w < (int64_t)n_chunks * splits; w += gridDim.x) {
+    for (int64_t w = bid; w < (int64_t)n_chunks * splits; w += nblk) {
         const int64_t chunk = w / splits;
         const int ct0 = (int)(w % splits) * tps;
         const int ct1 = min(a.n_tiles, ct0 + tps);
@@ -1466,6 +1467,13 @@ __global__ void __launch_bounds__(256, (DT <= 256 ? 2 : 1)) vq_refine_kernel(con
         if (row_ok && hi == 0)
             atomicMin(a.keys + pos, ((unsigned long long)hk << 32) | (unsigned long long)(unsigned)bi);
     }
+}
+
+template <int DT, bool XBF16, int METRIC>
+__global__ void __launch_bounds__(256, (DT <= 256 ? 2 : 1)) vq_refine_kernel(const RefineArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    vq_refine_body<DT, XBF16, METRIC>(a, smem, blockIdx.x, gridDim.x);
 }
 
 struct FinishArgs {
@@ -1583,33 +1591,42 @@ struct PairArgs {
 // in LDS (row pitch + 16 bytes: conflict-free b128 reads), and every lane then reads its own row's piece back.  The next
 // piece's global loads are in flight while the current one is multiplied.  Arithmetic unchanged: one ascending FMA chain per code.
 #define VQ_PAIR_WAVES 2
+template <bool XBF16> struct PairCfg {
+    static constexpr int KC = 32;
+    static constexpr int EP = KC * 4 + 16;                          // LDS row pitch of a code piece (bytes)
+    static constexpr int XP = (XBF16 ? KC * 2 : KC * 4) + 16;       // ... of a row piece
+    static constexpr int WAVE_B = 64 * (2 * EP + XP);
+    static constexpr int SMEM = VQ_PAIR_WAVES * WAVE_B;
+};
+
+// VQ_PAIR_WAVES waves of the workgroup work (the others return): in the merged launch the workgroups have the exact sweep's 4
 template <int DT, bool XBF16, int METRIC>
-__global__ void __launch_bounds__(VQ_PAIR_WAVES * 64) vq_pair_kernel(const PairArgs a)
+__device__ __forceinline__ void vq_pair_body(const PairArgs &a, char *smem, const unsigned bid, const unsigned nblk)
 {
-    constexpr int KC = 32, NCH = DT / KC;
-    constexpr int EP = KC * 4 + 16;                          // LDS row pitch of a code piece (bytes)
-    constexpr int XP = (XBF16 ? KC * 2 : KC * 4) + 16;       // ... of a row piece
+    constexpr int KC = PairCfg<XBF16>::KC, NCH = DT / KC;
+    constexpr int EP = PairCfg<XBF16>::EP;
+    constexpr int XP = PairCfg<XBF16>::XP;
     constexpr int NXL = XBF16 ? 4 : 8;                       // wave loads per row piece of the 64 rows
     constexpr int XLPR = 64 / (64 / NXL) ;                   // lanes per row piece: 4 (bf16: 64 B) or 8 (fp32: 128 B)
-    constexpr int WAVE_B = 64 * (2 * EP + XP);
-    __shared__ __attribute__((aligned(16))) char smem[VQ_PAIR_WAVES * WAVE_B];
+    constexpr int WAVE_B = PairCfg<XBF16>::WAVE_B;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (wave >= VQ_PAIR_WAVES) return;
     char *se1 = smem + wave * WAVE_B, *se2 = se1 + 64 * EP, *sx = se2 + 64 * EP;
     const int n = a.row_count[1];
-    for (int64_t base = ((int64_t)blockIdx.x * VQ_PAIR_WAVES + wave) * 64; base < n; base += (int64_t)gridDim.x * VQ_PAIR_WAVES * 64) {
+    for (int64_t base = ((int64_t)bid * VQ_PAIR_WAVES + wave) * 64; base < n; base += (int64_t)nblk * VQ_PAIR_WAVES * 64) {
         const int64_t p = (base + lane < n) ? base + lane : (int64_t)n - 1;
         const int64_t pos = a.cap - 1 - p;
         const int64_t row = a.row_list[pos];
         const unsigned long long cand = a.keys[pos];
         const int c1 = (int)(unsigned)(cand & 0xffffffffull), c2 = (int)(unsigned)(cand >> 32);
         // cooperative pieces: wave load i of a code stream covers the rows 8 i .. 8 i + 7 (8 lanes x 16 bytes each)
-        const float *pe1[8], *pe2[8];
+        unsigned oe1[8], oe2[8];          // byte offsets into embed (C * D * 4 < 2^32): uniform base + 32-bit lane offset
         const char *px[NXL];
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int r = i * 8 + (lane >> 3);
-            pe1[i] = a.embed + (size_t)__shfl(c1, r, 64) * DT + (lane & 7) * 4;
-            pe2[i] = a.embed + (size_t)__shfl(c2, r, 64) * DT + (lane & 7) * 4;
+            oe1[i] = (unsigned)__shfl(c1, r, 64) * (unsigned)(DT * 4) + (unsigned)(lane & 7) * 16u;
+            oe2[i] = (unsigned)__shfl(c2, r, 64) * (unsigned)(DT * 4) + (unsigned)(lane & 7) * 16u;
         }
 #pragma unroll
         for (int i = 0; i < NXL; ++i) {
@@ -1620,7 +1637,10 @@ __global__ void __launch_bounds__(VQ_PAIR_WAVES * 64) vq_pair_kernel(const PairA
         f32x4 g1[8], g2[8], gx[NXL];
         auto issue = [&](int k0) __attribute__((always_inline)) {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) { g1[i] = *(const f32x4 *)(pe1[i] + k0); g2[i] = *(const f32x4 *)(pe2[i] + k0); }
+            for (int i = 0; i < 8; ++i) {
+                g1[i] = *(const f32x4 *)((const char *)a.embed + (size_t)(oe1[i] + (unsigned)k0 * 4u));
+                g2[i] = *(const f32x4 *)((const char *)a.embed + (size_t)(oe2[i] + (unsigned)k0 * 4u));
+            }
 #pragma unroll
             for (int i = 0; i < NXL; ++i) gx[i] = *(const f32x4 *)(px[i] + (size_t)k0 * (XBF16 ? 2 : 4));
         };
@@ -1641,30 +1661,26 @@ __global__ void __launch_bounds__(VQ_PAIR_WAVES * 64) vq_pair_kernel(const PairA
             if (k + 1 < NCH) issue((k + 1) * KC);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            float xv[32];
-            if (XBF16) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const uint4 w = *(const uint4 *)(sx + lane * XP + q * 16);
-                    const unsigned ww[4] = {w.x, w.y, w.z, w.w};
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) { xv[8 * q + 2 * r] = __uint_as_float(ww[r] << 16); xv[8 * q + 2 * r + 1] = __uint_as_float(ww[r] & 0xffff0000u); }
-                }
-            } else {
-#pragma unroll
-                for (int q = 0; q < 8; ++q) { const f32x4 w = *(const f32x4 *)(sx + lane * XP + q * 16); xv[4 * q] = w.x; xv[4 * q + 1] = w.y; xv[4 * q + 2] = w.z; xv[4 * q + 3] = w.w; }
-            }
+            // this lane's row piece against its two code pieces, 4 elements at a time in ascending k (ONE FMA chain per code)
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
+                float w0, w1, w2, w3;
+                if (XBF16) {
+                    const uint2 w = *(const uint2 *)(sx + lane * XP + q * 8);
+                    w0 = __uint_as_float(w.x << 16); w1 = __uint_as_float(w.x & 0xffff0000u);
+                    w2 = __uint_as_float(w.y << 16); w3 = __uint_as_float(w.y & 0xffff0000u);
+                } else {
+                    const f32x4 w = *(const f32x4 *)(sx + lane * XP + q * 16);
+                    w0 = w.x; w1 = w.y; w2 = w.z; w3 = w.w;
+                }
                 const f32x4 u1 = *(const f32x4 *)(se1 + lane * EP + q * 16), u2 = *(const f32x4 *)(se2 + lane * EP + q * 16);
-                xy1 = __builtin_fmaf(xv[4 * q + 0], u1.x, xy1); xy1 = __builtin_fmaf(xv[4 * q + 1], u1.y, xy1);
-                xy1 = __builtin_fmaf(xv[4 * q + 2], u1.z, xy1); xy1 = __builtin_fmaf(xv[4 * q + 3], u1.w, xy1);
-                xy2 = __builtin_fmaf(xv[4 * q + 0], u2.x, xy2); xy2 = __builtin_fmaf(xv[4 * q + 1], u2.y, xy2);
-                xy2 = __builtin_fmaf(xv[4 * q + 2], u2.z, xy2); xy2 = __builtin_fmaf(xv[4 * q + 3], u2.w, xy2);
-            }
-            if (METRIC == 0) {
-#pragma unroll
-                for (int c = 0; c < 32; ++c) ch[c] += xv[c] * xv[c];
+                xy1 = __builtin_fmaf(w0, u1.x, xy1); xy1 = __builtin_fmaf(w1, u1.y, xy1);
+                xy1 = __builtin_fmaf(w2, u1.z, xy1); xy1 = __builtin_fmaf(w3, u1.w, xy1);
+                xy2 = __builtin_fmaf(w0, u2.x, xy2); xy2 = __builtin_fmaf(w1, u2.y, xy2);
+                xy2 = __builtin_fmaf(w2, u2.z, xy2); xy2 = __builtin_fmaf(w3, u2.w, xy2);
+                if (METRIC == 0) {
+                    ch[4 * q + 0] += w0 * w0; ch[4 * q + 1] += w1 * w1; ch[4 * q + 2] += w2 * w2; ch[4 * q + 3] += w3 * w3;
+                }
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   // this piece has been read before the next one is parked
             __builtin_amdgcn_wave_barrier();
@@ -1684,6 +1700,43 @@ __global__ void __launch_bounds__(VQ_PAIR_WAVES * 64) vq_pair_kernel(const PairA
         }
         if (base + lane < n) a.keys[pos] = (unsigned long long)(unsigned)win;
     }
+}
+
+template <int DT, bool XBF16, int METRIC>
+__global__ void __launch_bounds__(VQ_PAIR_WAVES * 64) vq_pair_kernel(const PairArgs a)
+{
+    __shared__ __attribute__((aligned(16))) char smem[PairCfg<XBF16>::SMEM];
+    vq_pair_body<DT, XBF16, METRIC>(a, smem, blockIdx.x, gridDim.x);
+}
+
+// The two exact passes are independent (open rows at the front of the list, pair rows at its back): ONE launch runs both side by
+// side -- workgroups [0, refine_blocks) sweep the codebook for the open rows, the rest decide the pair rows -- instead of two
+// small kernels back to back.
+template <int DT, bool XBF16, int METRIC>
+__global__ void __launch_bounds__(256, (DT <= 256 ? 2 : 1)) vq_listed_kernel(const RefineArgs r, const PairArgs p, const unsigned refine_blocks)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (blockIdx.x < refine_blocks) vq_refine_body<DT, XBF16, METRIC>(r, smem, blockIdx.x, refine_blocks);
+    else vq_pair_body<DT, XBF16, METRIC>(p, smem, blockIdx.x - refine_blocks, gridDim.x - refine_blocks);
+}
+
+template <int DT, bool XBF16, int METRIC>
+static int launch_listed(const RefineArgs &r, const PairArgs &p, unsigned gx, unsigned pair_blocks, hipStream_t st)
+{
+    constexpr int SMEM_R = 2 * (32 * DT + 256) * 4;
+    constexpr int SMEM = SMEM_R > PairCfg<XBF16>::SMEM ? SMEM_R : PairCfg<XBF16>::SMEM;
+    static VqAttrOnce once;
+    if (int rc = vq_set_max_smem(once, (const void *)vq_listed_kernel<DT, XBF16, METRIC>, SMEM, "vq_listed_kernel")) return rc;
+    hipLaunchKernelGGL((vq_listed_kernel<DT, XBF16, METRIC>), dim3(gx + pair_blocks), dim3(256), SMEM, st, r, p, gx);
+    return launch_status("vq_listed_kernel");
+}
+
+template <int DT>
+static int dispatch_listed(const RefineArgs &r, const PairArgs &p, int x_dtype, int metric, unsigned gx, unsigned pair_blocks, hipStream_t st)
+{
+    if (metric == VQHIP_EUCLID)
+        return x_dtype == VQHIP_BF16 ? launch_listed<DT, true, 0>(r, p, gx, pair_blocks, st) : launch_listed<DT, false, 0>(r, p, gx, pair_blocks, st);
+    return x_dtype == VQHIP_BF16 ? launch_listed<DT, true, 1>(r, p, gx, pair_blocks, st) : launch_listed<DT, false, 1>(r, p, gx, pair_blocks, st);
 }
 
 template <int DT>
@@ -1710,29 +1763,46 @@ int vq_assign_listed(const void *x, int x_dtype, int metric, int64_t N, int D, i
     const int64_t want = chunks * r.n_tiles;              // one workgroup per (chunk, tile) at most
     const unsigned gx = (unsigned)(want < VQ_REFINE_GRID ? want : VQ_REFINE_GRID);
     int rc;
-    switch (pick_dt(D)) {
-        case 32: rc = dispatch_refine<32>(r, x_dtype, metric, gx, st); break;
-        case 64: rc = dispatch_refine<64>(r, x_dtype, metric, gx, st); break;
-        case 128: rc = dispatch_refine<128>(r, x_dtype, metric, gx, st); break;
-        case 256: rc = dispatch_refine<256>(r, x_dtype, metric, gx, st); break;
-        case 512: rc = dispatch_refine<512>(r, x_dtype, metric, gx, st); break;
-        default: VQ_FAIL(VQHIP_EDIM, "assign_listed: D=%d unsupported", D);
-    }
-    if (rc) return rc;
-    if (with_pairs) {
-        PairArgs pa;
-        pa.x = x; pa.ldx = ldx; pa.embed = embed; pa.packed = packed; pa.D = D;
-        pa.row_list = row_list; pa.row_count = row_count; pa.cap = N; pa.keys = keys;
-        const int64_t pb = (N + VQ_PAIR_WAVES * 64 - 1) / (VQ_PAIR_WAVES * 64);
-        const unsigned blocks = (unsigned)(pb < 1024 ? pb : 1024);
+    // VQHIP_LISTED_MERGED=1: the two exact passes side by side in ONE launch (vq_listed_kernel).  Measured a wash against two
+    // launches back to back (cfg 2 +0.9 %, cfg 3 -1.4 %, cfg 5 +1.8 %: the pair rows' workgroups take the exact sweep's LDS and
+    // register budget), so the two-launch form stays the default.
+    static int split = -1;
+    if (split < 0) { const char *e = getenv("VQHIP_LISTED_MERGED"); split = (e && e[0] == '1') ? 0 : 1; }
+    PairArgs pa;
+    pa.x = x; pa.ldx = ldx; pa.embed = embed; pa.packed = packed; pa.D = D;
+    pa.row_list = row_list; pa.row_count = row_count; pa.cap = N; pa.keys = keys;
+    const int64_t pb = (N + VQ_PAIR_WAVES * 64 - 1) / (VQ_PAIR_WAVES * 64);
+    const unsigned blocks = (unsigned)(pb < 1024 ? pb : 1024);
+    if (with_pairs && !split) {
         switch (pick_dt(D)) {
-            case 32: rc = dispatch_pair<32>(pa, x_dtype, metric, blocks, st); break;
-            case 64: rc = dispatch_pair<64>(pa, x_dtype, metric, blocks, st); break;
-            case 128: rc = dispatch_pair<128>(pa, x_dtype, metric, blocks, st); break;
-            case 256: rc = dispatch_pair<256>(pa, x_dtype, metric, blocks, st); break;
-            default: rc = dispatch_pair<512>(pa, x_dtype, metric, blocks, st); break;
+            case 32: rc = dispatch_listed<32>(r, pa, x_dtype, metric, gx, blocks, st); break;
+            case 64: rc = dispatch_listed<64>(r, pa, x_dtype, metric, gx, blocks, st); break;
+            case 128: rc = dispatch_listed<128>(r, pa, x_dtype, metric, gx, blocks, st); break;
+            case 256: rc = dispatch_listed<256>(r, pa, x_dtype, metric, gx, blocks, st); break;
+            case 512: rc = dispatch_listed<512>(r, pa, x_dtype, metric, gx, blocks, st); break;
+            default: VQ_FAIL(VQHIP_EDIM, "assign_listed: D=%d unsupported", D);
         }
         if (rc) return rc;
+    } else {
+        switch (pick_dt(D)) {
+            case 32: rc = dispatch_refine<32>(r, x_dtype, metric, gx, st); break;
+            case 64: rc = dispatch_refine<64>(r, x_dtype, metric, gx, st); break;
+            case 128: rc = dispatch_refine<128>(r, x_dtype, metric, gx, st); break;
+            case 256: rc = dispatch_refine<256>(r, x_dtype, metric, gx, st); break;
+            case 512: rc = dispatch_refine<512>(r, x_dtype, metric, gx, st); break;
+            default: VQ_FAIL(VQHIP_EDIM, "assign_listed: D=%d unsupported", D);
+        }
+        if (rc) return rc;
+        if (with_pairs) {
+            switch (pick_dt(D)) {
+                case 32: rc = dispatch_pair<32>(pa, x_dtype, metric, blocks, st); break;
+                case 64: rc = dispatch_pair<64>(pa, x_dtype, metric, blocks, st); break;
+                case 128: rc = dispatch_pair<128>(pa, x_dtype, metric, blocks, st); break;
+                case 256: rc = dispatch_pair<256>(pa, x_dtype, metric, blocks, st); break;
+                default: rc = dispatch_pair<512>(pa, x_dtype, metric, blocks, st); break;
+            }
+            if (rc) return rc;
+        }
     }
     FinishArgs f;
     f.x = x; f.ldx = ldx;
