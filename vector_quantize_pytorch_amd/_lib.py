@@ -316,6 +316,8 @@ def rvq_chain_supported(x: torch.Tensor, C: int) -> bool:
     """can the residual loop run as a chain (every stage forms its input in its own prologue: vqhip_assign_screened_chain)?"""
     if not (x.is_cuda and x.dtype == torch.float32 and screening_enabled() and os.environ.get("VQHIP_RVQ_CHAIN", "1") != "0"):
         return False
+    if os.environ.get("VQHIP_SCREEN_VERIFY", "0") == "1" or screen_debug:
+        return False            # the paranoia / debug switches live in assign(): stage-by-stage loop
     xk, N, D, ldx = as_rows(x)
     return bool(N > 0 and lib().vqhip_screen_chain_supported(_dtype_code(xk), D) and lib().vqhip_screen_supported(N, D, C)
                 and xk.data_ptr() % 16 == 0 and (ldx * 4) % 16 == 0)

@@ -459,8 +459,29 @@ class Codebook(nn.Module):
                 ema_update_weight=None, accum_ema_update=False, ema_update=None, topk=None, update_usage=True):
         """Reference call shape (vqp.py:673-686): x is the *transformed* input; returns
         (quantize fp32, embed_ind, None) -- the N x C `dist` tensor is never produced."""
-        if codebook_transform_fn is not None or topk is not None:
-            raise NotImplementedError("codebook_transform_fn / topk are not on the MI355X hot path (SURVEY.md §8f)")
+        if topk is not None:
+            raise NotImplementedError("Codebook.forward(topk=): use VectorQuantize.forward(topk=) (vqhip_topk)")
+        if codebook_transform_fn is not None:
+            # QINCo (vqp.py:729-738, 769-776): one codebook per row; search = vqhip_assign_rowwise, quantize = a differentiable
+            # gather of the transformed codes, the EMA statistics (if any) go to the base codebook as usual (:783-784)
+            if self.num_codebooks != 1 or self.affine_param:
+                raise NotImplementedError("codebook_transform_fn: one codebook, no affine_param")
+            xf = x.float()
+            if not self._is_initted():
+                self.init_embed_(xf.detach().reshape(1, -1, self.dim), None if mask is None else mask.reshape(1, -1))
+            embed = self.embed if self.learnable_codebook else self.embed.detach()
+            if self.vq_bridge is not None:
+                embed = self.vq_bridge(embed)
+            te = codebook_transform_fn(embed)                                   # [1, b, n, c, d]
+            te = te.reshape(*xf.shape[:-1], te.shape[-2], te.shape[-1])
+            if self.use_cosine_sim:
+                te = torch.nn.functional.normalize(te, p=2, dim=-1, eps=1e-6)
+            ind = L.assign_rowwise(xf, te, cosine=self.use_cosine_sim)
+            q = te.gather(-2, ind[..., None, None].expand(*ind.shape, 1, te.shape[-1]))[..., 0, :]
+            if self.training and update_usage and not freeze_codebook:
+                self.update_indices(xf.detach(), ind, mask=mask, ema_update_weight=ema_update_weight,
+                                    accum_ema_update=accum_ema_update, ema_update=ema_update)
+            return q, ind, None
         r = self.quantize(x.float(), mask=mask, freeze_codebook=freeze_codebook, ema_update_weight=ema_update_weight,
                           accum_ema_update=accum_ema_update, ema_update=ema_update, update_usage=update_usage,
                           input_normalized=True)
