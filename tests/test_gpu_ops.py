@@ -214,6 +214,25 @@ def test_decode_sum(dev):
     assert (out1 - want1).abs().max().item() <= 1e-6
 
 
+@pytest.mark.parametrize("N,Q,C,D,out_dtype", [(20000, 8, 1024, 256, torch.float32), (16385, 3, 37, 64, torch.float32), (70001, 11, 512, 128, torch.bfloat16),
+                                               (32768, 2, 1000, 512, torch.float32)])
+def test_decode_sum_shared_codebook_from_lds(dev, N, Q, C, D, out_dtype):
+    """vq_decode_lds_kernel (shared codebook, column slices of the codes in LDS): bit-equal to the stage-order running sum of the
+    gathered rows (rvq.py:525), dropped stages (-1) add nothing, ragged row counts, more than 8 stages."""
+    from vector_quantize_pytorch_amd import _lib as L
+    g = torch.Generator(device=dev).manual_seed(N)
+    e = torch.randn(C, D, device=dev, generator=g)
+    idx = torch.randint(0, C, (N, Q), device=dev, generator=g)
+    idx[::7, Q - 1] = -1
+    idx[5, :] = -1
+    out = L.decode_sum(idx, e, out_dtype=out_dtype)
+    want = torch.zeros(N, D, device=dev)
+    for q in range(Q):
+        ok = (idx[:, q] >= 0)[:, None]
+        want = torch.where(ok, want + e[idx[:, q].clamp(min=0)], want)
+    assert torch.equal(out, want.to(out_dtype))
+
+
 @pytest.mark.parametrize("N,C,D,Q,dtype,shared", [(300, 64, 512, 3, torch.float32, True), (515, 100, 128, 4, torch.float32, False),
                                                    (1000, 256, 256, 8, torch.bfloat16, True), (129, 33, 32, 2, torch.float32, False)])
 def test_fused_rvq_kernel_vs_stagewise_oracle(dev, N, C, D, Q, dtype, shared):

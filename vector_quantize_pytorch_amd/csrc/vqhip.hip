@@ -2997,6 +2997,50 @@ __global__ void __launch_bounds__(256) vq_decode_kernel(const int64_t *__restric
     }
 }
 
+// One codebook shared by all stages and small enough that a 32-column slice of it fits in LDS (C <= 1024: 128 KiB): the
+// row-per-wave kernel above gathers Q code rows per output row from L2 (cfg 3: 8 KiB gathered per 1 KiB written, 1.4 TB/s of
+// output); here a workgroup parks columns [32 s, 32 s + 32) of every code in LDS once and then streams its share of the rows --
+// 8 lanes per row, 16 bytes each, the Q gathers come from LDS (conflict-free: consecutive lanes, consecutive 16-byte pieces of a
+// 128-byte row), the sums run in stage order like the reference's (rvq.py:525), and every store is a whole 128-byte line.
+#define VQ_DECODE_LDS_COLS 32
+__global__ void __launch_bounds__(1024) vq_decode_lds_kernel(const int64_t *__restrict__ idx, int64_t N, int Q, const float *__restrict__ embed,
+                                                             int C, int D, void *out, int out_bf16, int64_t ldo, int rows_per_block)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int nsl = D / VQ_DECODE_LDS_COLS;
+    const int sl = blockIdx.x % nsl;                       // column slice
+    const int64_t rb = blockIdx.x / nsl;                   // row chunk
+    // codes: 8 lanes x 16 bytes per code row slice
+    for (int i = tid; i < C * 8; i += blockDim.x)
+        *(f32x4 *)(smem + (size_t)i * 16) = *(const f32x4 *)(embed + (size_t)(i >> 3) * D + sl * VQ_DECODE_LDS_COLS + (i & 7) * 4);
+    __syncthreads();
+    const int part = tid & 7;                              // which 16 bytes of the slice
+    const int64_t r0 = rb * rows_per_block, r1 = (r0 + rows_per_block < N) ? r0 + rows_per_block : N;
+    for (int64_t n = r0 + (tid >> 3); n < r1; n += blockDim.x >> 3) {
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        for (int q0 = 0; q0 < Q; q0 += 8) {
+            // lane `part` of the row's group fetches stage q0 + part's index; the group shares them by shuffle
+            const int64_t mine = (q0 + part < Q) ? idx[n * Q + q0 + part] : -1;
+            const int lo = (int)mine;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int c = __shfl(lo, (threadIdx.x & 63 & ~7) + u, 64);
+                if (q0 + u < Q && c >= 0 && c < C) s += *(const f32x4 *)(smem + ((size_t)c * 8 + part) * 16);   // a skipped stage adds nothing
+            }
+        }
+        const int d = sl * VQ_DECODE_LDS_COLS + part * 4;
+        if (out_bf16) {
+            uint2 w;
+            w.x = (unsigned)f32_to_bf16_rne(s.x) | ((unsigned)f32_to_bf16_rne(s.y) << 16);
+            w.y = (unsigned)f32_to_bf16_rne(s.z) | ((unsigned)f32_to_bf16_rne(s.w) << 16);
+            *(uint2 *)((unsigned short *)out + n * ldo + d) = w;
+        } else {
+            *(f32x4 *)((float *)out + n * ldo + d) = s;
+        }
+    }
+}
+
 extern "C" int vqhip_decode_sum(const int64_t *idx, int64_t N, int Q, const float *embed, int64_t embed_qstride,
                                 int C, int D, void *out, int out_dtype, int64_t ldo, void *stream)
 {
@@ -3008,6 +3052,22 @@ extern "C" int vqhip_decode_sum(const int64_t *idx, int64_t N, int Q, const floa
     const int oes = (out_dtype == VQHIP_BF16) ? 2 : 4;
     const bool vec = (D % 4 == 0) && (embed_qstride % 4 == 0) && ((((uintptr_t)embed) & 15) == 0) &&
                      ((((uintptr_t)out) % (4 * oes)) == 0) && ((ldo * oes) % (4 * oes) == 0);
+    static int lds_ok = -1;      // VQHIP_DECODE_LDS=0: always the row-per-wave kernel (A/B runs)
+    if (lds_ok < 0) { const char *e = getenv("VQHIP_DECODE_LDS"); lds_ok = (e && e[0] == '0') ? 0 : 1; }
+    if (vec && lds_ok && Q >= 2 && (embed_qstride == 0 || Q == 1) && C <= 1024 && D % VQ_DECODE_LDS_COLS == 0 && N >= 16384) {
+        // shared codebook, several stages: the codes' column slices live in LDS (the gathers from L2 were the bound)
+        const int smem = C * VQ_DECODE_LDS_COLS * 4;
+        static VqAttrOnce once;
+        if (int rc = vq_set_max_smem(once, (const void *)vq_decode_lds_kernel, 1024 * VQ_DECODE_LDS_COLS * 4, "vq_decode_lds_kernel")) return rc;
+        const int nsl = D / VQ_DECODE_LDS_COLS;
+        // about four workgroups per CU and slice-group; every workgroup re-reads its slice of the codebook (C * 128 bytes)
+        int64_t chunks = (256 * 4) / nsl; if (chunks < 1) chunks = 1;
+        int64_t rpb = (N + chunks - 1) / chunks; rpb = (rpb + 127) / 128 * 128;
+        chunks = (N + rpb - 1) / rpb;
+        hipLaunchKernelGGL(vq_decode_lds_kernel, dim3((unsigned)(chunks * nsl)), dim3(1024), smem, (hipStream_t)stream, idx, N, Q, embed, C, D,
+                           out, out_dtype == VQHIP_BF16, ldo, (int)rpb);
+        return launch_status("vq_decode_lds_kernel");
+    }
     if (vec)
         hipLaunchKernelGGL(vq_decode_kernel<true>, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, (hipStream_t)stream, idx, N, Q, embed,
                            embed_qstride, C, D, out, out_dtype == VQHIP_BF16, ldo);
