@@ -165,6 +165,8 @@ int vqhip_route_bwd(const void *x, const void *q, const void *g_out, int dtype, 
 
 /* sum of `n` doubles times `scale` -> one fp32 (commit loss = scale * sum of partials). */
 int vqhip_reduce_partials(const double *partials, int64_t n, double scale, float *out, void *stream);
+/* R rows of partials in one launch (the per-stage losses of a residual VQ): out[r] = scale * sum(partials[r * stride .. + n)). */
+int vqhip_reduce_partials_rows(const double *partials, int R, int64_t n, int64_t stride, double scale, float *out, void *stream);
 
 /* ---- EMA sufficient statistics ----------------------------------------------------------------
  * Replaces embed_onehot.sum(1) and einsum('h n d, h n c -> h c d') (vqp.py:602, 605).
@@ -204,6 +206,13 @@ int vqhip_ema_finalize(float *cluster_size, float *embed_avg, float *embed,
                        const float *count, const float *embed_sum, const float *weight,
                        int C, int D, float one_minus_decay, float eps, int cosine,
                        int do_lerp, int do_update_ema, float *denom_ws, void *stream);
+
+/* The Q folds of a codebook shared by the stages of a residual VQ (residual_vq.py:213-217: every stage's update_codebook lerps
+ * its statistics into the one codebook, vqp.py:616-617; the renormalisation update_ema runs once afterwards, rvq.py:593-598) in
+ * one call: the same lerps in the same (stage) order.  stats: Q blocks of `stride` floats, each embed_sum [C, D] then count [C]. */
+int vqhip_ema_fold_many(float *cluster_size, float *embed_avg, float *embed, const float *stats, int Q, int64_t stride,
+                        int C, int D, float one_minus_decay, float eps, int cosine, int do_update_ema, float *denom_ws,
+                        void *stream);
 
 /* ---- decode -----------------------------------------------------------------------------------
  * Replaces codebook[indices] (vqp.py:1003) and get_at('q [c] d, b n q -> q b n d') + sum over q

@@ -197,6 +197,37 @@ def test_ema_finalize(dev, C, D, cos):
         assert torch.equal(d["e"].cpu(), st.embed[0])              # incl. ATen-order sum of cluster_size
 
 
+@pytest.mark.parametrize("C,D,Q,cos", [(1024, 256, 8, False), (300, 100, 3, False), (64, 32, 5, True)])
+def test_ema_fold_many_equals_successive_folds(dev, C, D, Q, cos):
+    """vqhip_ema_fold_many (the Q folds of a codebook shared by the stages of a residual VQ + one renormalisation, rvq.py:213-217,
+    593-598) == Q calls of vqhip_ema_finalize(do_lerp) followed by one update_ema, bit for bit; vqhip_reduce_partials_rows == rows
+    of vqhip_reduce_partials."""
+    from vector_quantize_pytorch_amd import _lib as L
+    g = torch.Generator(device=dev).manual_seed(C + Q)
+    cs = torch.rand(C, device=dev, generator=g) * 5
+    ea = torch.randn(C, D, device=dev, generator=g)
+    e = torch.randn(C, D, device=dev, generator=g)
+    stride = (C * D + C + 3) // 4 * 4
+    stats = torch.zeros(Q, stride, device=dev)
+    stats[:, : C * D] = torch.randn(Q, C * D, device=dev, generator=g) * 3
+    stats[:, C * D: C * D + C] = torch.randint(0, 9, (Q, C), device=dev, generator=g).float()
+    a = [t.clone() for t in (cs, ea, e)]
+    b = [t.clone() for t in (cs, ea, e)]
+    L.ema_fold_many(*a, stats, decay=0.8, eps=1e-5, cosine=cos, do_update_ema=True)
+    for q in range(Q):
+        L.ema_finalize(*b, stats[q, C * D: C * D + C], stats[q, : C * D].view(C, D), decay=0.8, eps=1e-5, cosine=cos, do_lerp=True, do_update_ema=False)
+    L.ema_finalize(*b, None, None, decay=0.8, eps=1e-5, cosine=cos, do_lerp=False, do_update_ema=True)
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+    c2 = [t.clone() for t in (cs, ea, e)]
+    L.ema_fold_many(*c2, stats, decay=0.8, eps=1e-5, cosine=cos, do_update_ema=False)      # folds only: embed untouched
+    assert torch.equal(c2[2], e) and torch.equal(c2[0], a[0]) and torch.equal(c2[1], a[1])
+    parts = torch.randn(Q, 777, device=dev, generator=g, dtype=torch.float64)
+    rows = L.reduce_partials_rows(parts, 0.5)
+    one = torch.stack([L.reduce_partials(parts[q], 777, 0.5) for q in range(Q)])
+    assert torch.equal(rows, one)
+
+
 def test_decode_sum(dev):
     from vector_quantize_pytorch_amd import _lib as L
     g = torch.Generator().manual_seed(2)

@@ -46,6 +46,10 @@ def lib():
     L.vqhip_pack_codebook.argtypes = [vp, i32, i32, vp, vp]
     L.vqhip_assign.argtypes = [vp, i32, i64, i32, i64, vp, vp, i32, i32, vp, vp, i32, i64, vp, vp, vp, vp, vp]
     L.vqhip_reduce_partials.argtypes = [vp, i64, f64, vp, vp]
+    L.vqhip_reduce_partials_rows.argtypes = [vp, i32, i64, i64, f64, vp, vp]
+    L.vqhip_reduce_partials_rows.restype = i32
+    L.vqhip_ema_fold_many.argtypes = [vp, vp, vp, vp, i32, i64, i32, i32, f32, f32, i32, i32, vp, vp]
+    L.vqhip_ema_fold_many.restype = i32
     L.vqhip_rvq_forward.argtypes = [vp, i32, i64, i32, i64, vp, i64, vp, i64, i32, i32, vp, vp, vp, vp, vp]
     L.vqhip_rvq_forward.restype = i32
     L.vqhip_scores.argtypes = [vp, i32, i64, i32, i64, vp, vp, i32, i32, vp, i64, vp, vp, vp]
@@ -99,7 +103,7 @@ def lib():
 
 EXPORTS = ("vqhip_version", "vqhip_last_error", "vqhip_packed_bytes", "vqhip_pack_codebook",
            "vqhip_assign_blocks", "vqhip_assign", "vqhip_screen_supported", "vqhip_screen_workspace_bytes",
-           "vqhip_screen_blocks", "vqhip_screen_partials", "vqhip_assign_screened", "vqhip_screen_chain_supported", "vqhip_assign_screened_chain", "vqhip_l2norm_rows", "vqhip_scores", "vqhip_rvq_forward", "vqhip_reduce_partials", "vqhip_ema_workspace_bytes", "vqhip_ema_accumulate", "vqhip_ema_sqerr_partials", "vqhip_ema_accumulate_sqerr",
+           "vqhip_screen_blocks", "vqhip_screen_partials", "vqhip_assign_screened", "vqhip_screen_chain_supported", "vqhip_assign_screened_chain", "vqhip_l2norm_rows", "vqhip_scores", "vqhip_rvq_forward", "vqhip_reduce_partials", "vqhip_reduce_partials_rows", "vqhip_ema_fold_many", "vqhip_ema_workspace_bytes", "vqhip_ema_accumulate", "vqhip_ema_sqerr_partials", "vqhip_ema_accumulate_sqerr",
            "vqhip_ema_finalize", "vqhip_decode_sum", "vqhip_row_sumsq", "vqhip_assign_rowwise", "vqhip_score_indices", "vqhip_topk", "vqhip_expire_scatter", "vqhip_kmeans_update", "vqhip_route_fwd", "vqhip_route_bwd")
 
 
@@ -472,6 +476,33 @@ def reduce_partials(partials: torch.Tensor, n: int, scale: float, out: torch.Ten
 
 
 @_on_device
+def reduce_partials_rows(partials: torch.Tensor, scale: float = 1.0) -> torch.Tensor:
+    """partials [R, P] float64 -> [R] float32: one launch for the per-stage losses of a residual VQ"""
+    _need_gpu(partials)
+    assert partials.dtype == torch.float64 and partials.ndim == 2 and partials.stride(1) == 1
+    out = torch.empty(partials.shape[0], dtype=torch.float32, device=partials.device)
+    _check(lib().vqhip_reduce_partials_rows(_ptr(partials), partials.shape[0], partials.shape[1], partials.stride(0), float(scale),
+                                            _ptr(out), _stream()), "vqhip_reduce_partials_rows")
+    return out
+
+
+@_on_device
+def ema_fold_many(cluster_size, embed_avg, embed, stats, *, decay, eps, cosine=False, do_update_ema=True, denom_ws=None):
+    """Q successive folds of one (shared) codebook in one call: stats [Q, stride >= C D + C] float32, each row embed_sum [C, D]
+    followed by count [C]; in place on cluster_size [C], embed_avg [C, D], embed [C, D]."""
+    _need_gpu(cluster_size, embed_avg, embed, stats)
+    C, D = embed.shape
+    for t in (cluster_size, embed_avg, embed):
+        assert t.is_contiguous() and t.dtype == torch.float32
+    assert stats.dtype == torch.float32 and stats.ndim == 2 and stats.stride(1) == 1 and stats.shape[1] >= C * D + C
+    if denom_ws is None and do_update_ema:
+        denom_ws = torch.empty(C, dtype=torch.float32, device=embed.device)
+    omd = float(torch.tensor(1.0 - decay, dtype=torch.float64).to(torch.float32))
+    _check(lib().vqhip_ema_fold_many(_ptr(cluster_size), _ptr(embed_avg), _ptr(embed), _ptr(stats), stats.shape[0], stats.stride(0),
+                                     C, D, omd, float(eps), int(cosine), int(do_update_ema), _ptr(denom_ws), _stream()), "vqhip_ema_fold_many")
+
+
+@_on_device
 def stats_sqerr_supported(x: torch.Tensor, cosine=False) -> bool:
     """can the statistics pass also sum the commitment loss' squared error for these rows (vqhip_ema_accumulate_sqerr)?"""
     if cosine or not x.is_cuda or x.dtype not in (torch.float32, torch.bfloat16) or os.environ.get("VQHIP_STATS_SQERR", "1") == "0":
@@ -483,7 +514,7 @@ def stats_sqerr_supported(x: torch.Tensor, cosine=False) -> bool:
 
 @_on_device
 def ema_accumulate(x: torch.Tensor, idx: torch.Tensor, C: int, *, cosine=False, rnorm=None, row_mask=None,
-                   count=None, embed_sum=None, idx_stride=1, idx_offset=0, sqerr_from=None):
+                   count=None, embed_sum=None, idx_stride=1, idx_offset=0, sqerr_from=None, sqerr_out=None):
     """Accumulates into (count [C], embed_sum [C, D]); allocates zeroed ones if not given.
     sqerr_from = (packed, embed): also returns the squared-error partials of the commitment loss, summed by the same pass
     (-> count, embed_sum, partials [P] float64); requires stats_sqerr_supported(x)."""
@@ -504,7 +535,12 @@ def ema_accumulate(x: torch.Tensor, idx: torch.Tensor, C: int, *, cosine=False, 
         if sqerr_from is not None:
             packed, embed = sqerr_from
             assert not cosine and embed.dtype == torch.float32 and embed.is_contiguous() and tuple(embed.shape) == (C, D)
-            partials = torch.empty(lib().vqhip_ema_sqerr_partials(N, C), dtype=torch.float64, device=dev)
+            npart = lib().vqhip_ema_sqerr_partials(N, C)
+            if sqerr_out is not None:          # a row of a caller-owned [Q, P] buffer (one batched reduction afterwards)
+                assert sqerr_out.dtype == torch.float64 and sqerr_out.is_contiguous() and sqerr_out.numel() == npart
+                partials = sqerr_out
+            else:
+                partials = torch.empty(npart, dtype=torch.float64, device=dev)
             _check(lib().vqhip_ema_accumulate_sqerr(_ptr(xk), _dtype_code(xk), N, D, ldx, idx_ptr, idx_stride, _ptr(row_mask), C,
                                                     _ptr(count), _ptr(embed_sum), _ptr(ws), nbytes, _ptr(packed), _ptr(embed),
                                                     _ptr(partials), _stream()), "vqhip_ema_accumulate_sqerr")

@@ -2235,6 +2235,29 @@ extern "C" int vqhip_reduce_partials(const double *partials, int64_t n, double s
     return launch_status("vq_reduce_kernel");
 }
 
+// R rows of partials in one launch (the per-stage losses of a residual VQ): out[r] = scale * sum(partials[r * stride .. + n))
+__global__ void __launch_bounds__(256) vq_reduce_rows_kernel(const double *__restrict__ p, int64_t n, int64_t stride, double scale, float *out)
+{
+    __shared__ double red[256];
+    const double *row = p + (size_t)blockIdx.x * stride;
+    double s = 0.0;
+    for (int64_t i = threadIdx.x; i < n; i += 256) s += row[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o >= 1; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[blockIdx.x] = (float)(red[0] * scale);
+}
+
+extern "C" int vqhip_reduce_partials_rows(const double *partials, int R, int64_t n, int64_t stride, double scale, float *out, void *stream)
+{
+    if (!out || R < 1 || n < 0 || stride < n || (n > 0 && !partials)) VQ_FAIL(VQHIP_EINVAL, "reduce_partials_rows: bad argument");
+    hipLaunchKernelGGL(vq_reduce_rows_kernel, dim3(R), dim3(256), 0, (hipStream_t)stream, partials, n, stride, scale, out);
+    return launch_status("vq_reduce_rows_kernel");
+}
+
 // ------------------------------------------------------------------------------------------------
 // EMA sufficient statistics: counting sort of the rows by code, then full-row segmented sums.
 //
@@ -2830,6 +2853,76 @@ extern "C" int vqhip_ema_finalize(float *cluster_size, float *embed_avg, float *
         hipLaunchKernelGGL(vq_ema_embed_kernel, dim3((C + 3) / 4), dim3(256), 0, st, embed_avg, embed, embed_sum, weight,
                            denom_ws, C, D, one_minus_decay, cosine, do_lerp, do_update_ema);
     return launch_status("vq_ema_finalize");
+}
+
+// A codebook shared by the Q stages of a residual VQ is lerp-ed Q times in stage order (rvq.py:213-217 + vqp.py:616-617: every
+// stage's update_codebook folds its statistics; the renormalisation runs once at the end, rvq.py:593-598).  The lerps are
+// element-wise, so one launch applies all Q of them -- the same aten_lerp calls in the same order, bit for bit -- instead of
+// 2 Q launches.  stats: Q blocks of `stride` floats, each embed_sum [C, D] followed by count [C].
+__global__ void __launch_bounds__(256) vq_ema_cs_lerp_many_kernel(float *cs, const float *stats, int Q, int64_t stride, int C, int D, float omd)
+{
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    float v = cs[c];
+    for (int q = 0; q < Q; ++q) v = aten_lerp(v, stats[(size_t)q * stride + (size_t)C * D + c], omd);
+    cs[c] = v;
+}
+
+__global__ void __launch_bounds__(256) vq_ema_embed_many_kernel(float *embed_avg, float *embed, const float *stats, int Q, int64_t stride,
+                                                                const float *denom, int C, int D, float omd, int cosine, int do_update)
+{
+    const int lane = threadIdx.x & 63;
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (c >= C) return;
+    const float den = do_update ? denom[c] : 1.f;
+    float e[8];
+    float ss = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int d = lane + 64 * k;
+        e[k] = 0.f;
+        if (d < D) {
+            const size_t o = (size_t)c * D + d;
+            float ea = embed_avg[o];
+            for (int q = 0; q < Q; ++q) ea = aten_lerp(ea, stats[(size_t)q * stride + o], omd);
+            embed_avg[o] = ea;
+            if (do_update) {
+                e[k] = ea / den;
+                ss += e[k] * e[k];
+            }
+        }
+    }
+    if (!do_update) return;
+    float inv = 1.f;
+    if (cosine) {
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) ss += __shfl_xor(ss, o, 64);
+        inv = fmaxf(sqrtf(ss), 1e-6f);
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int d = lane + 64 * k;
+        if (d < D) embed[(size_t)c * D + d] = cosine ? (e[k] / inv) : e[k];
+    }
+}
+
+extern "C" int vqhip_ema_fold_many(float *cluster_size, float *embed_avg, float *embed, const float *stats, int Q, int64_t stride,
+                                   int C, int D, float one_minus_decay, float eps, int cosine, int do_update_ema, float *denom_ws,
+                                   void *stream)
+{
+    if (!cluster_size || !embed_avg || !embed || !stats || C <= 0 || Q < 1) VQ_FAIL(VQHIP_EINVAL, "ema_fold_many: bad argument");
+    if (D < 1 || D > 512) VQ_FAIL(VQHIP_EDIM, "ema_fold_many: D=%d unsupported (1..512)", D);
+    if (stride < (int64_t)C * D + C) VQ_FAIL(VQHIP_EINVAL, "ema_fold_many: stride smaller than C D + C");
+    if (do_update_ema && !denom_ws) VQ_FAIL(VQHIP_EINVAL, "ema_fold_many: do_update_ema needs denom_ws");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(vq_ema_cs_lerp_many_kernel, dim3((C + 255) / 256), dim3(256), 0, st, cluster_size, stats, Q, stride, C, D, one_minus_decay);
+    if (do_update_ema) {
+        const float ceps = (float)((double)C * (double)eps);
+        hipLaunchKernelGGL(vq_ema_denom_kernel, dim3(1), dim3(256), (C <= 16384 ? (size_t)C * 4 : 0), st, cluster_size, C, eps, ceps, denom_ws);
+    }
+    hipLaunchKernelGGL(vq_ema_embed_many_kernel, dim3((C + 3) / 4), dim3(256), 0, st, embed_avg, embed, stats, Q, stride, denom_ws, C, D,
+                       one_minus_decay, cosine, do_update_ema);
+    return launch_status("vq_ema_fold_many");
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -295,13 +295,17 @@ class ResidualVQ(nn.Module):
         # stage re-reads its input to write a residual; the commitment loss' squared error then comes from the per-stage
         # statistics pass, which reads every row next to its code anyway (needs `update`; without a loss nothing is needed)
         chain = (L.screening_enabled() and D in (32, 64, 128, 256) and L.rvq_chain_supported(x, C) and (update or not want_loss))
-        sq_parts = [None] * Q
+        sq_parts = None
+        if chain and want_loss:             # one [Q, P] buffer of loss partials: one batched reduction after the loop
+            nrows = x.numel() // D
+            sq_parts = torch.empty(Q, L.lib().vqhip_ema_sqerr_partials(nrows, C), dtype=torch.float64, device=x.device)
 
         def accumulate(q, stage_input, idx_all):
             kw = dict(row_mask=mask, count=buf[q, C * D: C * D + C], embed_sum=buf[q, : C * D].view(C, D), idx_offset=q, idx_stride=Q)
             if chain and want_loss:
                 e_q = embed if self.shared_codebook else embed[q]
-                sq_parts[q] = L.ema_accumulate(stage_input, idx_all, C, sqerr_from=(packed if self.shared_codebook else packed[q], e_q), **kw)[2]
+                L.ema_accumulate(stage_input, idx_all, C, sqerr_from=(packed if self.shared_codebook else packed[q], e_q),
+                                 sqerr_out=sq_parts[q], **kw)
             else:
                 L.ema_accumulate(stage_input, idx_all, C, **kw)
 
@@ -341,9 +345,6 @@ class ResidualVQ(nn.Module):
             stage_in = (lambda q: r["inputs"][q]) if r.get("inputs") is not None else (lambda q: resid[..., q, :])
             if side is not None:
                 torch.cuda.current_stream(x.device).wait_stream(side)
-                for p_ in sq_parts:
-                    if p_ is not None:
-                        p_.record_stream(torch.cuda.current_stream(x.device))   # allocated on the statistics stream, reduced here
             else:
                 for q in range(Q):
                     accumulate(q, stage_in(q), idx)
@@ -351,7 +352,7 @@ class ResidualVQ(nn.Module):
         losses = torch.zeros(self.num_quantizers, device=x.device, dtype=torch.float32)
         if want_loss:
             if chain:
-                sums = torch.stack([L.reduce_partials(sq_parts[q], sq_parts[q].numel(), 1.0) for q in range(Q)])
+                sums = L.reduce_partials_rows(sq_parts)
             else:
                 sums = torch.stack([L.reduce_partials(r["sqerr_partials"][q], r["sqerr_partials"].shape[1], 1.0) for q in range(Q)])
             denom = float(x.numel()) if mask is None else (mask.sum() * D).to(torch.float32)
@@ -362,14 +363,21 @@ class ResidualVQ(nn.Module):
         if update:
             if vq0._codebook.use_ddp:
                 dist.all_reduce(buf)
-            for q in range(Q):
-                cb = self.layers[q]._codebook
-                cb._fold_stats(0, buf[q, C * D: C * D + C], buf[q, : C * D].view(C, D), None, False, cb.ema_update)
-                if not self.shared_codebook:                        # vqp.py:641: expire_codes_(flatten, seq_mask = mask)
-                    cb.expire_codes_(stage_in(q).reshape(1, -1, D),
-                                     seq_mask=None if mask is None else mask.reshape(1, -1).bool())
-            if self.shared_codebook and self.vq_is_ema_updating:    # rvq.py:593-598 (dead-code replacement never gets here:
-                vq0._codebook.update_ema()                           # _fused_eligible sends it to the per-stage path)
+            cb0 = vq0._codebook
+            if self.shared_codebook and cb0.cluster_size.grad is None and cb0.embed_avg.grad is None:
+                # the Q folds of the one codebook (stage order, vqp.py:616-617) and its renormalisation (rvq.py:593-598) in one call
+                cs, ea, e = cb0._views(0)
+                L.ema_fold_many(cs, ea, e, buf, decay=cb0.decay, eps=cb0.eps, cosine=cb0.use_cosine_sim,
+                                do_update_ema=bool(self.vq_is_ema_updating))
+            else:
+                for q in range(Q):
+                    cb = self.layers[q]._codebook
+                    cb._fold_stats(0, buf[q, C * D: C * D + C], buf[q, : C * D].view(C, D), None, False, cb.ema_update)
+                    if not self.shared_codebook:                        # vqp.py:641: expire_codes_(flatten, seq_mask = mask)
+                        cb.expire_codes_(stage_in(q).reshape(1, -1, D),
+                                         seq_mask=None if mask is None else mask.reshape(1, -1).bool())
+                if self.shared_codebook and self.vq_is_ema_updating:    # rvq.py:593-598 (dead-code replacement never gets here:
+                    vq0._codebook.update_ema()                           # _fused_eligible sends it to the per-stage path)
 
         if Q < self.num_quantizers:
             pad = torch.full((*idx.shape[:-1], self.num_quantizers - Q), -1, device=x.device, dtype=torch.long)
