@@ -1,29 +1,34 @@
-// vq_screen.hip -- screened nearest-code assignment, gfx950 only.  D in {32, 64, 128, 256}; bf16 rows (vq_screen_kernel)
-// and fp32 rows (vq_screen_f32_kernel, further down); Euclidean metric, or cosine on unit-norm rows (METRIC 1).
+// vq_screen.hip -- screened nearest-code assignment, gfx950 only.  D in {32, 64, 128, 256, 512}; bf16 and fp32 rows; Euclidean
+// metric, or cosine on unit-norm rows (METRIC 1).
 //
-// The exact kernel (vqhip.hip, vq_assign_kernel) evaluates the reference's cdist (vqp.py:58-62) bit for bit on the
-// fp32 MFMA pipe, which runs at 1/16 of the bf16 MFMA rate.  The same INDICES can be had much cheaper, still exactly
-// (described for bf16 rows and the Euclidean metric; the other variants state their differences where they are defined):
+// The exact kernel (vqhip.hip, vq_assign_kernel) evaluates the reference's cdist (vqp.py:58-62) bit for bit on the fp32 MFMA pipe,
+// which runs at 1/16 of the 16-bit MFMA rate.  The same INDICES can be had much cheaper, still exactly:
 //
-//   1. screen (this file): bf16 rows are exact MFMA operands; the fp32 codebook is split c = c_hi + c_lo into two
-//      bf16 parts (bf16 keeps 8 significant bits: |c - c_hi - c_lo| <= 2^-16 |c|) and  t[n, c] = x_n . c_hi + x_n . c_lo - ||c||^2 / 2  is
-//      accumulated by v_mfma_f32_32x32x16_bf16 (2 passes at 16x the fp32 rate).  argmax_c t = argmin_c cdist up to an
-//      error eps(n) that is bounded below; per row the kernel keeps the best and the second best t.
-//   2. a row whose margin (best - second) exceeds the bound has a certified winner: every other code is farther in
-//      the reference's own fp32 arithmetic as well, ties of the rounded sqrt included.  Its index, its gathered code
-//      and its squared error are final.
-//   3. the few rows that are not certified (a fraction of a percent to a few percent) are appended to a list and
-//      re-done by the exact kernel (vq_assign_listed), which overwrites their outputs.
+//   1. screen: an approximate score t[n, c] ~ x_n . c - ||c||^2 / 2 on the 16-bit MFMA pipe whose error against the reference's own
+//      fp32 arithmetic is BOUNDED (eps(n) below); per row the kernel keeps the best, second and third t.
+//   2. a row whose margin (best - second) exceeds the bound has a certified winner: every other code is farther in the reference's
+//      fp32 arithmetic as well, ties of the rounded sqrt included.  Its index (and gathered code, residual, squared error) are final.
+//   3. a row whose margin to the THIRD exceeds the bound has exactly two candidates: two distances in the exact arithmetic decide
+//      (vq_pair_kernel, vqhip.hip).  The rest (a fraction of a percent) is re-done by the exact sweep (vq_refine_kernel).
 //
-// Error bound, in units of s = ||x||^2 + ||c||^2 - 2 x.c (u = 2^-24, D features, X = ||x||, Y = max_c ||c||):
+// Kernels in this file, newest first (what runs by default is marked *):
+//   * vq_screen16_kernel      single-pass fp16 screen, two 32-row blocks per wave, D <= 256: bf16 rows (exact fp16 operands after a
+//                             power-of-two scaling) and fp32 rows (one fp16 operand set, measured residual in the bound); paired
+//                             sweep (every A fragment read from LDS once for both row blocks, the previous tile's top-3 fold between
+//                             this tile's MFMAs); residual chain in the prologue (vqhip_assign_screened_chain)
+//   * vq_screen16_1rb_kernel  one row block per wave: D = 512, and the two-operand-set fp32 variant (VQHIP_SCREEN_F32_2PART=1)
+//     vq_screen_kernel / vq_screen_f32_kernel   round 1: two-pass bf16 hi/lo split of the codebook, top 2 (VQHIP_SCREEN_BF16X2=1, A/B)
+//
+// Error bound of the round-1 kernels, in units of s = ||x||^2 + ||c||^2 - 2 x.c (u = 2^-24, D features, X = ||x||, Y = max_c ||c||); the
+// fp16 kernels state their own terms where they compute eps (codebook rounding through the exact residual norm, D + 1 accumulated terms):
 //   reference chain (oracle/vq_oracle.c::vqo_assign):  |s_ref - s| <= u (x2 + y2) + u s + 2 D u X Y
 //   screen:  split 2 * 2^-16 X Y = 512 u X Y;  accumulation of 2 D products + the initial value inside the MFMAs, modelled as one
-//            rounding per added term with TRUNCATION (2u) -- pessimistic for a fused dot-product unit --
-//            2 * 2 D * 2u * (X Y + Y^2 / 2) = 8 D u (X Y + Y^2 / 2)
+//            rounding per added term with TRUNCATION (2u) -- pessimistic for a fused dot-product unit; measured at < 9 % of the model,
+//            tests/test_gpu_screen_fuzz.py::test_mfma_accumulation_error_within_model --  2 * 2 D * 2u * (X Y + Y^2 / 2)
 //   sqrt collapse: distances that differ by < 4 ulp(s) may round to the same sqrt (vqp.py:62) and tie: 8 u s
 //   index bits: the kernel stores the lane-local code number in the 4 low mantissa bits of t: 2 * 16 ulp(t)
-// A row is certified when  t_best - t_second > eps_t,  eps_t = eps_s (an s margin of 2 eps_s).  tests/test_gpu_ops.py
-// measures the actual |t - t_exact| against this bound (observed: below 5 % of it) and checks indices bit for bit.
+// A row is certified when  t_best - t_second > eps_t,  eps_t = eps_s (an s margin of 2 eps_s).  tests/test_gpu_ops.py measures the
+// actual |t - t_exact| against this bound and tests/test_gpu_screen_fuzz.py checks 1.6e7 adversarial rows per run bit for bit.
 
 #include <math.h>
 #include <stdlib.h>
