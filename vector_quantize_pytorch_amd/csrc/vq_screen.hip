@@ -2209,6 +2209,9 @@ extern "C" int vqhip_assign_screened(const void *x, int x_dtype, int64_t N, int 
 
 extern "C" int vqhip_screen_chain_supported(int x_dtype, int D)
 {
+#ifdef VQS16_F32_DIRECT      // (A/B build whose fp32-row prologue has no chain step)
+    return 0;
+#endif
     return (x_dtype == VQHIP_F32 && (D == 32 || D == 64 || D == 128 || D == 256) && !screen_bf16x2() && !screen_f32_two_part()) ? 1 : 0;
 }
 
