@@ -531,16 +531,16 @@ __global__ void __launch_bounds__(VQS_WAVES * 64, 8 / VQS_WAVES) vq_screen16_ker
     constexpr int BUF_B = Cfg::BUF_B;               // LDS bytes per buffer: PMAX pieces for EVERY wave, so that no copy is conditional
     constexpr int PPS = (PMAX + SUB - 1) / SUB;     // pieces a wave copies during one tile
     constexpr int NBS = (NK >= 16) ? 2 : 1;         // staging batches per tile
-    constexpr int BS = (PPS + NBS - 1) / NBS;
-    constexpr int SPAN = NK / NBS;                  // steps between batch starts
-    constexpr int LAG = (SPAN >= 8) ? SPAN - 2 : SPAN - 1;   // steps between a batch's loads and its LDS stores
+    [[maybe_unused]] constexpr int BS = (PPS + NBS - 1) / NBS;
+    [[maybe_unused]] constexpr int SPAN = NK / NBS;                  // steps between batch starts
+    [[maybe_unused]] constexpr int LAG = (SPAN >= 8) ? SPAN - 2 : SPAN - 1;   // steps between a batch's loads and its LDS stores
     static_assert(VQ_F16_TILE_GROUP % SUB == 0, "tile padding must cover the tiles of one barrier");
     static_assert(LAG >= 1 && (NBS - 1) * SPAN + LAG < NK, "staging schedule");
-    constexpr int BS2 = (PPS + 1) / 2;              // skewed sweep: two staging batches per tile, one per row-block phase
+    [[maybe_unused]] constexpr int BS2 = (PPS + 1) / 2;              // skewed sweep: two staging batches per tile, one per row-block phase
 #ifdef VQS16_LAG2
-    constexpr int LAG2 = (NK > VQS16_LAG2 + 1) ? VQS16_LAG2 : NK - 1;
+    [[maybe_unused]] constexpr int LAG2 = (NK > VQS16_LAG2 + 1) ? VQS16_LAG2 : NK - 1;
 #else
-    constexpr int LAG2 = (NK >= 8) ? NK - 2 : NK - 1;
+    [[maybe_unused]] constexpr int LAG2 = (NK >= 8) ? NK - 2 : NK - 1;
 #endif
 
     const int tid = threadIdx.x;
@@ -982,7 +982,7 @@ __global__ void __launch_bounds__(VQS_WAVES * 64, 8 / VQS_WAVES) vq_screen16_ker
     for (int r = 0; r < 16; ++r) accB0[r] = accB1[r] = -3.0e38f;      // "padding codes": never win against a real one
     for (int st = 0; st < nst; ++st) {
         const int buf = st & 1;
-        const int ct = st;   // trace index
+        [[maybe_unused]] const int ct = st;   // trace index
         VQ_STAMP(0);
         __syncthreads();     // buffer `buf` has landed for every wave; the other buffer is free
         VQ_STAMP(1);
@@ -1034,7 +1034,7 @@ __global__ void __launch_bounds__(VQS_WAVES * 64, 8 / VQS_WAVES) vq_screen16_ker
     };
     for (int st = 0; st < nst; ++st) {
         const int buf = st & 1;
-        const int ct = st;   // trace index
+        [[maybe_unused]] const int ct = st;   // trace index
         VQ_STAMP(0);
         __syncthreads();     // buffer `buf` has landed for every wave; the other buffer is free
         VQ_STAMP(1);
@@ -1149,7 +1149,7 @@ __global__ void __launch_bounds__(VQS_WAVES * 64, 8 / VQS_WAVES) vq_screen16_ker
 #else   // VQS16_FLAT: both row blocks interleaved, epilogue behind the tile's MFMAs (first version, kept for A/B runs)
     for (int st = 0; st < nst; ++st) {
         const int buf = st & 1;
-        const int ct = st;   // trace index
+        [[maybe_unused]] const int ct = st;   // trace index
         VQ_STAMP(0);
         __syncthreads();     // buffer `buf` has landed for every wave; the other buffer is free
         VQ_STAMP(1);
