@@ -15,6 +15,10 @@ import math
 
 import pytest
 import torch
+import os
+
+# VQHIP_FUZZ_SEED=<int> shifts the seeds of the adversarial cases: other draws of the same distributions (default: the fixed set)
+_SEED_SHIFT = 100000 * int(os.environ.get("VQHIP_FUZZ_SEED", "0"))
 
 pytestmark = pytest.mark.gpu
 
@@ -103,7 +107,7 @@ def test_screened_equals_exact_kernel_adversarial_fuzz(dev, monkeypatch, dtype):
     from vector_quantize_pytorch_amd import _lib as L
     total = flagged = paired = 0
     for ci, (rk, ck, N, C, D, scale, offset) in enumerate(_CASES):
-        gen = torch.Generator(device=dev).manual_seed(1000 + ci)
+        gen = torch.Generator(device=dev).manual_seed(1000 + ci + _SEED_SHIFT)
         x = _rows(rk, N, D, scale, offset, gen, dev).to(dtype).contiguous()
         e = _codes(ck, C, D, scale, gen, dev, x=x)
         r1, r0 = _run_both(L, monkeypatch, x, e, cosine=False)
@@ -128,7 +132,7 @@ def test_screened_cosine_equals_exact_kernel_adversarial_fuzz(dev, monkeypatch, 
     for ci, (rk, ck, N, C, D, scale, offset) in enumerate(_CASES):
         if ci % 2 or C < 2:
             continue
-        gen = torch.Generator(device=dev).manual_seed(2000 + ci)
+        gen = torch.Generator(device=dev).manual_seed(2000 + ci + _SEED_SHIFT)
         x = _rows(rk, N, D, scale, offset, gen, dev).to(dtype).contiguous()
         e = _codes(ck, C, D, scale, gen, dev, x=x)
         e = torch.nn.functional.normalize(e, p=2, dim=-1, eps=1e-6).contiguous()    # the cosine codebook is kept unit-norm (vqp.py:388)
