@@ -1,0 +1,60 @@
+"""Dev tool: the persistent screening kernel (csrc/vq_screen_p.hip; bf16 rows, D = 256, C >= 1024, idx [+ q] outputs) against the exact
+fp32-MFMA kernel, bit for bit (idx, q).   python tools/persist_check.py"""
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("VQHIP_SCREEN_PERSIST", "1")
+from vector_quantize_pytorch_amd import _lib as L
+dev = torch.device("cuda:0")
+g = torch.Generator(device=dev).manual_seed(7)
+
+def codebook(kind, C, D, x):
+    if kind == "kaiming":
+        e = torch.empty(C, D, device=dev); torch.nn.init.kaiming_uniform_(e, generator=g); return e
+    if kind == "randn": return torch.randn(C, D, device=dev, generator=g)
+    if kind == "rows": return x[torch.randperm(x.shape[0], device=dev, generator=g)[:C]].float().contiguous()
+    if kind == "dups":
+        e = torch.randn(C, D, device=dev, generator=g); e[C // 2:] = e[: C - C // 2]; return e
+    if kind == "tiny": return torch.randn(C, D, device=dev, generator=g) * 1e-3
+    raise ValueError(kind)
+
+def rows(kind, N, D):
+    x = torch.randn(N, D, device=dev, generator=g)
+    if kind == "wild":      # row norms over 8 decades inside every super-block, some zero rows
+        x = x * torch.exp(torch.empty(N, 1, device=dev).uniform_(-9.0, 9.0, generator=g))
+        x[::97] = 0
+    if kind == "big": x = x * 3e4
+    if kind == "small": x = x * 1e-6
+    return x.to(torch.bfloat16)
+
+def run(x, e, pk, screened, cosine, want_q):
+    os.environ["VQHIP_SCREEN"] = "1" if screened else "0"
+    q = torch.empty_like(x) if want_q else None
+    if cosine and screened:
+        r = L.assign(L.l2norm_rows(x), pk, e, cosine=True, skip_l2norm=True, want_q=want_q, q_out=q)
+    else:
+        r = L.assign(x, pk, e, cosine=cosine, want_q=want_q, q_out=q)
+    os.environ["VQHIP_SCREEN"] = "1"
+    return r, q
+
+ok = True
+cases = [(1 << 17, 1024, "kaiming", "plain", False, True), (1 << 17, 1024, "kaiming", "plain", False, False),
+         ((1 << 17) - 77, 1024, "randn", "plain", False, True), (70001, 2048, "randn", "plain", False, True),
+         (1 << 16, 1024, "dups", "plain", False, True), (1 << 16, 1024, "tiny", "plain", False, True),
+         (1 << 17, 1024, "rows", "wild", False, True), (1 << 17, 1024, "randn", "big", False, True),
+         (1 << 17, 1024, "randn", "small", False, True), (1 << 17, 1000, "randn", "plain", False, True),
+         (1 << 17, 1024, "kaiming", "plain", True, True), (99999, 4096, "randn", "wild", True, True),
+         (1 << 20, 1024, "kaiming", "plain", False, True)]
+for (N, C, ck, rk, cosine, want_q) in cases:
+    x = rows(rk, N, 256)
+    e = codebook(ck, C, 256, x)
+    if cosine: e = torch.nn.functional.normalize(e, dim=-1)
+    pk = L.pack_codebook(e)
+    r0, q0 = run(x, e, pk, False, cosine, want_q)
+    r1, q1 = run(x, e, pk, True, cosine, want_q)
+    torch.cuda.synchronize()
+    bad = int((r0["idx"] != r1["idx"]).sum())
+    qeq = (not want_q) or bool(torch.equal(q0, q1))
+    print(f"N={N} C={C} {ck:8s} rows={rk:6s} cos={int(cosine)} q={int(want_q)}: idx bad {bad}, q_equal {qeq}, open {int(r1['n_exact'][0])} pair {int(r1['n_pair'][0])}", flush=True)
+    ok &= bad == 0 and qeq
+print("ALL OK" if ok else "FAILURES")
+sys.exit(0 if ok else 1)

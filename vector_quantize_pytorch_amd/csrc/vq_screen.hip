@@ -36,60 +36,7 @@
 
 #include "vqhip_internal.h"
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-
-#ifndef VQS_PF
-#define VQS_PF 4             // depth of the A-fragment ring (LDS -> VGPR prefetch distance in steps of 2 MFMAs)
-#define VQS_PIN 1
-#endif
-#ifndef VQS_OUT1
-#define VQS_OUT2 1           // output phase ordering (see below); -DVQS_OUT1 selects the first version for A/B runs
-#endif
-#ifndef VQS_WAVES
-#define VQS_WAVES 4          // waves per workgroup (2 workgroups of 4 or 1 of 8 per CU: 2 waves per SIMD either way)
-#endif
-
-#define VQ_SCREEN_ROWS (VQS_WAVES * 64)   // rows per workgroup: waves x 2 row blocks x 32
-
-struct ScreenArgs {
-    const void *x;                     // rows, bf16 (vq_screen_kernel) or fp32 (vq_screen_f32_kernel)
-    int64_t N;
-    int64_t ldx;
-    const char *tiles;                 // bf16 hi/lo screening tiles inside the packed codebook
-    const char *tiles16;               // fp16 screening tiles (vq_screen16_kernel)
-    int n_tiles16;                     // fp16 tiles incl. padding tiles (multiple of VQ_F16_TILE_GROUP)
-    const unsigned short *embed_bf16;  // bf16 codebook copy inside the packed codebook
-    const float *embed;                // fp32 codebook (q rows of fp32 I/O)
-    const unsigned *scalars;           // [0] = float bits of max ||c||^2, [1] = float bits of max ||c - c_f16||, [2] = sc
-    int C;
-    int n_tiles;
-    int64_t *idx_out;
-    void *q_out;                       // nullable, x's dtype
-    int64_t ldq;
-    void *resid_out;                   // nullable, x's dtype: x - q (the next residual-VQ stage's input, rvq.py:524)
-    int64_t ldr;
-    double *sqerr_partial;             // nullable, one entry per workgroup
-    const uint8_t *row_mask;
-    int *flag_count;                   // [0] open rows (list front), [1] pair rows (list back)
-    int *flag_rows;
-    unsigned long long *flag_keys;     // [N] keys of the exact pass, preset to ~0 for every appended row
-    float *dbg;                        // nullable [N, 4]: t_best, t_second, eps_t, flagged
-    // residual chain (vq_screen16_kernel, fp32 rows): this stage's rows are x - prev_embed[prev_idx], formed in the prologue from
-    // the PREVIOUS stage's input and indices and written to x_out (the exact passes and the statistics read them there)
-    int64_t idx_stride;                // idx_out[row * idx_stride] (a column of an [N, Q] index tensor)
-    const int64_t *prev_idx;           // nullable
-    int64_t prev_idx_stride;
-    const float *prev_embed;           // [C_prev, D] fp32
-    float *x_out;
-    int64_t ldxo;
-#ifdef VQ_TRACE
-    long long *trace;
-#endif
-};
+#include "vq_screen_args.h"
 
 #ifdef VQ_TRACE
 extern long long *vq_g_trace;
@@ -2130,6 +2077,9 @@ static int launch_screen(const ScreenArgs &a, int x_dtype, hipStream_t st)
         if (x_dtype == VQHIP_BF16) {
             static int one_rb = -1;      // VQHIP_SCREEN_1RB=1: bf16 rows through the one-row-block kernel (4 waves per SIMD), A/B
             if (one_rb < 0) { const char *e = getenv("VQHIP_SCREEN_1RB"); one_rb = (e && e[0] == '1') ? 1 : 0; }
+            if constexpr (DT == 256) {   // persistent, software-pipelined form (vq_screen_p.hip) where it applies
+                if (vq_screenp_eligible(a, x_dtype, DT)) return vq_screenp_launch(a, METRIC, st);
+            }
             if constexpr (DT <= 256) {
                 if (one_rb) {
                     static VqAttrOnce once1;
@@ -2292,6 +2242,11 @@ static int assign_screened_impl(const void *x, int x_dtype, int64_t N, int D, in
         default: rc = dispatch_screen<512>(a, x_dtype, metric, st); break;
     }
     if (rc) return rc;
+    {   // VQHIP_SCREEN_ONLY=1 (dev tools that time the screening kernel by itself): leave the listed rows undecided
+        static int only = -1;
+        if (only < 0) { const char *e = getenv("VQHIP_SCREEN_ONLY"); only = (e && e[0] == '1') ? 1 : 0; }
+        if (only) return 0;
+    }
     const int with_pairs = (screen_bf16x2() && D <= 256) ? 0 : 1;   // the fp16 screening kernels also build the pair list
     // a chained stage's rows were materialised by its screening kernel: the exact passes read them there
     const void *xl = (chain && chain->prev_idx) ? (const void *)chain->x_out : x;
