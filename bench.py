@@ -44,23 +44,30 @@ N_BATCHES = 4                        # distinct synthetic batches cycled through
 def cpu_baseline_and_audit(nthreads, dev):
     """Times the reference's CPU op sequence (oracle mode="aten": 3 N*C*D contractions + the N*C temporaries; proven
     bit-identical to the live reference in the build container, tests/test_oracle.py -- /root/reference itself is not on
-    the GPU box) on a bounded sample of the cfg-2 workload, and compares the GPU path's indices with the oracle's on the
-    SAME rows and codebook (mismatch count with tie audit)."""
+    the GPU box) on a bounded sample of the cfg-2 workload (the first 131072 vectors), then audits the GPU path's indices
+    against the oracle's on ALL 2^20 rows of that batch in chunks (mismatch count with tie audit):
+    for every mismatch the gap between the two candidates in the reference's own fp32 distances (ulps) and which of the two
+    is closer in float64."""
     from oracle import vq_oracle as O
     from vector_quantize_pytorch_amd import _lib
-    rows_b, rows_s = 8, 16384                       # 131072 of the 2^20 vectors per timed forward
+    rows_b, rows_s = 8, 16384                       # 131072 vectors per oracle forward
+    n_chunks = (B * S) // (rows_b * rows_s)
     g = torch.Generator().manual_seed(0)
-    x = torch.randn(rows_b, rows_s, D, generator=g).bfloat16()
+    xs = [torch.randn(rows_b, rows_s, D, generator=g).bfloat16() for _ in range(n_chunks)]
     bound = (6.0 / (C * D)) ** 0.5
     e = (torch.rand(1, C, D, generator=g) * 2 - 1) * bound
-    st = O.VQState(embed=e.clone(), embed_avg=e.clone(), cluster_size=torch.ones(1, C))
     cfg = O.VQConfig(dim=D, codebook_size=C)
+
+    def fresh():
+        return O.VQState(embed=e.clone(), embed_avg=e.clone(), cluster_size=torch.ones(1, C))
+
+    st = fresh()
     with torch.no_grad():
-        _, idx_aten, _ = O.vq_forward(st, cfg, x)   # warm-up; its indices (first step, codebook e) feed the audit
+        O.vq_forward(st, cfg, xs[0])                # warm-up
         ts = []
         for _ in range(3):
             t0 = time.perf_counter()
-            O.vq_forward(st, cfg, x)
+            O.vq_forward(st, cfg, xs[0])
             ts.append(time.perf_counter() - t0)
     t = sorted(ts)[1]
     base = dict(value=rows_b * rows_s / t, unit="vectors/s", cores=nthreads, kind="port",
@@ -68,22 +75,41 @@ def cpu_baseline_and_audit(nthreads, dev):
                         f"x=({rows_b},{rows_s},{D}) bf16 input as in cfg 2, fp32 arithmetic (the reference casts at vqp.py:692), "
                         f"C={C}, train step, median of 3 after 1 warm-up, {t:.3f} s/forward"))
 
-    # ---- audit: GPU (screened and exact) vs the reference op sequence on the same rows / codebook ----
-    xd, ed = x.reshape(-1, D).to(dev), e[0].to(dev).contiguous()
+    # ---- audit: GPU (screened + exact passes) vs the reference op sequence, same rows, same (initial) codebook ----
+    ed = e[0].to(dev).contiguous()
     packed = _lib.pack_codebook(ed)
-    gi = _lib.assign(xd, packed, ed, want_q=False)["idx"].cpu()
-    ia = idx_aten.reshape(-1)
-    mism = (gi != ia).nonzero().flatten()
-    max_ulps = 0
-    if mism.numel():
-        # tie audit: the reference's own fp32 distances of the two candidates, in units in the last place
-        rows = x.reshape(-1, D)[mism].float()
-        d = -O.neg_cdist(rows[None], e)[0]                                   # [m, C] cdist as the reference computes it
-        da = d.gather(1, ia[mism][:, None])[:, 0]
-        dg = d.gather(1, gi[mism][:, None])[:, 0]
-        ulps = (da.view(torch.int32).long() - dg.view(torch.int32).long()).abs()
-        max_ulps = int(ulps.max())
-    audit = dict(rows_checked_vs_aten=int(ia.numel()), mismatches_vs_aten=int(mism.numel()), tie_audit_max_ulps=max_ulps)
+    e64 = e[0].double()
+    hist = {"0": 0, "1": 0, "2": 0, ">2": 0}
+    closer = {"gpu": 0, "reference": 0, "exact_tie": 0}
+    n_rows = n_mism = max_ulps = 0
+    with torch.no_grad():
+        for x in xs:
+            _, idx_aten, _ = O.vq_forward(fresh(), cfg, x)          # first-step indices on codebook e
+            ia = idx_aten.reshape(-1)
+            gi = _lib.assign(x.reshape(-1, D).to(dev), packed, ed, want_q=False)["idx"].cpu()
+            mism = (gi != ia).nonzero().flatten()
+            n_rows += ia.numel()
+            n_mism += mism.numel()
+            if mism.numel():
+                rows = x.reshape(-1, D)[mism].float()
+                d = -O.neg_cdist(rows[None], e)[0]                   # [m, C] cdist exactly as the reference computes it (fp32)
+                da = d.gather(1, ia[mism][:, None])[:, 0]
+                dg = d.gather(1, gi[mism][:, None])[:, 0]
+                ulps = (da.view(torch.int32).long() - dg.view(torch.int32).long()).abs()
+                max_ulps = max(max_ulps, int(ulps.max()))
+                for u in ulps.tolist():
+                    hist[str(u) if u <= 2 else ">2"] += 1
+                r64 = rows.double()
+                ta = ((r64 - e64[ia[mism]]) ** 2).sum(-1)
+                tg = ((r64 - e64[gi[mism]]) ** 2).sum(-1)
+                closer["gpu"] += int((tg < ta).sum())
+                closer["reference"] += int((ta < tg).sum())
+                closer["exact_tie"] += int((ta == tg).sum())
+    audit = dict(rows_checked_vs_aten=n_rows, mismatches_vs_aten=n_mism, tie_audit_max_ulps=max_ulps,
+                 tie_audit_ulp_histogram=hist, closer_in_float64=closer,
+                 tie_audit_note=("ulps = gap between the two candidates in the reference's own fp32 cdist values; closer_in_float64 = which "
+                                 "candidate is nearer when the distance is evaluated in float64 (neither arithmetic is 'right' on a 0..1-ulp gap: "
+                                 "MKL's blocked sgemm and the kernels' ascending fp32 FMA chain round differently)"))
     return base, audit
 
 
@@ -109,20 +135,55 @@ def screened_vs_exact(x, vq):
 
 
 # ----------------------------------------------------------------------------------------------------------------------
-def _time_module(mod, batches, steps, warmup, sync):
+def _windows(run_step, steps, windows, sync):
+    """`windows` back-to-back timed windows of exactly `steps` steps, each bracketed by barrier + synchronize on both sides;
+    returns the per-window wall times (the reported step time is the MEDIAN window: one 20-step window is ~20 ms at cfg 2)"""
+    dts = []
+    k = 0
+    for _ in range(windows):
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            run_step(k)
+            k += 1
+        sync()
+        dts.append(time.perf_counter() - t0)
+    return dts
+
+
+def _median(v):
+    return sorted(v)[len(v) // 2]
+
+
+def _time_module(mod, batches, steps, warmup, sync, windows):
+    out = [None]
     with torch.no_grad():
         torch.cuda.synchronize(); t0 = time.perf_counter()
         mod(batches[0])                                 # first forward (k-means init for cfg 5)
         torch.cuda.synchronize(); first = time.perf_counter() - t0
         for i in range(warmup):
             mod(batches[i % len(batches)])
-        sync()
-        t0 = time.perf_counter()
-        for i in range(steps):
-            out = mod(batches[i % len(batches)])
-        sync()
-        dt = time.perf_counter() - t0
-    return dt, first, out
+
+        def step(k):
+            out[0] = mod(batches[k % len(batches)])
+        dts = _windows(step, steps, windows, sync)
+    return dts, first, out[0]
+
+
+def _time_grad_step(mod, batches, steps, warmup, sync, windows):
+    """BASELINE.md §4's second line: the same module and batches, `x.requires_grad_()` + backward of (sum(quantized) + sum(loss)):
+    training forward (search, EMA update) plus the gradient to the input through the straight-through / rotation-trick route and
+    the commitment loss."""
+    xs = [b.clone().requires_grad_(True) for b in batches]
+
+    def step(k):
+        x = xs[k % len(xs)]
+        x.grad = None
+        res = mod(x)
+        (res[0].float().sum() + res[2].sum()).backward()
+    for i in range(max(warmup, 1)):
+        step(i)
+    return _windows(step, steps, windows, sync)
 
 
 def other_workload(args, world, rank, dev):
@@ -186,19 +247,23 @@ def other_workload(args, world, rank, dev):
     _lib.rvq_forward_chained = counting_chained
     import vector_quantize_pytorch_amd.codebook as cbmod
     cbmod.L.assign = counting_assign
-    dt, first, _ = _time_module(mod, batches, args.steps, args.warmup, sync)
+    dts, first, _ = _time_module(mod, batches, args.steps, args.warmup, sync, args.windows)
     _lib.assign = orig_assign
     _lib.rvq_forward_chained = orig_chained
+    gdts = None
+    if args.workload in ("rvq_cfg3", "grvq_cfg5") and not args.no_grad_step:
+        gdts = _time_grad_step(mod, batches, args.steps, args.warmup, sync, args.windows)
     per_stage = None
     if counts:
         n_last = stages if len(counts) >= stages else len(counts)
         last = counts[-n_last:]                          # the searches of the last forward, in call order (group-major, then stage)
         per_stage = {"open_frac": [round(float(c[0].item()) / c[2], 5) for c in last],
                      "pair_frac": [round(float(c[1].item()) / c[2], 5) for c in last]}
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    tmax = torch.tensor(dts, dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = float(tmax.item())
+    dts = tmax.tolist()
+    dt = _median(dts)
     if rank != 0:
         return
     strong = args.workload == "vq_cfg4_sharded"
@@ -210,7 +275,13 @@ def other_workload(args, world, rank, dev):
                       "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
                       "scaling": "strong" if strong else "weak", "vs_baseline": None,
                       "dtype": "f16+f32" if screened else "f32", "data": "synthetic",
+                      "windows_ms_per_step": [round(d / args.steps * 1e3, 4) for d in dts],
+                      "grad_step": None if gdts is None else {
+                          "workload": "same module and batches, x.requires_grad_() + backward of sum(quantized) + sum(losses) (BASELINE.md §4, second line)",
+                          "ms_per_step": _median(gdts) / args.steps * 1e3, "value": n * args.steps / _median(gdts), "unit": "vectors/s",
+                          "windows_ms_per_step": [round(d / args.steps * 1e3, 4) for d in gdts]},
                       "config": {"workload": name, "parallelism": par, "vector_stages_per_s": n * stages * args.steps / dt,
+                                 "world_size": world, "backend": (dist.get_backend() if world > 1 else None),
                                  "first_forward_ms": first * 1e3, "uncertified_rows_per_search": per_stage},
                       "roofline": {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
                                    "traffic": None, "achieved_vs_fp32_mfma_peak": ach / PEAK_FP32_MFMA_TFLOPS,
@@ -260,16 +331,23 @@ def vq_cfg2(args, world, rank, dev):
             vq(batches[(i + 1) % N_BATCHES])
         sync()
         ev.clear(); exact_rows.clear(); pair_rows.clear()
-        t0 = time.perf_counter()
-        for i in range(args.steps):
-            q, idx, loss = vq(batches[i % N_BATCHES])
-        sync()
-        dt = time.perf_counter() - t0
+        last = [None]
 
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        def step(k):
+            last[0] = vq(batches[k % N_BATCHES])
+        dts = _windows(step, args.steps, args.windows, sync)
+        q, idx, loss = last[0]
+
+    cbmod.L.assign = orig_assign
+    gdts = None
+    if not args.no_grad_step:
+        gdts = _time_grad_step(vq, batches, args.steps, args.warmup, sync, args.windows)
+    tmax = torch.tensor(dts + (gdts or []), dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = float(tmax.item())
+    tl = tmax.tolist()
+    dts, gdts = tl[: len(dts)], (tl[len(dts):] if gdts else None)
+    dt = _median(dts)
     if rank != 0:
         return
 
@@ -303,6 +381,12 @@ def vq_cfg2(args, world, rank, dev):
         "vs_baseline": None,
         "dtype": "f16+f32" if screened else "f32",
         "data": "synthetic",
+        "windows_ms_per_step": [round(d / args.steps * 1e3, 4) for d in dts],   # ms_per_step / value = the median window
+        "grad_step": None if gdts is None else {
+            "workload": ("same module and batches, x.requires_grad_() + backward of sum(quantized) + loss: rotation-trick route (the "
+                         "module default, vqp.py:856) + commit-loss gradient (BASELINE.md §4, second line)"),
+            "ms_per_step": _median(gdts) / args.steps * 1e3, "value": world * n_vec * args.steps / _median(gdts), "unit": "vectors/s",
+            "windows_ms_per_step": [round(d / args.steps * 1e3, 4) for d in gdts]},
         "hbm_gbps": alg_bytes / step_s / 1e9,                     # algorithmic bytes of a step / step time, per GPU
         "hbm_frac": alg_bytes / step_s / 1e9 / PEAK_HBM_GBPS,
         "config": {"workload": f"VectorQuantize(dim={D}, codebook_size={C}) train forward + EMA update, x=({B},{S},{D}) bf16 per GPU, "
@@ -328,7 +412,6 @@ def vq_cfg2(args, world, rank, dev):
         out["roofline"]["rows_pair_pass_frac"] = float(torch.stack(pair_rows).double().mean().item()) / n_vec
         out["roofline"]["rows_pair_pass_frac_first_step"] = first_pair
     if world == 1:
-        cbmod.L.assign = orig_assign
         parity = {}
         if screened:
             n_chk, bad = screened_vs_exact(batches[0], vq)
@@ -373,6 +456,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-adversarial", action="store_true")
+    ap.add_argument("--no-grad-step", action="store_true", help="skip the requires_grad + backward measurement (grad_step)")
+    ap.add_argument("--windows", type=int, default=5, help="timed windows of --steps steps each; the median window is reported")
     ap.add_argument("--workload", default="vq_cfg2", choices=["vq_cfg2", "rvq_cfg3", "grvq_cfg5", "vq_cfg4_shard", "vq_cfg4_sharded"],
                     help="vq_cfg2 (default) is BASELINE.json's headline configuration; the others are informational")
     args = ap.parse_args()

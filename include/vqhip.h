@@ -163,6 +163,19 @@ int vqhip_route_bwd(const void *x, const void *q, const void *g_out, int dtype, 
                     int64_t ldx, int64_t ldq, int64_t ldg, const float *loss_coef, const uint8_t *row_mask,
                     int mode, void *grad_x, int64_t ldo, void *stream);
 
+/* ---- gradient routing through the residual loop -------------------------------------------------
+ * Replaces, for ResidualVQ.forward with an input that requires grad (rvq.py:469-568, quant_grad_frac = 0): per stage the
+ * straight-through / rotation-trick value and Jacobian (vqp.py:282-318, 1225-1233), `quantized_out += quantized` (rvq.py:525),
+ * `residual = residual - quantized.detach()` (rvq.py:524) and the backward of every stage's F.mse_loss (vqp.py:1327).
+ *  x, g_out, out: [N, D] rows of one dtype; embed: fp32 [Q][C, D] at stride embed_qstride elements (0 = one shared codebook);
+ *  idx: int64 [N, idx_stride], the first Q columns are the stages (a negative entry ends the row's loop: dropped quantizers).
+ *  backward == 0 : out = sum_q route(r_q, c_q)          (mode 0: plain sum of the codes, 1: straight-through, 2: rotation trick)
+ *  backward != 0 : out = sum_q J_q^T g_out (mode 1, 2) + 2 * loss_coef[q] * (r_q - c_q) on rows with row_mask != 0;
+ *                  loss_coef (nullable): Q DEVICE floats, d loss / d (sum of squared errors of stage q). */
+int vqhip_rvq_route(const void *x, int dtype, int64_t N, int D, int64_t ldx, const float *embed, int64_t embed_qstride,
+                    int C, const int64_t *idx, int64_t idx_stride, int Q, int mode, const void *g_out, int64_t ldg,
+                    const float *loss_coef, const uint8_t *row_mask, int backward, void *out, int64_t ldo, void *stream);
+
 /* sum of `n` doubles times `scale` -> one fp32 (commit loss = scale * sum of partials). */
 int vqhip_reduce_partials(const double *partials, int64_t n, double scale, float *out, void *stream);
 /* R rows of partials in one launch (the per-stage losses of a residual VQ): out[r] = scale * sum(partials[r * stride .. + n)). */

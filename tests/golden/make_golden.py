@@ -228,3 +228,13 @@ if __name__ == "__main__":
     qinco = dict(dim=32, num_quantizers=3, codebook_size=64, implicit_neural_codebook=True, mlp_kwargs=dict(depth=2))
     run_case("rvq_qinco", ResidualVQ, qinco, [randn(2, 50, 32, seed=100)], grad=True, param_grad=True, unit_codebook=True)
     run_case("rvq_qinco_eval", ResidualVQ, qinco, [randn(2, 40, 32, seed=101)], train=False, unit_codebook=True)
+    # gradients to the input through the residual loop (rvq.py:524-525 with quant_grad_frac = 0): every stage's rotation-trick
+    # (the default, vqp.py:856) / straight-through Jacobian (vqp.py:1225-1233) plus every stage's commitment-loss gradient, summed into dL/dx
+    run_case("rvq_shared_grad", ResidualVQ, dict(dim=64, num_quantizers=4, codebook_size=128, shared_codebook=True),
+             [randn(2, 128, 64, seed=110), randn(2, 128, 64, seed=111)], grad=True, unit_codebook=True)
+    run_case("rvq_grad_ste", ResidualVQ, dict(dim=64, num_quantizers=3, codebook_size=64, rotation_trick=False),
+             [randn(2, 100, 64, seed=112)], grad=True, unit_codebook=True)
+    run_case("rvq_grad_mask", ResidualVQ, dict(dim=32, num_quantizers=3, codebook_size=64),
+             [randn(2, 60, 32, seed=113)], fwd_kwargs=dict(mask=[[True] * 60, [True] * 37 + [False] * 23]), grad=True, unit_codebook=True)
+    run_case("grvq_grad", GroupedResidualVQ, dict(dim=128, groups=2, num_quantizers=3, codebook_size=64),
+             [randn(2, 100, 128, seed=114)], grad=True, unit_codebook=True)

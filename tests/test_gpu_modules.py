@@ -883,3 +883,94 @@ def test_residual_chain_equals_the_stage_by_stage_loop(dev, monkeypatch, kw):
         assert torch.allclose(la, lb, rtol=2e-6, atol=1e-12)
         _close(a.codebooks, b.codebooks, 1e-5, "codebooks")       # (embed_sum: fp32 atomics over a code's row chunks, in any order)
         b.load_state_dict(a.state_dict())
+
+
+@pytest.mark.parametrize("case", ["shared_rot", "separate_ste", "bf16", "masked", "no_route", "dropout"])
+def test_residual_vq_input_grad_runs_the_on_device_loop_and_matches_the_staged_path(dev, monkeypatch, case):
+    """An input that requires grad used to send ResidualVQ to the per-stage autograd path.  It now takes the same
+    chained on-device loop as the no-grad step (_RvqFusedFn: vq_rvq_route_kernel forward and backward, rvq.py:524-525 with
+    quant_grad_frac = 0); the staged path (forced here by patching _fused_eligible) stays the in-repo restatement it is compared
+    with: indices identical, output / losses / dL/dx / codebooks within the north-star tolerance."""
+    from vector_quantize_pytorch_amd import ResidualVQ
+    from vector_quantize_pytorch_amd import _lib as L
+    kw = dict(dim=256, num_quantizers=4, codebook_size=512)
+    dtype, tol, fk = torch.float32, 1e-5, {}
+    if case == "shared_rot":
+        kw.update(shared_codebook=True)
+    elif case == "separate_ste":
+        kw.update(rotation_trick=False, dim=64, codebook_size=256)
+    elif case == "bf16":
+        dtype, tol = torch.bfloat16, 2e-2
+    elif case == "no_route":
+        kw.update(route_gradients_to_input=False, dim=128)
+    elif case == "dropout":
+        kw.update(quantize_dropout=True, quantize_dropout_cutoff_index=1, dim=128)
+        fk = dict(rand_quantize_dropout_fixed_seed=3)
+    torch.manual_seed(0)
+    a = ResidualVQ(**kw).to(dev).train()
+    b = ResidualVQ(**kw).to(dev).train()
+    b.load_state_dict(a.state_dict())
+    monkeypatch.setattr(b, "_fused_eligible", lambda *args, **kws: False)
+    calls = []
+    orig = L.rvq_route
+    monkeypatch.setattr(L, "rvq_route", lambda *args, **kws: (calls.append(bool(kws.get("backward"))), orig(*args, **kws))[1])
+    for step in range(2):
+        x = (torch.randn(3, 1000, kw["dim"], device=dev) * (1.0 + step)).to(dtype)
+        mask = (torch.rand(3, 1000, device=dev) > 0.25) if case == "masked" else None
+        xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+        qa, ia, la = a(xa, mask=mask, **fk)
+        qb, ib, lb = b(xb, mask=mask, **fk)
+        assert torch.equal(ia, ib) and qa.dtype == dtype and la.dtype == torch.float32
+        _close(qa.float(), qb.float(), tol, "quantized")
+        _close(la, lb, tol, "losses")
+        w = torch.randn(qa.shape, device=dev).to(dtype)
+        ((qa * w).float().sum() + 3.0 * la.sum()).backward()
+        ((qb * w).float().sum() + 3.0 * lb.sum()).backward()
+        _close(xa.grad.float(), xb.grad.float(), tol, "grad_x")
+        _close(a.codebooks.float(), b.codebooks.float(), tol, "codebooks")
+        b.load_state_dict(a.state_dict())
+    assert calls == [False, True, False, True], calls       # one routed forward and one backward launch per step, on module a only
+
+
+def test_grouped_residual_vq_input_grad_on_strided_chunks(dev, monkeypatch):
+    """GroupedResidualVQ hands every group a strided feature chunk of x: the fused gradient path reads x and writes dL/dx through
+    those row strides, and the groups' gradients land in the right columns of x.grad."""
+    from vector_quantize_pytorch_amd import GroupedResidualVQ
+    torch.manual_seed(1)
+    kw = dict(dim=256, groups=2, num_quantizers=3, codebook_size=256)
+    a, b = GroupedResidualVQ(**kw).to(dev).train(), GroupedResidualVQ(**kw).to(dev).train()
+    b.load_state_dict(a.state_dict())
+    for r in b.rvqs:
+        monkeypatch.setattr(r, "_fused_eligible", lambda *args, **kws: False)
+    x = torch.randn(2, 900, 256, device=dev)
+    xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    qa, ia, la = a(xa)
+    qb, ib, lb = b(xb)
+    assert torch.equal(ia, ib)
+    w = torch.randn_like(qa)
+    ((qa * w).sum() + 2.0 * la.sum()).backward()
+    ((qb * w).sum() + 2.0 * lb.sum()).backward()
+    _close(qa, qb, 1e-5, "quantized")
+    _close(la, lb, 1e-5, "losses")
+    _close(xa.grad, xb.grad, 1e-5, "grad_x")
+
+
+def test_cosine_codebook_transform_sees_normalised_rows_with_or_without_input_grad(dev):
+    """with use_cosine_sim the autograd-glue path (here: codebook_transform_fn) must work on l2-normalised rows
+    whether or not the input requires grad -- the reference normalises first (vqp.py:1159).  Same module state, same x, with and
+    without requires_grad: identical indices, commitment loss and EMA-updated codebook."""
+    from vector_quantize_pytorch_amd import VectorQuantize
+    torch.manual_seed(2)
+    res = []
+    for needs_grad in (True, False):
+        torch.manual_seed(3)
+        vq = VectorQuantize(dim=32, codebook_size=64, use_cosine_sim=True).to(dev).train()
+        x = torch.randn(2, 200, 32, device=dev) * 4.0 + 0.5
+        if needs_grad:
+            x.requires_grad_(True)
+        fn = lambda codes: (codes * 1.25)[0][None, None].expand(2, 200, -1, -1)     # a per-row codebook, same for every row
+        q, idx, loss = vq(x, codebook_transform_fn=fn)
+        res.append((idx, loss.detach(), vq._codebook.embed.detach().clone()))
+    assert torch.equal(res[0][0], res[1][0])
+    _close(res[0][1].reshape(-1), res[1][1].reshape(-1), 1e-6, "commit loss")
+    _close(res[0][2], res[1][2], 1e-6, "embed after the EMA step")

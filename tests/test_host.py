@@ -174,3 +174,14 @@ def test_reference_residual_vq_forward_indices_is_broken_upstream():
             m(torch.randn(1, 4, 16), indices=torch.zeros(1, 4, 2, dtype=torch.long))
     finally:
         del sys.path[:2]
+
+
+def test_every_entry_point_has_a_declared_ctypes_signature():
+    """An entry point called without `argtypes` gets its int64 / pointer arguments passed as C ints: silently wrong strides on the
+    GPU box (this caught nothing on CPU before it was added)."""
+    from vector_quantize_pytorch_amd import _lib
+    L = _lib.lib()
+    for sym in _lib.EXPORTS:
+        if sym in ("vqhip_version", "vqhip_last_error"):
+            continue
+        assert getattr(L, sym).argtypes is not None, f"{sym}: no argtypes declared in _lib.lib()"

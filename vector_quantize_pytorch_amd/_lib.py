@@ -73,6 +73,8 @@ def lib():
     L.vqhip_route_fwd.argtypes = [vp, vp, i32, i64, i32, i64, i64, vp, i64, i32, vp]
     L.vqhip_route_bwd.argtypes = [vp, vp, vp, i32, i64, i32, i64, i64, i64, vp, vp, i32, vp, i64, vp]
     L.vqhip_route_fwd.restype = i32
+    # (x, dtype, N, D, ldx, embed, embed_qstride, C, idx, idx_stride, Q, mode, g_out, ldg, loss_coef, row_mask, backward, out, ldo, stream)
+    L.vqhip_rvq_route.argtypes = [vp, i32, i64, i32, i64, vp, i64, i32, vp, i64, i32, i32, vp, i64, vp, vp, i32, vp, i64, vp]
     L.vqhip_route_bwd.restype = i32
     L.vqhip_ema_workspace_bytes.restype = ctypes.c_size_t
     L.vqhip_ema_workspace_bytes.argtypes = [i64, i32]
@@ -95,7 +97,7 @@ def lib():
     L.vqhip_kmeans_update.argtypes = [vp, vp, vp, i32, i32, i32, vp]
     L.vqhip_kmeans_update.restype = i32
     for name in ("vqhip_pack_codebook", "vqhip_assign", "vqhip_reduce_partials", "vqhip_ema_accumulate",
-                 "vqhip_ema_finalize", "vqhip_decode_sum", "vqhip_row_sumsq", "vqhip_assign_rowwise", "vqhip_score_indices", "vqhip_topk", "vqhip_expire_scatter", "vqhip_kmeans_update", "vqhip_route_fwd", "vqhip_route_bwd"):
+                 "vqhip_ema_finalize", "vqhip_decode_sum", "vqhip_row_sumsq", "vqhip_assign_rowwise", "vqhip_score_indices", "vqhip_topk", "vqhip_expire_scatter", "vqhip_kmeans_update", "vqhip_route_fwd", "vqhip_route_bwd", "vqhip_rvq_route"):
         getattr(L, name).restype = i32
     _lib = L
     return L
@@ -104,7 +106,7 @@ def lib():
 EXPORTS = ("vqhip_version", "vqhip_last_error", "vqhip_packed_bytes", "vqhip_pack_codebook",
            "vqhip_assign_blocks", "vqhip_assign", "vqhip_screen_supported", "vqhip_screen_workspace_bytes",
            "vqhip_screen_blocks", "vqhip_screen_partials", "vqhip_assign_screened", "vqhip_screen_chain_supported", "vqhip_assign_screened_chain", "vqhip_l2norm_rows", "vqhip_scores", "vqhip_rvq_forward", "vqhip_reduce_partials", "vqhip_reduce_partials_rows", "vqhip_ema_fold_many", "vqhip_ema_workspace_bytes", "vqhip_ema_accumulate", "vqhip_ema_sqerr_partials", "vqhip_ema_accumulate_sqerr",
-           "vqhip_ema_finalize", "vqhip_decode_sum", "vqhip_row_sumsq", "vqhip_assign_rowwise", "vqhip_score_indices", "vqhip_topk", "vqhip_expire_scatter", "vqhip_kmeans_update", "vqhip_route_fwd", "vqhip_route_bwd")
+           "vqhip_ema_finalize", "vqhip_decode_sum", "vqhip_row_sumsq", "vqhip_assign_rowwise", "vqhip_score_indices", "vqhip_topk", "vqhip_expire_scatter", "vqhip_kmeans_update", "vqhip_route_fwd", "vqhip_route_bwd", "vqhip_rvq_route")
 
 
 def _check(rc, what):
@@ -464,6 +466,41 @@ def route_bwd(x: torch.Tensor, q: torch.Tensor, g_out, loss_coef, row_mask, mode
         _check(lib().vqhip_route_bwd(_ptr(xk), _ptr(qk), _ptr(gk), _dtype_code(xk), N, D, ldx, ldq, ldg, _ptr(loss_coef),
                                      _ptr(row_mask), mode if gk is not None else 0, _ptr(gx), D, _stream()), "vqhip_route_bwd")
     return gx
+
+
+@_on_device
+def rvq_route(x: torch.Tensor, embed: torch.Tensor, idx: torch.Tensor, Q: int, mode: int, *, g_out=None, loss_coef=None,
+              row_mask=None, backward=False) -> torch.Tensor:
+    """The residual loop's routed output (backward=False) or the gradient wrt x (backward=True) in ONE kernel that keeps the
+    residual row in registers (csrc: vq_rvq_route_kernel; rvq.py:469-568 with quant_grad_frac = 0).
+    x [..., D]; embed fp32 [Q', C, D] or [C, D] (shared); idx int64 [..., Q'] (first Q columns are used); mode 0 / STRAIGHT_THROUGH /
+    ROTATION; loss_coef: [Q] fp32 device tensor, d loss / d (sum of squared errors of stage q)."""
+    _need_gpu(x, embed, idx, g_out, loss_coef, row_mask)
+    xk, N, D, ldx = as_rows(x)
+    assert idx.dtype == torch.int64 and idx.is_contiguous() and embed.dtype == torch.float32 and embed.is_contiguous()
+    qs = idx.shape[-1]
+    assert 1 <= Q <= qs and idx.numel() == N * qs
+    if embed.ndim == 2:
+        C, qstride = embed.shape[0], 0
+    else:
+        assert embed.shape[0] >= Q
+        C, qstride = embed.shape[1], embed.shape[1] * embed.shape[2]
+    assert embed.shape[-1] == D
+    gk, ldg = None, 0
+    if backward and mode != 0:
+        gk, _, _, ldg = as_rows(g_out.to(x.dtype))
+    if loss_coef is not None:
+        loss_coef = loss_coef.to(torch.float32).reshape(-1).contiguous()
+        assert loss_coef.numel() >= Q
+    if row_mask is not None:
+        row_mask = row_mask.reshape(-1).to(torch.uint8).contiguous()
+        assert row_mask.numel() == N
+    out = torch.empty(x.shape, dtype=x.dtype, device=x.device)
+    if N > 0:
+        _check(lib().vqhip_rvq_route(_ptr(xk), _dtype_code(xk), N, D, ldx, _ptr(embed), qstride, C, _ptr(idx), qs, Q, mode,
+                                     _ptr(gk), ldg, _ptr(loss_coef), _ptr(row_mask), 1 if backward else 0, _ptr(out), D, _stream()),
+               "vqhip_rvq_route")
+    return out
 
 
 @_on_device

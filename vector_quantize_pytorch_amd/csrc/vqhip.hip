@@ -2212,6 +2212,141 @@ extern "C" int vqhip_route_bwd(const void *x, const void *q, const void *g_out, 
 }
 
 // ------------------------------------------------------------------------------------------------
+// gradient routing through the residual loop (ResidualVQ.forward, rvq.py:469-568 with quant_grad_frac = 0): stage q sees the
+// residual r_q = r_{q-1} - c_{q-1} (detached subtraction, rvq.py:524), its routed output is added to quantized_out (rvq.py:525),
+// its commitment loss compares r_q with c_q.  dL/dx therefore sums, over the stages, the straight-through / rotation-trick
+// Jacobian of that stage applied to the upstream gradient plus the stage's commit-loss gradient (d r_q / d x = I).
+// One wave per row keeps r in registers, gathers the Q code rows (L2) and never materialises a per-stage tensor:
+//   FWD: out = sum_q route_fwd(r_q, c_q)       BWD: out = sum_q J_q^T g + 2 coef_q (r_q - c_q)
+// bf16 tensors: every tensor op of the reference rounds to bf16 (code rows, residual, routed value, running sum).
+// ------------------------------------------------------------------------------------------------
+struct RvqRouteArgs {
+    const void *x, *g;
+    void *out;
+    const float *embed;        // [Q or 1][C, D] fp32
+    int64_t qstride;           // elements between the codebooks of consecutive stages (0: shared)
+    const int64_t *idx;        // [N, idx_stride]
+    int64_t idx_stride;
+    const float *loss_coef;    // BWD, nullable: [Q] device floats, d loss_total / d (sum of squares of stage q)
+    const uint8_t *row_mask;
+    int64_t N, ldx, ldg, ldo;
+    int D, Q, mode;
+};
+
+template <bool BF16, bool BWD>
+__global__ void __launch_bounds__(256) vq_rvq_route_kernel(const RvqRouteArgs a)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t n = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= a.N) return;
+    float r[8], g[8], acc[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int d = lane + 64 * k;
+        r[k] = g[k] = acc[k] = 0.f;
+        if (d < a.D) {
+            r[k] = load_elem<BF16>(a.x, n * a.ldx + d);
+            if (BWD && a.g) g[k] = load_elem<BF16>(a.g, n * a.ldg + d);
+        }
+    }
+    const bool counted = !a.row_mask || a.row_mask[n] != 0;
+    for (int q = 0; q < a.Q; ++q) {
+        const int64_t code = a.idx[n * a.idx_stride + q];
+        if (code < 0) break;                                     // dropped-out quantizers (rvq.py:478-482) and masked rows
+        const float *cp = a.embed + (size_t)q * a.qstride + (size_t)code * a.D;
+        float c[8];
+        float se = 0.f, sq = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int d = lane + 64 * k;
+            c[k] = d < a.D ? cp[d] : 0.f;
+            if (BF16) c[k] = round_to_bf16(c[k]);
+            se += r[k] * r[k];
+            sq += c[k] * c[k];
+        }
+        float t[8];
+        if (a.mode == 2) {                                       // rotation trick: the arithmetic of vq_route_kernel
+            const float ne = sqrtf(wave_sum(se)), nq = sqrtf(wave_sum(sq));
+            const float de = fmaxf(ne, 1e-6f), dq = fmaxf(nq, 1e-6f);
+            float u[8], qh[8], w[8];
+            float st = 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                u[k] = r[k] / de;
+                qh[k] = c[k] / dq;
+                w[k] = u[k] + qh[k];
+                st += w[k] * w[k];
+            }
+            const float nt = fmaxf(sqrtf(wave_sum(st)), 1e-6f);
+            float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                w[k] = w[k] / nt;
+                if (BWD) { a1 += g[k] * w[k]; a2 += g[k] * qh[k]; }
+                else     { a1 += r[k] * w[k]; a2 += r[k] * u[k]; }
+            }
+            a1 = wave_sum(a1);
+            a2 = wave_sum(a2);
+            const float sc = nq / de;
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                t[k] = BWD ? sc * (g[k] - 2.f * a1 * w[k] + 2.f * a2 * u[k]) : (r[k] - 2.f * a1 * w[k] + 2.f * a2 * qh[k]) * sc;
+        } else if (a.mode == 1) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) t[k] = BWD ? g[k] : (r[k] + (BF16 ? round_to_bf16(c[k] - r[k]) : (c[k] - r[k])));
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) t[k] = BWD ? 0.f : c[k];
+        }
+        if (BWD && a.loss_coef && counted) {
+            const float c2 = 2.f * a.loss_coef[q];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) t[k] += c2 * (r[k] - c[k]);
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            if (BF16 && !BWD) { acc[k] = round_to_bf16(acc[k] + round_to_bf16(t[k])); r[k] = round_to_bf16(r[k] - c[k]); }
+            else              { acc[k] += t[k]; r[k] = BF16 ? round_to_bf16(r[k] - c[k]) : (r[k] - c[k]); }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int d = lane + 64 * k;
+        if (d < a.D) {
+            if (BF16) ((unsigned short *)a.out)[n * a.ldo + d] = f32_to_bf16_rne(acc[k]);
+            else ((float *)a.out)[n * a.ldo + d] = acc[k];
+        }
+    }
+}
+
+extern "C" int vqhip_rvq_route(const void *x, int dtype, int64_t N, int D, int64_t ldx, const float *embed, int64_t embed_qstride,
+                               int C, const int64_t *idx, int64_t idx_stride, int Q, int mode, const void *g_out, int64_t ldg,
+                               const float *loss_coef, const uint8_t *row_mask, int backward, void *out, int64_t ldo, void *stream)
+{
+    if (N < 0 || !x || !embed || !idx || !out || C <= 0) VQ_FAIL(VQHIP_EINVAL, "rvq_route: bad argument");
+    if (D < 1 || D > 512) VQ_FAIL(VQHIP_EDIM, "rvq_route: D=%d unsupported (1..512)", D);
+    if (Q < 1 || idx_stride < Q) VQ_FAIL(VQHIP_EINVAL, "rvq_route: Q=%d, idx_stride=%lld", Q, (long long)idx_stride);
+    if (mode < 0 || mode > 2) VQ_FAIL(VQHIP_EINVAL, "rvq_route: mode must be 0 (plain sum / loss only), 1 or 2");
+    if (dtype != VQHIP_F32 && dtype != VQHIP_BF16) VQ_FAIL(VQHIP_EINVAL, "rvq_route: unknown dtype");
+    if (backward && mode != 0 && !g_out) VQ_FAIL(VQHIP_EINVAL, "rvq_route: backward with a routing mode needs g_out");
+    if (N == 0) return 0;
+    RvqRouteArgs a;
+    a.x = x; a.g = (backward && mode != 0) ? g_out : nullptr; a.out = out; a.embed = embed; a.qstride = embed_qstride;
+    a.idx = idx; a.idx_stride = idx_stride; a.loss_coef = backward ? loss_coef : nullptr; a.row_mask = row_mask;
+    a.N = N; a.ldx = ldx; a.ldg = ldg; a.ldo = ldo; a.D = D; a.Q = Q; a.mode = mode;
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid((unsigned)((N + 3) / 4));
+    if (dtype == VQHIP_BF16) {
+        if (backward) hipLaunchKernelGGL((vq_rvq_route_kernel<true, true>), grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((vq_rvq_route_kernel<true, false>), grid, dim3(256), 0, st, a);
+    } else {
+        if (backward) hipLaunchKernelGGL((vq_rvq_route_kernel<false, true>), grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((vq_rvq_route_kernel<false, false>), grid, dim3(256), 0, st, a);
+    }
+    return launch_status("vq_rvq_route_kernel");
+}
+
+// ------------------------------------------------------------------------------------------------
 // partial reduction (commit loss)
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) vq_reduce_kernel(const double *__restrict__ p, int64_t n, double scale, float *out)

@@ -224,7 +224,11 @@ class ResidualVQ(nn.Module):
         if is_beam:
             quantized_out, all_indices, all_losses = self._forward_beam(x, mask, sample_codebook_temp, freeze_codebook, beam_size, drop_at)
         elif self._fused_eligible(x, mask):
-            quantized_out, all_indices, all_losses = self._forward_fused(x, mask, freeze_codebook, drop_at)
+            if self._wants_input_grad(x):
+                # the same on-device loop, gradients to the input in closed form (one kernel forward, one backward)
+                quantized_out, all_indices, all_losses = _RvqFusedFn.apply(x, self, mask, freeze_codebook, drop_at)
+            else:
+                quantized_out, all_indices, all_losses = self._forward_fused(x, mask, freeze_codebook, drop_at)
         else:
             quantized_out, all_indices, all_losses = self._forward_staged(x, mask, sample_codebook_temp, freeze_codebook, drop_at)
 
@@ -247,8 +251,6 @@ class ResidualVQ(nn.Module):
             return False
         if self.codebook_dim % 32 != 0 or x.ndim != 3 or x.dtype not in (torch.float32, torch.bfloat16):
             return False
-        if self.training and x.requires_grad and torch.is_grad_enabled() and vq0.route_gradients_to_input:
-            return False            # gradients to the input take the per-stage autograd path
         if self.quant_grad_frac > 0:
             return False
         # The fused loop searches the stored `embed` with a plain argmin under no_grad: only plain EMA / frozen codebooks
@@ -269,8 +271,13 @@ class ResidualVQ(nn.Module):
             return False
         return all(layer._codebook._is_initted() for layer in self.layers)     # k-means runs in the staged path
 
+    def _wants_input_grad(self, x):
+        return self.training and x.requires_grad and torch.is_grad_enabled()
+
     @torch.no_grad()
-    def _forward_fused(self, x, mask, freeze_codebook, drop_at):
+    def _forward_fused(self, x, mask, freeze_codebook, drop_at, aux=None):
+        """aux (dict, filled for _RvqFusedFn): the codebook(s) the search used (a snapshot: the EMA fold below rewrites `embed` in
+        place), the number of active stages and d loss_q / d (sum of squared errors of stage q)."""
         Q = self.num_quantizers if drop_at is None else drop_at + 1
         vq0 = self.layers[0]
         D, C = self.codebook_dim, self.codebook_size
@@ -337,7 +344,10 @@ class ResidualVQ(nn.Module):
         else:
             r = L.rvq_forward(x, packed, embed, Q, want_resid=update, want_sqerr=want_loss, row_mask=mask)
         idx = r["idx"]
-        quantized_out = L.decode_sum(idx, embed, out_dtype=x.dtype)
+        quantized_out = L.decode_sum(idx, embed, out_dtype=x.dtype) if aux is None else None
+        if aux is not None:
+            aux["embed"] = embed.clone() if self.shared_codebook else embed      # (torch.stack above already copied)
+            aux["Q"] = Q
 
         stage_in = None
         if update:
@@ -357,7 +367,9 @@ class ResidualVQ(nn.Module):
                 sums = torch.stack([L.reduce_partials(r["sqerr_partials"][q], r["sqerr_partials"].shape[1], 1.0) for q in range(Q)])
             denom = float(x.numel()) if mask is None else (mask.sum() * D).to(torch.float32)
             losses[:Q] = sums / denom * vq0.commitment_weight
-        if train:
+            if aux is not None:
+                aux["loss_scale"] = vq0.commitment_weight / denom            # float, or a 0-dim device tensor under a mask
+        if train and aux is None:
             losses = torch.zeros(self.num_quantizers, device=x.device, requires_grad=True) + losses   # as vqp.py:1282
 
         if update:
@@ -480,6 +492,43 @@ class ResidualVQ(nn.Module):
                     stacked = torch.stack([s.flatten(2).transpose(1, 2) for s in stage_inputs], -2)
                 shared.expire_codes_(stacked.reshape(stacked.shape[0], -1, stacked.shape[-1]))
         return quantized_out, torch.stack(all_idx, -1), torch.stack(all_loss)
+
+
+class _RvqFusedFn(torch.autograd.Function):
+    """ResidualVQ's on-device loop for an input that requires grad.  Forward = the same chained search / statistics / EMA fold as
+    the no-grad path, the output formed by vq_rvq_route_kernel (sum over the stages of the straight-through / rotation-trick
+    value, rvq.py:525 + vqp.py:1225-1233); backward = the closed form of the reference's graph with quant_grad_frac = 0
+    (rvq.py:524: every stage's input is x minus DETACHED codes, so d r_q / d x = I):
+        dL/dx = sum_q J_q^T g_out + sum_q g_loss[q] * commitment_weight * 2 (r_q - c_q) / count
+    in one kernel that recomputes r_q from x and the saved indices (nothing per stage is kept)."""
+
+    @staticmethod
+    def forward(ctx, x, rvq, mask, freeze_codebook, drop_at):
+        aux = {}
+        _, idx, losses = rvq._forward_fused(x, mask, freeze_codebook, drop_at, aux=aux)
+        vq0 = rvq.layers[0]
+        mode = 0
+        if vq0.route_gradients_to_input:
+            mode = L.ROTATION if vq0.rotation_trick else L.STRAIGHT_THROUGH
+        out = L.rvq_route(x, aux["embed"], idx, aux["Q"], mode)
+        ctx.mode, ctx.Q, ctx.loss_scale, ctx.has_mask = mode, aux["Q"], aux.get("loss_scale"), mask is not None
+        ctx.save_for_backward(x, idx, aux["embed"], *([mask] if mask is not None else []))
+        ctx.mark_non_differentiable(idx)
+        return out, idx, losses
+
+    @staticmethod
+    def backward(ctx, g_out, g_idx, g_losses):
+        x, idx, embed = ctx.saved_tensors[:3]
+        mask = ctx.saved_tensors[3] if ctx.has_mask else None
+        coef = None
+        if g_losses is not None and ctx.loss_scale is not None:
+            coef = (g_losses[:ctx.Q].to(torch.float32) * ctx.loss_scale).contiguous()
+        use_g = ctx.mode != 0 and g_out is not None
+        if not use_g and coef is None:
+            return None, None, None, None, None
+        gx = L.rvq_route(x, embed, idx, ctx.Q, ctx.mode if use_g else 0, g_out=g_out.contiguous() if use_g else None,
+                         loss_coef=coef, row_mask=mask, backward=True)
+        return gx, None, None, None, None
 
 
 _SIDE_STREAMS = {}

@@ -548,15 +548,17 @@ class VectorQuantize(nn.Module):
         needs_grad = self.training and xs.requires_grad and torch.is_grad_enabled()
         dense = (return_loss or topk is not None or self.commitment_use_cross_entropy_loss or self.has_codebook_diversity_loss
                  or self.stochastic_sample_codes or self.gumbel_straight_through)
-        if self.use_cosine_sim and (needs_grad or dense or (mask is not None and self.training)):
+        param_path = (self._codebook.learnable_codebook or self._codebook.vq_bridge is not None or self.directional_reparam or dense
+                      or codebook_transform_fn is not None)
+        # (every branch of the autograd-glue path reads xs itself -- commit loss, update_indices, init_embed_, assign_rowwise -- so it
+        #  always gets the normalised rows, input with or without grad: the reference normalises first, vqp.py:1159)
+        if self.use_cosine_sim and (needs_grad or param_path or (mask is not None and self.training)):
             xs = F.normalize(xs, p=2, dim=-1, eps=1e-6)
             pre_normalized = True
 
         kw = dict(freeze_codebook=freeze_codebook, ema_update_weight=ema_update_weight,
                   accum_ema_update=accum_ema_update, ema_update=(ema_update if topk is None else False),
                   input_normalized=pre_normalized)
-        param_path = (self._codebook.learnable_codebook or self._codebook.vq_bridge is not None or self.directional_reparam or dense
-                      or codebook_transform_fn is not None)
         inplace_loss = orth_loss = diversity_loss = self.zero
         distances = None
         if param_path:
