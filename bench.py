@@ -171,16 +171,17 @@ def _time_module(mod, batches, steps, warmup, sync, windows):
 
 
 def _time_grad_step(mod, batches, steps, warmup, sync, windows):
-    """BASELINE.md §4's second line: the same module and batches, `x.requires_grad_()` + backward of (sum(quantized) + sum(loss)):
+    """BASELINE.md §4's second line: the same module and batches, `x.requires_grad_()` + backward with a resident upstream gradient for `quantized` plus the summed commitment loss(es):
     training forward (search, EMA update) plus the gradient to the input through the straight-through / rotation-trick route and
     the commitment loss."""
     xs = [b.clone().requires_grad_(True) for b in batches]
+    gq = torch.randn_like(batches[0])               # the upstream gradient of `quantized` (a decoder's), resident like the batches
 
     def step(k):
         x = xs[k % len(xs)]
         x.grad = None
         res = mod(x)
-        (res[0].float().sum() + res[2].sum()).backward()
+        torch.autograd.backward((res[0], res[2].sum()), (gq, None))     # dL/dx = J^T gq + d(sum of the commit losses)/dx
     for i in range(max(warmup, 1)):
         step(i)
     return _windows(step, steps, windows, sync)
@@ -214,7 +215,8 @@ def other_workload(args, world, rank, dev):
         shape, stages, flops = (16 // world, 16384, 512), 1, 2.0 * 16 * 16384 * 65536 * 512 / world
         name = (f"VectorQuantize(dim=512, codebook_size=65536, use_cosine_sim=True), codebook sharded over {world} rank(s), "
                 f"x=(16,16384,512) fp32 in total ({16 // world} x 16384 rows per rank, all-gathered), RCCL MAX all-reduce of packed (score, index) keys")
-        par = f"codebook sharded x{world} (rows all-gathered, one int64 MAX all-reduce, reduce-scatter of q)"
+        par = (f"codebook sharded x{world} (rows all-gathered, one int64 MAX all-reduce, then the cheaper of: all-gather of the codebook "
+               f"shards + local decode / reduce-scatter of the decoded rows)")
     nb = 2
     batches = [torch.randn(*shape, generator=gen, device=dev) for _ in range(nb)]
     if args.workload == "vq_cfg4_shard":     # what the all-gather hands a rank: rows its peers have already normalised
@@ -277,11 +279,12 @@ def other_workload(args, world, rank, dev):
                       "dtype": "f16+f32" if screened else "f32", "data": "synthetic",
                       "windows_ms_per_step": [round(d / args.steps * 1e3, 4) for d in dts],
                       "grad_step": None if gdts is None else {
-                          "workload": "same module and batches, x.requires_grad_() + backward of sum(quantized) + sum(losses) (BASELINE.md §4, second line)",
+                          "workload": "same module and batches, x.requires_grad_() + backward (upstream gradient of `quantized` resident in HBM, + sum of the commit losses) (BASELINE.md §4, second line)",
                           "ms_per_step": _median(gdts) / args.steps * 1e3, "value": n * args.steps / _median(gdts), "unit": "vectors/s",
                           "windows_ms_per_step": [round(d / args.steps * 1e3, 4) for d in gdts]},
                       "config": {"workload": name, "parallelism": par, "vector_stages_per_s": n * stages * args.steps / dt,
                                  "world_size": world, "backend": (dist.get_backend() if world > 1 else None),
+                                 "collective_bytes_per_rank_and_step": getattr(mod, "last_comm", None) or None,
                                  "first_forward_ms": first * 1e3, "uncertified_rows_per_search": per_stage},
                       "roofline": {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
                                    "traffic": None, "achieved_vs_fp32_mfma_peak": ach / PEAK_FP32_MFMA_TFLOPS,
@@ -383,7 +386,7 @@ def vq_cfg2(args, world, rank, dev):
         "data": "synthetic",
         "windows_ms_per_step": [round(d / args.steps * 1e3, 4) for d in dts],   # ms_per_step / value = the median window
         "grad_step": None if gdts is None else {
-            "workload": ("same module and batches, x.requires_grad_() + backward of sum(quantized) + loss: rotation-trick route (the "
+            "workload": ("same module and batches, x.requires_grad_() + backward (upstream gradient of `quantized` resident in HBM, + the commit loss): rotation-trick route (the "
                          "module default, vqp.py:856) + commit-loss gradient (BASELINE.md §4, second line)"),
             "ms_per_step": _median(gdts) / args.steps * 1e3, "value": world * n_vec * args.steps / _median(gdts), "unit": "vectors/s",
             "windows_ms_per_step": [round(d / args.steps * 1e3, 4) for d in gdts]},

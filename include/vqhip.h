@@ -220,6 +220,12 @@ int vqhip_ema_finalize(float *cluster_size, float *embed_avg, float *embed,
                        int C, int D, float one_minus_decay, float eps, int cosine,
                        int do_lerp, int do_update_ema, float *denom_ws, void *stream);
 
+/* update_ema (vqp.py:576-584) on ONE SHARD of a codebook partitioned over ranks: the Laplace smoothing (vqp.py:152-154) needs
+ * sum(cluster_size) and the code count of the whole codebook -- total_cluster_size is a DEVICE scalar (the caller all-reduces the
+ * shards' sums), C_total the global code count.  embed = embed_avg / ((cs + eps) / (total + C_total eps) * total) [, l2norm]. */
+int vqhip_ema_renormalize_shard(const float *cluster_size, float *embed_avg, float *embed, int C, int D, float eps,
+                                const float *total_cluster_size, int C_total, int cosine, float *denom_ws, void *stream);
+
 /* The Q folds of a codebook shared by the stages of a residual VQ (residual_vq.py:213-217: every stage's update_codebook lerps
  * its statistics into the one codebook, vqp.py:616-617; the renormalisation update_ema runs once afterwards, rvq.py:593-598) in
  * one call: the same lerps in the same (stage) order.  stats: Q blocks of `stride` floats, each embed_sum [C, D] then count [C]. */

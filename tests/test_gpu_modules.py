@@ -347,32 +347,42 @@ def test_route_kernels_match_autograd_of_the_reference_formula(dev, mode, dtype)
     _close(gx.float(), xr.grad, tol, "grad_x")
 
 
-def _sharded_worker(rank, world, port, out_path, cosine):
+def _sharded_worker(rank, world, port, out_path, cosine, exchange="auto", backend="gloo"):
     import os
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)       # 2 ranks on the ONE test GPU: gloo moves cuda tensors
+    if backend == "nccl":                                              # RCCL: one GPU per rank
+        torch.cuda.set_device(rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+        dev = torch.device("cuda", rank)
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)   # 2 ranks on the ONE test GPU: gloo moves cuda tensors
+        dev = torch.device("cuda:0")
     from vector_quantize_pytorch_amd.parallel import ShardedVectorQuantize
-    dev = torch.device("cuda:0")
     torch.manual_seed(0)
-    vq = ShardedVectorQuantize(64, 200, use_cosine_sim=cosine).to(dev).train()
+    vq = ShardedVectorQuantize(64, 200, use_cosine_sim=cosine, exchange=exchange).to(dev).train()
     g = torch.Generator().manual_seed(100 + rank)
     x = torch.randn(2, 300, 64, generator=g).to(dev)
     q, idx, loss = vq(x)
-    torch.save(dict(q=q.cpu(), idx=idx.cpu(), loss=loss.cpu(), embed=vq._codebook.embed.cpu(), lo=vq.lo, hi=vq.hi), f"{out_path}.{rank}")
+    full = vq.full_codebook_state()
+    torch.save(dict(q=q.cpu(), idx=idx.cpu(), loss=loss.cpu(), embed=vq._codebook.embed.cpu(), lo=vq.lo, hi=vq.hi,
+                    comm=dict(vq.last_comm), full_embed=full["embed"].cpu()), f"{out_path}.{rank}")
     dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("exchange", ["codebook", "rows"])
 @pytest.mark.parametrize("cosine", [False, True])
-def test_sharded_codebook_equals_unsharded(dev, tmp_path, cosine):
-    """2 ranks x half the codebook each == one VectorQuantize with the full codebook on the concatenated rows."""
+def test_sharded_codebook_equals_unsharded(dev, tmp_path, cosine, exchange, backend="gloo"):
+    """2 ranks x half the codebook each == one VectorQuantize with the full codebook on the concatenated rows, for both ways of
+    bringing the quantized rows home (all-gather of the codebook shards / reduce of the decoded rows)."""
     import socket
     import torch.multiprocessing as mp
     from vector_quantize_pytorch_amd import VectorQuantize
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     out = str(tmp_path / "sh")
-    mp.spawn(_sharded_worker, args=(2, port, out, cosine), nprocs=2, join=True)
+    mp.spawn(_sharded_worker, args=(2, port, out, cosine, exchange, backend), nprocs=2, join=True)
     r = [torch.load(f"{out}.{k}") for k in range(2)]
+    assert any(k.startswith("all_gather codebook") for k in r[0]["comm"]) == (exchange == "codebook"), r[0]["comm"]
     torch.manual_seed(0)
     vq = VectorQuantize(dim=64, codebook_size=200, use_cosine_sim=cosine).to(dev).train()
     xs = [torch.randn(2, 300, 64, generator=torch.Generator().manual_seed(100 + k)) for k in range(2)]
@@ -384,6 +394,17 @@ def test_sharded_codebook_equals_unsharded(dev, tmp_path, cosine):
     _close(torch.stack([r[0]["loss"], r[1]["loss"]]).mean(), loss, 1e-5, "loss")
     full = torch.cat([r[0]["embed"], r[1]["embed"]], 1)
     _close(full, vq._codebook.embed, 1e-5, "embed after the EMA step")
+    assert torch.equal(r[0]["full_embed"], full) and torch.equal(r[1]["full_embed"], full)     # full_codebook_state(): the gathered shards
+
+
+@pytest.mark.parametrize("exchange", ["codebook", "rows"])
+def test_sharded_codebook_over_rccl_on_two_gpus(dev, tmp_path, exchange):
+    """The same comparison with one GPU per rank over RCCL (backend "nccl"): all_gather_into_tensor, the int64 MAX all-reduce and
+    reduce_scatter_tensor on the real transport.  Needs two GPUs: skipped on the one-GPU test box, runs wherever the suite sees
+    a multi-GPU node."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs >= 2 GPUs (RCCL)")
+    test_sharded_codebook_equals_unsharded(dev, tmp_path, True, exchange, backend="nccl")
 
 
 def _dp_worker(rank, world, port, out_path):

@@ -73,6 +73,8 @@ def lib():
     L.vqhip_route_fwd.argtypes = [vp, vp, i32, i64, i32, i64, i64, vp, i64, i32, vp]
     L.vqhip_route_bwd.argtypes = [vp, vp, vp, i32, i64, i32, i64, i64, i64, vp, vp, i32, vp, i64, vp]
     L.vqhip_route_fwd.restype = i32
+    L.vqhip_ema_renormalize_shard.argtypes = [vp, vp, vp, i32, i32, f32, vp, i32, i32, vp, vp]
+    L.vqhip_ema_renormalize_shard.restype = i32
     # (x, dtype, N, D, ldx, embed, embed_qstride, C, idx, idx_stride, Q, mode, g_out, ldg, loss_coef, row_mask, backward, out, ldo, stream)
     L.vqhip_rvq_route.argtypes = [vp, i32, i64, i32, i64, vp, i64, i32, vp, i64, i32, i32, vp, i64, vp, vp, i32, vp, i64, vp]
     L.vqhip_route_bwd.restype = i32
@@ -97,7 +99,7 @@ def lib():
     L.vqhip_kmeans_update.argtypes = [vp, vp, vp, i32, i32, i32, vp]
     L.vqhip_kmeans_update.restype = i32
     for name in ("vqhip_pack_codebook", "vqhip_assign", "vqhip_reduce_partials", "vqhip_ema_accumulate",
-                 "vqhip_ema_finalize", "vqhip_decode_sum", "vqhip_row_sumsq", "vqhip_assign_rowwise", "vqhip_score_indices", "vqhip_topk", "vqhip_expire_scatter", "vqhip_kmeans_update", "vqhip_route_fwd", "vqhip_route_bwd", "vqhip_rvq_route"):
+                 "vqhip_ema_finalize", "vqhip_decode_sum", "vqhip_row_sumsq", "vqhip_assign_rowwise", "vqhip_score_indices", "vqhip_topk", "vqhip_expire_scatter", "vqhip_kmeans_update", "vqhip_route_fwd", "vqhip_route_bwd", "vqhip_rvq_route", "vqhip_ema_renormalize_shard"):
         getattr(L, name).restype = i32
     _lib = L
     return L
@@ -106,7 +108,7 @@ def lib():
 EXPORTS = ("vqhip_version", "vqhip_last_error", "vqhip_packed_bytes", "vqhip_pack_codebook",
            "vqhip_assign_blocks", "vqhip_assign", "vqhip_screen_supported", "vqhip_screen_workspace_bytes",
            "vqhip_screen_blocks", "vqhip_screen_partials", "vqhip_assign_screened", "vqhip_screen_chain_supported", "vqhip_assign_screened_chain", "vqhip_l2norm_rows", "vqhip_scores", "vqhip_rvq_forward", "vqhip_reduce_partials", "vqhip_reduce_partials_rows", "vqhip_ema_fold_many", "vqhip_ema_workspace_bytes", "vqhip_ema_accumulate", "vqhip_ema_sqerr_partials", "vqhip_ema_accumulate_sqerr",
-           "vqhip_ema_finalize", "vqhip_decode_sum", "vqhip_row_sumsq", "vqhip_assign_rowwise", "vqhip_score_indices", "vqhip_topk", "vqhip_expire_scatter", "vqhip_kmeans_update", "vqhip_route_fwd", "vqhip_route_bwd", "vqhip_rvq_route")
+           "vqhip_ema_finalize", "vqhip_decode_sum", "vqhip_row_sumsq", "vqhip_assign_rowwise", "vqhip_score_indices", "vqhip_topk", "vqhip_expire_scatter", "vqhip_kmeans_update", "vqhip_route_fwd", "vqhip_route_bwd", "vqhip_rvq_route", "vqhip_ema_renormalize_shard")
 
 
 def _check(rc, what):
@@ -605,6 +607,20 @@ def ema_finalize(cluster_size, embed_avg, embed, count, embed_sum, *, decay, eps
     _check(lib().vqhip_ema_finalize(_ptr(cluster_size), _ptr(embed_avg), _ptr(embed), _ptr(count), _ptr(embed_sum),
                                     _ptr(weight), C, D, omd, float(eps), int(cosine), int(do_lerp),
                                     int(do_update_ema), _ptr(denom_ws), _stream()), "vqhip_ema_finalize")
+
+
+@_on_device
+def ema_renormalize_shard(cluster_size, embed_avg, embed, total_cluster_size, C_total, *, eps, cosine=False):
+    """update_ema on one shard [C_local, D] of a codebook partitioned over ranks; total_cluster_size: 0-dim fp32 device tensor holding
+    sum(cluster_size) over ALL shards (vqp.py:152-154, 576-584)."""
+    _need_gpu(cluster_size, embed_avg, embed, total_cluster_size)
+    C, D = embed.shape
+    for t in (cluster_size, embed_avg, embed):
+        assert t.is_contiguous() and t.dtype == torch.float32
+    total = total_cluster_size.to(torch.float32).reshape(()).contiguous()
+    ws = torch.empty(C, dtype=torch.float32, device=embed.device)
+    _check(lib().vqhip_ema_renormalize_shard(_ptr(cluster_size), _ptr(embed_avg), _ptr(embed), C, D, float(eps), _ptr(total), int(C_total),
+                                             int(cosine), _ptr(ws), _stream()), "vqhip_ema_renormalize_shard")
 
 
 @_on_device

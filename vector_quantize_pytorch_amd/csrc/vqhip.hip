@@ -27,6 +27,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <math.h>
+#include <type_traits>
 
 #include "vqhip_internal.h"
 
@@ -2083,11 +2084,79 @@ extern "C" int vqhip_rvq_forward(const void *x, int x_dtype, int64_t N, int D, i
 //   commit loss mean((q.detach() - x)^2) (vqp.py:1327): grad_x += coef * 2 (x - q), coef = dL/d(sum of squares),
 //   a DEVICE scalar (no host sync), rows with row_mask == 0 excluded.
 // ------------------------------------------------------------------------------------------------
+// Sum over the 64 lanes, the same value in every lane.  DPP butterfly inside each row of 16 lanes (quad_perm, row_half_mirror,
+// row_mirror: VALU only), then the four row sums through v_readlane -- no LDS traffic.  (The first version was six __shfl_xor =
+// ds_bpermute round trips; with five reductions per row and stage the routing kernels ran at 1.5 TB/s of row traffic, LDS-queue bound.)
 __device__ __forceinline__ float wave_sum(float v)
 {
+    auto dpp = [](float x, auto ctrl) {
+        return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), decltype(ctrl)::value, 0xf, 0xf, true));
+    };
+    v += dpp(v, std::integral_constant<int, 0xB1>{});    // quad_perm [1, 0, 3, 2]
+    v += dpp(v, std::integral_constant<int, 0x4E>{});    // quad_perm [2, 3, 0, 1]
+    v += dpp(v, std::integral_constant<int, 0x141>{});   // row_half_mirror
+    v += dpp(v, std::integral_constant<int, 0x140>{});   // row_mirror: every lane of a row holds the row's sum
+    const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
+    const float r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+    const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
+    const float r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+    return (r0 + r1) + (r2 + r3);
+}
+
+// Row access of the routing kernels: lane l owns the elements 4 (64 k + l) + i, k < 2, i < 4 -- four CONTIGUOUS elements per
+// slice (NE = 4: D <= 256, one slice; NE = 8: two), moved by one 8-byte (bf16) / 16-byte (fp32) access when the row allows it (`vec`: D % 4 == 0 and base / stride aligned
+// to 4 elements); otherwise element by element.  (The first version gave lane l the elements l + 64 k: 2-byte accesses for bf16.)
+template <bool BF16, int NE>
+__device__ __forceinline__ void row_load8(const void *base, int64_t off, int D, int lane, bool vec, float (&v)[NE])
+{
 #pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    for (int k = 0; k < NE / 4; ++k) {
+        const int d0 = 4 * (64 * k + lane);
+        if (vec && d0 < D) {
+            if (BF16) {
+                const uint2 w = *(const uint2 *)((const unsigned short *)base + off + d0);
+                v[4 * k + 0] = __uint_as_float(w.x << 16); v[4 * k + 1] = __uint_as_float(w.x & 0xffff0000u);
+                v[4 * k + 2] = __uint_as_float(w.y << 16); v[4 * k + 3] = __uint_as_float(w.y & 0xffff0000u);
+            } else {
+                const f32x4 w = *(const f32x4 *)((const float *)base + off + d0);
+                v[4 * k + 0] = w.x; v[4 * k + 1] = w.y; v[4 * k + 2] = w.z; v[4 * k + 3] = w.w;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[4 * k + i] = (d0 + i < D) ? load_elem<BF16>(base, off + d0 + i) : 0.f;
+        }
+    }
+}
+
+template <bool BF16, int NE>
+__device__ __forceinline__ void row_store8(void *base, int64_t off, int D, int lane, bool vec, const float (&v)[NE])
+{
+#pragma unroll
+    for (int k = 0; k < NE / 4; ++k) {
+        const int d0 = 4 * (64 * k + lane);
+        if (vec && d0 < D) {
+            if (BF16) {
+                uint2 w;
+                w.x = (unsigned)f32_to_bf16_rne(v[4 * k + 0]) | ((unsigned)f32_to_bf16_rne(v[4 * k + 1]) << 16);
+                w.y = (unsigned)f32_to_bf16_rne(v[4 * k + 2]) | ((unsigned)f32_to_bf16_rne(v[4 * k + 3]) << 16);
+                *(uint2 *)((unsigned short *)base + off + d0) = w;
+            } else {
+                *(f32x4 *)((float *)base + off + d0) = f32x4{v[4 * k + 0], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]};
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (d0 + i < D) {
+                    if (BF16) ((unsigned short *)base)[off + d0 + i] = f32_to_bf16_rne(v[4 * k + i]);
+                    else ((float *)base)[off + d0 + i] = v[4 * k + i];
+                }
+        }
+    }
+}
+
+static inline bool rows_vec4(const void *p, int64_t ld, int D, int es)
+{
+    return p == nullptr || ((D & 3) == 0 && (ld & 3) == 0 && (((uintptr_t)p) % (size_t)(4 * es)) == 0);
 }
 
 struct RouteArgs {
@@ -2101,46 +2170,46 @@ struct RouteArgs {
     const float *loss_coef; // backward only, nullable device scalar
     const uint8_t *row_mask;
     int mode;
+    int vec;                // every row pointer / stride allows 4-element accesses
 };
 
-template <bool BF16, bool BWD>
+template <bool BF16, bool BWD, int NE>
 __global__ void __launch_bounds__(256) vq_route_kernel(const RouteArgs a)
 {
     const int lane = threadIdx.x & 63;
     const int64_t n = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (n >= a.N) return;
-    float e[8], qv[8], g[8];
+    float e[NE], qv[NE], g[NE];
     float se = 0.f, sq = 0.f;
+    row_load8<BF16, NE>(a.x, n * a.ldx, a.D, lane, a.vec != 0, e);
+    row_load8<BF16, NE>(a.q, n * a.ldq, a.D, lane, a.vec != 0, qv);
+    if (BWD && a.g) row_load8<BF16, NE>(a.g, n * a.ldg, a.D, lane, a.vec != 0, g);
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        const int d = lane + 64 * k;
-        e[k] = qv[k] = g[k] = 0.f;
-        if (d < a.D) {
-            e[k] = load_elem<BF16>(a.x, n * a.ldx + d);
-            qv[k] = load_elem<BF16>(a.q, n * a.ldq + d);
-            if (BWD && a.g) g[k] = load_elem<BF16>(a.g, n * a.ldg + d);
-        }
+    for (int k = 0; k < NE; ++k) {
+        if (!(BWD && a.g)) g[k] = 0.f;
         se += e[k] * e[k];
         sq += qv[k] * qv[k];
     }
-    float r[8];
+    float r[NE];
     if (a.mode == 2) {
         const float ne = sqrtf(wave_sum(se)), nq = sqrtf(wave_sum(sq));
         const float de = fmaxf(ne, 1e-6f), dq = fmaxf(nq, 1e-6f);
-        float u[8], qh[8], w[8];
+        const float ide = 1.f / de, idq = 1.f / dq;       // one reciprocal per row, then multiplies (x / |x| to 1 ulp): IEEE divisions per
+        float u[NE], qh[NE], w[NE];                       // element made these kernels ALU-bound (1.5 TB/s of row traffic)
         float st = 0.f;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            u[k] = e[k] / de;
-            qh[k] = qv[k] / dq;
+        for (int k = 0; k < NE; ++k) {
+            u[k] = e[k] * ide;
+            qh[k] = qv[k] * idq;
             w[k] = u[k] + qh[k];
             st += w[k] * w[k];
         }
         const float nt = fmaxf(sqrtf(wave_sum(st)), 1e-6f);
+        const float int_ = 1.f / nt;
         float a1 = 0.f, a2 = 0.f;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            w[k] = w[k] / nt;
+        for (int k = 0; k < NE; ++k) {
+            w[k] = w[k] * int_;
             if (BWD) { a1 += g[k] * w[k]; a2 += g[k] * qh[k]; }
             else     { a1 += e[k] * w[k]; a2 += e[k] * u[k]; }
         }
@@ -2148,39 +2217,33 @@ __global__ void __launch_bounds__(256) vq_route_kernel(const RouteArgs a)
         a2 = wave_sum(a2);
         const float sc = nq / de;
 #pragma unroll
-        for (int k = 0; k < 8; ++k)
+        for (int k = 0; k < NE; ++k)
             r[k] = BWD ? sc * (g[k] - 2.f * a1 * w[k] + 2.f * a2 * u[k]) : (e[k] - 2.f * a1 * w[k] + 2.f * a2 * qh[k]) * sc;
     } else {
 #pragma unroll
-        for (int k = 0; k < 8; ++k) r[k] = BWD ? g[k] : (e[k] + (qv[k] - e[k]));
+        for (int k = 0; k < NE; ++k) r[k] = BWD ? g[k] : (e[k] + (qv[k] - e[k]));
     }
     if (BWD && a.loss_coef) {
         const bool counted = !a.row_mask || a.row_mask[n] != 0;
         const float c2 = counted ? 2.f * (*a.loss_coef) : 0.f;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) r[k] += c2 * (e[k] - qv[k]);
+        for (int k = 0; k < NE; ++k) r[k] += c2 * (e[k] - qv[k]);
     }
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        const int d = lane + 64 * k;
-        if (d < a.D) {
-            if (BF16) ((unsigned short *)a.out)[n * a.ldo + d] = f32_to_bf16_rne(r[k]);
-            else ((float *)a.out)[n * a.ldo + d] = r[k];
-        }
-    }
+    row_store8<BF16, NE>(a.out, n * a.ldo, a.D, lane, a.vec != 0, r);
 }
 
 static int route_launch(const RouteArgs &a, int dtype, bool bwd, hipStream_t st)
 {
     if (a.N == 0) return 0;
     dim3 grid((unsigned)((a.N + 3) / 4));
+#define VQ_ROUTE_LAUNCH(BF, BW) do { if (a.D <= 256) hipLaunchKernelGGL((vq_route_kernel<BF, BW, 4>), grid, dim3(256), 0, st, a); \
+                                     else hipLaunchKernelGGL((vq_route_kernel<BF, BW, 8>), grid, dim3(256), 0, st, a); } while (0)
     if (dtype == VQHIP_BF16) {
-        if (bwd) hipLaunchKernelGGL((vq_route_kernel<true, true>), grid, dim3(256), 0, st, a);
-        else hipLaunchKernelGGL((vq_route_kernel<true, false>), grid, dim3(256), 0, st, a);
+        if (bwd) VQ_ROUTE_LAUNCH(true, true); else VQ_ROUTE_LAUNCH(true, false);
     } else {
-        if (bwd) hipLaunchKernelGGL((vq_route_kernel<false, true>), grid, dim3(256), 0, st, a);
-        else hipLaunchKernelGGL((vq_route_kernel<false, false>), grid, dim3(256), 0, st, a);
+        if (bwd) VQ_ROUTE_LAUNCH(false, true); else VQ_ROUTE_LAUNCH(false, false);
     }
+#undef VQ_ROUTE_LAUNCH
     return launch_status("vq_route_kernel");
 }
 
@@ -2194,6 +2257,8 @@ extern "C" int vqhip_route_fwd(const void *x, const void *q, int dtype, int64_t 
     RouteArgs a;
     a.x = x; a.q = q; a.g = nullptr; a.out = out; a.N = N; a.D = D; a.ldx = ldx; a.ldq = ldq; a.ldg = 0; a.ldo = ldo;
     a.loss_coef = nullptr; a.row_mask = nullptr; a.mode = mode;
+    const int es = dtype == VQHIP_BF16 ? 2 : 4;
+    a.vec = rows_vec4(x, ldx, D, es) && rows_vec4(q, ldq, D, es) && rows_vec4(out, ldo, D, es);
     return route_launch(a, dtype, false, (hipStream_t)stream);
 }
 
@@ -2208,6 +2273,8 @@ extern "C" int vqhip_route_bwd(const void *x, const void *q, const void *g_out, 
     RouteArgs a;
     a.x = x; a.q = q; a.g = (mode == 0) ? nullptr : g_out; a.out = grad_x; a.N = N; a.D = D; a.ldx = ldx; a.ldq = ldq;
     a.ldg = ldg; a.ldo = ldo; a.loss_coef = loss_coef; a.row_mask = row_mask; a.mode = (mode == 0) ? 1 : mode;
+    const int es = dtype == VQHIP_BF16 ? 2 : 4;
+    a.vec = rows_vec4(x, ldx, D, es) && rows_vec4(q, ldq, D, es) && rows_vec4(a.g, ldg, D, es) && rows_vec4(grad_x, ldo, D, es);
     return route_launch(a, dtype, true, (hipStream_t)stream);
 }
 
@@ -2230,58 +2297,57 @@ struct RvqRouteArgs {
     const float *loss_coef;    // BWD, nullable: [Q] device floats, d loss_total / d (sum of squares of stage q)
     const uint8_t *row_mask;
     int64_t N, ldx, ldg, ldo;
-    int D, Q, mode;
+    int D, Q, mode, vec;
 };
 
-template <bool BF16, bool BWD>
+template <bool BF16, bool BWD, int NE>
 __global__ void __launch_bounds__(256) vq_rvq_route_kernel(const RvqRouteArgs a)
 {
     const int lane = threadIdx.x & 63;
     const int64_t n = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (n >= a.N) return;
-    float r[8], g[8], acc[8];
+    float r[NE], g[NE], acc[NE];
+    row_load8<BF16, NE>(a.x, n * a.ldx, a.D, lane, a.vec != 0, r);
+    if (BWD && a.g) row_load8<BF16, NE>(a.g, n * a.ldg, a.D, lane, a.vec != 0, g);
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        const int d = lane + 64 * k;
-        r[k] = g[k] = acc[k] = 0.f;
-        if (d < a.D) {
-            r[k] = load_elem<BF16>(a.x, n * a.ldx + d);
-            if (BWD && a.g) g[k] = load_elem<BF16>(a.g, n * a.ldg + d);
-        }
+    for (int k = 0; k < NE; ++k) {
+        acc[k] = 0.f;
+        if (!(BWD && a.g)) g[k] = 0.f;
     }
     const bool counted = !a.row_mask || a.row_mask[n] != 0;
     for (int q = 0; q < a.Q; ++q) {
         const int64_t code = a.idx[n * a.idx_stride + q];
         if (code < 0) break;                                     // dropped-out quantizers (rvq.py:478-482) and masked rows
         const float *cp = a.embed + (size_t)q * a.qstride + (size_t)code * a.D;
-        float c[8];
+        float c[NE];
         float se = 0.f, sq = 0.f;
+        row_load8<false, NE>(cp, 0, a.D, lane, (a.D & 3) == 0, c);   // code rows: fp32, [C, D] contiguous, 16-byte aligned when D % 4 == 0
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int d = lane + 64 * k;
-            c[k] = d < a.D ? cp[d] : 0.f;
+        for (int k = 0; k < NE; ++k) {
             if (BF16) c[k] = round_to_bf16(c[k]);
             se += r[k] * r[k];
             sq += c[k] * c[k];
         }
-        float t[8];
+        float t[NE];
         if (a.mode == 2) {                                       // rotation trick: the arithmetic of vq_route_kernel
             const float ne = sqrtf(wave_sum(se)), nq = sqrtf(wave_sum(sq));
             const float de = fmaxf(ne, 1e-6f), dq = fmaxf(nq, 1e-6f);
-            float u[8], qh[8], w[8];
+            const float ide = 1.f / de, idq = 1.f / dq;
+            float u[NE], qh[NE], w[NE];
             float st = 0.f;
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                u[k] = r[k] / de;
-                qh[k] = c[k] / dq;
+            for (int k = 0; k < NE; ++k) {
+                u[k] = r[k] * ide;
+                qh[k] = c[k] * idq;
                 w[k] = u[k] + qh[k];
                 st += w[k] * w[k];
             }
             const float nt = fmaxf(sqrtf(wave_sum(st)), 1e-6f);
+            const float int_ = 1.f / nt;
             float a1 = 0.f, a2 = 0.f;
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                w[k] = w[k] / nt;
+            for (int k = 0; k < NE; ++k) {
+                w[k] = w[k] * int_;
                 if (BWD) { a1 += g[k] * w[k]; a2 += g[k] * qh[k]; }
                 else     { a1 += r[k] * w[k]; a2 += r[k] * u[k]; }
             }
@@ -2289,34 +2355,27 @@ __global__ void __launch_bounds__(256) vq_rvq_route_kernel(const RvqRouteArgs a)
             a2 = wave_sum(a2);
             const float sc = nq / de;
 #pragma unroll
-            for (int k = 0; k < 8; ++k)
+            for (int k = 0; k < NE; ++k)
                 t[k] = BWD ? sc * (g[k] - 2.f * a1 * w[k] + 2.f * a2 * u[k]) : (r[k] - 2.f * a1 * w[k] + 2.f * a2 * qh[k]) * sc;
         } else if (a.mode == 1) {
 #pragma unroll
-            for (int k = 0; k < 8; ++k) t[k] = BWD ? g[k] : (r[k] + (BF16 ? round_to_bf16(c[k] - r[k]) : (c[k] - r[k])));
+            for (int k = 0; k < NE; ++k) t[k] = BWD ? g[k] : (r[k] + (BF16 ? round_to_bf16(c[k] - r[k]) : (c[k] - r[k])));
         } else {
 #pragma unroll
-            for (int k = 0; k < 8; ++k) t[k] = BWD ? 0.f : c[k];
+            for (int k = 0; k < NE; ++k) t[k] = BWD ? 0.f : c[k];
         }
         if (BWD && a.loss_coef && counted) {
             const float c2 = 2.f * a.loss_coef[q];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) t[k] += c2 * (r[k] - c[k]);
+            for (int k = 0; k < NE; ++k) t[k] += c2 * (r[k] - c[k]);
         }
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
+        for (int k = 0; k < NE; ++k) {
             if (BF16 && !BWD) { acc[k] = round_to_bf16(acc[k] + round_to_bf16(t[k])); r[k] = round_to_bf16(r[k] - c[k]); }
             else              { acc[k] += t[k]; r[k] = BF16 ? round_to_bf16(r[k] - c[k]) : (r[k] - c[k]); }
         }
     }
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        const int d = lane + 64 * k;
-        if (d < a.D) {
-            if (BF16) ((unsigned short *)a.out)[n * a.ldo + d] = f32_to_bf16_rne(acc[k]);
-            else ((float *)a.out)[n * a.ldo + d] = acc[k];
-        }
-    }
+    row_store8<BF16, NE>(a.out, n * a.ldo, a.D, lane, a.vec != 0, acc);
 }
 
 extern "C" int vqhip_rvq_route(const void *x, int dtype, int64_t N, int D, int64_t ldx, const float *embed, int64_t embed_qstride,
@@ -2334,15 +2393,19 @@ extern "C" int vqhip_rvq_route(const void *x, int dtype, int64_t N, int D, int64
     a.x = x; a.g = (backward && mode != 0) ? g_out : nullptr; a.out = out; a.embed = embed; a.qstride = embed_qstride;
     a.idx = idx; a.idx_stride = idx_stride; a.loss_coef = backward ? loss_coef : nullptr; a.row_mask = row_mask;
     a.N = N; a.ldx = ldx; a.ldg = ldg; a.ldo = ldo; a.D = D; a.Q = Q; a.mode = mode;
+    const int es = dtype == VQHIP_BF16 ? 2 : 4;
+    a.vec = rows_vec4(x, ldx, D, es) && rows_vec4(a.g, ldg, D, es) && rows_vec4(out, ldo, D, es);
+    if ((D & 3) == 0 && ((((uintptr_t)embed) & 15) || (embed_qstride & 3))) VQ_FAIL(VQHIP_EALIGN, "rvq_route: embed must be 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
     dim3 grid((unsigned)((N + 3) / 4));
+#define VQ_RVQ_ROUTE_LAUNCH(BF, BW) do { if (D <= 256) hipLaunchKernelGGL((vq_rvq_route_kernel<BF, BW, 4>), grid, dim3(256), 0, st, a); \
+                                         else hipLaunchKernelGGL((vq_rvq_route_kernel<BF, BW, 8>), grid, dim3(256), 0, st, a); } while (0)
     if (dtype == VQHIP_BF16) {
-        if (backward) hipLaunchKernelGGL((vq_rvq_route_kernel<true, true>), grid, dim3(256), 0, st, a);
-        else hipLaunchKernelGGL((vq_rvq_route_kernel<true, false>), grid, dim3(256), 0, st, a);
+        if (backward) VQ_RVQ_ROUTE_LAUNCH(true, true); else VQ_RVQ_ROUTE_LAUNCH(true, false);
     } else {
-        if (backward) hipLaunchKernelGGL((vq_rvq_route_kernel<false, true>), grid, dim3(256), 0, st, a);
-        else hipLaunchKernelGGL((vq_rvq_route_kernel<false, false>), grid, dim3(256), 0, st, a);
+        if (backward) VQ_RVQ_ROUTE_LAUNCH(false, true); else VQ_RVQ_ROUTE_LAUNCH(false, false);
     }
+#undef VQ_RVQ_ROUTE_LAUNCH
     return launch_status("vq_rvq_route_kernel");
 }
 
@@ -2988,6 +3051,31 @@ extern "C" int vqhip_ema_finalize(float *cluster_size, float *embed_avg, float *
         hipLaunchKernelGGL(vq_ema_embed_kernel, dim3((C + 3) / 4), dim3(256), 0, st, embed_avg, embed, embed_sum, weight,
                            denom_ws, C, D, one_minus_decay, cosine, do_lerp, do_update_ema);
     return launch_status("vq_ema_finalize");
+}
+
+// Renormalisation of ONE SHARD of a codebook partitioned over ranks (parallel.ShardedVectorQuantize): the Laplace smoothing of
+// vqp.py:152-154 / :577 uses sum(cluster_size) and the code count of the WHOLE codebook, which the caller all-reduces and passes in
+// (a device scalar: no host sync); everything else is update_ema's arithmetic on the shard's rows (vqp.py:576-584).
+__global__ void __launch_bounds__(256) vq_ema_denom_ext_kernel(const float *cs, int C, float eps, float ceps_total, const float *total_p, float *denom)
+{
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const float total = *total_p;
+    denom[c] = (cs[c] + eps) / (total + ceps_total) * total;
+}
+
+extern "C" int vqhip_ema_renormalize_shard(const float *cluster_size, float *embed_avg, float *embed, int C, int D, float eps,
+                                           const float *total_cluster_size, int C_total, int cosine, float *denom_ws, void *stream)
+{
+    if (!cluster_size || !embed_avg || !embed || !total_cluster_size || !denom_ws || C <= 0 || C_total < C)
+        VQ_FAIL(VQHIP_EINVAL, "ema_renormalize_shard: null pointer, C <= 0 or C_total < C");
+    if (D < 1 || D > 512) VQ_FAIL(VQHIP_EDIM, "ema_renormalize_shard: D=%d unsupported (1..512)", D);
+    hipStream_t st = (hipStream_t)stream;
+    const float ceps = (float)((double)C_total * (double)eps);
+    hipLaunchKernelGGL(vq_ema_denom_ext_kernel, dim3((C + 255) / 256), dim3(256), 0, st, cluster_size, C, eps, ceps, total_cluster_size, denom_ws);
+    hipLaunchKernelGGL(vq_ema_embed_kernel, dim3((C + 3) / 4), dim3(256), 0, st, embed_avg, embed, (const float *)nullptr, (const float *)nullptr,
+                       denom_ws, C, D, 0.f, cosine, 0, 1);
+    return launch_status("vq_ema_renormalize_shard");
 }
 
 // A codebook shared by the Q stages of a residual VQ is lerp-ed Q times in stage order (rvq.py:213-217 + vqp.py:616-617: every

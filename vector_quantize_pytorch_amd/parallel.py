@@ -70,16 +70,26 @@ class ShardedVectorQuantize(torch.nn.Module):
     reference only replicates codebooks).  Rank p owns codes [lo_p, hi_p) (`shard_bounds`).
 
     forward(x): x [b, n, d] holds THIS rank's rows.  With `gather_input=True` (default) the rows of all
-    ranks are all-gathered, every rank scores all rows against its shard (vqhip_assign), ONE
-    all_reduce(MAX) of the packed int64 keys picks the global winner with the reference's tie rule, each
-    rank decodes the winners it owns and a reduce-scatter(SUM) hands every rank the quantized rows it
-    contributed.  EMA needs no collective for the sums: the owner of a code sees every row assigned to it;
-    only the scalar sum(cluster_size) of the Laplace smoothing (vqp.py:577) is all-reduced.
+    ranks are all-gathered (in the input's dtype: bf16 rows travel as bf16), every rank scores all rows against
+    its shard, ONE all_reduce(MAX) of the packed int64 keys picks the global winner with the reference's tie
+    rule -- after it EVERY rank knows the winning global index of every row.  The quantized rows then come back
+    by the cheaper of two exchanges (`exchange`, per-rank bytes on the wire in `last_comm`):
+      "codebook"  all-gather the codebook shards (C x d x 4 bytes) and decode this rank's rows locally;
+      "rows"      every rank decodes the winners it owns, reduce-scatter(SUM) of the zero-filled [N_total, d] fp32 rows.
+    cfg 4 (N_total = 262144, C = 65536, d = 512): 128 MiB against 512 MiB.
+    EMA needs no collective for the sums: the owner of a code sees every row assigned to it; only the scalar
+    sum(cluster_size) of the Laplace smoothing (vqp.py:577) is all-reduced, and the renormalisation is
+    vqhip_ema_renormalize_shard (update_ema's arithmetic).
     Returns (quantized [b, n, d], global indices [b, n], commit_loss) like VectorQuantize."""
 
     def __init__(self, dim, codebook_size, *, use_cosine_sim=False, decay=0.8, eps=1e-5, commitment_weight=1.,
-                 group=None, gather_input=True, emulate=None, rotation_trick=True, route_gradients_to_input=True, init_embed=None):
+                 group=None, gather_input=True, emulate=None, rotation_trick=None, route_gradients_to_input=True, init_embed=None,
+                 exchange="auto", register_codebook=True):
         super().__init__()
+        assert exchange in ("auto", "codebook", "rows")
+        self.exchange = exchange
+        self.last_comm = {}            # collective -> bytes this rank sent + received in the last forward (bench.py reports them)
+        rotation_trick = (dim > 1) if rotation_trick is None else rotation_trick       # the reference's default (vqp.py:856)
         from .codebook import Codebook
         self.group = group
         on = dist.is_available() and dist.is_initialized()
@@ -101,12 +111,32 @@ class ShardedVectorQuantize(torch.nn.Module):
             init_embed = Codebook(dim=dim, codebook_size=codebook_size, use_cosine_sim=use_cosine_sim, decay=decay, eps=eps,
                                   threshold_ema_dead_code=0, manual_ema_update=True).embed
         state = torch.random.get_rng_state()
-        self._codebook = Codebook(dim=dim, codebook_size=self.hi - self.lo, use_cosine_sim=use_cosine_sim, decay=decay,
-                                  eps=eps, threshold_ema_dead_code=0, manual_ema_update=True)
+        cb = Codebook(dim=dim, codebook_size=self.hi - self.lo, use_cosine_sim=use_cosine_sim, decay=decay,
+                      eps=eps, threshold_ema_dead_code=0, manual_ema_update=True)
         torch.random.set_rng_state(state)             # the shard's own (discarded) init does not advance the generator
+        if register_codebook:
+            self._codebook = cb
+        else:       # VectorQuantize(shard_codebook=True) registers the shard itself (ONE registration: state_dict keys `_codebook.*`)
+            object.__setattr__(self, "_codebook", cb)
         with torch.no_grad():
             self._codebook.embed.copy_(init_embed.detach()[:, self.lo:self.hi])
             self._codebook.embed_avg.copy_(init_embed.detach()[:, self.lo:self.hi])
+
+    @torch.no_grad()
+    def full_codebook_state(self):
+        """{embed, embed_avg, cluster_size} of the WHOLE codebook, all-gathered from the shards (equal shard sizes): what a checkpoint
+        that other world sizes -- or the reference -- can load should contain (state_dict() holds this rank's shard only)."""
+        cb = self._codebook
+        out = {}
+        for k in ("embed", "embed_avg", "cluster_size"):
+            t = getattr(cb, k).detach()
+            if self._collectives_on():
+                assert (self.hi - self.lo) * self.world == self.codebook_size, "all-gather needs equal shard sizes"
+                parts = [torch.empty_like(t) for _ in range(self.world)]
+                dist.all_gather(parts, t.contiguous(), group=self.group)
+                t = torch.cat(parts, dim=1)
+            out[k] = t.clone()
+        return out
 
     def _collectives_on(self):
         return self.world > 1 and not self._emulated
@@ -118,9 +148,12 @@ class ShardedVectorQuantize(torch.nn.Module):
         cb = self._codebook
         d = xin.shape[-1]
         cos = self.use_cosine_sim
+        comm = self.last_comm = {}
+        P = self.world
         if self._collectives_on() and self.gather_input:
-            allrows = torch.empty(self.world * xin.shape[0], d, dtype=xin.dtype, device=xin.device)
+            allrows = torch.empty(P * xin.shape[0], d, dtype=xin.dtype, device=xin.device)
             dist.all_gather_into_tensor(allrows, xin.contiguous(), group=self.group)
+            comm["all_gather rows"] = 2 * (P - 1) * xin.numel() * xin.element_size()
         else:
             allrows = xin
         e = cb.embed[0]
@@ -134,28 +167,47 @@ class ShardedVectorQuantize(torch.nn.Module):
             r = L.assign(allrows, packed, e, cosine=cos, skip_l2norm=True, want_q=False, want_best=True)
             best = r["best"]
         gidx, _ = merge_sharded_argmin(best, r["idx"], self.lo, euclid=not cos, group=self.group if self._collectives_on() else None)
+        if self._collectives_on():
+            comm["all_reduce(MAX) keys"] = 2 * (P - 1) * gidx.numel() * 8 // P
         mine = (gidx >= self.lo) & (gidx < self.hi)
         local = torch.where(mine, gidx - self.lo, torch.full_like(gidx, -1))
-        q_part = L.decode_sum(local[:, None].contiguous(), e, out_dtype=torch.float32)      # zeros where another rank owns the winner
         n_local = xin.shape[0]
-        if self._collectives_on():
-            if self.gather_input:
-                backend = dist.get_backend(self.group)
-                if backend == "nccl":
-                    q_rows = torch.empty(n_local, d, dtype=torch.float32, device=xin.device)
-                    dist.reduce_scatter_tensor(q_rows, q_part, group=self.group)
-                else:       # gloo (CPU-side tests): no reduce-scatter
-                    dist.all_reduce(q_part, group=self.group)
-                    q_rows = q_part[self.rank * n_local:(self.rank + 1) * n_local]
-                idx_rows = gidx[self.rank * n_local:(self.rank + 1) * n_local]
-            else:
-                dist.all_reduce(q_part, group=self.group)
-                q_rows, idx_rows = q_part, gidx
-        elif self._emulated:          # one rank of a larger job on its own: it keeps the rows it contributed to the gather
-            sl = slice(self.rank * (n_local // self.world), (self.rank + 1) * (n_local // self.world))
-            q_rows, idx_rows = q_part[sl], gidx[sl]
+        n_total = allrows.shape[0]
+        C_l = self.hi - self.lo
+        rows_bytes, cb_bytes = n_total * d * 4, P * C_l * d * 4
+        by_codebook = self.exchange == "codebook" or (self.exchange == "auto" and cb_bytes < rows_bytes)
+        uniform = C_l * P == self.codebook_size                # all_gather_into_tensor needs equal shards
+        if self._collectives_on() and by_codebook and uniform:
+            # every rank already holds the winning GLOBAL index of every row: fetch the codes instead of the rows
+            full = torch.empty(P * C_l, d, dtype=torch.float32, device=xin.device)
+            dist.all_gather_into_tensor(full, e.contiguous(), group=self.group)
+            comm["all_gather codebook shards"] = 2 * (P - 1) * C_l * d * 4
+            own = slice(self.rank * n_local, (self.rank + 1) * n_local) if self.gather_input else slice(None)
+            idx_rows = gidx[own]
+            q_rows = L.decode_sum(idx_rows[:, None].contiguous(), full, out_dtype=torch.float32)
         else:
-            q_rows, idx_rows = q_part, gidx
+            q_part = L.decode_sum(local[:, None].contiguous(), e, out_dtype=torch.float32)      # zeros where another rank owns the winner
+            if self._collectives_on():
+                if self.gather_input:
+                    if dist.get_backend(self.group) == "nccl":
+                        q_rows = torch.empty(n_local, d, dtype=torch.float32, device=xin.device)
+                        dist.reduce_scatter_tensor(q_rows, q_part, group=self.group)
+                        comm["reduce_scatter q rows"] = 2 * (P - 1) * n_local * d * 4
+                    else:       # gloo (CPU-side tests): no reduce-scatter
+                        dist.all_reduce(q_part, group=self.group)
+                        comm["all_reduce q rows"] = 2 * (P - 1) * q_part.numel() * 4 // P
+                        q_rows = q_part[self.rank * n_local:(self.rank + 1) * n_local]
+                    idx_rows = gidx[self.rank * n_local:(self.rank + 1) * n_local]
+                else:
+                    dist.all_reduce(q_part, group=self.group)
+                    comm["all_reduce q rows"] = 2 * (P - 1) * q_part.numel() * 4 // P
+                    q_rows, idx_rows = q_part, gidx
+            elif self._emulated:          # one rank of a larger job on its own: it keeps the rows it contributed to the gather
+                assert n_local % self.world == 0, "emulate=(rank, world): the row count must divide by the emulated world size"
+                sl = slice(self.rank * (n_local // self.world), (self.rank + 1) * (n_local // self.world))
+                q_rows, idx_rows = q_part[sl], gidx[sl]
+            else:
+                q_rows, idx_rows = q_part, gidx
 
         if self.training:
             # EMA on the owner: all rows, indices of foreign winners masked to -1 (skipped by the kernel)
@@ -165,11 +217,9 @@ class ShardedVectorQuantize(torch.nn.Module):
             total = cb.cluster_size.sum()
             if self._collectives_on():
                 dist.all_reduce(total, group=self.group)
-            smoothed = (cb.cluster_size + self.eps) / (total + self.codebook_size * self.eps) * total
-            new = cb.embed_avg / smoothed[..., None]
-            if cos:
-                new = torch.nn.functional.normalize(new, dim=-1, eps=1e-6)
-            cb.embed.copy_(new)
+                comm["all_reduce sum(cluster_size)"] = 2 * (P - 1) * 4 // P
+            cs, ea, em = cb._views(0)
+            L.ema_renormalize_shard(cs, ea, em, total, self.codebook_size, eps=self.eps, cosine=cos)
         return q_rows, idx_rows
 
     def forward(self, x):
@@ -180,6 +230,8 @@ class ShardedVectorQuantize(torch.nn.Module):
         if self._emulated:
             # x stands for the gathered rows of ALL ranks (unit-norm already for the cosine metric, as the all-gather delivers
             # them); this rank normalises, and gets outputs for, its own share only -- the work one rank of the real job does
+            assert rows.shape[0] % self.world == 0, "emulate=(rank, world): the row count must divide by the emulated world size"
+            assert not needs_grad, "emulate mode has no gradient path (the l2norm of the own rows runs in the HIP kernel)"
             per = rows.shape[0] // self.world
             own = rows[self.rank * per:(self.rank + 1) * per]
             xin = L.l2norm_rows(own) if self.use_cosine_sim else own

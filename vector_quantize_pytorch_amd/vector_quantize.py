@@ -290,8 +290,11 @@ class VectorQuantize(nn.Module):
             self._sharded = ShardedVectorQuantize(codebook_dim, codebook_size, use_cosine_sim=use_cosine_sim, decay=decay, eps=eps,
                                                   commitment_weight=commitment_weight, rotation_trick=rotation_trick,
                                                   route_gradients_to_input=route_gradients_to_input,
-                                                  init_embed=self._codebook.embed)     # same init as the unsharded module
-            self._codebook = self._sharded._codebook          # this rank's shard: state_dict keys as usual, one shard per rank
+                                                  init_embed=self._codebook.embed,     # same init as the unsharded module
+                                                  register_codebook=False)
+            # this rank's shard, registered ONCE (here): state_dict keys `_codebook.*` as usual, holding the shard's rows.  A
+            # checkpoint of the whole codebook loads too: _load_from_state_dict below keeps the rows this rank owns.
+            self._codebook = self._sharded._codebook
         self.in_place_codebook_optimizer = in_place_codebook_optimizer(self._codebook.parameters()) \
             if in_place_codebook_optimizer is not None else None
         self.manual_in_place_optimizer_update = manual_in_place_optimizer_update
@@ -483,6 +486,18 @@ class VectorQuantize(nn.Module):
         return x
 
     # ---- forward ----------------------------------------------------------------------------------
+    def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
+        """shard_codebook=True: a checkpoint of the WHOLE codebook (e.g. the reference's, or an unsharded module's) loads as well --
+        every rank keeps the rows [lo, hi) it owns.  (A shard-sized checkpoint loads as is.)"""
+        if self._sharded is not None:
+            sh = self._sharded
+            for k in ("embed", "embed_avg", "cluster_size"):
+                key = f"{prefix}_codebook.{k}"
+                t = state_dict.get(key)
+                if t is not None and t.ndim >= 2 and t.shape[1] == sh.codebook_size and sh.codebook_size != sh.hi - sh.lo:
+                    state_dict[key] = t[:, sh.lo:sh.hi]
+        super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
+
     def forward(
         self,
         x,
