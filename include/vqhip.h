@@ -133,6 +133,15 @@ int vqhip_scores(const void *x, int x_dtype, int64_t N, int D, int64_t ldx,
                  const float *packed, const float *embed, int C, int metric,
                  float *scores_out, int64_t lds, int64_t *idx_out, float *rnorm_out, void *stream);
 
+/* The same sweep with a streaming log-sum-exp epilogue instead of the N x C store: what F.cross_entropy(dist, codes) needs
+ * (cross-entropy "commitment" to the chosen codes, vqp.py:1242-1256, and forward(indices=...), vqp.py:1260-1261):
+ *   lse_out[n]    = log sum_c exp(dist[n, c])           (online max / sum per lane, merged per row)
+ *   tscore_out[n] = dist[n, target[n]]                   (target null: the winner's score; target[n] < 0: 0, the row is ignored)
+ * dist as in vqhip_scores.  idx_out [N] (argmax) must be given; rnorm_out as in vqhip_assign. */
+int vqhip_scores_lse(const void *x, int x_dtype, int64_t N, int D, int64_t ldx,
+                     const float *packed, const float *embed, int C, int metric, const int64_t *target,
+                     float *lse_out, float *tscore_out, int64_t *idx_out, float *rnorm_out, void *stream);
+
 /* ---- fused residual VQ loop ---------------------------------------------------------------------
  * Replaces the per-quantizer loop of ResidualVQ.forward (rvq.py:469-568) for the Euclidean metric and a
  * uniform codebook size: Q successive nearest-code searches on the running residual, which stays in

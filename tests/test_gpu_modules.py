@@ -24,7 +24,10 @@ def _close(a, b, tol, what):
 
 def _build(fx, dev):
     import vector_quantize_pytorch_amd as A
-    mod = G.build_special(fx.name, A) if fx.meta.get("build") else getattr(A, fx.meta["cls"])(**fx.kwargs)
+    if fx.meta["cls"] == "HierarchicalVQ":        # not a product class: its call pattern around VectorQuantize, test-side
+        mod = G.MultiScaleCaller(A.VectorQuantize, **fx.kwargs)
+    else:
+        mod = G.build_special(fx.name, A) if fx.meta.get("build") else getattr(A, fx.meta["cls"])(**fx.kwargs)
     missing, unexpected = mod.load_state_dict(fx.state("before"), strict=True)
     mod = mod.to(dev)
     if fx.meta["deterministic_sampling"]:
@@ -169,6 +172,7 @@ def test_grouped_residual_vq_group_streams_match_serial(dev):
     for r in b.rvqs:
         r.concurrent_stats = False
     s = torch.cuda.Stream(device=dev)
+    flips = 0
     for step in range(3):
         x = torch.randn(4, 2048, 256, device=dev)
         xa, xb = x.clone().requires_grad_(), x.clone().requires_grad_()
@@ -190,7 +194,11 @@ def test_grouped_residual_vq_group_streams_match_serial(dev):
             assert torch.equal(ia, ib) and torch.equal(qa, qb) and torch.equal(la, lb)
             assert torch.equal(xa.grad, xb.grad)
         assert (ia == ib).float().mean().item() > 0.999 and torch.allclose(la, lb, rtol=1e-4, atol=1e-6), step
-    assert torch.allclose(a.codebooks, b.codebooks, atol=1e-5)
+        flips += int((ia != ib).sum())
+    # a row that flips between two near-tied codes (last-bit differences of the atomically summed EMA statistics) moves the
+    # average of exactly two codes; every other code row must agree
+    moved = int(((a.codebooks - b.codebooks).abs().amax(-1) > 1e-5).sum())
+    assert moved <= 2 * flips, (moved, flips)
 
 
 def test_accum_ema_update(dev):                                               # tests/test_readme.py:467-492
@@ -995,3 +1003,48 @@ def test_cosine_codebook_transform_sees_normalised_rows_with_or_without_input_gr
     assert torch.equal(res[0][0], res[1][0])
     _close(res[0][1].reshape(-1), res[1][1].reshape(-1), 1e-6, "commit loss")
     _close(res[0][2], res[1][2], 1e-6, "embed after the EMA step")
+
+
+@pytest.mark.parametrize("cosine", [False, True])
+def test_cross_entropy_commitment_streams_a_log_sum_exp_instead_of_the_score_matrix(dev, cosine):
+    """the cross-entropy "commitment" (vqp.py:1242-1256, 1297-1305) and forward(indices=) no longer materialise the
+    [N, C] score tensor: forward = vqhip_scores_lse (exact sweep, online log-sum-exp), backward = chunked recomputation.  Same loss
+    and gradients as F.cross_entropy on the dense scores of the same (pre-update) codebook, and peak memory far below N x C x 4."""
+    from vector_quantize_pytorch_amd import VectorQuantize
+    from vector_quantize_pytorch_amd import _lib as L
+    from vector_quantize_pytorch_amd.vector_quantize import _ScoresFn
+    torch.manual_seed(5)
+    vq = VectorQuantize(dim=64, codebook_size=512, commitment_use_cross_entropy_loss=True, use_cosine_sim=cosine).to(dev).train()
+    x = torch.randn(4, 3000, 64, device=dev) * (1.0 if cosine else 0.1)       # distances of a few tenths: an unsaturated softmax
+    mask = torch.rand(4, 3000, device=dev) > 0.1                              # (saturated, p - onehot is pure cancellation noise)
+    if not cosine:
+        with torch.no_grad():
+            vq._codebook.embed.copy_(torch.randn_like(vq._codebook.embed) * 0.1)
+            vq._codebook.embed_avg.copy_(vq._codebook.embed)
+    e0 = vq._codebook.embed[0].detach().clone()
+    xa = x.clone().requires_grad_(True)
+    q, idx, loss = vq(xa, mask=mask)
+    vq._codebook.embed.data[0].copy_(e0)          # undo the EMA step: compare the pure cross-entropy gradient on ONE codebook
+    loss.backward()
+    # the same loss from the dense scores
+    xb = x.clone().requires_grad_(True)
+    xn = torch.nn.functional.normalize(xb, dim=-1, eps=1e-6) if cosine else xb
+    vq._codebook.embed.data[0].copy_(e0)          # (the reference's cdist backward reads the live buffer: see _CrossEntropyFn)
+    dist = _ScoresFn.apply(xn, e0, cosine)
+    want = torch.nn.functional.cross_entropy(dist.permute(0, 2, 1), idx.masked_fill(~mask, -1), ignore_index=-1)
+    want.backward()
+    _close(loss.reshape(1), want.reshape(1), 1e-5, "cross-entropy loss")
+    # dL/dx of the module = CE term only here (the routed output is not part of `loss`)
+    _close(xa.grad, xb.grad, 2e-5, "grad_x")
+
+    # memory: N = 2^18 rows x 4096 codes would be 4 GiB of scores (+ as much again for the softmax in backward)
+    vq2 = VectorQuantize(dim=64, codebook_size=4096, commitment_use_cross_entropy_loss=True).to(dev).train()
+    xl = torch.randn(16, 16384, 64, device=dev, requires_grad=True)
+    torch.cuda.synchronize(); torch.cuda.reset_peak_memory_stats()
+    base = torch.cuda.memory_allocated()
+    _, _, l2 = vq2(xl)
+    l2.backward()
+    torch.cuda.synchronize()
+    peak = torch.cuda.max_memory_allocated() - base
+    assert torch.isfinite(l2) and torch.isfinite(xl.grad).all()
+    assert peak < (1 << 30), f"peak {peak / 2**20:.0f} MiB: the score matrix is being materialised"

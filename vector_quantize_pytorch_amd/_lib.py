@@ -54,6 +54,8 @@ def lib():
     L.vqhip_rvq_forward.restype = i32
     L.vqhip_scores.argtypes = [vp, i32, i64, i32, i64, vp, vp, i32, i32, vp, i64, vp, vp, vp]
     L.vqhip_scores.restype = i32
+    L.vqhip_scores_lse.argtypes = [vp, i32, i64, i32, i64, vp, vp, i32, i32, vp, vp, vp, vp, vp, vp]
+    L.vqhip_scores_lse.restype = i32
     L.vqhip_screen_supported.argtypes = [i64, i32, i32]
     L.vqhip_screen_supported.restype = i32
     L.vqhip_screen_workspace_bytes.argtypes = [i64]
@@ -99,7 +101,7 @@ def lib():
     L.vqhip_kmeans_update.argtypes = [vp, vp, vp, i32, i32, i32, vp]
     L.vqhip_kmeans_update.restype = i32
     for name in ("vqhip_pack_codebook", "vqhip_assign", "vqhip_reduce_partials", "vqhip_ema_accumulate",
-                 "vqhip_ema_finalize", "vqhip_decode_sum", "vqhip_row_sumsq", "vqhip_assign_rowwise", "vqhip_score_indices", "vqhip_topk", "vqhip_expire_scatter", "vqhip_kmeans_update", "vqhip_route_fwd", "vqhip_route_bwd", "vqhip_rvq_route", "vqhip_ema_renormalize_shard"):
+                 "vqhip_ema_finalize", "vqhip_decode_sum", "vqhip_row_sumsq", "vqhip_assign_rowwise", "vqhip_score_indices", "vqhip_topk", "vqhip_expire_scatter", "vqhip_kmeans_update", "vqhip_route_fwd", "vqhip_route_bwd", "vqhip_rvq_route", "vqhip_ema_renormalize_shard", "vqhip_scores_lse"):
         getattr(L, name).restype = i32
     _lib = L
     return L
@@ -108,7 +110,7 @@ def lib():
 EXPORTS = ("vqhip_version", "vqhip_last_error", "vqhip_packed_bytes", "vqhip_pack_codebook",
            "vqhip_assign_blocks", "vqhip_assign", "vqhip_screen_supported", "vqhip_screen_workspace_bytes",
            "vqhip_screen_blocks", "vqhip_screen_partials", "vqhip_assign_screened", "vqhip_screen_chain_supported", "vqhip_assign_screened_chain", "vqhip_l2norm_rows", "vqhip_scores", "vqhip_rvq_forward", "vqhip_reduce_partials", "vqhip_reduce_partials_rows", "vqhip_ema_fold_many", "vqhip_ema_workspace_bytes", "vqhip_ema_accumulate", "vqhip_ema_sqerr_partials", "vqhip_ema_accumulate_sqerr",
-           "vqhip_ema_finalize", "vqhip_decode_sum", "vqhip_row_sumsq", "vqhip_assign_rowwise", "vqhip_score_indices", "vqhip_topk", "vqhip_expire_scatter", "vqhip_kmeans_update", "vqhip_route_fwd", "vqhip_route_bwd", "vqhip_rvq_route", "vqhip_ema_renormalize_shard")
+           "vqhip_ema_finalize", "vqhip_decode_sum", "vqhip_row_sumsq", "vqhip_assign_rowwise", "vqhip_score_indices", "vqhip_topk", "vqhip_expire_scatter", "vqhip_kmeans_update", "vqhip_route_fwd", "vqhip_route_bwd", "vqhip_rvq_route", "vqhip_ema_renormalize_shard", "vqhip_scores_lse")
 
 
 def _check(rc, what):
@@ -297,6 +299,29 @@ def scores(x: torch.Tensor, packed: torch.Tensor, embed2d: torch.Tensor, *, cosi
     return out, idx, rnorm
 
 
+@_on_device
+def scores_lse(x: torch.Tensor, packed: torch.Tensor, embed2d: torch.Tensor, target=None, *, cosine=False, skip_l2norm=False):
+    """Streaming form of what F.cross_entropy(dist, target) reads from the score row (vqp.py:1242-1256): x [..., D] ->
+    (lse [...] = log sum_c exp(dist[.., c]), tscore [...] = dist[.., target] (target None: the winner's score; target < 0: 0),
+    argmax idx [...]), dist as in scores().  No N x C tensor."""
+    _need_gpu(x, packed, embed2d, target)
+    xk, N, D, ldx = as_rows(x)
+    C = embed2d.shape[0]
+    lead, dev = x.shape[:-1], x.device
+    lse = torch.empty(lead, dtype=torch.float32, device=dev)
+    ts = torch.empty(lead, dtype=torch.float32, device=dev)
+    idx = torch.empty(lead, dtype=torch.int64, device=dev)
+    rnorm = torch.empty(lead, dtype=torch.float32, device=dev)
+    if target is not None:
+        target = target.reshape(-1).to(torch.int64).contiguous()
+        assert target.numel() == N
+    if N > 0:
+        metric = (COSINE_PRENORM if skip_l2norm else COSINE) if cosine else EUCLID
+        _check(lib().vqhip_scores_lse(_ptr(xk), _dtype_code(xk), N, D, ldx, _ptr(packed), _ptr(embed2d), C, metric, _ptr(target),
+                                      _ptr(lse), _ptr(ts), _ptr(idx), _ptr(rnorm), _stream()), "vqhip_scores_lse")
+    return lse, ts, idx
+
+
 def screen_supported(x: torch.Tensor, C: int) -> bool:
     """True when assign() would take the screened path for rows like x (Euclidean, or cosine on unit-norm rows)."""
     xk, N, D, ldx = as_rows(x)
@@ -332,11 +357,14 @@ def rvq_chain_supported(x: torch.Tensor, C: int) -> bool:
 
 
 @_on_device
-def rvq_forward_chained(x: torch.Tensor, packed: torch.Tensor, embed: torch.Tensor, Q: int, *, row_mask=None, stage_hook=None):
+def rvq_forward_chained(x: torch.Tensor, packed: torch.Tensor, embed: torch.Tensor, Q: int, *, row_mask=None, stage_hook=None,
+                        fill_masked=True):
     """The residual loop (rvq.py:469-568) as Q chained screened searches: stage q's kernel forms its input
     inputs[q-1] - embed[idx[:, q-1]] in its prologue and stores it as inputs[q]; no stage re-reads its input to write a residual,
     and every stage writes its column of idx directly.  No q / squared-error outputs: the caller's statistics pass sums the loss
-    (ema_accumulate(sqerr_from=...)).  -> dict(idx [..., Q], inputs [Q tensors], n_exact / n_pair per stage)."""
+    (ema_accumulate(sqerr_from=...)).  -> dict(idx [..., Q], inputs [Q tensors], n_exact / n_pair per stage).
+    fill_masked=False: the caller writes the -1 of the masked rows itself (mask_fill_indices) -- needed when stage_hook hands `idx`
+    to work on ANOTHER stream, which may still be reading it when this function returns."""
     _need_gpu(x, packed, embed, row_mask)
     shared = embed.ndim == 2
     xk, N, D, ldx = as_rows(x)
@@ -370,14 +398,19 @@ def rvq_forward_chained(x: torch.Tensor, packed: torch.Tensor, embed: torch.Tens
         if stage_hook is not None:      # stage q's input and indices are final (in stream order): the caller's per-stage work
             stage_hook(q, inputs[q], idx.view(*lead, Q))
     idx = idx.view(*lead, Q)
-    if row_mask is not None:      # as the fused kernel: masked rows carry index -1 (decode contributes nothing)
-        idx.masked_fill_(~row_mask.reshape(*lead, 1).bool(), -1)
+    if row_mask is not None and fill_masked:
+        mask_fill_indices(idx, row_mask)
     return dict(idx=idx, inputs=inputs, counts=counts)
+
+
+def mask_fill_indices(idx: torch.Tensor, row_mask: torch.Tensor):
+    """as the fused kernel: masked rows carry index -1 (decode contributes nothing)"""
+    idx.masked_fill_(~row_mask.reshape(*idx.shape[:-1], 1).bool(), -1)
 
 
 @_on_device
 def rvq_forward_screened(x: torch.Tensor, packed: torch.Tensor, embed: torch.Tensor, Q: int, *, want_resid=False,
-                         want_sqerr=False, row_mask=None, stage_hook=None):
+                         want_sqerr=False, row_mask=None, stage_hook=None, fill_masked=True):
     """The residual loop (rvq.py:469-568) as Q screened assignments: each stage's search runs on the bf16 MFMA pipe
     (csrc/vq_screen.hip) and writes the next stage's input x - q itself, so no N x D tensor op runs between stages.
     Same arguments as rvq_forward (+ stage_hook(q, stage_input, idx), called after stage q's launches);
@@ -400,8 +433,8 @@ def rvq_forward_screened(x: torch.Tensor, packed: torch.Tensor, embed: torch.Ten
         if stage_hook is not None:      # stage q's input and indices are final (in stream order): the caller's per-stage work
             stage_hook(q, cur, idx)
         cur = nxt
-    if row_mask is not None:      # as the fused kernel: masked rows carry index -1 (decode contributes nothing)
-        idx.masked_fill_(~row_mask.reshape(*lead, 1).bool(), -1)
+    if row_mask is not None and fill_masked:
+        mask_fill_indices(idx, row_mask)
     return dict(idx=idx, resid=None, inputs=inputs if want_resid else None,
                 sqerr_partials=torch.stack(parts) if want_sqerr else None)
 

@@ -483,6 +483,10 @@ struct AssignArgs {
     const uint8_t *row_mask;
     float *scores_out;  // nullable [N, lds]: the reference's `dist` tensor (-cdist or cosine similarity), rare options only
     int64_t lds;
+    // streaming log-sum-exp over the score row (cross-entropy to codes, vqp.py:1242-1256) instead of materialising it:
+    float *lse_out;            // nullable [N]: log sum_c exp(dist[n, c])
+    float *tscore_out;         // nullable [N]: dist[n, target[n]] (target null: the winner's score)
+    const int64_t *target;     // nullable [N]; negative = ignored row (tscore 0)
     int x_vec;  // 1: D == DT and x rows are vector-load aligned
     int q_vec;  // 1: D == DT and q rows are vector-store aligned
     int skip_norm;  // cosine: rows are already unit-norm
@@ -593,6 +597,8 @@ __global__ void __launch_bounds__(256, (DT <= 256 ? 2 : 1)) vq_assign_kernel(con
     float bs = INFINITY;                              // its pre-sqrt value (euclid only)
     int bi = 0;
 
+    float lse_m = -__builtin_inff(), lse_l = 0.f, ts = 0.f;
+    const int64_t tgt = (a.lse_out && a.target && row_ok) ? a.target[row] : (int64_t)-1;
     const int nt = a.n_tiles;
     for (int ct = 0; ct < nt; ++ct) {
         const int buf = ct & 1;
@@ -624,6 +630,24 @@ __global__ void __launch_bounds__(256, (DT <= 256 ? 2 : 1)) vq_assign_kernel(con
                 if (row_ok && code < a.C) a.scores_out[row * a.lds + code] = v;
             }
         }
+        if (a.lse_out) {      // cold path: online log-sum-exp of the same dist values, lane-local over this lane's 16 codes per tile
+            const float *y2s = (const float *)tile + 32 * DT;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int code = ct * 32 + 8 * (e >> 2) + 4 * hi + (e & 3);
+                float v = acc[e];
+                if (METRIC == 0) {
+                    const float t = x2 + y2s[8 * (e >> 2) + 4 * hi + (e & 3)];
+                    v = -sqrtf(fmaxf(__builtin_fmaf(-2.0f, v, t), 1e-8f));
+                }
+                if (code < a.C) {
+                    const float nm = fmaxf(lse_m, v);
+                    lse_l = lse_l * __expf(lse_m - nm) + __expf(v - nm);     // (-inf - finite -> exp = 0 on the first code)
+                    lse_m = nm;
+                    if ((int64_t)code == tgt) ts = v;
+                }
+            }
+        }
     }
 
     // ---- merge the two half-waves (same row, disjoint code subsets) ------------------------------
@@ -635,6 +659,15 @@ __global__ void __launch_bounds__(256, (DT <= 256 ? 2 : 1)) vq_assign_kernel(con
         bi = take ? oi : bi;
     }
 
+    if (a.lse_out) {          // merge the half-waves' (max, sum) pairs; the target's score sits in exactly one of them
+        const float om = __shfl_xor(lse_m, 32, 64), ol = __shfl_xor(lse_l, 32, 64), ot = __shfl_xor(ts, 32, 64);
+        const float M = fmaxf(lse_m, om);
+        const float Lsum = lse_l * __expf(lse_m - M) + ol * __expf(om - M);
+        if (row_ok && hi == 0) {
+            a.lse_out[row] = M + __logf(Lsum);
+            if (a.tscore_out) a.tscore_out[row] = a.target ? (tgt < 0 ? 0.f : ts + ot) : ((METRIC == 0) ? -bd : bd);
+        }
+    }
     if (row_ok && hi == 0) {
         a.idx_out[row] = (int64_t)bi;
         if (a.best_out) a.best_out[row] = bd;
@@ -1185,7 +1218,8 @@ static int assign_impl(const void *x, int x_dtype, int64_t N, int D, int64_t ldx
                        const float *packed, const float *embed, int C, int metric,
                        int64_t *idx_out, void *q_out, int q_dtype, int64_t ldq,
                        float *best_out, float *rnorm_out, double *sqerr_partial,
-                       const uint8_t *row_mask, float *scores_out, int64_t lds, void *stream);
+                       const uint8_t *row_mask, float *scores_out, int64_t lds, void *stream, float *lse_out = nullptr, float *tscore_out = nullptr,
+                       const int64_t *target = nullptr);
 
 extern "C" int vqhip_assign(const void *x, int x_dtype, int64_t N, int D, int64_t ldx,
                             const float *packed, const float *embed, int C, int metric,
@@ -1206,11 +1240,21 @@ extern "C" int vqhip_scores(const void *x, int x_dtype, int64_t N, int D, int64_
                        nullptr, nullptr, scores_out, lds, stream);
 }
 
+extern "C" int vqhip_scores_lse(const void *x, int x_dtype, int64_t N, int D, int64_t ldx,
+                                const float *packed, const float *embed, int C, int metric, const int64_t *target,
+                                float *lse_out, float *tscore_out, int64_t *idx_out, float *rnorm_out, void *stream)
+{
+    if (!lse_out) VQ_FAIL(VQHIP_EINVAL, "scores_lse: lse_out is null");
+    return assign_impl(x, x_dtype, N, D, ldx, packed, embed, C, metric, idx_out, nullptr, VQHIP_F32, D, nullptr, rnorm_out,
+                       nullptr, nullptr, nullptr, 0, stream, lse_out, tscore_out, target);
+}
+
 static int assign_impl(const void *x, int x_dtype, int64_t N, int D, int64_t ldx,
                             const float *packed, const float *embed, int C, int metric,
                             int64_t *idx_out, void *q_out, int q_dtype, int64_t ldq,
                             float *best_out, float *rnorm_out, double *sqerr_partial,
-                            const uint8_t *row_mask, float *scores_out, int64_t lds, void *stream)
+                            const uint8_t *row_mask, float *scores_out, int64_t lds, void *stream, float *lse_out, float *tscore_out,
+                            const int64_t *target)
 {
     if (N < 0 || C <= 0) VQ_FAIL(VQHIP_EINVAL, "assign: N < 0 or C <= 0");
     if (N == 0) return 0;
@@ -1240,6 +1284,7 @@ static int assign_impl(const void *x, int x_dtype, int64_t N, int D, int64_t ldx
     a.trace = g_trace;
 #endif
     a.scores_out = scores_out; a.lds = lds;
+    a.lse_out = lse_out; a.tscore_out = tscore_out; a.target = target;
     a.best_out = best_out; a.rnorm_out = rnorm_out; a.sqerr_partial = sqerr_partial; a.row_mask = row_mask;
     const int xes = (x_dtype == VQHIP_BF16) ? 2 : 4;
     a.x_vec = (D == DT) && (((uintptr_t)x) % (4 * xes) == 0) && ((ldx * xes) % (4 * xes) == 0) && ((((uintptr_t)embed) & 15) == 0);

@@ -335,15 +335,21 @@ class ResidualVQ(nn.Module):
                     side.wait_event(ev)
                     with torch.cuda.stream(side):
                         accumulate(q, stage_input, idx_all)
+            # (with a side-stream hook the -1 of the masked rows is written only after that stream has been joined below: its
+            #  statistics passes read `idx`)
             if chain:
-                r = L.rvq_forward_chained(x, packed, embed, Q, row_mask=mask, stage_hook=hook)
+                r = L.rvq_forward_chained(x, packed, embed, Q, row_mask=mask, stage_hook=hook, fill_masked=hook is None)
             else:
-                r = L.rvq_forward_screened(x, packed, embed, Q, want_resid=update, want_sqerr=want_loss, row_mask=mask, stage_hook=hook)
+                r = L.rvq_forward_screened(x, packed, embed, Q, want_resid=update, want_sqerr=want_loss, row_mask=mask, stage_hook=hook,
+                                           fill_masked=hook is None)
             if hook is None:
                 side = None
         else:
             r = L.rvq_forward(x, packed, embed, Q, want_resid=update, want_sqerr=want_loss, row_mask=mask)
         idx = r["idx"]
+        if side is not None and mask is not None:
+            torch.cuda.current_stream(x.device).wait_stream(side)       # the side stream's statistics passes have read idx
+            L.mask_fill_indices(idx, mask)
         quantized_out = L.decode_sum(idx, embed, out_dtype=x.dtype) if aux is None else None
         if aux is not None:
             aux["embed"] = embed.clone() if self.shared_codebook else embed      # (torch.stack above already copied)

@@ -90,6 +90,63 @@ class _RouteFn(torch.autograd.Function):
         return L.route_bwd(x, q, g.contiguous(), None, None, ctx.mode), None, None
 
 
+class _CrossEntropyFn(torch.autograd.Function):
+    """F.cross_entropy(dist, codes, ignore_index=-1) (vqp.py:1242-1256) without the [N, C] score tensor.  Forward: the exact sweep
+    with a streaming log-sum-exp epilogue (vqhip_scores_lse): loss = mean over the rows with codes >= 0 of lse - dist[code].
+    Backward: (softmax - onehot) / count pushed through dist's closed-form gradients (those of _ScoresFn), the scores recomputed over
+    row chunks of at most 128 MiB -- peak memory no longer grows with N x C.
+    `embed_at_search` is the codebook the scores were computed from; `embed` is the live tensor (the gradient goes to it).  They
+    differ for an EMA codebook, which is rewritten in place between forward and backward -- and the reference's cdist backward then
+    reads the REWRITTEN buffer next to the saved distances (its saved tensor aliases `self.embed`, whose .data the EMA step copies
+    into).  Replicated: the softmax weights come from the scores at search time, the GEMM operand is the live codebook."""
+
+    CHUNK_BYTES = 1 << 27
+
+    @staticmethod
+    def forward(ctx, x, embed, embed_at_search, codes, cosine):
+        e = embed_at_search.detach().float().contiguous()
+        lse, ts, _ = L.scores_lse(x.detach(), L.pack_codebook(e), e, codes, cosine=cosine, skip_l2norm=True)
+        valid = codes.reshape(lse.shape) >= 0
+        count = valid.sum()
+        ctx.cosine = cosine
+        ctx.save_for_backward(x, embed, e, codes, count)
+        return torch.where(valid, lse - ts, torch.zeros_like(lse)).sum() / count
+
+    @staticmethod
+    def backward(ctx, g):
+        x, embed, e_search, codes, count = ctx.saved_tensors
+        need_x, need_e = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        D, C = x.shape[-1], embed.shape[0]
+        rows, tg = x.detach().reshape(-1, D), codes.reshape(-1)
+        ef = embed.detach().float()
+        packed = L.pack_codebook(e_search)
+        gx = torch.empty(rows.shape, dtype=torch.float32, device=x.device) if need_x else None
+        ge = torch.zeros(embed.shape, dtype=torch.float32, device=x.device) if need_e else None
+        scale = (g / count).to(torch.float32)
+        step = max(1, _CrossEntropyFn.CHUNK_BYTES // (4 * C))
+        for i in range(0, rows.shape[0], step):
+            xc, tc = rows[i:i + step], tg[i:i + step]
+            dist, _, _ = L.scores(xc, packed, e_search, cosine=ctx.cosine, skip_l2norm=True)      # [rows, C], as in the forward
+            p = dist.softmax(dim=-1)
+            ok = tc >= 0
+            p[ok, tc[ok]] -= 1.0
+            p = torch.where(ok[:, None], p, torch.zeros_like(p)) * scale                           # d loss / d dist
+            xf = xc.float()
+            if ctx.cosine:                                                                         # dist = x . e
+                if need_x:
+                    gx[i:i + step] = p @ ef
+                if need_e:
+                    ge += p.t() @ xf
+            else:                                                                                  # dist = -|x - e|, zero where clamped
+                d = -dist
+                w = torch.where(d > 1.0001e-4, p / d, torch.zeros_like(p))
+                if need_x:
+                    gx[i:i + step] = w @ ef - w.sum(-1, keepdim=True) * xf
+                if need_e:
+                    ge -= w.sum(0)[:, None] * ef - w.t() @ xf
+        return (gx.reshape(x.shape).to(x.dtype) if need_x else None, ge.to(embed.dtype) if need_e else None, None, None, None)
+
+
 class _ScoresFn(torch.autograd.Function):
     """dist [b, n, C] = -cdist(x, embed) (Euclidean) or x . embed^T (cosine, x already unit-norm): forward on the HIP
     kernel (vqhip_scores, the reference's rounding sequence), backward = the closed-form gradients of vqp.py:58-62 /
@@ -561,10 +618,13 @@ class VectorQuantize(nn.Module):
         # normalisation stays an autograd op and the kernel is told the rows are already unit-norm.
         pre_normalized = False
         needs_grad = self.training and xs.requires_grad and torch.is_grad_enabled()
-        dense = (return_loss or topk is not None or self.commitment_use_cross_entropy_loss or self.has_codebook_diversity_loss
-                 or self.stochastic_sample_codes or self.gumbel_straight_through)
+        # options that read the WHOLE score row as a matrix (top-k, the diversity loss' batch-averaged softmax, gumbel noise / its
+        # straight-through softmax) materialise `dist`; the cross-entropy losses alone do not: they stream a log-sum-exp (_CrossEntropyFn)
+        need_matrix = (topk is not None or self.has_codebook_diversity_loss or self.stochastic_sample_codes or self.gumbel_straight_through)
+        ce_only = (return_loss or self.commitment_use_cross_entropy_loss) and not need_matrix and codebook_transform_fn is None
+        dense = need_matrix or ((return_loss or self.commitment_use_cross_entropy_loss) and not ce_only)
         param_path = (self._codebook.learnable_codebook or self._codebook.vq_bridge is not None or self.directional_reparam or dense
-                      or codebook_transform_fn is not None)
+                      or ce_only or codebook_transform_fn is not None)
         # (every branch of the autograd-glue path reads xs itself -- commit loss, update_indices, init_embed_, assign_rowwise -- so it
         #  always gets the normalised rows, input with or without grad: the reference normalises first, vqp.py:1159)
         if self.use_cosine_sim and (needs_grad or param_path or (mask is not None and self.training)):
@@ -575,28 +635,39 @@ class VectorQuantize(nn.Module):
                   accum_ema_update=accum_ema_update, ema_update=(ema_update if topk is None else False),
                   input_normalized=pre_normalized)
         inplace_loss = orth_loss = diversity_loss = self.zero
-        distances = None
+        distances = ce_embed = None
         if param_path:
+            if ce_only:     # the codebook the search is about to use, live and as a snapshot (the EMA fold inside the search rewrites
+                cb0 = self._codebook                                                  # `embed` in place; see _CrossEntropyFn)
+                ce_embed = (cb0.embed if cb0.vq_bridge is None else cb0.vq_bridge(cb0.embed))[0]
+                if not cb0.learnable_codebook:
+                    ce_embed = ce_embed.detach()
+                ce_embed_at_search = ce_embed.detach().clone()
             quantize, embed_ind, commit_quantize, inplace_loss, distances = self._forward_general(
-                xs, rmask, freeze_codebook, kw, dense=dense, topk=topk, temp=sample_codebook_temp, need_dist=return_loss,
+                xs, rmask, freeze_codebook, kw, dense=dense, topk=topk, temp=sample_codebook_temp, need_dist=return_loss and dense,
                 transform_fn=codebook_transform_fn)
         else:
             fold = (mask is None and self.training and self.has_commitment_loss)     # sq_sum then already is the mean
             quantize, embed_ind, sq_sum = _QuantizeFn.apply(xs, self, rmask, kw, 1.0 / float(max(xs.numel(), 1)) if fold else 1.0)
 
         # ---- loss (vqp.py:1282-1348) --------------------------------------------------------------
-        # the reference's loss starts as a leaf that requires grad in training (vqp.py:1282); one cached leaf per device instead of
-        # a fill kernel per forward
+        # the reference's loss starts as a leaf that requires grad in training (vqp.py:1282).  Here: a cached CONSTANT zero per
+        # (device, inference mode) -- no fill kernel per forward, and no shared autograd leaf (a cached leaf would accumulate .grad
+        # across backward() calls and be shared between concurrent forwards); `requires_grad` is restored on the result below
         if self.training:
-            anchor = self.__dict__.get("_loss_anchor")
-            if anchor is None or anchor.device != x.device:
-                anchor = torch.zeros((), device=x.device, dtype=torch.float32, requires_grad=True)
-                self.__dict__["_loss_anchor"] = anchor
+            key = (x.device, torch.is_inference_mode_enabled())
+            cache = self.__dict__.setdefault("_loss_anchor", {})
+            anchor = cache.get(key)
+            if anchor is None:
+                anchor = cache[key] = torch.zeros((), device=x.device, dtype=torch.float32)
             loss = anchor
         else:
+            anchor = None
             loss = torch.zeros((), device=x.device, dtype=torch.float32)
         commit_loss = self.zero
         def ce_loss(codes):                                                          # vqp.py:1242-1256, heads == 1
+            if distances is None:
+                return _CrossEntropyFn.apply(xs, ce_embed, ce_embed_at_search, codes, self.use_cosine_sim)
             return F.cross_entropy(distances.permute(0, 2, 1), codes, ignore_index=-1)
 
         if return_loss:                                                              # vqp.py:1260-1261
@@ -649,8 +720,11 @@ class VectorQuantize(nn.Module):
                 commit_loss = diff[mask].mean()
             loss = loss + (commit_loss if self.commitment_weight == 1. else commit_loss * self.commitment_weight)
 
-        if self.training and loss is self.__dict__.get("_loss_anchor"):
-            loss = loss.clone()                      # no loss term was added: hand out a fresh tensor, not the cached leaf
+        if self.training:
+            if loss is anchor:
+                loss = loss.clone()                  # no loss term was added: hand out a fresh tensor, not the cached constant
+            if torch.is_grad_enabled() and not loss.requires_grad:
+                loss = loss.detach().requires_grad_(True)        # as the reference's loss (a view: no kernel), a fresh leaf per forward
 
         # ---- indices / quantized back to the caller's layout (vqp.py:1265-1396) -------------------
         if self.heads > 1:
