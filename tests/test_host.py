@@ -35,12 +35,12 @@ def test_host_only_entry_points():
     L = _lib.lib()
     tile = 128 * 256 + 1024   # fp32 A-operand tile == bf16 hi/lo screening tile, bytes (csrc/vqhip_internal.h)
     tile16 = 64 * 256 + 1024  # fp16 single-pass screening tile
-    assert L.vqhip_packed_bytes(1024, 256) == (32 * tile + 4096) + 1024 * 256 * 2 + (32 * tile + 8192) + 64 + (32 * tile16 + 8192)
+    assert L.vqhip_packed_bytes(1024, 256) == (32 * tile + 4096) + (1024 * 256 * 2 + 8192) + 64 + (32 * tile16 + 8192)
     assert L.vqhip_screen_supported(1 << 20, 256, 1024) == 1 and L.vqhip_screen_supported(1 << 20, 512, 1024) == 1 and L.vqhip_screen_supported(1 << 20, 96, 1024) == 0
     assert L.vqhip_screen_partials(1 << 20, 1) == (1 << 20) // 256 + 512   # bf16: screen workgroups + finish workgroups of the exact pass
     assert L.vqhip_screen_partials(1 << 20, 0) == (1 << 20) // 256 + 512   # fp32: 8 waves x 32 rows per workgroup
     assert L.vqhip_screen_workspace_bytes(1000) >= 16 + 4 * 1000 + 8 * 1000
-    assert L.vqhip_packed_bytes(33, 100) == (2 * 2 * (128 * 128 + 1024) + 4096 + 8192 + 33 * 100 * 2 + 8 + 64
+    assert L.vqhip_packed_bytes(33, 100) == (2 * (128 * 128 + 1024) + 4096 + (33 * 100 * 2 + 8) + 8192 + 64
                                              + 8 * (64 * 128 + 1024) + 8192)   # D padded to 128, C to 64 (fp16 tiles: to 8 tiles); bf16 copy 16-byte rounded
     assert L.vqhip_packed_bytes(16, 513) == 0                              # unsupported D
     assert L.vqhip_assign_blocks(0) == 0 and L.vqhip_assign_blocks(1) == 1 and L.vqhip_assign_blocks(129) == 2

@@ -11,20 +11,20 @@
 //   3. a row whose margin to the THIRD exceeds the bound has exactly two candidates: two distances in the exact arithmetic decide
 //      (vq_pair_kernel, vqhip.hip).  The rest (a fraction of a percent) is re-done by the exact sweep (vq_refine_kernel).
 //
-// Kernels in this file, newest first (what runs by default is marked *):
-//   * vq_screen16_kernel      single-pass fp16 screen, two 32-row blocks per wave, D <= 256: bf16 rows (exact fp16 operands after a
-//                             power-of-two scaling) and fp32 rows (one fp16 operand set, measured residual in the bound); paired
-//                             sweep (every A fragment read from LDS once for both row blocks, the previous tile's top-3 fold between
-//                             this tile's MFMAs); residual chain in the prologue (vqhip_assign_screened_chain)
-//   * vq_screen16_1rb_kernel  one row block per wave: D = 512, and the two-operand-set fp32 variant (VQHIP_SCREEN_F32_2PART=1)
-//     vq_screen_kernel / vq_screen_f32_kernel   round 1: two-pass bf16 hi/lo split of the codebook, top 2 (VQHIP_SCREEN_BF16X2=1, A/B)
+// Kernels in this file:
+//   vq_screen16_kernel      single-pass fp16 screen, two 32-row blocks per wave, D <= 256: bf16 rows (exact fp16 operands after a
+//                           power-of-two scaling) and fp32 rows (one fp16 operand set, measured residual in the bound); paired
+//                           sweep (every A fragment read from LDS once for both row blocks, the previous tile's top-3 fold between
+//                           this tile's MFMAs); residual chain in the prologue (vqhip_assign_screened_chain)
+//   vq_screen16_1rb_kernel  one row block per wave: D = 512, and the two-operand-set fp32 variant (VQHIP_SCREEN_F32_2PART=1)
+//   (vq_screen_p.hip: the persistent ping-pong form of the first one, opt-in.)
+// Round 1's two-pass bf16 hi/lo kernels and round 2's flat / skewed sweeps are in the git history (removed in round 3).
 //
-// Error bound of the round-1 kernels, in units of s = ||x||^2 + ||c||^2 - 2 x.c (u = 2^-24, D features, X = ||x||, Y = max_c ||c||); the
-// fp16 kernels state their own terms where they compute eps (codebook rounding through the exact residual norm, D + 1 accumulated terms):
+// Error bound, in units of s = ||x||^2 + ||c||^2 - 2 x.c (u = 2^-24, D features, X = ||x||, Y = max_c ||c||); the kernels state their
+// own terms where they compute eps (codebook rounding through the exact residual norm, D + 1 accumulated terms):
 //   reference chain (oracle/vq_oracle.c::vqo_assign):  |s_ref - s| <= u (x2 + y2) + u s + 2 D u X Y
-//   screen:  split 2 * 2^-16 X Y = 512 u X Y;  accumulation of 2 D products + the initial value inside the MFMAs, modelled as one
-//            rounding per added term with TRUNCATION (2u) -- pessimistic for a fused dot-product unit; measured at < 9 % of the model,
-//            tests/test_gpu_screen_fuzz.py::test_mfma_accumulation_error_within_model --  2 * 2 D * 2u * (X Y + Y^2 / 2)
+//   MFMA accumulation: one rounding per added term with TRUNCATION (2u) -- pessimistic for a fused dot-product unit; measured at
+//            < 9 % of the model, tests/test_gpu_screen_fuzz.py::test_mfma_accumulation_error_within_model
 //   sqrt collapse: distances that differ by < 4 ulp(s) may round to the same sqrt (vqp.py:62) and tie: 8 u s
 //   index bits: the kernel stores the lane-local code number in the 4 low mantissa bits of t: 2 * 16 ulp(t)
 // A row is certified when  t_best - t_second > eps_t,  eps_t = eps_s (an s margin of 2 eps_s).  tests/test_gpu_ops.py measures the
@@ -50,376 +50,6 @@ extern long long *vq_g_trace;
 #define VQ_STAMP(slot) do {} while (0)
 #define VQ_PHASE(slot) do {} while (0)
 #endif
-
-// best / second best of a 16-score accumulator.  key = score with its 4 low mantissa bits replaced by the register
-// number, so one v_med3 + one v_max per score track both values AND the position of the best.
-__device__ __forceinline__ void top2_tile(const f32x16 &acc, float &m1, float &m2, int &tix, int ct)
-{
-    const float om = m1;
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-        const float k = __uint_as_float((__float_as_uint(acc[e]) & 0xfffffff0u) | (unsigned)e);
-        m2 = __builtin_amdgcn_fmed3f(m1, m2, k);      // m1 >= m2: the median is the new runner-up
-        // fmaxf() on a value made by integer ops costs an extra canonicalising v_max_f32 k, k, k: emit the bare instruction
-        asm("v_max_f32 %0, %1, %2" : "=v"(m1) : "v"(m1), "v"(k));
-    }
-    tix = (m1 != om) ? ct : tix;
-}
-
-// best / second / third of a 16-score accumulator, and which tile the best and the second came from.  The third value
-// separates "the winner is one of two known codes" (decided by two exact distances, vq_pair_kernel) from "anything
-// goes" (full exact sweep): one more v_med3 per score.  When the new runner-up carries the bits of the old best, it IS the
-// old best (or an equal key, in which case second == third and the pair class is never entered).
-__device__ __forceinline__ void top3_tile(const f32x16 &acc, float &m1, float &m2, float &m3, int &t1, int &t2, int ct)
-{
-    const float om1 = m1, om2 = m2;
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-        const float k = __uint_as_float((__float_as_uint(acc[e]) & 0xfffffff0u) | (unsigned)e);
-        m3 = __builtin_amdgcn_fmed3f(m2, m3, k);
-        m2 = __builtin_amdgcn_fmed3f(m1, m2, k);
-        asm("v_max_f32 %0, %1, %2" : "=v"(m1) : "v"(m1), "v"(k));
-    }
-    const bool c1 = m1 != om1;
-    const int from_old_best = (c1 && m2 == om1) ? t1 : ct;
-    t2 = (m2 != om2) ? from_old_best : t2;
-    t1 = c1 ? ct : t1;
-}
-
-// METRIC 0: Euclidean (t = x.c - ||c||^2 / 2).  METRIC 1: cosine on rows that are already unit-norm (t = x.c, the
-// reference's einsum at vqp.py:741; no sqrt, ties only between equal floats): the accumulator starts at 0 and the bound has
-// no norm terms -- reference chain D u XY, split 2^-16 XY, accumulation 4 D u XY, and the margin must cover both codes: 2x.
-template <int DT, int METRIC>
-__global__ void __launch_bounds__(VQS_WAVES * 64, 8 / VQS_WAVES) vq_screen_kernel(const ScreenArgs a)
-{
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int TILE_B = 128 * DT + 1024;
-    constexpr int NCHUNK = TILE_B / 1024;          // 1-KiB pieces per tile
-    constexpr int NK = DT / 16;                    // MFMA k-steps
-    constexpr int STEPS = 2 * NK;                  // (k-step, hi/lo part) pairs, 2 MFMAs each
-    constexpr int PMAX = (NCHUNK + VQS_WAVES - 1) / VQS_WAVES;   // pieces per wave
-#ifndef VQS_NB
-#define VQS_NB 2
-#endif
-    constexpr int NB = (STEPS >= 2 * VQS_NB) ? VQS_NB : 2;   // staging batches
-    constexpr int BS = (PMAX + NB - 1) / NB;
-    constexpr int HALF = STEPS / NB;               // steps between batch starts
-#ifdef VQS_LAGM
-    constexpr int LAG = (HALF > VQS_LAGM + 1) ? HALF - VQS_LAGM : 1;
-#else
-    constexpr int LAG = (HALF > 3) ? HALF - 2 : 1; // steps between a batch's loads and its LDS stores
-#endif
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int j = lane & 31;
-    const int half = lane >> 5;
-    const int64_t wrow0 = (int64_t)blockIdx.x * VQ_SCREEN_ROWS + wave * 64;
-    VQ_PHASE(0);
-
-    // ---- tile 0: wave w copies the 1-KiB pieces w, w + WAVES, ... ----
-    constexpr int PSTRIDE = VQS_WAVES * 1024;
-    const int my_pieces = (NCHUNK - wave + VQS_WAVES - 1) / VQS_WAVES;
-    const int piece_off = wave * 1024 + lane * 16;
-    for (int k = 0; k < my_pieces; ++k)
-        *(f32x4 *)(smem + piece_off + k * PSTRIDE) = *(const f32x4 *)(a.tiles + piece_off + (size_t)k * PSTRIDE);
-
-    // ---- x rows -> B operands: lane (j, half) holds x[row][16 ks + 8 half + 0..7] for every k-step ----
-    uint4 xb[2][NK];
-    int64_t rows[2];
-    bool row_ok[2];
-#pragma unroll
-    for (int rb = 0; rb < 2; ++rb) {
-        rows[rb] = wrow0 + rb * 32 + j;
-        row_ok[rb] = rows[rb] < a.N;
-        const int64_t rc = row_ok[rb] ? rows[rb] : (a.N - 1);
-        const unsigned short *p = (const unsigned short *)a.x + rc * a.ldx + 8 * half;
-#pragma unroll
-        for (int ks = 0; ks < NK; ++ks) xb[rb][ks] = *(const uint4 *)(p + ks * 16);
-    }
-
-    // ---- ||x||^2 (any order: it only scales the error bound) ----
-    float eps[2];
-    {
-        const float y2max = __uint_as_float(a.scalars[0]);
-        const float ymax = sqrtf(y2max) * 1.0001f;
-        const float u = 5.9604645e-8f;   // 2^-24
-#pragma unroll
-        for (int rb = 0; rb < 2; ++rb) {
-            float xs = 0.f;
-#pragma unroll
-            for (int ks = 0; ks < NK; ++ks) {
-                const unsigned w[4] = {xb[rb][ks].x, xb[rb][ks].y, xb[rb][ks].z, xb[rb][ks].w};
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    xs = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, w[q]), __builtin_bit_cast(bf16x2, w[q]), xs, false);
-            }
-            xs += __shfl_xor(xs, 32, 64);
-            xs *= 1.001f;
-            const float xn = sqrtf(xs) * 1.0001f;
-            const float xy = xn * ymax;
-            // eps_s (see the header): 10 u (x2 + y2max + 2 xy)  >=  u (x2 + y2) + 9 u s
-            if (METRIC == 0) eps[rb] = u * (10.f * (xs + y2max + 2.f * xy) + (2.f * DT + 512.f) * xy + 8.f * DT * (xy + 0.5f * y2max)) + 4e-8f;
-            else             eps[rb] = 2.f * u * (5.f * DT + 256.f) * xy + 1e-30f;
-        }
-    }
-
-    float m1[2] = {-__builtin_inff(), -__builtin_inff()};
-    float m2[2] = {-__builtin_inff(), -__builtin_inff()};
-    int tix[2] = {0, 0};
-    VQ_PHASE(1);   // x loaded, eps computed
-
-    const int nt = a.n_tiles;
-    for (int ct = 0; ct < nt; ++ct) {
-        const int buf = ct & 1;
-        VQ_STAMP(0);
-        __syncthreads();   // tile ct has landed for every wave; the other buffer is free
-        VQ_STAMP(1);
-        const char *tile = smem + buf * TILE_B;
-        const bool more = ct + 1 < nt;
-        const char *gsrc = a.tiles + (size_t)(more ? ct + 1 : ct) * TILE_B + piece_off;
-        char *ldst = smem + (buf ^ 1) * TILE_B + piece_off;
-        const int npieces = more ? my_pieces : 0;
-
-        // accumulators start at -||c||^2 / 2 of the register's code (same mapping as the fp32 kernel:
-        // register e <-> code 8 (e >> 2) + 4 half + (e & 3) of the tile)
-        const float *nh = (const float *)(tile + 128 * DT);
-        f32x16 acc0, acc1;
-        if (METRIC == 0 || (ct == nt - 1 && (a.C & 31))) {   // cosine starts at 0; only a ragged last tile needs the
-#pragma unroll                                               // -3e38 of its padding codes (they would score 0 otherwise)
-            for (int q = 0; q < 4; ++q) {
-                f32x4 v = *(const f32x4 *)(nh + 8 * q + 4 * half);
-                if (METRIC != 0) { v.x = v.x < -1e38f ? v.x : 0.f; v.y = v.y < -1e38f ? v.y : 0.f;
-                                   v.z = v.z < -1e38f ? v.z : 0.f; v.w = v.w < -1e38f ? v.w : 0.f; }
-                acc0[4 * q + 0] = v.x; acc0[4 * q + 1] = v.y; acc0[4 * q + 2] = v.z; acc0[4 * q + 3] = v.w;
-            }
-        } else {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc0[r] = 0.f;
-        }
-        acc1 = acc0;
-
-        const uint4 *ap = (const uint4 *)tile + lane;
-        f32x4 stg[BS];
-        uint4 af[VQS_PF];   // A-fragment ring: the ds_read of step s + VQS_PF is issued behind the MFMAs of step s
-#pragma unroll
-        for (int p = 0; p < VQS_PF; ++p) af[p] = ap[(p < STEPS ? p : 0) * 64];
-#pragma unroll
-        for (int s = 0; s < STEPS; ++s) {
-            const int ks = s >> 1;
-            const bf16x8 av = __builtin_bit_cast(bf16x8, af[s % VQS_PF]);
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, __builtin_bit_cast(bf16x8, xb[0][ks]), acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, __builtin_bit_cast(bf16x8, xb[1][ks]), acc1, 0, 0, 0);
-            if (s + VQS_PF < STEPS) af[s % VQS_PF] = ap[(s + VQS_PF) * 64];
-#ifdef VQS_PIN
-            __builtin_amdgcn_sched_barrier(0);   // keep the prefetch distance: hipcc otherwise sinks the ds_reads next to their use
-#endif
-#ifdef VQS_GLDS
-            // LDS-DMA variant: piece s of this wave's share goes L2 -> LDS directly (no staging registers, no ds_write);
-            // the wave waits for its DMAs at the end of the tile, before the barrier that publishes the buffer
-            if (s < PMAX && s < npieces)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gsrc + (size_t)s * PSTRIDE),
-                                                 (__attribute__((address_space(3))) void *)(ldst - lane * 16 + s * PSTRIDE), 16, 0, 0);
-#elif !defined(VQS_NO_STAGE)
-#pragma unroll
-            for (int b = 0; b < NB; ++b) {
-                if (s == b * HALF) {
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int i = 0; i < BS; ++i)   // unconditional: a piece past this wave's share reads the tail pad
-                        if (b * BS + i < PMAX) stg[i] = *(const f32x4 *)(gsrc + (size_t)(b * BS + i) * PSTRIDE);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                if (s == b * HALF + LAG) {
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int i = 0; i < BS; ++i)
-                        if (b * BS + i < npieces) *(f32x4 *)(ldst + (b * BS + i) * PSTRIDE) = stg[i];
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            }
-#endif
-        }
-#ifdef VQS_GLDS
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
-        VQ_STAMP(2);
-#ifndef VQS_NO_EPI
-        top2_tile(acc0, m1[0], m2[0], tix[0], ct);
-        top2_tile(acc1, m1[1], m2[1], tix[1], ct);
-        VQ_STAMP(3);
-#else
-        m1[0] = fmaxf(m1[0], acc0[ct & 15]); m1[1] = fmaxf(m1[1], acc1[ct & 15]);
-#endif
-    }
-
-    VQ_PHASE(2);   // sweep done
-    // ---- merge the half-waves, certify, emit ----
-    int code[2];
-    bool flagged[2];
-#pragma unroll
-    for (int rb = 0; rb < 2; ++rb) {
-        const int e = (int)(__float_as_uint(m1[rb]) & 15u);
-        const int c_own = tix[rb] * 32 + 8 * (e >> 2) + 4 * half + (e & 3);
-        const float o1 = __shfl_xor(m1[rb], 32, 64);
-        const float o2 = __shfl_xor(m2[rb], 32, 64);
-        const int oc = __shfl_xor(c_own, 32, 64);
-        const bool take = o1 > m1[rb];
-        const float b1 = take ? o1 : m1[rb];
-        const float lo1 = take ? m1[rb] : o1;
-        const float b2 = fmaxf(lo1, fmaxf(m2[rb], o2));
-        code[rb] = take ? oc : c_own;
-        const float thr = eps[rb] + 8e-6f * fabsf(b1);
-        flagged[rb] = !((b1 - b2) > thr) || code[rb] >= a.C;
-        if (row_ok[rb] && half == 0) {
-            a.idx_out[rows[rb]] = (int64_t)(code[rb] < a.C ? code[rb] : 0);
-            if (a.dbg) {
-                float *d = a.dbg + rows[rb] * 4;
-                d[0] = b1; d[1] = b2; d[2] = thr; d[3] = flagged[rb] ? 1.f : 0.f;
-            }
-        }
-        if (code[rb] >= a.C) code[rb] = 0;
-        // append the uncertified rows to the list (one atomic per wave and row block)
-        const bool f = flagged[rb] && row_ok[rb] && half == 0;
-        const unsigned long long bal = __ballot(f);
-        if (bal) {
-            int base = 0;
-            if (lane == 0) base = atomicAdd(a.flag_count, (int)__popcll(bal));
-            base = __builtin_amdgcn_readfirstlane(base);
-            if (f) {
-                const int slot = base + (int)__popcll(bal & ((1ull << lane) - 1ull));
-                a.flag_rows[slot] = (int)rows[rb];
-                a.flag_keys[slot] = ~0ull;
-            }
-        }
-    }
-
-    VQ_PHASE(3);   // idx + list written
-    // ---- outputs per row block: the loss operands (this lane's slice of its row's code, L2) are requested first so
-    //      their latency hides behind the q copy; q = bf16 codebook rows written as whole rows, 16 rows in flight;
-    //      squared error of the certified rows from the registers (the listed rows are counted by the exact pass) ----
-    double ds = 0.0;
-#ifdef VQS_OUT2
-    if (!a.resid_out) {
-        // loss(rb 0) -> [q rows of rb 0, 32 in flight || loss operands of rb 1] -> loss(rb 1) -> q rows of rb 1, 32 in flight:
-        // three load round trips, no batch waits for the previous batch's stores (its registers are not reused)
-        auto loss_of = [&](int rb, const uint4 (&gq)[NK]) {
-            f32x2 ls = {0.f, 0.f};
-#pragma unroll
-            for (int ks = 0; ks < NK; ++ks) {
-                const unsigned gw[4] = {gq[ks].x, gq[ks].y, gq[ks].z, gq[ks].w};
-                const unsigned xw[4] = {xb[rb][ks].x, xb[rb][ks].y, xb[rb][ks].z, xb[rb][ks].w};
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const f32x2 gv = {__uint_as_float(gw[q] << 16), __uint_as_float(gw[q] & 0xffff0000u)};
-                    const f32x2 xv = {__uint_as_float(xw[q] << 16), __uint_as_float(xw[q] & 0xffff0000u)};
-                    const f32x2 df = gv - xv;
-                    ls = __builtin_elementwise_fma(df, df, ls);
-                }
-            }
-            const bool counted = row_ok[rb] && !flagged[rb] && (!a.row_mask || a.row_mask[rows[rb]] != 0);
-            ds += counted ? (double)(ls[0] + ls[1]) : 0.0;
-        };
-        uint4 gq0[NK], gq1[NK];
-        if (a.sqerr_partial) {
-            const unsigned short *er = a.embed_bf16 + (size_t)code[0] * DT + 8 * half;
-#pragma unroll
-            for (int ks = 0; ks < NK; ++ks) gq0[ks] = *(const uint4 *)(er + ks * 16);
-            loss_of(0, gq0);
-            __builtin_amdgcn_sched_barrier(0);
-            const unsigned short *er1 = a.embed_bf16 + (size_t)code[1] * DT + 8 * half;
-#pragma unroll
-            for (int ks = 0; ks < NK; ++ks) gq1[ks] = *(const uint4 *)(er1 + ks * 16);
-        }
-#pragma unroll
-        for (int rb = 0; rb < 2; ++rb) {
-            if (a.q_out) {
-                uint2 g[32];
-#pragma unroll
-                for (int u = 0; u < 32; ++u) {
-                    const int c = __builtin_amdgcn_readlane(code[rb], u);
-                    if (lane * 4 < DT) g[u] = *(const uint2 *)(a.embed_bf16 + (size_t)c * DT + lane * 4);
-                }
-#pragma unroll
-                for (int u = 0; u < 32; ++u) {
-                    const int64_t rr = wrow0 + rb * 32 + u;
-                    if (rr < a.N && lane * 4 < DT) *(uint2 *)((unsigned short *)a.q_out + rr * a.ldq + lane * 4) = g[u];
-                }
-            }
-            if (rb == 0 && a.sqerr_partial) {
-                loss_of(1, gq1);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-    } else
-#endif
-#pragma unroll
-    for (int rb = 0; rb < 2; ++rb) {
-        uint4 gq[NK];
-        if (a.sqerr_partial) {
-            const unsigned short *er = a.embed_bf16 + (size_t)code[rb] * DT + 8 * half;
-#pragma unroll
-            for (int ks = 0; ks < NK; ++ks) gq[ks] = *(const uint4 *)(er + ks * 16);
-        }
-        if (a.q_out || a.resid_out) {
-            const bool want_r = a.resid_out != nullptr;
-#pragma unroll
-            for (int r0 = 0; r0 < 32; r0 += 16) {
-                uint2 g[16], xv[16];
-#pragma unroll
-                for (int u = 0; u < 16; ++u) {
-                    const int c = __builtin_amdgcn_readlane(code[rb], r0 + u);
-                    const int64_t rr = wrow0 + rb * 32 + r0 + u;
-                    if (lane * 4 < DT) {
-                        g[u] = *(const uint2 *)(a.embed_bf16 + (size_t)c * DT + lane * 4);
-                        if (want_r) xv[u] = *(const uint2 *)((const unsigned short *)a.x + (rr < a.N ? rr : a.N - 1) * a.ldx + lane * 4);
-                    }
-                }
-#pragma unroll
-                for (int u = 0; u < 16; ++u) {
-                    const int64_t rr = wrow0 + rb * 32 + r0 + u;
-                    if (rr < a.N && lane * 4 < DT) {
-                        if (a.q_out) *(uint2 *)((unsigned short *)a.q_out + rr * a.ldq + lane * 4) = g[u];
-                        if (want_r) *(uint2 *)((unsigned short *)a.resid_out + rr * a.ldr + lane * 4) = vq_bf16x4_sub(xv[u], g[u]);
-                    }
-                }
-            }
-        }
-        if (a.sqerr_partial) {
-            f32x2 ls = {0.f, 0.f};
-#pragma unroll
-            for (int ks = 0; ks < NK; ++ks) {
-                const unsigned gw[4] = {gq[ks].x, gq[ks].y, gq[ks].z, gq[ks].w};
-                const unsigned xw[4] = {xb[rb][ks].x, xb[rb][ks].y, xb[rb][ks].z, xb[rb][ks].w};
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const f32x2 gv = {__uint_as_float(gw[q] << 16), __uint_as_float(gw[q] & 0xffff0000u)};
-                    const f32x2 xv = {__uint_as_float(xw[q] << 16), __uint_as_float(xw[q] & 0xffff0000u)};
-                    const f32x2 df = gv - xv;
-                    ls = __builtin_elementwise_fma(df, df, ls);
-                }
-            }
-            const bool counted = row_ok[rb] && !flagged[rb] && (!a.row_mask || a.row_mask[rows[rb]] != 0);
-            ds += counted ? (double)(ls[0] + ls[1]) : 0.0;
-        }
-    }
-    VQ_PHASE(4);   // q rows + squared error done
-    if (a.sqerr_partial) {
-#pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) ds += __shfl_xor(ds, o, 64);
-        __syncthreads();
-        double *red = (double *)smem;
-        if (lane == 0) red[wave] = ds;
-        __syncthreads();
-        if (tid == 0) {
-            double t = 0.0;
-#pragma unroll
-            for (int w = 0; w < VQS_WAVES; ++w) t += red[w];
-            a.sqerr_partial[blockIdx.x] = t;
-        }
-    }
-}
 
 // ------------------------------------------------------------------------------------------------
 // Single-pass fp16 screen for bf16 rows (vq_screen16_kernel).  Half the MFMAs of the hi/lo kernel above:
@@ -806,7 +436,6 @@ __global__ void __launch_bounds__(VQS_WAVES * 64, 8 / VQS_WAVES) vq_screen16_ker
 #else
     const int nst = a.n_tiles16 / SUB;   // barriers
 #endif
-#if !defined(VQS16_SKEWED) && !defined(VQS16_FLAT)
     // ---- paired sweep: every A fragment is read from LDS ONCE and multiplied with both row blocks (two MFMAs on DIFFERENT
     //      accumulators back to back: no dependent-accumulator stall between them), and the top-3 epilogue of the PREVIOUS tile's
     //      two accumulators is issued in slices between this tile's MFMAs.  Tiles are processed in pairs with the accumulator
@@ -955,241 +584,6 @@ __global__ void __launch_bounds__(VQS_WAVES * 64, 8 / VQS_WAVES) vq_screen16_ker
         book(o10, o20, m1[0], m2[0], tix[0], tix2[0], ptile);
         book(o11, o21, m1[1], m2[1], tix[1], tix2[1], ptile);
     }
-#elif !defined(VQS16_FLAT)
-    // ---- skewed sweep: a tile is swept for row block 0 (NK MFMAs into acc0), then for row block 1 (NK MFMAs into acc1).
-    //      The top-3 epilogue of a finished accumulator is issued in slices BETWEEN the MFMAs of the other row block -- acc1 of
-    //      the previous tile beside this tile's row-block-0 MFMAs, acc0 beside the row-block-1 MFMAs -- so a wave's VALU work
-    //      runs in the shadow of its own matrix instructions (measured: a lone wave needed 2.5k cycles per tile for 1k cycles
-    //      of MFMA issue with the epilogue behind the MFMAs).  Costs a second LDS read of every A fragment, no registers. ----
-    f32x16 pa1;                                           // row block 1's scores of the previous tile
-#pragma unroll
-    for (int r = 0; r < 16; ++r) pa1[r] = -3.0e38f;      // "a padding code": never wins against a real one
-    int ptile = 0;
-    // one score into (best, second, third).  The key is formed by the compiler (it pads the MFMA -> VALU read hazard of
-    // acc[e]); the three updates are ONE volatile asm statement: as builtins, hipcc sinks every v_med3 of a tile behind the
-    // tile's last MFMA (their results are only needed there), which un-does the overlap and keeps 32 temporaries alive.
-    auto fold = [&](const f32x16 &acc, int e, float &b1, float &b2, float &b3) {
-        const float k = __uint_as_float((__float_as_uint(acc[e]) & 0xfffffff0u) | (unsigned)e);
-        asm volatile("v_med3_f32 %2, %1, %2, %3\n\tv_med3_f32 %1, %0, %1, %3\n\tv_max_f32 %0, %0, %3"
-                     : "+v"(b1), "+v"(b2), "+v"(b3) : "v"(k));
-    };
-    auto book = [&](float om1, float om2, float n1, float n2, int &t1, int &t2, int tile_id) {   // which tiles hold best / second
-        const bool c1 = n1 != om1;
-        const int from_old_best = (c1 && n2 == om1) ? t1 : tile_id;
-        t2 = (n2 != om2) ? from_old_best : t2;
-        t1 = c1 ? tile_id : t1;
-    };
-    for (int st = 0; st < nst; ++st) {
-        const int buf = st & 1;
-        [[maybe_unused]] const int ct = st;   // trace index
-        VQ_STAMP(0);
-        __syncthreads();     // buffer `buf` has landed for every wave; the other buffer is free
-        VQ_STAMP(1);
-        const char *sbase = smem + buf * BUF_B;
-        const bool more = st + 1 < nst;
-        const char *gsrc = tiles + (size_t)(more ? st + 1 : st) * SUPER_B + piece_off;
-        char *ldst = smem + (buf ^ 1) * BUF_B + piece_off;   // (the last interval re-copies its own buffer into the idle one: no branch)
-#pragma unroll 1
-        for (int sub = 0; sub < SUB; ++sub) {
-            const char *tile = sbase + sub * TILE_B;
-            const float *nh = (const float *)(tile + 64 * DT);
-            const int tile_id = st * SUB + sub;
-            const bool has_pad = (tile_id + 1) * 32 > a.C;
-            const uint4 *ap = (const uint4 *)tile + lane;
-            uint4 af[VQS16_PF];
-            f32x4 stg[BS];
-            f32x16 acc0, acc1;
-            const int p0 = sub * PPS;
-            float o1 = m1[1], o2 = m2[1];     // row block 1's best / second before the previous tile is folded in
-            f32x16 init;
-#pragma unroll
-            for (int p = 0; p < VQS16_PF; ++p) af[p] = ap[(p % NK) * 64];
-#pragma unroll
-            for (int s = 0; s < 2 * NK; ++s) {
-                const int ph = s / NK, ks = s % NK;
-                const f16x8 av = __builtin_bit_cast(f16x8, af[s % VQS16_PF]);
-                if (XF32 ? (ks == 0) : (s == 0)) {   // fp32 rows: the two row blocks have their own scales, hence their own start values
-                    // start value -||c||^2 / 2 (scaled); register e <-> code 8 (e >> 2) + 4 half + (e & 3) of the tile.  Tiles with
-                    // padding codes clamp it to a finite -3e38 (scaled, the padding's -3e38 overflows to -inf, and -inf with the
-                    // code number in its mantissa is a NaN key that v_med3_f32 must never see).
-                    if (METRIC == 0 || has_pad) {
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            f32x4 v = *(const f32x4 *)(nh + 8 * q + 4 * half);
-                            if (METRIC != 0) { v.x = v.x < -1e38f ? v.x : 0.f; v.y = v.y < -1e38f ? v.y : 0.f;
-                                               v.z = v.z < -1e38f ? v.z : 0.f; v.w = v.w < -1e38f ? v.w : 0.f; }
-                            init[4 * q + 0] = v.x * SSv[ph]; init[4 * q + 1] = v.y * SSv[ph]; init[4 * q + 2] = v.z * SSv[ph]; init[4 * q + 3] = v.w * SSv[ph];
-                        }
-                        if (has_pad) {
-#pragma unroll
-                            for (int r = 0; r < 16; ++r) init[r] = fmaxf(init[r], -3.0e38f);
-                        }
-                    } else {
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) init[r] = 0.f;
-                    }
-                }
-                if (ks == 0) {
-                    if (ph == 0) acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, __builtin_bit_cast(f16x8, xb[0][ks]), init, 0, 0, 0);
-                    else         acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, __builtin_bit_cast(f16x8, xb[1][ks]), init, 0, 0, 0);
-                } else {
-                    if (ph == 0) acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, __builtin_bit_cast(f16x8, xb[0][ks]), acc0, 0, 0, 0);
-                    else         acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, __builtin_bit_cast(f16x8, xb[1][ks]), acc1, 0, 0, 0);
-                }
-                if (NPART == 2) {   // the low part of the rows against the same A fragment
-                    if (ph == 0) acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, __builtin_bit_cast(f16x8, xm[0][NPART == 2 ? ks : 0]), acc0, 0, 0, 0);
-                    else         acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, __builtin_bit_cast(f16x8, xm[1][NPART == 2 ? ks : 0]), acc1, 0, 0, 0);
-                }
-                if (s + VQS16_PF < 2 * NK) af[s % VQS16_PF] = ap[((s + VQS16_PF) % NK) * 64];
-#ifndef VQS16_NO_EPI
-                // epilogue slice of the accumulator the OTHER row block finished: independent of the MFMA just issued
-                if (ks >= 1) {   // the 16 scores spread evenly over the steps 1 .. NK - 1 of the phase
-#pragma unroll
-                    for (int e = (ks - 1) * 16 / (NK - 1); e < ks * 16 / (NK - 1); ++e) {
-                        if (ph == 0) fold(pa1, e, m1[1], m2[1], m3[1]);
-                        else         fold(acc0, e, m1[0], m2[0], m3[0]);
-                    }
-                }
-#endif
-                __builtin_amdgcn_sched_barrier(0);   // pins the slice and the prefetch distance between the MFMAs
-                if (s == NK - 1) {                    // the previous tile's row block 1 is folded in: which tiles hold its best / second
-                    book(o1, o2, m1[1], m2[1], tix[1], tix2[1], ptile);
-                    o1 = m1[0]; o2 = m2[0];           // row block 0's state before this tile's scores
-                }
-#ifndef VQS16_NO_STAGE
-#pragma unroll
-                for (int bt = 0; bt < 2; ++bt) {
-                    if (s == bt * NK) {
-#pragma unroll
-                        for (int i = 0; i < BS2; ++i)   // unconditional (a guarded load makes hipcc wait right behind it, a guarded store
-                            if (bt * BS2 + i < PPS) {   // costs a scalar branch each): a piece past this wave's share repeats its last one
-                                const int pc = min(p0 + bt * BS2 + i, PMAX - 1);
-                                stg[i] = *(const f32x4 *)(gsrc + (size_t)pc * PSTRIDE);
-                            }
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                    if (s == bt * NK + LAG2) {
-#pragma unroll
-                        for (int i = 0; i < BS2; ++i)
-                            if (bt * BS2 + i < PPS) *(f32x4 *)(ldst + min(p0 + bt * BS2 + i, PMAX - 1) * PSTRIDE) = stg[i];
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                }
-#endif
-            }
-#ifndef VQS16_NO_EPI
-            book(o1, o2, m1[0], m2[0], tix[0], tix2[0], tile_id);
-#else
-            m1[0] = fmaxf(m1[0], acc0[st & 15]);
-#endif
-            pa1 = acc1;
-            ptile = tile_id;
-        }
-        VQ_STAMP(2);
-    }
-    {   // row block 1 of the last tile
-        const float o1 = m1[1], o2 = m2[1];
-#pragma unroll
-        for (int e = 0; e < 16; ++e) fold(pa1, e, m1[1], m2[1], m3[1]);
-        book(o1, o2, m1[1], m2[1], tix[1], tix2[1], ptile);
-    }
-#else   // VQS16_FLAT: both row blocks interleaved, epilogue behind the tile's MFMAs (first version, kept for A/B runs)
-    for (int st = 0; st < nst; ++st) {
-        const int buf = st & 1;
-        [[maybe_unused]] const int ct = st;   // trace index
-        VQ_STAMP(0);
-        __syncthreads();     // buffer `buf` has landed for every wave; the other buffer is free
-        VQ_STAMP(1);
-        const char *sbase = smem + buf * BUF_B;
-        const bool more = st + 1 < nst;
-        const char *gsrc = tiles + (size_t)(more ? st + 1 : st) * SUPER_B + piece_off;
-        char *ldst = smem + (buf ^ 1) * BUF_B + piece_off;
-        const int npieces = more ? (NCHUNK - wave + VQS_WAVES - 1) / VQS_WAVES : 0;
-
-        // NOT unrolled over the tiles of a buffer: unrolled, hipcc hoists every tile's LDS reads to the top of the interval
-        // and spills the resident rows; each tile stages its own share (PPS pieces) of the next buffer instead
-#pragma unroll 1
-        for (int sub = 0; sub < SUB; ++sub) {
-            const char *tile = sbase + sub * TILE_B;
-            // accumulators start at -||c||^2 / 2 (scaled); register e <-> code 8 (e >> 2) + 4 half + (e & 3) of the tile.
-            // Tiles that contain padding codes (the ragged last tile, the tiles that pad the count to a multiple of SUB) clamp the
-            // start value to a finite -3e38: scaled, the padding's -3e38 would overflow to -inf, and -inf with the code number
-            // in its mantissa bits is a NaN key that v_med3_f32 must never see.
-            const float *nh = (const float *)(tile + 64 * DT);
-            const bool has_pad = (st * SUB + sub + 1) * 32 > a.C;
-            f32x16 init;
-            if (METRIC == 0 || has_pad) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    f32x4 v = *(const f32x4 *)(nh + 8 * q + 4 * half);
-                    if (METRIC != 0) { v.x = v.x < -1e38f ? v.x : 0.f; v.y = v.y < -1e38f ? v.y : 0.f;
-                                       v.z = v.z < -1e38f ? v.z : 0.f; v.w = v.w < -1e38f ? v.w : 0.f; }
-                    init[4 * q + 0] = v.x * SSv[0]; init[4 * q + 1] = v.y * SSv[0]; init[4 * q + 2] = v.z * SSv[0]; init[4 * q + 3] = v.w * SSv[0];
-                }
-                if (has_pad) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) init[r] = fmaxf(init[r], -3.0e38f);
-                }
-            } else {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) init[r] = 0.f;
-            }
-            f32x16 acc0, acc1;
-            const uint4 *ap = (const uint4 *)tile + lane;
-            uint4 af[VQS16_PF];
-            f32x4 stg[BS];
-            const int p0 = sub * PPS;   // first piece of this tile's share
-#pragma unroll
-            for (int p = 0; p < VQS16_PF; ++p) af[p] = ap[(p < NK ? p : 0) * 64];
-#pragma unroll
-            for (int s = 0; s < NK; ++s) {
-                const f16x8 av = __builtin_bit_cast(f16x8, af[s % VQS16_PF]);
-                if (s == 0) {
-                    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, __builtin_bit_cast(f16x8, xb[0][s]), init, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, __builtin_bit_cast(f16x8, xb[1][s]), init, 0, 0, 0);
-                } else {
-                    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, __builtin_bit_cast(f16x8, xb[0][s]), acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, __builtin_bit_cast(f16x8, xb[1][s]), acc1, 0, 0, 0);
-                }
-                if (s + VQS16_PF < NK) af[s % VQS16_PF] = ap[(s + VQS16_PF) * 64];
-                __builtin_amdgcn_sched_barrier(0);   // keep the prefetch distance: hipcc otherwise sinks the ds_reads next to their use
-#ifndef VQS16_NO_STAGE
-#pragma unroll
-                for (int b = 0; b < NBS; ++b) {
-                    if (s == b * SPAN) {
-#pragma unroll
-                        for (int i = 0; i < BS; ++i)   // unconditional loads (a guarded load makes hipcc wait right behind it): a piece
-                            if (b * BS + i < PPS) {    // past this wave's share re-reads its last one
-                                const int pc = min(p0 + b * BS + i, PMAX - 1);
-                                stg[i] = *(const f32x4 *)(gsrc + (size_t)pc * PSTRIDE);
-                            }
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                    if (s == b * SPAN + LAG) {
-#pragma unroll
-                        for (int i = 0; i < BS; ++i)
-                            if (b * BS + i < PPS && p0 + b * BS + i < npieces) *(f32x4 *)(ldst + (p0 + b * BS + i) * PSTRIDE) = stg[i];
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                }
-#endif
-            }
-#ifndef VQS16_NO_EPI
-#ifdef VQS16_TOP2   // A/B: no third value, no pair class (every uncertified row takes the full exact sweep)
-            top2_tile(acc0, m1[0], m2[0], tix[0], st * SUB + sub);
-            top2_tile(acc1, m1[1], m2[1], tix[1], st * SUB + sub);
-#else
-            top3_tile(acc0, m1[0], m2[0], m3[0], tix[0], tix2[0], st * SUB + sub);
-            top3_tile(acc1, m1[1], m2[1], m3[1], tix[1], tix2[1], st * SUB + sub);
-#endif
-#else
-            m1[0] = fmaxf(m1[0], acc0[st & 15]); m1[1] = fmaxf(m1[1], acc1[st & 15]);
-#endif
-        }
-        VQ_STAMP(2);
-    }
-
-#endif
 
     VQ_PHASE(2);   // sweep done
     // ---- merge the half-waves (each holds the top 3 of its 16 of a tile's 32 codes), classify, emit ----
@@ -1783,252 +1177,6 @@ __global__ void __launch_bounds__(VQS_F32_WAVES * 64, (XBF16 && NPART == 1 && DT
     }
 }
 
-// ------------------------------------------------------------------------------------------------
-// fp32 rows.  x is split as well, x = x_hi + x_mid + r_x (bf16 parts, |r_x| <= 2^-16 |x|), and three products are
-// accumulated per k-step: c_hi x_hi, c_hi x_mid, c_lo x_hi.  Dropped: c_lo x_mid, c r_x, r_c x -- each <= 2^-16 |x||c|
-// (+ second order), so the split term of the bound becomes 3.03 * 2 * 2^-16 X Y <= 1600 u X Y and the accumulation term
-// 12 D u (3 D products).  One 32-row block per wave (the two operand sets of a row block fill the registers the bf16
-// kernel spends on a second row block), VQS_F32_WAVES waves per workgroup; the three MFMAs of a k-step alternate between
-// two accumulators so that no MFMA waits for its predecessor.  q (fp32 code rows) and the squared error are produced by
-// a row-cooperative pass that re-reads x, because the registers only hold x to 16 bits.
-// ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void split8_bf16(const f32x4 &v0, const f32x4 &v1, uint4 &h, uint4 &m)
-{
-    const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-    unsigned hw[4], mw[4];
-#pragma unroll
-    for (int e = 0; e < 8; e += 2) {
-        const unsigned short h0 = vq_f32_to_bf16_rne(v[e]), h1 = vq_f32_to_bf16_rne(v[e + 1]);
-        const unsigned short m0 = vq_f32_to_bf16_rne(v[e] - vq_bf16_bits_to_f32(h0));       // v - h is exact in fp32
-        const unsigned short m1 = vq_f32_to_bf16_rne(v[e + 1] - vq_bf16_bits_to_f32(h1));
-        hw[e >> 1] = (unsigned)h0 | ((unsigned)h1 << 16);
-        mw[e >> 1] = (unsigned)m0 | ((unsigned)m1 << 16);
-    }
-    h = make_uint4(hw[0], hw[1], hw[2], hw[3]);
-    m = make_uint4(mw[0], mw[1], mw[2], mw[3]);
-}
-
-template <int DT, int METRIC>
-__global__ void __launch_bounds__(VQS_F32_WAVES * 64, 8 / VQS_F32_WAVES) vq_screen_f32_kernel(const ScreenArgs a)
-{
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int W = VQS_F32_WAVES;
-    constexpr int TILE_B = 128 * DT + 1024;
-    constexpr int NCHUNK = TILE_B / 1024;
-    constexpr int NK = DT / 16;
-    constexpr int STEPS = 2 * NK;
-    constexpr int PMAX = (NCHUNK + W - 1) / W;
-    constexpr int NB = 2;
-    constexpr int BS = (PMAX + NB - 1) / NB;
-    constexpr int HALF = STEPS / 2;
-    constexpr int LAG = (HALF > 3) ? HALF - 2 : 1;
-    constexpr int PSTRIDE = W * 1024;
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int j = lane & 31;
-    const int half = lane >> 5;
-    const int64_t wrow0 = (int64_t)blockIdx.x * VQ_SCREEN_F32_ROWS + wave * 32;
-
-    const int my_pieces = (NCHUNK - wave + W - 1) / W;
-    const int piece_off = wave * 1024 + lane * 16;
-    for (int k = 0; k < my_pieces; ++k)
-        *(f32x4 *)(smem + piece_off + k * PSTRIDE) = *(const f32x4 *)(a.tiles + piece_off + (size_t)k * PSTRIDE);
-
-    // ---- x rows -> two bf16 B-operand sets; lane (j, half) holds features 16 ks + 8 half + 0..7 ----
-    const int64_t row = wrow0 + j;
-    const bool row_ok = row < a.N;
-    uint4 xh[NK], xm[NK];
-    float eps;
-    {
-        const float *p = (const float *)a.x + (row_ok ? row : (a.N - 1)) * a.ldx + 8 * half;
-        float xs = 0.f;
-#pragma unroll
-        for (int ks = 0; ks < NK; ++ks) {
-            const f32x4 v0 = *(const f32x4 *)(p + ks * 16), v1 = *(const f32x4 *)(p + ks * 16 + 4);
-            split8_bf16(v0, v1, xh[ks], xm[ks]);
-            xs = __builtin_fmaf(v0.x, v0.x, xs); xs = __builtin_fmaf(v0.y, v0.y, xs);
-            xs = __builtin_fmaf(v0.z, v0.z, xs); xs = __builtin_fmaf(v0.w, v0.w, xs);
-            xs = __builtin_fmaf(v1.x, v1.x, xs); xs = __builtin_fmaf(v1.y, v1.y, xs);
-            xs = __builtin_fmaf(v1.z, v1.z, xs); xs = __builtin_fmaf(v1.w, v1.w, xs);
-        }
-        xs += __shfl_xor(xs, 32, 64);
-        xs *= 1.001f;
-        const float y2max = __uint_as_float(a.scalars[0]);
-        const float xy = sqrtf(xs) * 1.0001f * sqrtf(y2max) * 1.0001f;
-        const float u = 5.9604645e-8f;   // 2^-24
-        if (METRIC == 0) eps = u * (10.f * (xs + y2max + 2.f * xy) + (2.f * DT + 1600.f) * xy + (12.f * DT + 2.f) * (xy + 0.5f * y2max)) + 4e-8f;
-        else             eps = 2.f * u * (7.f * DT + 802.f) * xy + 1e-30f;
-    }
-
-    float m1 = -__builtin_inff(), m2 = -__builtin_inff();
-    int tix = 0;
-    const int nt = a.n_tiles;
-    for (int ct = 0; ct < nt; ++ct) {
-        const int buf = ct & 1;
-        __syncthreads();
-        const char *tile = smem + buf * TILE_B;
-        const bool more = ct + 1 < nt;
-        const char *gsrc = a.tiles + (size_t)(more ? ct + 1 : ct) * TILE_B + piece_off;
-        char *ldst = smem + (buf ^ 1) * TILE_B + piece_off;
-        const int npieces = more ? my_pieces : 0;
-
-        const float *nh = (const float *)(tile + 128 * DT);
-        f32x16 acc0, acc1;
-        if (METRIC == 0 || (ct == nt - 1 && (a.C & 31))) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                f32x4 v = *(const f32x4 *)(nh + 8 * q + 4 * half);
-                if (METRIC != 0) { v.x = v.x < -1e38f ? v.x : 0.f; v.y = v.y < -1e38f ? v.y : 0.f;
-                                   v.z = v.z < -1e38f ? v.z : 0.f; v.w = v.w < -1e38f ? v.w : 0.f; }
-                acc0[4 * q + 0] = v.x; acc0[4 * q + 1] = v.y; acc0[4 * q + 2] = v.z; acc0[4 * q + 3] = v.w;
-            }
-        } else {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc0[r] = 0.f;
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc1[r] = 0.f;
-
-        const uint4 *ap = (const uint4 *)tile + lane;
-        f32x4 stg[BS];
-        uint4 af[VQS_PF];
-#pragma unroll
-        for (int p = 0; p < VQS_PF; ++p) af[p] = ap[(p < STEPS ? p : 0) * 64];
-#pragma unroll
-        for (int s = 0; s < STEPS; ++s) {
-            const int ks = s >> 1;
-            const bf16x8 av = __builtin_bit_cast(bf16x8, af[s % VQS_PF]);
-            const bf16x8 bh = __builtin_bit_cast(bf16x8, xh[ks]);
-            // accumulators strictly alternate over the 3 MFMAs of a k-step (k-step parity picks who starts)
-            if ((s & 1) == 0) {        // c_hi: times x_hi and x_mid
-                const bf16x8 bm = __builtin_bit_cast(bf16x8, xm[ks]);
-                if ((ks & 1) == 0) {
-                    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bh, acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bm, acc1, 0, 0, 0);
-                } else {
-                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bh, acc1, 0, 0, 0);
-                    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bm, acc0, 0, 0, 0);
-                }
-            } else {                   // c_lo: times x_hi
-                if ((ks & 1) == 0) acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bh, acc0, 0, 0, 0);
-                else               acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bh, acc1, 0, 0, 0);
-            }
-            if (s + VQS_PF < STEPS) af[s % VQS_PF] = ap[(s + VQS_PF) * 64];
-#ifdef VQS_PIN
-            __builtin_amdgcn_sched_barrier(0);
-#endif
-#pragma unroll
-            for (int b = 0; b < NB; ++b) {
-                if (s == b * HALF) {
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int i = 0; i < BS; ++i)
-                        if (b * BS + i < PMAX) stg[i] = *(const f32x4 *)(gsrc + (size_t)(b * BS + i) * PSTRIDE);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                if (s == b * HALF + LAG) {
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int i = 0; i < BS; ++i)
-                        if (b * BS + i < npieces) *(f32x4 *)(ldst + (b * BS + i) * PSTRIDE) = stg[i];
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc0[r] += acc1[r];
-        top2_tile(acc0, m1, m2, tix, ct);
-    }
-
-    // ---- merge the half-waves, certify, emit ----
-    int code;
-    bool flagged;
-    {
-        const int e = (int)(__float_as_uint(m1) & 15u);
-        const int c_own = tix * 32 + 8 * (e >> 2) + 4 * half + (e & 3);
-        const float o1 = __shfl_xor(m1, 32, 64);
-        const float o2 = __shfl_xor(m2, 32, 64);
-        const int oc = __shfl_xor(c_own, 32, 64);
-        const bool take = o1 > m1;
-        const float b1 = take ? o1 : m1;
-        const float lo1 = take ? m1 : o1;
-        const float b2 = fmaxf(lo1, fmaxf(m2, o2));
-        code = take ? oc : c_own;
-        const float thr = eps + 8e-6f * fabsf(b1);
-        flagged = !((b1 - b2) > thr) || code >= a.C;
-        if (code >= a.C) code = 0;
-        if (row_ok && half == 0) {
-            a.idx_out[row] = (int64_t)code;
-            if (a.dbg) {
-                float *d = a.dbg + row * 4;
-                d[0] = b1; d[1] = b2; d[2] = thr; d[3] = flagged ? 1.f : 0.f;
-            }
-        }
-        const bool f = flagged && row_ok && half == 0;
-        const unsigned long long bal = __ballot(f);
-        if (bal) {
-            int base = 0;
-            if (lane == 0) base = atomicAdd(a.flag_count, (int)__popcll(bal));
-            base = __builtin_amdgcn_readfirstlane(base);
-            if (f) {
-                const int slot = base + (int)__popcll(bal & ((1ull << lane) - 1ull));
-                a.flag_rows[slot] = (int)row;
-                a.flag_keys[slot] = ~0ull;
-            }
-        }
-    }
-
-    // ---- q rows (fp32, from embed) and squared error: whole rows per wave, 8 in flight; x is re-read (coalesced) ----
-    if (a.q_out || a.sqerr_partial || a.resid_out) {
-        const int counted = (row_ok && !flagged && (!a.row_mask || a.row_mask[row] != 0)) ? 1 : 0;
-        const bool want_sq = a.sqerr_partial != nullptr;
-        const bool want_x = want_sq || a.resid_out != nullptr;
-        double ds = 0.0;
-#pragma unroll
-        for (int r0 = 0; r0 < 32; r0 += 8) {
-            f32x4 g[8], xv[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int c = __builtin_amdgcn_readlane(code, r0 + u);
-                const int64_t rr = wrow0 + r0 + u;
-                if (lane * 4 < DT) {
-                    g[u] = *(const f32x4 *)(a.embed + (size_t)c * DT + lane * 4);
-                    if (want_x) xv[u] = *(const f32x4 *)((const float *)a.x + (rr < a.N ? rr : a.N - 1) * a.ldx + lane * 4);
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int64_t rr = wrow0 + r0 + u;
-                const int cnt = __builtin_amdgcn_readlane(counted, r0 + u);
-                if (lane * 4 < DT) {
-                    if (a.q_out && rr < a.N) *(f32x4 *)((float *)a.q_out + rr * a.ldq + lane * 4) = g[u];
-                    if (a.resid_out && rr < a.N) *(f32x4 *)((float *)a.resid_out + rr * a.ldr + lane * 4) = xv[u] - g[u];
-                    if (want_sq && cnt) {
-                        const float d0 = g[u].x - xv[u].x, d1 = g[u].y - xv[u].y, d2 = g[u].z - xv[u].z, d3 = g[u].w - xv[u].w;
-                        ds += (double)(((d0 * d0 + d1 * d1) + d2 * d2) + d3 * d3);
-                    }
-                }
-            }
-        }
-        if (a.sqerr_partial) {
-#pragma unroll
-            for (int o = 32; o >= 1; o >>= 1) ds += __shfl_xor(ds, o, 64);
-            __syncthreads();
-            double *red = (double *)smem;
-            if (lane == 0) red[wave] = ds;
-            __syncthreads();
-            if (tid == 0) {
-                double t = 0.0;
-#pragma unroll
-                for (int w = 0; w < W; ++w) t += red[w];
-                a.sqerr_partial[blockIdx.x] = t;
-            }
-        }
-    }
-}
-
 static inline int64_t screen_rows_per_block(int x_dtype) { return x_dtype == VQHIP_BF16 ? VQ_SCREEN_ROWS : VQ_SCREEN_F32_ROWS; }
 
 extern "C" int64_t vqhip_screen_blocks(int64_t N, int x_dtype)
@@ -2053,14 +1201,6 @@ extern "C" int vqhip_screen_supported(int64_t N, int D, int C)
     return (D == 32 || D == 64 || D == 128 || D == 256 || D == 512) && N > 0 && N < ((int64_t)1 << 31) - 512 && C >= 2;
 }
 
-// VQHIP_SCREEN_BF16X2=1 selects the two-pass bf16 hi/lo kernel for bf16 rows (A/B runs against vq_screen16_kernel)
-static bool screen_bf16x2()
-{
-    static int v = -1;
-    if (v < 0) { const char *e = getenv("VQHIP_SCREEN_BF16X2"); v = (e && e[0] == '1') ? 1 : 0; }
-    return v == 1;
-}
-
 static bool screen_f32_two_part()     // VQHIP_SCREEN_F32_2PART=1: fp32 rows through the two-operand-set kernel (A/B runs)
 {
     static int v = -1;
@@ -2072,69 +1212,56 @@ template <int DT, int METRIC>
 static int launch_screen(const ScreenArgs &a, int x_dtype, hipStream_t st)
 {
     const unsigned blocks = (unsigned)vqhip_screen_blocks(a.N, x_dtype);
-    if (!screen_bf16x2() || DT > 256) {
-        // fp16 single-codebook-part kernels: bf16 rows with D <= 256 keep two row blocks per wave, everything else one
-        if (x_dtype == VQHIP_BF16) {
-            static int one_rb = -1;      // VQHIP_SCREEN_1RB=1: bf16 rows through the one-row-block kernel (4 waves per SIMD), A/B
-            if (one_rb < 0) { const char *e = getenv("VQHIP_SCREEN_1RB"); one_rb = (e && e[0] == '1') ? 1 : 0; }
-            if constexpr (DT == 256) {   // persistent, software-pipelined form (vq_screen_p.hip) where it applies
-                if (vq_screenp_eligible(a, x_dtype, DT)) return vq_screenp_launch(a, METRIC, st);
+    // fp16 single-codebook-part kernels: bf16 rows with D <= 256 keep two row blocks per wave, everything else one
+    if (x_dtype == VQHIP_BF16) {
+        static int one_rb = -1;      // VQHIP_SCREEN_1RB=1: bf16 rows through the one-row-block kernel (4 waves per SIMD), A/B
+        if (one_rb < 0) { const char *e = getenv("VQHIP_SCREEN_1RB"); one_rb = (e && e[0] == '1') ? 1 : 0; }
+        if constexpr (DT == 256) {   // persistent, software-pipelined form (vq_screen_p.hip) where it applies
+            if (vq_screenp_eligible(a, x_dtype, DT)) return vq_screenp_launch(a, METRIC, st);
+        }
+        if constexpr (DT <= 256) {
+            if (one_rb) {
+                static VqAttrOnce once1;
+                constexpr int SMEM1 = Screen16F32Cfg<DT>::SMEM;
+                if (int rc = vq_set_max_smem(once1, (const void *)vq_screen16_1rb_kernel<DT, METRIC, true, 1>, SMEM1, "vq_screen16_1rb_kernel")) return rc;
+                hipLaunchKernelGGL((vq_screen16_1rb_kernel<DT, METRIC, true, 1>), dim3(blocks), dim3(VQS_F32_WAVES * 64), SMEM1, st, a);
+                return vq_launch_status("vq_screen16_1rb_kernel (bf16)");
             }
-            if constexpr (DT <= 256) {
-                if (one_rb) {
-                    static VqAttrOnce once1;
-                    constexpr int SMEM1 = Screen16F32Cfg<DT>::SMEM;
-                    if (int rc = vq_set_max_smem(once1, (const void *)vq_screen16_1rb_kernel<DT, METRIC, true, 1>, SMEM1, "vq_screen16_1rb_kernel")) return rc;
-                    hipLaunchKernelGGL((vq_screen16_1rb_kernel<DT, METRIC, true, 1>), dim3(blocks), dim3(VQS_F32_WAVES * 64), SMEM1, st, a);
-                    return vq_launch_status("vq_screen16_1rb_kernel (bf16)");
-                }
-                static VqAttrOnce once;
+            static VqAttrOnce once;
 #ifndef VQS16_LDS_PAD
 #define VQS16_LDS_PAD 0      // A/B: extra dynamic LDS (> 8 KiB at D = 256: one workgroup per CU, i.e. one wave per SIMD)
 #endif
-                constexpr int SMEM16 = Screen16Cfg<DT>::SMEM + VQS16_LDS_PAD;
-                if (int rc = vq_set_max_smem(once, (const void *)vq_screen16_kernel<DT, METRIC>, SMEM16, "vq_screen16_kernel")) return rc;
-                hipLaunchKernelGGL((vq_screen16_kernel<DT, METRIC>), dim3(blocks), dim3(VQS_WAVES * 64), SMEM16, st, a);
-            } else {
-                static VqAttrOnce once;
-                constexpr int SMEM16 = Screen16F32Cfg<DT>::SMEM;
-                if (int rc = vq_set_max_smem(once, (const void *)vq_screen16_1rb_kernel<DT, METRIC, true, 1>, SMEM16, "vq_screen16_1rb_kernel")) return rc;
-                hipLaunchKernelGGL((vq_screen16_1rb_kernel<DT, METRIC, true, 1>), dim3(blocks), dim3(VQS_F32_WAVES * 64), SMEM16, st, a);
-            }
+            constexpr int SMEM16 = Screen16Cfg<DT>::SMEM + VQS16_LDS_PAD;
+            if (int rc = vq_set_max_smem(once, (const void *)vq_screen16_kernel<DT, METRIC>, SMEM16, "vq_screen16_kernel")) return rc;
+            hipLaunchKernelGGL((vq_screen16_kernel<DT, METRIC>), dim3(blocks), dim3(VQS_WAVES * 64), SMEM16, st, a);
         } else {
-            // fp32 rows, D <= 256: one fp16 operand set, two row blocks per wave (VQHIP_SCREEN_F32_2PART=1: the two-set kernel, A/B)
-            const int two_part = screen_f32_two_part() ? 1 : 0;
-            if constexpr (DT <= 256) {
-                if (!two_part) {
-                    static VqAttrOnce once;
-                    constexpr int SMEM16 = Screen16Cfg<DT>::SMEM;
-                    // (NPART = 2 fits the registers for D <= 128 and halves the uncertified rows of fp32 inputs, but its second MFMA per
-                    //  k-step costs more than the exact passes it saves: cfg 5 26.0 vs 23.5 ms -- measured, not adopted)
-                    constexpr int NP = 1;
-                    if (int rc = vq_set_max_smem(once, (const void *)vq_screen16_kernel<DT, METRIC, true, NP>, SMEM16, "vq_screen16_kernel (fp32 rows)")) return rc;
-                    hipLaunchKernelGGL((vq_screen16_kernel<DT, METRIC, true, NP>), dim3(blocks), dim3(VQS_WAVES * 64), SMEM16, st, a);
-                    return vq_launch_status("vq_screen16_kernel (fp32 rows)");
-                }
-            }
             static VqAttrOnce once;
             constexpr int SMEM16 = Screen16F32Cfg<DT>::SMEM;
-            constexpr int NPART = DT <= 256 ? 2 : 1;
-            if (int rc = vq_set_max_smem(once, (const void *)vq_screen16_1rb_kernel<DT, METRIC, false, NPART>, SMEM16, "vq_screen16_1rb_kernel")) return rc;
-            hipLaunchKernelGGL((vq_screen16_1rb_kernel<DT, METRIC, false, NPART>), dim3(blocks), dim3(VQS_F32_WAVES * 64), SMEM16, st, a);
+            if (int rc = vq_set_max_smem(once, (const void *)vq_screen16_1rb_kernel<DT, METRIC, true, 1>, SMEM16, "vq_screen16_1rb_kernel")) return rc;
+            hipLaunchKernelGGL((vq_screen16_1rb_kernel<DT, METRIC, true, 1>), dim3(blocks), dim3(VQS_F32_WAVES * 64), SMEM16, st, a);
         }
-        return vq_launch_status("vq_screen16 kernels");
+    } else {
+        // fp32 rows, D <= 256: one fp16 operand set, two row blocks per wave (VQHIP_SCREEN_F32_2PART=1: the two-set kernel, A/B)
+        const int two_part = screen_f32_two_part() ? 1 : 0;
+        if constexpr (DT <= 256) {
+            if (!two_part) {
+                static VqAttrOnce once;
+                constexpr int SMEM16 = Screen16Cfg<DT>::SMEM;
+                // (NPART = 2 fits the registers for D <= 128 and halves the uncertified rows of fp32 inputs, but its second MFMA per
+                //  k-step costs more than the exact passes it saves: cfg 5 26.0 vs 23.5 ms -- measured, not adopted)
+                constexpr int NP = 1;
+                if (int rc = vq_set_max_smem(once, (const void *)vq_screen16_kernel<DT, METRIC, true, NP>, SMEM16, "vq_screen16_kernel (fp32 rows)")) return rc;
+                hipLaunchKernelGGL((vq_screen16_kernel<DT, METRIC, true, NP>), dim3(blocks), dim3(VQS_WAVES * 64), SMEM16, st, a);
+                return vq_launch_status("vq_screen16_kernel (fp32 rows)");
+            }
+        }
+        static VqAttrOnce once;
+        constexpr int SMEM16 = Screen16F32Cfg<DT>::SMEM;
+        constexpr int NPART = DT <= 256 ? 2 : 1;
+        if (int rc = vq_set_max_smem(once, (const void *)vq_screen16_1rb_kernel<DT, METRIC, false, NPART>, SMEM16, "vq_screen16_1rb_kernel")) return rc;
+        hipLaunchKernelGGL((vq_screen16_1rb_kernel<DT, METRIC, false, NPART>), dim3(blocks), dim3(VQS_F32_WAVES * 64), SMEM16, st, a);
     }
-    if constexpr (DT <= 256) {   // VQHIP_SCREEN_BF16X2=1: the two-pass bf16 hi/lo kernels (A/B runs)
-        constexpr int SMEM = 2 * (128 * DT + 1024);
-        static VqAttrOnce once_b, once_f;
-        if (int rc = vq_set_max_smem(once_b, (const void *)vq_screen_kernel<DT, METRIC>, SMEM, "vq_screen_kernel")) return rc;
-        if (int rc = vq_set_max_smem(once_f, (const void *)vq_screen_f32_kernel<DT, METRIC>, SMEM, "vq_screen_f32_kernel")) return rc;
-        if (x_dtype == VQHIP_BF16)
-            hipLaunchKernelGGL((vq_screen_kernel<DT, METRIC>), dim3(blocks), dim3(VQS_WAVES * 64), SMEM, st, a);
-        else
-            hipLaunchKernelGGL((vq_screen_f32_kernel<DT, METRIC>), dim3(blocks), dim3(VQS_F32_WAVES * 64), SMEM, st, a);
-    }
-    return vq_launch_status("vq_screen_kernel");
+    return vq_launch_status("vq_screen16 kernels");
 }
 
 template <int DT>
@@ -2162,7 +1289,7 @@ extern "C" int vqhip_screen_chain_supported(int x_dtype, int D)
 #ifdef VQS16_F32_DIRECT      // (A/B build whose fp32-row prologue has no chain step)
     return 0;
 #endif
-    return (x_dtype == VQHIP_F32 && (D == 32 || D == 64 || D == 128 || D == 256) && !screen_bf16x2() && !screen_f32_two_part()) ? 1 : 0;
+    return (x_dtype == VQHIP_F32 && (D == 32 || D == 64 || D == 128 || D == 256) && !screen_f32_two_part()) ? 1 : 0;
 }
 
 extern "C" int vqhip_assign_screened_chain(const void *x, int x_dtype, int64_t N, int D, int64_t ldx, const float *packed,
@@ -2213,13 +1340,12 @@ static int assign_screened_impl(const void *x, int x_dtype, int64_t N, int D, in
     const char *base = (const char *)packed;
     ScreenArgs a;
     a.x = x; a.N = N; a.ldx = ldx;
-    a.tiles = base + vq_packed_screen_offset(C, D);
     a.tiles16 = base + vq_packed_f16_offset(C, D);
     a.n_tiles16 = (int)vq_tiles16(C);
     a.embed_bf16 = (const unsigned short *)(base + vq_packed_bf16_offset(C, D));
     a.embed = embed;
     a.scalars = (const unsigned *)(base + vq_packed_scalars_offset(C, D));
-    a.C = C; a.n_tiles = (C + 31) / 32;
+    a.C = C;
     a.idx_out = idx_out; a.q_out = q_out; a.ldq = ldq; a.resid_out = resid_out; a.ldr = ldr;
     a.sqerr_partial = sqerr_partial; a.row_mask = row_mask;
     unsigned long long *keys = (unsigned long long *)((char *)workspace + 16 + (((size_t)N * sizeof(int) + 7) & ~(size_t)7));
@@ -2247,7 +1373,7 @@ static int assign_screened_impl(const void *x, int x_dtype, int64_t N, int D, in
         if (only < 0) { const char *e = getenv("VQHIP_SCREEN_ONLY"); only = (e && e[0] == '1') ? 1 : 0; }
         if (only) return 0;
     }
-    const int with_pairs = (screen_bf16x2() && D <= 256) ? 0 : 1;   // the fp16 screening kernels also build the pair list
+    const int with_pairs = 1;                                       // the screening kernels build the pair list as well
     // a chained stage's rows were materialised by its screening kernel: the exact passes read them there
     const void *xl = (chain && chain->prev_idx) ? (const void *)chain->x_out : x;
     const int64_t ldl = (chain && chain->prev_idx) ? chain->ldxo : ldx;

@@ -9,13 +9,6 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 
-#ifndef VQS_PF
-#define VQS_PF 4             // depth of the A-fragment ring (LDS -> VGPR prefetch distance in steps of 2 MFMAs)
-#define VQS_PIN 1
-#endif
-#ifndef VQS_OUT1
-#define VQS_OUT2 1           // output phase ordering (see below); -DVQS_OUT1 selects the first version for A/B runs
-#endif
 #ifndef VQS_WAVES
 #define VQS_WAVES 4          // waves per workgroup (2 workgroups of 4 or 1 of 8 per CU: 2 waves per SIMD either way)
 #endif
@@ -23,17 +16,15 @@ typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 #define VQ_SCREEN_ROWS (VQS_WAVES * 64)   // rows per workgroup: waves x 2 row blocks x 32
 
 struct ScreenArgs {
-    const void *x;                     // rows, bf16 (vq_screen_kernel) or fp32 (vq_screen_f32_kernel)
+    const void *x;                     // rows, bf16 or fp32
     int64_t N;
     int64_t ldx;
-    const char *tiles;                 // bf16 hi/lo screening tiles inside the packed codebook
     const char *tiles16;               // fp16 screening tiles (vq_screen16_kernel)
     int n_tiles16;                     // fp16 tiles incl. padding tiles (multiple of VQ_F16_TILE_GROUP)
     const unsigned short *embed_bf16;  // bf16 codebook copy inside the packed codebook
     const float *embed;                // fp32 codebook (q rows of fp32 I/O)
     const unsigned *scalars;           // [0] = float bits of max ||c||^2, [1] = float bits of max ||c - c_f16||, [2] = sc
     int C;
-    int n_tiles;
     int64_t *idx_out;
     void *q_out;                       // nullable, x's dtype
     int64_t ldq;

@@ -132,12 +132,12 @@ extern "C" size_t vqhip_packed_bytes(int C, int D)
 
 __global__ void __launch_bounds__(256) vq_pack_kernel(const float *__restrict__ embed, int C, int D, int DT,
                                                       float *__restrict__ packed, unsigned short *__restrict__ ebf,
-                                                      char *__restrict__ screen, unsigned *__restrict__ scalars, int legacy_screen)
+                                                      unsigned *__restrict__ scalars)
 {
     __shared__ float y2sh[32];
     const int t = blockIdx.x;
     // blockIdx.y splits a tile's work over two workgroups (a 1024-code codebook is only 32 tiles): y = 1 writes the bf16 copy,
-    // y = 0 the fp32 tile, the norms and (legacy_screen: VQHIP_SCREEN_BF16X2=1 A/B runs only) the bf16 hi/lo screening tile
+    // y = 0 the fp32 tile and the norms
     if (blockIdx.y == 1) {
     if ((D & 3) == 0) {   // RNE-rounded bf16 copy of this tile's 32 code rows, 4 elements per store
         for (int p = threadIdx.x; p < 8 * D; p += 256) {
@@ -184,43 +184,9 @@ __global__ void __launch_bounds__(256) vq_pack_kernel(const float *__restrict__ 
         }
         out[32 * DT + i] = v;
     }
-    // ---- screening tile (vq_screen.hip): c = c_hi + c_lo (+ <= 2^-16 |c|), both bf16, in the A-operand order of
-    //      v_mfma_f32_32x32x16_bf16: 16 bytes per lane and (k-step, part); lane l = code (l & 31), k-slot 8 * (l >> 5) + e.
-    //      Then 32 floats -||c||^2 / 2 (the accumulator's initial value; -3e38 for padding codes).
-    unsigned short *st = (unsigned short *)(screen + (size_t)t * vq_tile_bytes(DT));
-    for (int p = threadIdx.x; legacy_screen && p < 4 * DT; p += 256) {   // one (k-step, lane) per iteration: 8 features -> hi and lo fragment
-        const int l = p & 63;
-        const int ks = p >> 6;
-        const int code = t * 32 + (l & 31);
-        const int k0 = ks * 16 + 8 * (l >> 5);
-        float v[8];
-        if (code < C && k0 + 8 <= D && (D & 3) == 0) {
-            const f32x4 a0 = *(const f32x4 *)(embed + (size_t)code * D + k0), a1 = *(const f32x4 *)(embed + (size_t)code * D + k0 + 4);
-            v[0] = a0.x; v[1] = a0.y; v[2] = a0.z; v[3] = a0.w; v[4] = a1.x; v[5] = a1.y; v[6] = a1.z; v[7] = a1.w;
-        } else {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = (code < C && k0 + e < D) ? embed[(size_t)code * D + k0 + e] : 0.f;
-        }
-        unsigned hw[4], lw[4];
-#pragma unroll
-        for (int e = 0; e < 8; e += 2) {
-            const unsigned short h0 = f32_to_bf16_rne(v[e]), h1 = f32_to_bf16_rne(v[e + 1]);
-            const unsigned short l0 = f32_to_bf16_rne(v[e] - bf16_bits_to_f32(h0));       // v - h is exact in fp32
-            const unsigned short l1 = f32_to_bf16_rne(v[e + 1] - bf16_bits_to_f32(h1));
-            hw[e >> 1] = (unsigned)h0 | ((unsigned)h1 << 16);
-            lw[e >> 1] = (unsigned)l0 | ((unsigned)l1 << 16);
-        }
-        *(uint4 *)(st + ((size_t)(ks * 2 + 0) * 64 + l) * 8) = make_uint4(hw[0], hw[1], hw[2], hw[3]);
-        *(uint4 *)(st + ((size_t)(ks * 2 + 1) * 64 + l) * 8) = make_uint4(lw[0], lw[1], lw[2], lw[3]);
-    }
     __syncthreads();
-    {
-        float *nh = (float *)((char *)st + (size_t)128 * DT);
-        const int i = threadIdx.x;
-        const bool real = (i < 32) && (t * 32 + i < C);
-        nh[i] = (i < 32) ? (real ? -0.5f * y2sh[i] : -3.0e38f) : 0.f;
-        if (real) atomicMax(scalars, __float_as_uint(y2sh[i]));   // non-negative floats order like their bit patterns
-    }
+    if (threadIdx.x < 32 && t * 32 + (int)threadIdx.x < C)
+        atomicMax(scalars, __float_as_uint(y2sh[threadIdx.x]));   // max ||c||^2: non-negative floats order like their bit patterns
 }
 
 // Second pack phase (needs max ||c||^2 of the first): fp16 A-operand tiles of the single-pass screening kernel
@@ -300,10 +266,8 @@ extern "C" int vqhip_pack_codebook(const float *embed, int C, int D, float *pack
     unsigned *scalars = (unsigned *)(base + vq_packed_scalars_offset(C, D));
     hipError_t e = hipMemsetAsync(scalars, 0, VQ_PACKED_SCALARS_BYTES, (hipStream_t)stream);
     if (e != hipSuccess) VQ_FAIL((int)e, "pack_codebook: hipMemsetAsync: %s", hipGetErrorString(e));
-    static int legacy = -1;      // the bf16 hi/lo tiles are only read by the VQHIP_SCREEN_BF16X2=1 kernels
-    if (legacy < 0) { const char *ev = getenv("VQHIP_SCREEN_BF16X2"); legacy = (ev && ev[0] == '1') ? 1 : 0; }
     hipLaunchKernelGGL(vq_pack_kernel, dim3(tiles, 2), dim3(256), 0, (hipStream_t)stream, embed, C, D, DT, packed,
-                       (unsigned short *)(base + packed_bf16_offset(C, D)), base + vq_packed_screen_offset(C, D), scalars, legacy);
+                       (unsigned short *)(base + packed_bf16_offset(C, D)), scalars);
     if (int rc = launch_status("vq_pack_kernel")) return rc;
     hipLaunchKernelGGL(vq_pack16_kernel, dim3((unsigned)vq_tiles16(C)), dim3(256), 0, (hipStream_t)stream, embed, C, D, DT, tiles,
                        (const float *)packed, base + vq_packed_f16_offset(C, D), scalars);

@@ -66,8 +66,6 @@ static inline int vq_pick_dt(int D)
 //   [0)                     fp32 A-operand tiles of the exact kernel: tiles * (128*DT + 1024)
 //   [+4096)                 tail pad (the staged tile copy over-reads <= 3 KiB)
 //   [bf16_offset)           codebook rounded to bf16, [C, D] row-major (q / loss of bf16 I/O), 16-byte padded
-//   [screen_offset)         bf16 hi/lo split A-operand tiles of the fp32-row screening kernel: tiles * (128*DT + 1024)
-//   [+8192)                 tail pad (8 waves x 1 KiB over-read at most)
 //   [scalars_offset)        64 bytes: [0] float bits of max_c ||c||^2, [1] float bits of max_c ||c - c_f16|| (x 1.01),
 //                           [2] int sc: the fp16 tiles hold c * 2^sc, rest reserved
 //   [f16_offset)            fp16 A-operand tiles of the single-pass screening kernel (vq_screen16_kernel):
@@ -87,14 +85,9 @@ static inline size_t vq_packed_bf16_offset(int C, int D)
     const size_t tiles = ((size_t)C + 31) / 32;
     return tiles * vq_tile_bytes(vq_pick_dt(D)) + 4096;
 }
-static inline size_t vq_packed_screen_offset(int C, int D)
-{
-    return vq_packed_bf16_offset(C, D) + (((size_t)C * D * 2 + 15) & ~(size_t)15);
-}
 static inline size_t vq_packed_scalars_offset(int C, int D)
 {
-    const size_t tiles = ((size_t)C + 31) / 32;
-    return vq_packed_screen_offset(C, D) + tiles * vq_tile_bytes(vq_pick_dt(D)) + 8192;
+    return vq_packed_bf16_offset(C, D) + (((size_t)C * D * 2 + 15) & ~(size_t)15) + 8192;   // (+ pad: row-cooperative over-reads)
 }
 static inline size_t vq_packed_f16_offset(int C, int D) { return vq_packed_scalars_offset(C, D) + VQ_PACKED_SCALARS_BYTES; }
 static inline size_t vq_packed_total_bytes(int C, int D)
