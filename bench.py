@@ -273,6 +273,13 @@ def other_workload(args, world, rank, dev):
     screened = _lib.screening_enabled()
     peak = PEAK_BF16_MFMA_TFLOPS if screened else PEAK_FP32_MFMA_TFLOPS
     ach = flops * args.steps / dt / 1e12
+    traffic = traffic_src = None
+    try:        # HBM bytes of one step from the committed rocprofv3 PMC passes of this workload (tools/collect_profile.py), not re-measured here
+        tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get("step_traffic", {}).get(args.workload)
+        if tj and screened:
+            traffic, traffic_src = tj["bytes_per_step"], tj.get("source")
+    except Exception:
+        pass
     print(json.dumps({"metric": "vectors quantized/sec", "value": n * args.steps / dt, "unit": "vectors/s", "n_gpus": world,
                       "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
                       "scaling": "strong" if strong else "weak", "vs_baseline": None,
@@ -287,7 +294,7 @@ def other_workload(args, world, rank, dev):
                                  "collective_bytes_per_rank_and_step": getattr(mod, "last_comm", None) or None,
                                  "first_forward_ms": first * 1e3, "uncertified_rows_per_search": per_stage},
                       "roofline": {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
-                                   "traffic": None, "achieved_vs_fp32_mfma_peak": ach / PEAK_FP32_MFMA_TFLOPS,
+                                   "traffic": traffic, "traffic_source": traffic_src, "achieved_vs_fp32_mfma_peak": ach / PEAK_FP32_MFMA_TFLOPS,
                                    "note": "whole step (all kernels) PER GPU, not one kernel; algorithmic flops (2*C*D per vector and stage); "
                                            "peak = dense f16 MFMA when the search runs screened (VQHIP_SCREEN != 0), fp32 MFMA otherwise"}}), flush=True)
 

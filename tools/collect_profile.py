@@ -26,13 +26,14 @@ def run(cmd, **kw):
 
 def main():
     tag = sys.argv[1]
-    bargs = sys.argv[2:] or ["--steps", "5", "--warmup", "2", "--no-cpu-baseline", "--no-adversarial"]
+    bargs = sys.argv[2:] or ["--steps", "5", "--warmup", "2", "--windows", "1", "--no-grad-step", "--no-cpu-baseline", "--no-adversarial"]
     out = os.path.join(ROOT, "gpurun_out", tag)
     os.makedirs(out, exist_ok=True)
     bench = [sys.executable, os.path.join(ROOT, "bench.py")] + bargs
     env = dict(os.environ, TMPDIR="/tmp")
 
-    p = run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline"], env=env, cwd=ROOT)
+    wl = ["--workload", bargs[bargs.index("--workload") + 1]] if "--workload" in bargs else []
+    p = run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", *wl], env=env, cwd=ROOT)
     line = [l for l in p.stdout.splitlines() if l.startswith("{")]
     open(os.path.join(out, "bench.json"), "w").write((line[-1] if line else p.stdout[-2000:]) + "\n")
 
@@ -64,6 +65,40 @@ def main():
             vals = list(per.values())
             summary.setdefault(name, {})[ctr] = {"launches": len(vals), "mean": sum(vals) / len(vals)}
     json.dump(summary, open(os.path.join(out, "pmc_summary.json"), "w"), indent=1)
+    # HBM / fabric bytes of ONE STEP, all vq_* kernels together, by DIFFERENCE of two runs that differ only in the number of timed
+    # steps (so first-forward work -- k-means, packing -- cancels).  FETCH_SIZE / WRITE_SIZE are reported in KiB; FETCH_SIZE is
+    # doubled (gfx950 counts the 128-byte requests of wide coalesced reads as 64 bytes: MI355X_MICROARCH.md "HBM", calibration in
+    # profiles/traffic.json).
+    def with_steps(n):
+        b = [a for a in bargs]
+        for flag, val in (("--steps", str(n)), ("--windows", "1")):
+            if flag in b:
+                b[b.index(flag) + 1] = val
+            else:
+                b += [flag, val]
+        return b
+
+    def total_kib(ctr, n):
+        d = os.path.join(out, f"traffic_{ctr}_{n}")
+        run(["rocprofv3", "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", d, "-o", "p", "--",
+             sys.executable, os.path.join(ROOT, "bench.py")] + with_steps(n), env=env, cwd="/tmp")
+        f = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+        tot = 0.0
+        for row in csv.DictReader(open(f[0])) if f else []:
+            if row["Kernel_Name"].replace("void ", "").startswith("vq_") and row["Counter_Name"] == ctr:
+                tot += float(row["Counter_Value"])
+        shutil.rmtree(d, ignore_errors=True)
+        return tot
+
+    s_lo, s_hi = 4, 14
+    fetch = (total_kib("FETCH_SIZE", s_hi) - total_kib("FETCH_SIZE", s_lo)) / (s_hi - s_lo)
+    write = (total_kib("WRITE_SIZE", s_hi) - total_kib("WRITE_SIZE", s_lo)) / (s_hi - s_lo)
+    entry = {"fetch_bytes_per_step": 2.0 * 1024.0 * fetch, "write_bytes_per_step": 1024.0 * write,
+             "bytes_per_step": 2.0 * 1024.0 * fetch + 1024.0 * write, "bench_args": bargs,
+             "method": f"all vq_* kernels; (run with {s_hi} timed steps - run with {s_lo}) / {s_hi - s_lo}; rocprofv3 --kernel-trace --pmc "
+                       "FETCH_SIZE / WRITE_SIZE in separate passes; KiB -> bytes; FETCH x 2"}
+    json.dump(entry, open(os.path.join(out, "traffic_step.json"), "w"), indent=1)
+    print(json.dumps(entry))
     for sub in ["trace"] + [f"pmc{i}" for i in range(len(PMC_PASSES))]:
         shutil.rmtree(os.path.join(out, sub), ignore_errors=True)
     print(open(os.path.join(out, "bench.json")).read())

@@ -138,6 +138,18 @@ __global__ void __launch_bounds__(VQS_WAVES * 64, 8 / VQS_WAVES) vq_screen16_ker
 #endif
         for (int i = 0; i < VQS16_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
 #endif
+#ifdef VQS16_STAGGER_CU
+    // A/B: the workgroups of the first round start spread over VQS16_STAGGER_CU x 9 us (those of one CU together), and every later
+    // round inherits the spread: the HBM-bound row loads / output phases of different CUs then no longer coincide
+    if (blockIdx.x < 512) {
+#ifdef VQS16_STAGGER_ALL
+        const int n_sl = (((int)blockIdx.x & 511) * VQS16_STAGGER_CU) >> 3;
+#else
+        const int n_sl = (((int)blockIdx.x & 255) * VQS16_STAGGER_CU) >> 2;
+#endif
+        for (int i = 0; i < n_sl; ++i) __builtin_amdgcn_s_sleep(4);
+    }
+#endif
     VQ_PHASE(0);
 
     // ---- first buffer: wave w copies the 1-KiB pieces w, w + WAVES, ... ----
@@ -430,6 +442,9 @@ __global__ void __launch_bounds__(VQS_WAVES * 64, 8 / VQS_WAVES) vq_screen16_ker
     float m3[2] = {-__builtin_inff(), -__builtin_inff()};
     int tix[2] = {0, 0}, tix2[2] = {0, 0};
     VQ_PHASE(1);
+#ifdef VQS16_PRIO
+    __builtin_amdgcn_s_setprio(VQS16_PRIO);      // A/B: the sweeping wave wins the issue arbitration against a workgroup in a memory phase
+#endif
 
 #ifdef VQS16_NO_SWEEP      // A/B: prologue and output phases only
     const int nst = 0;
@@ -586,6 +601,9 @@ __global__ void __launch_bounds__(VQS_WAVES * 64, 8 / VQS_WAVES) vq_screen16_ker
     }
 
     VQ_PHASE(2);   // sweep done
+#ifdef VQS16_PRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
     // ---- merge the half-waves (each holds the top 3 of its 16 of a tile's 32 codes), classify, emit ----
     //   certified:  best - second > thr                      -> final here
     //   pair:       best - third  > thr (second is too close) -> vq_pair_kernel decides between the two codes exactly
@@ -638,10 +656,12 @@ __global__ void __launch_bounds__(VQS_WAVES * 64, 8 / VQS_WAVES) vq_screen16_ker
     const unsigned long long balp0 = __ballot(cls[0] == 2), balp1 = __ballot(cls[1] == 2);
     const int n_open = (int)(__popcll(balo0) + __popcll(balo1)), n_pair = (int)(__popcll(balp0) + __popcll(balp1));
     int base_o = 0, base_p = 0;
+#ifndef VQS16_NO_ATOMIC     // A/B: no list atomics (every wave writes its entries to the front of the lists: wrong lists, timing only)
     if (lane == 0) {
         if (n_open) base_o = atomicAdd(a.flag_count, n_open);
         if (n_pair) base_p = atomicAdd(a.flag_count + 1, n_pair);
     }
+#endif
 
     VQ_PHASE(3);   // idx + list written
     // ---- outputs: whole rows per wave instruction (lane l moves elements 4 l .. 4 l + 3), RU rows in flight; x is re-read
