@@ -2,6 +2,5 @@
 for v in "" "$@"; do
   if [ -n "$v" ]; then export VQHIP_SO=$PWD/tools/variants/libvqhip_$v.so; else unset VQHIP_SO; fi
   echo "== variant '$v'"; python tools/time_assign.py 2>&1 | tail -2
-  if [ -n "$PERSIST_AB" ] && [ -n "$v" ]; then echo "   (VQHIP_SCREEN_PERSIST=0)"; VQHIP_SCREEN_PERSIST=0 python tools/time_assign.py 2>&1 | tail -2; fi
   if [ -n "$CHECK" ] && [ -n "$v" ]; then python tools/screen_check.py --quick 2>&1 | grep -c "idx_equal=True (bad 0) q_equal=True"; python tools/screen_check.py --quick 2>&1 | grep -v "idx_equal=True (bad 0) q_equal=True" | tail -3; fi
 done

@@ -17,7 +17,7 @@
 //                           sweep (every A fragment read from LDS once for both row blocks, the previous tile's top-3 fold between
 //                           this tile's MFMAs); residual chain in the prologue (vqhip_assign_screened_chain)
 //   vq_screen16_1rb_kernel  one row block per wave: D = 512, and the two-operand-set fp32 variant (VQHIP_SCREEN_F32_2PART=1)
-//   (vq_screen_p.hip: the persistent ping-pong form of the first one, opt-in.)
+//   (vq_screen_c.hip: a persistent form of the first one with a cyclic tile stream, opt-in through VQHIP_SCREEN_PERSIST=2.)
 // Round 1's two-pass bf16 hi/lo kernels and round 2's flat / skewed sweeps are in the git history (removed in round 3).
 //
 // Error bound, in units of s = ||x||^2 + ||c||^2 - 2 x.c (u = 2^-24, D features, X = ||x||, Y = max_c ||c||); the kernels state their
@@ -126,30 +126,6 @@ __global__ void __launch_bounds__(VQS_WAVES * 64, 8 / VQS_WAVES) vq_screen16_ker
     const int j = lane & 31;
     const int half = lane >> 5;
     const int64_t wrow0 = (int64_t)blockIdx.x * VQ_SCREEN_ROWS + wave * 64;
-#ifdef VQS16_STAGGER
-    // A/B: the second workgroup of every CU (blocks 256 .. 511 of the first round) starts late, so that the two workgroups of a CU
-    // are not in their memory phases (row load, outputs) at the same time for the rest of the kernel
-#ifdef VQS16_STAGGER_LDSBASE
-    // the workgroup whose LDS allocation does not start at 0 is the second one on its CU (HW_REG_LDS_ALLOC, LDS_BASE field)
-    const bool second_wg = (__builtin_amdgcn_s_getreg((11 << 11) | (0 << 6) | 6) & 0xfff) != 0;
-    if (second_wg && blockIdx.x < 512)
-#else
-    if (blockIdx.x >= 256 && blockIdx.x < 512)
-#endif
-        for (int i = 0; i < VQS16_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
-#endif
-#ifdef VQS16_STAGGER_CU
-    // A/B: the workgroups of the first round start spread over VQS16_STAGGER_CU x 9 us (those of one CU together), and every later
-    // round inherits the spread: the HBM-bound row loads / output phases of different CUs then no longer coincide
-    if (blockIdx.x < 512) {
-#ifdef VQS16_STAGGER_ALL
-        const int n_sl = (((int)blockIdx.x & 511) * VQS16_STAGGER_CU) >> 3;
-#else
-        const int n_sl = (((int)blockIdx.x & 255) * VQS16_STAGGER_CU) >> 2;
-#endif
-        for (int i = 0; i < n_sl; ++i) __builtin_amdgcn_s_sleep(4);
-    }
-#endif
     VQ_PHASE(0);
 
     // ---- first buffer: wave w copies the 1-KiB pieces w, w + WAVES, ... ----
@@ -442,9 +418,6 @@ __global__ void __launch_bounds__(VQS_WAVES * 64, 8 / VQS_WAVES) vq_screen16_ker
     float m3[2] = {-__builtin_inff(), -__builtin_inff()};
     int tix[2] = {0, 0}, tix2[2] = {0, 0};
     VQ_PHASE(1);
-#ifdef VQS16_PRIO
-    __builtin_amdgcn_s_setprio(VQS16_PRIO);      // A/B: the sweeping wave wins the issue arbitration against a workgroup in a memory phase
-#endif
 
 #ifdef VQS16_NO_SWEEP      // A/B: prologue and output phases only
     const int nst = 0;
@@ -601,9 +574,6 @@ __global__ void __launch_bounds__(VQS_WAVES * 64, 8 / VQS_WAVES) vq_screen16_ker
     }
 
     VQ_PHASE(2);   // sweep done
-#ifdef VQS16_PRIO
-    __builtin_amdgcn_s_setprio(0);
-#endif
     // ---- merge the half-waves (each holds the top 3 of its 16 of a tile's 32 codes), classify, emit ----
     //   certified:  best - second > thr                      -> final here
     //   pair:       best - third  > thr (second is too close) -> vq_pair_kernel decides between the two codes exactly
@@ -656,12 +626,10 @@ __global__ void __launch_bounds__(VQS_WAVES * 64, 8 / VQS_WAVES) vq_screen16_ker
     const unsigned long long balp0 = __ballot(cls[0] == 2), balp1 = __ballot(cls[1] == 2);
     const int n_open = (int)(__popcll(balo0) + __popcll(balo1)), n_pair = (int)(__popcll(balp0) + __popcll(balp1));
     int base_o = 0, base_p = 0;
-#ifndef VQS16_NO_ATOMIC     // A/B: no list atomics (every wave writes its entries to the front of the lists: wrong lists, timing only)
     if (lane == 0) {
         if (n_open) base_o = atomicAdd(a.flag_count, n_open);
         if (n_pair) base_p = atomicAdd(a.flag_count + 1, n_pair);
     }
-#endif
 
     VQ_PHASE(3);   // idx + list written
     // ---- outputs: whole rows per wave instruction (lane l moves elements 4 l .. 4 l + 3), RU rows in flight; x is re-read
@@ -1213,7 +1181,11 @@ extern "C" int64_t vqhip_screen_partials(int64_t N, int x_dtype)
 extern "C" size_t vqhip_screen_workspace_bytes(int64_t N)
 {
     // 16-byte header (count) | N ints (row list, padded to 8 bytes) | N u64 (keys of the exact pass)
-    return N <= 0 ? 0 : 16 + (((size_t)N * sizeof(int) + 7) & ~(size_t)7) + (size_t)N * sizeof(unsigned long long);
+    // | segmented staging of the persistent screening kernel: 2 VQ_SEG_MAX counters, (N + 256 VQ_SEG_MAX) u64 keys and as many int rows
+    if (N <= 0) return 0;
+    const size_t nseg = (size_t)N + 256 * (size_t)VQ_SEG_MAX;
+    return 16 + (((size_t)N * sizeof(int) + 7) & ~(size_t)7) + (size_t)N * sizeof(unsigned long long)
+         + 2 * VQ_SEG_MAX * sizeof(int) + nseg * sizeof(unsigned long long) + nseg * sizeof(int);
 }
 
 extern "C" int vqhip_screen_supported(int64_t N, int D, int C)
@@ -1236,8 +1208,8 @@ static int launch_screen(const ScreenArgs &a, int x_dtype, hipStream_t st)
     if (x_dtype == VQHIP_BF16) {
         static int one_rb = -1;      // VQHIP_SCREEN_1RB=1: bf16 rows through the one-row-block kernel (4 waves per SIMD), A/B
         if (one_rb < 0) { const char *e = getenv("VQHIP_SCREEN_1RB"); one_rb = (e && e[0] == '1') ? 1 : 0; }
-        if constexpr (DT == 256) {   // persistent, software-pipelined form (vq_screen_p.hip) where it applies
-            if (vq_screenp_eligible(a, x_dtype, DT)) return vq_screenp_launch(a, METRIC, st);
+        if constexpr (DT == 256) {   // persistent form with the cyclic tile stream (vq_screen_c.hip), opt-in
+            if (vq_screenc_eligible(a, x_dtype, DT)) return vq_screenc_launch(a, METRIC, st);
         }
         if constexpr (DT <= 256) {
             if (one_rb) {
@@ -1370,6 +1342,13 @@ static int assign_screened_impl(const void *x, int x_dtype, int64_t N, int D, in
     a.sqerr_partial = sqerr_partial; a.row_mask = row_mask;
     unsigned long long *keys = (unsigned long long *)((char *)workspace + 16 + (((size_t)N * sizeof(int) + 7) & ~(size_t)7));
     a.flag_count = count; a.flag_rows = rows; a.flag_keys = keys; a.dbg = debug_out;
+    {
+        const size_t nseg = (size_t)N + 256 * (size_t)VQ_SEG_MAX;
+        a.seg_counts = (int *)(keys + N);
+        a.seg_keys = (unsigned long long *)(a.seg_counts + 2 * VQ_SEG_MAX);
+        a.seg_rows = (int *)(a.seg_keys + nseg);
+        a.seg_cap = 0;
+    }
     a.idx_stride = chain ? chain->idx_stride : 1;
     a.prev_idx = chain ? chain->prev_idx : nullptr;
     a.prev_idx_stride = chain ? chain->prev_idx_stride : 1;

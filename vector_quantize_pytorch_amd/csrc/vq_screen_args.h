@@ -1,4 +1,4 @@
-// vq_screen_args.h -- argument block and vector types shared by the screening kernels (vq_screen.hip, vq_screen_p.hip).
+// vq_screen_args.h -- argument block and vector types shared by the screening kernels (vq_screen.hip, vq_screen_c.hip).
 #pragma once
 
 #include "vqhip_internal.h"
@@ -14,6 +14,7 @@ typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 #endif
 
 #define VQ_SCREEN_ROWS (VQS_WAVES * 64)   // rows per workgroup: waves x 2 row blocks x 32
+#define VQ_SEG_MAX 512                    // list segments of the persistent screening kernel (= its largest grid: 2 workgroups x 256 CUs)
 
 struct ScreenArgs {
     const void *x;                     // rows, bf16 or fp32
@@ -44,12 +45,18 @@ struct ScreenArgs {
     const float *prev_embed;           // [C_prev, D] fp32
     float *x_out;
     int64_t ldxo;
+    // segmented lists (vq_screenc_kernel: every workgroup appends to its own segment, no global atomics; vq_compact_lists_kernel
+    // packs the segments into flag_rows / flag_keys and writes flag_count)
+    int *seg_counts;                   // [2 * VQ_SEG_MAX]: open, pair entries per segment
+    int *seg_rows;                     // [VQ_SEG_MAX * seg_cap]
+    unsigned long long *seg_keys;      // [VQ_SEG_MAX * seg_cap]
+    int seg_cap;                       // entries per segment: the rows its workgroup handles
 #ifdef VQ_TRACE
     long long *trace;
 #endif
 };
 
 
-// persistent screening kernel (vq_screen_p.hip): 1 if it serves this launch, and the launch itself
-int vq_screenp_eligible(const ScreenArgs &a, int x_dtype, int DT);
-int vq_screenp_launch(const ScreenArgs &a, int metric_is_cosine, hipStream_t st);
+// persistent screening kernel with the cyclic tile stream (vq_screen_c.hip): 1 if it serves this launch, and the launch itself
+int vq_screenc_eligible(const ScreenArgs &a, int x_dtype, int DT);
+int vq_screenc_launch(const ScreenArgs &a, int metric_is_cosine, hipStream_t st);
