@@ -2112,15 +2112,36 @@ __device__ __forceinline__ float wave_sum(float v)
     return (r0 + r1) + (r2 + r3);
 }
 
-// Row access of the routing kernels: lane l owns the elements 4 (64 k + l) + i, k < 2, i < 4 -- four CONTIGUOUS elements per
+// Sum over the LPR lanes that share a row, the same value in each of them.  LPR = 16: one DPP row = one tensor row, four rows
+// per wave, no scalar step at all.
+template <int LPR>
+__device__ __forceinline__ float row_sum(float v)
+{
+    if (LPR == 64) return wave_sum(v);
+    auto dpp = [](float x, auto ctrl) {
+        return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), decltype(ctrl)::value, 0xf, 0xf, true));
+    };
+    v += dpp(v, std::integral_constant<int, 0xB1>{});
+    v += dpp(v, std::integral_constant<int, 0x4E>{});
+    v += dpp(v, std::integral_constant<int, 0x141>{});
+    v += dpp(v, std::integral_constant<int, 0x140>{});
+    return v;
+}
+
+// Rows per wave of the routing kernels.  One wave per row (LPR = 64) spends most of its instructions on the five row reductions
+// of a rotation-trick stage (4 DPP + 4 v_readlane + 3 adds each) for 4 elements per lane -- and half its lanes idle at D = 128.
+// With one row per 16 lanes (D <= 256: 4 .. 16 elements per lane) a reduction is 4 DPP adds for FOUR rows at once: the kernels
+// go from instruction-bound towards their HBM traffic (forward + backward of a step: cfg 3 1.5 -> 0.7 ms, cfg 5 6.1 -> 1.4 ms).
+//
+// Row access of the routing kernels: lane l owns the elements 4 (LPR k + l) + i, k < NE / 4, i < 4 -- four CONTIGUOUS elements per
 // slice (NE = 4: D <= 256, one slice; NE = 8: two), moved by one 8-byte (bf16) / 16-byte (fp32) access when the row allows it (`vec`: D % 4 == 0 and base / stride aligned
 // to 4 elements); otherwise element by element.  (The first version gave lane l the elements l + 64 k: 2-byte accesses for bf16.)
-template <bool BF16, int NE>
+template <bool BF16, int NE, int LPR = 64>
 __device__ __forceinline__ void row_load8(const void *base, int64_t off, int D, int lane, bool vec, float (&v)[NE])
 {
 #pragma unroll
     for (int k = 0; k < NE / 4; ++k) {
-        const int d0 = 4 * (64 * k + lane);
+        const int d0 = 4 * (LPR * k + lane);
         if (vec && d0 < D) {
             if (BF16) {
                 const uint2 w = *(const uint2 *)((const unsigned short *)base + off + d0);
@@ -2137,12 +2158,12 @@ __device__ __forceinline__ void row_load8(const void *base, int64_t off, int D, 
     }
 }
 
-template <bool BF16, int NE>
+template <bool BF16, int NE, int LPR = 64>
 __device__ __forceinline__ void row_store8(void *base, int64_t off, int D, int lane, bool vec, const float (&v)[NE])
 {
 #pragma unroll
     for (int k = 0; k < NE / 4; ++k) {
-        const int d0 = 4 * (64 * k + lane);
+        const int d0 = 4 * (LPR * k + lane);
         if (vec && d0 < D) {
             if (BF16) {
                 uint2 w;
@@ -2182,17 +2203,20 @@ struct RouteArgs {
     int vec;                // every row pointer / stride allows 4-element accesses
 };
 
-template <bool BF16, bool BWD, int NE>
+template <bool BF16, bool BWD, int NE, int LPR>
 __global__ void __launch_bounds__(256) vq_route_kernel(const RouteArgs a)
 {
-    const int lane = threadIdx.x & 63;
-    const int64_t n = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (n >= a.N) return;
+    constexpr int RPW = 64 / LPR;                      // rows per wave
+    const int lane = threadIdx.x & (LPR - 1);          // lane within its row
+    const int64_t n0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW + ((threadIdx.x & 63) / LPR);
+    const bool valid = n0 < a.N;
+    if (LPR == 64 && !valid) return;
+    const int64_t n = valid ? n0 : a.N - 1;            // (rows share a wave: the ones past the end repeat the last row and store nothing)
     float e[NE], qv[NE], g[NE];
     float se = 0.f, sq = 0.f;
-    row_load8<BF16, NE>(a.x, n * a.ldx, a.D, lane, a.vec != 0, e);
-    row_load8<BF16, NE>(a.q, n * a.ldq, a.D, lane, a.vec != 0, qv);
-    if (BWD && a.g) row_load8<BF16, NE>(a.g, n * a.ldg, a.D, lane, a.vec != 0, g);
+    row_load8<BF16, NE, LPR>(a.x, n * a.ldx, a.D, lane, a.vec != 0, e);
+    row_load8<BF16, NE, LPR>(a.q, n * a.ldq, a.D, lane, a.vec != 0, qv);
+    if (BWD && a.g) row_load8<BF16, NE, LPR>(a.g, n * a.ldg, a.D, lane, a.vec != 0, g);
 #pragma unroll
     for (int k = 0; k < NE; ++k) {
         if (!(BWD && a.g)) g[k] = 0.f;
@@ -2201,7 +2225,7 @@ __global__ void __launch_bounds__(256) vq_route_kernel(const RouteArgs a)
     }
     float r[NE];
     if (a.mode == 2) {
-        const float ne = sqrtf(wave_sum(se)), nq = sqrtf(wave_sum(sq));
+        const float ne = sqrtf(row_sum<LPR>(se)), nq = sqrtf(row_sum<LPR>(sq));
         const float de = fmaxf(ne, 1e-6f), dq = fmaxf(nq, 1e-6f);
         const float ide = 1.f / de, idq = 1.f / dq;       // one reciprocal per row, then multiplies (x / |x| to 1 ulp): IEEE divisions per
         float u[NE], qh[NE], w[NE];                       // element made these kernels ALU-bound (1.5 TB/s of row traffic)
@@ -2213,7 +2237,7 @@ __global__ void __launch_bounds__(256) vq_route_kernel(const RouteArgs a)
             w[k] = u[k] + qh[k];
             st += w[k] * w[k];
         }
-        const float nt = fmaxf(sqrtf(wave_sum(st)), 1e-6f);
+        const float nt = fmaxf(sqrtf(row_sum<LPR>(st)), 1e-6f);
         const float int_ = 1.f / nt;
         float a1 = 0.f, a2 = 0.f;
 #pragma unroll
@@ -2222,8 +2246,8 @@ __global__ void __launch_bounds__(256) vq_route_kernel(const RouteArgs a)
             if (BWD) { a1 += g[k] * w[k]; a2 += g[k] * qh[k]; }
             else     { a1 += e[k] * w[k]; a2 += e[k] * u[k]; }
         }
-        a1 = wave_sum(a1);
-        a2 = wave_sum(a2);
+        a1 = row_sum<LPR>(a1);
+        a2 = row_sum<LPR>(a2);
         const float sc = nq / de;
 #pragma unroll
         for (int k = 0; k < NE; ++k)
@@ -2238,15 +2262,18 @@ __global__ void __launch_bounds__(256) vq_route_kernel(const RouteArgs a)
 #pragma unroll
         for (int k = 0; k < NE; ++k) r[k] += c2 * (e[k] - qv[k]);
     }
-    row_store8<BF16, NE>(a.out, n * a.ldo, a.D, lane, a.vec != 0, r);
+    if (valid) row_store8<BF16, NE, LPR>(a.out, n * a.ldo, a.D, lane, a.vec != 0, r);
 }
 
 static int route_launch(const RouteArgs &a, int dtype, bool bwd, hipStream_t st)
 {
     if (a.N == 0) return 0;
-    dim3 grid((unsigned)((a.N + 3) / 4));
-#define VQ_ROUTE_LAUNCH(BF, BW) do { if (a.D <= 256) hipLaunchKernelGGL((vq_route_kernel<BF, BW, 4>), grid, dim3(256), 0, st, a); \
-                                     else hipLaunchKernelGGL((vq_route_kernel<BF, BW, 8>), grid, dim3(256), 0, st, a); } while (0)
+    dim3 grid((unsigned)((a.N + 3) / 4)), grid16((unsigned)((a.N + 15) / 16));
+    // D <= 256: one row per 16 lanes (NE = 4 ceil(D / 64) elements per lane), else one row per wave
+#define VQ_ROUTE_LAUNCH(BF, BW) do { if (a.D <= 64) hipLaunchKernelGGL((vq_route_kernel<BF, BW, 4, 16>), grid16, dim3(256), 0, st, a); \
+                                     else if (a.D <= 128) hipLaunchKernelGGL((vq_route_kernel<BF, BW, 8, 16>), grid16, dim3(256), 0, st, a); \
+                                     else if (a.D <= 256) hipLaunchKernelGGL((vq_route_kernel<BF, BW, 16, 16>), grid16, dim3(256), 0, st, a); \
+                                     else hipLaunchKernelGGL((vq_route_kernel<BF, BW, 8, 64>), grid, dim3(256), 0, st, a); } while (0)
     if (dtype == VQHIP_BF16) {
         if (bwd) VQ_ROUTE_LAUNCH(true, true); else VQ_ROUTE_LAUNCH(true, false);
     } else {
@@ -2309,28 +2336,34 @@ struct RvqRouteArgs {
     int D, Q, mode, vec;
 };
 
-template <bool BF16, bool BWD, int NE>
+template <bool BF16, bool BWD, int NE, int LPR>
 __global__ void __launch_bounds__(256) vq_rvq_route_kernel(const RvqRouteArgs a)
 {
-    const int lane = threadIdx.x & 63;
-    const int64_t n = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (n >= a.N) return;
+    constexpr int RPW = 64 / LPR;                      // rows per wave
+    const int lane = threadIdx.x & (LPR - 1);          // lane within its row
+    const int64_t n0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW + ((threadIdx.x & 63) / LPR);
+    const bool valid = n0 < a.N;
+    if (LPR == 64 && !valid) return;
+    const int64_t n = valid ? n0 : a.N - 1;
     float r[NE], g[NE], acc[NE];
-    row_load8<BF16, NE>(a.x, n * a.ldx, a.D, lane, a.vec != 0, r);
-    if (BWD && a.g) row_load8<BF16, NE>(a.g, n * a.ldg, a.D, lane, a.vec != 0, g);
+    row_load8<BF16, NE, LPR>(a.x, n * a.ldx, a.D, lane, a.vec != 0, r);
+    if (BWD && a.g) row_load8<BF16, NE, LPR>(a.g, n * a.ldg, a.D, lane, a.vec != 0, g);
 #pragma unroll
     for (int k = 0; k < NE; ++k) {
         acc[k] = 0.f;
         if (!(BWD && a.g)) g[k] = 0.f;
     }
     const bool counted = !a.row_mask || a.row_mask[n] != 0;
+    bool alive = true;
     for (int q = 0; q < a.Q; ++q) {
-        const int64_t code = a.idx[n * a.idx_stride + q];
-        if (code < 0) break;                                     // dropped-out quantizers (rvq.py:478-482) and masked rows
+        const int64_t code0 = a.idx[n * a.idx_stride + q];
+        alive = alive && code0 >= 0;                             // dropped-out quantizers (rvq.py:478-482) and masked rows: this row is done
+        if (!__any(alive)) break;                                // (the rows of a wave end independently; a finished row idles along)
+        const int64_t code = alive ? code0 : 0;
         const float *cp = a.embed + (size_t)q * a.qstride + (size_t)code * a.D;
         float c[NE];
         float se = 0.f, sq = 0.f;
-        row_load8<false, NE>(cp, 0, a.D, lane, (a.D & 3) == 0, c);   // code rows: fp32, [C, D] contiguous, 16-byte aligned when D % 4 == 0
+        row_load8<false, NE, LPR>(cp, 0, a.D, lane, (a.D & 3) == 0, c);   // code rows: fp32, [C, D] contiguous, 16-byte aligned when D % 4 == 0
 #pragma unroll
         for (int k = 0; k < NE; ++k) {
             if (BF16) c[k] = round_to_bf16(c[k]);
@@ -2339,7 +2372,7 @@ __global__ void __launch_bounds__(256) vq_rvq_route_kernel(const RvqRouteArgs a)
         }
         float t[NE];
         if (a.mode == 2) {                                       // rotation trick: the arithmetic of vq_route_kernel
-            const float ne = sqrtf(wave_sum(se)), nq = sqrtf(wave_sum(sq));
+            const float ne = sqrtf(row_sum<LPR>(se)), nq = sqrtf(row_sum<LPR>(sq));
             const float de = fmaxf(ne, 1e-6f), dq = fmaxf(nq, 1e-6f);
             const float ide = 1.f / de, idq = 1.f / dq;
             float u[NE], qh[NE], w[NE];
@@ -2351,7 +2384,7 @@ __global__ void __launch_bounds__(256) vq_rvq_route_kernel(const RvqRouteArgs a)
                 w[k] = u[k] + qh[k];
                 st += w[k] * w[k];
             }
-            const float nt = fmaxf(sqrtf(wave_sum(st)), 1e-6f);
+            const float nt = fmaxf(sqrtf(row_sum<LPR>(st)), 1e-6f);
             const float int_ = 1.f / nt;
             float a1 = 0.f, a2 = 0.f;
 #pragma unroll
@@ -2360,8 +2393,8 @@ __global__ void __launch_bounds__(256) vq_rvq_route_kernel(const RvqRouteArgs a)
                 if (BWD) { a1 += g[k] * w[k]; a2 += g[k] * qh[k]; }
                 else     { a1 += r[k] * w[k]; a2 += r[k] * u[k]; }
             }
-            a1 = wave_sum(a1);
-            a2 = wave_sum(a2);
+            a1 = row_sum<LPR>(a1);
+            a2 = row_sum<LPR>(a2);
             const float sc = nq / de;
 #pragma unroll
             for (int k = 0; k < NE; ++k)
@@ -2378,13 +2411,15 @@ __global__ void __launch_bounds__(256) vq_rvq_route_kernel(const RvqRouteArgs a)
 #pragma unroll
             for (int k = 0; k < NE; ++k) t[k] += c2 * (r[k] - c[k]);
         }
+        if (alive) {
 #pragma unroll
-        for (int k = 0; k < NE; ++k) {
-            if (BF16 && !BWD) { acc[k] = round_to_bf16(acc[k] + round_to_bf16(t[k])); r[k] = round_to_bf16(r[k] - c[k]); }
-            else              { acc[k] += t[k]; r[k] = BF16 ? round_to_bf16(r[k] - c[k]) : (r[k] - c[k]); }
+            for (int k = 0; k < NE; ++k) {
+                if (BF16 && !BWD) { acc[k] = round_to_bf16(acc[k] + round_to_bf16(t[k])); r[k] = round_to_bf16(r[k] - c[k]); }
+                else              { acc[k] += t[k]; r[k] = BF16 ? round_to_bf16(r[k] - c[k]) : (r[k] - c[k]); }
+            }
         }
     }
-    row_store8<BF16, NE>(a.out, n * a.ldo, a.D, lane, a.vec != 0, acc);
+    if (valid) row_store8<BF16, NE, LPR>(a.out, n * a.ldo, a.D, lane, a.vec != 0, acc);
 }
 
 extern "C" int vqhip_rvq_route(const void *x, int dtype, int64_t N, int D, int64_t ldx, const float *embed, int64_t embed_qstride,
@@ -2406,9 +2441,11 @@ extern "C" int vqhip_rvq_route(const void *x, int dtype, int64_t N, int D, int64
     a.vec = rows_vec4(x, ldx, D, es) && rows_vec4(a.g, ldg, D, es) && rows_vec4(out, ldo, D, es);
     if ((D & 3) == 0 && ((((uintptr_t)embed) & 15) || (embed_qstride & 3))) VQ_FAIL(VQHIP_EALIGN, "rvq_route: embed must be 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
-    dim3 grid((unsigned)((N + 3) / 4));
-#define VQ_RVQ_ROUTE_LAUNCH(BF, BW) do { if (D <= 256) hipLaunchKernelGGL((vq_rvq_route_kernel<BF, BW, 4>), grid, dim3(256), 0, st, a); \
-                                         else hipLaunchKernelGGL((vq_rvq_route_kernel<BF, BW, 8>), grid, dim3(256), 0, st, a); } while (0)
+    dim3 grid((unsigned)((N + 3) / 4)), grid16((unsigned)((N + 15) / 16));
+#define VQ_RVQ_ROUTE_LAUNCH(BF, BW) do { if (D <= 64) hipLaunchKernelGGL((vq_rvq_route_kernel<BF, BW, 4, 16>), grid16, dim3(256), 0, st, a); \
+                                         else if (D <= 128) hipLaunchKernelGGL((vq_rvq_route_kernel<BF, BW, 8, 16>), grid16, dim3(256), 0, st, a); \
+                                         else if (D <= 256) hipLaunchKernelGGL((vq_rvq_route_kernel<BF, BW, 16, 16>), grid16, dim3(256), 0, st, a); \
+                                         else hipLaunchKernelGGL((vq_rvq_route_kernel<BF, BW, 8, 64>), grid, dim3(256), 0, st, a); } while (0)
     if (dtype == VQHIP_BF16) {
         if (backward) VQ_RVQ_ROUTE_LAUNCH(true, true); else VQ_RVQ_ROUTE_LAUNCH(true, false);
     } else {
