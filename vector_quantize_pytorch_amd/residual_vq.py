@@ -7,6 +7,8 @@ reference -- the quantize-dropout seed, rvq.py:96-102 -- is taken only when quan
 """
 from __future__ import annotations
 
+import os
+
 import random
 from math import ceil
 from typing import Optional
@@ -545,6 +547,10 @@ def _stats_stream(device, main):
     """The statistics stream that pairs with `main` (one per caller stream, so concurrent groups do not share one)."""
     key = (torch.device(device).index, main.cuda_stream)
     if key not in _STATS_STREAMS:
+        # (default priority.  The statistics chain is five short launches behind one another -- memset, histogram, scan, scatter,
+        #  segmented sum -- and beside a search that fills every CU each of them waits for a workgroup slot: rocprofv3 shows the
+        #  4 KB memset at 124 us wall, the chain at 340 us for ~100 us of work.  A high-priority stream was tried in round 3:
+        #  cfg 3 2.996 -> 2.974 ms, cfg 5 15.5 -> 18.9 ms -- the statistics then push the searches of the other groups aside.)
         _STATS_STREAMS[key] = torch.cuda.Stream(device=device)
     return _STATS_STREAMS[key]
 
