@@ -191,8 +191,11 @@ def test_grouped_residual_vq_group_streams_match_serial(dev):
         (qb.sum() + lb.sum()).backward()
         torch.cuda.synchronize()
         if step == 0:        # identical codebooks: bit-identical results (later steps: the EMA sums are atomics, last bits may differ)
-            assert torch.equal(ia, ib) and torch.equal(qa, qb) and torch.equal(la, lb)
+            assert torch.equal(ia, ib) and torch.equal(qa, qb)
             assert torch.equal(xa.grad, xb.grad)
+            # the commitment loss is summed by the statistics pass in the order its counting sort left the rows in (global atomics
+            # between workgroups: any order), so its last bits are not reproducible from run to run -- with or without group streams
+            assert torch.allclose(la, lb, rtol=2e-6, atol=0)
         assert (ia == ib).float().mean().item() > 0.999 and torch.allclose(la, lb, rtol=1e-4, atol=1e-6), step
         flips += int((ia != ib).sum())
     # a row that flips between two near-tied codes (last-bit differences of the atomically summed EMA statistics) moves the
