@@ -80,17 +80,19 @@ int vqhip_assign(const void *x, int x_dtype, int64_t N, int D, int64_t ldx,
  * arithmetic vqhip_assign(metric VQHIP_COSINE) applies internally.  D in {32, 64, 128, 256}; rows aligned to 4 elements. */
 int vqhip_l2norm_rows(const void *x, int x_dtype, int64_t N, int D, int64_t ldx, void *out, int64_t ldo, void *stream);
 
-/* ---- screened assignment (D in {32, 64, 128, 256}) ------------------------------------------------------
+/* ---- screened assignment (D in {32, 64, 128, 256, 512}) -------------------------------------------------
  * metric: VQHIP_EUCLID, or VQHIP_COSINE_PRENORM on rows already normalised (vqhip_l2norm_rows).
  * Same contract as vqhip_assign(same metric, q in x's dtype): idx_out bit-identical to the exact kernel, q_out
- * the gathered code rows, sqerr_partial the squared-error partials -- but the codebook sweep runs on the bf16 MFMA pipe
- * against a two-part bf16 split of the codebook made by vqhip_pack_codebook (fp32 rows are split as well, three products
- * per k-step), and only the rows whose best-vs-second margin is inside the proven error bound (csrc/vq_screen.hip) are
- * re-evaluated by the exact fp32-MFMA arithmetic, on the same stream, before the call's work completes.  Replaces the
- * same reference lines as vqhip_assign.
+ * the gathered code rows, sqerr_partial the squared-error partials -- but the codebook sweep runs on the fp16 MFMA pipe
+ * against ONE fp16 copy of the codebook made by vqhip_pack_codebook (rows: bf16 values scaled by a power of two are exact
+ * fp16 operands; fp32 rows are rounded to one fp16 operand set and the measured residual is charged), tracking the three
+ * best scores per row.  A row whose best-vs-second margin exceeds the proven error bound (csrc/vq_screen.hip) is final;
+ * a row with two candidates inside the bound is decided by two exact distances; the rest is re-evaluated by the exact
+ * fp32-MFMA sweep -- all on the same stream, before the call's work completes.  Replaces the same reference lines as
+ * vqhip_assign.
  *   supported:      vqhip_screen_supported(N, D, C) != 0; x rows 16-byte aligned, q rows aligned to 4 elements
  *   workspace:      vqhip_screen_workspace_bytes(N) bytes, 8-byte aligned; on completion ((int *)workspace)[0] is the
- *                   number of rows that took the exact pass (diagnostic)
+ *                   number of rows that took the exact sweep, [1] the number decided between two candidates (diagnostic)
  *   sqerr_partial:  nullable, vqhip_screen_partials(N, x_dtype) doubles, all written; feed them to vqhip_reduce_partials
  *   resid_out:      nullable [N, ldr] in x's dtype: x - q in the reference's tensor arithmetic (bf16 tensors subtract in
  *                   fp32 and round to bf16), i.e. the input of the next ResidualVQ stage (rvq.py:524); q_out may be null
