@@ -77,7 +77,7 @@ int vqhip_assign(const void *x, int x_dtype, int64_t N, int D, int64_t ldx,
 /* ---- l2norm of rows ------------------------------------------------------------------------------
  * Replaces l2norm (vqp.py:37-38) as applied to the input at :1159: out = x / max(||x||, 1e-6) with ||x||^2 summed in
  * ATen's CPU order and, for bf16 tensors, norm and quotient rounded to bf16 as the reference's bf16 ops do -- the same
- * arithmetic vqhip_assign(metric VQHIP_COSINE) applies internally.  D in {32, 64, 128, 256}; rows aligned to 4 elements. */
+ * arithmetic vqhip_assign(metric VQHIP_COSINE) applies internally.  D in {32, 64, 128, 256, 512}; rows aligned to 4 elements. */
 int vqhip_l2norm_rows(const void *x, int x_dtype, int64_t N, int D, int64_t ldx, void *out, int64_t ldo, void *stream);
 
 /* ---- screened assignment (D in {32, 64, 128, 256, 512}) -------------------------------------------------
