@@ -1,6 +1,6 @@
 """Adversarial parity tests of the SCREENED search (csrc/vq_screen.hip).
 
-The screened path certifies an index from a bf16-MFMA score and a model of that score's error.  These tests put the
+The screened path certifies an index from an fp16-MFMA score and a model of that score's error.  These tests put the
 certificate under load instead of trusting the model:
 
 * a fuzz over magnitudes 1e-6 .. 1e4, DC offsets, heavy tails, mixed-norm codebooks, 2 <= C <= 65536,

@@ -411,7 +411,7 @@ def mask_fill_indices(idx: torch.Tensor, row_mask: torch.Tensor):
 @_on_device
 def rvq_forward_screened(x: torch.Tensor, packed: torch.Tensor, embed: torch.Tensor, Q: int, *, want_resid=False,
                          want_sqerr=False, row_mask=None, stage_hook=None, fill_masked=True):
-    """The residual loop (rvq.py:469-568) as Q screened assignments: each stage's search runs on the bf16 MFMA pipe
+    """The residual loop (rvq.py:469-568) as Q screened assignments: each stage's search runs on the fp16 MFMA pipe
     (csrc/vq_screen.hip) and writes the next stage's input x - q itself, so no N x D tensor op runs between stages.
     Same arguments as rvq_forward (+ stage_hook(q, stage_input, idx), called after stage q's launches);
     -> dict(idx [..., Q], inputs = the Q stage inputs (inputs[0] is x) | None, sqerr_partials [Q, P] | None)."""
