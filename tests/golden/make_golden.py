@@ -228,6 +228,16 @@ if __name__ == "__main__":
     qinco = dict(dim=32, num_quantizers=3, codebook_size=64, implicit_neural_codebook=True, mlp_kwargs=dict(depth=2))
     run_case("rvq_qinco", ResidualVQ, qinco, [randn(2, 50, 32, seed=100)], grad=True, param_grad=True, unit_codebook=True)
     run_case("rvq_qinco_eval", ResidualVQ, qinco, [randn(2, 40, 32, seed=101)], train=False, unit_codebook=True)
+    # the per-row codebook path with the COSINE metric and an input that does not require grad (the reference l2-normalises
+    # x before anything else, vqp.py:1159, so the commitment loss and the EMA statistics see normalised rows).  QINCo itself cannot be
+    # cosine -- the reference asserts against cosine + learnable_codebook (vqp.py:884) -- so the fixture drives codebook_transform_fn
+    # directly, through the harness shared with the tests
+    import importlib.util
+    _spec = importlib.util.spec_from_file_location("golden_util", os.path.join(ROOT, "tests", "golden_util.py"))
+    _gu = importlib.util.module_from_spec(_spec); _spec.loader.exec_module(_gu)
+    run_case("vq_cos_transform_nograd", VectorQuantize, dict(dim=32, codebook_size=64, use_cosine_sim=True),
+             [randn(2, 50, 32, seed=102) * 3.0 + 0.5, randn(2, 50, 32, seed=103) * 3.0 + 0.5], unit_codebook=True,
+             build=lambda: _gu.TransformCaller(VectorQuantize(dim=32, codebook_size=64, use_cosine_sim=True)))
     # gradients to the input through the residual loop (rvq.py:524-525 with quant_grad_frac = 0): every stage's rotation-trick
     # (the default, vqp.py:856) / straight-through Jacobian (vqp.py:1225-1233) plus every stage's commitment-loss gradient, summed into dL/dx
     run_case("rvq_shared_grad", ResidualVQ, dict(dim=64, num_quantizers=4, codebook_size=128, shared_codebook=True),

@@ -64,8 +64,25 @@ class Fixture:
         return fk
 
 
+class TransformCaller(torch.nn.Module):
+    """TEST HARNESS (used by tests/golden/make_golden.py around the LIVE reference and by the GPU tests around this repo's module):
+    a VectorQuantize called with a fixed, row-dependent `codebook_transform_fn` (vqp.py:729-738) -- every row searches the codebook
+    shifted by a tenth of the (detached) row itself."""
+
+    def __init__(self, vq):
+        super().__init__()
+        self.vq = vq
+
+    def forward(self, x, **kw):
+        shift = 0.1 * x.detach()
+        # codes [h, c, d] -> one codebook per row, [h, b, n, c, d] (the layout vqp.py:731 expects)
+        return self.vq(x, codebook_transform_fn=lambda codes: codes[:, None, None] + shift[None, ..., None, :], **kw)
+
+
 def build_special(name, A):
     """fixtures whose constructor takes callables / modules (not serialisable in the fixture's kwargs)"""
+    if name == "vq_cos_transform_nograd":
+        return TransformCaller(A.VectorQuantize(dim=32, codebook_size=64, use_cosine_sim=True))
     if name == "vq_inplace_opt":
         return A.VectorQuantize(dim=32, codebook_size=64, learnable_codebook=True, ema_update=False,
                                 in_place_codebook_optimizer=lambda p: torch.optim.SGD(p, lr=0.5))
