@@ -219,6 +219,12 @@ if __name__ == "__main__":
     run_case("rvq_separate", ResidualVQ, dict(dim=64, num_quantizers=4, codebook_size=128), [randn(2, 200, 64, seed=19)], unit_codebook=True)
     run_case("rvq_tiger", ResidualVQ, dict(dim=2, codebook_size=(5, 128, 256)), [randn(2, 32, 2, seed=20)], unit_codebook=True)
     run_case("rvq_cosine_eval", ResidualVQ, dict(dim=64, num_quantizers=3, codebook_size=64, use_cosine_sim=True), [randn(1, 256, 64, seed=21)], train=False)
+    # the residual loop with bf16 rows (every tensor op of the reference rounds to bf16: the residual update, the running sum) and
+    # with cosine codebooks in training (EMA on l2-normalised rows, staged path)
+    run_case("rvq_bf16", ResidualVQ, dict(dim=64, num_quantizers=3, codebook_size=64), [randn(2, 120, 64, seed=120, dtype=torch.bfloat16),
+             randn(2, 120, 64, seed=121, dtype=torch.bfloat16)], unit_codebook=True)
+    run_case("rvq_cosine_train", ResidualVQ, dict(dim=64, num_quantizers=3, codebook_size=64, use_cosine_sim=True),
+             [randn(2, 150, 64, seed=122), randn(2, 150, 64, seed=123)], unit_codebook=True)
     # cfg 5: grouped RVQ, scaled down (k-means through the deterministic sampler)
     run_case("grvq", GroupedResidualVQ, dict(dim=128, groups=2, num_quantizers=3, codebook_size=64), [randn(2, 100, 128, seed=22)], unit_codebook=True)
     run_case("grvq_kmeans", GroupedResidualVQ, dict(dim=64, groups=2, num_quantizers=2, codebook_size=32, kmeans_init=True, kmeans_iters=3),
