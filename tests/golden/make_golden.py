@@ -225,6 +225,13 @@ if __name__ == "__main__":
              randn(2, 120, 64, seed=121, dtype=torch.bfloat16)], unit_codebook=True)
     run_case("rvq_cosine_train", ResidualVQ, dict(dim=64, num_quantizers=3, codebook_size=64, use_cosine_sim=True),
              [randn(2, 150, 64, seed=122), randn(2, 150, 64, seed=123)], unit_codebook=True)
+    # quantizer dropout (rvq.py:478-482, seeded through rand_quantize_dropout_fixed_seed): dropped stages return -1 / zero loss
+    run_case("rvq_dropout", ResidualVQ, dict(dim=32, num_quantizers=4, codebook_size=64, quantize_dropout=True, quantize_dropout_cutoff_index=1),
+             [randn(2, 90, 32, seed=124), randn(2, 90, 32, seed=125)], fwd_kwargs=dict(rand_quantize_dropout_fixed_seed=3), unit_codebook=True)
+    # cosine codebook, variable lengths, training without an input gradient: the masked commitment loss compares against the
+    # un-normalised input (vqp.py:1319) while the EMA statistics see the normalised rows
+    run_case("vq_cosine_lens_train", VectorQuantize, dict(dim=32, codebook_size=64, use_cosine_sim=True),
+             [randn(3, 40, 32, seed=126) * 2.0, randn(3, 40, 32, seed=127) * 2.0], fwd_kwargs=dict(lens=[40, 17, 29]), unit_codebook=True)
     # cfg 5: grouped RVQ, scaled down (k-means through the deterministic sampler)
     run_case("grvq", GroupedResidualVQ, dict(dim=128, groups=2, num_quantizers=3, codebook_size=64), [randn(2, 100, 128, seed=22)], unit_codebook=True)
     run_case("grvq_kmeans", GroupedResidualVQ, dict(dim=64, groups=2, num_quantizers=2, codebook_size=32, kmeans_init=True, kmeans_iters=3),
