@@ -232,6 +232,14 @@ if __name__ == "__main__":
     # un-normalised input (vqp.py:1319) while the EMA statistics see the normalised rows
     run_case("vq_cosine_lens_train", VectorQuantize, dict(dim=32, codebook_size=64, use_cosine_sim=True),
              [randn(3, 40, 32, seed=126) * 2.0, randn(3, 40, 32, seed=127) * 2.0], fwd_kwargs=dict(lens=[40, 17, 29]), unit_codebook=True)
+    # bf16 rows with the cosine metric (the reference l2-normalises in bf16: norm and quotient rounded), k-means init with the cosine
+    # metric (means re-normalised every iteration, vqp.py:262-276), grouped residual VQ on bf16 rows
+    run_case("vq_bf16_cos", VectorQuantize, dict(dim=64, codebook_size=128, use_cosine_sim=True),
+             [randn(2, 256, 64, seed=130, dtype=torch.bfloat16), randn(2, 256, 64, seed=131, dtype=torch.bfloat16)])
+    run_case("vq_kmeans_cos", VectorQuantize, dict(dim=32, codebook_size=32, use_cosine_sim=True, kmeans_init=True, kmeans_iters=4),
+             [randn(1, 1024, 32, seed=132), randn(1, 1024, 32, seed=133)], deterministic_sampling=True)
+    run_case("grvq_bf16", GroupedResidualVQ, dict(dim=128, groups=2, num_quantizers=3, codebook_size=64),
+             [randn(2, 100, 128, seed=134, dtype=torch.bfloat16)], unit_codebook=True)
     # cfg 5: grouped RVQ, scaled down (k-means through the deterministic sampler)
     run_case("grvq", GroupedResidualVQ, dict(dim=128, groups=2, num_quantizers=3, codebook_size=64), [randn(2, 100, 128, seed=22)], unit_codebook=True)
     run_case("grvq_kmeans", GroupedResidualVQ, dict(dim=64, groups=2, num_quantizers=2, codebook_size=32, kmeans_init=True, kmeans_iters=3),
