@@ -240,6 +240,12 @@ if __name__ == "__main__":
              [randn(1, 1024, 32, seed=132), randn(1, 1024, 32, seed=133)], deterministic_sampling=True)
     run_case("grvq_bf16", GroupedResidualVQ, dict(dim=128, groups=2, num_quantizers=3, codebook_size=64),
              [randn(2, 100, 128, seed=134, dtype=torch.bfloat16)], unit_codebook=True)
+    # dead-code replacement inside the residual loop (separate codebooks: every layer replaces its expired codes with rows of ITS stage
+    # input, vqp.py:564-574 through the deterministic sampler), and two EMA steps on bf16 rows
+    run_case("rvq_expire", ResidualVQ, dict(dim=32, num_quantizers=3, codebook_size=128, threshold_ema_dead_code=2),
+             [randn(1, 256, 32, seed=140), randn(1, 256, 32, seed=141)], unit_codebook=True, deterministic_sampling=True)
+    run_case("vq_bf16_2step", VectorQuantize, dict(dim=64, codebook_size=256),
+             [randn(2, 300, 64, seed=142, dtype=torch.bfloat16), randn(2, 300, 64, seed=143, dtype=torch.bfloat16)], unit_codebook=True)
     # cfg 5: grouped RVQ, scaled down (k-means through the deterministic sampler)
     run_case("grvq", GroupedResidualVQ, dict(dim=128, groups=2, num_quantizers=3, codebook_size=64), [randn(2, 100, 128, seed=22)], unit_codebook=True)
     run_case("grvq_kmeans", GroupedResidualVQ, dict(dim=64, groups=2, num_quantizers=2, codebook_size=32, kmeans_init=True, kmeans_iters=3),
