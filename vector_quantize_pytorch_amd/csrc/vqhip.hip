@@ -282,7 +282,7 @@ extern "C" int vqhip_pack_codebook(const float *embed, int C, int D, float *pack
 // tile (global / LDS); piece k of this wave is 4 KiB further (waves interleave 1-KiB pieces).  Loads of a batch
 // are issued behind one MFMA, the ds_write_b128s a few MFMA groups later when the data has arrived.
 // Why not LDS-DMA (global_load_lds) as in the first version: each glds kept the issuing wave busy ~270 cycles
-// (9 per tile = 2.4k cycles per wave and tile, tools/ablate.py), and because a wave's MFMAs form ONE dependent
+// (9 per tile = 2.4k cycles per wave and tile, measured in round 1), and because a wave's MFMAs form ONE dependent
 // chain nothing of that hides behind its own MFMAs; a global_load + ds_write pair costs the wave ~30 cycles.
 template <int DT>
 __device__ __forceinline__ void mfma_sweep_tile(const f32x4 *ap, const float (&xr)[DT / 2], f32x16 &acc,
