@@ -367,13 +367,14 @@ def vq_cfg2(args, world, rank, dev):
     alg_bytes = n_vec * 1032 + C * D * 4                         # D*2 in + D*2 out + 8 per vector (+ codebook once)
     achieved = flops / (k_ms * 1e-3) / 1e12
     screened = _lib.screening_enabled()
-    traffic, traffic_src = None, None
+    traffic, traffic_src, step_traffic = None, None, None
     tp = os.path.join(ROOT, "profiles", "traffic.json")          # HBM bytes per launch from rocprofv3 PMC passes (not measured in this run)
     if os.path.exists(tp):
         try:
             tj = json.load(open(tp))
             traffic = tj.get("assign_screened_cfg2_bytes_per_launch" if screened else "vq_assign_kernel_cfg2_bytes_per_launch")
             traffic_src = "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, committed; not re-measured in this run)"
+            step_traffic = (tj.get("step_traffic", {}).get("vq_cfg2") or {}).get("bytes_per_step") if screened else None
         except Exception:
             traffic = None
     peak = PEAK_BF16_MFMA_TFLOPS if screened else PEAK_FP32_MFMA_TFLOPS
@@ -409,7 +410,8 @@ def vq_cfg2(args, world, rank, dev):
                      "kernel": ("vq_screen16_kernel<256> + vq_refine_kernel<256> + vq_pair_kernel<256> + vq_finish_listed_kernel" if screened
                                 else "vq_assign_kernel<256,bf16,euclid>"),
                      "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-                     "traffic": traffic, "traffic_source": traffic_src, "kernel_ms": k_ms, "algorithmic_flops_per_launch": flops,
+                     "traffic": traffic, "traffic_source": traffic_src, "traffic_whole_step": step_traffic,
+                     "kernel_ms": k_ms, "algorithmic_flops_per_launch": flops,
                      "algorithmic_bytes_per_launch": alg_bytes,
                      "achieved_vs_fp32_mfma_peak": achieved / PEAK_FP32_MFMA_TFLOPS,
                      "note": ("achieved counts algorithmic flops (2*C*D per vector) over the whole search (screen + exact pass on the "
