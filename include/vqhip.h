@@ -120,6 +120,7 @@ typedef struct {
     const float *prev_embed;       /* previous stage's codebook [C_prev, D] fp32 */
     void *x_out;                   /* [N, D] fp32 at row stride ldxo: receives this stage's input */
     int64_t ldxo;
+    int64_t route_mode;            /* 0 / 1 / 2, see above */
 } vqhip_chain_t;
 int vqhip_screen_chain_supported(int x_dtype, int D);
 int vqhip_assign_screened_chain(const void *x, int x_dtype, int64_t N, int D, int64_t ldx, const float *packed,
@@ -138,7 +139,8 @@ int vqhip_scores(const void *x, int x_dtype, int64_t N, int D, int64_t ldx,
 /* The same sweep with a streaming log-sum-exp epilogue instead of the N x C store: what F.cross_entropy(dist, codes) needs
  * (cross-entropy "commitment" to the chosen codes, vqp.py:1242-1256, and forward(indices=...), vqp.py:1260-1261):
  *   lse_out[n]    = log sum_c exp(dist[n, c])           (online max / sum per lane, merged per row)
- *   tscore_out[n] = dist[n, target[n]]                   (target null: the winner's score; target[n] < 0: 0, the row is ignored)
+ *   tscore_out[n] = dist[n, target[n]]                   (target null: the winner's score; target[n] < 0: 0, the row is ignored;
+ *                                                          target[n] >= C: NaN -- F.cross_entropy raises there, nothing silent)
  * dist as in vqhip_scores.  idx_out [N] (argmax) must be given; rnorm_out as in vqhip_assign. */
 int vqhip_scores_lse(const void *x, int x_dtype, int64_t N, int D, int64_t ldx,
                      const float *packed, const float *embed, int C, int metric, const int64_t *target,
@@ -181,10 +183,14 @@ int vqhip_route_bwd(const void *x, const void *q, const void *g_out, int dtype, 
  *  x, g_out, out: [N, D] rows of one dtype; embed: fp32 [Q][C, D] at stride embed_qstride elements (0 = one shared codebook);
  *  idx: int64 [N, idx_stride], the first Q columns are the stages (a negative entry ends the row's loop: dropped quantizers).
  *  backward == 0 : out = sum_q route(r_q, c_q)          (mode 0: plain sum of the codes, 1: straight-through, 2: rotation trick)
- *  backward != 0 : out = sum_q J_q^T g_out (mode 1, 2) + 2 * loss_coef[q] * (r_q - c_q) on rows with row_mask != 0;
- *                  loss_coef (nullable): Q DEVICE floats, d loss / d (sum of squared errors of stage q). */
+ *  backward != 0 : out = sum_q J_q^T g_out (mode 1, 2; g_out null = zero) + 2 * loss_coef[q] * (r_q - c_q) on rows with row_mask != 0;
+ *                  loss_coef (nullable): Q DEVICE floats, d loss / d (sum of squared errors of stage q).
+ *  resid_routed  : how r_{q+1} is re-derived from r_q.  != 0 (and mode 1 / 2): r_q - route(r_q, c_q), the reference's
+ *                  `residual - quantized.detach()` when the layer returned the ROUTED value (training with an input that
+ *                  requires grad, vqp.py:1225-1233) -- this is what the indices were searched with (vqhip_chain_t.route_mode);
+ *                  0: r_q - c_q (no-grad forward: `quantized` is the code row). */
 int vqhip_rvq_route(const void *x, int dtype, int64_t N, int D, int64_t ldx, const float *embed, int64_t embed_qstride,
-                    int C, const int64_t *idx, int64_t idx_stride, int Q, int mode, const void *g_out, int64_t ldg,
+                    int C, const int64_t *idx, int64_t idx_stride, int Q, int mode, int resid_routed, const void *g_out, int64_t ldg,
                     const float *loss_coef, const uint8_t *row_mask, int backward, void *out, int64_t ldo, void *stream);
 
 /* sum of `n` doubles times `scale` -> one fp32 (commit loss = scale * sum of partials). */

@@ -102,6 +102,8 @@ def run_case(name, cls, kwargs, xs, *, train=True, fwd_kwargs=None, grad=False, 
         if grad:
             x.requires_grad_(True)
         res = mod(x, **fk)
+        if torch.is_tensor(res) and res.dtype.is_floating_point:   # RandomProjectionQuantizer(indices=) returns the cross-entropy only
+            res = (torch.zeros(1), torch.zeros(1, dtype=torch.long), res)
         if torch.is_tensor(res):                      # RandomProjectionQuantizer returns indices only
             res = (torch.zeros(1), res, torch.zeros(()))
         if len(res) == 2:                             # forward(indices=...) returns (quantize, cross-entropy loss)
@@ -137,6 +139,28 @@ def run_case(name, cls, kwargs, xs, *, train=True, fwd_kwargs=None, grad=False, 
     path = os.path.join(HERE, name + ".npz")
     np.savez_compressed(path, **arrays)
     print(f"{name}: {os.path.getsize(path) / 1e6:.2f} MB  loss0={float(arrays['loss0'].reshape(-1)[0]):.6f}")
+
+
+def run_big_case(name, kwargs, shape, seed, *, grad):
+    """tests/golden/big/<name>.npz: ONE training step of the live reference's ResidualVQ at a size where near-ties show up
+    (>= 65 536 rows x 8 stages, default tiny kaiming codebook).  Stored: the codebook before the step, the INDICES
+    (int16: codebook_size <= 32768), the per-stage losses and a sha1 of x -- x itself is re-drawn by the tests from `seed` with
+    torch's CPU generator (same torch build on the GPU box; the sha1 guards that)."""
+    if ONLY and name not in ONLY:
+        return
+    torch.manual_seed(1234)
+    mod = ResidualVQ(**kwargs).train()
+    before = {k: to_np(v) for k, v in mod.state_dict().items() if k.startswith("layers.0._codebook.") and not k.endswith("embed_avg")}
+    x = randn(*shape, seed=seed)
+    xin = x.clone().requires_grad_(True) if grad else x.clone()
+    _, idx, losses = mod(xin)
+    assert int(idx.max()) < 32768
+    meta = dict(name=name, kwargs=kwargs, shape=list(shape), seed=seed, grad=grad, xsha=sha(x))
+    os.makedirs(os.path.join(HERE, "big"), exist_ok=True)
+    path = os.path.join(HERE, "big", name + ".npz")
+    np.savez_compressed(path, idx=idx.numpy().astype(np.int16), losses=to_np(losses.float()),
+                        meta=np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8), **{"before/" + k: v for k, v in before.items()})
+    print(f"big/{name}: {os.path.getsize(path) / 1e6:.2f} MB  losses={losses.detach().numpy().round(5).tolist()}")
 
 
 def randn(*shape, seed=0, dtype=torch.float32):
@@ -187,6 +211,8 @@ if __name__ == "__main__":
     run_case("residual_simvq", ResidualSimVQ, dict(dim=64, num_quantizers=4, codebook_size=128), [randn(2, 100, 64, seed=52)], grad=True, param_grad=True)
     # callers
     run_case("rpq", RandomProjectionQuantizer, dict(dim=64, codebook_size=32, codebook_dim=16, num_codebooks=4), [randn(2, 50, 64, seed=60)])
+    run_case("rpq_indices", RandomProjectionQuantizer, dict(dim=64, codebook_size=32, codebook_dim=16, num_codebooks=4), [randn(2, 50, 64, seed=64)],
+             fwd_kwargs=dict(indices=torch.randint(0, 32, (2, 50, 4), generator=torch.Generator().manual_seed(6)).tolist()), grad=True)
     run_case("hvq", HierarchicalVQ, dict(dim=32, codebook_size=64, scales=(1, 2, 4, 8), accept_image_fmap=True),
              [randn(2, 32, 8, 8, seed=61), randn(2, 32, 8, 8, seed=62)], deterministic_sampling=True)
     run_case("hvq_nokmeans", HierarchicalVQ, dict(dim=32, codebook_size=64, scales=(2, 4), kmeans_init=False, threshold_ema_dead_code=0,
@@ -275,3 +301,14 @@ if __name__ == "__main__":
              [randn(2, 60, 32, seed=113)], fwd_kwargs=dict(mask=[[True] * 60, [True] * 37 + [False] * 23]), grad=True, unit_codebook=True)
     run_case("grvq_grad", GroupedResidualVQ, dict(dim=128, groups=2, num_quantizers=3, codebook_size=64),
              [randn(2, 100, 128, seed=114)], grad=True, unit_codebook=True)
+    # cross-entropy commitment on the FIRST step of a k-means-initialised codebook -- the reference initialises before it
+    # computes `dist` (vqp.py:718-720), so the loss is taken against the initialised codes, not the all-zero buffer
+    run_case("vq_ce_kmeans", VectorQuantize, dict(dim=32, codebook_size=32, kmeans_init=True, kmeans_iters=3, commitment_use_cross_entropy_loss=True),
+             [randn(2, 400, 32, seed=150), randn(2, 400, 32, seed=151)], grad=True, deterministic_sampling=True)
+    # the same loop at a size where near-ties show up: 65 536 rows x 8 stages x 1024 shared codes, default init (cfg 3's shape, a
+    # quarter of its rows) -- without an input gradient, and with one under the rotation trick (default) / straight-through, where
+    # rvq.py:524 subtracts the layer's ROUTED value from the residual and the later stages' indices depend on its last bits
+    big = dict(dim=256, num_quantizers=8, codebook_size=1024, shared_codebook=True)
+    run_big_case("rvq_big_nograd", big, (8, 8192, 256), 200, grad=False)
+    run_big_case("rvq_big_rot", big, (8, 8192, 256), 200, grad=True)
+    run_big_case("rvq_big_ste", dict(big, rotation_trick=False), (8, 8192, 256), 200, grad=True)

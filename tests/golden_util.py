@@ -91,54 +91,6 @@ def build_special(name, A):
     raise KeyError(name)
 
 
-class MultiScaleCaller(torch.nn.Module):
-    """TEST HARNESS (not product code): the call pattern of the reference's HierarchicalVQ (hierarchical_vq.py:88-170) around the
-    repo's VectorQuantize, for the golden fixtures `hvq*` -- one shared quantizer applied to the residual image map pooled to
-    s x s for growing s, each quantized map up-sampled, mixed by a residual 3x3 conv and subtracted.  Sub-module names follow the
-    fixture's state_dict (vq, phi_shared | phi_levels.N with .conv) so that it loads strictly."""
-
-    class _Mix(torch.nn.Module):
-        def __init__(self, dim, ratio):
-            super().__init__()
-            self.ratio, self.conv = abs(float(ratio)), torch.nn.Conv2d(dim, dim, 3, padding=1)
-
-        def forward(self, t):
-            return t if self.ratio <= 1e-8 else (1. - self.ratio) * t + self.ratio * self.conv(t)
-
-    def __init__(self, vq_cls, *, dim, codebook_size, scales, quant_resi=0.5, share_quant_resi=1, accept_image_fmap=True, **vq_kwargs):
-        super().__init__()
-        defaults = dict(decay=0.99, rotation_trick=False, kmeans_init=True, kmeans_iters=10, threshold_ema_dead_code=2,
-                        sample_codebook_temp=0.1, orthogonal_reg_max_codes=128)          # hierarchical_vq.py:34-47
-        self.scales = tuple(int(s) for s in scales)
-        self.vq = vq_cls(dim=dim, codebook_size=codebook_size, accept_image_fmap=True, **{**defaults, **vq_kwargs})
-        n_mix = 1 if share_quant_resi == 1 else (len(self.scales) if share_quant_resi <= 0 else min(len(self.scales), int(share_quant_resi)))
-        mixes = [self._Mix(dim, quant_resi) for _ in range(n_mix)]
-        if share_quant_resi == 1:
-            self.phi_shared = mixes[0]
-        else:
-            self.phi_levels = torch.nn.ModuleList(mixes)
-        self._mixes = mixes
-
-    def _mix_of(self, i):                       # hierarchical_vq.py:95-108: levels spread evenly over the scales
-        m, L = len(self._mixes), len(self.scales)
-        if m == 1 or L == 1:
-            return self._mixes[0]
-        return self._mixes[i] if m == L else self._mixes[max(0, min(m - 1, round(i / (L - 1) * (m - 1))))]
-
-    def forward(self, x, **kw):
-        import torch.nn.functional as F
-        size = tuple(x.shape[-2:])
-        rest, total, idxs, losses = x, torch.zeros_like(x), [], []
-        for i, s in enumerate(self.scales):
-            q, idx, loss = self.vq(F.adaptive_avg_pool2d(rest, (s, s)), **kw)
-            if tuple(q.shape[-2:]) != size:
-                q = F.interpolate(q, size=size, mode="bilinear", align_corners=False)
-            q = self._mix_of(i)(q)
-            total, rest = total + q, rest - q
-            idxs.append(idx); losses.append(loss)
-        return total, tuple(idxs), torch.stack(losses).mean()
-
-
 def first_rows(samples, num):
     n = samples.shape[1]
     if n >= num:

@@ -24,10 +24,7 @@ def _close(a, b, tol, what):
 
 def _build(fx, dev):
     import vector_quantize_pytorch_amd as A
-    if fx.meta["cls"] == "HierarchicalVQ":        # not a product class: its call pattern around VectorQuantize, test-side
-        mod = G.MultiScaleCaller(A.VectorQuantize, **fx.kwargs)
-    else:
-        mod = G.build_special(fx.name, A) if fx.meta.get("build") else getattr(A, fx.meta["cls"])(**fx.kwargs)
+    mod = G.build_special(fx.name, A) if fx.meta.get("build") else getattr(A, fx.meta["cls"])(**fx.kwargs)
     missing, unexpected = mod.load_state_dict(fx.state("before"), strict=True)
     mod = mod.to(dev)
     if fx.meta["deterministic_sampling"]:
@@ -49,6 +46,8 @@ def test_module_matches_reference_golden(dev, name):
         if fx.meta["grad"]:
             x.requires_grad_(True)
         res = mod(x, **fx.fwd_kwargs(dev))
+        if torch.is_tensor(res) and res.dtype.is_floating_point:   # RandomProjectionQuantizer(indices=) returns the cross-entropy only
+            res = (torch.zeros(1, device=dev, dtype=x.dtype), torch.zeros(1, dtype=torch.long, device=dev), res)
         if torch.is_tensor(res):                      # RandomProjectionQuantizer returns indices only
             res = (torch.zeros(1, device=dev, dtype=x.dtype), res, torch.zeros((), device=dev))
         if len(res) == 2:                             # forward(indices=...) returns (quantize, cross-entropy loss)
@@ -917,6 +916,95 @@ def test_residual_chain_equals_the_stage_by_stage_loop(dev, monkeypatch, kw):
         b.load_state_dict(a.state_dict())
 
 
+def _route64(r, c, mode):
+    """float64 restatement of what a layer returns for an input that requires grad (vqp.py:282-318): 1 straight-through, 2 rotation"""
+    if mode == 1:
+        return r + (c - r)
+    if mode == 0:
+        return c
+    nr, nc = r.norm(dim=-1, keepdim=True), c.norm(dim=-1, keepdim=True)
+    u, qh = r / nr.clamp_min(1e-6), c / nc.clamp_min(1e-6)
+    w = torch.nn.functional.normalize(u + qh, dim=-1, eps=1e-6)
+    out = r - 2 * (r * w).sum(-1, keepdim=True) * w + 2 * (r * u).sum(-1, keepdim=True) * qh
+    return out * (nc / nr.clamp_min(1e-6))
+
+
+@pytest.mark.parametrize("name", ["rvq_big_nograd", "rvq_big_ste", "rvq_big_rot"])
+def test_residual_vq_big_golden_fused_equals_staged_and_flips_are_audited_near_ties(dev, monkeypatch, name):
+    """VERDICT r3 #1.  65 536 rows x 8 stages x 1024 shared codes on the default (tiny, tie-prone) init, one training step of the
+    LIVE reference (tests/golden/big, made by make_golden.py::run_big_case) -- without an input gradient and with one, where
+    rvq.py:524 subtracts the layer's ROUTED value (straight-through / rotation trick) and every later stage's indices depend on its
+    last bits.  Contract: (1) the on-device loop and the per-stage path are bit-identical -- indices, output, losses of
+    one module state; (2) against the reference, a row may continue with another code only where the two codes are a near-tie of
+    the reference's own fp32 distances (the rotation's row reductions are summed in another order than torch's CPU kernels:
+    1-ulp differences of the routed value that nothing short of re-implementing MKL's reduction order removes); every such row
+    is audited in float64 and the count is bounded.  For comparison: the reference's own with-grad and no-grad index sequences
+    differ on 76 of these 65 536 rows."""
+    import hashlib
+    import json
+    import os
+    import numpy as np
+    from vector_quantize_pytorch_amd import ResidualVQ
+    z = np.load(os.path.join(G.GOLDEN, "big", name + ".npz"))
+    meta = json.loads(bytes(z["meta"]).decode())
+    x = torch.randn(*meta["shape"], generator=torch.Generator().manual_seed(meta["seed"]))
+    if hashlib.sha1(x.numpy().tobytes()).hexdigest() != meta["xsha"]:
+        pytest.skip("torch's CPU generator draws other numbers here than in the container that made the fixture")
+    want = torch.from_numpy(z["idx"].astype(np.int64)).to(dev)
+    kw = meta["kwargs"]
+    Q = kw["num_quantizers"]
+    sd = {}
+    for k in z.files:
+        if k.startswith("before/"):
+            for q in range(Q):
+                sd[k[len("before/"):].replace("layers.0.", f"layers.{q}.")] = torch.from_numpy(np.array(z[k]))
+    for q in range(Q):
+        sd[f"layers.{q}._codebook.embed_avg"] = sd[f"layers.{q}._codebook.embed"].clone()
+    mode = 0 if not meta["grad"] else (2 if kw.get("rotation_trick", True) else 1)
+
+    outs = {}
+    for path in ("fused", "staged"):
+        mod = ResidualVQ(**kw)
+        mod.load_state_dict(sd, strict=True)
+        mod = mod.to(dev).train()
+        if path == "staged":
+            monkeypatch.setattr(mod, "_fused_eligible", lambda *a, **k: False)
+        xin = x.to(dev).requires_grad_(meta["grad"])
+        q, idx, losses = mod(xin)
+        outs[path] = (q.detach(), idx, losses.detach())
+    (qa, ia, la), (qb, ib, lb) = outs["fused"], outs["staged"]
+    assert torch.equal(ia, ib), f"fused vs staged: {int((ia != ib).any(-1).sum())} rows differ"
+    _close(qa, qb, 1e-6, "quantized, fused vs staged")
+    _close(la, lb, 1e-5, "losses, fused vs staged")
+    _close(la, torch.from_numpy(np.array(z["losses"])), 1e-5, "losses vs the reference")
+
+    diff = (ia != want)
+    rows = diff.any(-1).reshape(-1).nonzero().reshape(-1)
+    n_rows = ia.numel() // Q
+    report = dict(rows_differing=int(rows.numel()), of=n_rows)
+    if rows.numel():
+        # float64 audit of every parted row at its FIRST differing stage: the residual re-derived along the common prefix, then the
+        # distance to the reference's code and to ours -- a near-tie iff the two are within a few ulp of the fp32 distance
+        embed = torch.from_numpy(np.array(z["before/layers.0._codebook.embed"]))[0].to(dev).double()
+        first = diff.reshape(-1, Q)[rows].int().argmax(-1)
+        r = x.to(dev).reshape(-1, x.shape[-1])[rows].double()
+        mine, ref = ia.reshape(-1, Q)[rows], want.reshape(-1, Q)[rows]
+        gap_ulp = torch.zeros(rows.numel(), device=dev, dtype=torch.float64)
+        for q in range(Q):
+            at = first == q
+            if at.any():
+                d_me = (r[at] - embed[mine[at, q]]).norm(dim=-1)
+                d_ref = (r[at] - embed[ref[at, q]]).norm(dim=-1)
+                ulp = torch.tensor(np.spacing(d_ref.float().cpu().numpy()), device=dev, dtype=torch.float64)
+                gap_ulp[at] = (d_me - d_ref).abs() / ulp
+            r = r - _route64(r, embed[mine[:, q]], mode)
+        report.update(max_gap_ulp=float(gap_ulp.max()), first_stage_histogram=torch.bincount(first, minlength=Q).tolist())
+        assert float(gap_ulp.max()) <= 8.0, f"{name}: a parted row is not a near-tie: {report}"
+    print(f"[big golden {name}] {report}")
+    # the reference's own with-grad vs no-grad sequences part on 76 of these rows; the budget is of that order
+    assert rows.numel() <= 96, f"{name}: {report}"
+
+
 @pytest.mark.parametrize("case", ["shared_rot", "separate_ste", "bf16", "masked", "no_route", "dropout"])
 def test_residual_vq_input_grad_runs_the_on_device_loop_and_matches_the_staged_path(dev, monkeypatch, case):
     """An input that requires grad used to send ResidualVQ to the per-stage autograd path.  It now takes the same
@@ -953,22 +1041,20 @@ def test_residual_vq_input_grad_runs_the_on_device_loop_and_matches_the_staged_p
         qa, ia, la = a(xa, mask=mask, **fk)
         qb, ib, lb = b(xb, mask=mask, **fk)
         assert qa.dtype == dtype and la.dtype == torch.float32
-        # The two paths may part on a near-tie: the staged path subtracts the ROUTED value from the residual (x + (q - x) or the rotated
-        # x, as rvq.py:524 does -- equal to the code row only up to an fp32 rounding), the on-device loop the code row itself.  A row
-        # whose two best codes are closer than that rounding then continues with another code (seen about once in 10^5 row-stages).
-        same = (ia == ib).all(-1)
-        flips = int((~same).sum())
-        assert flips <= 3, f"{flips} rows of {same.numel()} took different codes"
-        loose = tol if flips == 0 else max(tol, 2e-3)           # a parted row moves its codes' means and the mean loss by 1 / rows-per-code
-        _close(qa.float()[same], qb.float()[same], tol, "quantized")
-        _close(la, lb, loose, "losses")
+        # both paths subtract the layer's ROUTED value from the residual (rvq.py:524) in the same arithmetic (vq_route_math.h)
+        assert torch.equal(ia, ib), f"{int((ia != ib).any(-1).sum())} rows took different codes"
+        _close(qa.float(), qb.float(), tol, "quantized")
+        _close(la, lb, tol, "losses")
         w = torch.randn(qa.shape, device=dev).to(dtype)
         ((qa * w).float().sum() + 3.0 * la.sum()).backward()
         ((qb * w).float().sum() + 3.0 * lb.sum()).backward()
-        _close(xa.grad.float()[same], xb.grad.float()[same], tol, "grad_x")
-        _close(a.codebooks.float(), b.codebooks.float(), loose, "codebooks")
+        _close(xa.grad.float(), xb.grad.float(), tol, "grad_x")
+        _close(a.codebooks.float(), b.codebooks.float(), tol, "codebooks")
         b.load_state_dict(a.state_dict())
-    assert calls == [False, True, False, True], calls       # one routed forward and one backward launch per step, on module a only
+    if case == "bf16":            # bf16 rows with routed gradients: the chain covers fp32 rows only -> the per-stage path, no rvq_route launch
+        assert calls == [], calls
+    else:
+        assert calls == [False, True, False, True], calls   # one routed forward and one backward launch per step, on module a only
 
 
 def test_grouped_residual_vq_input_grad_on_strided_chunks(dev, monkeypatch):

@@ -5,6 +5,6 @@ from .codebook import Codebook
 from .vector_quantize import VectorQuantize, LossBreakdown
 from .residual_vq import ResidualVQ, GroupedResidualVQ
 from .sim_vq import SimVQ, ResidualSimVQ
-from .callers import RandomProjectionQuantizer
+from .callers import HierarchicalVQ, RandomProjectionQuantizer
 
-__all__ = ["VectorQuantize", "ResidualVQ", "GroupedResidualVQ", "SimVQ", "ResidualSimVQ", "RandomProjectionQuantizer", "Codebook", "LossBreakdown"]
+__all__ = ["VectorQuantize", "ResidualVQ", "GroupedResidualVQ", "SimVQ", "ResidualSimVQ", "RandomProjectionQuantizer", "HierarchicalVQ", "Codebook", "LossBreakdown"]

@@ -78,7 +78,7 @@ def lib():
     L.vqhip_ema_renormalize_shard.argtypes = [vp, vp, vp, i32, i32, f32, vp, i32, i32, vp, vp]
     L.vqhip_ema_renormalize_shard.restype = i32
     # (x, dtype, N, D, ldx, embed, embed_qstride, C, idx, idx_stride, Q, mode, g_out, ldg, loss_coef, row_mask, backward, out, ldo, stream)
-    L.vqhip_rvq_route.argtypes = [vp, i32, i64, i32, i64, vp, i64, i32, vp, i64, i32, i32, vp, i64, vp, vp, i32, vp, i64, vp]
+    L.vqhip_rvq_route.argtypes = [vp, i32, i64, i32, i64, vp, i64, i32, vp, i64, i32, i32, i32, vp, i64, vp, vp, i32, vp, i64, vp]
     L.vqhip_route_bwd.restype = i32
     L.vqhip_ema_workspace_bytes.restype = ctypes.c_size_t
     L.vqhip_ema_workspace_bytes.argtypes = [i64, i32]
@@ -342,7 +342,7 @@ def l2norm_rows(x: torch.Tensor) -> torch.Tensor:
 
 class _Chain(ctypes.Structure):          # vqhip_chain_t (include/vqhip.h)
     _fields_ = [("idx_stride", ctypes.c_int64), ("prev_idx", ctypes.c_void_p), ("prev_idx_stride", ctypes.c_int64),
-                ("prev_embed", ctypes.c_void_p), ("x_out", ctypes.c_void_p), ("ldxo", ctypes.c_int64)]
+                ("prev_embed", ctypes.c_void_p), ("x_out", ctypes.c_void_p), ("ldxo", ctypes.c_int64), ("route_mode", ctypes.c_int64)]
 
 
 def rvq_chain_supported(x: torch.Tensor, C: int) -> bool:
@@ -358,13 +358,15 @@ def rvq_chain_supported(x: torch.Tensor, C: int) -> bool:
 
 @_on_device
 def rvq_forward_chained(x: torch.Tensor, packed: torch.Tensor, embed: torch.Tensor, Q: int, *, row_mask=None, stage_hook=None,
-                        fill_masked=True):
+                        fill_masked=True, route_mode=0):
     """The residual loop (rvq.py:469-568) as Q chained screened searches: stage q's kernel forms its input
     inputs[q-1] - embed[idx[:, q-1]] in its prologue and stores it as inputs[q]; no stage re-reads its input to write a residual,
     and every stage writes its column of idx directly.  No q / squared-error outputs: the caller's statistics pass sums the loss
     (ema_accumulate(sqerr_from=...)).  -> dict(idx [..., Q], inputs [Q tensors], n_exact / n_pair per stage).
     fill_masked=False: the caller writes the -1 of the masked rows itself (mask_fill_indices) -- needed when stage_hook hands `idx`
-    to work on ANOTHER stream, which may still be reading it when this function returns."""
+    to work on ANOTHER stream, which may still be reading it when this function returns.
+    route_mode (0 / STRAIGHT_THROUGH / ROTATION): what each layer returned as `quantized`, i.e. what rvq.py:524 subtracted -- the
+    code row, or the routed value of a training step whose input requires grad (the arithmetic of route_fwd, bit for bit)."""
     _need_gpu(x, packed, embed, row_mask)
     shared = embed.ndim == 2
     xk, N, D, ldx = as_rows(x)
@@ -379,7 +381,7 @@ def rvq_forward_chained(x: torch.Tensor, packed: torch.Tensor, embed: torch.Tens
     inputs, counts = [x], []
     for q in range(Q):
         ws = torch.empty((nws + 3) // 4, dtype=torch.int32, device=dev)
-        ch = _Chain(idx_stride=Q, prev_idx=None, prev_idx_stride=Q, prev_embed=None, x_out=None, ldxo=D)
+        ch = _Chain(idx_stride=Q, prev_idx=None, prev_idx_stride=Q, prev_embed=None, x_out=None, ldxo=D, route_mode=int(route_mode))
         src, lds = xk, ldx
         if q > 0:
             prev_e = embed if shared else embed[q - 1]
@@ -505,11 +507,12 @@ def route_bwd(x: torch.Tensor, q: torch.Tensor, g_out, loss_coef, row_mask, mode
 
 @_on_device
 def rvq_route(x: torch.Tensor, embed: torch.Tensor, idx: torch.Tensor, Q: int, mode: int, *, g_out=None, loss_coef=None,
-              row_mask=None, backward=False) -> torch.Tensor:
+              row_mask=None, backward=False, resid_routed=False, loss_only=False) -> torch.Tensor:
     """The residual loop's routed output (backward=False) or the gradient wrt x (backward=True) in ONE kernel that keeps the
     residual row in registers (csrc: vq_rvq_route_kernel; rvq.py:469-568 with quant_grad_frac = 0).
     x [..., D]; embed fp32 [Q', C, D] or [C, D] (shared); idx int64 [..., Q'] (first Q columns are used); mode 0 / STRAIGHT_THROUGH /
-    ROTATION; loss_coef: [Q] fp32 device tensor, d loss / d (sum of squared errors of stage q)."""
+    ROTATION; loss_coef: [Q] fp32 device tensor, d loss / d (sum of squared errors of stage q).  resid_routed: the residuals are
+    re-derived as r - route(r, c) (what rvq.py:524 subtracts when the layers returned routed values) instead of r - c."""
     _need_gpu(x, embed, idx, g_out, loss_coef, row_mask)
     xk, N, D, ldx = as_rows(x)
     assert idx.dtype == torch.int64 and idx.is_contiguous() and embed.dtype == torch.float32 and embed.is_contiguous()
@@ -522,7 +525,7 @@ def rvq_route(x: torch.Tensor, embed: torch.Tensor, idx: torch.Tensor, Q: int, m
         C, qstride = embed.shape[1], embed.shape[1] * embed.shape[2]
     assert embed.shape[-1] == D
     gk, ldg = None, 0
-    if backward and mode != 0:
+    if backward and mode != 0 and not loss_only:       # loss_only: no upstream gradient for the output (treated as zero)
         gk, _, _, ldg = as_rows(g_out.to(x.dtype))
     if loss_coef is not None:
         loss_coef = loss_coef.to(torch.float32).reshape(-1).contiguous()
@@ -533,7 +536,7 @@ def rvq_route(x: torch.Tensor, embed: torch.Tensor, idx: torch.Tensor, Q: int, m
     out = torch.empty(x.shape, dtype=x.dtype, device=x.device)
     if N > 0:
         _check(lib().vqhip_rvq_route(_ptr(xk), _dtype_code(xk), N, D, ldx, _ptr(embed), qstride, C, _ptr(idx), qs, Q, mode,
-                                     _ptr(gk), ldg, _ptr(loss_coef), _ptr(row_mask), 1 if backward else 0, _ptr(out), D, _stream()),
+                                     1 if resid_routed else 0, _ptr(gk), ldg, _ptr(loss_coef), _ptr(row_mask), 1 if backward else 0, _ptr(out), D, _stream()),
                "vqhip_rvq_route")
     return out
 

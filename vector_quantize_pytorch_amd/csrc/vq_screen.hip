@@ -37,6 +37,7 @@
 #include "vqhip_internal.h"
 
 #include "vq_screen_args.h"
+#include "vq_route_math.h"
 
 #ifdef VQ_TRACE
 extern long long *vq_g_trace;
@@ -94,7 +95,9 @@ template <int DT> struct Screen16Cfg {
 // NPART = 2 (fp32 rows, D <= 128, where two operand sets per row block still fit the registers): x' = x_h + x_m, both truncated
 // fp16 parts (|x' - x_h - x_m| <= 2^-20 |x'|), two MFMAs per k-step on one A fragment -- the x side then costs the certificate
 // 2^-20 X Y instead of the measured 2^-11-level residual, which brings the uncertified fraction of fp32 rows down to bf16 levels.
-template <int DT, int METRIC, bool XF32 = false, int NPART = 1>
+// ROUTED: the chain prologue subtracts the previous layer's ROUTED value (a.prev_route = 1 / 2) instead of its code row -- an
+// instantiation of its own, so that the row reductions' registers do not weigh on the prologue of the default kernel.
+template <int DT, int METRIC, bool XF32 = false, int NPART = 1, bool ROUTED = false>
 __global__ void __launch_bounds__(VQS_WAVES * 64, 8 / VQS_WAVES) vq_screen16_kernel(const ScreenArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -254,6 +257,21 @@ __global__ void __launch_bounds__(VQS_WAVES * 64, 8 / VQS_WAVES) vq_screen16_ker
                         f32x4 e[NSTEP];
 #pragma unroll
                         for (int st = 0; st < NSTEP; ++st) e[st] = *(const f32x4 *)(pe + st * CH);
+                        if constexpr (ROUTED) {
+                            // the previous layer returned the ROUTED value (straight-through / rotation trick: training with an input
+                            // that requires grad, vqp.py:1225-1233) and rvq.py:524 subtracted that: the same arithmetic as
+                            // vq_route_kernel / vq_rvq_route_kernel (vq_route_math.h; this lane's elements are the 16-lane row
+                            // layout's, so the sums are formed in the same order), bit for bit
+                            float rv[4 * NSTEP], cv[4 * NSTEP], tv[4 * NSTEP];
+#pragma unroll
+                            for (int st = 0; st < NSTEP; ++st) {
+                                rv[4 * st + 0] = g[st][i].x; rv[4 * st + 1] = g[st][i].y; rv[4 * st + 2] = g[st][i].z; rv[4 * st + 3] = g[st][i].w;
+                                cv[4 * st + 0] = e[st].x; cv[4 * st + 1] = e[st].y; cv[4 * st + 2] = e[st].z; cv[4 * st + 3] = e[st].w;
+                            }
+                            vq_route_value<4 * NSTEP, LPR>(rv, cv, a.prev_route, tv);
+#pragma unroll
+                            for (int st = 0; st < NSTEP; ++st) e[st] = f32x4{tv[4 * st + 0], tv[4 * st + 1], tv[4 * st + 2], tv[4 * st + 3]};
+                        }
 #pragma unroll
                         for (int st = 0; st < NSTEP; ++st) {
                             g[st][i] = g[st][i] - e[st];
@@ -1242,6 +1260,14 @@ static int launch_screen(const ScreenArgs &a, int x_dtype, hipStream_t st)
                 // (NPART = 2 fits the registers for D <= 128 and halves the uncertified rows of fp32 inputs, but its second MFMA per
                 //  k-step costs more than the exact passes it saves: cfg 5 26.0 vs 23.5 ms -- measured, not adopted)
                 constexpr int NP = 1;
+                if (a.prev_idx && a.prev_route != 0) {
+                    if constexpr (METRIC == 0) {       // (the chain is Euclidean only)
+                        static VqAttrOnce once_r;
+                        if (int rc = vq_set_max_smem(once_r, (const void *)vq_screen16_kernel<DT, METRIC, true, NP, true>, SMEM16, "vq_screen16_kernel (fp32 rows, routed chain)")) return rc;
+                        hipLaunchKernelGGL((vq_screen16_kernel<DT, METRIC, true, NP, true>), dim3(blocks), dim3(VQS_WAVES * 64), SMEM16, st, a);
+                        return vq_launch_status("vq_screen16_kernel (fp32 rows, routed chain)");
+                    }
+                }
                 if (int rc = vq_set_max_smem(once, (const void *)vq_screen16_kernel<DT, METRIC, true, NP>, SMEM16, "vq_screen16_kernel (fp32 rows)")) return rc;
                 hipLaunchKernelGGL((vq_screen16_kernel<DT, METRIC, true, NP>), dim3(blocks), dim3(VQS_WAVES * 64), SMEM16, st, a);
                 return vq_launch_status("vq_screen16_kernel (fp32 rows)");
@@ -1297,6 +1323,7 @@ extern "C" int vqhip_assign_screened_chain(const void *x, int x_dtype, int64_t N
             VQ_FAIL(VQHIP_EINVAL, "assign_screened_chain: prev_idx needs prev_embed, x_out and valid strides");
         if ((((uintptr_t)chain->prev_embed) & 15) || (((uintptr_t)chain->x_out) & 15) || ((chain->ldxo * 4) & 15))
             VQ_FAIL(VQHIP_EALIGN, "assign_screened_chain: prev_embed / x_out rows must be 16-byte aligned");
+        if (chain->route_mode < 0 || chain->route_mode > 2) VQ_FAIL(VQHIP_EINVAL, "assign_screened_chain: route_mode must be 0, 1 or 2");
     }
     return assign_screened_impl(x, x_dtype, N, D, ldx, packed, embed, C, metric, idx_out, nullptr, D, nullptr, D, nullptr, row_mask,
                                 workspace, workspace_bytes, nullptr, chain, stream);
@@ -1355,6 +1382,7 @@ static int assign_screened_impl(const void *x, int x_dtype, int64_t N, int D, in
     a.prev_embed = chain ? chain->prev_embed : nullptr;
     a.x_out = chain ? (float *)chain->x_out : nullptr;
     a.ldxo = chain ? chain->ldxo : 0;
+    a.prev_route = (chain && chain->prev_idx) ? (int)chain->route_mode : 0;
 #ifdef VQ_TRACE
     a.trace = vq_g_trace;
 #endif

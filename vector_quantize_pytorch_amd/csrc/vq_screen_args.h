@@ -45,6 +45,7 @@ struct ScreenArgs {
     const float *prev_embed;           // [C_prev, D] fp32
     float *x_out;
     int64_t ldxo;
+    int prev_route;                    // what the previous layer returned (and rvq.py:524 subtracted): 0 the code row, 1 straight-through, 2 rotation trick
     // segmented lists (vq_screenc_kernel: every workgroup appends to its own segment, no global atomics; vq_compact_lists_kernel
     // packs the segments into flag_rows / flag_keys and writes flag_count)
     int *seg_counts;                   // [2 * VQ_SEG_MAX]: open, pair entries per segment

@@ -30,6 +30,7 @@
 #include <type_traits>
 
 #include "vqhip_internal.h"
+#include "vq_route_math.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -606,7 +607,7 @@ __global__ void __launch_bounds__(256, (DT <= 256 ? 2 : 1)) vq_assign_kernel(con
                 }
                 if (code < a.C) {
                     const float nm = fmaxf(lse_m, v);
-                    lse_l = lse_l * __expf(lse_m - nm) + __expf(v - nm);     // (-inf - finite -> exp = 0 on the first code)
+                    lse_l = lse_l * expf(lse_m - nm) + expf(v - nm);     // (-inf - finite -> exp = 0 on the first code)
                     lse_m = nm;
                     if ((int64_t)code == tgt) ts = v;
                 }
@@ -626,10 +627,10 @@ __global__ void __launch_bounds__(256, (DT <= 256 ? 2 : 1)) vq_assign_kernel(con
     if (a.lse_out) {          // merge the half-waves' (max, sum) pairs; the target's score sits in exactly one of them
         const float om = __shfl_xor(lse_m, 32, 64), ol = __shfl_xor(lse_l, 32, 64), ot = __shfl_xor(ts, 32, 64);
         const float M = fmaxf(lse_m, om);
-        const float Lsum = lse_l * __expf(lse_m - M) + ol * __expf(om - M);
+        const float Lsum = lse_l * expf(lse_m - M) + ol * expf(om - M);
         if (row_ok && hi == 0) {
-            a.lse_out[row] = M + __logf(Lsum);
-            if (a.tscore_out) a.tscore_out[row] = a.target ? (tgt < 0 ? 0.f : ts + ot) : ((METRIC == 0) ? -bd : bd);
+            a.lse_out[row] = M + logf(Lsum);
+            if (a.tscore_out) a.tscore_out[row] = a.target ? (tgt < 0 ? 0.f : (tgt >= a.C ? __builtin_nanf("") : ts + ot)) : ((METRIC == 0) ? -bd : bd);   // target >= C: NaN (F.cross_entropy raises there; no silent 0)
         }
     }
     if (row_ok && hi == 0) {
@@ -2093,40 +2094,7 @@ extern "C" int vqhip_rvq_forward(const void *x, int x_dtype, int64_t N, int D, i
 //   commit loss mean((q.detach() - x)^2) (vqp.py:1327): grad_x += coef * 2 (x - q), coef = dL/d(sum of squares),
 //   a DEVICE scalar (no host sync), rows with row_mask == 0 excluded.
 // ------------------------------------------------------------------------------------------------
-// Sum over the 64 lanes, the same value in every lane.  DPP butterfly inside each row of 16 lanes (quad_perm, row_half_mirror,
-// row_mirror: VALU only), then the four row sums through v_readlane -- no LDS traffic.  (The first version was six __shfl_xor =
-// ds_bpermute round trips; with five reductions per row and stage the routing kernels ran at 1.5 TB/s of row traffic, LDS-queue bound.)
-__device__ __forceinline__ float wave_sum(float v)
-{
-    auto dpp = [](float x, auto ctrl) {
-        return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), decltype(ctrl)::value, 0xf, 0xf, true));
-    };
-    v += dpp(v, std::integral_constant<int, 0xB1>{});    // quad_perm [1, 0, 3, 2]
-    v += dpp(v, std::integral_constant<int, 0x4E>{});    // quad_perm [2, 3, 0, 1]
-    v += dpp(v, std::integral_constant<int, 0x141>{});   // row_half_mirror
-    v += dpp(v, std::integral_constant<int, 0x140>{});   // row_mirror: every lane of a row holds the row's sum
-    const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
-    const float r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
-    const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
-    const float r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
-    return (r0 + r1) + (r2 + r3);
-}
-
-// Sum over the LPR lanes that share a row, the same value in each of them.  LPR = 16: one DPP row = one tensor row, four rows
-// per wave, no scalar step at all.
-template <int LPR>
-__device__ __forceinline__ float row_sum(float v)
-{
-    if (LPR == 64) return wave_sum(v);
-    auto dpp = [](float x, auto ctrl) {
-        return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), decltype(ctrl)::value, 0xf, 0xf, true));
-    };
-    v += dpp(v, std::integral_constant<int, 0xB1>{});
-    v += dpp(v, std::integral_constant<int, 0x4E>{});
-    v += dpp(v, std::integral_constant<int, 0x141>{});
-    v += dpp(v, std::integral_constant<int, 0x140>{});
-    return v;
-}
+// (row reductions and the routed value itself: vq_route_math.h, shared with the screening kernel's chain prologue)
 
 // Rows per wave of the routing kernels.  One wave per row (LPR = 64) spends most of its instructions on the five row reductions
 // of a rotation-trick stage (4 DPP + 4 v_readlane + 3 adds each) for 4 elements per lane -- and half its lanes idle at D = 128.
@@ -2213,48 +2181,19 @@ __global__ void __launch_bounds__(256) vq_route_kernel(const RouteArgs a)
     if (LPR == 64 && !valid) return;
     const int64_t n = valid ? n0 : a.N - 1;            // (rows share a wave: the ones past the end repeat the last row and store nothing)
     float e[NE], qv[NE], g[NE];
-    float se = 0.f, sq = 0.f;
     row_load8<BF16, NE, LPR>(a.x, n * a.ldx, a.D, lane, a.vec != 0, e);
     row_load8<BF16, NE, LPR>(a.q, n * a.ldq, a.D, lane, a.vec != 0, qv);
     if (BWD && a.g) row_load8<BF16, NE, LPR>(a.g, n * a.ldg, a.D, lane, a.vec != 0, g);
-#pragma unroll
-    for (int k = 0; k < NE; ++k) {
-        if (!(BWD && a.g)) g[k] = 0.f;
-        se += e[k] * e[k];
-        sq += qv[k] * qv[k];
-    }
     float r[NE];
-    if (a.mode == 2) {
-        const float ne = sqrtf(row_sum<LPR>(se)), nq = sqrtf(row_sum<LPR>(sq));
-        const float de = fmaxf(ne, 1e-6f), dq = fmaxf(nq, 1e-6f);
-        const float ide = 1.f / de, idq = 1.f / dq;       // one reciprocal per row, then multiplies (x / |x| to 1 ulp): IEEE divisions per
-        float u[NE], qh[NE], w[NE];                       // element made these kernels ALU-bound (1.5 TB/s of row traffic)
-        float st = 0.f;
-#pragma unroll
-        for (int k = 0; k < NE; ++k) {
-            u[k] = e[k] * ide;
-            qh[k] = qv[k] * idq;
-            w[k] = u[k] + qh[k];
-            st += w[k] * w[k];
-        }
-        const float nt = fmaxf(sqrtf(row_sum<LPR>(st)), 1e-6f);
-        const float int_ = 1.f / nt;
-        float a1 = 0.f, a2 = 0.f;
-#pragma unroll
-        for (int k = 0; k < NE; ++k) {
-            w[k] = w[k] * int_;
-            if (BWD) { a1 += g[k] * w[k]; a2 += g[k] * qh[k]; }
-            else     { a1 += e[k] * w[k]; a2 += e[k] * u[k]; }
-        }
-        a1 = row_sum<LPR>(a1);
-        a2 = row_sum<LPR>(a2);
-        const float sc = nq / de;
-#pragma unroll
-        for (int k = 0; k < NE; ++k)
-            r[k] = BWD ? sc * (g[k] - 2.f * a1 * w[k] + 2.f * a2 * u[k]) : (e[k] - 2.f * a1 * w[k] + 2.f * a2 * qh[k]) * sc;
+    if (!BWD) {
+        vq_route_value<NE, LPR, BF16>(e, qv, a.mode, r);            // vq_route_math.h (mode 1 / 2)
+    } else if (a.mode == 2 && a.g) {
+        float u[NE], qh[NE], w[NE], sc;
+        vq_rot_frame<NE, LPR>(e, qv, u, qh, w, sc);
+        vq_rot_bwd<NE, LPR>(g, u, qh, w, sc, r);
     } else {
 #pragma unroll
-        for (int k = 0; k < NE; ++k) r[k] = BWD ? g[k] : (e[k] + (qv[k] - e[k]));
+        for (int k = 0; k < NE; ++k) r[k] = a.g ? g[k] : 0.f;
     }
     if (BWD && a.loss_coef) {
         const bool counted = !a.row_mask || a.row_mask[n] != 0;
@@ -2334,6 +2273,7 @@ struct RvqRouteArgs {
     const uint8_t *row_mask;
     int64_t N, ldx, ldg, ldo;
     int D, Q, mode, vec;
+    int resid_routed;          // the residual loop subtracted the routed value (mode != 0), not the code row, between stages
 };
 
 template <bool BF16, bool BWD, int NE, int LPR>
@@ -2362,49 +2302,30 @@ __global__ void __launch_bounds__(256) vq_rvq_route_kernel(const RvqRouteArgs a)
         const int64_t code = alive ? code0 : 0;
         const float *cp = a.embed + (size_t)q * a.qstride + (size_t)code * a.D;
         float c[NE];
-        float se = 0.f, sq = 0.f;
         row_load8<false, NE, LPR>(cp, 0, a.D, lane, (a.D & 3) == 0, c);   // code rows: fp32, [C, D] contiguous, 16-byte aligned when D % 4 == 0
+        if (BF16) {
 #pragma unroll
-        for (int k = 0; k < NE; ++k) {
-            if (BF16) c[k] = round_to_bf16(c[k]);
-            se += r[k] * r[k];
-            sq += c[k] * c[k];
+            for (int k = 0; k < NE; ++k) c[k] = round_to_bf16(c[k]);
         }
-        float t[NE];
-        if (a.mode == 2) {                                       // rotation trick: the arithmetic of vq_route_kernel
-            const float ne = sqrtf(row_sum<LPR>(se)), nq = sqrtf(row_sum<LPR>(sq));
-            const float de = fmaxf(ne, 1e-6f), dq = fmaxf(nq, 1e-6f);
-            const float ide = 1.f / de, idq = 1.f / dq;
-            float u[NE], qh[NE], w[NE];
-            float st = 0.f;
-#pragma unroll
-            for (int k = 0; k < NE; ++k) {
-                u[k] = r[k] * ide;
-                qh[k] = c[k] * idq;
-                w[k] = u[k] + qh[k];
-                st += w[k] * w[k];
-            }
-            const float nt = fmaxf(sqrtf(row_sum<LPR>(st)), 1e-6f);
-            const float int_ = 1.f / nt;
-            float a1 = 0.f, a2 = 0.f;
-#pragma unroll
-            for (int k = 0; k < NE; ++k) {
-                w[k] = w[k] * int_;
-                if (BWD) { a1 += g[k] * w[k]; a2 += g[k] * qh[k]; }
-                else     { a1 += r[k] * w[k]; a2 += r[k] * u[k]; }
-            }
-            a1 = row_sum<LPR>(a1);
-            a2 = row_sum<LPR>(a2);
-            const float sc = nq / de;
-#pragma unroll
-            for (int k = 0; k < NE; ++k)
-                t[k] = BWD ? sc * (g[k] - 2.f * a1 * w[k] + 2.f * a2 * u[k]) : (r[k] - 2.f * a1 * w[k] + 2.f * a2 * qh[k]) * sc;
-        } else if (a.mode == 1) {
-#pragma unroll
-            for (int k = 0; k < NE; ++k) t[k] = BWD ? g[k] : (r[k] + (BF16 ? round_to_bf16(c[k] - r[k]) : (c[k] - r[k])));
+        // tf: the value the layer returns for this row (vq_route_math.h) -- what the forward sums, and with resid_routed what
+        // rvq.py:524 subtracts from the residual.  t: this stage's term of the output (forward) / of dL/dx (backward).
+        float t[NE], tf[NE];
+        const bool need_tf = !BWD || (a.resid_routed && a.mode != 0);
+        if (a.mode == 2) {                                       // rotation trick
+            float u[NE], qh[NE], w[NE], sc;
+            vq_rot_frame<NE, LPR>(r, c, u, qh, w, sc);
+            if (need_tf) vq_rot_fwd<NE, LPR>(r, u, qh, w, sc, tf);
+            if (BWD) vq_rot_bwd<NE, LPR>(g, u, qh, w, sc, t);
         } else {
+            if (need_tf) vq_route_value<NE, LPR, BF16>(r, c, a.mode, tf);
+            if (BWD) {
 #pragma unroll
-            for (int k = 0; k < NE; ++k) t[k] = BWD ? 0.f : c[k];
+                for (int k = 0; k < NE; ++k) t[k] = a.mode == 1 ? g[k] : 0.f;
+            }
+        }
+        if (!BWD) {
+#pragma unroll
+            for (int k = 0; k < NE; ++k) t[k] = tf[k];
         }
         if (BWD && a.loss_coef && counted) {
             const float c2 = 2.f * a.loss_coef[q];
@@ -2412,10 +2333,16 @@ __global__ void __launch_bounds__(256) vq_rvq_route_kernel(const RvqRouteArgs a)
             for (int k = 0; k < NE; ++k) t[k] += c2 * (r[k] - c[k]);
         }
         if (alive) {
+            // the next stage's input: residual - quantized.detach() (rvq.py:524).  `quantized` is the ROUTED value when the layer
+            // routed gradients to its input (training, input requires grad: vqp.py:1225-1233), else the code row itself;
+            // bf16 tensors round after every tensor op.
+            const bool routed = a.resid_routed && a.mode != 0;
 #pragma unroll
             for (int k = 0; k < NE; ++k) {
-                if (BF16 && !BWD) { acc[k] = round_to_bf16(acc[k] + round_to_bf16(t[k])); r[k] = round_to_bf16(r[k] - c[k]); }
-                else              { acc[k] += t[k]; r[k] = BF16 ? round_to_bf16(r[k] - c[k]) : (r[k] - c[k]); }
+                const float sub = routed ? (BF16 ? round_to_bf16(tf[k]) : tf[k]) : c[k];
+                if (BF16 && !BWD) acc[k] = round_to_bf16(acc[k] + round_to_bf16(t[k]));
+                else              acc[k] += t[k];
+                r[k] = BF16 ? round_to_bf16(r[k] - sub) : (r[k] - sub);
             }
         }
     }
@@ -2423,7 +2350,7 @@ __global__ void __launch_bounds__(256) vq_rvq_route_kernel(const RvqRouteArgs a)
 }
 
 extern "C" int vqhip_rvq_route(const void *x, int dtype, int64_t N, int D, int64_t ldx, const float *embed, int64_t embed_qstride,
-                               int C, const int64_t *idx, int64_t idx_stride, int Q, int mode, const void *g_out, int64_t ldg,
+                               int C, const int64_t *idx, int64_t idx_stride, int Q, int mode, int resid_routed, const void *g_out, int64_t ldg,
                                const float *loss_coef, const uint8_t *row_mask, int backward, void *out, int64_t ldo, void *stream)
 {
     if (N < 0 || !x || !embed || !idx || !out || C <= 0) VQ_FAIL(VQHIP_EINVAL, "rvq_route: bad argument");
@@ -2431,12 +2358,11 @@ extern "C" int vqhip_rvq_route(const void *x, int dtype, int64_t N, int D, int64
     if (Q < 1 || idx_stride < Q) VQ_FAIL(VQHIP_EINVAL, "rvq_route: Q=%d, idx_stride=%lld", Q, (long long)idx_stride);
     if (mode < 0 || mode > 2) VQ_FAIL(VQHIP_EINVAL, "rvq_route: mode must be 0 (plain sum / loss only), 1 or 2");
     if (dtype != VQHIP_F32 && dtype != VQHIP_BF16) VQ_FAIL(VQHIP_EINVAL, "rvq_route: unknown dtype");
-    if (backward && mode != 0 && !g_out) VQ_FAIL(VQHIP_EINVAL, "rvq_route: backward with a routing mode needs g_out");
     if (N == 0) return 0;
     RvqRouteArgs a;
     a.x = x; a.g = (backward && mode != 0) ? g_out : nullptr; a.out = out; a.embed = embed; a.qstride = embed_qstride;
     a.idx = idx; a.idx_stride = idx_stride; a.loss_coef = backward ? loss_coef : nullptr; a.row_mask = row_mask;
-    a.N = N; a.ldx = ldx; a.ldg = ldg; a.ldo = ldo; a.D = D; a.Q = Q; a.mode = mode;
+    a.N = N; a.ldx = ldx; a.ldg = ldg; a.ldo = ldo; a.D = D; a.Q = Q; a.mode = mode; a.resid_routed = resid_routed;
     const int es = dtype == VQHIP_BF16 ? 2 : 4;
     a.vec = rows_vec4(x, ldx, D, es) && rows_vec4(a.g, ldg, D, es) && rows_vec4(out, ldo, D, es);
     if ((D & 3) == 0 && ((((uintptr_t)embed) & 15) || (embed_qstride & 3))) VQ_FAIL(VQHIP_EALIGN, "rvq_route: embed must be 16-byte aligned");

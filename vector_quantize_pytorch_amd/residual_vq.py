@@ -225,9 +225,13 @@ class ResidualVQ(nn.Module):
 
         if is_beam:
             quantized_out, all_indices, all_losses = self._forward_beam(x, mask, sample_codebook_temp, freeze_codebook, beam_size, drop_at)
-        elif self._fused_eligible(x, mask):
+        elif self._fused_eligible(x, mask) and not (self._wants_input_grad(x) and self._route_mode() != 0
+                                                    and not self._chain_eligible(x, freeze_codebook)):
             if self._wants_input_grad(x):
-                # the same on-device loop, gradients to the input in closed form (one kernel forward, one backward)
+                # the same on-device loop, gradients to the input in closed form (one kernel forward, one backward).  With
+                # routed gradients every layer RETURNS the straight-through / rotation-trick value and rvq.py:524 subtracts
+                # that from the residual, so the searches run as the chain with route_mode (anything the chain does not
+                # cover -- bf16 rows, D = 512 -- took the per-stage path above).
                 quantized_out, all_indices, all_losses = _RvqFusedFn.apply(x, self, mask, freeze_codebook, drop_at)
             else:
                 quantized_out, all_indices, all_losses = self._forward_fused(x, mask, freeze_codebook, drop_at)
@@ -271,10 +275,32 @@ class ResidualVQ(nn.Module):
         # which changes `embed` before the next stage's search -- a stage-by-stage dependency the fused loop cannot honour
         if self.shared_codebook and cb0.has_dead_code_replacement and self.training:
             return False
+        if mask is not None and not all(layer.return_zeros_for_masked_padding for layer in self.layers):
+            return False                                     # (masked rows keep their input: the per-stage path's fill)
         return all(layer._codebook._is_initted() for layer in self.layers)     # k-means runs in the staged path
 
     def _wants_input_grad(self, x):
         return self.training and x.requires_grad and torch.is_grad_enabled()
+
+    def _route_mode(self):
+        """what a layer returns as `quantized` for an input that requires grad (vqp.py:1225-1233)"""
+        vq0 = self.layers[0]
+        if not vq0.route_gradients_to_input:
+            return 0
+        return L.ROTATION if vq0.rotation_trick else L.STRAIGHT_THROUGH
+
+    def _update_and_loss(self, freeze_codebook):
+        vq0 = self.layers[0]
+        update = self.training and not (freeze_codebook or vq0.freeze_codebook) and \
+            (vq0._codebook.ema_update or vq0._codebook.has_dead_code_replacement)
+        return update, self.training and vq0.has_commitment_loss
+
+    def _chain_eligible(self, x, freeze_codebook):
+        """the residual chain (csrc: vqhip_assign_screened_chain): fp32 rows, D in {32, 64, 128, 256}; the per-stage commitment
+        loss comes from the statistics pass, so a loss without an EMA update has no producer there"""
+        update, want_loss = self._update_and_loss(freeze_codebook)
+        return bool(L.screening_enabled() and self.codebook_dim in (32, 64, 128, 256) and L.rvq_chain_supported(x, self.codebook_size)
+                    and (update or not want_loss))
 
     @torch.no_grad()
     def _forward_fused(self, x, mask, freeze_codebook, drop_at, aux=None):
@@ -290,9 +316,8 @@ class ResidualVQ(nn.Module):
         else:
             embed = torch.stack([layer._codebook.embed[0] for layer in self.layers[:Q]]).contiguous()
             packed = torch.stack([L.pack_codebook(embed[q]) for q in range(Q)])
-        update = train and not (freeze_codebook or vq0.freeze_codebook) and \
-            (vq0._codebook.ema_update or vq0._codebook.has_dead_code_replacement)
-        want_loss = train and vq0.has_commitment_loss
+        update, want_loss = self._update_and_loss(freeze_codebook)
+        route_mode = self._route_mode() if aux is not None else 0       # aux: called from _RvqFusedFn (the input requires grad)
         buf = side = None
         if update:
             # statistics of ALL stages in one buffer [Q, C D + C] (embed_sum || count per stage): under data parallelism ONE
@@ -303,7 +328,8 @@ class ResidualVQ(nn.Module):
         # Residual chain (csrc: vqhip_assign_screened_chain): every stage forms its input x_prev - code in its own prologue, so no
         # stage re-reads its input to write a residual; the commitment loss' squared error then comes from the per-stage
         # statistics pass, which reads every row next to its code anyway (needs `update`; without a loss nothing is needed)
-        chain = (L.screening_enabled() and D in (32, 64, 128, 256) and L.rvq_chain_supported(x, C) and (update or not want_loss))
+        chain = self._chain_eligible(x, freeze_codebook)
+        assert chain or route_mode == 0, "routed residuals need the chain (ResidualVQ.forward sends the rest to the per-stage path)"
         sq_parts = None
         if chain and want_loss:             # one [Q, P] buffer of loss partials: one batched reduction after the loop
             nrows = x.numel() // D
@@ -340,7 +366,8 @@ class ResidualVQ(nn.Module):
             # (with a side-stream hook the -1 of the masked rows is written only after that stream has been joined below: its
             #  statistics passes read `idx`)
             if chain:
-                r = L.rvq_forward_chained(x, packed, embed, Q, row_mask=mask, stage_hook=hook, fill_masked=hook is None)
+                r = L.rvq_forward_chained(x, packed, embed, Q, row_mask=mask, stage_hook=hook, fill_masked=hook is None,
+                                          route_mode=route_mode)
             else:
                 r = L.rvq_forward_screened(x, packed, embed, Q, want_resid=update, want_sqerr=want_loss, row_mask=mask, stage_hook=hook,
                                            fill_masked=hook is None)
@@ -504,9 +531,11 @@ class ResidualVQ(nn.Module):
 
 class _RvqFusedFn(torch.autograd.Function):
     """ResidualVQ's on-device loop for an input that requires grad.  Forward = the same chained search / statistics / EMA fold as
-    the no-grad path, the output formed by vq_rvq_route_kernel (sum over the stages of the straight-through / rotation-trick
-    value, rvq.py:525 + vqp.py:1225-1233); backward = the closed form of the reference's graph with quant_grad_frac = 0
-    (rvq.py:524: every stage's input is x minus DETACHED codes, so d r_q / d x = I):
+    the no-grad path, except that every stage's input is the previous one minus the previous layer's ROUTED value (the chain's
+    route_mode: rvq.py:524 subtracts `quantized.detach()`, which is the straight-through / rotation-trick value here); the
+    output is formed by vq_rvq_route_kernel (sum over the stages of that value, rvq.py:525 + vqp.py:1225-1233); backward = the
+    closed form of the reference's graph with quant_grad_frac = 0 (every stage's input is x minus DETACHED values, so
+    d r_q / d x = I):
         dL/dx = sum_q J_q^T g_out + sum_q g_loss[q] * commitment_weight * 2 (r_q - c_q) / count
     in one kernel that recomputes r_q from x and the saved indices (nothing per stage is kept)."""
 
@@ -514,11 +543,8 @@ class _RvqFusedFn(torch.autograd.Function):
     def forward(ctx, x, rvq, mask, freeze_codebook, drop_at):
         aux = {}
         _, idx, losses = rvq._forward_fused(x, mask, freeze_codebook, drop_at, aux=aux)
-        vq0 = rvq.layers[0]
-        mode = 0
-        if vq0.route_gradients_to_input:
-            mode = L.ROTATION if vq0.rotation_trick else L.STRAIGHT_THROUGH
-        out = L.rvq_route(x, aux["embed"], idx, aux["Q"], mode)
+        mode = rvq._route_mode()
+        out = L.rvq_route(x, aux["embed"], idx, aux["Q"], mode, resid_routed=True)
         ctx.mode, ctx.Q, ctx.loss_scale, ctx.has_mask = mode, aux["Q"], aux.get("loss_scale"), mask is not None
         ctx.save_for_backward(x, idx, aux["embed"], *([mask] if mask is not None else []))
         ctx.mark_non_differentiable(idx)
@@ -534,8 +560,8 @@ class _RvqFusedFn(torch.autograd.Function):
         use_g = ctx.mode != 0 and g_out is not None
         if not use_g and coef is None:
             return None, None, None, None, None
-        gx = L.rvq_route(x, embed, idx, ctx.Q, ctx.mode if use_g else 0, g_out=g_out.contiguous() if use_g else None,
-                         loss_coef=coef, row_mask=mask, backward=True)
+        gx = L.rvq_route(x, embed, idx, ctx.Q, ctx.mode, g_out=g_out.contiguous() if use_g else None,
+                         loss_coef=coef, row_mask=mask, backward=True, resid_routed=True, loss_only=not use_g)
         return gx, None, None, None, None
 
 

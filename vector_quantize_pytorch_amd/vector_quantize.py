@@ -103,11 +103,13 @@ class _CrossEntropyFn(torch.autograd.Function):
     CHUNK_BYTES = 1 << 27
 
     @staticmethod
-    def forward(ctx, x, embed, embed_at_search, codes, cosine):
+    def forward(ctx, x, embed, embed_at_search, codes, cosine, count=None):
+        """count (optional 0-dim tensor): the number of valid targets the mean runs over when this call covers only a part of
+        them (one head of a multi-headed module: the reference takes ONE mean over all heads, vqp.py:1242-1256)"""
         e = embed_at_search.detach().float().contiguous()
         lse, ts, _ = L.scores_lse(x.detach(), L.pack_codebook(e), e, codes, cosine=cosine, skip_l2norm=True)
         valid = codes.reshape(lse.shape) >= 0
-        count = valid.sum()
+        count = valid.sum() if count is None else count
         ctx.cosine = cosine
         ctx.save_for_backward(x, embed, e, codes, count)
         return torch.where(valid, lse - ts, torch.zeros_like(lse)).sum() / count
@@ -129,7 +131,7 @@ class _CrossEntropyFn(torch.autograd.Function):
             dist, _, _ = L.scores(xc, packed, e_search, cosine=ctx.cosine, skip_l2norm=True)      # [rows, C], as in the forward
             p = dist.softmax(dim=-1)
             ok = tc >= 0
-            p[ok, tc[ok]] -= 1.0
+            p.scatter_add_(1, tc.clamp(min=0)[:, None], -ok.to(p.dtype)[:, None])                  # - onehot (no host sync)
             p = torch.where(ok[:, None], p, torch.zeros_like(p)) * scale                           # d loss / d dist
             xf = xc.float()
             if ctx.cosine:                                                                         # dist = x . e
@@ -144,7 +146,7 @@ class _CrossEntropyFn(torch.autograd.Function):
                     gx[i:i + step] = w @ ef - w.sum(-1, keepdim=True) * xf
                 if need_e:
                     ge -= w.sum(0)[:, None] * ef - w.t() @ xf
-        return (gx.reshape(x.shape).to(x.dtype) if need_x else None, ge.to(embed.dtype) if need_e else None, None, None, None)
+        return (gx.reshape(x.shape).to(x.dtype) if need_x else None, ge.to(embed.dtype) if need_e else None, None, None, None, None)
 
 
 class _ScoresFn(torch.autograd.Function):
@@ -586,8 +588,8 @@ class VectorQuantize(nn.Module):
             q, ind, loss = self._sharded(self.project_in(xs))
             q = self.project_out(q)
             return (q if self.channel_last else q.transpose(1, 2)), ind, loss
-        if (indices is not None or topk is not None) and self.heads > 1:
-            raise NotImplementedError("forward(indices= / topk=) is implemented for heads == 1 only")
+        if topk is not None and self.heads > 1:
+            raise NotImplementedError("forward(topk=) is implemented for heads == 1 only")
         L._need_gpu(x)
         return_loss = indices is not None
         orig_input = x
@@ -621,7 +623,10 @@ class VectorQuantize(nn.Module):
         # options that read the WHOLE score row as a matrix (top-k, the diversity loss' batch-averaged softmax, gumbel noise / its
         # straight-through softmax) materialise `dist`; the cross-entropy losses alone do not: they stream a log-sum-exp (_CrossEntropyFn)
         need_matrix = (topk is not None or self.has_codebook_diversity_loss or self.stochastic_sample_codes or self.gumbel_straight_through)
-        ce_only = (return_loss or self.commitment_use_cross_entropy_loss) and not need_matrix and codebook_transform_fn is None
+        # (with an in-place optimizer the second search runs on the stepped codebook and the reference recomputes `dist` from it,
+        #  vqp.py:1186-1210: that case keeps the dense path, which does the same)
+        ce_only = ((return_loss or self.commitment_use_cross_entropy_loss) and not need_matrix and codebook_transform_fn is None
+                   and self.in_place_codebook_optimizer is None)
         dense = need_matrix or ((return_loss or self.commitment_use_cross_entropy_loss) and not ce_only)
         param_path = (self._codebook.learnable_codebook or self._codebook.vq_bridge is not None or self.directional_reparam or dense
                       or ce_only or codebook_transform_fn is not None)
@@ -639,7 +644,9 @@ class VectorQuantize(nn.Module):
         if param_path:
             if ce_only:     # the codebook the search is about to use, live and as a snapshot (the EMA fold inside the search rewrites
                 cb0 = self._codebook                                                  # `embed` in place; see _CrossEntropyFn)
-                ce_embed = (cb0.embed if cb0.vq_bridge is None else cb0.vq_bridge(cb0.embed))[0]
+                if not cb0._is_initted():     # k-means init runs BEFORE the reference computes `dist` (vqp.py:718-720): snapshot after it
+                    cb0.init_embed_(xs.detach().reshape(1, -1, xs.shape[-1]).float(), None if rmask is None else rmask.reshape(1, -1))
+                ce_embed = cb0.embed if cb0.vq_bridge is None else cb0.vq_bridge(cb0.embed)        # [H, C, D]
                 if not cb0.learnable_codebook:
                     ce_embed = ce_embed.detach()
                 ce_embed_at_search = ce_embed.detach().clone()
@@ -665,10 +672,18 @@ class VectorQuantize(nn.Module):
             anchor = None
             loss = torch.zeros((), device=x.device, dtype=torch.float32)
         commit_loss = self.zero
-        def ce_loss(codes):                                                          # vqp.py:1242-1256, heads == 1
-            if distances is None:
-                return _CrossEntropyFn.apply(xs, ce_embed, ce_embed_at_search, codes, self.use_cosine_sim)
-            return F.cross_entropy(distances.permute(0, 2, 1), codes, ignore_index=-1)
+        def ce_loss(codes):                                                          # vqp.py:1242-1256
+            if distances is not None:                                                # (dense path: heads == 1)
+                return F.cross_entropy(distances.permute(0, 2, 1), codes, ignore_index=-1)
+            if self.heads == 1:
+                return _CrossEntropyFn.apply(xs, ce_embed[0], ce_embed_at_search[0], codes, self.use_cosine_sim)
+            # multi-headed: codes [b, n, h]; the reference takes one mean over every (row, head) target
+            if not self.separate_codebook_per_head:                                  # rows [(b h), n, d], one codebook
+                codes_bh = codes.permute(0, 2, 1).reshape(xs.shape[0], xs.shape[1])
+                return _CrossEntropyFn.apply(xs, ce_embed[0], ce_embed_at_search[0], codes_bh, self.use_cosine_sim)
+            total = (codes >= 0).sum()                                               # rows [h, b, n, d], one codebook per head
+            return sum(_CrossEntropyFn.apply(xs[h], ce_embed[h], ce_embed_at_search[h], codes[..., h].contiguous(), self.use_cosine_sim, total)
+                       for h in range(self.heads))
 
         if return_loss:                                                              # vqp.py:1260-1261
             return quantize, ce_loss(indices)
