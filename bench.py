@@ -151,6 +151,10 @@ def _windows(run_step, steps, windows, sync):
     return dts
 
 
+def _mean(v):
+    return None if not v else round(sum(v) / len(v), 5)
+
+
 def _median(v):
     return sorted(v)[len(v) // 2]
 
@@ -187,8 +191,15 @@ def _time_grad_step(mod, batches, steps, warmup, sync, windows):
     return _windows(step, steps, windows, sync)
 
 
-def other_workload(args, world, rank, dev):
-    """BASELINE configs 3, 4 and 5 (informational; the contract line is vq_cfg2)."""
+def other_workload(args, world, rank, dev, workload=None, steps=None, warmup=None, windows=None):
+    """BASELINE configs 3, 4 and 5 (informational; the contract line is vq_cfg2).  Returns the JSON line as a dict (rank 0) or None."""
+    class _A:        # the same measurement under other step counts (the compact `other_workloads` object of the default line)
+        pass
+    a2 = _A()
+    a2.__dict__.update(vars(args))
+    a2.workload = workload or args.workload
+    a2.steps, a2.warmup, a2.windows = steps or args.steps, (args.warmup if warmup is None else warmup), windows or args.windows
+    args = a2
     from vector_quantize_pytorch_amd import GroupedResidualVQ, ResidualVQ, _lib
     from vector_quantize_pytorch_amd.parallel import ShardedVectorQuantize
     torch.manual_seed(0)
@@ -280,7 +291,7 @@ def other_workload(args, world, rank, dev):
             traffic, traffic_src = tj["bytes_per_step"], tj.get("source")
     except Exception:
         pass
-    print(json.dumps({"metric": "vectors quantized/sec", "value": n * args.steps / dt, "unit": "vectors/s", "n_gpus": world,
+    return ({"metric": "vectors quantized/sec", "value": n * args.steps / dt, "unit": "vectors/s", "n_gpus": world,
                       "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
                       "scaling": "strong" if strong else "weak", "vs_baseline": None,
                       "dtype": "f16+f32" if screened else "f32", "data": "synthetic",
@@ -296,7 +307,7 @@ def other_workload(args, world, rank, dev):
                       "roofline": {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
                                    "traffic": traffic, "traffic_source": traffic_src, "achieved_vs_fp32_mfma_peak": ach / PEAK_FP32_MFMA_TFLOPS,
                                    "note": "whole step (all kernels) PER GPU, not one kernel; algorithmic flops (2*C*D per vector and stage); "
-                                           "peak = dense f16 MFMA when the search runs screened (VQHIP_SCREEN != 0), fp32 MFMA otherwise"}}), flush=True)
+                                           "peak = dense f16 MFMA when the search runs screened (VQHIP_SCREEN != 0), fp32 MFMA otherwise"}})
 
 
 # ----------------------------------------------------------------------------------------------------------------------
@@ -450,6 +461,27 @@ def vq_cfg2(args, world, rank, dev):
             out["cpu_baseline"] = base
             parity.update(audit)
         out["parity"] = parity
+        if not args.no_other_workloads:
+            # BASELINE configs 3 / 4 (one rank's shard work) / 5 under the driver's clock as well: the same measurement as
+            # `--workload X`, fewer steps, compacted (a few seconds in total)
+            del batches, q, idx, loss, last
+            vq = None
+            torch.cuda.empty_cache()
+            ow = {}
+            for wl, st in (("rvq_cfg3", 10), ("grvq_cfg5", 5), ("vq_cfg4_shard", 10)):
+                try:
+                    r = other_workload(args, 1, 0, dev, workload=wl, steps=st, warmup=2, windows=3)
+                    ow[wl] = {"ms_per_step": round(r["ms_per_step"], 4), "vectors_per_s": r["value"],
+                              "grad_ms_per_step": None if r["grad_step"] is None else round(r["grad_step"]["ms_per_step"], 4),
+                              "frac_of_f16_mfma_peak_whole_step": round(r["roofline"]["frac"], 4),
+                              "first_forward_ms": round(r["config"]["first_forward_ms"], 2),
+                              "open_frac_mean": _mean((r["config"]["uncertified_rows_per_search"] or {}).get("open_frac")),
+                              "pair_frac_mean": _mean((r["config"]["uncertified_rows_per_search"] or {}).get("pair_frac")),
+                              "steps": st, "windows": 3, "workload": r["config"]["workload"]}
+                except Exception as ex:      # the contract line must not die with an informational one
+                    ow[wl] = {"error": f"{type(ex).__name__}: {ex}"}
+                torch.cuda.empty_cache()
+            out["other_workloads"] = ow
     print(json.dumps(out), flush=True)
 
 
@@ -469,6 +501,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-adversarial", action="store_true")
     ap.add_argument("--no-grad-step", action="store_true", help="skip the requires_grad + backward measurement (grad_step)")
+    ap.add_argument("--no-other-workloads", action="store_true", help="skip the compact rvq_cfg3 / grvq_cfg5 / vq_cfg4_shard lines of the default run")
     ap.add_argument("--windows", type=int, default=5, help="timed windows of --steps steps each; the median window is reported")
     ap.add_argument("--workload", default="vq_cfg2", choices=["vq_cfg2", "rvq_cfg3", "grvq_cfg5", "vq_cfg4_shard", "vq_cfg4_sharded"],
                     help="vq_cfg2 (default) is BASELINE.json's headline configuration; the others are informational")
@@ -500,7 +533,9 @@ def main():
         if args.workload == "vq_cfg2":
             vq_cfg2(args, world, rank, dev)
         else:
-            other_workload(args, world, rank, dev)
+            line = other_workload(args, world, rank, dev)
+            if line is not None:
+                print(json.dumps(line), flush=True)
     finally:
         if world > 1:
             dist.destroy_process_group()

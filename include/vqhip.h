@@ -285,6 +285,20 @@ int vqhip_kmeans_update(float *means, const float *embed_sum, const float *count
 int vqhip_score_indices(const void *x, int x_dtype, int64_t N, int D, int64_t ldx, const float *packed, const float *embed,
                         int C, int metric, const int64_t *idx, float *out, void *stream);
 
+/* K11 helper of the codebook-sharded argmin (vq_pack_best_u64 / unpack; no counterpart in the reference, which only
+ * replicates codebooks -- its tie rule is ATen argmax's first occurrence, vector_quantize_pytorch.py:140).
+ * vqhip_pack_best: key_out[n] = (sortable(negate ? -best[n] : best[n]) << 32) | (0xFFFFFFFF - (idx[n] + index_offset)) as int64:
+ *   key order == (score to MAXIMISE, then LOWER global index), so ONE all_reduce(MAX) of N x 8 bytes over the shards yields the
+ *   global winner.  best: the shard's winning distance (negate = 1, Euclidean) or similarity (negate = 0); idx: index inside the
+ *   shard; index_offset: the shard's first global code.  Global indices must stay below 2^32.
+ * vqhip_unpack_best: after the reduction -- gidx_out[n] (nullable) the winning global index, local_out[n] (nullable) that index
+ *   relative to own_lo if this rank owns it (own_lo <= g < own_hi) else -1 (what vqhip_decode_sum / vqhip_ema_accumulate skip),
+ *   best_out[n] (nullable) the winning score with the sign of the input restored.  One launch each. */
+int vqhip_pack_best(const float *best, const int64_t *idx, int64_t N, int64_t index_offset, int negate, int64_t *key_out,
+                    void *stream);
+int vqhip_unpack_best(const int64_t *key, int64_t N, int64_t own_lo, int64_t own_hi, int negate, int64_t *gidx_out,
+                      int64_t *local_out, float *best_out, void *stream);
+
 /* A separate codebook per row (QINCo's implicit neural codebook; reference: Codebook.forward(codebook_transform_fn=),
  * vector_quantize_pytorch.py:729-738: dist = -F.pairwise_distance(x[..., None, :], transformed) or the cosine einsum, then argmax).
  * x [N, D] fp32 at row stride ldx, codes [N, C, D] fp32 contiguous: idx_out[n] = argmin_c ||x_n - codes[n, c] + 1e-6||_2

@@ -696,3 +696,28 @@ def test_assign_rowwise_matches_pairwise_distance(dev, N, C, D, cos):
     codes[:, C - 1] = codes[:, 0]
     x2 = codes[:, 0].clone()
     assert (L.assign_rowwise(x2, codes, cosine=cos) == 0).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("negate", [False, True])
+def test_pack_unpack_best_equals_the_key_algebra(dev, negate):
+    """vqhip_pack_best / vqhip_unpack_best (the K11 helper of the codebook-sharded argmin) against the torch restatement of the key
+    (parallel.pack_score_index): bit-identical keys, key order == (score, then lower index), ownership mask and local index."""
+    from vector_quantize_pytorch_amd.parallel import pack_score_index, unpack_score_index
+    g = torch.Generator().manual_seed(5)
+    N, lo, hi, off = 100_003, 8192, 16384, 8192
+    s = torch.randn(N, generator=g)
+    s[:7] = torch.tensor([0.0, -0.0, float("inf"), -float("inf"), 1e-45, -1e-45, 3.0])
+    s[100:200] = s[300:400]                                   # equal scores: the lower index must win
+    idx = torch.randint(0, hi - lo, (N,), generator=g)
+    key = L.pack_best(s.to(dev), idx.to(dev), off, negate=negate)
+    ref = pack_score_index(-s if negate else s, idx + off)
+    assert torch.equal(key.cpu(), ref)
+    other = pack_score_index(-s.roll(1) if negate else s.roll(1), idx.roll(1) + 3 * off)     # "another shard's" keys
+    red = torch.maximum(ref, other).to(dev)
+    gidx, local, best = L.unpack_best(red, lo, hi, negate=negate, want_best=True)
+    s2, i2 = unpack_score_index(red.cpu())
+    assert torch.equal(gidx.cpu(), i2)
+    assert torch.equal(best.cpu().view(torch.int32), (-s2 if negate else s2).view(torch.int32))
+    mine = (i2 >= lo) & (i2 < hi)
+    assert torch.equal(local.cpu(), torch.where(mine, i2 - lo, torch.full_like(i2, -1)))

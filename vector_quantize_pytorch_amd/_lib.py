@@ -100,6 +100,10 @@ def lib():
     L.vqhip_expire_scatter.restype = i32
     L.vqhip_kmeans_update.argtypes = [vp, vp, vp, i32, i32, i32, vp]
     L.vqhip_kmeans_update.restype = i32
+    L.vqhip_pack_best.argtypes = [vp, vp, i64, i64, i32, vp, vp]
+    L.vqhip_pack_best.restype = i32
+    L.vqhip_unpack_best.argtypes = [vp, i64, i64, i64, i32, vp, vp, vp, vp]
+    L.vqhip_unpack_best.restype = i32
     for name in ("vqhip_pack_codebook", "vqhip_assign", "vqhip_reduce_partials", "vqhip_ema_accumulate",
                  "vqhip_ema_finalize", "vqhip_decode_sum", "vqhip_row_sumsq", "vqhip_assign_rowwise", "vqhip_score_indices", "vqhip_topk", "vqhip_expire_scatter", "vqhip_kmeans_update", "vqhip_route_fwd", "vqhip_route_bwd", "vqhip_rvq_route", "vqhip_ema_renormalize_shard", "vqhip_scores_lse"):
         getattr(L, name).restype = i32
@@ -110,7 +114,8 @@ def lib():
 EXPORTS = ("vqhip_version", "vqhip_last_error", "vqhip_packed_bytes", "vqhip_pack_codebook",
            "vqhip_assign_blocks", "vqhip_assign", "vqhip_screen_supported", "vqhip_screen_workspace_bytes",
            "vqhip_screen_blocks", "vqhip_screen_partials", "vqhip_assign_screened", "vqhip_screen_chain_supported", "vqhip_assign_screened_chain", "vqhip_l2norm_rows", "vqhip_scores", "vqhip_rvq_forward", "vqhip_reduce_partials", "vqhip_reduce_partials_rows", "vqhip_ema_fold_many", "vqhip_ema_workspace_bytes", "vqhip_ema_accumulate", "vqhip_ema_sqerr_partials", "vqhip_ema_accumulate_sqerr",
-           "vqhip_ema_finalize", "vqhip_decode_sum", "vqhip_row_sumsq", "vqhip_assign_rowwise", "vqhip_score_indices", "vqhip_topk", "vqhip_expire_scatter", "vqhip_kmeans_update", "vqhip_route_fwd", "vqhip_route_bwd", "vqhip_rvq_route", "vqhip_ema_renormalize_shard", "vqhip_scores_lse")
+           "vqhip_ema_finalize", "vqhip_decode_sum", "vqhip_row_sumsq", "vqhip_assign_rowwise", "vqhip_score_indices", "vqhip_topk", "vqhip_expire_scatter", "vqhip_kmeans_update", "vqhip_route_fwd", "vqhip_route_bwd", "vqhip_rvq_route", "vqhip_ema_renormalize_shard", "vqhip_scores_lse",
+           "vqhip_pack_best", "vqhip_unpack_best")
 
 
 def _check(rc, what):
@@ -708,6 +713,29 @@ def score_indices(x: torch.Tensor, packed: torch.Tensor, embed2d: torch.Tensor, 
         _check(lib().vqhip_score_indices(_ptr(xk), _dtype_code(xk), N, D, ldx, _ptr(packed), _ptr(embed2d), embed2d.shape[0],
                                          COSINE_PRENORM if cosine else EUCLID, _ptr(idx), _ptr(out), _stream()), "vqhip_score_indices")
     return out
+
+
+@_on_device
+def pack_best(best: torch.Tensor, local_index: torch.Tensor, index_offset: int, *, negate: bool) -> torch.Tensor:
+    """(shard winner's score, index inside the shard) -> order-preserving int64 key for the MAX all-reduce (vqhip_pack_best)."""
+    _need_gpu(best, local_index)
+    assert best.dtype == torch.float32 and local_index.dtype == torch.int64 and best.numel() == local_index.numel()
+    best, local_index = best.contiguous(), local_index.contiguous()
+    key = torch.empty(best.shape, dtype=torch.int64, device=best.device)
+    _check(lib().vqhip_pack_best(_ptr(best), _ptr(local_index), best.numel(), int(index_offset), int(negate), _ptr(key), _stream()), "vqhip_pack_best")
+    return key
+
+
+@_on_device
+def unpack_best(key: torch.Tensor, lo: int, hi: int, *, negate: bool, want_best=False):
+    """reduced keys -> (global index, index inside [lo, hi) or -1[, winning score]) in one launch (vqhip_unpack_best)."""
+    _need_gpu(key)
+    assert key.dtype == torch.int64
+    key = key.contiguous()
+    gidx, local = torch.empty_like(key), torch.empty_like(key)
+    best = torch.empty(key.shape, dtype=torch.float32, device=key.device) if want_best else None
+    _check(lib().vqhip_unpack_best(_ptr(key), key.numel(), int(lo), int(hi), int(negate), _ptr(gidx), _ptr(local), _ptr(best), _stream()), "vqhip_unpack_best")
+    return (gidx, local, best) if want_best else (gidx, local)
 
 
 TOPK_MAX = 8

@@ -3218,6 +3218,60 @@ extern "C" int vqhip_kmeans_update(float *means, const float *embed_sum, const f
 }
 
 // ------------------------------------------------------------------------------------------------
+// K11 helper of the codebook-sharded argmin (vector_quantize_pytorch_amd/parallel.py): the per-shard winner
+// (score, global index) as ONE order-preserving int64 key, so that a single all_reduce(MAX) of N x 8 bytes picks the global
+// winner with ATen argmax's first-occurrence rule (vqp.py:140).  High word: the IEEE-754 bits of the score TO MAXIMISE mapped
+// to a signed int32 that sorts like the float (negative floats: magnitude bits flipped); low word: 0xFFFFFFFF - index, so that
+// among equal scores the LOWEST index has the LARGEST key.  (torch has no uint64 collectives, hence the signed construction.)
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) vq_pack_best_kernel(const float *__restrict__ best, const int64_t *__restrict__ idx, int64_t N,
+                                                           int64_t offset, int negate, int64_t *__restrict__ key)
+{
+    const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    float s = best[n];
+    if (negate) s = -s;
+    int b = __float_as_int(s);
+    b = b < 0 ? (b ^ 0x7FFFFFFF) : b;
+    const int64_t g = idx[n] + offset;
+    key[n] = (int64_t)(((uint64_t)(uint32_t)b << 32) | (uint64_t)(uint32_t)(0xFFFFFFFFu - (uint32_t)g));
+}
+
+__global__ void __launch_bounds__(256) vq_unpack_best_kernel(const int64_t *__restrict__ key, int64_t N, int64_t lo, int64_t hi, int negate,
+                                                             int64_t *__restrict__ gidx, int64_t *__restrict__ local, float *__restrict__ best)
+{
+    const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    const uint64_t k = (uint64_t)key[n];
+    const int64_t g = (int64_t)(0xFFFFFFFFu - (uint32_t)(k & 0xFFFFFFFFull));
+    int b = (int)(uint32_t)(k >> 32);
+    b = b < 0 ? (b ^ 0x7FFFFFFF) : b;
+    if (gidx) gidx[n] = g;
+    if (local) local[n] = (g >= lo && g < hi) ? g - lo : -1;       // -1: another rank owns the winner (skipped by decode / EMA)
+    if (best) { const float s = __int_as_float(b); best[n] = negate ? -s : s; }
+}
+
+extern "C" int vqhip_pack_best(const float *best, const int64_t *idx, int64_t N, int64_t index_offset, int negate, int64_t *key_out,
+                               void *stream)
+{
+    if (N < 0 || (N > 0 && (!best || !idx || !key_out)) || index_offset < 0) VQ_FAIL(VQHIP_EINVAL, "pack_best: bad argument");
+    if (N == 0) return 0;
+    hipLaunchKernelGGL(vq_pack_best_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, (hipStream_t)stream, best, idx, N,
+                       index_offset, negate, key_out);
+    return launch_status("vq_pack_best_kernel");
+}
+
+extern "C" int vqhip_unpack_best(const int64_t *key, int64_t N, int64_t own_lo, int64_t own_hi, int negate, int64_t *gidx_out,
+                                 int64_t *local_out, float *best_out, void *stream)
+{
+    if (N < 0 || (N > 0 && !key) || own_lo > own_hi) VQ_FAIL(VQHIP_EINVAL, "unpack_best: bad argument");
+    if (N == 0) return 0;
+    hipLaunchKernelGGL(vq_unpack_best_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, (hipStream_t)stream, key, N, own_lo,
+                       own_hi, negate, gidx_out, local_out, best_out);
+    return launch_status("vq_unpack_best_kernel");
+}
+
+// ------------------------------------------------------------------------------------------------
 // decode: out[n,:] = sum_q embed_q[idx[n,q],:]   (sequential in q, like the reference's running sum)
 // ------------------------------------------------------------------------------------------------
 // one wave per output row.  The Q indices of a row are fetched first, then the code rows of 8 stages at a time are all

@@ -36,14 +36,30 @@ def unpack_score_index(key: torch.Tensor):
 
 
 def merge_sharded_argmin(best: torch.Tensor, local_index: torch.Tensor, shard_offset: int, *, euclid: bool,
-                         group=None):
+                         group=None, own=None):
     """best: winning distance (euclid) or similarity (cosine) of THIS rank's shard, local_index its index
-    inside the shard.  Returns (global index int64, global best fp32), identical on every rank."""
+    inside the shard.  Returns (global index int64, global best fp32), identical on every rank -- and, with
+    own=(lo, hi), (global index, index inside [lo, hi) or -1) instead.  Device tensors: ONE launch packs the keys
+    (vqhip_pack_best), one unpacks the reduced keys into everything the caller needs (vqhip_unpack_best); host tensors
+    (the gloo tests of the key algebra): the same arithmetic in torch ops."""
+    on = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+    if best.is_cuda:
+        from . import _lib as L
+        key = L.pack_best(best, local_index, shard_offset, negate=euclid)
+        if on:
+            dist.all_reduce(key, op=dist.ReduceOp.MAX, group=group)
+        if own is not None:
+            return L.unpack_best(key, own[0], own[1], negate=euclid)
+        gidx, _, s = L.unpack_best(key, 0, 0, negate=euclid, want_best=True)
+        return gidx, s
     score = -best if euclid else best
     key = pack_score_index(score, local_index + shard_offset)
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    if on:
         dist.all_reduce(key, op=dist.ReduceOp.MAX, group=group)
     s, idx = unpack_score_index(key)
+    if own is not None:
+        mine = (idx >= own[0]) & (idx < own[1])
+        return idx, torch.where(mine, idx - own[0], torch.full_like(idx, -1))
     return idx, (-s if euclid else s)
 
 
@@ -166,11 +182,11 @@ class ShardedVectorQuantize(torch.nn.Module):
         else:
             r = L.assign(allrows, packed, e, cosine=cos, skip_l2norm=True, want_q=False, want_best=True)
             best = r["best"]
-        gidx, _ = merge_sharded_argmin(best, r["idx"], self.lo, euclid=not cos, group=self.group if self._collectives_on() else None)
+        # (score, index) -> key, ONE all_reduce(MAX), key -> (global index, index inside this shard or -1): two launches around the collective
+        gidx, local = merge_sharded_argmin(best, r["idx"], self.lo, euclid=not cos, group=self.group if self._collectives_on() else None,
+                                           own=(self.lo, self.hi))
         if self._collectives_on():
             comm["all_reduce(MAX) keys"] = 2 * (P - 1) * gidx.numel() * 8 // P
-        mine = (gidx >= self.lo) & (gidx < self.hi)
-        local = torch.where(mine, gidx - self.lo, torch.full_like(gidx, -1))
         n_local = xin.shape[0]
         n_total = allrows.shape[0]
         C_l = self.hi - self.lo
