@@ -703,6 +703,7 @@ def test_assign_rowwise_matches_pairwise_distance(dev, N, C, D, cos):
 def test_pack_unpack_best_equals_the_key_algebra(dev, negate):
     """vqhip_pack_best / vqhip_unpack_best (the K11 helper of the codebook-sharded argmin) against the torch restatement of the key
     (parallel.pack_score_index): bit-identical keys, key order == (score, then lower index), ownership mask and local index."""
+    from vector_quantize_pytorch_amd import _lib as L
     from vector_quantize_pytorch_amd.parallel import pack_score_index, unpack_score_index
     g = torch.Generator().manual_seed(5)
     N, lo, hi, off = 100_003, 8192, 16384, 8192

@@ -1,11 +1,16 @@
 #!/bin/bash
-# round-4 second GPU call: per-kernel profile of the cfg-3 gradient step (regressed 3.6 -> 5.3 ms with the routed chain prologue),
-# and the default bench line with its new other_workloads object
+# per-kernel profile of the cfg-3 / cfg-5 gradient step (cfg 3 regressed 3.6 -> 5.3 ms with the routed chain prologue) and of the cfg-5 forward
 set -x
 O=$PWD/gpurun_out/r4b; mkdir -p $O
 export TMPDIR=/tmp
-(cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $O/prof_grad3 -o g3 -- python $GRAFT_REPO_ROOT/tools/grad_step.py rvq_cfg3 5 > $O/prof_grad3.log 2>&1)
-find $O/prof_grad3 -name '*kernel_stats.csv' | head -1 | xargs -I{} sh -c "cut -c1-160 {} | head -25" > $O/grad3_kernel_stats.txt
-find $O/prof_grad3 -name '*.db' -delete; find $O/prof_grad3 -name '*kernel_trace.csv' -delete
-timeout 600 python bench.py --no-cpu-baseline > $O/bench_default.json 2> $O/bench_default.err
-cat $O/grad3_kernel_stats.txt
+timeout 300 python -m pytest tests/test_gpu_ops.py -q -x -k "pack_unpack" 2>&1 | tail -3 > $O/test_pack.log
+prof() {  # tag, command...
+  tag=$1; shift
+  (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$tag -o t -- "$@" > $O/prof_$tag.log 2>&1)
+  f=$(find $O/prof_$tag -name '*kernel_stats.csv' | head -1)
+  [ -n "$f" ] && cut -c1-150 "$f" | head -30 > $O/${tag}_kernel_stats.txt
+  rm -rf $O/prof_$tag
+}
+prof grad3 python $GRAFT_REPO_ROOT/tools/grad_step.py rvq_cfg3 5
+prof grad5 python $GRAFT_REPO_ROOT/tools/grad_step.py grvq_cfg5 3
+cat $O/test_pack.log; cat $O/grad3_kernel_stats.txt
