@@ -337,6 +337,23 @@ def vq_cfg2(args, world, rank, dev):
         return r
 
     cbmod.L.assign = timed_assign
+    # the fused train step (vqhip_vq_train_step) contains the search: the library records the two events around it itself
+    orig_step = _lib.vq_train_step
+
+    def event_pair():
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); e1.record()                     # (creates the handles; the library records them again on the same stream)
+        ev.append((e0, e1))
+        return e0, e1
+
+    def counting_step(*a, **k):
+        r = orig_step(*a, **k)
+        exact_rows.append(r["n_exact"][0])
+        pair_rows.append(r["n_pair"][0])
+        return r
+
+    _lib.step_event_hook = event_pair
+    cbmod.L.vq_train_step = counting_step
 
     def sync():
         if world > 1:
@@ -360,6 +377,8 @@ def vq_cfg2(args, world, rank, dev):
         q, idx, loss = last[0]
 
     cbmod.L.assign = orig_assign
+    cbmod.L.vq_train_step = orig_step
+    _lib.step_event_hook = None
     gdts = None
     if not args.no_grad_step:
         gdts = _time_grad_step(vq, batches, args.steps, args.warmup, sync, args.windows)

@@ -121,6 +121,9 @@ typedef struct {
     void *x_out;                   /* [N, D] fp32 at row stride ldxo: receives this stage's input */
     int64_t ldxo;
     int64_t route_mode;            /* 0 / 1 / 2, see above */
+    int *hist;                     /* nullable [C] ints, zeroed by the caller: receives the rows per code of THIS stage (the counting sort of
+                                      vqhip_ema_accumulate_hist then skips its histogram pass); row_mask must be null */
+    int64_t header_zeroed;         /* != 0: the caller has zeroed the first 16 bytes of `workspace` on this stream (no memset launch) */
 } vqhip_chain_t;
 int vqhip_screen_chain_supported(int x_dtype, int D);
 int vqhip_assign_screened_chain(const void *x, int x_dtype, int64_t N, int D, int64_t ldx, const float *packed,
@@ -197,6 +200,35 @@ int vqhip_rvq_route(const void *x, int dtype, int64_t N, int D, int64_t ldx, con
 int vqhip_reduce_partials(const double *partials, int64_t n, double scale, float *out, void *stream);
 /* R rows of partials in one launch (the per-stage losses of a residual VQ): out[r] = scale * sum(partials[r * stride .. + n)). */
 int vqhip_reduce_partials_rows(const double *partials, int R, int64_t n, int64_t stride, double scale, float *out, void *stream);
+
+/* ---- fused train step ---------------------------------------------------------------------------
+ * One call = one training forward of a Euclidean EMA codebook (VectorQuantize.forward in training mode, vqp.py:1176 ->
+ * EuclideanCodebook.forward :673-800): pack the codebook, nearest-code search (screened, bit-identical indices), gather q,
+ * EMA statistics (count / embed_sum, vqp.py:602-606), the commitment loss' squared error (vqp.py:1327) and -- with fold != 0 --
+ * ema_inplace of cluster_size and embed_avg and update_ema (vqp.py:610-617, 576-584).  The same kernels as vqhip_pack_codebook +
+ * vqhip_assign_screened + vqhip_ema_accumulate_sqerr + vqhip_ema_finalize + vqhip_reduce_partials, minus what only exists between
+ * separate calls: one zeroing kernel for every counter / accumulator, no histogram pass (the search counts the rows per code),
+ * cluster_size folded inside the statistics' scan kernel, embed_avg / embed / loss in one tail kernel (11 launches, was 19).
+ * fold == 0 stops after the statistics (data parallel: all-reduce `stats`, then vqhip_ema_finalize).
+ * Requirements: vqhip_vq_step_supported(); x rows 16-byte aligned; no row mask; no dead-code replacement inside (caller's). */
+typedef struct {
+    const void *x; int64_t x_dtype; int64_t N; int64_t D; int64_t ldx;
+    float *embed; float *embed_avg; float *cluster_size; int64_t C;       /* [C, D], [C, D], [C]; updated in place when fold != 0 */
+    int64_t *idx_out;                                                     /* [N] */
+    void *q_out; int64_t ldq;                                             /* nullable; x's dtype */
+    float *stats;                                                         /* [C * D + C]: embed_sum || count of THIS batch (zeroed here) */
+    float *loss_out;                                                      /* nullable: loss_scale * sum (q - x)^2 */
+    double loss_scale;
+    float *packed;                                                        /* vqhip_packed_bytes(C, D) bytes, 16-byte aligned */
+    void *workspace; size_t workspace_bytes;                              /* vqhip_vq_step_workspace_bytes(N, C), 256-byte aligned */
+    double one_minus_decay; double eps;                                   /* (1 - decay) as the fp32 value ATen uses, Laplace eps */
+    int64_t fold;
+    void *ev_search_begin; void *ev_search_end;                           /* nullable hipEvent_t: recorded on `stream` around the search
+                                                                             (screen + exact passes) -- bench.py's roofline measurement */
+} vqhip_vq_step_t;
+int vqhip_vq_step_supported(int x_dtype, int64_t N, int D, int C);
+size_t vqhip_vq_step_workspace_bytes(int64_t N, int C);
+int vqhip_vq_train_step(const vqhip_vq_step_t *step, void *stream);
 
 /* ---- EMA sufficient statistics ----------------------------------------------------------------
  * Replaces embed_onehot.sum(1) and einsum('h n d, h n c -> h c d') (vqp.py:602, 605).

@@ -856,6 +856,46 @@ def test_commit_loss_from_the_statistics_pass_equals_the_search_kernels(dev, mon
         b.load_state_dict(a.state_dict())                                                     # same start for the next step
 
 
+@pytest.mark.parametrize("dtype,kw,shape", [(torch.bfloat16, dict(dim=256, codebook_size=1024), (4, 4099)),
+                                            (torch.float32, dict(dim=256, codebook_size=512), (3, 2000)),
+                                            (torch.float32, dict(dim=128, codebook_size=4096, decay=0.9), (2, 3000)),
+                                            (torch.bfloat16, dict(dim=64, codebook_size=37, threshold_ema_dead_code=2), (5, 777)),
+                                            (torch.bfloat16, dict(dim=512, codebook_size=2048, commitment_weight=0.25), (1, 6000))])
+def test_fused_train_step_equals_the_separate_calls(dev, monkeypatch, dtype, kw, shape):
+    """vqhip_vq_train_step (one call: zeroing kernel, pack, search that also counts the rows per code, statistics whose scan kernel
+    folds cluster_size, one tail kernel for embed_avg / embed / loss) against the separate calls it replaces (VQHIP_FUSED_STEP=0):
+    indices, q and cluster_size identical, loss / embed_avg / embed equal to the rounding of the fp32 atomics in the segmented sums;
+    several steps with an evolving codebook, with and without an input that requires grad."""
+    from vector_quantize_pytorch_amd import VectorQuantize, _lib
+    import vector_quantize_pytorch_amd.codebook as cbmod
+    torch.manual_seed(0)
+    a, b = VectorQuantize(**kw).to(dev).train(), VectorQuantize(**kw).to(dev).train()
+    b.load_state_dict(a.state_dict())
+    calls = []
+    orig = _lib.vq_train_step
+    monkeypatch.setattr(cbmod.L, "vq_train_step", lambda *ar, **k: (calls.append(1), orig(*ar, **k))[1])
+    for step in range(4):
+        x = torch.randn(*shape, kw["dim"], device=dev).to(dtype) * (1.0 + step)
+        xa, xb = x.clone().requires_grad_(step == 3), x.clone().requires_grad_(step == 3)
+        rng = torch.cuda.get_rng_state(dev)
+        monkeypatch.setenv("VQHIP_FUSED_STEP", "1")
+        qa, ia, la = a(xa)
+        torch.cuda.set_rng_state(rng, dev)
+        monkeypatch.setenv("VQHIP_FUSED_STEP", "0")
+        qb, ib, lb = b(xb)
+        assert len(calls) == step + 1, "the fused step did not serve the forward"
+        assert torch.equal(ia, ib) and torch.equal(qa, qb)
+        assert torch.allclose(la, lb, rtol=2e-6, atol=0)
+        assert torch.equal(a._codebook.cluster_size, b._codebook.cluster_size)
+        _close(a._codebook.embed_avg, b._codebook.embed_avg, 1e-5, "embed_avg")
+        _close(a._codebook.embed, b._codebook.embed, 1e-5, "embed")
+        if step == 3:
+            (qa.float().square().mean() + la.sum()).backward()
+            (qb.float().square().mean() + lb.sum()).backward()
+            assert torch.equal(xa.grad, xb.grad)
+        b.load_state_dict(a.state_dict())
+
+
 def test_qinco_implicit_neural_codebook_round_trip(dev):
     """ResidualVQ(implicit_neural_codebook=True) (rvq.py:107-162, 460-499): same parameter names as the reference (goldens rvq_qinco*
     pin values and gradients); here: decode from indices reproduces the forward's output, dropped quantizers decode to zero,

@@ -1,0 +1,58 @@
+"""Timeline of ONE steady-state step from a rocprofv3 kernel trace: every launch with its stream, start offset, duration and the idle gap
+on its stream since the previous kernel -- where the launch gaps and the small kernels of a step sit.
+    python tools/timeline.py <tag> [bench.py args...]        (on the GPU box; writes gpurun_out/<tag>/timeline.txt)
+A step starts at a `vq_pack_kernel` launch whose predecessor in time is not a pack kernel (the residual modules pack all their
+codebooks first); the LAST complete step of the run is printed."""
+import csv
+import glob
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def main():
+    tag = sys.argv[1]
+    bargs = sys.argv[2:] or ["--steps", "4", "--warmup", "2", "--windows", "1", "--no-grad-step", "--no-cpu-baseline", "--no-adversarial",
+                             "--no-other-workloads"]
+    out = os.path.join(ROOT, "gpurun_out", tag)
+    os.makedirs(out, exist_ok=True)
+    d = os.path.join(out, "trace")
+    env = dict(os.environ, TMPDIR="/tmp")
+    p = subprocess.run(["rocprofv3", "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "t", "--", sys.executable,
+                        os.path.join(ROOT, "bench.py")] + bargs, env=env, cwd="/tmp", stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    f = glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True)
+    if not f:
+        open(os.path.join(out, "timeline.txt"), "w").write("no trace\n" + p.stdout[-3000:])
+        return
+    rows = []
+    for r in csv.DictReader(open(f[0])):
+        rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r.get("Queue_Id", "?"), r.get("Stream_Id", "?")))
+    rows.sort()
+    short = lambda n: n.replace("void ", "").split("(")[0][:70]
+    starts = [i for i, r in enumerate(rows) if short(r[2]).startswith("vq_pack_kernel") and (i == 0 or not short(rows[i - 1][2]).startswith("vq_pack"))]
+    lines = []
+    if len(starts) >= 3:
+        a, b = starts[-3], starts[-2]          # (the very last step may be followed by the audit kernels)
+        t0 = rows[a][0]
+        last_end = {}
+        lines.append(f"step of {(rows[b][0] - t0) / 1000:.1f} us, {b - a} launches\n")
+        lines.append(f"{'start us':>9} {'dur us':>8} {'gap us':>7}  q   kernel\n")
+        busy = 0
+        for s, e, n, q, st in rows[a:b]:
+            gap = (s - last_end[q]) / 1000 if q in last_end else 0.0
+            last_end[q] = e
+            busy += e - s
+            lines.append(f"{(s - t0) / 1000:9.1f} {(e - s) / 1000:8.1f} {gap:7.1f}  {q:>3} {short(n)}\n")
+        lines.append(f"sum of kernel durations {busy / 1000:.1f} us\n")
+    else:
+        lines.append(f"only {len(starts)} step starts found among {len(rows)} launches\n")
+    open(os.path.join(out, "timeline.txt"), "w").writelines(lines)
+    for g in glob.glob(os.path.join(d, "**", "*"), recursive=True):
+        if os.path.isfile(g):
+            os.remove(g)
+
+
+if __name__ == "__main__":
+    main()

@@ -104,6 +104,12 @@ def lib():
     L.vqhip_pack_best.restype = i32
     L.vqhip_unpack_best.argtypes = [vp, i64, i64, i64, i32, vp, vp, vp, vp]
     L.vqhip_unpack_best.restype = i32
+    L.vqhip_vq_step_supported.argtypes = [i32, i64, i32, i32]
+    L.vqhip_vq_step_supported.restype = i32
+    L.vqhip_vq_step_workspace_bytes.argtypes = [i64, i32]
+    L.vqhip_vq_step_workspace_bytes.restype = ctypes.c_size_t
+    L.vqhip_vq_train_step.argtypes = [vp, vp]
+    L.vqhip_vq_train_step.restype = i32
     for name in ("vqhip_pack_codebook", "vqhip_assign", "vqhip_reduce_partials", "vqhip_ema_accumulate",
                  "vqhip_ema_finalize", "vqhip_decode_sum", "vqhip_row_sumsq", "vqhip_assign_rowwise", "vqhip_score_indices", "vqhip_topk", "vqhip_expire_scatter", "vqhip_kmeans_update", "vqhip_route_fwd", "vqhip_route_bwd", "vqhip_rvq_route", "vqhip_ema_renormalize_shard", "vqhip_scores_lse"):
         getattr(L, name).restype = i32
@@ -115,7 +121,7 @@ EXPORTS = ("vqhip_version", "vqhip_last_error", "vqhip_packed_bytes", "vqhip_pac
            "vqhip_assign_blocks", "vqhip_assign", "vqhip_screen_supported", "vqhip_screen_workspace_bytes",
            "vqhip_screen_blocks", "vqhip_screen_partials", "vqhip_assign_screened", "vqhip_screen_chain_supported", "vqhip_assign_screened_chain", "vqhip_l2norm_rows", "vqhip_scores", "vqhip_rvq_forward", "vqhip_reduce_partials", "vqhip_reduce_partials_rows", "vqhip_ema_fold_many", "vqhip_ema_workspace_bytes", "vqhip_ema_accumulate", "vqhip_ema_sqerr_partials", "vqhip_ema_accumulate_sqerr",
            "vqhip_ema_finalize", "vqhip_decode_sum", "vqhip_row_sumsq", "vqhip_assign_rowwise", "vqhip_score_indices", "vqhip_topk", "vqhip_expire_scatter", "vqhip_kmeans_update", "vqhip_route_fwd", "vqhip_route_bwd", "vqhip_rvq_route", "vqhip_ema_renormalize_shard", "vqhip_scores_lse",
-           "vqhip_pack_best", "vqhip_unpack_best")
+           "vqhip_pack_best", "vqhip_unpack_best", "vqhip_vq_step_supported", "vqhip_vq_step_workspace_bytes", "vqhip_vq_train_step")
 
 
 def _check(rc, what):
@@ -347,7 +353,8 @@ def l2norm_rows(x: torch.Tensor) -> torch.Tensor:
 
 class _Chain(ctypes.Structure):          # vqhip_chain_t (include/vqhip.h)
     _fields_ = [("idx_stride", ctypes.c_int64), ("prev_idx", ctypes.c_void_p), ("prev_idx_stride", ctypes.c_int64),
-                ("prev_embed", ctypes.c_void_p), ("x_out", ctypes.c_void_p), ("ldxo", ctypes.c_int64), ("route_mode", ctypes.c_int64)]
+                ("prev_embed", ctypes.c_void_p), ("x_out", ctypes.c_void_p), ("ldxo", ctypes.c_int64), ("route_mode", ctypes.c_int64),
+                ("hist", ctypes.c_void_p), ("header_zeroed", ctypes.c_int64)]
 
 
 def rvq_chain_supported(x: torch.Tensor, C: int) -> bool:
@@ -631,6 +638,66 @@ def ema_accumulate(x: torch.Tensor, idx: torch.Tensor, C: int, *, cosine=False, 
     if sqerr_from is not None:
         return count, embed_sum, torch.zeros(1, dtype=torch.float64, device=dev)
     return count, embed_sum
+
+
+class _Step(ctypes.Structure):           # vqhip_vq_step_t (include/vqhip.h)
+    _fields_ = [("x", ctypes.c_void_p), ("x_dtype", ctypes.c_int64), ("N", ctypes.c_int64), ("D", ctypes.c_int64), ("ldx", ctypes.c_int64),
+                ("embed", ctypes.c_void_p), ("embed_avg", ctypes.c_void_p), ("cluster_size", ctypes.c_void_p), ("C", ctypes.c_int64),
+                ("idx_out", ctypes.c_void_p), ("q_out", ctypes.c_void_p), ("ldq", ctypes.c_int64),
+                ("stats", ctypes.c_void_p), ("loss_out", ctypes.c_void_p), ("loss_scale", ctypes.c_double),
+                ("packed", ctypes.c_void_p), ("workspace", ctypes.c_void_p), ("workspace_bytes", ctypes.c_size_t),
+                ("one_minus_decay", ctypes.c_double), ("eps", ctypes.c_double), ("fold", ctypes.c_int64),
+                ("ev_search_begin", ctypes.c_void_p), ("ev_search_end", ctypes.c_void_p)]
+
+
+step_event_hook = None   # bench.py: callable -> (begin, end) torch.cuda.Event pair (already recorded once, so that their handles exist),
+                         # recorded by the library around the search of the next fused step
+
+
+def vq_step_supported(x: torch.Tensor, C: int) -> bool:
+    """can this training forward run as ONE fused call (vqhip_vq_train_step)?  VQHIP_FUSED_STEP=0 keeps the separate calls."""
+    if not (x.is_cuda and x.dtype in (torch.float32, torch.bfloat16) and screening_enabled()):
+        return False
+    if os.environ.get("VQHIP_FUSED_STEP", "1") == "0" or os.environ.get("VQHIP_SCREEN_VERIFY", "0") == "1" or screen_debug:
+        return False
+    xk, N, D, ldx = as_rows(x)
+    es = xk.element_size()
+    return bool(N > 0 and lib().vqhip_vq_step_supported(_dtype_code(xk), N, D, C) and xk.data_ptr() % 16 == 0 and (ldx * es) % 16 == 0)
+
+
+@_on_device
+def vq_train_step(x: torch.Tensor, embed, embed_avg, cluster_size, *, decay, eps, want_q=True, q_out=None, loss_scale=None, fold=True):
+    """One training forward of a Euclidean EMA codebook in one library call (vqhip_vq_train_step; reference: vqp.py:673-800 under
+    VectorQuantize.forward :1176).  embed / embed_avg / cluster_size: [C, D], [C, D], [C] fp32, updated in place when fold.
+    -> dict(q, idx, count [C], embed_sum [C, D] (views of one [C D + C] buffer: one all-reduce), loss (0-dim fp32 or None))"""
+    _need_gpu(x, embed, embed_avg, cluster_size)
+    xk, N, D, ldx = as_rows(x)
+    C = embed.shape[0]
+    dev = x.device
+    for t in (embed, embed_avg, cluster_size):
+        assert t.is_contiguous() and t.dtype == torch.float32
+    idx = torch.empty(N, dtype=torch.int64, device=dev)
+    q = None
+    if want_q:
+        q = q_out if q_out is not None else torch.empty(N, D, dtype=xk.dtype, device=dev)
+        assert q.dtype == xk.dtype and q.is_contiguous() and q.numel() == N * D
+    stats = torch.empty(C * D + C, dtype=torch.float32, device=dev)
+    loss = torch.empty((), dtype=torch.float32, device=dev) if loss_scale is not None else None
+    packed = torch.empty(lib().vqhip_packed_bytes(C, D), dtype=torch.uint8, device=dev)
+    nws = lib().vqhip_vq_step_workspace_bytes(N, C)
+    ws = torch.empty(nws, dtype=torch.uint8, device=dev)
+    omd = float(torch.tensor(1.0 - decay, dtype=torch.float64).to(torch.float32))
+    st = _Step(x=xk.data_ptr(), x_dtype=_dtype_code(xk), N=N, D=D, ldx=ldx, embed=embed.data_ptr(), embed_avg=embed_avg.data_ptr(),
+               cluster_size=cluster_size.data_ptr(), C=C, idx_out=idx.data_ptr(), q_out=None if q is None else q.data_ptr(), ldq=D,
+               stats=stats.data_ptr(), loss_out=None if loss is None else loss.data_ptr(), loss_scale=float(loss_scale or 0.0),
+               packed=packed.data_ptr(), workspace=ws.data_ptr(), workspace_bytes=nws, one_minus_decay=omd, eps=float(eps), fold=int(bool(fold)))
+    if step_event_hook is not None:
+        e0, e1 = step_event_hook()
+        st.ev_search_begin, st.ev_search_end = e0.cuda_event, e1.cuda_event
+    _check(lib().vqhip_vq_train_step(ctypes.byref(st), _stream()), "vqhip_vq_train_step")
+    hdr = ws[:16].view(torch.int32)       # [0] rows of the exact sweep, [1] rows decided between two candidates (device-side counters)
+    return dict(q=None if q is None else q.reshape(x.shape), idx=idx.reshape(x.shape[:-1]), stats=stats,
+                embed_sum=stats[: C * D].view(C, D), count=stats[C * D:], loss=loss, n_exact=hdr[:1], n_pair=hdr[1:2])
 
 
 @_on_device

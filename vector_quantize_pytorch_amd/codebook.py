@@ -363,10 +363,11 @@ class Codebook(nn.Module):
     @torch.no_grad()
     def quantize(self, x: Tensor, *, mask: Optional[Tensor] = None, freeze_codebook=False,
                  ema_update_weight=None, accum_ema_update=False, ema_update=None, update_usage=True,
-                 want_sqerr=False, input_normalized=False, q_out=None, embed_override=None, want_q=True):
+                 want_sqerr=False, input_normalized=False, q_out=None, embed_override=None, want_q=True, loss_scale=None):
         """x [b, n, d] (or [h, b, n, d] when num_codebooks > 1), float32 / bfloat16, RAW input: for the
         cosine metric the l2norm of vqp.py:1159 is fused into the kernel (pass input_normalized=True
-        when x is already unit-norm).  Returns dict(q, idx, sqerr_partials, nblk, rnorm)."""
+        when x is already unit-norm).  Returns dict(q, idx, sqerr_partials, nblk, rnorm); with loss_scale given the fused
+        train step may serve the call, and the dict then carries `loss` (= loss_scale * sum of squared errors) instead of partials."""
         ema_update = self.ema_update if ema_update is None else ema_update
         H, C = self.num_codebooks, self.codebook_size
         xs = x if x.ndim == 4 else x[None]
@@ -391,6 +392,20 @@ class Codebook(nn.Module):
             embed_override = (base.detach() - self.codebook_mean) * (bstd / cstd) + self.batch_mean
             if do_update:
                 x_stats = ((flat - self.batch_mean) * (cstd / bstd) + self.codebook_mean).reshape(xs.shape)
+        # the whole training forward of the plain case as ONE library call (vqhip_vq_train_step): pack, search, statistics, the
+        # commitment loss' squared error and -- without a collective in between -- the EMA fold
+        if (H == 1 and do_update and want_sqerr and loss_scale is not None and rmask is None and ema_update and not self.use_cosine_sim
+                and not self.affine_param and embed_override is None and ema_update_weight is None and not accum_ema_update
+                and not self.manual_ema_update and self.cluster_size.grad is None and self.embed.dtype == torch.float32
+                and L.vq_step_supported(xs[0], C)):
+            cs, ea, e = self._views(0)
+            r = L.vq_train_step(xs[0], e, ea, cs, decay=self.decay, eps=self.eps, want_q=want_q, q_out=q_out, loss_scale=loss_scale,
+                                fold=not self.use_ddp)
+            if self.use_ddp:
+                dist.all_reduce(r["stats"])   # ONE collective for count || embed_sum (RCCL over xGMI), then the fold
+                self._fold_stats(0, r["count"], r["embed_sum"], None, False, ema_update)
+            self.expire_codes_(xs.reshape(H, -1, self.dim), seq_mask=None)
+            return dict(q=r["q"], idx=r["idx"], sqerr_partials=None, nblk=0, rnorm=None, loss=r["loss"], n_exact=r["n_exact"], n_pair=r["n_pair"])
         outs = []
         for h in range(H):
             # embed_override: the codebook actually searched when it is a function of the stored one (vq_bridge)

@@ -636,6 +636,7 @@ __global__ void __launch_bounds__(VQS_WAVES * 64, 8 / VQS_WAVES) vq_screen16_ker
         const bool on = row_ok[rb] && half == 0;
         cls[rb] = !on ? 0 : (certified ? 0 : (pair ? 2 : 1));
         id2s[rb] = id2;
+        if (a.hist && on && certified) atomicAdd(&a.hist[code[rb]], 1);   // (no return value: fire and forget)
     }
     // the uncertified rows go to their lists -- open rows from the front, pair rows from the back of the same arrays.  ONE
     // atomic per wave and list, issued here; the slots are only needed after the output phase, which hides the round trip
@@ -1092,6 +1093,7 @@ __global__ void __launch_bounds__(VQS_F32_WAVES * 64, (XBF16 && NPART == 1 && DT
         if (code >= a.C) code = 0;
         const bool on = row_ok && half == 0;
         cls = !on ? 0 : (certified ? 0 : (pair ? 2 : 1));
+        if (a.hist && on && certified) atomicAdd(&a.hist[code], 1);
     }
     const unsigned long long balo = __ballot(cls == 1), balp = __ballot(cls == 2);
     int base_o = 0, base_p = 0;
@@ -1288,18 +1290,14 @@ static int dispatch_screen(const ScreenArgs &a, int x_dtype, int metric, hipStre
     return metric == VQHIP_EUCLID ? launch_screen<DT, 0>(a, x_dtype, st) : launch_screen<DT, 1>(a, x_dtype, st);
 }
 
-static int assign_screened_impl(const void *x, int x_dtype, int64_t N, int D, int64_t ldx, const float *packed,
-                                const float *embed, int C, int metric, int64_t *idx_out, void *q_out, int64_t ldq,
-                                void *resid_out, int64_t ldr, double *sqerr_partial, const uint8_t *row_mask,
-                                void *workspace, size_t workspace_bytes, float *debug_out, const vqhip_chain_t *chain, void *stream);
 
 extern "C" int vqhip_assign_screened(const void *x, int x_dtype, int64_t N, int D, int64_t ldx, const float *packed,
                                      const float *embed, int C, int metric, int64_t *idx_out, void *q_out, int64_t ldq,
                                      void *resid_out, int64_t ldr, double *sqerr_partial, const uint8_t *row_mask,
                                      void *workspace, size_t workspace_bytes, float *debug_out, void *stream)
 {
-    return assign_screened_impl(x, x_dtype, N, D, ldx, packed, embed, C, metric, idx_out, q_out, ldq, resid_out, ldr, sqerr_partial,
-                                row_mask, workspace, workspace_bytes, debug_out, nullptr, stream);
+    return vq_assign_screened_impl(x, x_dtype, N, D, ldx, packed, embed, C, metric, idx_out, q_out, ldq, resid_out, ldr, sqerr_partial,
+                                   row_mask, workspace, workspace_bytes, debug_out, nullptr, nullptr, 0, stream);
 }
 
 extern "C" int vqhip_screen_chain_supported(int x_dtype, int D)
@@ -1325,14 +1323,17 @@ extern "C" int vqhip_assign_screened_chain(const void *x, int x_dtype, int64_t N
             VQ_FAIL(VQHIP_EALIGN, "assign_screened_chain: prev_embed / x_out rows must be 16-byte aligned");
         if (chain->route_mode < 0 || chain->route_mode > 2) VQ_FAIL(VQHIP_EINVAL, "assign_screened_chain: route_mode must be 0, 1 or 2");
     }
-    return assign_screened_impl(x, x_dtype, N, D, ldx, packed, embed, C, metric, idx_out, nullptr, D, nullptr, D, nullptr, row_mask,
-                                workspace, workspace_bytes, nullptr, chain, stream);
+    return vq_assign_screened_impl(x, x_dtype, N, D, ldx, packed, embed, C, metric, idx_out, nullptr, D, nullptr, D, nullptr, row_mask,
+                                   workspace, workspace_bytes, nullptr, chain, chain->hist, chain->header_zeroed != 0, stream);
 }
 
-static int assign_screened_impl(const void *x, int x_dtype, int64_t N, int D, int64_t ldx, const float *packed,
-                                const float *embed, int C, int metric, int64_t *idx_out, void *q_out, int64_t ldq,
-                                void *resid_out, int64_t ldr, double *sqerr_partial, const uint8_t *row_mask,
-                                void *workspace, size_t workspace_bytes, float *debug_out, const vqhip_chain_t *chain, void *stream)
+// hist (nullable, [C] ints zeroed by the caller): the rows per code, counted here for the EMA statistics' counting sort.
+// header_zeroed: the caller has zeroed the first 16 bytes of the workspace (the list counters) on this stream already.
+int vq_assign_screened_impl(const void *x, int x_dtype, int64_t N, int D, int64_t ldx, const float *packed,
+                            const float *embed, int C, int metric, int64_t *idx_out, void *q_out, int64_t ldq,
+                            void *resid_out, int64_t ldr, double *sqerr_partial, const uint8_t *row_mask,
+                            void *workspace, size_t workspace_bytes, float *debug_out, const vqhip_chain_t *chain,
+                            int *hist, int header_zeroed, void *stream)
 {
     if (N < 0 || C <= 0) VQ_FAIL(VQHIP_EINVAL, "assign_screened: N < 0 or C <= 0");
     if (N == 0) return 0;
@@ -1353,8 +1354,11 @@ static int assign_screened_impl(const void *x, int x_dtype, int64_t N, int D, in
     hipStream_t st = (hipStream_t)stream;
     int *count = (int *)workspace;
     int *rows = count + 4;
-    hipError_t e = hipMemsetAsync(count, 0, 16, st);
-    if (e != hipSuccess) VQ_FAIL((int)e, "assign_screened: hipMemsetAsync: %s", hipGetErrorString(e));
+    if (hist && row_mask) VQ_FAIL(VQHIP_EINVAL, "assign_screened: the fused histogram does not take a row mask");
+    if (!header_zeroed) {
+        hipError_t e = hipMemsetAsync(count, 0, 16, st);
+        if (e != hipSuccess) VQ_FAIL((int)e, "assign_screened: hipMemsetAsync: %s", hipGetErrorString(e));
+    }
 
     const char *base = (const char *)packed;
     ScreenArgs a;
@@ -1368,7 +1372,7 @@ static int assign_screened_impl(const void *x, int x_dtype, int64_t N, int D, in
     a.idx_out = idx_out; a.q_out = q_out; a.ldq = ldq; a.resid_out = resid_out; a.ldr = ldr;
     a.sqerr_partial = sqerr_partial; a.row_mask = row_mask;
     unsigned long long *keys = (unsigned long long *)((char *)workspace + 16 + (((size_t)N * sizeof(int) + 7) & ~(size_t)7));
-    a.flag_count = count; a.flag_rows = rows; a.flag_keys = keys; a.dbg = debug_out;
+    a.flag_count = count; a.flag_rows = rows; a.flag_keys = keys; a.dbg = debug_out; a.hist = hist;
     {
         const size_t nseg = (size_t)N + 256 * (size_t)VQ_SEG_MAX;
         a.seg_counts = (int *)(keys + N);
@@ -1406,5 +1410,5 @@ static int assign_screened_impl(const void *x, int x_dtype, int64_t N, int D, in
     const int64_t ldl = (chain && chain->prev_idx) ? chain->ldxo : ldx;
     return vq_assign_listed(xl, x_dtype, metric, N, D, ldl, packed, embed, C, idx_out, a.idx_stride, q_out, ldq, resid_out, ldr,
                             sqerr_partial ? sqerr_partial + vqhip_screen_blocks(N, x_dtype) : nullptr, row_mask, rows, count, keys,
-                            with_pairs, st);
+                            with_pairs, hist, st);
 }

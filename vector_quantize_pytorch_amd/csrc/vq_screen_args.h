@@ -37,6 +37,8 @@ struct ScreenArgs {
     int *flag_rows;
     unsigned long long *flag_keys;     // [N] keys of the exact pass, preset to ~0 for every appended row
     float *dbg;                        // nullable [N, 4]: t_best, t_second, eps_t, flagged
+    int *hist;                         // nullable [C]: rows per code of the EMA statistics' counting sort (vqp.py:602), zeroed by the caller --
+                                       // certified rows are counted here, listed rows by vq_finish_listed_kernel (no vq_hist_kernel pass)
     // residual chain (vq_screen16_kernel, fp32 rows): this stage's rows are x - prev_embed[prev_idx], formed in the prologue from
     // the PREVIOUS stage's input and indices and written to x_out (the exact passes and the statistics read them there)
     int64_t idx_stride;                // idx_out[row * idx_stride] (a column of an [N, Q] index tensor)

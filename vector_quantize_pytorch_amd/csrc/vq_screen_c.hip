@@ -405,6 +405,7 @@ __global__ void __launch_bounds__(256, 2) vq_screenc_kernel(const ScreenArgs a, 
             if (code >= a.C) code = 0;
             cls = !on ? 0 : (certified ? 0 : (pair ? 2 : 1));
             prow = (int)row;
+            if (a.hist && on && certified) atomicAdd(&a.hist[code], 1);
         }
         const unsigned long long balo = __ballot(cls == 1), balp = __ballot(cls == 2);
         // list space: this workgroup's own segment of the staging lists (open rows from its front, pair rows from its back), handed

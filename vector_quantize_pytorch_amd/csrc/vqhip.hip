@@ -256,7 +256,7 @@ __global__ void __launch_bounds__(256) vq_pack16_kernel(const float *__restrict_
     }
 }
 
-extern "C" int vqhip_pack_codebook(const float *embed, int C, int D, float *packed, void *stream)
+static int pack_codebook_impl(const float *embed, int C, int D, float *packed, int scalars_zeroed, void *stream)
 {
     if (!embed || !packed || C <= 0) VQ_FAIL(VQHIP_EINVAL, "pack_codebook: null pointer or C <= 0");
     const int DT = pick_dt(D);
@@ -265,14 +265,21 @@ extern "C" int vqhip_pack_codebook(const float *embed, int C, int D, float *pack
     const int tiles = (C + 31) / 32;
     char *base = (char *)packed;
     unsigned *scalars = (unsigned *)(base + vq_packed_scalars_offset(C, D));
-    hipError_t e = hipMemsetAsync(scalars, 0, VQ_PACKED_SCALARS_BYTES, (hipStream_t)stream);
-    if (e != hipSuccess) VQ_FAIL((int)e, "pack_codebook: hipMemsetAsync: %s", hipGetErrorString(e));
+    if (!scalars_zeroed) {
+        hipError_t e = hipMemsetAsync(scalars, 0, VQ_PACKED_SCALARS_BYTES, (hipStream_t)stream);
+        if (e != hipSuccess) VQ_FAIL((int)e, "pack_codebook: hipMemsetAsync: %s", hipGetErrorString(e));
+    }
     hipLaunchKernelGGL(vq_pack_kernel, dim3(tiles, 2), dim3(256), 0, (hipStream_t)stream, embed, C, D, DT, packed,
                        (unsigned short *)(base + packed_bf16_offset(C, D)), scalars);
     if (int rc = launch_status("vq_pack_kernel")) return rc;
     hipLaunchKernelGGL(vq_pack16_kernel, dim3((unsigned)vq_tiles16(C)), dim3(256), 0, (hipStream_t)stream, embed, C, D, DT, tiles,
                        (const float *)packed, base + vq_packed_f16_offset(C, D), scalars);
     return launch_status("vq_pack16_kernel");
+}
+
+extern "C" int vqhip_pack_codebook(const float *embed, int C, int D, float *packed, void *stream)
+{
+    return pack_codebook_impl(embed, C, D, packed, 0, stream);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1504,6 +1511,7 @@ struct FinishArgs {
     int64_t ldr;
     double *sqerr_partial;   // nullable, one entry per workgroup
     const uint8_t *row_mask;
+    int *hist;               // nullable [C]: rows per code for the statistics' counting sort (the certified rows were counted by the screen)
 };
 
 // one wave per listed row: idx, q row, sum (q - x)^2.  A row is a chain of dependent loads (list -> key -> code row): the kernel is
@@ -1522,7 +1530,10 @@ __global__ void __launch_bounds__(VQ_FINISH_WAVES * 64) vq_finish_listed_kernel(
         const int64_t pos = v < n_full ? v : a.cap - 1 - (v - n_full);
         const int64_t row = a.row_list[pos];
         const int idx = (int)(unsigned)(a.keys[pos] & 0xffffffffull);
-        if (lane == 0) a.idx_out[row * a.idx_stride] = (int64_t)idx;
+        if (lane == 0) {
+            a.idx_out[row * a.idx_stride] = (int64_t)idx;
+            if (a.hist) atomicAdd(&a.hist[idx], 1);
+        }
         float ls = 0.f;
         for (int c0 = lane * 4; c0 < a.D; c0 += 256) {
             float d0, d1, d2, d3;
@@ -1763,7 +1774,7 @@ static int dispatch_pair(const PairArgs &a, int x_dtype, int metric, unsigned bl
 int vq_assign_listed(const void *x, int x_dtype, int metric, int64_t N, int D, int64_t ldx, const float *packed, const float *embed, int C,
                      int64_t *idx_out, int64_t idx_stride, void *q_out, int64_t ldq, void *resid_out, int64_t ldr, double *sqerr_partial,
                      const uint8_t *row_mask, const int *row_list, const int *row_count, unsigned long long *keys, int with_pairs,
-                     hipStream_t st)
+                     int *hist, hipStream_t st)
 {
     // keys[0 .. row_count[0]) were preset to ~0 by whoever built the list (the screening kernels); the pair entries at
     // [N - row_count[1], N) hold their two candidates
@@ -1819,7 +1830,7 @@ int vq_assign_listed(const void *x, int x_dtype, int metric, int64_t N, int D, i
     f.x = x; f.ldx = ldx;
     f.codes = (x_dtype == VQHIP_BF16) ? (const void *)((const char *)packed + packed_bf16_offset(C, D)) : (const void *)embed;
     f.D = D; f.row_list = row_list; f.row_count = row_count; f.cap = N; f.keys = keys;
-    f.idx_out = idx_out; f.idx_stride = idx_stride; f.q_out = q_out; f.ldq = ldq; f.resid_out = resid_out; f.ldr = ldr; f.sqerr_partial = sqerr_partial; f.row_mask = row_mask;
+    f.idx_out = idx_out; f.idx_stride = idx_stride; f.q_out = q_out; f.ldq = ldq; f.resid_out = resid_out; f.ldr = ldr; f.sqerr_partial = sqerr_partial; f.row_mask = row_mask; f.hist = hist;
     if (x_dtype == VQHIP_BF16)
         hipLaunchKernelGGL(vq_finish_listed_kernel<true>, dim3(VQ_FINISH_BLOCKS), dim3(VQ_FINISH_WAVES * 64), 0, st, f);
     else
@@ -2451,6 +2462,58 @@ extern "C" int vqhip_reduce_partials_rows(const double *partials, int R, int64_t
 #define VQ_SORT_ROWS_PER_BLOCK 4096
 #endif
 
+// ATen CPU lerp (vectorised form): |w| < 0.5 ? fma(w, end - start, start) : fma(w - 1, end - start, end)
+__device__ __forceinline__ float aten_lerp(float start, float end, float w)
+{
+    const float diff = end - start;
+    return (fabsf(w) < 0.5f) ? __builtin_fmaf(w, diff, start) : __builtin_fmaf(w - 1.0f, diff, end);
+}
+
+// total = cluster_size.sum() in ATen's cascade order (8 lanes x 4 ILP chains, 4 cascade levels);
+// denom[c] = (cs + eps) / (total + C eps) * total        (vqp.py:152-154, 577).  cs: C floats readable by every thread of the
+// workgroup (LDS, or global for C > 16384); part [32] and total_s in LDS; NT = threads of the workgroup (all of them call).
+template <int NT>
+__device__ __forceinline__ void ema_denom_block(const float *cs, int C, float eps, float ceps, float *denom, float *part, float *total_s)
+{
+    const int tid = threadIdx.x;
+    if (tid < 32) {
+        const int V = C >> 3;
+        const int size = V >> 2;
+        int cl2 = 0;
+        while ((1 << cl2) < size) cl2++;
+        int lp = cl2 / 4;
+        if (lp < 4) lp = 4;
+        const int step = 1 << lp;
+        const int lmask = step - 1;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        int i = 0;
+        for (; i + step <= size;) {
+            for (int jj = 0; jj < step; ++jj, ++i) a0 += cs[32 * i + tid];
+            a1 += a0; a0 = 0.f;
+            if ((i & (lmask << lp)) == 0) {
+                a2 += a1; a1 = 0.f;
+                if ((i & (lmask << (2 * lp))) == 0) { a3 += a2; a2 = 0.f; }
+            }
+        }
+        for (; i < size; ++i) a0 += cs[32 * i + tid];
+        a0 += a1; a0 += a2; a0 += a3;
+        if (tid < 8)
+            for (int v = size * 4; v < V; ++v) a0 += cs[v * 8 + tid];
+        part[tid] = a0;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        float fin = 0.f;
+        for (int e = (C >> 3) << 3; e < C; ++e) fin += cs[e];
+        for (int l = 0; l < 8; ++l) fin += ((part[l] + part[8 + l]) + part[16 + l]) + part[24 + l];
+        *total_s = fin;
+    }
+    __syncthreads();
+    const float total = *total_s;
+    const float den = total + ceps;
+    for (int c = tid; c < C; c += NT) denom[c] = ((cs[c] + eps) / den) * total;
+}
+
 struct SortArgs {
     const int64_t *idx;
     int64_t idx_stride;
@@ -2465,6 +2528,12 @@ struct SortArgs {
     float *count;  // [C] fp32, accumulated into
     int direct;    // 1: one global atomic per row, 256 rows per workgroup (few rows per code: a workgroup's LDS histogram would hold
                    // one or two rows per bin and cost C more atomics to flush); 0: LDS histogram per VQ_SORT_ROWS_PER_BLOCK rows
+    // fused train step (vqhip_vq_train_step, no collective between the statistics and the fold): the scan kernel -- the one
+    // workgroup that sees every count -- also folds them into cluster_size (ema_inplace, vqp.py:76-97 at :610) and forms the
+    // Laplace-smoothed denominators of update_ema (vqp.py:576-584).  cs null: not fused.  C <= 8192 (LDS copy of cluster_size).
+    float *cs;     // [C] cluster_size, in place
+    float *denom;  // [C] out
+    float omd, eps, ceps;
 };
 
 __device__ __forceinline__ int sort_code(const SortArgs &a, int64_t row)
@@ -2505,6 +2574,9 @@ __global__ void __launch_bounds__(1024) vq_scan_kernel(const SortArgs a)
 {
     __shared__ int s_cnt[1024];
     __shared__ int s_chk[1024];
+    __shared__ float s_part[32];
+    __shared__ float s_total;
+    extern __shared__ float s_cs[];        // C floats when a.cs is given
     const int tid = threadIdx.x;
     const int per = (a.C + 1023) / 1024;
     const int c_lo = min(a.C, tid * per), c_hi = min(a.C, c_lo + per);
@@ -2532,12 +2604,21 @@ __global__ void __launch_bounds__(1024) vq_scan_kernel(const SortArgs a)
         a.chunk_off[c] = ok;
         a.cursor[c * 16] = oc;
         if (n) a.count[c] += (float)n;
+        if (a.cs) {                        // (count was zero before this step: the batch's count IS n)
+            const float v = aten_lerp(a.cs[c], (float)n, a.omd);
+            a.cs[c] = v;
+            s_cs[c] = v;
+        }
         oc += n;
         ok += (n + VQ_SEG_CH - 1) / VQ_SEG_CH;
     }
     if (tid == 1023) {
         a.seg_off[a.C] = s_cnt[1023];
         a.chunk_off[a.C] = s_chk[1023];
+    }
+    if (a.cs) {
+        __syncthreads();
+        ema_denom_block<1024>(s_cs, a.C, a.eps, a.ceps, a.denom, s_part, &s_total);
     }
 }
 
@@ -2800,11 +2881,20 @@ static inline int64_t seg_work_items(int64_t N, int C)
 
 extern "C" int64_t vqhip_ema_sqerr_partials(int64_t N, int C) { return (N < 0 || C <= 0) ? 0 : seg_work_items(N, C); }
 
+// what the fused train step adds to the statistics pass: hist_ready -- the workspace's histogram (its first C ints) was zeroed by the
+// caller and filled by the search (ScreenArgs.hist), no memset and no vq_hist_kernel; cs / denom -- the scan kernel folds the
+// counts into cluster_size and forms update_ema's denominators (SortArgs)
+struct StatsFuse {
+    int hist_ready;
+    float *cs, *denom;
+    float omd, eps;
+};
+
 static int ema_accumulate_impl(const void *x, int x_dtype, int64_t N, int D, int64_t ldx,
                                const int64_t *idx, int64_t idx_stride, const float *rnorm, int metric,
                                const uint8_t *row_mask, int C,
                                float *count, float *embed_sum, void *workspace, size_t workspace_bytes,
-                               const void *qsrc, double *sqerr_partial, void *stream)
+                               const void *qsrc, double *sqerr_partial, void *stream, const StatsFuse *fuse = nullptr)
 {
     if (N < 0 || C <= 0 || D < 1) VQ_FAIL(VQHIP_EINVAL, "ema_accumulate: bad size");
     if (N == 0) {
@@ -2832,8 +2922,18 @@ static int ema_accumulate_impl(const void *x, int x_dtype, int64_t N, int D, int
     s.chunk_off = (int *)ws;      ws += align_up(((size_t)C + 1) * 4, 256);
     s.perm = (int *)ws;
 
-    hipError_t e = hipMemsetAsync(s.hist, 0, (size_t)C * 4, st);
-    if (e != hipSuccess) VQ_FAIL((int)e, "hipMemsetAsync(hist): %s", hipGetErrorString(e));
+    const bool hist_ready = fuse && fuse->hist_ready;
+    if (hist_ready && row_mask) VQ_FAIL(VQHIP_EINVAL, "ema_accumulate: a histogram counted by the search knows no row mask");
+    s.cs = fuse ? fuse->cs : nullptr;
+    s.denom = fuse ? fuse->denom : nullptr;
+    s.omd = fuse ? fuse->omd : 0.f;
+    s.eps = fuse ? fuse->eps : 0.f;
+    s.ceps = fuse ? (float)((double)C * (double)fuse->eps) : 0.f;
+    if (s.cs && (C > 8192 || !s.denom)) VQ_FAIL(VQHIP_EINVAL, "ema_accumulate: the fused cluster-size fold needs C <= 8192 and a denominator buffer");
+    if (!hist_ready) {
+        hipError_t e = hipMemsetAsync(s.hist, 0, (size_t)C * 4, st);
+        if (e != hipSuccess) VQ_FAIL((int)e, "hipMemsetAsync(hist): %s", hipGetErrorString(e));
+    }
     // LDS histograms, one global atomic per (workgroup, code), while the histogram fits.  (Round 3 tried the direct path -- one
     // returning global atomic per row from a full grid -- for few rows per code, N < 128 C: cfg 5 15.5 -> 19.7 ms, cfg 4 shard
     // 3.02 -> 3.15 ms.  Per-row returning atomics are slower than the flush of a sparse LDS histogram.)
@@ -2841,8 +2941,8 @@ static int ema_accumulate_impl(const void *x, int x_dtype, int64_t N, int D, int
     const int rpb = s.direct ? 256 : VQ_SORT_ROWS_PER_BLOCK;
     const unsigned sort_blocks = (unsigned)((N + rpb - 1) / rpb);
     const int lds = s.direct ? 0 : C * 4;
-    hipLaunchKernelGGL(vq_hist_kernel, dim3(sort_blocks), dim3(256), lds, st, s);
-    hipLaunchKernelGGL(vq_scan_kernel, dim3(1), dim3(1024), 0, st, s);
+    if (!hist_ready) hipLaunchKernelGGL(vq_hist_kernel, dim3(sort_blocks), dim3(256), lds, st, s);
+    hipLaunchKernelGGL(vq_scan_kernel, dim3(1), dim3(1024), s.cs ? (size_t)C * 4 : 0, st, s);
     hipLaunchKernelGGL(vq_scatter_kernel, dim3(sort_blocks), dim3(256), lds, st, s);
 
     SegArgs g;
@@ -2901,13 +3001,6 @@ extern "C" int vqhip_ema_accumulate_sqerr(const void *x, int x_dtype, int64_t N,
 // ------------------------------------------------------------------------------------------------
 // EMA fold + codebook renormalisation
 // ------------------------------------------------------------------------------------------------
-// ATen CPU lerp (vectorised form): |w| < 0.5 ? fma(w, end - start, start) : fma(w - 1, end - start, end)
-__device__ __forceinline__ float aten_lerp(float start, float end, float w)
-{
-    const float diff = end - start;
-    return (fabsf(w) < 0.5f) ? __builtin_fmaf(w, diff, start) : __builtin_fmaf(w - 1.0f, diff, end);
-}
-
 __global__ void __launch_bounds__(256) vq_ema_cs_lerp_kernel(float *cs, const float *count, const float *weight, int C, float omd)
 {
     const int c = blockIdx.x * 256 + threadIdx.x;
@@ -2916,66 +3009,29 @@ __global__ void __launch_bounds__(256) vq_ema_cs_lerp_kernel(float *cs, const fl
     cs[c] = aten_lerp(cs[c], count[c], w);
 }
 
-// total = cluster_size.sum() in ATen's cascade order (8 lanes x 4 ILP chains, 4 cascade levels);
-// denom[c] = (cs + eps) / (total + C eps) * total        (vqp.py:152-154, 577)
+// (the arithmetic: ema_denom_block above)
 __global__ void __launch_bounds__(256) vq_ema_denom_kernel(const float *cs_g, int C, float eps, float ceps, float *denom)
 {
     __shared__ float part[32];
     __shared__ float total_s;
     extern __shared__ float cs_lds[];      // C floats when the launch provides them (C <= 16384), else unused
     const int tid = threadIdx.x;
-    // the 32 summation chains below are latency-bound on dependent global loads (33 us at C = 4096): stage cluster_size in LDS first
+    // the 32 summation chains are latency-bound on dependent global loads (33 us at C = 4096): stage cluster_size in LDS first
     const float *cs = cs_g;
     if (C <= 16384) {
         for (int c = tid; c < C; c += 256) cs_lds[c] = cs_g[c];
         __syncthreads();
         cs = cs_lds;
     }
-    if (tid < 32) {
-        const int V = C >> 3;
-        const int size = V >> 2;
-        int cl2 = 0;
-        while ((1 << cl2) < size) cl2++;
-        int lp = cl2 / 4;
-        if (lp < 4) lp = 4;
-        const int step = 1 << lp;
-        const int lmask = step - 1;
-        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-        int i = 0;
-        for (; i + step <= size;) {
-            for (int jj = 0; jj < step; ++jj, ++i) a0 += cs[32 * i + tid];
-            a1 += a0; a0 = 0.f;
-            if ((i & (lmask << lp)) == 0) {
-                a2 += a1; a1 = 0.f;
-                if ((i & (lmask << (2 * lp))) == 0) { a3 += a2; a2 = 0.f; }
-            }
-        }
-        for (; i < size; ++i) a0 += cs[32 * i + tid];
-        a0 += a1; a0 += a2; a0 += a3;
-        if (tid < 8)
-            for (int v = size * 4; v < V; ++v) a0 += cs[v * 8 + tid];
-        part[tid] = a0;
-    }
-    __syncthreads();
-    if (tid == 0) {
-        float fin = 0.f;
-        for (int e = (C >> 3) << 3; e < C; ++e) fin += cs[e];
-        for (int l = 0; l < 8; ++l) fin += ((part[l] + part[8 + l]) + part[16 + l]) + part[24 + l];
-        total_s = fin;
-    }
-    __syncthreads();
-    const float total = total_s;
-    const float den = total + ceps;
-    for (int c = tid; c < C; c += 256) denom[c] = ((cs[c] + eps) / den) * total;
+    ema_denom_block<256>(cs, C, eps, ceps, denom, part, &total_s);
 }
 
 // one wave per code row
-__global__ void __launch_bounds__(256) vq_ema_embed_kernel(float *embed_avg, float *embed, const float *embed_sum,
-                                                           const float *weight, const float *denom, int C, int D,
-                                                           float omd, int cosine, int do_lerp, int do_update)
+__device__ __forceinline__ void ema_embed_row(float *embed_avg, float *embed, const float *embed_sum,
+                                              const float *weight, const float *denom, int C, int D,
+                                              float omd, int cosine, int do_lerp, int do_update, int c)
 {
     const int lane = threadIdx.x & 63;
-    const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (c >= C) return;
     const float w = weight ? omd * weight[c] : omd;
     const float den = do_update ? denom[c] : 1.f;
@@ -3010,6 +3066,36 @@ __global__ void __launch_bounds__(256) vq_ema_embed_kernel(float *embed_avg, flo
         const int d = lane + 64 * q;
         if (d < D) embed[(size_t)c * D + d] = cosine ? (e[q] / inv) : e[q];
     }
+}
+
+__global__ void __launch_bounds__(256) vq_ema_embed_kernel(float *embed_avg, float *embed, const float *embed_sum,
+                                                           const float *weight, const float *denom, int C, int D,
+                                                           float omd, int cosine, int do_lerp, int do_update)
+{
+    ema_embed_row(embed_avg, embed, embed_sum, weight, denom, C, D, omd, cosine, do_lerp, do_update, blockIdx.x * 4 + (threadIdx.x >> 6));
+}
+
+// tail of the fused train step: workgroups [0, ceil(C / 4)) fold embed_sum into embed_avg and renormalise embed (the kernel above),
+// the LAST workgroup reduces the commitment loss' partials (vq_reduce_kernel's arithmetic: fp64, fixed order)
+__global__ void __launch_bounds__(256) vq_step_fold_kernel(float *embed_avg, float *embed, const float *embed_sum, const float *denom,
+                                                           int C, int D, float omd, const double *__restrict__ partials, int64_t n_partials,
+                                                           double scale, float *loss_out)
+{
+    if (blockIdx.x + 1 < gridDim.x) {
+        ema_embed_row(embed_avg, embed, embed_sum, nullptr, denom, C, D, omd, 0, 1, 1, blockIdx.x * 4 + (threadIdx.x >> 6));
+        return;
+    }
+    if (!loss_out) return;
+    __shared__ double red[256];
+    double sum = 0.0;
+    for (int64_t i = threadIdx.x; i < n_partials; i += 256) sum += partials[i];
+    red[threadIdx.x] = sum;
+    __syncthreads();
+    for (int o = 128; o >= 1; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *loss_out = (float)(red[0] * scale);
 }
 
 extern "C" int vqhip_ema_finalize(float *cluster_size, float *embed_avg, float *embed,
@@ -3426,4 +3512,88 @@ extern "C" int vqhip_decode_sum(const int64_t *idx, int64_t N, int Q, const floa
         hipLaunchKernelGGL(vq_decode_kernel<false>, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, (hipStream_t)stream, idx, N, Q, embed,
                            embed_qstride, C, D, out, out_dtype == VQHIP_BF16, ldo);
     return launch_status("vq_decode_kernel");
+}
+
+// ------------------------------------------------------------------------------------------------
+// fused train step (vqhip_vq_train_step): the launches of pack -> search -> statistics -> fold with everything that only exists
+// because they are separate API calls removed -- ONE zeroing kernel instead of four memsets / fills, no histogram pass (the search
+// counts the rows per code), cluster_size folded by the scan kernel, embed_avg / embed / loss by one tail kernel.
+// ------------------------------------------------------------------------------------------------
+struct ZeroArgs { unsigned *p[4]; unsigned n[4]; };   // up to four regions of n 32-bit words each
+__global__ void __launch_bounds__(256) vq_zero_kernel(const ZeroArgs a)
+{
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+        for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < a.n[r]; i += gridDim.x * 256) a.p[r][i] = 0u;
+}
+
+static inline size_t step_ws_screen(int64_t N) { return align_up(vqhip_screen_workspace_bytes(N), 256); }
+
+extern "C" size_t vqhip_vq_step_workspace_bytes(int64_t N, int C)
+{
+    if (N <= 0 || C <= 0) return 0;
+    // screening workspace | statistics workspace (histogram first) | denominators [C] | squared-error partials
+    return step_ws_screen(N) + align_up(vqhip_ema_workspace_bytes(N, C), 256) + align_up((size_t)C * 4, 256) +
+           align_up((size_t)seg_work_items(N, C) * sizeof(double), 256);
+}
+
+extern "C" int vqhip_vq_step_supported(int x_dtype, int64_t N, int D, int C)
+{
+    return (x_dtype == VQHIP_F32 || x_dtype == VQHIP_BF16) && vqhip_screen_supported(N, D, C) && (D % 4 == 0) && C <= 8192 ? 1 : 0;
+}
+
+extern "C" int vqhip_vq_train_step(const vqhip_vq_step_t *s, void *stream)
+{
+    if (!s) VQ_FAIL(VQHIP_EINVAL, "vq_train_step: null argument block");
+    const int64_t N = s->N;
+    const int D = (int)s->D, C = (int)s->C, x_dtype = (int)s->x_dtype;
+    if (!s->x || !s->embed || !s->idx_out || !s->stats || !s->packed || !s->workspace) VQ_FAIL(VQHIP_EINVAL, "vq_train_step: null pointer");
+    if (s->fold && (!s->embed_avg || !s->cluster_size)) VQ_FAIL(VQHIP_EINVAL, "vq_train_step: fold needs embed_avg and cluster_size");
+    if (!vqhip_vq_step_supported(x_dtype, N, D, C)) VQ_FAIL(VQHIP_EDIM, "vq_train_step: N=%lld D=%d C=%d dtype=%d outside the fused step", (long long)N, D, C, x_dtype);
+    if (s->workspace_bytes < vqhip_vq_step_workspace_bytes(N, C)) VQ_FAIL(VQHIP_EINVAL, "vq_train_step: workspace too small");
+    if ((((uintptr_t)s->workspace) & 255) || (((uintptr_t)s->stats) & 15) || (((uintptr_t)s->packed) & 15))
+        VQ_FAIL(VQHIP_EALIGN, "vq_train_step: workspace must be 256-byte aligned, stats / packed 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    char *ws = (char *)s->workspace;
+    void *ws_screen = ws;                          ws += step_ws_screen(N);
+    void *ws_stats = ws;                           ws += align_up(vqhip_ema_workspace_bytes(N, C), 256);
+    float *denom = (float *)ws;                    ws += align_up((size_t)C * 4, 256);
+    double *partials = (double *)ws;
+    const int64_t n_part = seg_work_items(N, C);
+    float *embed_sum = s->stats, *count = s->stats + (size_t)C * D;
+
+    ZeroArgs z;
+    z.p[0] = (unsigned *)((char *)s->packed + vq_packed_scalars_offset(C, D)); z.n[0] = VQ_PACKED_SCALARS_BYTES / 4;
+    z.p[1] = (unsigned *)ws_screen;                                            z.n[1] = 4;
+    z.p[2] = (unsigned *)ws_stats;                                             z.n[2] = (unsigned)C;      // the histogram
+    z.p[3] = (unsigned *)s->stats;                                             z.n[3] = (unsigned)((size_t)C * D + C);
+    const unsigned zb = (z.n[3] + 1023) / 1024;
+    hipLaunchKernelGGL(vq_zero_kernel, dim3(zb < 1 ? 1 : (zb > 512 ? 512 : zb)), dim3(256), 0, st, z);
+    if (int rc = launch_status("vq_zero_kernel")) return rc;
+
+    if (int rc = pack_codebook_impl(s->embed, C, D, s->packed, 1, stream)) return rc;
+    if (s->ev_search_begin) (void)hipEventRecord((hipEvent_t)s->ev_search_begin, st);
+    if (int rc = vq_assign_screened_impl(s->x, x_dtype, N, D, s->ldx, s->packed, s->embed, C, VQHIP_EUCLID, s->idx_out, s->q_out, s->ldq,
+                                         nullptr, D, nullptr, nullptr, ws_screen, step_ws_screen(N), nullptr, nullptr,
+                                         (int *)ws_stats, 1, stream)) return rc;
+    if (s->ev_search_end) (void)hipEventRecord((hipEvent_t)s->ev_search_end, st);
+    StatsFuse f;
+    f.hist_ready = 1;
+    f.cs = s->fold ? s->cluster_size : nullptr;
+    f.denom = s->fold ? denom : nullptr;
+    f.omd = (float)s->one_minus_decay;
+    f.eps = (float)s->eps;
+    const void *qsrc = (x_dtype == VQHIP_BF16) ? (const void *)((const char *)s->packed + packed_bf16_offset(C, D)) : (const void *)s->embed;
+    if (int rc = ema_accumulate_impl(s->x, x_dtype, N, D, s->ldx, s->idx_out, 1, nullptr, VQHIP_EUCLID, nullptr, C, count, embed_sum,
+                                     ws_stats, vqhip_ema_workspace_bytes(N, C), qsrc, partials, stream, &f)) return rc;
+    if (s->fold) {
+        hipLaunchKernelGGL(vq_step_fold_kernel, dim3((unsigned)((C + 3) / 4 + 1)), dim3(256), 0, st, s->embed_avg, s->embed, embed_sum, denom,
+                           C, D, (float)s->one_minus_decay, partials, n_part, s->loss_scale, s->loss_out);
+        return launch_status("vq_step_fold_kernel");
+    }
+    if (s->loss_out) {
+        hipLaunchKernelGGL(vq_reduce_kernel, dim3(1), dim3(256), 0, st, partials, n_part, s->loss_scale, s->loss_out);
+        return launch_status("vq_reduce_kernel");
+    }
+    return 0;
 }

@@ -41,12 +41,12 @@ class _QuantizeFn(torch.autograd.Function):
         """loss_scale: constant folded into the squared-error reduction (1 / numel for the unmasked commit loss), so that the
         third output IS mean((q - x)^2) without further elementwise kernels"""
         cb = vq._codebook
-        r = cb.quantize(x, mask=mask, want_sqerr=vq.training and vq.has_commitment_loss, **kw)
+        r = cb.quantize(x, mask=mask, want_sqerr=vq.training and vq.has_commitment_loss, loss_scale=float(loss_scale), **kw)
         q, idx = r["q"], r["idx"]
         loss_sum = None
         ctx.loss_scale = float(loss_scale)
         if vq.training and vq.has_commitment_loss:
-            loss_sum = L.reduce_partials(r["sqerr_partials"], r["nblk"], float(loss_scale))
+            loss_sum = r["loss"] if r.get("loss") is not None else L.reduce_partials(r["sqerr_partials"], r["nblk"], float(loss_scale))
         out = q
         mode = 0
         if vq.training and x.requires_grad and vq.route_gradients_to_input:
