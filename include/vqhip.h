@@ -120,9 +120,8 @@ typedef struct {
     const float *prev_embed;       /* previous stage's codebook [C_prev, D] fp32 */
     void *x_out;                   /* [N, D] fp32 at row stride ldxo: receives this stage's input */
     int64_t ldxo;
-    int64_t route_mode;            /* 0 / 1 / 2, see above */
-    int *hist;                     /* nullable [C] ints, zeroed by the caller: receives the rows per code of THIS stage (the counting sort of
-                                      vqhip_ema_accumulate_hist then skips its histogram pass); row_mask must be null */
+    int64_t route_mode;            /* must be 0.  (Round 4's first form subtracted the previous layer's ROUTED value here; that is a
+                                      kernel of its own now -- vqhip_route_residual -- whose output is passed as x with prev_idx NULL.) */
     int64_t header_zeroed;         /* != 0: the caller has zeroed the first 16 bytes of `workspace` on this stream (no memset launch) */
 } vqhip_chain_t;
 int vqhip_screen_chain_supported(int x_dtype, int D);
@@ -196,6 +195,12 @@ int vqhip_rvq_route(const void *x, int dtype, int64_t N, int D, int64_t ldx, con
                     int C, const int64_t *idx, int64_t idx_stride, int Q, int mode, int resid_routed, const void *g_out, int64_t ldg,
                     const float *loss_coef, const uint8_t *row_mask, int backward, void *out, int64_t ldo, void *stream);
 
+/* out[n] = x[n] - route(x[n], embed[idx[n * idx_stride]]) for fp32 rows: the input of the next ResidualVQ stage when the layer returned
+ * the ROUTED value (`residual - quantized.detach()`, rvq.py:524, in a training step whose input requires grad, vqp.py:1225-1233).
+ * mode 1 / 2 and arithmetic as vqhip_route_fwd (bit for bit).  embed [C, D] fp32 contiguous. */
+int vqhip_route_residual(const void *x, int64_t N, int D, int64_t ldx, const float *embed, const int64_t *idx, int64_t idx_stride,
+                         int mode, void *out, int64_t ldo, void *stream);
+
 /* sum of `n` doubles times `scale` -> one fp32 (commit loss = scale * sum of partials). */
 int vqhip_reduce_partials(const double *partials, int64_t n, double scale, float *out, void *stream);
 /* R rows of partials in one launch (the per-stage losses of a residual VQ): out[r] = scale * sum(partials[r * stride .. + n)). */
@@ -207,8 +212,8 @@ int vqhip_reduce_partials_rows(const double *partials, int R, int64_t n, int64_t
  * EMA statistics (count / embed_sum, vqp.py:602-606), the commitment loss' squared error (vqp.py:1327) and -- with fold != 0 --
  * ema_inplace of cluster_size and embed_avg and update_ema (vqp.py:610-617, 576-584).  The same kernels as vqhip_pack_codebook +
  * vqhip_assign_screened + vqhip_ema_accumulate_sqerr + vqhip_ema_finalize + vqhip_reduce_partials, minus what only exists between
- * separate calls: one zeroing kernel for every counter / accumulator, no histogram pass (the search counts the rows per code),
- * cluster_size folded inside the statistics' scan kernel, embed_avg / embed / loss in one tail kernel (11 launches, was 19).
+ * separate calls: one zeroing kernel for every counter / accumulator, cluster_size folded inside the statistics' scan kernel,
+ * embed_avg / embed / loss in one tail kernel (12 launches, was 19).
  * fold == 0 stops after the statistics (data parallel: all-reduce `stats`, then vqhip_ema_finalize).
  * Requirements: vqhip_vq_step_supported(); x rows 16-byte aligned; no row mask; no dead-code replacement inside (caller's). */
 typedef struct {

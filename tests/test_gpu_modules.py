@@ -896,6 +896,68 @@ def test_fused_train_step_equals_the_separate_calls(dev, monkeypatch, dtype, kw,
         b.load_state_dict(a.state_dict())
 
 
+@pytest.mark.parametrize("kw", [dict(codebook_diversity_loss_weight=0.5, codebook_diversity_temperature=10.),
+                                dict(straight_through=True, rotation_trick=False, sample_codebook_temp=0.5),
+                                dict(stochastic_sample_codes=True, sample_codebook_temp=0., codebook_diversity_loss_weight=0.1,
+                                     learnable_codebook=True, ema_update=False)])
+def test_score_row_options_run_in_position_slices_without_the_full_score_matrix(dev, monkeypatch, kw):
+    """Diversity loss (vqp.py:1287-1292), gumbel straight-through (vqp.py:144-148) and sampling (vqp.py:117-140) read whole score
+    rows.  Beyond VQHIP_SCORE_CHUNK_MB the module produces `dist` for a slice of the positions at a time and recomputes it in
+    backward (checkpoint): same indices, outputs, losses and gradients as the single N x C call, peak memory one slice."""
+    from vector_quantize_pytorch_amd import VectorQuantize
+    torch.manual_seed(0)
+    a, b = VectorQuantize(dim=64, codebook_size=256, **kw).to(dev).train(), VectorQuantize(dim=64, codebook_size=256, **kw).to(dev).train()
+    b.load_state_dict(a.state_dict())
+    for step in range(2):
+        x = torch.randn(3, 1000, 64, device=dev)
+        xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+        monkeypatch.setenv("VQHIP_SCORE_CHUNK_MB", "4096")
+        qa, ia, la = a(xa)
+        monkeypatch.setenv("VQHIP_SCORE_CHUNK_MB", "0.25")          # 3 x 256 x 4 bytes per position: slices of 85 positions
+        torch.cuda.reset_peak_memory_stats(dev)
+        qb, ib, lb = b(xb)
+        assert torch.equal(ia, ib)
+        _close(qb, qa, 1e-6, "quantized")
+        _close(lb, la, 1e-5, "loss")
+        (qa.square().mean() + la.sum()).backward()
+        (qb.square().mean() + lb.sum()).backward()
+        _close(xb.grad, xa.grad, 1e-5, "input gradient")
+        for (na, pa), (nb, pb) in zip(a.named_parameters(), b.named_parameters()):
+            if pa.grad is not None:
+                _close(pb.grad, pa.grad, 1e-5, f"gradient of {na}")
+                pa.grad = pb.grad = None
+        _close(b._codebook.embed, a._codebook.embed, 1e-5, "embed")
+        b.load_state_dict(a.state_dict())
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_residual_vq_dim_512_screened_stage_loop_equals_the_exact_fused_kernel(dev, monkeypatch, dtype):
+    """D = 512 residual loops run as Q screened searches (vq_screen16_1rb_kernel, each writing the next stage's input) since round 4;
+    VQHIP_SCREEN=0 sends them to the exact fused kernel (vq_rvq_kernel, residual rows in registers across the stages): same indices,
+    outputs, losses and codebooks, train and eval."""
+    from vector_quantize_pytorch_amd import ResidualVQ
+    torch.manual_seed(0)
+    kw = dict(dim=512, num_quantizers=3, codebook_size=300, shared_codebook=False)
+    a, b = ResidualVQ(**kw).to(dev).train(), ResidualVQ(**kw).to(dev).train()
+    b.load_state_dict(a.state_dict())
+    for step in range(3):
+        if step == 2:
+            a.eval(); b.eval()
+        x = torch.randn(2, 3000, 512, device=dev).to(dtype)
+        monkeypatch.setenv("VQHIP_SCREEN", "1")
+        qa, ia, la = a(x)
+        monkeypatch.setenv("VQHIP_SCREEN", "0")
+        qb, ib, lb = b(x)
+        assert torch.equal(ia, ib)
+        tol = 1e-2 if dtype == torch.bfloat16 else 1e-5
+        _close(qa, qb, tol, "quantized")
+        _close(la, lb, 1e-5 if dtype == torch.float32 else 1e-3, "losses")
+        for (na, pa), (nb, pb) in zip(a.state_dict().items(), b.state_dict().items()):
+            if pa.dtype.is_floating_point:
+                _close(pa, pb, 1e-5, na)
+        b.load_state_dict(a.state_dict())
+
+
 def test_qinco_implicit_neural_codebook_round_trip(dev):
     """ResidualVQ(implicit_neural_codebook=True) (rvq.py:107-162, 460-499): same parameter names as the reference (goldens rvq_qinco*
     pin values and gradients); here: decode from indices reproduces the forward's output, dropped quantizers decode to zero,

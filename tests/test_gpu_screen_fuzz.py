@@ -288,15 +288,17 @@ def test_mfma_accumulation_error_f32_rows(dev):
         assert bool((err <= model + idx_bits).all()), f"f32-row screen: worst ratio {(err / (model + idx_bits)).max():.3f}"
 
 
-def test_persistent_screening_kernel_equals_exact_kernel():
-    """The opt-in persistent screening kernel (csrc/vq_screen_c.hip, VQHIP_SCREEN_PERSIST=2: cyclic tile stream, per-workgroup list
-    segments + vq_compact_lists_kernel) against the exact fp32-MFMA kernel, bit for bit (indices, q rows), on the cases of
+@pytest.mark.parametrize("persist", ["1", "0"])
+def test_both_screening_kernels_equal_exact_kernel(persist):
+    """The persistent screening kernel (csrc/vq_screen_c.hip: cyclic tile stream, per-workgroup list segments +
+    vq_compact_lists_kernel; the default for bf16 rows at D = 256 from 131 072 rows on) and the 4-wave kernel it replaced there
+    (VQHIP_SCREEN_PERSIST=0) against the exact fp32-MFMA kernel, bit for bit (indices, q rows), on the cases of
     tools/persist_check.py: ragged N, padded codebooks, twin codes, wild row norms, both metrics.  A subprocess: the switch is read
     once per process."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, VQHIP_SCREEN_PERSIST="2")
+    env = dict(os.environ, VQHIP_SCREEN_PERSIST=persist)
     p = subprocess.run([sys.executable, os.path.join(root, "tools", "persist_check.py")], env=env, cwd=root,
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
     assert p.returncode == 0 and "ALL OK" in p.stdout, p.stdout[-3000:]

@@ -1,8 +1,8 @@
-"""Dev tool: the persistent screening kernel (csrc/vq_screen_c.hip; bf16 rows, D = 256, N >= 2^17, idx [+ q] outputs) against the exact
-fp32-MFMA kernel, bit for bit (idx, q).   python tools/persist_check.py"""
+"""Dev tool / test helper: the screening kernel that serves bf16 rows at D = 256, N >= 2^17, idx [+ q] outputs -- the persistent one of
+csrc/vq_screen_c.hip by default, the 4-wave kernel under VQHIP_SCREEN_PERSIST=0 -- against the exact fp32-MFMA kernel, bit for bit
+(idx, q).   python tools/persist_check.py"""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-os.environ.setdefault("VQHIP_SCREEN_PERSIST", "2")
 from vector_quantize_pytorch_amd import _lib as L
 dev = torch.device("cuda:0")
 g = torch.Generator(device=dev).manual_seed(7)

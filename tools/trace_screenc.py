@@ -3,7 +3,6 @@ Per wave and interval of the kernel: cycles of work (start -> its wait) and cycl
 import sys, os, ctypes, torch
 os.environ.setdefault("VQHIP_SO", os.path.join(os.path.dirname(os.path.abspath(__file__)), "variants", "libvqhip_ctrace.so"))
 os.environ["VQHIP_SCREEN_ONLY"] = "1"
-os.environ["VQHIP_SCREEN_PERSIST"] = "2"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from vector_quantize_pytorch_amd import _lib as L
 dev = torch.device('cuda:0')

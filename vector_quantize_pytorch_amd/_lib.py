@@ -104,6 +104,8 @@ def lib():
     L.vqhip_pack_best.restype = i32
     L.vqhip_unpack_best.argtypes = [vp, i64, i64, i64, i32, vp, vp, vp, vp]
     L.vqhip_unpack_best.restype = i32
+    L.vqhip_route_residual.argtypes = [vp, i64, i32, i64, vp, vp, i64, i32, vp, i64, vp]
+    L.vqhip_route_residual.restype = i32
     L.vqhip_vq_step_supported.argtypes = [i32, i64, i32, i32]
     L.vqhip_vq_step_supported.restype = i32
     L.vqhip_vq_step_workspace_bytes.argtypes = [i64, i32]
@@ -121,7 +123,7 @@ EXPORTS = ("vqhip_version", "vqhip_last_error", "vqhip_packed_bytes", "vqhip_pac
            "vqhip_assign_blocks", "vqhip_assign", "vqhip_screen_supported", "vqhip_screen_workspace_bytes",
            "vqhip_screen_blocks", "vqhip_screen_partials", "vqhip_assign_screened", "vqhip_screen_chain_supported", "vqhip_assign_screened_chain", "vqhip_l2norm_rows", "vqhip_scores", "vqhip_rvq_forward", "vqhip_reduce_partials", "vqhip_reduce_partials_rows", "vqhip_ema_fold_many", "vqhip_ema_workspace_bytes", "vqhip_ema_accumulate", "vqhip_ema_sqerr_partials", "vqhip_ema_accumulate_sqerr",
            "vqhip_ema_finalize", "vqhip_decode_sum", "vqhip_row_sumsq", "vqhip_assign_rowwise", "vqhip_score_indices", "vqhip_topk", "vqhip_expire_scatter", "vqhip_kmeans_update", "vqhip_route_fwd", "vqhip_route_bwd", "vqhip_rvq_route", "vqhip_ema_renormalize_shard", "vqhip_scores_lse",
-           "vqhip_pack_best", "vqhip_unpack_best", "vqhip_vq_step_supported", "vqhip_vq_step_workspace_bytes", "vqhip_vq_train_step")
+           "vqhip_pack_best", "vqhip_unpack_best", "vqhip_vq_step_supported", "vqhip_vq_step_workspace_bytes", "vqhip_vq_train_step", "vqhip_route_residual")
 
 
 def _check(rc, what):
@@ -354,7 +356,7 @@ def l2norm_rows(x: torch.Tensor) -> torch.Tensor:
 class _Chain(ctypes.Structure):          # vqhip_chain_t (include/vqhip.h)
     _fields_ = [("idx_stride", ctypes.c_int64), ("prev_idx", ctypes.c_void_p), ("prev_idx_stride", ctypes.c_int64),
                 ("prev_embed", ctypes.c_void_p), ("x_out", ctypes.c_void_p), ("ldxo", ctypes.c_int64), ("route_mode", ctypes.c_int64),
-                ("hist", ctypes.c_void_p), ("header_zeroed", ctypes.c_int64)]
+                ("header_zeroed", ctypes.c_int64)]
 
 
 def rvq_chain_supported(x: torch.Tensor, C: int) -> bool:
@@ -393,9 +395,18 @@ def rvq_forward_chained(x: torch.Tensor, packed: torch.Tensor, embed: torch.Tens
     inputs, counts = [x], []
     for q in range(Q):
         ws = torch.empty((nws + 3) // 4, dtype=torch.int32, device=dev)
-        ch = _Chain(idx_stride=Q, prev_idx=None, prev_idx_stride=Q, prev_embed=None, x_out=None, ldxo=D, route_mode=int(route_mode))
+        ch = _Chain(idx_stride=Q, prev_idx=None, prev_idx_stride=Q, prev_embed=None, x_out=None, ldxo=D, route_mode=0)
         src, lds = xk, ldx
-        if q > 0:
+        if q > 0 and route_mode:
+            # the previous layer returned its ROUTED value (rotation trick / straight-through on an input that requires grad) and
+            # rvq.py:524 subtracted THAT: an HBM-bound kernel of its own (vqhip_route_residual) writes this stage's input, which
+            # the search then reads like a first stage's
+            prev_e = embed if shared else embed[q - 1]
+            psrc, plds = (xk, ldx) if q == 1 else (bufs[q - 2], D)
+            _check(lib().vqhip_route_residual(_ptr(psrc), N, D, plds, _ptr(prev_e), ctypes.c_void_p(idx.data_ptr() + 8 * (q - 1)), Q,
+                                              int(route_mode), _ptr(bufs[q - 1]), D, _stream()), "vqhip_route_residual")
+            src, lds = bufs[q - 1], D
+        elif q > 0:
             prev_e = embed if shared else embed[q - 1]
             ch.prev_idx = idx.data_ptr() + 8 * (q - 1)
             ch.prev_embed = prev_e.data_ptr()

@@ -37,7 +37,6 @@
 #include "vqhip_internal.h"
 
 #include "vq_screen_args.h"
-#include "vq_route_math.h"
 
 #ifdef VQ_TRACE
 extern long long *vq_g_trace;
@@ -95,9 +94,7 @@ template <int DT> struct Screen16Cfg {
 // NPART = 2 (fp32 rows, D <= 128, where two operand sets per row block still fit the registers): x' = x_h + x_m, both truncated
 // fp16 parts (|x' - x_h - x_m| <= 2^-20 |x'|), two MFMAs per k-step on one A fragment -- the x side then costs the certificate
 // 2^-20 X Y instead of the measured 2^-11-level residual, which brings the uncertified fraction of fp32 rows down to bf16 levels.
-// ROUTED: the chain prologue subtracts the previous layer's ROUTED value (a.prev_route = 1 / 2) instead of its code row -- an
-// instantiation of its own, so that the row reductions' registers do not weigh on the prologue of the default kernel.
-template <int DT, int METRIC, bool XF32 = false, int NPART = 1, bool ROUTED = false>
+template <int DT, int METRIC, bool XF32 = false, int NPART = 1>
 __global__ void __launch_bounds__(VQS_WAVES * 64, 8 / VQS_WAVES) vq_screen16_kernel(const ScreenArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -257,21 +254,6 @@ __global__ void __launch_bounds__(VQS_WAVES * 64, 8 / VQS_WAVES) vq_screen16_ker
                         f32x4 e[NSTEP];
 #pragma unroll
                         for (int st = 0; st < NSTEP; ++st) e[st] = *(const f32x4 *)(pe + st * CH);
-                        if constexpr (ROUTED) {
-                            // the previous layer returned the ROUTED value (straight-through / rotation trick: training with an input
-                            // that requires grad, vqp.py:1225-1233) and rvq.py:524 subtracted that: the same arithmetic as
-                            // vq_route_kernel / vq_rvq_route_kernel (vq_route_math.h; this lane's elements are the 16-lane row
-                            // layout's, so the sums are formed in the same order), bit for bit
-                            float rv[4 * NSTEP], cv[4 * NSTEP], tv[4 * NSTEP];
-#pragma unroll
-                            for (int st = 0; st < NSTEP; ++st) {
-                                rv[4 * st + 0] = g[st][i].x; rv[4 * st + 1] = g[st][i].y; rv[4 * st + 2] = g[st][i].z; rv[4 * st + 3] = g[st][i].w;
-                                cv[4 * st + 0] = e[st].x; cv[4 * st + 1] = e[st].y; cv[4 * st + 2] = e[st].z; cv[4 * st + 3] = e[st].w;
-                            }
-                            vq_route_value<4 * NSTEP, LPR>(rv, cv, a.prev_route, tv);
-#pragma unroll
-                            for (int st = 0; st < NSTEP; ++st) e[st] = f32x4{tv[4 * st + 0], tv[4 * st + 1], tv[4 * st + 2], tv[4 * st + 3]};
-                        }
 #pragma unroll
                         for (int st = 0; st < NSTEP; ++st) {
                             g[st][i] = g[st][i] - e[st];
@@ -636,7 +618,6 @@ __global__ void __launch_bounds__(VQS_WAVES * 64, 8 / VQS_WAVES) vq_screen16_ker
         const bool on = row_ok[rb] && half == 0;
         cls[rb] = !on ? 0 : (certified ? 0 : (pair ? 2 : 1));
         id2s[rb] = id2;
-        if (a.hist && on && certified) atomicAdd(&a.hist[code[rb]], 1);   // (no return value: fire and forget)
     }
     // the uncertified rows go to their lists -- open rows from the front, pair rows from the back of the same arrays.  ONE
     // atomic per wave and list, issued here; the slots are only needed after the output phase, which hides the round trip
@@ -1093,7 +1074,6 @@ __global__ void __launch_bounds__(VQS_F32_WAVES * 64, (XBF16 && NPART == 1 && DT
         if (code >= a.C) code = 0;
         const bool on = row_ok && half == 0;
         cls = !on ? 0 : (certified ? 0 : (pair ? 2 : 1));
-        if (a.hist && on && certified) atomicAdd(&a.hist[code], 1);
     }
     const unsigned long long balo = __ballot(cls == 1), balp = __ballot(cls == 2);
     int base_o = 0, base_p = 0;
@@ -1213,32 +1193,16 @@ extern "C" int vqhip_screen_supported(int64_t N, int D, int C)
     return (D == 32 || D == 64 || D == 128 || D == 256 || D == 512) && N > 0 && N < ((int64_t)1 << 31) - 512 && C >= 2;
 }
 
-static bool screen_f32_two_part()     // VQHIP_SCREEN_F32_2PART=1: fp32 rows through the two-operand-set kernel (A/B runs)
-{
-    static int v = -1;
-    if (v < 0) { const char *e = getenv("VQHIP_SCREEN_F32_2PART"); v = (e && e[0] == '1') ? 1 : 0; }
-    return v != 0;
-}
-
 template <int DT, int METRIC>
 static int launch_screen(const ScreenArgs &a, int x_dtype, hipStream_t st)
 {
     const unsigned blocks = (unsigned)vqhip_screen_blocks(a.N, x_dtype);
     // fp16 single-codebook-part kernels: bf16 rows with D <= 256 keep two row blocks per wave, everything else one
     if (x_dtype == VQHIP_BF16) {
-        static int one_rb = -1;      // VQHIP_SCREEN_1RB=1: bf16 rows through the one-row-block kernel (4 waves per SIMD), A/B
-        if (one_rb < 0) { const char *e = getenv("VQHIP_SCREEN_1RB"); one_rb = (e && e[0] == '1') ? 1 : 0; }
-        if constexpr (DT == 256) {   // persistent form with the cyclic tile stream (vq_screen_c.hip), opt-in
+        if constexpr (DT == 256) {   // persistent form with the cyclic tile stream (vq_screen_c.hip): large batches without squared-error / residual outputs
             if (vq_screenc_eligible(a, x_dtype, DT)) return vq_screenc_launch(a, METRIC, st);
         }
         if constexpr (DT <= 256) {
-            if (one_rb) {
-                static VqAttrOnce once1;
-                constexpr int SMEM1 = Screen16F32Cfg<DT>::SMEM;
-                if (int rc = vq_set_max_smem(once1, (const void *)vq_screen16_1rb_kernel<DT, METRIC, true, 1>, SMEM1, "vq_screen16_1rb_kernel")) return rc;
-                hipLaunchKernelGGL((vq_screen16_1rb_kernel<DT, METRIC, true, 1>), dim3(blocks), dim3(VQS_F32_WAVES * 64), SMEM1, st, a);
-                return vq_launch_status("vq_screen16_1rb_kernel (bf16)");
-            }
             static VqAttrOnce once;
 #ifndef VQS16_LDS_PAD
 #define VQS16_LDS_PAD 0      // A/B: extra dynamic LDS (> 8 KiB at D = 256: one workgroup per CU, i.e. one wave per SIMD)
@@ -1253,33 +1217,27 @@ static int launch_screen(const ScreenArgs &a, int x_dtype, hipStream_t st)
             hipLaunchKernelGGL((vq_screen16_1rb_kernel<DT, METRIC, true, 1>), dim3(blocks), dim3(VQS_F32_WAVES * 64), SMEM16, st, a);
         }
     } else {
-        // fp32 rows, D <= 256: one fp16 operand set, two row blocks per wave (VQHIP_SCREEN_F32_2PART=1: the two-set kernel, A/B)
-        const int two_part = screen_f32_two_part() ? 1 : 0;
+        // fp32 rows, D <= 256: one fp16 operand set, two row blocks per wave.  (The two-operand-set form x_h + x_m of the one-row-block
+        // kernel -- NPART = 2, half the uncertified rows -- was measured slower in rounds 2 and 3, 1.43 vs 1.21 ms at cfg-2 size, and is
+        // no longer instantiated.)
         if constexpr (DT <= 256) {
-            if (!two_part) {
+            {
                 static VqAttrOnce once;
                 constexpr int SMEM16 = Screen16Cfg<DT>::SMEM;
                 // (NPART = 2 fits the registers for D <= 128 and halves the uncertified rows of fp32 inputs, but its second MFMA per
                 //  k-step costs more than the exact passes it saves: cfg 5 26.0 vs 23.5 ms -- measured, not adopted)
                 constexpr int NP = 1;
-                if (a.prev_idx && a.prev_route != 0) {
-                    if constexpr (METRIC == 0) {       // (the chain is Euclidean only)
-                        static VqAttrOnce once_r;
-                        if (int rc = vq_set_max_smem(once_r, (const void *)vq_screen16_kernel<DT, METRIC, true, NP, true>, SMEM16, "vq_screen16_kernel (fp32 rows, routed chain)")) return rc;
-                        hipLaunchKernelGGL((vq_screen16_kernel<DT, METRIC, true, NP, true>), dim3(blocks), dim3(VQS_WAVES * 64), SMEM16, st, a);
-                        return vq_launch_status("vq_screen16_kernel (fp32 rows, routed chain)");
-                    }
-                }
                 if (int rc = vq_set_max_smem(once, (const void *)vq_screen16_kernel<DT, METRIC, true, NP>, SMEM16, "vq_screen16_kernel (fp32 rows)")) return rc;
                 hipLaunchKernelGGL((vq_screen16_kernel<DT, METRIC, true, NP>), dim3(blocks), dim3(VQS_WAVES * 64), SMEM16, st, a);
                 return vq_launch_status("vq_screen16_kernel (fp32 rows)");
             }
         }
-        static VqAttrOnce once;
-        constexpr int SMEM16 = Screen16F32Cfg<DT>::SMEM;
-        constexpr int NPART = DT <= 256 ? 2 : 1;
-        if (int rc = vq_set_max_smem(once, (const void *)vq_screen16_1rb_kernel<DT, METRIC, false, NPART>, SMEM16, "vq_screen16_1rb_kernel")) return rc;
-        hipLaunchKernelGGL((vq_screen16_1rb_kernel<DT, METRIC, false, NPART>), dim3(blocks), dim3(VQS_F32_WAVES * 64), SMEM16, st, a);
+        if constexpr (DT > 256) {
+            static VqAttrOnce once;
+            constexpr int SMEM16 = Screen16F32Cfg<DT>::SMEM;
+            if (int rc = vq_set_max_smem(once, (const void *)vq_screen16_1rb_kernel<DT, METRIC, false, 1>, SMEM16, "vq_screen16_1rb_kernel")) return rc;
+            hipLaunchKernelGGL((vq_screen16_1rb_kernel<DT, METRIC, false, 1>), dim3(blocks), dim3(VQS_F32_WAVES * 64), SMEM16, st, a);
+        }
     }
     return vq_launch_status("vq_screen16 kernels");
 }
@@ -1297,7 +1255,7 @@ extern "C" int vqhip_assign_screened(const void *x, int x_dtype, int64_t N, int 
                                      void *workspace, size_t workspace_bytes, float *debug_out, void *stream)
 {
     return vq_assign_screened_impl(x, x_dtype, N, D, ldx, packed, embed, C, metric, idx_out, q_out, ldq, resid_out, ldr, sqerr_partial,
-                                   row_mask, workspace, workspace_bytes, debug_out, nullptr, nullptr, 0, stream);
+                                   row_mask, workspace, workspace_bytes, debug_out, nullptr, 0, stream);
 }
 
 extern "C" int vqhip_screen_chain_supported(int x_dtype, int D)
@@ -1305,7 +1263,7 @@ extern "C" int vqhip_screen_chain_supported(int x_dtype, int D)
 #ifdef VQS16_F32_DIRECT      // (A/B build whose fp32-row prologue has no chain step)
     return 0;
 #endif
-    return (x_dtype == VQHIP_F32 && (D == 32 || D == 64 || D == 128 || D == 256) && !screen_f32_two_part()) ? 1 : 0;
+    return (x_dtype == VQHIP_F32 && (D == 32 || D == 64 || D == 128 || D == 256)) ? 1 : 0;
 }
 
 extern "C" int vqhip_assign_screened_chain(const void *x, int x_dtype, int64_t N, int D, int64_t ldx, const float *packed,
@@ -1321,19 +1279,19 @@ extern "C" int vqhip_assign_screened_chain(const void *x, int x_dtype, int64_t N
             VQ_FAIL(VQHIP_EINVAL, "assign_screened_chain: prev_idx needs prev_embed, x_out and valid strides");
         if ((((uintptr_t)chain->prev_embed) & 15) || (((uintptr_t)chain->x_out) & 15) || ((chain->ldxo * 4) & 15))
             VQ_FAIL(VQHIP_EALIGN, "assign_screened_chain: prev_embed / x_out rows must be 16-byte aligned");
-        if (chain->route_mode < 0 || chain->route_mode > 2) VQ_FAIL(VQHIP_EINVAL, "assign_screened_chain: route_mode must be 0, 1 or 2");
+        if (chain->route_mode != 0)
+            VQ_FAIL(VQHIP_EINVAL, "assign_screened_chain: route_mode is gone (round 4): form a routed residual with vqhip_route_residual and pass it as x with prev_idx = NULL");
     }
     return vq_assign_screened_impl(x, x_dtype, N, D, ldx, packed, embed, C, metric, idx_out, nullptr, D, nullptr, D, nullptr, row_mask,
-                                   workspace, workspace_bytes, nullptr, chain, chain->hist, chain->header_zeroed != 0, stream);
+                                   workspace, workspace_bytes, nullptr, chain, chain->header_zeroed != 0, stream);
 }
 
-// hist (nullable, [C] ints zeroed by the caller): the rows per code, counted here for the EMA statistics' counting sort.
 // header_zeroed: the caller has zeroed the first 16 bytes of the workspace (the list counters) on this stream already.
 int vq_assign_screened_impl(const void *x, int x_dtype, int64_t N, int D, int64_t ldx, const float *packed,
                             const float *embed, int C, int metric, int64_t *idx_out, void *q_out, int64_t ldq,
                             void *resid_out, int64_t ldr, double *sqerr_partial, const uint8_t *row_mask,
                             void *workspace, size_t workspace_bytes, float *debug_out, const vqhip_chain_t *chain,
-                            int *hist, int header_zeroed, void *stream)
+                            int header_zeroed, void *stream)
 {
     if (N < 0 || C <= 0) VQ_FAIL(VQHIP_EINVAL, "assign_screened: N < 0 or C <= 0");
     if (N == 0) return 0;
@@ -1354,7 +1312,6 @@ int vq_assign_screened_impl(const void *x, int x_dtype, int64_t N, int D, int64_
     hipStream_t st = (hipStream_t)stream;
     int *count = (int *)workspace;
     int *rows = count + 4;
-    if (hist && row_mask) VQ_FAIL(VQHIP_EINVAL, "assign_screened: the fused histogram does not take a row mask");
     if (!header_zeroed) {
         hipError_t e = hipMemsetAsync(count, 0, 16, st);
         if (e != hipSuccess) VQ_FAIL((int)e, "assign_screened: hipMemsetAsync: %s", hipGetErrorString(e));
@@ -1372,7 +1329,7 @@ int vq_assign_screened_impl(const void *x, int x_dtype, int64_t N, int D, int64_
     a.idx_out = idx_out; a.q_out = q_out; a.ldq = ldq; a.resid_out = resid_out; a.ldr = ldr;
     a.sqerr_partial = sqerr_partial; a.row_mask = row_mask;
     unsigned long long *keys = (unsigned long long *)((char *)workspace + 16 + (((size_t)N * sizeof(int) + 7) & ~(size_t)7));
-    a.flag_count = count; a.flag_rows = rows; a.flag_keys = keys; a.dbg = debug_out; a.hist = hist;
+    a.flag_count = count; a.flag_rows = rows; a.flag_keys = keys; a.dbg = debug_out;
     {
         const size_t nseg = (size_t)N + 256 * (size_t)VQ_SEG_MAX;
         a.seg_counts = (int *)(keys + N);
@@ -1386,7 +1343,6 @@ int vq_assign_screened_impl(const void *x, int x_dtype, int64_t N, int D, int64_
     a.prev_embed = chain ? chain->prev_embed : nullptr;
     a.x_out = chain ? (float *)chain->x_out : nullptr;
     a.ldxo = chain ? chain->ldxo : 0;
-    a.prev_route = (chain && chain->prev_idx) ? (int)chain->route_mode : 0;
 #ifdef VQ_TRACE
     a.trace = vq_g_trace;
 #endif
@@ -1410,5 +1366,5 @@ int vq_assign_screened_impl(const void *x, int x_dtype, int64_t N, int D, int64_
     const int64_t ldl = (chain && chain->prev_idx) ? chain->ldxo : ldx;
     return vq_assign_listed(xl, x_dtype, metric, N, D, ldl, packed, embed, C, idx_out, a.idx_stride, q_out, ldq, resid_out, ldr,
                             sqerr_partial ? sqerr_partial + vqhip_screen_blocks(N, x_dtype) : nullptr, row_mask, rows, count, keys,
-                            with_pairs, hist, st);
+                            with_pairs, st);
 }

@@ -37,8 +37,6 @@ struct ScreenArgs {
     int *flag_rows;
     unsigned long long *flag_keys;     // [N] keys of the exact pass, preset to ~0 for every appended row
     float *dbg;                        // nullable [N, 4]: t_best, t_second, eps_t, flagged
-    int *hist;                         // nullable [C]: rows per code of the EMA statistics' counting sort (vqp.py:602), zeroed by the caller --
-                                       // certified rows are counted here, listed rows by vq_finish_listed_kernel (no vq_hist_kernel pass)
     // residual chain (vq_screen16_kernel, fp32 rows): this stage's rows are x - prev_embed[prev_idx], formed in the prologue from
     // the PREVIOUS stage's input and indices and written to x_out (the exact passes and the statistics read them there)
     int64_t idx_stride;                // idx_out[row * idx_stride] (a column of an [N, Q] index tensor)
@@ -47,7 +45,6 @@ struct ScreenArgs {
     const float *prev_embed;           // [C_prev, D] fp32
     float *x_out;
     int64_t ldxo;
-    int prev_route;                    // what the previous layer returned (and rvq.py:524 subtracted): 0 the code row, 1 straight-through, 2 rotation trick
     // segmented lists (vq_screenc_kernel: every workgroup appends to its own segment, no global atomics; vq_compact_lists_kernel
     // packs the segments into flag_rows / flag_keys and writes flag_count)
     int *seg_counts;                   // [2 * VQ_SEG_MAX]: open, pair entries per segment

@@ -12,7 +12,8 @@
 //     spread over a fraction of a period, so that the chip's row traffic (the HBM-bound part of vq_screen16_kernel, where all
 //     workgroups load, sweep and write in the same phase of every round) is spread over the whole launch.
 //
-// Eligibility (launch_screen in vq_screen.hip): bf16 rows, D = 256, no residual / squared-error output, N >= VQC_MIN_ROWS.
+// Eligibility (launch_screen in vq_screen.hip): bf16 rows, D = 256, no residual / squared-error output, N >= VQC_MIN_ROWS -- the
+// default there since round 4 (full adversarial fuzz of tests/test_gpu_screen_fuzz.py green; VQHIP_SCREEN_PERSIST=0: the 4-wave kernel).
 // Reference arithmetic that the screen certifies: cdist at vqp.py:58-62, argmax at vqp.py:140 (cosine: einsum at vqp.py:741).
 
 #include <type_traits>
@@ -405,7 +406,6 @@ __global__ void __launch_bounds__(256, 2) vq_screenc_kernel(const ScreenArgs a, 
             if (code >= a.C) code = 0;
             cls = !on ? 0 : (certified ? 0 : (pair ? 2 : 1));
             prow = (int)row;
-            if (a.hist && on && certified) atomicAdd(&a.hist[code], 1);
         }
         const unsigned long long balo = __ballot(cls == 1), balp = __ballot(cls == 2);
         // list space: this workgroup's own segment of the staging lists (open rows from its front, pair rows from its back), handed
@@ -530,7 +530,7 @@ extern "C" void vqhip_screenc_set_trace(long long *p) { vqc_g_trace = p; }
 static int vqc_enabled()
 {
     static int v = -1;
-    if (v < 0) { const char *e = getenv("VQHIP_SCREEN_PERSIST"); v = (e && e[0] == '2') ? 1 : 0; }
+    if (v < 0) { const char *e = getenv("VQHIP_SCREEN_PERSIST"); v = (e && e[0] == '0') ? 0 : 1; }   // =0: the 4-wave kernel (A/B runs)
     return v;
 }
 

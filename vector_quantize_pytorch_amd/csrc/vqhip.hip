@@ -572,6 +572,7 @@ __global__ void __launch_bounds__(256, (DT <= 256 ? 2 : 1)) vq_assign_kernel(con
     float lse_m = -__builtin_inff(), lse_l = 0.f, ts = 0.f;
     const int64_t tgt = (a.lse_out && a.target && row_ok) ? a.target[row] : (int64_t)-1;
     const int nt = a.n_tiles;
+#pragma unroll 1
     for (int ct = 0; ct < nt; ++ct) {
         const int buf = ct & 1;
         VQ_STAMP(0);
@@ -646,86 +647,44 @@ __global__ void __launch_bounds__(256, (DT <= 256 ? 2 : 1)) vq_assign_kernel(con
         if (a.rnorm_out) a.rnorm_out[row] = (METRIC == 0) ? x2 : nrm;
     }
 
-    // ---- q = embed[idx]: row-cooperative copy.  For each of the wave's 32 rows all 64 lanes move the
-    //      winning code row L2 -> HBM as whole contiguous rows (per-lane-row stores of 8..16 bytes were
-    //      measured at 1.7x write amplification: profiles/r1_first).  8 rows in flight per wave. ------
-    if (a.q_out) {
+    // ---- commitment-loss partial: sum over the wave's rows of sum_d (q - x)^2, x still in registers (before the q copy: the
+    //      rows' registers are dead afterwards and the copy's staging takes their place -- D = 512 spilled 600 registers otherwise) ----
+    if (DT == 512 && a.sqerr_partial) {
+        // D = 512: the rows fill 256 registers; keeping them alive past the sweep for this sum cost 470 - 660 spilled registers.
+        // x and the winning code rows are re-read instead, a row at a time across the wave (coalesced; the fallback kernel's loss only).
         const int64_t wrow0 = (int64_t)blockIdx.x * VQHIP_ASSIGN_ROWS_PER_BLOCK + wave * 32;
         const bool qb = a.q_bf16 != 0;
-        if (a.q_vec && a.x_vec && qb) {     // bf16 out: verbatim copy of the pre-rounded rows, 8 bytes per lane
-#pragma unroll
-            for (int r0 = 0; r0 < 32; r0 += 8) {
-                uint2 g[8][(DT + 255) / 256];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int c = __builtin_amdgcn_readlane(bi, r0 + u);
-                    const unsigned short *er = a.embed_bf16 + (size_t)c * DT;
-#pragma unroll
-                    for (int h = 0; h < (DT + 255) / 256; ++h) {
-                        const int d = h * 256 + lane * 4;
-                        if (d < DT) g[u][h] = *(const uint2 *)(er + d);
-                    }
+        double ds = 0.0;
+#pragma unroll 1
+        for (int r = 0; r < 32; ++r) {
+            const int64_t rr = wrow0 + r;
+            if (rr >= a.N) break;
+            if (a.row_mask && a.row_mask[rr] == 0) continue;
+            const int c = __builtin_amdgcn_readlane(bi, r);
+            const float nr = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(nrm), r));
+            float ls = 0.f;
+            for (int d = lane; d < a.D; d += 64) {
+                float g = a.embed[(size_t)c * a.D + d];
+                if (qb) g = round_to_bf16(g);
+                float xv = load_elem<XBF16>(a.x, rr * a.ldx + d);
+                if (METRIC == 1 && !a.skip_norm) {      // the l2norm the prologue applied to the registers (vqp.py:37-38)
+                    xv = xv / nr;
+                    if (XBF16) xv = round_to_bf16(xv);
                 }
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int64_t rr = wrow0 + r0 + u;
-                    if (rr < a.N) {
-#pragma unroll
-                        for (int h = 0; h < (DT + 255) / 256; ++h) {
-                            const int d = h * 256 + lane * 4;
-                            if (d < DT) *(uint2 *)((unsigned short *)a.q_out + rr * a.ldq + d) = g[u][h];
-                        }
-                    }
-                }
+                const float df = g - xv;
+                ls += df * df;
             }
-        } else if (a.q_vec && a.x_vec) {
-#pragma unroll
-            for (int r0 = 0; r0 < 32; r0 += 8) {
-                f32x4 g[8][(DT + 255) / 256];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int c = __builtin_amdgcn_readlane(bi, r0 + u);
-                    const float *er = a.embed + (size_t)c * DT;
-#pragma unroll
-                    for (int h = 0; h < (DT + 255) / 256; ++h) {
-                        const int d = h * 256 + lane * 4;
-                        if (d < DT) g[u][h] = *(const f32x4 *)(er + d);
-                    }
-                }
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int64_t rr = wrow0 + r0 + u;
-                    if (rr < a.N) {
-#pragma unroll
-                        for (int h = 0; h < (DT + 255) / 256; ++h) {
-                            const int d = h * 256 + lane * 4;
-                            if (d < DT) *(f32x4 *)((float *)a.q_out + rr * a.ldq + d) = g[u][h];
-                        }
-                    }
-                }
-            }
-        } else {
-            for (int r = 0; r < 32; ++r) {
-                const int64_t rr = wrow0 + r;
-                if (rr >= a.N) break;
-                const int c = __builtin_amdgcn_readlane(bi, r);
-                const float *er = a.embed + (size_t)c * a.D;
-                for (int d = lane; d < a.D; d += 64) {
-                    if (qb) ((unsigned short *)a.q_out)[rr * a.ldq + d] = f32_to_bf16_rne(er[d]);
-                    else ((float *)a.q_out)[rr * a.ldq + d] = er[d];
-                }
-            }
+            ds += (double)ls;
         }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) ds += __shfl_xor(ds, o, 64);
+        __syncthreads();
+        double *red = (double *)smem;
+        if (lane == 0) red[wave] = ds;
+        __syncthreads();
+        if (tid == 0) a.sqerr_partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
     }
-
-    // ---- commitment-loss partial: sum over the wave's rows of sum_d (q - x)^2, x still in registers ----
-    if (a.sqerr_partial) {
-        // back to the load layout (the swap is an involution)
-#pragma unroll
-        for (int m = 0; m < NG; ++m) {
-            swap32(xr[4 * m + 0], xr[4 * m + 1]);
-            swap32(xr[4 * m + 2], xr[4 * m + 3]);
-        }
+    if (DT < 512 && a.sqerr_partial) {
         const float *er = a.embed + (size_t)bi * a.D;
         const unsigned short *erb = a.embed_bf16 + (size_t)bi * a.D;
         const bool qb = a.q_bf16 != 0;
@@ -734,6 +693,8 @@ __global__ void __launch_bounds__(256, (DT <= 256 ? 2 : 1)) vq_assign_kernel(con
 #pragma unroll
         for (int m = 0; m < NG; ++m) {
             const int k0 = 8 * m + 4 * hi;
+            swap32(xr[4 * m + 0], xr[4 * m + 1]);   // this group back to the load layout (the swap is an involution)
+            swap32(xr[4 * m + 2], xr[4 * m + 3]);
             float g[4];
             if (a.x_vec && qb) {        // 4 pre-rounded bf16 values in one 8-byte load
                 const uint2 w = *(const uint2 *)(erb + k0);
@@ -761,6 +722,9 @@ __global__ void __launch_bounds__(256, (DT <= 256 ? 2 : 1)) vq_assign_kernel(con
                     lsum += df * df;
                 }
             }
+            // at most 8 code-row loads in flight: requested all at once (NG = 64 at D = 512: 256 registers next to the 256 of the
+            // rows) they cost the D = 512 fp32 kernel 470 spilled registers
+            if ((m & 7) == 7) __builtin_amdgcn_sched_barrier(0);
         }
         lsum += lsum2[0] + lsum2[1];
         const bool counted = row_ok && (!a.row_mask || a.row_mask[row] != 0);
@@ -774,6 +738,77 @@ __global__ void __launch_bounds__(256, (DT <= 256 ? 2 : 1)) vq_assign_kernel(con
         __syncthreads();
         if (tid == 0) a.sqerr_partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
     }
+    // ---- q = embed[idx]: row-cooperative copy.  For each of the wave's 32 rows all 64 lanes move the
+    //      winning code row L2 -> HBM as whole contiguous rows (per-lane-row stores of 8..16 bytes were
+    //      measured at 1.7x write amplification: profiles/r1_first).  8 rows in flight per wave. ------
+    if (a.q_out) {
+        const int64_t wrow0 = (int64_t)blockIdx.x * VQHIP_ASSIGN_ROWS_PER_BLOCK + wave * 32;
+        const bool qb = a.q_bf16 != 0;
+        // LPR lanes move one row (4 elements each; 64 lanes x 2 passes at D = 512), RPI rows per wave instruction, up to 8
+        // instructions in flight.  (One row per instruction with the lanes past the row's end masked off -- the first version --
+        // made hipcc spill 1 200 - 1 800 registers at D = 128: every guarded load became a divergent region of its own.)
+        constexpr int LPR = DT >= 256 ? 64 : DT / 4;
+        constexpr int RPI = 64 / LPR;
+        constexpr int NH = (DT + 255) / 256;
+        constexpr int NINS = 32 / RPI;                  // wave instructions for the wave's 32 rows
+        constexpr int FL = DT > 256 ? 4 : (NINS < 8 ? NINS : 8);   // in flight
+        const int sub = lane / LPR, lc4 = (lane % LPR) * 4;
+        if (a.q_vec && a.x_vec && qb) {     // bf16 out: verbatim copy of the pre-rounded rows, 8 bytes per lane
+#pragma unroll
+            for (int i0 = 0; i0 < NINS; i0 += FL) {
+                uint2 g[FL][NH];
+#pragma unroll
+                for (int u = 0; u < FL; ++u) {
+                    const int rl = (i0 + u) * RPI + sub;
+                    const int c = RPI == 1 ? __builtin_amdgcn_readlane(bi, rl) : __shfl(bi, rl, 64);
+                    const unsigned short *er = a.embed_bf16 + (size_t)c * DT + lc4;
+#pragma unroll
+                    for (int h = 0; h < NH; ++h) g[u][h] = *(const uint2 *)(er + h * 256);
+                }
+#pragma unroll
+                for (int u = 0; u < FL; ++u) {
+                    const int64_t rr = wrow0 + (i0 + u) * RPI + sub;
+                    if (rr < a.N) {
+#pragma unroll
+                        for (int h = 0; h < NH; ++h) *(uint2 *)((unsigned short *)a.q_out + rr * a.ldq + lc4 + h * 256) = g[u][h];
+                    }
+                }
+            }
+        } else if (a.q_vec && a.x_vec) {
+#pragma unroll
+            for (int i0 = 0; i0 < NINS; i0 += FL) {
+                f32x4 g[FL][NH];
+#pragma unroll
+                for (int u = 0; u < FL; ++u) {
+                    const int rl = (i0 + u) * RPI + sub;
+                    const int c = RPI == 1 ? __builtin_amdgcn_readlane(bi, rl) : __shfl(bi, rl, 64);
+                    const float *er = a.embed + (size_t)c * DT + lc4;
+#pragma unroll
+                    for (int h = 0; h < NH; ++h) g[u][h] = *(const f32x4 *)(er + h * 256);
+                }
+#pragma unroll
+                for (int u = 0; u < FL; ++u) {
+                    const int64_t rr = wrow0 + (i0 + u) * RPI + sub;
+                    if (rr < a.N) {
+#pragma unroll
+                        for (int h = 0; h < NH; ++h) *(f32x4 *)((float *)a.q_out + rr * a.ldq + lc4 + h * 256) = g[u][h];
+                    }
+                }
+            }
+        } else {
+            for (int r = 0; r < 32; ++r) {
+                const int64_t rr = wrow0 + r;
+                if (rr >= a.N) break;
+                const int c = __builtin_amdgcn_readlane(bi, r);
+                const float *er = a.embed + (size_t)c * a.D;
+                for (int d = lane; d < a.D; d += 64) {
+                    if (qb) ((unsigned short *)a.q_out)[rr * a.ldq + d] = f32_to_bf16_rne(er[d]);
+                    else ((float *)a.q_out)[rr * a.ldq + d] = er[d];
+                }
+            }
+        }
+    }
+
 }
 
 extern "C" int64_t vqhip_assign_blocks(int64_t N)
@@ -1511,7 +1546,6 @@ struct FinishArgs {
     int64_t ldr;
     double *sqerr_partial;   // nullable, one entry per workgroup
     const uint8_t *row_mask;
-    int *hist;               // nullable [C]: rows per code for the statistics' counting sort (the certified rows were counted by the screen)
 };
 
 // one wave per listed row: idx, q row, sum (q - x)^2.  A row is a chain of dependent loads (list -> key -> code row): the kernel is
@@ -1530,10 +1564,7 @@ __global__ void __launch_bounds__(VQ_FINISH_WAVES * 64) vq_finish_listed_kernel(
         const int64_t pos = v < n_full ? v : a.cap - 1 - (v - n_full);
         const int64_t row = a.row_list[pos];
         const int idx = (int)(unsigned)(a.keys[pos] & 0xffffffffull);
-        if (lane == 0) {
-            a.idx_out[row * a.idx_stride] = (int64_t)idx;
-            if (a.hist) atomicAdd(&a.hist[idx], 1);
-        }
+        if (lane == 0) a.idx_out[row * a.idx_stride] = (int64_t)idx;
         float ls = 0.f;
         for (int c0 = lane * 4; c0 < a.D; c0 += 256) {
             float d0, d1, d2, d3;
@@ -1621,7 +1652,6 @@ template <bool XBF16> struct PairCfg {
     static constexpr int SMEM = VQ_PAIR_WAVES * WAVE_B;
 };
 
-// VQ_PAIR_WAVES waves of the workgroup work (the others return): in the merged launch the workgroups have the exact sweep's 4
 template <int DT, bool XBF16, int METRIC>
 __device__ __forceinline__ void vq_pair_body(const PairArgs &a, char *smem, const unsigned bid, const unsigned nblk)
 {
@@ -1731,36 +1761,6 @@ __global__ void __launch_bounds__(VQ_PAIR_WAVES * 64) vq_pair_kernel(const PairA
     vq_pair_body<DT, XBF16, METRIC>(a, smem, blockIdx.x, gridDim.x);
 }
 
-// The two exact passes are independent (open rows at the front of the list, pair rows at its back): ONE launch runs both side by
-// side -- workgroups [0, refine_blocks) sweep the codebook for the open rows, the rest decide the pair rows -- instead of two
-// small kernels back to back.
-template <int DT, bool XBF16, int METRIC>
-__global__ void __launch_bounds__(256, (DT <= 256 ? 2 : 1)) vq_listed_kernel(const RefineArgs r, const PairArgs p, const unsigned refine_blocks)
-{
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    if (blockIdx.x < refine_blocks) vq_refine_body<DT, XBF16, METRIC>(r, smem, blockIdx.x, refine_blocks);
-    else vq_pair_body<DT, XBF16, METRIC>(p, smem, blockIdx.x - refine_blocks, gridDim.x - refine_blocks);
-}
-
-template <int DT, bool XBF16, int METRIC>
-static int launch_listed(const RefineArgs &r, const PairArgs &p, unsigned gx, unsigned pair_blocks, hipStream_t st)
-{
-    constexpr int SMEM_R = 2 * (32 * DT + 256) * 4;
-    constexpr int SMEM = SMEM_R > PairCfg<XBF16>::SMEM ? SMEM_R : PairCfg<XBF16>::SMEM;
-    static VqAttrOnce once;
-    if (int rc = vq_set_max_smem(once, (const void *)vq_listed_kernel<DT, XBF16, METRIC>, SMEM, "vq_listed_kernel")) return rc;
-    hipLaunchKernelGGL((vq_listed_kernel<DT, XBF16, METRIC>), dim3(gx + pair_blocks), dim3(256), SMEM, st, r, p, gx);
-    return launch_status("vq_listed_kernel");
-}
-
-template <int DT>
-static int dispatch_listed(const RefineArgs &r, const PairArgs &p, int x_dtype, int metric, unsigned gx, unsigned pair_blocks, hipStream_t st)
-{
-    if (metric == VQHIP_EUCLID)
-        return x_dtype == VQHIP_BF16 ? launch_listed<DT, true, 0>(r, p, gx, pair_blocks, st) : launch_listed<DT, false, 0>(r, p, gx, pair_blocks, st);
-    return x_dtype == VQHIP_BF16 ? launch_listed<DT, true, 1>(r, p, gx, pair_blocks, st) : launch_listed<DT, false, 1>(r, p, gx, pair_blocks, st);
-}
-
 template <int DT>
 static int dispatch_pair(const PairArgs &a, int x_dtype, int metric, unsigned blocks, hipStream_t st)
 {
@@ -1774,7 +1774,7 @@ static int dispatch_pair(const PairArgs &a, int x_dtype, int metric, unsigned bl
 int vq_assign_listed(const void *x, int x_dtype, int metric, int64_t N, int D, int64_t ldx, const float *packed, const float *embed, int C,
                      int64_t *idx_out, int64_t idx_stride, void *q_out, int64_t ldq, void *resid_out, int64_t ldr, double *sqerr_partial,
                      const uint8_t *row_mask, const int *row_list, const int *row_count, unsigned long long *keys, int with_pairs,
-                     int *hist, hipStream_t st)
+                     hipStream_t st)
 {
     // keys[0 .. row_count[0]) were preset to ~0 by whoever built the list (the screening kernels); the pair entries at
     // [N - row_count[1], N) hold their two candidates
@@ -1785,52 +1785,37 @@ int vq_assign_listed(const void *x, int x_dtype, int metric, int64_t N, int D, i
     const int64_t want = chunks * r.n_tiles;              // one workgroup per (chunk, tile) at most
     const unsigned gx = (unsigned)(want < VQ_REFINE_GRID ? want : VQ_REFINE_GRID);
     int rc;
-    // VQHIP_LISTED_MERGED=1: the two exact passes side by side in ONE launch (vq_listed_kernel).  Measured a wash against two
-    // launches back to back (cfg 2 +0.9 %, cfg 3 -1.4 %, cfg 5 +1.8 %: the pair rows' workgroups take the exact sweep's LDS and
-    // register budget), so the two-launch form stays the default.
-    static int split = -1;
-    if (split < 0) { const char *e = getenv("VQHIP_LISTED_MERGED"); split = (e && e[0] == '1') ? 0 : 1; }
+    // (Both exact passes side by side in ONE launch -- workgroups [0, gx) sweep, the rest decide pairs -- measured a wash in round 3:
+    //  cfg 2 +0.9 %, cfg 3 -1.4 %, cfg 5 +1.8 %; the pair rows' workgroups inherit the sweep's LDS and register budget.  Removed.)
     PairArgs pa;
     pa.x = x; pa.ldx = ldx; pa.embed = embed; pa.packed = packed; pa.D = D;
     pa.row_list = row_list; pa.row_count = row_count; pa.cap = N; pa.keys = keys;
     const int64_t pb = (N + VQ_PAIR_WAVES * 64 - 1) / (VQ_PAIR_WAVES * 64);
     const unsigned blocks = (unsigned)(pb < 1024 ? pb : 1024);
-    if (with_pairs && !split) {
+    switch (pick_dt(D)) {
+        case 32: rc = dispatch_refine<32>(r, x_dtype, metric, gx, st); break;
+        case 64: rc = dispatch_refine<64>(r, x_dtype, metric, gx, st); break;
+        case 128: rc = dispatch_refine<128>(r, x_dtype, metric, gx, st); break;
+        case 256: rc = dispatch_refine<256>(r, x_dtype, metric, gx, st); break;
+        case 512: rc = dispatch_refine<512>(r, x_dtype, metric, gx, st); break;
+        default: VQ_FAIL(VQHIP_EDIM, "assign_listed: D=%d unsupported", D);
+    }
+    if (rc) return rc;
+    if (with_pairs) {
         switch (pick_dt(D)) {
-            case 32: rc = dispatch_listed<32>(r, pa, x_dtype, metric, gx, blocks, st); break;
-            case 64: rc = dispatch_listed<64>(r, pa, x_dtype, metric, gx, blocks, st); break;
-            case 128: rc = dispatch_listed<128>(r, pa, x_dtype, metric, gx, blocks, st); break;
-            case 256: rc = dispatch_listed<256>(r, pa, x_dtype, metric, gx, blocks, st); break;
-            case 512: rc = dispatch_listed<512>(r, pa, x_dtype, metric, gx, blocks, st); break;
-            default: VQ_FAIL(VQHIP_EDIM, "assign_listed: D=%d unsupported", D);
+            case 32: rc = dispatch_pair<32>(pa, x_dtype, metric, blocks, st); break;
+            case 64: rc = dispatch_pair<64>(pa, x_dtype, metric, blocks, st); break;
+            case 128: rc = dispatch_pair<128>(pa, x_dtype, metric, blocks, st); break;
+            case 256: rc = dispatch_pair<256>(pa, x_dtype, metric, blocks, st); break;
+            default: rc = dispatch_pair<512>(pa, x_dtype, metric, blocks, st); break;
         }
         if (rc) return rc;
-    } else {
-        switch (pick_dt(D)) {
-            case 32: rc = dispatch_refine<32>(r, x_dtype, metric, gx, st); break;
-            case 64: rc = dispatch_refine<64>(r, x_dtype, metric, gx, st); break;
-            case 128: rc = dispatch_refine<128>(r, x_dtype, metric, gx, st); break;
-            case 256: rc = dispatch_refine<256>(r, x_dtype, metric, gx, st); break;
-            case 512: rc = dispatch_refine<512>(r, x_dtype, metric, gx, st); break;
-            default: VQ_FAIL(VQHIP_EDIM, "assign_listed: D=%d unsupported", D);
-        }
-        if (rc) return rc;
-        if (with_pairs) {
-            switch (pick_dt(D)) {
-                case 32: rc = dispatch_pair<32>(pa, x_dtype, metric, blocks, st); break;
-                case 64: rc = dispatch_pair<64>(pa, x_dtype, metric, blocks, st); break;
-                case 128: rc = dispatch_pair<128>(pa, x_dtype, metric, blocks, st); break;
-                case 256: rc = dispatch_pair<256>(pa, x_dtype, metric, blocks, st); break;
-                default: rc = dispatch_pair<512>(pa, x_dtype, metric, blocks, st); break;
-            }
-            if (rc) return rc;
-        }
     }
     FinishArgs f;
     f.x = x; f.ldx = ldx;
     f.codes = (x_dtype == VQHIP_BF16) ? (const void *)((const char *)packed + packed_bf16_offset(C, D)) : (const void *)embed;
     f.D = D; f.row_list = row_list; f.row_count = row_count; f.cap = N; f.keys = keys;
-    f.idx_out = idx_out; f.idx_stride = idx_stride; f.q_out = q_out; f.ldq = ldq; f.resid_out = resid_out; f.ldr = ldr; f.sqerr_partial = sqerr_partial; f.row_mask = row_mask; f.hist = hist;
+    f.idx_out = idx_out; f.idx_stride = idx_stride; f.q_out = q_out; f.ldq = ldq; f.resid_out = resid_out; f.ldr = ldr; f.sqerr_partial = sqerr_partial; f.row_mask = row_mask;
     if (x_dtype == VQHIP_BF16)
         hipLaunchKernelGGL(vq_finish_listed_kernel<true>, dim3(VQ_FINISH_BLOCKS), dim3(VQ_FINISH_WAVES * 64), 0, st, f);
     else
@@ -1869,7 +1854,9 @@ struct RvqArgs {
     int x_vec;
 };
 
-template <int DT, bool XBF16>
+// VEC: D == DT and every row is vector-aligned (an instantiation of its own: with the element-wise fallback in the same body the
+// D = 256 / 512 kernels spilled 400 - 1 000 registers)
+template <int DT, bool XBF16, bool VEC>
 __global__ void __launch_bounds__(256, (DT <= 256 ? 2 : 1)) vq_rvq_kernel(const RvqArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1900,7 +1887,7 @@ __global__ void __launch_bounds__(256, (DT <= 256 ? 2 : 1)) vq_rvq_kernel(const 
         *(f32x4 *)(smem + piece_off + k * 4096) = *(const f32x4 *)(tile_src(0) + (size_t)k * 4096);
 
     float xr[DT / 2];   // the running residual, load layout between stages, B-operand layout inside a sweep
-    if (a.x_vec) {
+    if (VEC) {
         if (XBF16) {
             const uint2 *p = (const uint2 *)((const unsigned short *)a.x + rowc * a.ldx + 4 * hi);
 #pragma unroll
@@ -1937,7 +1924,7 @@ __global__ void __launch_bounds__(256, (DT <= 256 ? 2 : 1)) vq_rvq_kernel(const 
 #pragma unroll
             for (int m = 0; m < NG; ++m) {
                 const int k0 = 8 * m + 4 * hi;
-                if (a.x_vec) {
+                if (VEC) {
                     if (XBF16) {
                         uint2 w;
                         w.x = (__float_as_uint(xr[4 * m + 0]) >> 16) | (__float_as_uint(xr[4 * m + 1]) & 0xffff0000u);
@@ -2016,15 +2003,16 @@ __global__ void __launch_bounds__(256, (DT <= 256 ? 2 : 1)) vq_rvq_kernel(const 
         const float *er = a.embed + (size_t)q * a.embed_qstride + (size_t)bi * a.D;
         const unsigned short *erb = (const unsigned short *)((const char *)(a.packed + (size_t)q * a.packed_qstride) + a.bf16_off) + (size_t)bi * a.D;
         float lsum = 0.f;
+        [[maybe_unused]] float lsum4[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int m = 0; m < NG; ++m) {
             const int k0 = 8 * m + 4 * hi;
             float g[4];
-            if (a.x_vec && XBF16) {     // quantized is a bf16 tensor in the reference: pre-rounded rows
+            if (VEC && XBF16) {     // quantized is a bf16 tensor in the reference: pre-rounded rows
                 const uint2 w = *(const uint2 *)(erb + k0);
                 g[0] = __uint_as_float(w.x << 16); g[1] = __uint_as_float(w.x & 0xffff0000u);
                 g[2] = __uint_as_float(w.y << 16); g[3] = __uint_as_float(w.y & 0xffff0000u);
-            } else if (a.x_vec) {
+            } else if (VEC) {
                 const f32x4 w = *(const f32x4 *)(er + k0);
                 g[0] = w.x; g[1] = w.y; g[2] = w.z; g[3] = w.w;
             } else {
@@ -2036,14 +2024,21 @@ __global__ void __launch_bounds__(256, (DT <= 256 ? 2 : 1)) vq_rvq_kernel(const 
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float df = g[r] - xr[4 * m + r];
-                lsum += df * df;
                 float nr = xr[4 * m + r] - g[r];               // residual - quantized (rvq.py:524)
-                if (XBF16) nr = round_to_bf16(nr);             // bf16 tensors in the reference
+                if (XBF16) {                                   // bf16 tensors in the reference
+                    const float df = g[r] - xr[4 * m + r];
+                    lsum += df * df;
+                    nr = round_to_bf16(nr);
+                } else {
+                    // (g - x)^2 == (x - g)^2 bit for bit: one difference serves the loss and the update, four independent sums
+                    // (the single chain next to a second subtraction cost the fp32 kernels 200 - 380 spilled registers)
+                    lsum4[r] = __builtin_fmaf(nr, nr, lsum4[r]);
+                }
                 xr[4 * m + r] = live ? nr : xr[4 * m + r];
             }
         }
         if (a.sqerr_partial) {
+            if (!XBF16) lsum = (lsum4[0] + lsum4[1]) + (lsum4[2] + lsum4[3]);
             double ds = live ? (double)lsum : 0.0;
 #pragma unroll
             for (int o = 32; o >= 1; o >>= 1) ds += __shfl_xor(ds, o, 64);
@@ -2057,9 +2052,14 @@ template <int DT, bool XBF16>
 static int launch_rvq(const RvqArgs &a, hipStream_t st)
 {
     constexpr int SMEM = 2 * (32 * DT + 256) * 4;
-    static VqAttrOnce once;
-    if (int rc = vq_set_max_smem(once, (const void *)vq_rvq_kernel<DT, XBF16>, SMEM, "vq_rvq_kernel")) return rc;
-    hipLaunchKernelGGL((vq_rvq_kernel<DT, XBF16>), dim3((unsigned)vqhip_assign_blocks(a.N)), dim3(256), SMEM, st, a);
+    static VqAttrOnce once_v, once_s;
+    if (a.x_vec) {
+        if (int rc = vq_set_max_smem(once_v, (const void *)vq_rvq_kernel<DT, XBF16, true>, SMEM, "vq_rvq_kernel")) return rc;
+        hipLaunchKernelGGL((vq_rvq_kernel<DT, XBF16, true>), dim3((unsigned)vqhip_assign_blocks(a.N)), dim3(256), SMEM, st, a);
+    } else {
+        if (int rc = vq_set_max_smem(once_s, (const void *)vq_rvq_kernel<DT, XBF16, false>, SMEM, "vq_rvq_kernel")) return rc;
+        hipLaunchKernelGGL((vq_rvq_kernel<DT, XBF16, false>), dim3((unsigned)vqhip_assign_blocks(a.N)), dim3(256), SMEM, st, a);
+    }
     return launch_status("vq_rvq_kernel");
 }
 
@@ -2180,6 +2180,10 @@ struct RouteArgs {
     const uint8_t *row_mask;
     int mode;
     int vec;                // every row pointer / stride allows 4-element accesses
+    // residual step of a residual VQ whose layers return the ROUTED value (vqhip_route_residual, forward only, fp32 rows):
+    // q rows are embed[qidx[n * qidx_stride]] (a.q = the fp32 codebook, ldq = D) and out = x - route(x, q)   (rvq.py:524)
+    const int64_t *qidx;
+    int64_t qidx_stride;
 };
 
 template <bool BF16, bool BWD, int NE, int LPR>
@@ -2193,11 +2197,16 @@ __global__ void __launch_bounds__(256) vq_route_kernel(const RouteArgs a)
     const int64_t n = valid ? n0 : a.N - 1;            // (rows share a wave: the ones past the end repeat the last row and store nothing)
     float e[NE], qv[NE], g[NE];
     row_load8<BF16, NE, LPR>(a.x, n * a.ldx, a.D, lane, a.vec != 0, e);
-    row_load8<BF16, NE, LPR>(a.q, n * a.ldq, a.D, lane, a.vec != 0, qv);
+    const int64_t qrow = (!BWD && !BF16 && a.qidx) ? a.qidx[n * a.qidx_stride] : n;
+    row_load8<BF16, NE, LPR>(a.q, qrow * a.ldq, a.D, lane, a.vec != 0, qv);
     if (BWD && a.g) row_load8<BF16, NE, LPR>(a.g, n * a.ldg, a.D, lane, a.vec != 0, g);
     float r[NE];
     if (!BWD) {
         vq_route_value<NE, LPR, BF16>(e, qv, a.mode, r);            // vq_route_math.h (mode 1 / 2)
+        if (!BF16 && a.qidx) {
+#pragma unroll
+            for (int k = 0; k < NE; ++k) r[k] = e[k] - r[k];          // the next stage's input: residual - quantized.detach() (rvq.py:524)
+        }
     } else if (a.mode == 2 && a.g) {
         float u[NE], qh[NE], w[NE], sc;
         vq_rot_frame<NE, LPR>(e, qv, u, qh, w, sc);
@@ -2242,10 +2251,28 @@ extern "C" int vqhip_route_fwd(const void *x, const void *q, int dtype, int64_t 
     if (dtype != VQHIP_F32 && dtype != VQHIP_BF16) VQ_FAIL(VQHIP_EINVAL, "route_fwd: unknown dtype");
     RouteArgs a;
     a.x = x; a.q = q; a.g = nullptr; a.out = out; a.N = N; a.D = D; a.ldx = ldx; a.ldq = ldq; a.ldg = 0; a.ldo = ldo;
-    a.loss_coef = nullptr; a.row_mask = nullptr; a.mode = mode;
+    a.loss_coef = nullptr; a.row_mask = nullptr; a.mode = mode; a.qidx = nullptr; a.qidx_stride = 0;
     const int es = dtype == VQHIP_BF16 ? 2 : 4;
     a.vec = rows_vec4(x, ldx, D, es) && rows_vec4(q, ldq, D, es) && rows_vec4(out, ldo, D, es);
     return route_launch(a, dtype, false, (hipStream_t)stream);
+}
+
+// The residual a ResidualVQ stage hands to the next one when its layer returned the ROUTED value (training with an input that
+// requires grad: `residual = residual - quantized.detach()`, rvq.py:524 with vqp.py:1225-1233): out = x - route(x, embed[idx]),
+// the arithmetic of vqhip_route_fwd / vqhip_rvq_route bit for bit (vq_route_math.h), fp32 rows.  An HBM-bound kernel of its own at
+// full occupancy: inside the screening kernel's prologue (round 4's first form) the row reductions ran on 256-register waves and
+// doubled that kernel's time (459 vs 217 us per cfg-3 stage).
+extern "C" int vqhip_route_residual(const void *x, int64_t N, int D, int64_t ldx, const float *embed, const int64_t *idx,
+                                    int64_t idx_stride, int mode, void *out, int64_t ldo, void *stream)
+{
+    if (!x || !embed || !idx || !out) VQ_FAIL(VQHIP_EINVAL, "route_residual: null pointer");
+    if (N < 0 || D < 1 || D > 512 || idx_stride < 1) VQ_FAIL(VQHIP_EINVAL, "route_residual: bad size");
+    if (mode != 1 && mode != 2) VQ_FAIL(VQHIP_EINVAL, "route_residual: mode must be 1 (straight-through) or 2 (rotation trick)");
+    RouteArgs a;
+    a.x = x; a.q = embed; a.g = nullptr; a.out = out; a.N = N; a.D = D; a.ldx = ldx; a.ldq = D; a.ldg = 0; a.ldo = ldo;
+    a.loss_coef = nullptr; a.row_mask = nullptr; a.mode = mode; a.qidx = idx; a.qidx_stride = idx_stride;
+    a.vec = rows_vec4(x, ldx, D, 4) && rows_vec4(embed, D, D, 4) && rows_vec4(out, ldo, D, 4);
+    return route_launch(a, VQHIP_F32, false, (hipStream_t)stream);
 }
 
 extern "C" int vqhip_route_bwd(const void *x, const void *q, const void *g_out, int dtype, int64_t N, int D,
@@ -2259,6 +2286,7 @@ extern "C" int vqhip_route_bwd(const void *x, const void *q, const void *g_out, 
     RouteArgs a;
     a.x = x; a.q = q; a.g = (mode == 0) ? nullptr : g_out; a.out = grad_x; a.N = N; a.D = D; a.ldx = ldx; a.ldq = ldq;
     a.ldg = ldg; a.ldo = ldo; a.loss_coef = loss_coef; a.row_mask = row_mask; a.mode = (mode == 0) ? 1 : mode;
+    a.qidx = nullptr; a.qidx_stride = 0;
     const int es = dtype == VQHIP_BF16 ? 2 : 4;
     a.vec = rows_vec4(x, ldx, D, es) && rows_vec4(q, ldq, D, es) && rows_vec4(a.g, ldg, D, es) && rows_vec4(grad_x, ldo, D, es);
     return route_launch(a, dtype, true, (hipStream_t)stream);
@@ -2881,11 +2909,11 @@ static inline int64_t seg_work_items(int64_t N, int C)
 
 extern "C" int64_t vqhip_ema_sqerr_partials(int64_t N, int C) { return (N < 0 || C <= 0) ? 0 : seg_work_items(N, C); }
 
-// what the fused train step adds to the statistics pass: hist_ready -- the workspace's histogram (its first C ints) was zeroed by the
-// caller and filled by the search (ScreenArgs.hist), no memset and no vq_hist_kernel; cs / denom -- the scan kernel folds the
-// counts into cluster_size and forms update_ema's denominators (SortArgs)
+// what the fused train step adds to the statistics pass: hist_zeroed -- the workspace's histogram (its first C ints) was zeroed by
+// the caller on this stream, no memset launch; cs / denom -- the scan kernel folds the counts into cluster_size and forms
+// update_ema's denominators (SortArgs)
 struct StatsFuse {
-    int hist_ready;
+    int hist_zeroed;
     float *cs, *denom;
     float omd, eps;
 };
@@ -2922,15 +2950,14 @@ static int ema_accumulate_impl(const void *x, int x_dtype, int64_t N, int D, int
     s.chunk_off = (int *)ws;      ws += align_up(((size_t)C + 1) * 4, 256);
     s.perm = (int *)ws;
 
-    const bool hist_ready = fuse && fuse->hist_ready;
-    if (hist_ready && row_mask) VQ_FAIL(VQHIP_EINVAL, "ema_accumulate: a histogram counted by the search knows no row mask");
+    const bool hist_zeroed = fuse && fuse->hist_zeroed;
     s.cs = fuse ? fuse->cs : nullptr;
     s.denom = fuse ? fuse->denom : nullptr;
     s.omd = fuse ? fuse->omd : 0.f;
     s.eps = fuse ? fuse->eps : 0.f;
     s.ceps = fuse ? (float)((double)C * (double)fuse->eps) : 0.f;
     if (s.cs && (C > 8192 || !s.denom)) VQ_FAIL(VQHIP_EINVAL, "ema_accumulate: the fused cluster-size fold needs C <= 8192 and a denominator buffer");
-    if (!hist_ready) {
+    if (!hist_zeroed) {
         hipError_t e = hipMemsetAsync(s.hist, 0, (size_t)C * 4, st);
         if (e != hipSuccess) VQ_FAIL((int)e, "hipMemsetAsync(hist): %s", hipGetErrorString(e));
     }
@@ -2941,7 +2968,7 @@ static int ema_accumulate_impl(const void *x, int x_dtype, int64_t N, int D, int
     const int rpb = s.direct ? 256 : VQ_SORT_ROWS_PER_BLOCK;
     const unsigned sort_blocks = (unsigned)((N + rpb - 1) / rpb);
     const int lds = s.direct ? 0 : C * 4;
-    if (!hist_ready) hipLaunchKernelGGL(vq_hist_kernel, dim3(sort_blocks), dim3(256), lds, st, s);
+    hipLaunchKernelGGL(vq_hist_kernel, dim3(sort_blocks), dim3(256), lds, st, s);
     hipLaunchKernelGGL(vq_scan_kernel, dim3(1), dim3(1024), s.cs ? (size_t)C * 4 : 0, st, s);
     hipLaunchKernelGGL(vq_scatter_kernel, dim3(sort_blocks), dim3(256), lds, st, s);
 
@@ -3489,9 +3516,7 @@ extern "C" int vqhip_decode_sum(const int64_t *idx, int64_t N, int Q, const floa
     const int oes = (out_dtype == VQHIP_BF16) ? 2 : 4;
     const bool vec = (D % 4 == 0) && (embed_qstride % 4 == 0) && ((((uintptr_t)embed) & 15) == 0) &&
                      ((((uintptr_t)out) % (4 * oes)) == 0) && ((ldo * oes) % (4 * oes) == 0);
-    static int lds_ok = -1;      // VQHIP_DECODE_LDS=0: always the row-per-wave kernel (A/B runs)
-    if (lds_ok < 0) { const char *e = getenv("VQHIP_DECODE_LDS"); lds_ok = (e && e[0] == '0') ? 0 : 1; }
-    if (vec && lds_ok && Q >= 2 && (embed_qstride == 0 || Q == 1) && C <= 1024 && D % VQ_DECODE_LDS_COLS == 0 && N >= 16384) {
+    if (vec && Q >= 2 && (embed_qstride == 0 || Q == 1) && C <= 1024 && D % VQ_DECODE_LDS_COLS == 0 && N >= 16384) {
         // shared codebook, several stages: the codes' column slices live in LDS (the gathers from L2 were the bound)
         const int smem = C * VQ_DECODE_LDS_COLS * 4;
         static VqAttrOnce once;
@@ -3516,8 +3541,9 @@ extern "C" int vqhip_decode_sum(const int64_t *idx, int64_t N, int Q, const floa
 
 // ------------------------------------------------------------------------------------------------
 // fused train step (vqhip_vq_train_step): the launches of pack -> search -> statistics -> fold with everything that only exists
-// because they are separate API calls removed -- ONE zeroing kernel instead of four memsets / fills, no histogram pass (the search
-// counts the rows per code), cluster_size folded by the scan kernel, embed_avg / embed / loss by one tail kernel.
+// because they are separate API calls removed -- ONE zeroing kernel instead of four memsets / fills, cluster_size folded by the scan
+// kernel, embed_avg / embed / loss by one tail kernel.  (Counting the rows per code inside the search -- one global atomic per
+// certified row -- was built and measured: it saves the 14 us histogram pass and costs the search 20 us; not kept.)
 // ------------------------------------------------------------------------------------------------
 struct ZeroArgs { unsigned *p[4]; unsigned n[4]; };   // up to four regions of n 32-bit words each
 __global__ void __launch_bounds__(256) vq_zero_kernel(const ZeroArgs a)
@@ -3574,11 +3600,10 @@ extern "C" int vqhip_vq_train_step(const vqhip_vq_step_t *s, void *stream)
     if (int rc = pack_codebook_impl(s->embed, C, D, s->packed, 1, stream)) return rc;
     if (s->ev_search_begin) (void)hipEventRecord((hipEvent_t)s->ev_search_begin, st);
     if (int rc = vq_assign_screened_impl(s->x, x_dtype, N, D, s->ldx, s->packed, s->embed, C, VQHIP_EUCLID, s->idx_out, s->q_out, s->ldq,
-                                         nullptr, D, nullptr, nullptr, ws_screen, step_ws_screen(N), nullptr, nullptr,
-                                         (int *)ws_stats, 1, stream)) return rc;
+                                         nullptr, D, nullptr, nullptr, ws_screen, step_ws_screen(N), nullptr, nullptr, 1, stream)) return rc;
     if (s->ev_search_end) (void)hipEventRecord((hipEvent_t)s->ev_search_end, st);
     StatsFuse f;
-    f.hist_ready = 1;
+    f.hist_zeroed = 1;
     f.cs = s->fold ? s->cluster_size : nullptr;
     f.denom = s->fold ? denom : nullptr;
     f.omd = (float)s->one_minus_decay;

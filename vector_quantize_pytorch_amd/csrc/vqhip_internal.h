@@ -100,18 +100,17 @@ static inline size_t vq_packed_total_bytes(int C, int D)
 // VQHIP_COSINE_PRENORM.  keys: N u64, entries [0 .. row_count[0]) preset to ~0 by the list builder.  with_pairs: rows whose
 // winner is one of two known codes sit at list positions N - 1 - p, p < row_count[1], their keys hold the candidates
 // (c1 | c2 << 32); vq_pair_kernel decides them with two exact distances instead of a codebook sweep.
-// sqerr_partial (nullable) receives VQ_FINISH_BLOCKS entries.  hist (nullable, [C]): every listed row is counted under its final code.
+// sqerr_partial (nullable) receives VQ_FINISH_BLOCKS entries.
 #define VQ_FINISH_BLOCKS 512
 int vq_assign_listed(const void *x, int x_dtype, int metric, int64_t N, int D, int64_t ldx, const float *packed, const float *embed, int C,
                      int64_t *idx_out, int64_t idx_stride, void *q_out, int64_t ldq, void *resid_out, int64_t ldr, double *sqerr_partial,
                      const uint8_t *row_mask, const int *row_list, const int *row_count, unsigned long long *keys, int with_pairs,
-                     int *hist, hipStream_t st);
+                     hipStream_t st);
 
-// the screened assignment behind vqhip_assign_screened / vqhip_assign_screened_chain (vq_screen.hip), with the extras of the fused
-// train step (vqhip_vq_train_step): hist (nullable, [C] ints zeroed by the caller) receives the rows per code, header_zeroed says
-// that the caller has already zeroed the workspace's 16-byte list header on this stream
+// the screened assignment behind vqhip_assign_screened / vqhip_assign_screened_chain (vq_screen.hip); header_zeroed says that the
+// caller (the fused train step, vqhip_vq_train_step) has already zeroed the workspace's 16-byte list header on this stream
 int vq_assign_screened_impl(const void *x, int x_dtype, int64_t N, int D, int64_t ldx, const float *packed,
                             const float *embed, int C, int metric, int64_t *idx_out, void *q_out, int64_t ldq,
                             void *resid_out, int64_t ldr, double *sqerr_partial, const uint8_t *row_mask,
                             void *workspace, size_t workspace_bytes, float *debug_out, const vqhip_chain_t *chain,
-                            int *hist, int header_zeroed, void *stream);
+                            int header_zeroed, void *stream);

@@ -344,9 +344,9 @@ class ResidualVQ(nn.Module):
             else:
                 L.ema_accumulate(stage_input, idx_all, C, **kw)
 
-        if L.screening_enabled() and D in (32, 64, 128, 256) and x.data_ptr() % 16 == 0:
+        if L.screening_enabled() and D in (32, 64, 128, 256, 512) and x.data_ptr() % 16 == 0:
             # Q screened searches on the f16 MFMA pipe (csrc/vq_screen.hip), each writing the next stage's input; beats
-            # the fused exact-fp32 kernel, which keeps the dims the screen does not cover (96, 160, ..., 512)
+            # the fused exact-fp32 kernel, which keeps the dims the screen does not cover (96, 160, ...)
             hook = None
             if update and x.is_cuda and self.concurrent_stats and not torch.cuda.is_current_stream_capturing():
                 # no search reads a codebook this forward changes (shared or not, embed is only rewritten after the loop), so

@@ -8,6 +8,8 @@ construction / call time -- there is no silent fallback and nothing here runs on
 """
 from __future__ import annotations
 
+import os
+
 from collections import namedtuple
 from functools import cache
 from typing import Callable, Optional
@@ -26,6 +28,12 @@ LossBreakdown = namedtuple('LossBreakdown', ['commitment', 'codebook_diversity',
 @cache
 def _is_distributed():
     return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
+def SCORE_CHUNK_BYTES() -> int:
+    """largest score matrix (`dist`, vqp.py:741-743) the options that read whole score rows materialise at once; beyond it the
+    rows are processed a slice of positions at a time (VQHIP_SCORE_CHUNK_MB, default 128)"""
+    return int(float(os.environ.get("VQHIP_SCORE_CHUNK_MB", "128")) * (1 << 20))
 
 
 class _QuantizeFn(torch.autograd.Function):
@@ -156,8 +164,12 @@ class _ScoresFn(torch.autograd.Function):
     clamp(min=1e-8) is active).  Only the rare options that read the whole row use it."""
 
     @staticmethod
-    def forward(ctx, x, embed, cosine):
-        e = embed.detach().float().contiguous()
+    def forward(ctx, x, embed, cosine, embed_at_search=None):
+        """embed_at_search: a snapshot of the codebook to compute `dist` from.  The EMA fold rewrites `embed` in place right after the
+        search, and like the reference's autograd graph (cdist saves the buffer, `.data.copy_` rewrites it) the backward below reads
+        the LIVE embed next to the distances of the search; a forward that is re-run later (the position slices are recomputed in
+        backward, torch.utils.checkpoint) must see the codebook the search saw."""
+        e = (embed if embed_at_search is None else embed_at_search).detach().float().contiguous()
         dist, _, _ = L.scores(x.detach(), L.pack_codebook(e), e, cosine=cosine, skip_l2norm=True)
         ctx.cosine = cosine
         ctx.save_for_backward(x, embed, dist)
@@ -178,7 +190,7 @@ class _ScoresFn(torch.autograd.Function):
             ge = -ge
         gx = gx.reshape(x.shape).to(x.dtype) if ctx.needs_input_grad[0] else None
         ge = ge.to(embed.dtype) if ctx.needs_input_grad[1] else None
-        return gx, ge, None
+        return gx, ge, None, None
 
 
 class VectorQuantize(nn.Module):
@@ -456,17 +468,55 @@ class VectorQuantize(nn.Module):
                 ind = L.topk(xs.detach(), L.pack_codebook(e2), e2.shape[0], topk, cosine=cb.use_cosine_sim, skip_l2norm=True)
                 q = F.embedding(ind, embed_eff[0])
                 return q.to(xs.dtype), ind, None
-            dist = _ScoresFn.apply(xs, embed_eff[0], cb.use_cosine_sim)               # vqp.py:740-743, [b, n, C]
-            logits = dist
-            if self.training and self.stochastic_sample_codes and temp > 0:           # vqp.py:117-119, 132-133
-                u = torch.zeros_like(dist).uniform_(0, 1)
-                logits = dist / temp - torch.log((-torch.log(u.clamp(min=1e-20))).clamp(min=1e-20))
-            ind = logits.topk(topk, dim=-1).indices if topk is not None else logits.argmax(dim=-1)   # vqp.py:137-140
-            q = F.embedding(ind, embed_eff[0])        # materialised before any EMA fold below touches the codebook
-            if self.gumbel_straight_through and temp > 0 and self.training:           # vqp.py:144-148: one_hot + pi - pi.detach()
-                assert topk is None
-                pi = (dist / temp).softmax(dim=-1)
-                q = q + (pi - pi.detach()) @ embed_eff[0].detach()
+            E = embed_eff[0]
+            want_div = self.training and self.has_codebook_diversity_loss
+
+            def rows_to_codes(xc, E_search=None):                                     # xc [b, n', d] -> q, ind, dist, entropy sum
+                dist = _ScoresFn.apply(xc, E, cb.use_cosine_sim, E_search)            # vqp.py:740-743, [b, n', C]
+                logits = dist
+                if self.training and self.stochastic_sample_codes and temp > 0:       # vqp.py:117-119, 132-133
+                    u = torch.zeros_like(dist).uniform_(0, 1)
+                    logits = dist / temp - torch.log((-torch.log(u.clamp(min=1e-20))).clamp(min=1e-20))
+                ind = logits.topk(topk, dim=-1).indices if topk is not None else logits.argmax(dim=-1)   # vqp.py:137-140
+                q = F.embedding(ind, E)               # materialised before any EMA fold below touches the codebook
+                if self.gumbel_straight_through and temp > 0 and self.training:       # vqp.py:144-148: one_hot + pi - pi.detach()
+                    assert topk is None
+                    pi = (dist / temp).softmax(dim=-1)
+                    q = q + (pi - pi.detach()) @ E.detach()
+                ent = dist.new_zeros(())
+                if want_div:                                                          # vqp.py:1287-1292, 67-68: softmax averaged over
+                    avg = (dist * self.codebook_diversity_temperature).softmax(dim=-1).mean(dim=0)    # the batch, per position
+                    ent = (-avg * torch.log(avg.clamp(min=1e-5))).sum()              # summed over this chunk's positions
+                return q, ind, dist, ent
+
+            # The options that get here read whole score rows (gumbel noise, the straight-through softmax, the diversity loss'
+            # batch-averaged softmax).  `dist` is N x C floats -- 4 GiB at BASELINE cfg 2 -- so beyond SCORE_CHUNK_BYTES it is
+            # produced for a slice of the positions at a time (all batch entries of a position stay together: the diversity loss
+            # averages over the batch), consumed, and recomputed in backward (checkpoint): peak memory = one slice, not N x C.
+            # Callers that want the matrix itself (top-k next to other options, the dense cross-entropy of the in-place-optimizer /
+            # transform paths) keep the single call.
+            nb, npos, C_ = xs.shape[0], xs.shape[1], E.shape[0]
+            pos_per = max(1, SCORE_CHUNK_BYTES() // (4 * C_ * max(nb, 1)))
+            if topk is None and not need_dist and xs.ndim == 3 and npos > pos_per:
+                from torch.utils.checkpoint import checkpoint
+                grad = torch.is_grad_enabled() and (xs.requires_grad or E.requires_grad)
+                E_search = E.detach().clone() if grad else None       # (the recomputation in backward runs after the EMA fold)
+                qs, inds, ent_sum = [], [], xs.new_zeros((), dtype=torch.float32)
+                for n0 in range(0, npos, pos_per):
+                    xc = xs[:, n0:n0 + pos_per].contiguous()
+                    if grad:
+                        def piece(a, e_):                                             # (e_: makes the codebook an input of the checkpoint)
+                            q_, ind_, _, ent_ = rows_to_codes(a, E_search)
+                            return q_, ind_, ent_
+                        q_, ind_, ent_ = checkpoint(piece, xc, E, use_reentrant=False)
+                    else:
+                        q_, ind_, _, ent_ = rows_to_codes(xc)
+                    qs.append(q_); inds.append(ind_)
+                    ent_sum = ent_sum + ent_
+                q, ind, dist = torch.cat(qs, 1), torch.cat(inds, 1), None
+            else:
+                q, ind, dist, ent_sum = rows_to_codes(xs)
+            self.__dict__["_diversity_from_search"] = (-(ent_sum / npos)) if want_div else None   # -ent.mean() over the positions
             if self.training and update_usage and not freeze_codebook and topk is None:                 # vqp.py:783-784
                 cb.update_indices(xs.detach(), ind, mask=rmask, ema_update_weight=kw.get("ema_update_weight"),
                                   accum_ema_update=kw.get("accum_ema_update", False), ema_update=kw.get("ema_update"))
@@ -689,11 +739,8 @@ class VectorQuantize(nn.Module):
             return quantize, ce_loss(indices)
 
         if self.training and param_path:
-            if self.has_codebook_diversity_loss:                                     # vqp.py:1287-1292, 67-68
-                prob = (distances * self.codebook_diversity_temperature).softmax(dim=-1)
-                avg = prob.mean(dim=0)                                               # over the batch, per position
-                ent = (-avg * torch.log(avg.clamp(min=1e-5))).sum(dim=-1)
-                diversity_loss = -ent.mean()
+            if self.has_codebook_diversity_loss:                                     # vqp.py:1287-1292, 67-68: computed next to the
+                diversity_loss = self.__dict__.pop("_diversity_from_search")           # scores it reads (_forward_general: rows_to_codes)
                 loss = loss + diversity_loss * self.codebook_diversity_loss_weight
             if self.has_commitment_loss:
                 if self.commitment_use_cross_entropy_loss:                           # vqp.py:1297-1305
