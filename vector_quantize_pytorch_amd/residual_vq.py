@@ -385,10 +385,17 @@ class ResidualVQ(nn.Module):
             aux["Q"] = Q
 
         stage_in = None
+        reduced = False
         if update:
             resid = r.get("resid")
             stage_in = (lambda q: r["inputs"][q]) if r.get("inputs") is not None else (lambda q: resid[..., q, :])
             if side is not None:
+                if vq0._codebook.use_ddp:
+                    # the ONE all-reduce of the forward, issued on the statistics stream: it queues behind the last stage's
+                    # statistics pass and runs beside the decode on the main stream (the fold below waits for both)
+                    with torch.cuda.stream(side):
+                        dist.all_reduce(buf)
+                    reduced = True
                 torch.cuda.current_stream(x.device).wait_stream(side)
             else:
                 for q in range(Q):
@@ -408,7 +415,7 @@ class ResidualVQ(nn.Module):
             losses = torch.zeros(self.num_quantizers, device=x.device, requires_grad=True) + losses   # as vqp.py:1282
 
         if update:
-            if vq0._codebook.use_ddp:
+            if vq0._codebook.use_ddp and not reduced:
                 dist.all_reduce(buf)
             cb0 = vq0._codebook
             if self.shared_codebook and cb0.cluster_size.grad is None and cb0.embed_avg.grad is None:
@@ -576,7 +583,9 @@ def _stats_stream(device, main):
         # (default priority.  The statistics chain is five short launches behind one another -- memset, histogram, scan, scatter,
         #  segmented sum -- and beside a search that fills every CU each of them waits for a workgroup slot: rocprofv3 shows the
         #  4 KB memset at 124 us wall, the chain at 340 us for ~100 us of work.  A high-priority stream was tried in round 3:
-        #  cfg 3 2.996 -> 2.974 ms, cfg 5 15.5 -> 18.9 ms -- the statistics then push the searches of the other groups aside.)
+        #  cfg 3 2.996 -> 2.974 ms, cfg 5 15.5 -> 18.9 ms -- the statistics then push the searches of the other groups aside.
+        #  Round 4 confined this stream to 16 / 32 / 64 CUs (hipExtStreamCreateWithCUMask through torch.cuda.ExternalStream):
+        #  cfg 3 2.93 -> 4.73 / 4.43 / 4.43 ms, cfg 5 15.5 -> 27.1 ms -- a masked queue loses its concurrency with the search.)
         _STATS_STREAMS[key] = torch.cuda.Stream(device=device)
     return _STATS_STREAMS[key]
 
