@@ -106,6 +106,27 @@ int vqhip_assign_screened(const void *x, int x_dtype, int64_t N, int D, int64_t 
                           void *resid_out, int64_t ldr, double *sqerr_partial, const uint8_t *row_mask,
                           void *workspace, size_t workspace_bytes, float *debug_out, void *stream);
 
+/* H searches in one set of launches (grid dimension y = head): the heads of a multi-head VectorQuantize with separate codebooks
+ * (vqp.py:1044-1049) or of RandomProjectionQuantizer (random_projection_quantizer.py:37-59), which the reference runs as one batched
+ * einsum over the head axis.  Head h's buffers sit h strides behind head 0's: x at x_hstride elements; packed at
+ * vqhip_packed_bytes(C, D) bytes (made by vqhip_pack_codebook_batched from embed [H, C, D]); embed at C * D floats; idx_out [H, N];
+ * q_out (nullable) at q_hstride elements; workspace at vqhip_screen_batched_ws_stride(N) bytes (H of them).  row_mask (nullable, [N])
+ * is shared by the heads.  Index and q outputs only; contract per head as vqhip_assign_screened. */
+int vqhip_pack_codebook_batched(const float *embed, int H, int C, int D, float *packed, void *stream);
+size_t vqhip_screen_batched_ws_stride(int64_t N);
+int vqhip_assign_screened_batched(const void *x, int x_dtype, int H, int64_t N, int D, int64_t ldx, int64_t x_hstride,
+                                  const float *packed, const float *embed, int C, int metric, int64_t *idx_out,
+                                  void *q_out, int64_t ldq, int64_t q_hstride, const uint8_t *row_mask,
+                                  void *workspace, size_t workspace_bytes, void *stream);
+
+/* The exact search of H heads in one launch (grid dimension y = head), for the dims the screened search does not take -- e.g. the
+ * 16-wide heads of RandomProjectionQuantizer.  Buffers laid out as for vqhip_assign_screened_batched; rnorm_out (nullable as in
+ * vqhip_assign) is [H, N].  Index, q and rnorm outputs only. */
+int vqhip_assign_batched(const void *x, int x_dtype, int H, int64_t N, int D, int64_t ldx, int64_t x_hstride,
+                         const float *packed, const float *embed, int C, int metric,
+                         int64_t *idx_out, void *q_out, int q_dtype, int64_t ldq, int64_t q_hstride,
+                         float *rnorm_out, const uint8_t *row_mask, void *stream);
+
 /* Residual chain for the stages of a residual VQ (reference: the loop body of ResidualVQ.forward, residual_vq.py:469-568, with
  * `residual = residual - quantized.detach()` at :524).  A stage's screening kernel forms its own input in its prologue,
  * x - prev_embed[prev_idx] in fp32 (exactly the x - q the previous stage would have written), from the PREVIOUS stage's input x

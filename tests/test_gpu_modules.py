@@ -958,6 +958,40 @@ def test_residual_vq_dim_512_screened_stage_loop_equals_the_exact_fused_kernel(d
         b.load_state_dict(a.state_dict())
 
 
+@pytest.mark.parametrize("kw,dtype,train", [
+    (dict(dim=256, codebook_size=512, heads=4, separate_codebook_per_head=True), torch.float32, True),
+    (dict(dim=256, codebook_size=300, heads=8, separate_codebook_per_head=True, use_cosine_sim=True), torch.float32, False),
+    (dict(dim=512, codebook_size=1024, heads=2, codebook_dim=256, separate_codebook_per_head=True), torch.bfloat16, True),
+    (dict(dim=512, codebook_size=64, heads=16, separate_codebook_per_head=True, use_cosine_sim=True, codebook_dim=16), torch.float32, False)])
+def test_heads_with_their_own_codebooks_search_in_one_batched_launch(dev, monkeypatch, kw, dtype, train):
+    """separate_codebook_per_head (vqp.py:1044-1049): the H packs and the H screened searches run as one set of launches (grid
+    dimension y = head: vqhip_pack_codebook_batched / vqhip_assign_screened_batched) -- same indices, outputs, losses and codebooks
+    as the per-head loop, with a lens mask too; and the launch count of a forward shows it."""
+    from vector_quantize_pytorch_amd import VectorQuantize, _lib
+    import vector_quantize_pytorch_amd.codebook as cbmod
+    torch.manual_seed(0)
+    a, b = VectorQuantize(**kw).to(dev).train(train), VectorQuantize(**kw).to(dev).train(train)
+    b.load_state_dict(a.state_dict())
+    calls = []
+    orig = _lib.assign_batched
+    monkeypatch.setattr(cbmod.L, "assign_batched", lambda *ar, **k: (calls.append(1), orig(*ar, **k))[1])
+    supported = _lib.assign_batched_supported
+    for step in range(3):
+        x = torch.randn(3, 700, kw["dim"], device=dev).to(dtype)
+        lens = torch.tensor([700, 13, 512], device=dev) if step == 2 else None
+        monkeypatch.setattr(cbmod.L, "assign_batched_supported", supported)
+        qa, ia, la = a(x, lens=lens)
+        monkeypatch.setattr(cbmod.L, "assign_batched_supported", lambda *ar, **k: False)
+        qb, ib, lb = b(x, lens=lens)
+        assert len(calls) == step + 1, "the batched search did not serve the forward"
+        assert torch.equal(ia, ib) and torch.equal(qa, qb)
+        assert torch.allclose(la, lb, rtol=2e-6, atol=0)
+        for (na, pa), (nb, pb) in zip(a.state_dict().items(), b.state_dict().items()):
+            if pa.dtype.is_floating_point:
+                _close(pa, pb, 1e-5, na)
+        b.load_state_dict(a.state_dict())
+
+
 def test_qinco_implicit_neural_codebook_round_trip(dev):
     """ResidualVQ(implicit_neural_codebook=True) (rvq.py:107-162, 460-499): same parameter names as the reference (goldens rvq_qinco*
     pin values and gradients); here: decode from indices reproduces the forward's output, dropped quantizers decode to zero,

@@ -104,6 +104,14 @@ def lib():
     L.vqhip_pack_best.restype = i32
     L.vqhip_unpack_best.argtypes = [vp, i64, i64, i64, i32, vp, vp, vp, vp]
     L.vqhip_unpack_best.restype = i32
+    L.vqhip_pack_codebook_batched.argtypes = [vp, i32, i32, i32, vp, vp]
+    L.vqhip_pack_codebook_batched.restype = i32
+    L.vqhip_screen_batched_ws_stride.argtypes = [i64]
+    L.vqhip_screen_batched_ws_stride.restype = ctypes.c_size_t
+    L.vqhip_assign_screened_batched.argtypes = [vp, i32, i32, i64, i32, i64, i64, vp, vp, i32, i32, vp, vp, i64, i64, vp, vp, ctypes.c_size_t, vp]
+    L.vqhip_assign_screened_batched.restype = i32
+    L.vqhip_assign_batched.argtypes = [vp, i32, i32, i64, i32, i64, i64, vp, vp, i32, i32, vp, vp, i32, i64, i64, vp, vp, vp]
+    L.vqhip_assign_batched.restype = i32
     L.vqhip_route_residual.argtypes = [vp, i64, i32, i64, vp, vp, i64, i32, vp, i64, vp]
     L.vqhip_route_residual.restype = i32
     L.vqhip_vq_step_supported.argtypes = [i32, i64, i32, i32]
@@ -123,7 +131,8 @@ EXPORTS = ("vqhip_version", "vqhip_last_error", "vqhip_packed_bytes", "vqhip_pac
            "vqhip_assign_blocks", "vqhip_assign", "vqhip_screen_supported", "vqhip_screen_workspace_bytes",
            "vqhip_screen_blocks", "vqhip_screen_partials", "vqhip_assign_screened", "vqhip_screen_chain_supported", "vqhip_assign_screened_chain", "vqhip_l2norm_rows", "vqhip_scores", "vqhip_rvq_forward", "vqhip_reduce_partials", "vqhip_reduce_partials_rows", "vqhip_ema_fold_many", "vqhip_ema_workspace_bytes", "vqhip_ema_accumulate", "vqhip_ema_sqerr_partials", "vqhip_ema_accumulate_sqerr",
            "vqhip_ema_finalize", "vqhip_decode_sum", "vqhip_row_sumsq", "vqhip_assign_rowwise", "vqhip_score_indices", "vqhip_topk", "vqhip_expire_scatter", "vqhip_kmeans_update", "vqhip_route_fwd", "vqhip_route_bwd", "vqhip_rvq_route", "vqhip_ema_renormalize_shard", "vqhip_scores_lse",
-           "vqhip_pack_best", "vqhip_unpack_best", "vqhip_vq_step_supported", "vqhip_vq_step_workspace_bytes", "vqhip_vq_train_step", "vqhip_route_residual")
+           "vqhip_pack_best", "vqhip_unpack_best", "vqhip_vq_step_supported", "vqhip_vq_step_workspace_bytes", "vqhip_vq_train_step", "vqhip_route_residual",
+           "vqhip_pack_codebook_batched", "vqhip_screen_batched_ws_stride", "vqhip_assign_screened_batched", "vqhip_assign_batched")
 
 
 def _check(rc, what):
@@ -212,6 +221,69 @@ def pack_codebook(embed2d: torch.Tensor, out: torch.Tensor | None = None) -> tor
         out = torch.empty(nbytes // 4, dtype=torch.float32, device=embed2d.device)
     _check(lib().vqhip_pack_codebook(_ptr(embed2d), C, D, _ptr(out), _stream()), "vqhip_pack_codebook")
     return out
+
+
+@_on_device
+def pack_codebook_batched(embed3d: torch.Tensor) -> torch.Tensor:
+    """embed [H, C, D] -> packed [H, packed floats]: the H codebooks of a multi-head module in two launches"""
+    _need_gpu(embed3d)
+    assert embed3d.dtype == torch.float32 and embed3d.is_contiguous() and embed3d.ndim == 3
+    H, C, D = embed3d.shape
+    nbytes = lib().vqhip_packed_bytes(C, D)
+    if nbytes == 0:
+        raise VQHipError(f"codebook [{C}, {D}] unsupported: the HIP path handles 1 <= dim <= 512")
+    out = torch.empty(H, nbytes // 4, dtype=torch.float32, device=embed3d.device)
+    _check(lib().vqhip_pack_codebook_batched(_ptr(embed3d), H, C, D, _ptr(out), _stream()), "vqhip_pack_codebook_batched")
+    return out
+
+
+def assign_batched_supported(xs: torch.Tensor, C: int, *, cosine=False, skip_l2norm=False) -> bool:
+    """can the H searches of xs [H, ..., D] run as ONE launch set (vqhip_assign_screened_batched, or vqhip_assign_batched for the
+    dims the screen does not take)?  Needs one uniform row stride for every head and a uniform stride between the heads."""
+    if not (xs.is_cuda and xs.ndim >= 3 and xs.shape[0] > 1 and xs.dtype in (torch.float32, torch.bfloat16)):
+        return False
+    if os.environ.get("VQHIP_SCREEN_VERIFY", "0") == "1" or screen_debug or xs.shape[-1] > 512:
+        return False
+    xk, N, D, ldx = as_rows(xs[0])
+    es = xk.element_size()
+    return bool(N > 0 and xk.data_ptr() == xs.data_ptr() and (xs.stride(0) * es) % 16 == 0 and xs.data_ptr() % 16 == 0
+                and all(as_rows(xs[h])[3] == ldx and as_rows(xs[h])[0].data_ptr() == xs[h].data_ptr() for h in range(1, xs.shape[0])))
+
+
+@_on_device
+def assign_batched(xs: torch.Tensor, packed: torch.Tensor, embed3d: torch.Tensor, *, cosine=False, skip_l2norm=False, want_q=True,
+                   want_rnorm=False, row_mask=None):
+    """xs [H, ..., D] (head h's rows h * xs.stride(0) elements behind head 0's), packed [H, P] from pack_codebook_batched, embed [H, C, D]
+    -> dict(idx [H, ...], q [H, ..., D] | None, rnorm [H, ...] | None): the search of every head in one set of launches -- screened
+    (csrc/vq_screen.hip) when the dim allows it and the rows need no l2norm inside the kernel, the exact kernel otherwise."""
+    _need_gpu(xs, packed, embed3d, row_mask)
+    H = xs.shape[0]
+    xk, N, D, ldx = as_rows(xs[0])
+    C = embed3d.shape[1]
+    assert embed3d.shape == (H, C, D) and embed3d.is_contiguous() and embed3d.dtype == torch.float32 and packed.is_contiguous()
+    dev, lead = xs.device, xs.shape[1:-1]
+    idx = torch.empty(H, N, dtype=torch.int64, device=dev)
+    q = torch.empty(H, N, D, dtype=xs.dtype, device=dev) if want_q else None
+    if row_mask is not None:
+        row_mask = row_mask.reshape(-1).to(torch.uint8).contiguous()
+        assert row_mask.numel() == N
+    es = xk.element_size()
+    screened = ((not cosine or skip_l2norm) and not want_rnorm and screening_enabled() and bool(lib().vqhip_screen_supported(N, D, C))
+                and (ldx * es) % 16 == 0)
+    rnorm = None
+    if screened:
+        wss = lib().vqhip_screen_batched_ws_stride(N)
+        ws = torch.empty(H * wss, dtype=torch.uint8, device=dev)
+        _check(lib().vqhip_assign_screened_batched(_ptr(xk), _dtype_code(xk), H, N, D, ldx, xs.stride(0), _ptr(packed), _ptr(embed3d), C,
+                                                   COSINE_PRENORM if cosine else EUCLID, _ptr(idx), _ptr(q), D, N * D, _ptr(row_mask),
+                                                   _ptr(ws), H * wss, _stream()), "vqhip_assign_screened_batched")
+    else:
+        need_rn = want_rnorm or cosine or (D % 32 != 0)
+        rnorm = torch.empty(H, N, dtype=torch.float32, device=dev) if need_rn else None
+        _check(lib().vqhip_assign_batched(_ptr(xk), _dtype_code(xk), H, N, D, ldx, xs.stride(0), _ptr(packed), _ptr(embed3d), C,
+                                          (COSINE_PRENORM if skip_l2norm else COSINE) if cosine else EUCLID, _ptr(idx), _ptr(q),
+                                          _dtype_code(xs), D, N * D, _ptr(rnorm), _ptr(row_mask), _stream()), "vqhip_assign_batched")
+    return dict(idx=idx.view(H, *lead), q=None if q is None else q.view(H, *lead, D), rnorm=None if rnorm is None else rnorm.view(H, *lead))
 
 
 screen_debug = False   # tests: also return the screening kernel's per-row (best, second, threshold, flagged)

@@ -407,10 +407,31 @@ class Codebook(nn.Module):
             self.expire_codes_(xs.reshape(H, -1, self.dim), seq_mask=None)
             return dict(q=r["q"], idx=r["idx"], sqerr_partials=None, nblk=0, rnorm=None, loss=r["loss"], n_exact=r["n_exact"], n_pair=r["n_pair"])
         outs = []
+        # Several heads with their own codebooks (vqp.py:1044-1049; the reference runs them as one batched einsum over h): ONE set of
+        # launches for the H packs and the H searches (vqhip_pack_codebook_batched / vqhip_assign_screened_batched, grid dimension y =
+        # head) instead of H x (2 + 4).  Needs the screened search for every head and no squared error from the search kernel (the
+        # statistics pass sums it when it runs on the searched rows); everything else keeps the per-head loop below.
+        rb = packed_all = None
+        xs_raw = xs                     # (dead-code replacement below samples the rows as they came in, like the per-head loop)
+        E_all = (self.embed if embed_override is None else embed_override).detach()
+        stats_sums_loss = want_sqerr and do_update and x_stats is xs and not self.use_cosine_sim and L.stats_sqerr_supported(xs[0])
+        if H > 1 and not self.affine_param and (not want_sqerr or stats_sums_loss) and E_all.dtype == torch.float32:
+            xs_b = xs
+            if self.use_cosine_sim and not input_normalized and L.screen_supported(xs[0], C):
+                xs_b = L.l2norm_rows(xs)            # (rows are independent: every head's rows in one launch, vqp.py:37-38 at :1159)
+            prenorm_b = input_normalized or xs_b is not xs
+            if L.assign_batched_supported(xs_b, C, cosine=self.use_cosine_sim, skip_l2norm=prenorm_b):
+                E_all = E_all.contiguous()
+                packed_all = L.pack_codebook_batched(E_all)
+                rb = L.assign_batched(xs_b, packed_all, E_all, cosine=self.use_cosine_sim, skip_l2norm=prenorm_b, want_q=want_q,
+                                      want_rnorm=self.use_cosine_sim and not prenorm_b, row_mask=rmask)
+                if xs_b is not xs:
+                    xs = x_stats = xs_b
+                    input_normalized = True
         for h in range(H):
             # embed_override: the codebook actually searched when it is a function of the stored one (vq_bridge)
-            e = (self.embed if embed_override is None else embed_override)[h].detach().contiguous()
-            packed = L.pack_codebook(e)
+            e = E_all[h].contiguous()
+            packed = packed_all[h] if packed_all is not None else L.pack_codebook(e)
             xh, xst, prenorm = xs[h], x_stats[h], input_normalized
             if self.use_cosine_sim and not prenorm and not self.affine_param and L.screen_supported(xh, C):
                 # cosine through the screened search (csrc/vq_screen.hip), which takes unit-norm rows: normalise once with
@@ -420,9 +441,13 @@ class Codebook(nn.Module):
             # the statistics pass below reads every row next to its code: when it runs on the rows that were searched, it also
             # sums the commitment loss' squared error, and the search does not re-read x for it (csrc: vq_segsum_fast_kernel)
             sq_in_stats = (want_sqerr and do_update and x_stats is xs and not self.use_cosine_sim and L.stats_sqerr_supported(xh))
-            r = L.assign(xh, packed, e, cosine=self.use_cosine_sim, want_q=want_q, want_sqerr=want_sqerr and not sq_in_stats,
-                         row_mask=rmask, skip_l2norm=prenorm, want_rnorm=self.use_cosine_sim and not prenorm,
-                         q_out=q_out if H == 1 else None)
+            if rb is not None:
+                r = dict(idx=rb["idx"][h], q=None if rb["q"] is None else rb["q"][h], sqerr_partials=None, nblk=0,
+                         rnorm=None if rb["rnorm"] is None else rb["rnorm"][h])
+            else:
+                r = L.assign(xh, packed, e, cosine=self.use_cosine_sim, want_q=want_q, want_sqerr=want_sqerr and not sq_in_stats,
+                             row_mask=rmask, skip_l2norm=prenorm, want_rnorm=self.use_cosine_sim and not prenorm,
+                             q_out=q_out if H == 1 else None)
             if do_update:
                 buf = torch.zeros(C * self.dim + C, dtype=torch.float32, device=x.device)
                 esum, count = buf[: C * self.dim].view(C, self.dim), buf[C * self.dim:]
@@ -438,10 +463,14 @@ class Codebook(nn.Module):
                 self._fold_stats(h, count, esum, ema_update_weight, accum_ema_update, ema_update)
             outs.append(r)
         if do_update and not accum_ema_update:
-            self.expire_codes_(xs.reshape(H, -1, self.dim), seq_mask=None if rmask is None else rmask[None].expand(H, -1).bool())
+            self.expire_codes_(xs_raw.reshape(H, -1, self.dim), seq_mask=None if rmask is None else rmask[None].expand(H, -1).bool())
         if H == 1:
             return outs[0]
-        return dict(q=torch.stack([o["q"] for o in outs]) if want_q else None, idx=torch.stack([o["idx"] for o in outs]),
+        if rb is not None:
+            q_all, idx_all = rb["q"], rb["idx"]
+        else:
+            q_all, idx_all = (torch.stack([o["q"] for o in outs]) if want_q else None), torch.stack([o["idx"] for o in outs])
+        return dict(q=q_all, idx=idx_all,
                     sqerr_partials=None if not want_sqerr else torch.cat([o["sqerr_partials"][: o["nblk"]] for o in outs]),
                     nblk=sum(o["nblk"] for o in outs), rnorm=None)
 

@@ -95,9 +95,10 @@ template <int DT> struct Screen16Cfg {
 // fp16 parts (|x' - x_h - x_m| <= 2^-20 |x'|), two MFMAs per k-step on one A fragment -- the x side then costs the certificate
 // 2^-20 X Y instead of the measured 2^-11-level residual, which brings the uncertified fraction of fp32 rows down to bf16 levels.
 template <int DT, int METRIC, bool XF32 = false, int NPART = 1>
-__global__ void __launch_bounds__(VQS_WAVES * 64, 8 / VQS_WAVES) vq_screen16_kernel(const ScreenArgs a)
+__global__ void __launch_bounds__(VQS_WAVES * 64, 8 / VQS_WAVES) vq_screen16_kernel(const ScreenArgs a0)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    const ScreenArgs a = vq_head_screen_args(a0);
     using Cfg = Screen16Cfg<DT>;
     constexpr int TILE_B = Cfg::TILE_B;
     constexpr int SUB = Cfg::SUB;
@@ -775,9 +776,10 @@ template <int DT> struct Screen16F32Cfg {
 //                              charges the measured residual, |(x' - x_h).c| <= ||x' - x_h|| Y per code (computed per row)
 //   XBF16 = true,  NPART = 1 : bf16 rows, D = 512 -- exact operands like vq_screen16_kernel, half its rows per wave
 template <int DT, int METRIC, bool XBF16, int NPART>
-__global__ void __launch_bounds__(VQS_F32_WAVES * 64, (XBF16 && NPART == 1 && DT <= 256) ? 4 : 8 / VQS_F32_WAVES) vq_screen16_1rb_kernel(const ScreenArgs a)
+__global__ void __launch_bounds__(VQS_F32_WAVES * 64, (XBF16 && NPART == 1 && DT <= 256) ? 4 : 8 / VQS_F32_WAVES) vq_screen16_1rb_kernel(const ScreenArgs a0)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    const ScreenArgs a = vq_head_screen_args(a0);
     using Cfg = Screen16F32Cfg<DT>;
     constexpr int W = VQS_F32_WAVES;
     constexpr int TILE_B = Cfg::TILE_B;
@@ -1209,12 +1211,12 @@ static int launch_screen(const ScreenArgs &a, int x_dtype, hipStream_t st)
 #endif
             constexpr int SMEM16 = Screen16Cfg<DT>::SMEM + VQS16_LDS_PAD;
             if (int rc = vq_set_max_smem(once, (const void *)vq_screen16_kernel<DT, METRIC>, SMEM16, "vq_screen16_kernel")) return rc;
-            hipLaunchKernelGGL((vq_screen16_kernel<DT, METRIC>), dim3(blocks), dim3(VQS_WAVES * 64), SMEM16, st, a);
+            hipLaunchKernelGGL((vq_screen16_kernel<DT, METRIC>), dim3(blocks, (unsigned)(a.heads > 1 ? a.heads : 1)), dim3(VQS_WAVES * 64), SMEM16, st, a);
         } else {
             static VqAttrOnce once;
             constexpr int SMEM16 = Screen16F32Cfg<DT>::SMEM;
             if (int rc = vq_set_max_smem(once, (const void *)vq_screen16_1rb_kernel<DT, METRIC, true, 1>, SMEM16, "vq_screen16_1rb_kernel")) return rc;
-            hipLaunchKernelGGL((vq_screen16_1rb_kernel<DT, METRIC, true, 1>), dim3(blocks), dim3(VQS_F32_WAVES * 64), SMEM16, st, a);
+            hipLaunchKernelGGL((vq_screen16_1rb_kernel<DT, METRIC, true, 1>), dim3(blocks, (unsigned)(a.heads > 1 ? a.heads : 1)), dim3(VQS_F32_WAVES * 64), SMEM16, st, a);
         }
     } else {
         // fp32 rows, D <= 256: one fp16 operand set, two row blocks per wave.  (The two-operand-set form x_h + x_m of the one-row-block
@@ -1228,7 +1230,7 @@ static int launch_screen(const ScreenArgs &a, int x_dtype, hipStream_t st)
                 //  k-step costs more than the exact passes it saves: cfg 5 26.0 vs 23.5 ms -- measured, not adopted)
                 constexpr int NP = 1;
                 if (int rc = vq_set_max_smem(once, (const void *)vq_screen16_kernel<DT, METRIC, true, NP>, SMEM16, "vq_screen16_kernel (fp32 rows)")) return rc;
-                hipLaunchKernelGGL((vq_screen16_kernel<DT, METRIC, true, NP>), dim3(blocks), dim3(VQS_WAVES * 64), SMEM16, st, a);
+                hipLaunchKernelGGL((vq_screen16_kernel<DT, METRIC, true, NP>), dim3(blocks, (unsigned)(a.heads > 1 ? a.heads : 1)), dim3(VQS_WAVES * 64), SMEM16, st, a);
                 return vq_launch_status("vq_screen16_kernel (fp32 rows)");
             }
         }
@@ -1236,7 +1238,7 @@ static int launch_screen(const ScreenArgs &a, int x_dtype, hipStream_t st)
             static VqAttrOnce once;
             constexpr int SMEM16 = Screen16F32Cfg<DT>::SMEM;
             if (int rc = vq_set_max_smem(once, (const void *)vq_screen16_1rb_kernel<DT, METRIC, false, 1>, SMEM16, "vq_screen16_1rb_kernel")) return rc;
-            hipLaunchKernelGGL((vq_screen16_1rb_kernel<DT, METRIC, false, 1>), dim3(blocks), dim3(VQS_F32_WAVES * 64), SMEM16, st, a);
+            hipLaunchKernelGGL((vq_screen16_1rb_kernel<DT, METRIC, false, 1>), dim3(blocks, (unsigned)(a.heads > 1 ? a.heads : 1)), dim3(VQS_F32_WAVES * 64), SMEM16, st, a);
         }
     }
     return vq_launch_status("vq_screen16 kernels");
@@ -1256,6 +1258,39 @@ extern "C" int vqhip_assign_screened(const void *x, int x_dtype, int64_t N, int 
 {
     return vq_assign_screened_impl(x, x_dtype, N, D, ldx, packed, embed, C, metric, idx_out, q_out, ldq, resid_out, ldr, sqerr_partial,
                                    row_mask, workspace, workspace_bytes, debug_out, nullptr, 0, stream);
+}
+
+// H searches in one set of launches (blockIdx.y = head): the heads of a multi-head VectorQuantize with separate codebooks
+// (vqp.py:1044-1049), RandomProjectionQuantizer's 16 heads (random_projection_quantizer.py:37-59).  Every buffer of head h sits
+// h strides behind head 0's: x at x_hstride ELEMENTS, packed at vqhip_packed_bytes(C, D), embed at C * D floats, idx_out at N, q_out at
+// q_hstride elements, the workspace at vqhip_screen_batched_ws_stride(N) bytes.
+extern "C" size_t vqhip_screen_batched_ws_stride(int64_t N)
+{
+    return (vqhip_screen_workspace_bytes(N) + 255) & ~(size_t)255;
+}
+
+extern "C" int vqhip_assign_screened_batched(const void *x, int x_dtype, int H, int64_t N, int D, int64_t ldx, int64_t x_hstride,
+                                             const float *packed, const float *embed, int C, int metric, int64_t *idx_out,
+                                             void *q_out, int64_t ldq, int64_t q_hstride, const uint8_t *row_mask,
+                                             void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (H < 1) VQ_FAIL(VQHIP_EINVAL, "assign_screened_batched: H < 1");
+    const size_t wss = vqhip_screen_batched_ws_stride(N);
+    if (workspace_bytes < wss * (size_t)H) VQ_FAIL(VQHIP_EINVAL, "assign_screened_batched: workspace too small");
+    const int es = (x_dtype == VQHIP_BF16) ? 2 : 4;
+    if ((x_hstride * es) & 15) VQ_FAIL(VQHIP_EALIGN, "assign_screened_batched: heads' rows must stay 16-byte aligned");
+    if (q_out && ((q_hstride * es) % (4 * es))) VQ_FAIL(VQHIP_EALIGN, "assign_screened_batched: heads' q rows must stay aligned to 4 elements");
+    VqHeadStrides hs;
+    hs.heads = H;
+    hs.x = x_hstride * es;
+    hs.packed = (int64_t)vqhip_packed_bytes(C, D);
+    hs.embed = (int64_t)C * D * 4;
+    hs.codes = (x_dtype == VQHIP_BF16) ? hs.packed : hs.embed;
+    hs.idx = N * 8;
+    hs.q = q_hstride * es;
+    hs.ws = (int64_t)wss;
+    return vq_assign_screened_impl(x, x_dtype, N, D, ldx, packed, embed, C, metric, idx_out, q_out, ldq, nullptr, D, nullptr, row_mask,
+                                   workspace, wss, nullptr, nullptr, 0, stream, &hs);
 }
 
 extern "C" int vqhip_screen_chain_supported(int x_dtype, int D)
@@ -1291,8 +1326,11 @@ int vq_assign_screened_impl(const void *x, int x_dtype, int64_t N, int D, int64_
                             const float *embed, int C, int metric, int64_t *idx_out, void *q_out, int64_t ldq,
                             void *resid_out, int64_t ldr, double *sqerr_partial, const uint8_t *row_mask,
                             void *workspace, size_t workspace_bytes, float *debug_out, const vqhip_chain_t *chain,
-                            int header_zeroed, void *stream)
+                            int header_zeroed, void *stream, const VqHeadStrides *hs)
 {
+    const int heads = (hs && hs->heads > 1) ? hs->heads : 1;
+    if (heads > 1 && (resid_out || sqerr_partial || debug_out || chain))
+        VQ_FAIL(VQHIP_EINVAL, "assign_screened: a batched launch has index and q outputs only");
     if (N < 0 || C <= 0) VQ_FAIL(VQHIP_EINVAL, "assign_screened: N < 0 or C <= 0");
     if (N == 0) return 0;
     if (!x || !packed || !embed || !idx_out || !workspace) VQ_FAIL(VQHIP_EINVAL, "assign_screened: null pointer");
@@ -1313,7 +1351,7 @@ int vq_assign_screened_impl(const void *x, int x_dtype, int64_t N, int D, int64_
     int *count = (int *)workspace;
     int *rows = count + 4;
     if (!header_zeroed) {
-        hipError_t e = hipMemsetAsync(count, 0, 16, st);
+        hipError_t e = heads > 1 ? hipMemset2DAsync(count, (size_t)hs->ws, 0, 16, (size_t)heads, st) : hipMemsetAsync(count, 0, 16, st);
         if (e != hipSuccess) VQ_FAIL((int)e, "assign_screened: hipMemsetAsync: %s", hipGetErrorString(e));
     }
 
@@ -1337,6 +1375,9 @@ int vq_assign_screened_impl(const void *x, int x_dtype, int64_t N, int D, int64_
         a.seg_rows = (int *)(a.seg_keys + nseg);
         a.seg_cap = 0;
     }
+    a.heads = heads;
+    a.hs_x = hs ? hs->x : 0; a.hs_packed = hs ? hs->packed : 0; a.hs_embed = hs ? hs->embed : 0;
+    a.hs_idx = hs ? hs->idx : 0; a.hs_q = hs ? hs->q : 0; a.hs_ws = hs ? hs->ws : 0;
     a.idx_stride = chain ? chain->idx_stride : 1;
     a.prev_idx = chain ? chain->prev_idx : nullptr;
     a.prev_idx_stride = chain ? chain->prev_idx_stride : 1;
@@ -1366,5 +1407,5 @@ int vq_assign_screened_impl(const void *x, int x_dtype, int64_t N, int D, int64_
     const int64_t ldl = (chain && chain->prev_idx) ? chain->ldxo : ldx;
     return vq_assign_listed(xl, x_dtype, metric, N, D, ldl, packed, embed, C, idx_out, a.idx_stride, q_out, ldq, resid_out, ldr,
                             sqerr_partial ? sqerr_partial + vqhip_screen_blocks(N, x_dtype) : nullptr, row_mask, rows, count, keys,
-                            with_pairs, st);
+                            with_pairs, st, hs);
 }

@@ -47,6 +47,11 @@ struct ScreenArgs {
     int64_t ldxo;
     // segmented lists (vq_screenc_kernel: every workgroup appends to its own segment, no global atomics; vq_compact_lists_kernel
     // packs the segments into flag_rows / flag_keys and writes flag_count)
+    // several heads in one launch (vqhip_assign_screened_batched: blockIdx.y = head): byte strides between consecutive heads' rows,
+    // packed codebooks, fp32 codebooks, index / q outputs and workspaces.  heads <= 1: a plain launch.  (No residual / squared-error
+    // / chain outputs in a batched launch.)
+    int heads;
+    int64_t hs_x, hs_packed, hs_embed, hs_idx, hs_q, hs_ws;
     int *seg_counts;                   // [2 * VQ_SEG_MAX]: open, pair entries per segment
     int *seg_rows;                     // [VQ_SEG_MAX * seg_cap]
     unsigned long long *seg_keys;      // [VQ_SEG_MAX * seg_cap]
@@ -56,6 +61,25 @@ struct ScreenArgs {
 #endif
 };
 
+
+// the argument block of head blockIdx.y of a batched launch
+__device__ __forceinline__ ScreenArgs vq_head_screen_args(const ScreenArgs &a0)
+{
+    if (a0.heads <= 1) return a0;
+    ScreenArgs a = a0;
+    const int64_t h = blockIdx.y;
+    a.x = (const char *)a0.x + h * a0.hs_x;
+    a.tiles16 = a0.tiles16 + h * a0.hs_packed;
+    a.embed_bf16 = (const unsigned short *)((const char *)a0.embed_bf16 + h * a0.hs_packed);
+    a.scalars = (const unsigned *)((const char *)a0.scalars + h * a0.hs_packed);
+    a.embed = (const float *)((const char *)a0.embed + h * a0.hs_embed);
+    a.idx_out = (int64_t *)((char *)a0.idx_out + h * a0.hs_idx);
+    if (a0.q_out) a.q_out = (char *)a0.q_out + h * a0.hs_q;
+    a.flag_count = (int *)((char *)a0.flag_count + h * a0.hs_ws);
+    a.flag_rows = (int *)((char *)a0.flag_rows + h * a0.hs_ws);
+    a.flag_keys = (unsigned long long *)((char *)a0.flag_keys + h * a0.hs_ws);
+    return a;
+}
 
 // persistent screening kernel with the cyclic tile stream (vq_screen_c.hip): 1 if it serves this launch, and the launch itself
 int vq_screenc_eligible(const ScreenArgs &a, int x_dtype, int DT);

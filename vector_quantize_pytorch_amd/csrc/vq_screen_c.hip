@@ -537,7 +537,7 @@ static int vqc_enabled()
 int vq_screenc_eligible(const ScreenArgs &a, int x_dtype, int DT)
 {
     if (!vqc_enabled()) return 0;
-    if (x_dtype != VQHIP_BF16 || DT != 256) return 0;
+    if (x_dtype != VQHIP_BF16 || DT != 256 || a.heads > 1) return 0;
     if (a.n_tiles16 < 2 || (a.n_tiles16 & 1)) return 0;
     if (a.resid_out || a.sqerr_partial || a.prev_idx) return 0;
     if (a.N < VQC_MIN_ROWS) return 0;

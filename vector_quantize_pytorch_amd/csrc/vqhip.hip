@@ -131,12 +131,18 @@ extern "C" size_t vqhip_packed_bytes(int C, int D)
     return vq_packed_total_bytes(C, D);   // layout: vqhip_internal.h
 }
 
-__global__ void __launch_bounds__(256) vq_pack_kernel(const float *__restrict__ embed, int C, int D, int DT,
-                                                      float *__restrict__ packed, unsigned short *__restrict__ ebf,
-                                                      unsigned *__restrict__ scalars)
+__global__ void __launch_bounds__(256) vq_pack_kernel(const float *embed, int C, int D, int DT,
+                                                      float *packed, unsigned short *ebf,
+                                                      unsigned *scalars, size_t head_bytes)
 {
     __shared__ float y2sh[32];
     const int t = blockIdx.x;
+    if (blockIdx.z) {      // batched heads (vqhip_pack_codebook_batched): head z's codebook and packed buffer
+        embed += (size_t)blockIdx.z * C * D;
+        packed = (float *)((char *)packed + (size_t)blockIdx.z * head_bytes);
+        ebf = (unsigned short *)((char *)ebf + (size_t)blockIdx.z * head_bytes);
+        scalars = (unsigned *)((char *)scalars + (size_t)blockIdx.z * head_bytes);
+    }
     // blockIdx.y splits a tile's work over two workgroups (a 1024-code codebook is only 32 tiles): y = 1 writes the bf16 copy,
     // y = 0 the fp32 tile and the norms
     if (blockIdx.y == 1) {
@@ -197,12 +203,18 @@ __global__ void __launch_bounds__(256) vq_pack_kernel(const float *__restrict__ 
 // 16 bytes per lane and k-step; lane l = code (l & 31), k-slot 8 * (l >> 5) + e.  Tile tail: 32 floats -||c||^2 / 2
 // (-3e38 for padding codes).  scalars[1] <- max_c ||c - c_f16|| (the certificate charges X * that for the rounding),
 // scalars[2] <- sc.
-__global__ void __launch_bounds__(256) vq_pack16_kernel(const float *__restrict__ embed, int C, int D, int DT, int n_tiles,
-                                                        const float *__restrict__ packed, char *__restrict__ tiles16,
-                                                        unsigned *__restrict__ scalars)
+__global__ void __launch_bounds__(256) vq_pack16_kernel(const float *embed, int C, int D, int DT, int n_tiles,
+                                                        const float *packed, char *tiles16,
+                                                        unsigned *scalars, size_t head_bytes)
 {
     __shared__ float rsq[32];
     const int t = blockIdx.x;
+    if (blockIdx.z) {
+        embed += (size_t)blockIdx.z * C * D;
+        packed = (const float *)((const char *)packed + (size_t)blockIdx.z * head_bytes);
+        tiles16 += (size_t)blockIdx.z * head_bytes;
+        scalars = (unsigned *)((char *)scalars + (size_t)blockIdx.z * head_bytes);
+    }
     const unsigned y2bits = scalars[0];
     int sc = 0;
     if (y2bits != 0u) {
@@ -256,30 +268,36 @@ __global__ void __launch_bounds__(256) vq_pack16_kernel(const float *__restrict_
     }
 }
 
-static int pack_codebook_impl(const float *embed, int C, int D, float *packed, int scalars_zeroed, void *stream)
+static int pack_codebook_impl(const float *embed, int C, int D, float *packed, int scalars_zeroed, void *stream, int H = 1)
 {
-    if (!embed || !packed || C <= 0) VQ_FAIL(VQHIP_EINVAL, "pack_codebook: null pointer or C <= 0");
+    if (!embed || !packed || C <= 0 || H < 1) VQ_FAIL(VQHIP_EINVAL, "pack_codebook: null pointer, C <= 0 or H < 1");
     const int DT = pick_dt(D);
     if (D < 1 || DT == 0) VQ_FAIL(VQHIP_EDIM, "pack_codebook: D=%d unsupported (1..512)", D);
     if (((uintptr_t)packed) & 15) VQ_FAIL(VQHIP_EALIGN, "pack_codebook: packed must be 16-byte aligned");
     const int tiles = (C + 31) / 32;
     char *base = (char *)packed;
     unsigned *scalars = (unsigned *)(base + vq_packed_scalars_offset(C, D));
+    const size_t head_bytes = vq_packed_total_bytes(C, D);     // (a multiple of 16: every head's buffer keeps the alignment)
     if (!scalars_zeroed) {
-        hipError_t e = hipMemsetAsync(scalars, 0, VQ_PACKED_SCALARS_BYTES, (hipStream_t)stream);
-        if (e != hipSuccess) VQ_FAIL((int)e, "pack_codebook: hipMemsetAsync: %s", hipGetErrorString(e));
+        hipError_t e = hipMemset2DAsync(scalars, head_bytes, 0, VQ_PACKED_SCALARS_BYTES, (size_t)H, (hipStream_t)stream);
+        if (e != hipSuccess) VQ_FAIL((int)e, "pack_codebook: hipMemset2DAsync: %s", hipGetErrorString(e));
     }
-    hipLaunchKernelGGL(vq_pack_kernel, dim3(tiles, 2), dim3(256), 0, (hipStream_t)stream, embed, C, D, DT, packed,
-                       (unsigned short *)(base + packed_bf16_offset(C, D)), scalars);
+    hipLaunchKernelGGL(vq_pack_kernel, dim3(tiles, 2, H), dim3(256), 0, (hipStream_t)stream, embed, C, D, DT, packed,
+                       (unsigned short *)(base + packed_bf16_offset(C, D)), scalars, head_bytes);
     if (int rc = launch_status("vq_pack_kernel")) return rc;
-    hipLaunchKernelGGL(vq_pack16_kernel, dim3((unsigned)vq_tiles16(C)), dim3(256), 0, (hipStream_t)stream, embed, C, D, DT, tiles,
-                       (const float *)packed, base + vq_packed_f16_offset(C, D), scalars);
+    hipLaunchKernelGGL(vq_pack16_kernel, dim3((unsigned)vq_tiles16(C), 1, H), dim3(256), 0, (hipStream_t)stream, embed, C, D, DT, tiles,
+                       (const float *)packed, base + vq_packed_f16_offset(C, D), scalars, head_bytes);
     return launch_status("vq_pack16_kernel");
 }
 
 extern "C" int vqhip_pack_codebook(const float *embed, int C, int D, float *packed, void *stream)
 {
     return pack_codebook_impl(embed, C, D, packed, 0, stream);
+}
+
+extern "C" int vqhip_pack_codebook_batched(const float *embed, int H, int C, int D, float *packed, void *stream)
+{
+    return pack_codebook_impl(embed, C, D, packed, 0, stream, H);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -462,6 +480,10 @@ struct AssignArgs {
     int x_vec;  // 1: D == DT and x rows are vector-load aligned
     int q_vec;  // 1: D == DT and q rows are vector-store aligned
     int skip_norm;  // cosine: rows are already unit-norm
+    // several heads in one launch (vqhip_assign_batched: blockIdx.y = head): byte strides between consecutive heads' buffers
+    // (index / q / rnorm outputs only then)
+    int heads;
+    int64_t hs_x, hs_packed, hs_embed, hs_idx, hs_q, hs_rnorm;
 #ifdef VQ_TRACE
     long long *trace;
 #endif
@@ -476,9 +498,20 @@ __device__ __forceinline__ void swap32(float &a, float &b)
 }
 
 template <int DT, bool XBF16, int METRIC>
-__global__ void __launch_bounds__(256, (DT <= 256 ? 2 : 1)) vq_assign_kernel(const AssignArgs a)
+__global__ void __launch_bounds__(256, (DT <= 256 ? 2 : 1)) vq_assign_kernel(const AssignArgs a0)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    AssignArgs a = a0;
+    if (a0.heads > 1) {
+        const int64_t h = blockIdx.y;
+        a.x = (const char *)a0.x + h * a0.hs_x;
+        a.packed = (const float *)((const char *)a0.packed + h * a0.hs_packed);
+        a.embed_bf16 = (const unsigned short *)((const char *)a0.embed_bf16 + h * a0.hs_packed);
+        a.embed = (const float *)((const char *)a0.embed + h * a0.hs_embed);
+        a.idx_out = (int64_t *)((char *)a0.idx_out + h * a0.hs_idx);
+        if (a0.q_out) a.q_out = (char *)a0.q_out + h * a0.hs_q;
+        if (a0.rnorm_out) a.rnorm_out = (float *)((char *)a0.rnorm_out + h * a0.hs_rnorm);
+    }
     constexpr int TILE_F = 32 * DT + 256;
     constexpr int TILE_B = TILE_F * 4;
     constexpr int NCHUNK = TILE_B / 1024;  // 1 KiB LDS-DMA pieces per tile
@@ -824,7 +857,7 @@ static int launch_assign(const AssignArgs &a, hipStream_t st)
     static VqAttrOnce once;   // per instantiation and device
     if (int rc = vq_set_max_smem(once, (const void *)vq_assign_kernel<DT, XBF16, METRIC>, SMEM, "vq_assign_kernel")) return rc;
     const int64_t blocks = vqhip_assign_blocks(a.N);
-    hipLaunchKernelGGL((vq_assign_kernel<DT, XBF16, METRIC>), dim3((unsigned)blocks), dim3(256), SMEM, st, a);
+    hipLaunchKernelGGL((vq_assign_kernel<DT, XBF16, METRIC>), dim3((unsigned)blocks, (unsigned)(a.heads > 1 ? a.heads : 1)), dim3(256), SMEM, st, a);
     return launch_status("vq_assign_kernel");
 }
 
@@ -1225,8 +1258,8 @@ static int assign_impl(const void *x, int x_dtype, int64_t N, int D, int64_t ldx
                        const float *packed, const float *embed, int C, int metric,
                        int64_t *idx_out, void *q_out, int q_dtype, int64_t ldq,
                        float *best_out, float *rnorm_out, double *sqerr_partial,
-                       const uint8_t *row_mask, float *scores_out, int64_t lds, void *stream, float *lse_out = nullptr, float *tscore_out = nullptr,
-                       const int64_t *target = nullptr);
+                       const uint8_t *row_mask, float *scores_out, int64_t lds, void *stream, float *lse_out, float *tscore_out,
+                       const int64_t *target, int heads, int64_t x_hstride, int64_t q_hstride);
 
 extern "C" int vqhip_assign(const void *x, int x_dtype, int64_t N, int D, int64_t ldx,
                             const float *packed, const float *embed, int C, int metric,
@@ -1235,7 +1268,19 @@ extern "C" int vqhip_assign(const void *x, int x_dtype, int64_t N, int D, int64_
                             const uint8_t *row_mask, void *stream)
 {
     return assign_impl(x, x_dtype, N, D, ldx, packed, embed, C, metric, idx_out, q_out, q_dtype, ldq, best_out, rnorm_out,
-                       sqerr_partial, row_mask, nullptr, 0, stream);
+                       sqerr_partial, row_mask, nullptr, 0, stream, nullptr, nullptr, nullptr, 1, 0, 0);
+}
+
+// the exact search of H heads in one launch (grid dimension y = head): dims the screened search does not take (e.g. the 16-wide
+// heads of RandomProjectionQuantizer).  Layout of the heads' buffers as in vqhip_assign_screened_batched; rnorm_out [H, N].
+extern "C" int vqhip_assign_batched(const void *x, int x_dtype, int H, int64_t N, int D, int64_t ldx, int64_t x_hstride,
+                                    const float *packed, const float *embed, int C, int metric,
+                                    int64_t *idx_out, void *q_out, int q_dtype, int64_t ldq, int64_t q_hstride,
+                                    float *rnorm_out, const uint8_t *row_mask, void *stream)
+{
+    if (H < 1) VQ_FAIL(VQHIP_EINVAL, "assign_batched: H < 1");
+    return assign_impl(x, x_dtype, N, D, ldx, packed, embed, C, metric, idx_out, q_out, q_dtype, ldq, nullptr, rnorm_out,
+                       nullptr, row_mask, nullptr, 0, stream, nullptr, nullptr, nullptr, H, x_hstride, q_hstride);
 }
 
 extern "C" int vqhip_scores(const void *x, int x_dtype, int64_t N, int D, int64_t ldx,
@@ -1244,7 +1289,7 @@ extern "C" int vqhip_scores(const void *x, int x_dtype, int64_t N, int D, int64_
 {
     if (!scores_out || lds < C) VQ_FAIL(VQHIP_EINVAL, "scores: scores_out null or row stride smaller than C");
     return assign_impl(x, x_dtype, N, D, ldx, packed, embed, C, metric, idx_out, nullptr, VQHIP_F32, D, nullptr, rnorm_out,
-                       nullptr, nullptr, scores_out, lds, stream);
+                       nullptr, nullptr, scores_out, lds, stream, nullptr, nullptr, nullptr, 1, 0, 0);
 }
 
 extern "C" int vqhip_scores_lse(const void *x, int x_dtype, int64_t N, int D, int64_t ldx,
@@ -1253,7 +1298,7 @@ extern "C" int vqhip_scores_lse(const void *x, int x_dtype, int64_t N, int D, in
 {
     if (!lse_out) VQ_FAIL(VQHIP_EINVAL, "scores_lse: lse_out is null");
     return assign_impl(x, x_dtype, N, D, ldx, packed, embed, C, metric, idx_out, nullptr, VQHIP_F32, D, nullptr, rnorm_out,
-                       nullptr, nullptr, nullptr, 0, stream, lse_out, tscore_out, target);
+                       nullptr, nullptr, nullptr, 0, stream, lse_out, tscore_out, target, 1, 0, 0);
 }
 
 static int assign_impl(const void *x, int x_dtype, int64_t N, int D, int64_t ldx,
@@ -1261,9 +1306,11 @@ static int assign_impl(const void *x, int x_dtype, int64_t N, int D, int64_t ldx
                             int64_t *idx_out, void *q_out, int q_dtype, int64_t ldq,
                             float *best_out, float *rnorm_out, double *sqerr_partial,
                             const uint8_t *row_mask, float *scores_out, int64_t lds, void *stream, float *lse_out, float *tscore_out,
-                            const int64_t *target)
+                            const int64_t *target, int heads, int64_t x_hstride, int64_t q_hstride)
 {
     if (N < 0 || C <= 0) VQ_FAIL(VQHIP_EINVAL, "assign: N < 0 or C <= 0");
+    if (heads > 1 && (best_out || sqerr_partial || scores_out || lse_out))
+        VQ_FAIL(VQHIP_EINVAL, "assign: a batched launch has index, q and rnorm outputs only");
     if (N == 0) return 0;
     if (!x || !packed || !embed || !idx_out) VQ_FAIL(VQHIP_EINVAL, "assign: null pointer");
     if (x_dtype != VQHIP_F32 && x_dtype != VQHIP_BF16) VQ_FAIL(VQHIP_EINVAL, "assign: unknown x dtype %d", x_dtype);
@@ -1277,8 +1324,11 @@ static int assign_impl(const void *x, int x_dtype, int64_t N, int D, int64_t ldx
 
     hipStream_t st = (hipStream_t)stream;
     if (D & 31) {  // exact ATen-order ||x||^2 for odd D: pre-pass into rnorm_out, the kernel reads it back
-        int rc = vqhip_row_sumsq(x, x_dtype, N, D, ldx, rnorm_out, stream);
-        if (rc) return rc;
+        for (int h = 0; h < (heads > 1 ? heads : 1); ++h) {
+            int rc = vqhip_row_sumsq((const char *)x + (size_t)h * x_hstride * ((x_dtype == VQHIP_BF16) ? 2 : 4), x_dtype, N, D, ldx,
+                                     rnorm_out + (size_t)h * N, stream);
+            if (rc) return rc;
+        }
     }
 
     AssignArgs a;
@@ -1294,6 +1344,11 @@ static int assign_impl(const void *x, int x_dtype, int64_t N, int D, int64_t ldx
     a.lse_out = lse_out; a.tscore_out = tscore_out; a.target = target;
     a.best_out = best_out; a.rnorm_out = rnorm_out; a.sqerr_partial = sqerr_partial; a.row_mask = row_mask;
     const int xes = (x_dtype == VQHIP_BF16) ? 2 : 4;
+    a.heads = heads > 1 ? heads : 1;
+    a.hs_x = x_hstride * xes; a.hs_packed = (int64_t)vq_packed_total_bytes(C, D); a.hs_embed = (int64_t)C * D * 4;
+    a.hs_idx = N * 8; a.hs_q = q_hstride * ((q_dtype == VQHIP_BF16) ? 2 : 4); a.hs_rnorm = N * 4;
+    if (heads > 1 && (((x_hstride * xes) % (4 * xes)) || (q_out && ((q_hstride * ((q_dtype == VQHIP_BF16) ? 2 : 4)) % 16))))
+        VQ_FAIL(VQHIP_EALIGN, "assign: heads' rows must stay aligned to 4 elements");
     a.x_vec = (D == DT) && (((uintptr_t)x) % (4 * xes) == 0) && ((ldx * xes) % (4 * xes) == 0) && ((((uintptr_t)embed) & 15) == 0);
     if (q_out) {
         const int qes = a.q_bf16 ? 2 : 4;
@@ -1420,13 +1475,15 @@ struct RefineArgs {
     const int *row_list;
     const int *row_count;
     unsigned long long *keys;   // [list capacity], preset to ~0
+    VqHeadStrides hs;           // batched heads: blockIdx.y = head
 };
 
 // (bid, nblk): this workgroup's number and the number of workgroups doing this work -- the kernel's own grid, or its share of
 // the merged launch vq_listed_kernel further down
 template <int DT, bool XBF16, int METRIC>
-__device__ __forceinline__ void vq_refine_body(const RefineArgs &a, char *smem, const unsigned bid, const unsigned nblk)
+__device__ __forceinline__ void vq_refine_body(const RefineArgs &a0, char *smem, const unsigned bid, const unsigned nblk)
 {
+    RefineArgs a = a0;
     constexpr int TILE_F = 32 * DT + 256;
     constexpr int TILE_B = TILE_F * 4;
     constexpr int NCHUNK = TILE_B / 1024;
@@ -1437,6 +1494,14 @@ __device__ __forceinline__ void vq_refine_body(const RefineArgs &a, char *smem, 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 31;
     const int hi = lane >> 5;
+    if (a0.hs.heads > 1) {
+        const int64_t h = blockIdx.y;
+        a.x = (const char *)a0.x + h * a0.hs.x;
+        a.packed = (const float *)((const char *)a0.packed + h * a0.hs.packed);
+        a.row_list = (const int *)((const char *)a0.row_list + h * a0.hs.ws);
+        a.row_count = (const int *)((const char *)a0.row_count + h * a0.hs.ws);
+        a.keys = (unsigned long long *)((char *)a0.keys + h * a0.hs.ws);
+    }
     const int list_n = __builtin_amdgcn_readfirstlane(*a.row_count);
     if (list_n <= 0) return;
     // the list length only exists on the device: a fixed 1-D grid, and the codebook sweep of every 128-row chunk is split over
@@ -1546,15 +1611,27 @@ struct FinishArgs {
     int64_t ldr;
     double *sqerr_partial;   // nullable, one entry per workgroup
     const uint8_t *row_mask;
+    VqHeadStrides hs;        // batched heads: blockIdx.y = head (no residual / squared-error outputs then)
 };
 
 // one wave per listed row: idx, q row, sum (q - x)^2.  A row is a chain of dependent loads (list -> key -> code row): the kernel is
 // latency bound, so VQ_FINISH_WAVES waves per workgroup (8192 waves in the grid) keep the rows per wave at a handful
 #define VQ_FINISH_WAVES 16
 template <bool XBF16>
-__global__ void __launch_bounds__(VQ_FINISH_WAVES * 64) vq_finish_listed_kernel(const FinishArgs a)
+__global__ void __launch_bounds__(VQ_FINISH_WAVES * 64) vq_finish_listed_kernel(const FinishArgs a0)
 {
     __shared__ double red[VQ_FINISH_WAVES];
+    FinishArgs a = a0;
+    if (a0.hs.heads > 1) {
+        const int64_t h = blockIdx.y;
+        a.x = (const char *)a0.x + h * a0.hs.x;
+        a.codes = (const char *)a0.codes + h * a0.hs.codes;
+        a.row_list = (const int *)((const char *)a0.row_list + h * a0.hs.ws);
+        a.row_count = (const int *)((const char *)a0.row_count + h * a0.hs.ws);
+        a.keys = (const unsigned long long *)((const char *)a0.keys + h * a0.hs.ws);
+        a.idx_out = (int64_t *)((char *)a0.idx_out + h * a0.hs.idx);
+        if (a0.q_out) a.q_out = (char *)a0.q_out + h * a0.hs.q;
+    }
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int n_full = a.row_count[0];
@@ -1609,7 +1686,7 @@ static int launch_refine(const RefineArgs &a, unsigned gx, hipStream_t st)
     constexpr int SMEM = 2 * (32 * DT + 256) * 4;
     static VqAttrOnce once;
     if (int rc = vq_set_max_smem(once, (const void *)vq_refine_kernel<DT, XBF16, METRIC>, SMEM, "vq_refine_kernel")) return rc;
-    hipLaunchKernelGGL((vq_refine_kernel<DT, XBF16, METRIC>), dim3(gx), dim3(256), SMEM, st, a);
+    hipLaunchKernelGGL((vq_refine_kernel<DT, XBF16, METRIC>), dim3(gx, a.hs.heads > 1 ? a.hs.heads : 1), dim3(256), SMEM, st, a);
     return launch_status("vq_refine_kernel");
 }
 
@@ -1636,6 +1713,7 @@ struct PairArgs {
     const int *row_count;     // [1] = number of pair rows, stored at list positions cap - 1 - p
     int64_t cap;
     unsigned long long *keys;
+    VqHeadStrides hs;         // batched heads: blockIdx.y = head
 };
 
 // The 16-byte pieces a lane streams from its OWN row and its two code rows would touch 64 different cache lines per wave
@@ -1653,8 +1731,18 @@ template <bool XBF16> struct PairCfg {
 };
 
 template <int DT, bool XBF16, int METRIC>
-__device__ __forceinline__ void vq_pair_body(const PairArgs &a, char *smem, const unsigned bid, const unsigned nblk)
+__device__ __forceinline__ void vq_pair_body(const PairArgs &a0, char *smem, const unsigned bid, const unsigned nblk)
 {
+    PairArgs a = a0;
+    if (a0.hs.heads > 1) {
+        const int64_t h = blockIdx.y;
+        a.x = (const char *)a0.x + h * a0.hs.x;
+        a.embed = (const float *)((const char *)a0.embed + h * a0.hs.embed);
+        a.packed = (const float *)((const char *)a0.packed + h * a0.hs.packed);
+        a.row_list = (const int *)((const char *)a0.row_list + h * a0.hs.ws);
+        a.row_count = (const int *)((const char *)a0.row_count + h * a0.hs.ws);
+        a.keys = (unsigned long long *)((char *)a0.keys + h * a0.hs.ws);
+    }
     constexpr int KC = PairCfg<XBF16>::KC, NCH = DT / KC;
     constexpr int EP = PairCfg<XBF16>::EP;
     constexpr int XP = PairCfg<XBF16>::XP;
@@ -1764,7 +1852,7 @@ __global__ void __launch_bounds__(VQ_PAIR_WAVES * 64) vq_pair_kernel(const PairA
 template <int DT>
 static int dispatch_pair(const PairArgs &a, int x_dtype, int metric, unsigned blocks, hipStream_t st)
 {
-#define VQ_PAIR(B, M) hipLaunchKernelGGL((vq_pair_kernel<DT, B, M>), dim3(blocks), dim3(VQ_PAIR_WAVES * 64), 0, st, a)
+#define VQ_PAIR(B, M) hipLaunchKernelGGL((vq_pair_kernel<DT, B, M>), dim3(blocks, a.hs.heads > 1 ? a.hs.heads : 1), dim3(VQ_PAIR_WAVES * 64), 0, st, a)
     if (metric == VQHIP_EUCLID) { if (x_dtype == VQHIP_BF16) VQ_PAIR(true, 0); else VQ_PAIR(false, 0); }
     else                        { if (x_dtype == VQHIP_BF16) VQ_PAIR(true, 1); else VQ_PAIR(false, 1); }
 #undef VQ_PAIR
@@ -1774,13 +1862,17 @@ static int dispatch_pair(const PairArgs &a, int x_dtype, int metric, unsigned bl
 int vq_assign_listed(const void *x, int x_dtype, int metric, int64_t N, int D, int64_t ldx, const float *packed, const float *embed, int C,
                      int64_t *idx_out, int64_t idx_stride, void *q_out, int64_t ldq, void *resid_out, int64_t ldr, double *sqerr_partial,
                      const uint8_t *row_mask, const int *row_list, const int *row_count, unsigned long long *keys, int with_pairs,
-                     hipStream_t st)
+                     hipStream_t st, const VqHeadStrides *hs)
 {
+    VqHeadStrides h1;
+    h1.heads = 1; h1.x = h1.packed = h1.embed = h1.codes = h1.idx = h1.q = h1.ws = 0;
+    const VqHeadStrides &H = hs ? *hs : h1;
+    if (H.heads > 1 && (resid_out || sqerr_partial)) VQ_FAIL(VQHIP_EINVAL, "assign_listed: no residual / squared-error outputs in a batched launch");
     // keys[0 .. row_count[0]) were preset to ~0 by whoever built the list (the screening kernels); the pair entries at
     // [N - row_count[1], N) hold their two candidates
     RefineArgs r;
     r.x = x; r.ldx = ldx; r.packed = packed; r.C = C; r.n_tiles = (C + 31) / 32;
-    r.row_list = row_list; r.row_count = row_count; r.keys = keys;
+    r.row_list = row_list; r.row_count = row_count; r.keys = keys; r.hs = H;
     const int64_t chunks = vqhip_assign_blocks(N);
     const int64_t want = chunks * r.n_tiles;              // one workgroup per (chunk, tile) at most
     const unsigned gx = (unsigned)(want < VQ_REFINE_GRID ? want : VQ_REFINE_GRID);
@@ -1789,7 +1881,7 @@ int vq_assign_listed(const void *x, int x_dtype, int metric, int64_t N, int D, i
     //  cfg 2 +0.9 %, cfg 3 -1.4 %, cfg 5 +1.8 %; the pair rows' workgroups inherit the sweep's LDS and register budget.  Removed.)
     PairArgs pa;
     pa.x = x; pa.ldx = ldx; pa.embed = embed; pa.packed = packed; pa.D = D;
-    pa.row_list = row_list; pa.row_count = row_count; pa.cap = N; pa.keys = keys;
+    pa.row_list = row_list; pa.row_count = row_count; pa.cap = N; pa.keys = keys; pa.hs = H;
     const int64_t pb = (N + VQ_PAIR_WAVES * 64 - 1) / (VQ_PAIR_WAVES * 64);
     const unsigned blocks = (unsigned)(pb < 1024 ? pb : 1024);
     switch (pick_dt(D)) {
@@ -1811,15 +1903,16 @@ int vq_assign_listed(const void *x, int x_dtype, int metric, int64_t N, int D, i
         }
         if (rc) return rc;
     }
+    const unsigned nh = (unsigned)(H.heads > 1 ? H.heads : 1);
     FinishArgs f;
     f.x = x; f.ldx = ldx;
     f.codes = (x_dtype == VQHIP_BF16) ? (const void *)((const char *)packed + packed_bf16_offset(C, D)) : (const void *)embed;
     f.D = D; f.row_list = row_list; f.row_count = row_count; f.cap = N; f.keys = keys;
-    f.idx_out = idx_out; f.idx_stride = idx_stride; f.q_out = q_out; f.ldq = ldq; f.resid_out = resid_out; f.ldr = ldr; f.sqerr_partial = sqerr_partial; f.row_mask = row_mask;
+    f.idx_out = idx_out; f.idx_stride = idx_stride; f.q_out = q_out; f.ldq = ldq; f.resid_out = resid_out; f.ldr = ldr; f.sqerr_partial = sqerr_partial; f.row_mask = row_mask; f.hs = H;
     if (x_dtype == VQHIP_BF16)
-        hipLaunchKernelGGL(vq_finish_listed_kernel<true>, dim3(VQ_FINISH_BLOCKS), dim3(VQ_FINISH_WAVES * 64), 0, st, f);
+        hipLaunchKernelGGL(vq_finish_listed_kernel<true>, dim3(VQ_FINISH_BLOCKS, nh), dim3(VQ_FINISH_WAVES * 64), 0, st, f);
     else
-        hipLaunchKernelGGL(vq_finish_listed_kernel<false>, dim3(VQ_FINISH_BLOCKS), dim3(VQ_FINISH_WAVES * 64), 0, st, f);
+        hipLaunchKernelGGL(vq_finish_listed_kernel<false>, dim3(VQ_FINISH_BLOCKS, nh), dim3(VQ_FINISH_WAVES * 64), 0, st, f);
     return launch_status("vq_finish_listed_kernel");
 }
 

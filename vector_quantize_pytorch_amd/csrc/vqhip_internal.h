@@ -102,10 +102,16 @@ static inline size_t vq_packed_total_bytes(int C, int D)
 // (c1 | c2 << 32); vq_pair_kernel decides them with two exact distances instead of a codebook sweep.
 // sqerr_partial (nullable) receives VQ_FINISH_BLOCKS entries.
 #define VQ_FINISH_BLOCKS 512
+// several heads in one launch (blockIdx.y = head): byte strides between consecutive heads' rows, packed codebooks, fp32 codebooks,
+// the gather source of the finish kernel (bf16 copy inside the packed buffer, or embed), index / q outputs and workspaces
+struct VqHeadStrides {
+    int heads;          // <= 1: a plain launch
+    int64_t x, packed, embed, codes, idx, q, ws;
+};
 int vq_assign_listed(const void *x, int x_dtype, int metric, int64_t N, int D, int64_t ldx, const float *packed, const float *embed, int C,
                      int64_t *idx_out, int64_t idx_stride, void *q_out, int64_t ldq, void *resid_out, int64_t ldr, double *sqerr_partial,
                      const uint8_t *row_mask, const int *row_list, const int *row_count, unsigned long long *keys, int with_pairs,
-                     hipStream_t st);
+                     hipStream_t st, const VqHeadStrides *hs = nullptr);
 
 // the screened assignment behind vqhip_assign_screened / vqhip_assign_screened_chain (vq_screen.hip); header_zeroed says that the
 // caller (the fused train step, vqhip_vq_train_step) has already zeroed the workspace's 16-byte list header on this stream
@@ -113,4 +119,4 @@ int vq_assign_screened_impl(const void *x, int x_dtype, int64_t N, int D, int64_
                             const float *embed, int C, int metric, int64_t *idx_out, void *q_out, int64_t ldq,
                             void *resid_out, int64_t ldr, double *sqerr_partial, const uint8_t *row_mask,
                             void *workspace, size_t workspace_bytes, float *debug_out, const vqhip_chain_t *chain,
-                            int header_zeroed, void *stream);
+                            int header_zeroed, void *stream, const VqHeadStrides *hs = nullptr);
