@@ -216,6 +216,14 @@ int vqhip_rvq_route(const void *x, int dtype, int64_t N, int D, int64_t ldx, con
                     int C, const int64_t *idx, int64_t idx_stride, int Q, int mode, int resid_routed, const void *g_out, int64_t ldg,
                     const float *loss_coef, const uint8_t *row_mask, int backward, void *out, int64_t ldo, void *stream);
 
+/* vqhip_route_fwd / vqhip_route_bwd with q gathered by index from a code table (codes [C, D] in the rows' dtype, contiguous; q[n] =
+ * codes[idx[n * idx_stride]]): the [N, D] q tensor is neither written by the search nor read here.  Arithmetic unchanged. */
+int vqhip_route_fwd_gather(const void *x, const void *codes, const int64_t *idx, int64_t idx_stride, int dtype, int64_t N, int D,
+                           int64_t ldx, void *out, int64_t ldo, int mode, void *stream);
+int vqhip_route_bwd_gather(const void *x, const void *codes, const int64_t *idx, int64_t idx_stride, const void *g_out, int dtype,
+                           int64_t N, int D, int64_t ldx, int64_t ldg, const float *loss_coef, const uint8_t *row_mask,
+                           int mode, void *grad_x, int64_t ldo, void *stream);
+
 /* out[n] = x[n] - route(x[n], embed[idx[n * idx_stride]]) for fp32 rows: the input of the next ResidualVQ stage when the layer returned
  * the ROUTED value (`residual - quantized.detach()`, rvq.py:524, in a training step whose input requires grad, vqp.py:1225-1233).
  * mode 1 / 2 and arithmetic as vqhip_route_fwd (bit for bit).  embed [C, D] fp32 contiguous. */

@@ -112,6 +112,10 @@ def lib():
     L.vqhip_assign_screened_batched.restype = i32
     L.vqhip_assign_batched.argtypes = [vp, i32, i32, i64, i32, i64, i64, vp, vp, i32, i32, vp, vp, i32, i64, i64, vp, vp, vp]
     L.vqhip_assign_batched.restype = i32
+    L.vqhip_route_fwd_gather.argtypes = [vp, vp, vp, i64, i32, i64, i32, i64, vp, i64, i32, vp]
+    L.vqhip_route_fwd_gather.restype = i32
+    L.vqhip_route_bwd_gather.argtypes = [vp, vp, vp, i64, vp, i32, i64, i32, i64, i64, vp, vp, i32, vp, i64, vp]
+    L.vqhip_route_bwd_gather.restype = i32
     L.vqhip_route_residual.argtypes = [vp, i64, i32, i64, vp, vp, i64, i32, vp, i64, vp]
     L.vqhip_route_residual.restype = i32
     L.vqhip_vq_step_supported.argtypes = [i32, i64, i32, i32]
@@ -132,7 +136,8 @@ EXPORTS = ("vqhip_version", "vqhip_last_error", "vqhip_packed_bytes", "vqhip_pac
            "vqhip_screen_blocks", "vqhip_screen_partials", "vqhip_assign_screened", "vqhip_screen_chain_supported", "vqhip_assign_screened_chain", "vqhip_l2norm_rows", "vqhip_scores", "vqhip_rvq_forward", "vqhip_reduce_partials", "vqhip_reduce_partials_rows", "vqhip_ema_fold_many", "vqhip_ema_workspace_bytes", "vqhip_ema_accumulate", "vqhip_ema_sqerr_partials", "vqhip_ema_accumulate_sqerr",
            "vqhip_ema_finalize", "vqhip_decode_sum", "vqhip_row_sumsq", "vqhip_assign_rowwise", "vqhip_score_indices", "vqhip_topk", "vqhip_expire_scatter", "vqhip_kmeans_update", "vqhip_route_fwd", "vqhip_route_bwd", "vqhip_rvq_route", "vqhip_ema_renormalize_shard", "vqhip_scores_lse",
            "vqhip_pack_best", "vqhip_unpack_best", "vqhip_vq_step_supported", "vqhip_vq_step_workspace_bytes", "vqhip_vq_train_step", "vqhip_route_residual",
-           "vqhip_pack_codebook_batched", "vqhip_screen_batched_ws_stride", "vqhip_assign_screened_batched", "vqhip_assign_batched")
+           "vqhip_pack_codebook_batched", "vqhip_screen_batched_ws_stride", "vqhip_assign_screened_batched", "vqhip_assign_batched",
+           "vqhip_route_fwd_gather", "vqhip_route_bwd_gather")
 
 
 def _check(rc, what):
@@ -581,6 +586,39 @@ def route_fwd(x: torch.Tensor, q: torch.Tensor, mode: int) -> torch.Tensor:
         _check(lib().vqhip_route_fwd(_ptr(xk), _ptr(qk), _dtype_code(xk), N, D, ldx, ldq, _ptr(out), D, mode, _stream()),
                "vqhip_route_fwd")
     return out
+
+
+@_on_device
+def route_fwd_gather(x: torch.Tensor, codes: torch.Tensor, idx: torch.Tensor, mode: int) -> torch.Tensor:
+    """route_fwd with q = codes[idx] gathered inside the kernel (codes [C, D] in x's dtype): no [N, D] q tensor"""
+    _need_gpu(x, codes, idx)
+    assert codes.dtype == x.dtype and codes.is_contiguous() and codes.ndim == 2 and idx.dtype == torch.int64 and idx.is_contiguous()
+    xk, N, D, ldx = as_rows(x)
+    assert idx.numel() == N and codes.shape[1] == D
+    out = torch.empty(x.shape, dtype=x.dtype, device=x.device)
+    if N > 0:
+        _check(lib().vqhip_route_fwd_gather(_ptr(xk), _ptr(codes), _ptr(idx), 1, _dtype_code(xk), N, D, ldx, _ptr(out), D, mode, _stream()),
+               "vqhip_route_fwd_gather")
+    return out
+
+
+@_on_device
+def route_bwd_gather(x: torch.Tensor, codes: torch.Tensor, idx: torch.Tensor, g_out, loss_coef, row_mask, mode: int) -> torch.Tensor:
+    """route_bwd with q = codes[idx] gathered inside the kernel"""
+    _need_gpu(x, codes, idx, g_out, loss_coef, row_mask)
+    xk, N, D, ldx = as_rows(x)
+    gk, ldg = None, 0
+    if g_out is not None and mode != 0:
+        gk, _, _, ldg = as_rows(g_out.to(x.dtype))
+    if loss_coef is not None:
+        loss_coef = loss_coef.to(torch.float32).reshape(()).contiguous()
+    if row_mask is not None:
+        row_mask = row_mask.reshape(-1).to(torch.uint8).contiguous()
+    gx = torch.empty(x.shape, dtype=x.dtype, device=x.device)
+    if N > 0:
+        _check(lib().vqhip_route_bwd_gather(_ptr(xk), _ptr(codes), _ptr(idx), 1, _ptr(gk), _dtype_code(xk), N, D, ldx, ldg, _ptr(loss_coef),
+                                            _ptr(row_mask), mode if gk is not None else 0, _ptr(gx), D, _stream()), "vqhip_route_bwd_gather")
+    return gx
 
 
 @_on_device

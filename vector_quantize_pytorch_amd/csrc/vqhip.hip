@@ -2273,10 +2273,12 @@ struct RouteArgs {
     const uint8_t *row_mask;
     int mode;
     int vec;                // every row pointer / stride allows 4-element accesses
-    // residual step of a residual VQ whose layers return the ROUTED value (vqhip_route_residual, forward only, fp32 rows):
-    // q rows are embed[qidx[n * qidx_stride]] (a.q = the fp32 codebook, ldq = D) and out = x - route(x, q)   (rvq.py:524)
+    // q rows gathered from a code table instead of read from an [N, D] tensor: q[n] = a.q[qidx[n * qidx_stride]] (a.q = [C, D] in the
+    // rows' dtype, ldq = D) -- the q tensor then never has to exist (vqhip_route_fwd_gather / _bwd_gather); sub: out = x - route(x, q),
+    // the residual step of a residual VQ whose layers return the ROUTED value (vqhip_route_residual, rvq.py:524)
     const int64_t *qidx;
     int64_t qidx_stride;
+    int sub;
 };
 
 template <bool BF16, bool BWD, int NE, int LPR>
@@ -2290,13 +2292,13 @@ __global__ void __launch_bounds__(256) vq_route_kernel(const RouteArgs a)
     const int64_t n = valid ? n0 : a.N - 1;            // (rows share a wave: the ones past the end repeat the last row and store nothing)
     float e[NE], qv[NE], g[NE];
     row_load8<BF16, NE, LPR>(a.x, n * a.ldx, a.D, lane, a.vec != 0, e);
-    const int64_t qrow = (!BWD && !BF16 && a.qidx) ? a.qidx[n * a.qidx_stride] : n;
+    const int64_t qrow = a.qidx ? a.qidx[n * a.qidx_stride] : n;
     row_load8<BF16, NE, LPR>(a.q, qrow * a.ldq, a.D, lane, a.vec != 0, qv);
     if (BWD && a.g) row_load8<BF16, NE, LPR>(a.g, n * a.ldg, a.D, lane, a.vec != 0, g);
     float r[NE];
     if (!BWD) {
         vq_route_value<NE, LPR, BF16>(e, qv, a.mode, r);            // vq_route_math.h (mode 1 / 2)
-        if (!BF16 && a.qidx) {
+        if (!BF16 && a.sub) {
 #pragma unroll
             for (int k = 0; k < NE; ++k) r[k] = e[k] - r[k];          // the next stage's input: residual - quantized.detach() (rvq.py:524)
         }
@@ -2344,7 +2346,7 @@ extern "C" int vqhip_route_fwd(const void *x, const void *q, int dtype, int64_t 
     if (dtype != VQHIP_F32 && dtype != VQHIP_BF16) VQ_FAIL(VQHIP_EINVAL, "route_fwd: unknown dtype");
     RouteArgs a;
     a.x = x; a.q = q; a.g = nullptr; a.out = out; a.N = N; a.D = D; a.ldx = ldx; a.ldq = ldq; a.ldg = 0; a.ldo = ldo;
-    a.loss_coef = nullptr; a.row_mask = nullptr; a.mode = mode; a.qidx = nullptr; a.qidx_stride = 0;
+    a.loss_coef = nullptr; a.row_mask = nullptr; a.mode = mode; a.qidx = nullptr; a.qidx_stride = 0; a.sub = 0;
     const int es = dtype == VQHIP_BF16 ? 2 : 4;
     a.vec = rows_vec4(x, ldx, D, es) && rows_vec4(q, ldq, D, es) && rows_vec4(out, ldo, D, es);
     return route_launch(a, dtype, false, (hipStream_t)stream);
@@ -2363,7 +2365,7 @@ extern "C" int vqhip_route_residual(const void *x, int64_t N, int D, int64_t ldx
     if (mode != 1 && mode != 2) VQ_FAIL(VQHIP_EINVAL, "route_residual: mode must be 1 (straight-through) or 2 (rotation trick)");
     RouteArgs a;
     a.x = x; a.q = embed; a.g = nullptr; a.out = out; a.N = N; a.D = D; a.ldx = ldx; a.ldq = D; a.ldg = 0; a.ldo = ldo;
-    a.loss_coef = nullptr; a.row_mask = nullptr; a.mode = mode; a.qidx = idx; a.qidx_stride = idx_stride;
+    a.loss_coef = nullptr; a.row_mask = nullptr; a.mode = mode; a.qidx = idx; a.qidx_stride = idx_stride; a.sub = 1;
     a.vec = rows_vec4(x, ldx, D, 4) && rows_vec4(embed, D, D, 4) && rows_vec4(out, ldo, D, 4);
     return route_launch(a, VQHIP_F32, false, (hipStream_t)stream);
 }
@@ -2379,9 +2381,44 @@ extern "C" int vqhip_route_bwd(const void *x, const void *q, const void *g_out, 
     RouteArgs a;
     a.x = x; a.q = q; a.g = (mode == 0) ? nullptr : g_out; a.out = grad_x; a.N = N; a.D = D; a.ldx = ldx; a.ldq = ldq;
     a.ldg = ldg; a.ldo = ldo; a.loss_coef = loss_coef; a.row_mask = row_mask; a.mode = (mode == 0) ? 1 : mode;
-    a.qidx = nullptr; a.qidx_stride = 0;
+    a.qidx = nullptr; a.qidx_stride = 0; a.sub = 0;
     const int es = dtype == VQHIP_BF16 ? 2 : 4;
     a.vec = rows_vec4(x, ldx, D, es) && rows_vec4(q, ldq, D, es) && rows_vec4(a.g, ldg, D, es) && rows_vec4(grad_x, ldo, D, es);
+    return route_launch(a, dtype, true, (hipStream_t)stream);
+}
+
+// The same two kernels with q GATHERED from a code table by index (codes [C, D] in the rows' dtype, contiguous: the bf16 copy inside
+// the packed codebook for bf16 rows, embed for fp32 rows): a training step whose input requires grad then neither writes nor re-reads
+// an [N, D] q tensor -- the search returns indices only, the forward value and the gradient gather the code rows from L2.
+extern "C" int vqhip_route_fwd_gather(const void *x, const void *codes, const int64_t *idx, int64_t idx_stride, int dtype, int64_t N, int D,
+                                      int64_t ldx, void *out, int64_t ldo, int mode, void *stream)
+{
+    if (!x || !codes || !idx || !out) VQ_FAIL(VQHIP_EINVAL, "route_fwd_gather: null pointer");
+    if (dtype != VQHIP_F32 && dtype != VQHIP_BF16) VQ_FAIL(VQHIP_EINVAL, "route_fwd_gather: unknown dtype");
+    if (N < 0 || D < 1 || D > 512 || idx_stride < 1) VQ_FAIL(VQHIP_EINVAL, "route_fwd_gather: bad size");
+    if (mode != 1 && mode != 2) VQ_FAIL(VQHIP_EINVAL, "route_fwd_gather: mode must be 1 (straight-through) or 2 (rotation trick)");
+    RouteArgs a;
+    a.x = x; a.q = codes; a.g = nullptr; a.out = out; a.N = N; a.D = D; a.ldx = ldx; a.ldq = D; a.ldg = 0; a.ldo = ldo;
+    a.loss_coef = nullptr; a.row_mask = nullptr; a.mode = mode; a.qidx = idx; a.qidx_stride = idx_stride; a.sub = 0;
+    const int es = dtype == VQHIP_BF16 ? 2 : 4;
+    a.vec = rows_vec4(x, ldx, D, es) && rows_vec4(codes, D, D, es) && rows_vec4(out, ldo, D, es);
+    return route_launch(a, dtype, false, (hipStream_t)stream);
+}
+
+extern "C" int vqhip_route_bwd_gather(const void *x, const void *codes, const int64_t *idx, int64_t idx_stride, const void *g_out, int dtype,
+                                      int64_t N, int D, int64_t ldx, int64_t ldg, const float *loss_coef, const uint8_t *row_mask,
+                                      int mode, void *grad_x, int64_t ldo, void *stream)
+{
+    if (!x || !codes || !idx || !grad_x) VQ_FAIL(VQHIP_EINVAL, "route_bwd_gather: null pointer");
+    if (dtype != VQHIP_F32 && dtype != VQHIP_BF16) VQ_FAIL(VQHIP_EINVAL, "route_bwd_gather: unknown dtype");
+    if (N < 0 || D < 1 || D > 512 || idx_stride < 1) VQ_FAIL(VQHIP_EINVAL, "route_bwd_gather: bad size");
+    if (mode < 0 || mode > 2) VQ_FAIL(VQHIP_EINVAL, "route_bwd_gather: mode must be 0, 1 or 2");
+    RouteArgs a;
+    a.x = x; a.q = codes; a.g = (mode == 0) ? nullptr : g_out; a.out = grad_x; a.N = N; a.D = D; a.ldx = ldx; a.ldq = D;
+    a.ldg = ldg; a.ldo = ldo; a.loss_coef = loss_coef; a.row_mask = row_mask; a.mode = (mode == 0) ? 1 : mode;
+    a.qidx = idx; a.qidx_stride = idx_stride; a.sub = 0;
+    const int es = dtype == VQHIP_BF16 ? 2 : 4;
+    a.vec = rows_vec4(x, ldx, D, es) && rows_vec4(codes, D, D, es) && rows_vec4(a.g, ldg, D, es) && rows_vec4(grad_x, ldo, D, es);
     return route_launch(a, dtype, true, (hipStream_t)stream);
 }
 

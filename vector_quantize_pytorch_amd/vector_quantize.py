@@ -49,20 +49,33 @@ class _QuantizeFn(torch.autograd.Function):
         """loss_scale: constant folded into the squared-error reduction (1 / numel for the unmasked commit loss), so that the
         third output IS mean((q - x)^2) without further elementwise kernels"""
         cb = vq._codebook
-        r = cb.quantize(x, mask=mask, want_sqerr=vq.training and vq.has_commitment_loss, loss_scale=float(loss_scale), **kw)
+        mode = 0
+        if vq.training and x.requires_grad and vq.route_gradients_to_input:
+            mode = L.ROTATION if vq.rotation_trick else L.STRAIGHT_THROUGH
+        # Routed output on ONE codebook: `quantized` is a function of x and the winning CODE, so the [N, D] tensor of gathered codes need
+        # not exist -- the search returns indices only and the routing kernels (forward here, backward below) gather the code rows from a
+        # C x D snapshot in the rows' dtype (taken before the search: the EMA fold rewrites `embed` in place).  1 GB less HBM traffic per
+        # cfg-2 step in each direction.
+        gather = (mode != 0 and x.ndim == 3 and cb.num_codebooks == 1 and cb._is_initted() and not cb.affine_param
+                  and x.is_contiguous() and x.dtype in (torch.float32, torch.bfloat16))
+        codes = cb.embed[0].detach().to(x.dtype, copy=True) if gather else None
+        r = cb.quantize(x, mask=mask, want_sqerr=vq.training and vq.has_commitment_loss, loss_scale=float(loss_scale),
+                        **(dict(kw, want_q=False) if gather else kw))
         q, idx = r["q"], r["idx"]
         loss_sum = None
         ctx.loss_scale = float(loss_scale)
         if vq.training and vq.has_commitment_loss:
             loss_sum = r["loss"] if r.get("loss") is not None else L.reduce_partials(r["sqerr_partials"], r["nblk"], float(loss_scale))
         out = q
-        mode = 0
-        if vq.training and x.requires_grad and vq.route_gradients_to_input:
-            mode = L.ROTATION if vq.rotation_trick else L.STRAIGHT_THROUGH
+        if gather:
+            idx = idx.contiguous()
+            out = L.route_fwd_gather(x, codes, idx, mode)
+        elif mode != 0:
             out = L.route_fwd(x, q, mode)
         ctx.mode = mode
+        ctx.gather = gather
         ctx.has_mask = mask is not None
-        ctx.save_for_backward(x, q, *([mask] if mask is not None else []))
+        ctx.save_for_backward(x, *((codes, idx) if gather else (q,)), *([mask] if mask is not None else []))
         ctx.mark_non_differentiable(idx)
         if loss_sum is None:
             loss_sum = torch.zeros((), dtype=torch.float32, device=x.device)
@@ -71,14 +84,17 @@ class _QuantizeFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_out, g_idx, g_loss):
         tensors = ctx.saved_tensors
-        x, q = tensors[0], tensors[1]
-        mask = tensors[2] if ctx.has_mask else None
+        x = tensors[0]
+        mask = tensors[-1] if ctx.has_mask else None
         use_g = ctx.mode != 0 and g_out is not None
         if not use_g and g_loss is None:
             return None, None, None, None, None
         if g_loss is not None and ctx.loss_scale != 1.0:
             g_loss = g_loss * ctx.loss_scale
-        gx = L.route_bwd(x, q, g_out.contiguous() if use_g else None, g_loss, mask, ctx.mode if use_g else 0)
+        if ctx.gather:
+            gx = L.route_bwd_gather(x, tensors[1], tensors[2], g_out.contiguous() if use_g else None, g_loss, mask, ctx.mode if use_g else 0)
+        else:
+            gx = L.route_bwd(x, tensors[1], g_out.contiguous() if use_g else None, g_loss, mask, ctx.mode if use_g else 0)
         return gx, None, None, None, None
 
 
