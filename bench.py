@@ -437,7 +437,8 @@ def vq_cfg2(args, world, rank, dev):
                    "world_size": world, "backend": (dist.get_backend() if world > 1 else None),
                    "loss": float(loss.item())},
         "roofline": {"bound": "mfma",
-                     "kernel": ("vq_screen16_kernel<256> + vq_refine_kernel<256> + vq_pair_kernel<256> + vq_finish_listed_kernel" if screened
+                     "kernel": (("vq_screenc_kernel<256> + vq_compact_lists_kernel" if os.environ.get("VQHIP_SCREEN_PERSIST", "1") != "0" else "vq_screen16_kernel<256>")
+                                + " + vq_refine_kernel<256> + vq_pair_kernel<256> + vq_finish_listed_kernel" if screened
                                 else "vq_assign_kernel<256,bf16,euclid>"),
                      "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                      "traffic": traffic, "traffic_source": traffic_src, "traffic_whole_step": step_traffic,

@@ -26,14 +26,15 @@ def run(cmd, **kw):
 
 def main():
     tag = sys.argv[1]
-    bargs = sys.argv[2:] or ["--steps", "5", "--warmup", "2", "--windows", "1", "--no-grad-step", "--no-cpu-baseline", "--no-adversarial"]
+    bargs = sys.argv[2:] or ["--steps", "5", "--warmup", "2", "--windows", "1", "--no-grad-step", "--no-cpu-baseline", "--no-adversarial",
+                             "--no-other-workloads"]
     out = os.path.join(ROOT, "gpurun_out", tag)
     os.makedirs(out, exist_ok=True)
     bench = [sys.executable, os.path.join(ROOT, "bench.py")] + bargs
     env = dict(os.environ, TMPDIR="/tmp")
 
     wl = ["--workload", bargs[bargs.index("--workload") + 1]] if "--workload" in bargs else []
-    p = run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", *wl], env=env, cwd=ROOT)
+    p = run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--no-other-workloads", *wl], env=env, cwd=ROOT)
     line = [l for l in p.stdout.splitlines() if l.startswith("{")]
     open(os.path.join(out, "bench.json"), "w").write((line[-1] if line else p.stdout[-2000:]) + "\n")
 

@@ -5,6 +5,7 @@ A step starts at a `vq_pack_kernel` launch whose predecessor in time is not a pa
 codebooks first); the LAST complete step of the run is printed."""
 import csv
 import glob
+import json
 import os
 import subprocess
 import sys
@@ -31,7 +32,18 @@ def main():
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r.get("Queue_Id", "?"), r.get("Stream_Id", "?")))
     rows.sort()
     short = lambda n: n.replace("void ", "").split("(")[0][:70]
-    starts = [i for i, r in enumerate(rows) if short(r[2]).startswith("vq_pack_kernel") and (i == 0 or not short(rows[i - 1][2]).startswith("vq_pack"))]
+    # step length from the profiled run's own bench line; a pack kernel that starts more than half a step after the previous pack
+    # kernel opens a step (modules with several codebooks pack all of them at the beginning of their forward)
+    step_ms = None
+    for l in p.stdout.splitlines():
+        if l.startswith("{"):
+            try:
+                step_ms = json.loads(l)["ms_per_step"]
+            except Exception:
+                pass
+    packs = [i for i, r in enumerate(rows) if short(r[2]).startswith("vq_pack_kernel")]
+    thr = 0.5 * (step_ms or 0.5) * 1e6
+    starts = [i for k, i in enumerate(packs) if k == 0 or rows[i][0] - rows[packs[k - 1]][0] > thr]
     lines = []
     if len(starts) >= 3:
         a, b = starts[-3], starts[-2]          # (the very last step may be followed by the audit kernels)
@@ -44,8 +56,16 @@ def main():
             gap = (s - last_end[q]) / 1000 if q in last_end else 0.0
             last_end[q] = e
             busy += e - s
-            lines.append(f"{(s - t0) / 1000:9.1f} {(e - s) / 1000:8.1f} {gap:7.1f}  {q:>3} {short(n)}\n")
-        lines.append(f"sum of kernel durations {busy / 1000:.1f} us\n")
+            if b - a <= 150:
+                lines.append(f"{(s - t0) / 1000:9.1f} {(e - s) / 1000:8.1f} {gap:7.1f}  {q:>3} {short(n)}\n")
+        lines.append(f"sum of kernel durations {busy / 1000:.1f} us\n\nper kernel in this step:\n")
+        per = {}
+        for s_, e_, n, q, st in rows[a:b]:
+            k = short(n)
+            per.setdefault(k, [0, 0])
+            per[k][0] += 1; per[k][1] += e_ - s_
+        for k, (c, t) in sorted(per.items(), key=lambda kv: -kv[1][1]):
+            lines.append(f"{t / 1000:10.1f} us {100.0 * t / busy:5.1f} %  x{c:<4d} {k}\n")
     else:
         lines.append(f"only {len(starts)} step starts found among {len(rows)} launches\n")
     open(os.path.join(out, "timeline.txt"), "w").writelines(lines)

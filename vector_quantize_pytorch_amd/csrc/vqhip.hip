@@ -688,6 +688,48 @@ __global__ void __launch_bounds__(256, (DT <= 256 ? 2 : 1)) vq_assign_kernel(con
         const int64_t wrow0 = (int64_t)blockIdx.x * VQHIP_ASSIGN_ROWS_PER_BLOCK + wave * 32;
         const bool qb = a.q_bf16 != 0;
         double ds = 0.0;
+        if (METRIC == 0 && a.x_vec) {
+            // whole rows per wave instruction (lane l: elements 4 l .. 4 l + 3 of both 256-column halves), four rows in flight
+#pragma unroll 1
+            for (int r0 = 0; r0 < 32; r0 += 4) {
+                float xv[4][8], gv[4][8];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int64_t rr = wrow0 + r0 + u;
+                    const int64_t rc = rr < a.N ? rr : a.N - 1;
+                    const int c = __builtin_amdgcn_readlane(bi, r0 + u);
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const int d = h * 256 + lane * 4;
+                        if (XBF16) {
+                            const uint2 w = *(const uint2 *)((const unsigned short *)a.x + rc * a.ldx + d);
+                            xv[u][4 * h + 0] = __uint_as_float(w.x << 16); xv[u][4 * h + 1] = __uint_as_float(w.x & 0xffff0000u);
+                            xv[u][4 * h + 2] = __uint_as_float(w.y << 16); xv[u][4 * h + 3] = __uint_as_float(w.y & 0xffff0000u);
+                        } else {
+                            const f32x4 w = *(const f32x4 *)((const float *)a.x + rc * a.ldx + d);
+                            xv[u][4 * h + 0] = w.x; xv[u][4 * h + 1] = w.y; xv[u][4 * h + 2] = w.z; xv[u][4 * h + 3] = w.w;
+                        }
+                        if (qb) {
+                            const uint2 w = *(const uint2 *)(a.embed_bf16 + (size_t)c * DT + d);
+                            gv[u][4 * h + 0] = __uint_as_float(w.x << 16); gv[u][4 * h + 1] = __uint_as_float(w.x & 0xffff0000u);
+                            gv[u][4 * h + 2] = __uint_as_float(w.y << 16); gv[u][4 * h + 3] = __uint_as_float(w.y & 0xffff0000u);
+                        } else {
+                            const f32x4 w = *(const f32x4 *)(a.embed + (size_t)c * DT + d);
+                            gv[u][4 * h + 0] = w.x; gv[u][4 * h + 1] = w.y; gv[u][4 * h + 2] = w.z; gv[u][4 * h + 3] = w.w;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int64_t rr = wrow0 + r0 + u;
+                    const bool counted = rr < a.N && (!a.row_mask || a.row_mask[rr] != 0);
+                    float ls = 0.f;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) { const float df = gv[u][k] - xv[u][k]; ls += df * df; }
+                    ds += counted ? (double)ls : 0.0;
+                }
+            }
+        } else
 #pragma unroll 1
         for (int r = 0; r < 32; ++r) {
             const int64_t rr = wrow0 + r;
