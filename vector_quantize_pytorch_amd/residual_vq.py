@@ -585,7 +585,10 @@ def _stats_stream(device, main):
         #  4 KB memset at 124 us wall, the chain at 340 us for ~100 us of work.  A high-priority stream was tried in round 3:
         #  cfg 3 2.996 -> 2.974 ms, cfg 5 15.5 -> 18.9 ms -- the statistics then push the searches of the other groups aside.
         #  Round 4 confined this stream to 16 / 32 / 64 CUs (hipExtStreamCreateWithCUMask through torch.cuda.ExternalStream):
-        #  cfg 3 2.93 -> 4.73 / 4.43 / 4.43 ms, cfg 5 15.5 -> 27.1 ms -- a masked queue loses its concurrency with the search.)
+        #  cfg 3 2.93 -> 4.73 / 4.43 / 4.43 ms, cfg 5 15.5 -> 27.1 ms -- a masked queue loses its concurrency with the search.
+        #  Also round 4: stage q's pass held back until stage q + 1's screening kernel has finished (an event recorded by the
+        #  library between that kernel and its exact passes), so that it runs in the shadow of those short kernels: cfg 3 3.01 ->
+        #  3.03 ms, cfg 5 16.0 -> 16.4 ms -- the pass outlasts that shadow and meets the next screen anyway.)
         _STATS_STREAMS[key] = torch.cuda.Stream(device=device)
     return _STATS_STREAMS[key]
 
