@@ -290,6 +290,12 @@ int vqhip_ema_accumulate_sqerr(const void *x, int x_dtype, int64_t N, int D, int
                                const int64_t *idx, int64_t idx_stride, const uint8_t *row_mask, int C,
                                float *count, float *embed_sum, void *workspace, size_t workspace_bytes,
                                const float *packed, const float *embed, double *sqerr_partial, void *stream);
+/* vqhip_ema_accumulate[_sqerr] for a caller that has zeroed the histogram (the first C ints of `workspace`) itself, e.g. for all stages
+ * of a residual VQ in one launch; packed / embed / sqerr_partial may be null together.  Euclidean. */
+int vqhip_ema_accumulate_prezeroed(const void *x, int x_dtype, int64_t N, int D, int64_t ldx,
+                               const int64_t *idx, int64_t idx_stride, const uint8_t *row_mask, int C,
+                               float *count, float *embed_sum, void *workspace, size_t workspace_bytes,
+                               const float *packed, const float *embed, double *sqerr_partial, void *stream);
 
 /* ---- EMA fold + codebook renormalisation ------------------------------------------------------
  * Replaces ema_inplace x2 (vqp.py:76-97, ATen lerp_ semantics), laplace_smoothing + update_ema

@@ -992,6 +992,21 @@ def test_heads_with_their_own_codebooks_search_in_one_batched_launch(dev, monkey
         b.load_state_dict(a.state_dict())
 
 
+def test_cfg2_full_batch_indices_against_the_reference_op_sequence_are_audited_near_ties(dev):
+    """BASELINE config 2 at FULL size (2^20 bf16 rows, C = 1024, D = 256, the reference's default init): the screened search against
+    the reference's ATen op sequence on the host (oracle mode "aten": bit-identical to the live reference on the build box,
+    tests/test_oracle.py), every row, in 8 chunks -- bench.py's audit as a test.  MKL's blocked dot products and the kernels'
+    ascending fp32 FMA chain round differently, so a few hundred rows whose two best codes are 0..2 ulp apart in the reference's OWN
+    fp32 distances may differ; nothing else may."""
+    import bench
+    _, audit = bench.cpu_baseline_and_audit(torch.get_num_threads(), dev)
+    assert audit["rows_checked_vs_aten"] == 1 << 20
+    assert audit["tie_audit_ulp_histogram"][">2"] == 0 and audit["tie_audit_max_ulps"] <= 2, audit
+    assert audit["mismatches_vs_aten"] <= 1 << 10, audit                    # (0.1 % of the rows; measured: ~180)
+    print(f"\n[cfg-2 full-batch audit] {audit['mismatches_vs_aten']} of 2^20 rows differ, ulp histogram {audit['tie_audit_ulp_histogram']}, "
+          f"closer in float64: {audit['closer_in_float64']}")
+
+
 def test_qinco_implicit_neural_codebook_round_trip(dev):
     """ResidualVQ(implicit_neural_codebook=True) (rvq.py:107-162, 460-499): same parameter names as the reference (goldens rvq_qinco*
     pin values and gradients); here: decode from indices reproduces the forward's output, dropped quantizers decode to zero,

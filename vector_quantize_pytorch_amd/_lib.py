@@ -87,6 +87,8 @@ def lib():
     L.vqhip_ema_sqerr_partials.restype = i64
     L.vqhip_ema_accumulate_sqerr.argtypes = [vp, i32, i64, i32, i64, vp, i64, vp, i32, vp, vp, vp, ctypes.c_size_t, vp, vp, vp, vp]
     L.vqhip_ema_accumulate_sqerr.restype = i32
+    L.vqhip_ema_accumulate_prezeroed.argtypes = [vp, i32, i64, i32, i64, vp, i64, vp, i32, vp, vp, vp, ctypes.c_size_t, vp, vp, vp, vp]
+    L.vqhip_ema_accumulate_prezeroed.restype = i32
     L.vqhip_ema_finalize.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, f32, f32, i32, i32, i32, vp, vp]
     L.vqhip_decode_sum.argtypes = [vp, i64, i32, vp, i64, i32, i32, vp, i32, i64, vp]
     L.vqhip_row_sumsq.argtypes = [vp, i32, i64, i32, i64, vp, vp]
@@ -137,7 +139,7 @@ EXPORTS = ("vqhip_version", "vqhip_last_error", "vqhip_packed_bytes", "vqhip_pac
            "vqhip_ema_finalize", "vqhip_decode_sum", "vqhip_row_sumsq", "vqhip_assign_rowwise", "vqhip_score_indices", "vqhip_topk", "vqhip_expire_scatter", "vqhip_kmeans_update", "vqhip_route_fwd", "vqhip_route_bwd", "vqhip_rvq_route", "vqhip_ema_renormalize_shard", "vqhip_scores_lse",
            "vqhip_pack_best", "vqhip_unpack_best", "vqhip_vq_step_supported", "vqhip_vq_step_workspace_bytes", "vqhip_vq_train_step", "vqhip_route_residual",
            "vqhip_pack_codebook_batched", "vqhip_screen_batched_ws_stride", "vqhip_assign_screened_batched", "vqhip_assign_batched",
-           "vqhip_route_fwd_gather", "vqhip_route_bwd_gather")
+           "vqhip_route_fwd_gather", "vqhip_route_bwd_gather", "vqhip_ema_accumulate_prezeroed")
 
 
 def _check(rc, what):
@@ -725,7 +727,7 @@ def stats_sqerr_supported(x: torch.Tensor, cosine=False) -> bool:
 
 @_on_device
 def ema_accumulate(x: torch.Tensor, idx: torch.Tensor, C: int, *, cosine=False, rnorm=None, row_mask=None,
-                   count=None, embed_sum=None, idx_stride=1, idx_offset=0, sqerr_from=None, sqerr_out=None):
+                   count=None, embed_sum=None, idx_stride=1, idx_offset=0, sqerr_from=None, sqerr_out=None, ws=None):
     """Accumulates into (count [C], embed_sum [C, D]); allocates zeroed ones if not given.
     sqerr_from = (packed, embed): also returns the squared-error partials of the commitment loss, summed by the same pass
     (-> count, embed_sum, partials [P] float64); requires stats_sqerr_supported(x)."""
@@ -741,8 +743,23 @@ def ema_accumulate(x: torch.Tensor, idx: torch.Tensor, C: int, *, cosine=False, 
         row_mask = row_mask.reshape(-1).to(torch.uint8).contiguous()
     if N > 0:
         nbytes = lib().vqhip_ema_workspace_bytes(N, C)
-        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)     # caching allocator: 512-byte aligned
         idx_ptr = ctypes.c_void_p(idx.data_ptr() + 8 * idx_offset)     # e.g. column q of an [N, Q] index tensor
+        if ws is not None:
+            # a workspace of the caller's whose histogram (the first C ints) it has zeroed already, e.g. for all stages of a residual
+            # VQ at once (ema_workspaces): no memset launch queued on the statistics stream
+            assert not cosine and ws.dtype == torch.uint8 and ws.is_contiguous() and ws.numel() >= nbytes and ws.data_ptr() % 256 == 0
+            partials = None
+            pk = em = None
+            if sqerr_from is not None:
+                pk, em = sqerr_from
+                npart = lib().vqhip_ema_sqerr_partials(N, C)
+                partials = sqerr_out if sqerr_out is not None else torch.empty(npart, dtype=torch.float64, device=dev)
+                assert partials.dtype == torch.float64 and partials.is_contiguous() and partials.numel() == npart
+            _check(lib().vqhip_ema_accumulate_prezeroed(_ptr(xk), _dtype_code(xk), N, D, ldx, idx_ptr, idx_stride, _ptr(row_mask), C,
+                                                        _ptr(count), _ptr(embed_sum), _ptr(ws), ws.numel(), _ptr(pk), _ptr(em),
+                                                        _ptr(partials), _stream()), "vqhip_ema_accumulate_prezeroed")
+            return (count, embed_sum, partials) if sqerr_from is not None else (count, embed_sum)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)     # caching allocator: 512-byte aligned
         if sqerr_from is not None:
             packed, embed = sqerr_from
             assert not cosine and embed.dtype == torch.float32 and embed.is_contiguous() and tuple(embed.shape) == (C, D)
@@ -822,6 +839,14 @@ def vq_train_step(x: torch.Tensor, embed, embed_avg, cluster_size, *, decay, eps
     hdr = ws[:16].view(torch.int32)       # [0] rows of the exact sweep, [1] rows decided between two candidates (device-side counters)
     return dict(q=None if q is None else q.reshape(x.shape), idx=idx.reshape(x.shape[:-1]), stats=stats,
                 embed_sum=stats[: C * D].view(C, D), count=stats[C * D:], loss=loss, n_exact=hdr[:1], n_pair=hdr[1:2])
+
+
+def ema_workspaces(Q: int, N: int, C: int, device) -> torch.Tensor:
+    """[Q, bytes] statistics workspaces with their histograms zeroed in ONE launch (ema_accumulate(ws=...))"""
+    nbytes = (lib().vqhip_ema_workspace_bytes(N, C) + 255) // 256 * 256
+    ws = torch.empty(Q, nbytes, dtype=torch.uint8, device=device)
+    ws[:, : C * 4].zero_()
+    return ws
 
 
 @_on_device

@@ -83,6 +83,15 @@ def sample_rows_distributed(samples: Tensor, num: int) -> Tensor:
     return out[None]
 
 
+def fused_stats_allreduce(embed_sum: torch.Tensor, count: torch.Tensor, group=None):
+    """embed_sum [C, D] and count [C] must be views of ONE contiguous buffer (Codebook.quantize allocates
+    them that way); a single SUM all-reduce instead of the reference's two (vqp.py:603, 607)."""
+    base = embed_sum.untyped_storage().data_ptr()
+    assert count.untyped_storage().data_ptr() == base, "embed_sum and count must share one buffer"
+    flat = torch.as_strided(embed_sum, (embed_sum.numel() + count.numel(),), (1,), embed_sum.storage_offset())
+    dist.all_reduce(flat, group=group)
+
+
 class Codebook(nn.Module):
     def __init__(
         self,
@@ -459,7 +468,7 @@ class Codebook(nn.Module):
                     L.ema_accumulate(xst, r["idx"].reshape(-1), C, cosine=self.use_cosine_sim and not prenorm,
                                      rnorm=r["rnorm"], row_mask=rmask, count=count, embed_sum=esum)
                 if self.use_ddp:
-                    dist.all_reduce(buf)          # ONE collective for count || embed_sum (RCCL over xGMI)
+                    fused_stats_allreduce(esum, count)   # ONE collective for count || embed_sum (RCCL over xGMI)
                 self._fold_stats(h, count, esum, ema_update_weight, accum_ema_update, ema_update)
             outs.append(r)
         if do_update and not accum_ema_update:
@@ -492,7 +501,7 @@ class Codebook(nn.Module):
             esum, count = buf[: C * self.dim].view(C, self.dim), buf[C * self.dim:]
             L.ema_accumulate(xs[h], ind[h], C, row_mask=rmask, count=count, embed_sum=esum)
             if self.use_ddp:
-                dist.all_reduce(buf)              # ONE collective for count || embed_sum
+                fused_stats_allreduce(esum, count)    # ONE collective for count || embed_sum
             self._fold_stats(h, count, esum, ema_update_weight, accum_ema_update, ema_update)
         if not accum_ema_update:
             self.expire_codes_(xs.reshape(H, -1, self.dim), seq_mask=None if rmask is None else rmask[None].expand(H, -1).bool())

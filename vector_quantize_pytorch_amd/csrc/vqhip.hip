@@ -3197,6 +3197,24 @@ extern "C" int vqhip_ema_accumulate_sqerr(const void *x, int x_dtype, int64_t N,
                                workspace_bytes, qsrc, sqerr_partial, stream);
 }
 
+// The same pass for a caller that has zeroed the histogram -- the first C ints of `workspace` -- itself: a residual VQ zeroes the
+// workspaces of all its stages in one launch before the loop, instead of one memset per stage queued on the statistics stream
+// behind a chip-filling search.  packed / embed / sqerr_partial may be null together (statistics only).
+extern "C" int vqhip_ema_accumulate_prezeroed(const void *x, int x_dtype, int64_t N, int D, int64_t ldx,
+                                              const int64_t *idx, int64_t idx_stride, const uint8_t *row_mask, int C,
+                                              float *count, float *embed_sum, void *workspace, size_t workspace_bytes,
+                                              const float *packed, const float *embed, double *sqerr_partial, void *stream)
+{
+    if (D < 1 || D > 512 || C <= 0) VQ_FAIL(VQHIP_EINVAL, "ema_accumulate_prezeroed: bad size");
+    if (sqerr_partial && (!packed || !embed)) VQ_FAIL(VQHIP_EINVAL, "ema_accumulate_prezeroed: the loss needs packed and embed");
+    const void *qsrc = !sqerr_partial ? nullptr
+                     : (x_dtype == VQHIP_BF16) ? (const void *)((const char *)packed + vq_packed_bf16_offset(C, D)) : (const void *)embed;
+    StatsFuse f;
+    f.hist_zeroed = 1; f.cs = nullptr; f.denom = nullptr; f.omd = 0.f; f.eps = 0.f;
+    return ema_accumulate_impl(x, x_dtype, N, D, ldx, idx, idx_stride, nullptr, VQHIP_EUCLID, row_mask, C, count, embed_sum, workspace,
+                               workspace_bytes, qsrc, sqerr_partial, stream, &f);
+}
+
 // ------------------------------------------------------------------------------------------------
 // EMA fold + codebook renormalisation
 // ------------------------------------------------------------------------------------------------

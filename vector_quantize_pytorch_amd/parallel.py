@@ -13,6 +13,8 @@ from __future__ import annotations
 import torch
 import torch.distributed as dist
 
+from .codebook import fused_stats_allreduce   # noqa: F401 (re-exported: the data-parallel helper lives beside Codebook)
+
 _LOW = 0xFFFFFFFF
 
 
@@ -67,15 +69,6 @@ def shard_bounds(C: int, world: int, rank: int):
     per = (C + world - 1) // world
     lo = min(rank * per, C)
     return lo, min(lo + per, C)
-
-
-def fused_stats_allreduce(embed_sum: torch.Tensor, count: torch.Tensor, group=None):
-    """embed_sum [C, D] and count [C] must be views of ONE contiguous buffer (Codebook.quantize allocates
-    them that way); a single SUM all-reduce instead of the reference's two (vqp.py:603, 607)."""
-    base = embed_sum.untyped_storage().data_ptr()
-    assert count.untyped_storage().data_ptr() == base, "embed_sum and count must share one buffer"
-    flat = torch.as_strided(embed_sum, (embed_sum.numel() + count.numel(),), (1,), embed_sum.storage_offset())
-    dist.all_reduce(flat, group=group)
 
 
 # ------------------------------------------------------------------------------------------------------

@@ -335,8 +335,14 @@ class ResidualVQ(nn.Module):
             nrows = x.numel() // D
             sq_parts = torch.empty(Q, L.lib().vqhip_ema_sqerr_partials(nrows, C), dtype=torch.float64, device=x.device)
 
+        # the statistics workspaces of all stages, their histograms zeroed in one launch (a memset per stage queued on the statistics
+        # stream showed up as 14 % of the summed kernel time of a cfg-3 profile: it waits there for a workgroup slot)
+        stats_ws = L.ema_workspaces(Q, x.numel() // D, C, x.device) if (update and x.is_cuda and x.numel() > 0) else None
+
         def accumulate(q, stage_input, idx_all):
             kw = dict(row_mask=mask, count=buf[q, C * D: C * D + C], embed_sum=buf[q, : C * D].view(C, D), idx_offset=q, idx_stride=Q)
+            if stats_ws is not None and not vq0._codebook.use_cosine_sim:
+                kw["ws"] = stats_ws[q]
             if chain and want_loss:
                 e_q = embed if self.shared_codebook else embed[q]
                 L.ema_accumulate(stage_input, idx_all, C, sqerr_from=(packed if self.shared_codebook else packed[q], e_q),
