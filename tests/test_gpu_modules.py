@@ -357,7 +357,7 @@ def test_route_kernels_match_autograd_of_the_reference_formula(dev, mode, dtype)
     _close(gx.float(), xr.grad, tol, "grad_x")
 
 
-def _sharded_worker(rank, world, port, out_path, cosine, exchange="auto", backend="gloo"):
+def _sharded_worker(rank, world, port, out_path, cosine, exchange="auto", backend="gloo", C=200):
     import os
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
@@ -370,7 +370,7 @@ def _sharded_worker(rank, world, port, out_path, cosine, exchange="auto", backen
         dev = torch.device("cuda:0")
     from vector_quantize_pytorch_amd.parallel import ShardedVectorQuantize
     torch.manual_seed(0)
-    vq = ShardedVectorQuantize(64, 200, use_cosine_sim=cosine, exchange=exchange).to(dev).train()
+    vq = ShardedVectorQuantize(64, C, use_cosine_sim=cosine, exchange=exchange).to(dev).train()
     g = torch.Generator().manual_seed(100 + rank)
     x = torch.randn(2, 300, 64, generator=g).to(dev)
     q, idx, loss = vq(x)
@@ -405,6 +405,30 @@ def test_sharded_codebook_equals_unsharded(dev, tmp_path, cosine, exchange, back
     full = torch.cat([r[0]["embed"], r[1]["embed"]], 1)
     _close(full, vq._codebook.embed, 1e-5, "embed after the EMA step")
     assert torch.equal(r[0]["full_embed"], full) and torch.equal(r[1]["full_embed"], full)     # full_codebook_state(): the gathered shards
+
+
+def test_sharded_codebook_with_unequal_shards(dev, tmp_path):
+    """codebook_size not a multiple of the world size (201 codes over 2 ranks: 101 + 100): same indices and outputs as one module with
+    the whole codebook, and full_codebook_state() pads the shards for its all-gather and trims them again."""
+    import socket
+    import torch.multiprocessing as mp
+    from vector_quantize_pytorch_amd import VectorQuantize
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    out = str(tmp_path / "shu")
+    mp.spawn(_sharded_worker, args=(2, port, out, False, "rows", "gloo", 201), nprocs=2, join=True)
+    r = [torch.load(f"{out}.{k}") for k in range(2)]
+    assert (r[0]["hi"] - r[0]["lo"], r[1]["hi"] - r[1]["lo"]) == (101, 100)
+    torch.manual_seed(0)
+    vq = VectorQuantize(dim=64, codebook_size=201).to(dev).train()
+    x = torch.cat([torch.randn(2, 300, 64, generator=torch.Generator().manual_seed(100 + k)) for k in range(2)], 0).to(dev)
+    q, idx, loss = vq(x)
+    for k in range(2):
+        assert torch.equal(r[k]["idx"], idx[2 * k:2 * k + 2].cpu())
+        _close(r[k]["q"], q[2 * k:2 * k + 2], 1e-6, "quantized")
+    full = torch.cat([r[0]["embed"], r[1]["embed"]], 1)
+    assert full.shape[1] == 201
+    _close(full, vq._codebook.embed, 1e-5, "embed after the EMA step")
+    assert torch.equal(r[0]["full_embed"], full) and torch.equal(r[1]["full_embed"], full)
 
 
 @pytest.mark.parametrize("exchange", ["codebook", "rows"])

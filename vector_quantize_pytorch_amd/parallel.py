@@ -133,17 +133,21 @@ class ShardedVectorQuantize(torch.nn.Module):
 
     @torch.no_grad()
     def full_codebook_state(self):
-        """{embed, embed_avg, cluster_size} of the WHOLE codebook, all-gathered from the shards (equal shard sizes): what a checkpoint
-        that other world sizes -- or the reference -- can load should contain (state_dict() holds this rank's shard only)."""
+        """{embed, embed_avg, cluster_size} of the WHOLE codebook, all-gathered from the shards: what a checkpoint that other world
+        sizes -- or the reference -- can load should contain (state_dict() holds this rank's shard only).  Shards of unequal size
+        (codebook_size not a multiple of the world size: the last rank owns fewer codes) are padded for the collective and trimmed."""
         cb = self._codebook
         out = {}
+        sizes = [b - a for a, b in (shard_bounds(self.codebook_size, self.world, r) for r in range(self.world))]
         for k in ("embed", "embed_avg", "cluster_size"):
             t = getattr(cb, k).detach()
             if self._collectives_on():
-                assert (self.hi - self.lo) * self.world == self.codebook_size, "all-gather needs equal shard sizes"
+                width = max(sizes)
+                if t.shape[1] < width:                       # [1, C_local, ...] -> padded to the widest shard
+                    t = torch.cat((t, t.new_zeros(t.shape[0], width - t.shape[1], *t.shape[2:])), dim=1)
                 parts = [torch.empty_like(t) for _ in range(self.world)]
                 dist.all_gather(parts, t.contiguous(), group=self.group)
-                t = torch.cat(parts, dim=1)
+                t = torch.cat([p_[:, :n] for p_, n in zip(parts, sizes)], dim=1)
             out[k] = t.clone()
         return out
 

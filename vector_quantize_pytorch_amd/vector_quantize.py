@@ -616,6 +616,11 @@ class VectorQuantize(nn.Module):
         every rank keeps the rows [lo, hi) it owns.  (A shard-sized checkpoint loads as is.)"""
         if self._sharded is not None:
             sh = self._sharded
+            for k in ("initted", "embed", "embed_avg", "cluster_size"):
+                # (checkpoints written while the shard was registered under `_sharded` as well carry both key sets: keep one)
+                legacy = state_dict.pop(f"{prefix}_sharded._codebook.{k}", None)
+                if legacy is not None and f"{prefix}_codebook.{k}" not in state_dict:
+                    state_dict[f"{prefix}_codebook.{k}"] = legacy
             for k in ("embed", "embed_avg", "cluster_size"):
                 key = f"{prefix}_codebook.{k}"
                 t = state_dict.get(key)
