@@ -15,6 +15,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def main():
     tag = sys.argv[1]
+    packs_per_step = None
+    if "--packs" in sys.argv:                  # pack launches per step (codebooks of the module): steps are then cut by COUNT from the end
+        i = sys.argv.index("--packs")
+        packs_per_step = int(sys.argv[i + 1])
+        del sys.argv[i:i + 2]
     bargs = sys.argv[2:] or ["--steps", "4", "--warmup", "2", "--windows", "1", "--no-grad-step", "--no-cpu-baseline", "--no-adversarial",
                              "--no-other-workloads"]
     out = os.path.join(ROOT, "gpurun_out", tag)
@@ -44,6 +49,8 @@ def main():
     packs = [i for i, r in enumerate(rows) if short(r[2]).startswith("vq_pack_kernel")]
     thr = 0.5 * (step_ms or 0.5) * 1e6
     starts = [i for k, i in enumerate(packs) if k == 0 or rows[i][0] - rows[packs[k - 1]][0] > thr]
+    if packs_per_step:                         # (several streams: the packs of a step interleave with the previous step's tail)
+        starts = [packs[k] for k in range(len(packs) % packs_per_step, len(packs), packs_per_step)]
     lines = []
     if len(starts) >= 3:
         a, b = starts[-3], starts[-2]          # (the very last step may be followed by the audit kernels)
