@@ -235,6 +235,22 @@ int vqhip_reduce_partials(const double *partials, int64_t n, double scale, float
 /* R rows of partials in one launch (the per-stage losses of a residual VQ): out[r] = scale * sum(partials[r * stride .. + n)). */
 int vqhip_reduce_partials_rows(const double *partials, int R, int64_t n, int64_t stride, double scale, float *out, void *stream);
 
+/* Statistics and folds of H heads in one set of launches (grid dimension y = head), for multi-head modules with separate codebooks
+ * (vqp.py:1044-1049: the reference's einsums carry the head axis).  x [H, N, D] at x_hstride elements between heads, idx [H, N], stats
+ * [H, stats_stride] floats = embed_sum [C, D] || count [C] per head -- ACCUMULATED INTO, zero it first; it is the buffer a data-parallel
+ * caller all-reduces, once for all heads.  workspace: H x vqhip_ema_batched_ws_stride(N, C) bytes.  packed (vqhip_pack_codebook_batched)
+ * / embed [H, C, D] / sqerr_partial [H, vqhip_ema_sqerr_partials(N, C)] may be null together (no loss).  Euclidean, or cosine on
+ * unit-norm rows.  vqhip_ema_finalize_batched: vqhip_ema_finalize for the H codebooks as the module stores them (cluster_size [H, C],
+ * embed_avg / embed [H, C, D]), denom_ws [H, C]. */
+size_t vqhip_ema_batched_ws_stride(int64_t N, int C);
+int vqhip_ema_accumulate_batched(const void *x, int x_dtype, int H, int64_t N, int D, int64_t ldx, int64_t x_hstride,
+                                 const int64_t *idx, const uint8_t *row_mask, int C, float *stats, int64_t stats_stride,
+                                 void *workspace, size_t workspace_bytes, const float *packed, const float *embed,
+                                 double *sqerr_partial, void *stream);
+int vqhip_ema_finalize_batched(float *cluster_size, float *embed_avg, float *embed, const float *stats, int64_t stats_stride,
+                               int H, int C, int D, float one_minus_decay, float eps, int cosine, int do_update_ema,
+                               float *denom_ws, void *stream);
+
 /* ---- fused train step ---------------------------------------------------------------------------
  * One call = one training forward of a Euclidean EMA codebook (VectorQuantize.forward in training mode, vqp.py:1176 ->
  * EuclideanCodebook.forward :673-800): pack the codebook, nearest-code search (screened, bit-identical indices), gather q,

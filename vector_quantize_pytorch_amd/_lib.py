@@ -118,6 +118,12 @@ def lib():
     L.vqhip_route_fwd_gather.restype = i32
     L.vqhip_route_bwd_gather.argtypes = [vp, vp, vp, i64, vp, i32, i64, i32, i64, i64, vp, vp, i32, vp, i64, vp]
     L.vqhip_route_bwd_gather.restype = i32
+    L.vqhip_ema_batched_ws_stride.argtypes = [i64, i32]
+    L.vqhip_ema_batched_ws_stride.restype = ctypes.c_size_t
+    L.vqhip_ema_accumulate_batched.argtypes = [vp, i32, i32, i64, i32, i64, i64, vp, vp, i32, vp, i64, vp, ctypes.c_size_t, vp, vp, vp, vp]
+    L.vqhip_ema_accumulate_batched.restype = i32
+    L.vqhip_ema_finalize_batched.argtypes = [vp, vp, vp, vp, i64, i32, i32, i32, f32, f32, i32, i32, vp, vp]
+    L.vqhip_ema_finalize_batched.restype = i32
     L.vqhip_route_residual.argtypes = [vp, i64, i32, i64, vp, vp, i64, i32, vp, i64, vp]
     L.vqhip_route_residual.restype = i32
     L.vqhip_vq_step_supported.argtypes = [i32, i64, i32, i32]
@@ -139,7 +145,8 @@ EXPORTS = ("vqhip_version", "vqhip_last_error", "vqhip_packed_bytes", "vqhip_pac
            "vqhip_ema_finalize", "vqhip_decode_sum", "vqhip_row_sumsq", "vqhip_assign_rowwise", "vqhip_score_indices", "vqhip_topk", "vqhip_expire_scatter", "vqhip_kmeans_update", "vqhip_route_fwd", "vqhip_route_bwd", "vqhip_rvq_route", "vqhip_ema_renormalize_shard", "vqhip_scores_lse",
            "vqhip_pack_best", "vqhip_unpack_best", "vqhip_vq_step_supported", "vqhip_vq_step_workspace_bytes", "vqhip_vq_train_step", "vqhip_route_residual",
            "vqhip_pack_codebook_batched", "vqhip_screen_batched_ws_stride", "vqhip_assign_screened_batched", "vqhip_assign_batched",
-           "vqhip_route_fwd_gather", "vqhip_route_bwd_gather", "vqhip_ema_accumulate_prezeroed")
+           "vqhip_route_fwd_gather", "vqhip_route_bwd_gather", "vqhip_ema_accumulate_prezeroed",
+           "vqhip_ema_batched_ws_stride", "vqhip_ema_accumulate_batched", "vqhip_ema_finalize_batched")
 
 
 def _check(rc, what):
@@ -839,6 +846,46 @@ def vq_train_step(x: torch.Tensor, embed, embed_avg, cluster_size, *, decay, eps
     hdr = ws[:16].view(torch.int32)       # [0] rows of the exact sweep, [1] rows decided between two candidates (device-side counters)
     return dict(q=None if q is None else q.reshape(x.shape), idx=idx.reshape(x.shape[:-1]), stats=stats,
                 embed_sum=stats[: C * D].view(C, D), count=stats[C * D:], loss=loss, n_exact=hdr[:1], n_pair=hdr[1:2])
+
+
+@_on_device
+def ema_accumulate_batched(xs: torch.Tensor, idx: torch.Tensor, C: int, stats: torch.Tensor, *, row_mask=None, sqerr_from=None):
+    """The statistics of H heads in one set of launches: xs [H, ..., D] (uniform strides, as for assign_batched), idx [H, ...], stats
+    [H, stride >= C D + C] float32, ZEROED by the caller (embed_sum || count per head: one buffer, one all-reduce under data
+    parallelism).  sqerr_from = (packed [H, P], embed [H, C, D]): also the squared-error partials of the commitment loss [H, P']."""
+    _need_gpu(xs, idx, stats, row_mask)
+    H = xs.shape[0]
+    xk, N, D, ldx = as_rows(xs[0])
+    assert idx.dtype == torch.int64 and idx.is_contiguous() and idx.numel() == H * N
+    assert stats.dtype == torch.float32 and stats.ndim == 2 and stats.shape[0] == H and stats.stride(1) == 1 and stats.shape[1] >= C * D + C
+    dev = xs.device
+    if row_mask is not None:
+        row_mask = row_mask.reshape(-1).to(torch.uint8).contiguous()
+    wss = lib().vqhip_ema_batched_ws_stride(N, C)
+    ws = torch.empty(H * wss, dtype=torch.uint8, device=dev)
+    pk = em = parts = None
+    if sqerr_from is not None:
+        pk, em = sqerr_from
+        assert em.dtype == torch.float32 and em.is_contiguous() and tuple(em.shape) == (H, C, D) and pk.is_contiguous()
+        parts = torch.empty(H, lib().vqhip_ema_sqerr_partials(N, C), dtype=torch.float64, device=dev)
+    _check(lib().vqhip_ema_accumulate_batched(_ptr(xk), _dtype_code(xk), H, N, D, ldx, xs.stride(0), _ptr(idx), _ptr(row_mask), C,
+                                              _ptr(stats), stats.stride(0), _ptr(ws), H * wss, _ptr(pk), _ptr(em), _ptr(parts), _stream()),
+           "vqhip_ema_accumulate_batched")
+    return parts
+
+
+@_on_device
+def ema_finalize_batched(cluster_size, embed_avg, embed, stats, *, decay, eps, cosine=False, do_update_ema=True):
+    """ema_finalize for the H codebooks of a multi-head module in three launches: cluster_size [H, C], embed_avg / embed [H, C, D] (the
+    module buffers, in place), stats [H, stride] as filled by ema_accumulate_batched."""
+    _need_gpu(cluster_size, embed_avg, embed, stats)
+    H, C, D = embed.shape
+    for t in (cluster_size, embed_avg, embed):
+        assert t.is_contiguous() and t.dtype == torch.float32
+    denom = torch.empty(H, C, dtype=torch.float32, device=embed.device) if do_update_ema else None
+    omd = float(torch.tensor(1.0 - decay, dtype=torch.float64).to(torch.float32))
+    _check(lib().vqhip_ema_finalize_batched(_ptr(cluster_size), _ptr(embed_avg), _ptr(embed), _ptr(stats), stats.stride(0), H, C, D, omd,
+                                            float(eps), int(cosine), int(do_update_ema), _ptr(denom), _stream()), "vqhip_ema_finalize_batched")
 
 
 def ema_workspaces(Q: int, N: int, C: int, device) -> torch.Tensor:

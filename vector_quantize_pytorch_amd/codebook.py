@@ -437,6 +437,20 @@ class Codebook(nn.Module):
                 if xs_b is not xs:
                     xs = x_stats = xs_b
                     input_normalized = True
+        if (rb is not None and do_update and rb["rnorm"] is None and x_stats is xs and embed_override is None and ema_update_weight is None
+                and not accum_ema_update and self.cluster_size.grad is None and self.embed_avg.grad is None):
+            # ... and the H statistics passes and folds as well (vqhip_ema_accumulate_batched / vqhip_ema_finalize_batched): one
+            # [H, C D + C] buffer, ONE all-reduce for all heads under data parallelism (the reference: two per head)
+            stats = torch.zeros(H, (C * self.dim + C + 3) // 4 * 4, dtype=torch.float32, device=x.device)
+            parts = L.ema_accumulate_batched(xs, rb["idx"].reshape(H, -1), C, stats, row_mask=rmask,
+                                             sqerr_from=(packed_all, E_all) if stats_sums_loss else None)
+            if self.use_ddp:
+                dist.all_reduce(stats)
+            L.ema_finalize_batched(self.cluster_size, self.embed_avg, self.embed.data, stats, decay=self.decay, eps=self.eps,
+                                   cosine=self.use_cosine_sim, do_update_ema=bool(ema_update and not self.manual_ema_update))
+            self.expire_codes_(xs_raw.reshape(H, -1, self.dim), seq_mask=None if rmask is None else rmask[None].expand(H, -1).bool())
+            return dict(q=rb["q"], idx=rb["idx"], sqerr_partials=None if parts is None else parts.reshape(-1),
+                        nblk=0 if parts is None else parts.numel(), rnorm=None)
         for h in range(H):
             # embed_override: the codebook actually searched when it is a function of the stored one (vq_bridge)
             e = E_all[h].contiguous()

@@ -2734,7 +2734,26 @@ struct SortArgs {
     float *cs;     // [C] cluster_size, in place
     float *denom;  // [C] out
     float omd, eps, ceps;
+    // several heads in one launch (vqhip_ema_accumulate_batched: blockIdx.y = head): byte strides between consecutive heads' index
+    // rows, workspaces (hist / cursor / seg_off / chunk_off / perm share one) and count vectors
+    int heads;
+    int64_t hs_idx, hs_ws, hs_count;
 };
+
+__device__ __forceinline__ SortArgs sort_head_args(const SortArgs &a0)
+{
+    if (a0.heads <= 1) return a0;
+    SortArgs a = a0;
+    const int64_t h = blockIdx.y;
+    a.idx = (const int64_t *)((const char *)a0.idx + h * a0.hs_idx);
+    a.hist = (int *)((char *)a0.hist + h * a0.hs_ws);
+    a.cursor = (int *)((char *)a0.cursor + h * a0.hs_ws);
+    a.seg_off = (int *)((char *)a0.seg_off + h * a0.hs_ws);
+    a.chunk_off = (int *)((char *)a0.chunk_off + h * a0.hs_ws);
+    a.perm = (int *)((char *)a0.perm + h * a0.hs_ws);
+    a.count = (float *)((char *)a0.count + h * a0.hs_count);
+    return a;
+}
 
 __device__ __forceinline__ int sort_code(const SortArgs &a, int64_t row)
 {
@@ -2743,8 +2762,9 @@ __device__ __forceinline__ int sort_code(const SortArgs &a, int64_t row)
     return ok ? (int)ci : -1;
 }
 
-__global__ void __launch_bounds__(256) vq_hist_kernel(const SortArgs a)
+__global__ void __launch_bounds__(256) vq_hist_kernel(const SortArgs a0)
 {
+    const SortArgs a = sort_head_args(a0);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int *lh = (int *)smem;
     const bool use_lds = !a.direct;
@@ -2770,8 +2790,9 @@ __global__ void __launch_bounds__(256) vq_hist_kernel(const SortArgs a)
     }
 }
 
-__global__ void __launch_bounds__(1024) vq_scan_kernel(const SortArgs a)
+__global__ void __launch_bounds__(1024) vq_scan_kernel(const SortArgs a0)
 {
+    const SortArgs a = sort_head_args(a0);
     __shared__ int s_cnt[1024];
     __shared__ int s_chk[1024];
     __shared__ float s_part[32];
@@ -2822,8 +2843,9 @@ __global__ void __launch_bounds__(1024) vq_scan_kernel(const SortArgs a)
     }
 }
 
-__global__ void __launch_bounds__(256) vq_scatter_kernel(const SortArgs a)
+__global__ void __launch_bounds__(256) vq_scatter_kernel(const SortArgs a0)
 {
+    const SortArgs a = sort_head_args(a0);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int *lc = (int *)smem;
     const bool use_lds = !a.direct;
@@ -2874,12 +2896,31 @@ struct SegArgs {
     const void *qsrc;          // nullable: codebook rows in x's dtype, [C, D] -- the q of the commitment loss
     double *sqerr_partial;     // nullable: one entry per work item (n_partial of them)
     int64_t n_partial;
+    // several heads in one launch (blockIdx.y = head): byte strides of the rows, the workspace, embed_sum, the loss' code rows, the partials
+    int heads;
+    int64_t hs_x, hs_ws, hs_sum, hs_qsrc, hs_sq;
 };
+
+__device__ __forceinline__ SegArgs seg_head_args(const SegArgs &a0)
+{
+    if (a0.heads <= 1) return a0;
+    SegArgs a = a0;
+    const int64_t h = blockIdx.y;
+    a.x = (const char *)a0.x + h * a0.hs_x;
+    a.seg_off = (const int *)((const char *)a0.seg_off + h * a0.hs_ws);
+    a.chunk_off = (const int *)((const char *)a0.chunk_off + h * a0.hs_ws);
+    a.perm = (const int *)((const char *)a0.perm + h * a0.hs_ws);
+    a.embed_sum = (float *)((char *)a0.embed_sum + h * a0.hs_sum);
+    if (a0.qsrc) a.qsrc = (const char *)a0.qsrc + h * a0.hs_qsrc;
+    if (a0.sqerr_partial) a.sqerr_partial = (double *)((char *)a0.sqerr_partial + h * a0.hs_sq);
+    return a;
+}
 
 // EPL = elements per lane (vector path: D == 64 * EPL * nvec ... handled by the h loop)
 template <bool XBF16, bool VEC>
-__global__ void __launch_bounds__(256) vq_segsum_kernel(const SegArgs a)
+__global__ void __launch_bounds__(256) vq_segsum_kernel(const SegArgs a0)
 {
+    const SegArgs a = seg_head_args(a0);
     const int lane = threadIdx.x & 63;
     const int w = blockIdx.x * 4 + (threadIdx.x >> 6);   // work item = (code, chunk)
     const int total = a.chunk_off[a.C];
@@ -2968,8 +3009,9 @@ __global__ void __launch_bounds__(256) vq_segsum_kernel(const SegArgs a)
 // double per batch of rows in flight (relative error of the total ~1e-8; the loss is held to 1e-5) -- so the search does not have to
 // re-read x for it.
 template <bool XBF16, bool SQ>
-__global__ void __launch_bounds__(256) vq_segsum_fast_kernel(const SegArgs a)
+__global__ void __launch_bounds__(256) vq_segsum_fast_kernel(const SegArgs a0)
 {
+    const SegArgs a = seg_head_args(a0);
     const int lane = threadIdx.x & 63;
     const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int total = a.chunk_off[a.C];
@@ -3088,6 +3130,10 @@ struct StatsFuse {
     int hist_zeroed;
     float *cs, *denom;
     float omd, eps;
+    // several heads (vqhip_ema_accumulate_batched): byte strides; count / embed_sum / workspace / qsrc / sqerr_partial of head h sit h
+    // strides behind head 0's
+    int heads = 1;
+    int64_t hs_x = 0, hs_idx = 0, hs_ws = 0, hs_stats = 0, hs_qsrc = 0, hs_sq = 0;
 };
 
 static int ema_accumulate_impl(const void *x, int x_dtype, int64_t N, int D, int64_t ldx,
@@ -3129,8 +3175,12 @@ static int ema_accumulate_impl(const void *x, int x_dtype, int64_t N, int D, int
     s.eps = fuse ? fuse->eps : 0.f;
     s.ceps = fuse ? (float)((double)C * (double)fuse->eps) : 0.f;
     if (s.cs && (C > 8192 || !s.denom)) VQ_FAIL(VQHIP_EINVAL, "ema_accumulate: the fused cluster-size fold needs C <= 8192 and a denominator buffer");
+    const unsigned nh = (unsigned)((fuse && fuse->heads > 1) ? fuse->heads : 1);
+    s.heads = (int)nh;
+    s.hs_idx = fuse ? fuse->hs_idx : 0; s.hs_ws = fuse ? fuse->hs_ws : 0; s.hs_count = fuse ? fuse->hs_stats : 0;
+    if (nh > 1 && (rnorm || metric == VQHIP_COSINE)) VQ_FAIL(VQHIP_EINVAL, "ema_accumulate: batched heads take unit-norm or Euclidean rows");
     if (!hist_zeroed) {
-        hipError_t e = hipMemsetAsync(s.hist, 0, (size_t)C * 4, st);
+        hipError_t e = nh > 1 ? hipMemset2DAsync(s.hist, (size_t)s.hs_ws, 0, (size_t)C * 4, nh, st) : hipMemsetAsync(s.hist, 0, (size_t)C * 4, st);
         if (e != hipSuccess) VQ_FAIL((int)e, "hipMemsetAsync(hist): %s", hipGetErrorString(e));
     }
     // LDS histograms, one global atomic per (workgroup, code), while the histogram fits.  (Round 3 tried the direct path -- one
@@ -3140,14 +3190,18 @@ static int ema_accumulate_impl(const void *x, int x_dtype, int64_t N, int D, int
     const int rpb = s.direct ? 256 : VQ_SORT_ROWS_PER_BLOCK;
     const unsigned sort_blocks = (unsigned)((N + rpb - 1) / rpb);
     const int lds = s.direct ? 0 : C * 4;
-    hipLaunchKernelGGL(vq_hist_kernel, dim3(sort_blocks), dim3(256), lds, st, s);
-    hipLaunchKernelGGL(vq_scan_kernel, dim3(1), dim3(1024), s.cs ? (size_t)C * 4 : 0, st, s);
-    hipLaunchKernelGGL(vq_scatter_kernel, dim3(sort_blocks), dim3(256), lds, st, s);
+    hipLaunchKernelGGL(vq_hist_kernel, dim3(sort_blocks, nh), dim3(256), lds, st, s);
+    hipLaunchKernelGGL(vq_scan_kernel, dim3(1, nh), dim3(1024), s.cs ? (size_t)C * 4 : 0, st, s);
+    hipLaunchKernelGGL(vq_scatter_kernel, dim3(sort_blocks, nh), dim3(256), lds, st, s);
 
     SegArgs g;
     g.x = x; g.D = D; g.ldx = ldx; g.rnorm = rnorm; g.cosine = (metric == VQHIP_COSINE); g.C = C;
     g.seg_off = s.seg_off; g.chunk_off = s.chunk_off; g.perm = s.perm; g.embed_sum = embed_sum;
     g.qsrc = qsrc; g.sqerr_partial = sqerr_partial; g.n_partial = seg_work_items(N, C);
+    g.heads = (int)nh;
+    g.hs_x = fuse ? fuse->hs_x : 0; g.hs_ws = fuse ? fuse->hs_ws : 0; g.hs_sum = fuse ? fuse->hs_stats : 0;
+    g.hs_qsrc = fuse ? fuse->hs_qsrc : 0; g.hs_sq = fuse ? fuse->hs_sq : 0;
+    if (nh > 1 && s.cs) VQ_FAIL(VQHIP_EINVAL, "ema_accumulate: the fused cluster-size fold is for one head");
     const unsigned seg_blocks = (unsigned)(seg_work_items(N, C) / 4);
     const int es = (x_dtype == VQHIP_BF16) ? 2 : 4;
     const bool vec = (D % 4 == 0) && (((uintptr_t)x) % (4 * es) == 0) && ((ldx * es) % (4 * es) == 0);
@@ -3157,20 +3211,20 @@ static int ema_accumulate_impl(const void *x, int x_dtype, int64_t N, int D, int
 #ifndef VQ_SEG_SLOW
     if (vec && D <= 512 && !g.cosine) {
         if (sqerr_partial) {
-            if (bf) hipLaunchKernelGGL((vq_segsum_fast_kernel<true, true>), dim3(seg_blocks), dim3(256), 0, st, g);
-            else hipLaunchKernelGGL((vq_segsum_fast_kernel<false, true>), dim3(seg_blocks), dim3(256), 0, st, g);
+            if (bf) hipLaunchKernelGGL((vq_segsum_fast_kernel<true, true>), dim3(seg_blocks, nh), dim3(256), 0, st, g);
+            else hipLaunchKernelGGL((vq_segsum_fast_kernel<false, true>), dim3(seg_blocks, nh), dim3(256), 0, st, g);
         } else {
-            if (bf) hipLaunchKernelGGL((vq_segsum_fast_kernel<true, false>), dim3(seg_blocks), dim3(256), 0, st, g);
-            else hipLaunchKernelGGL((vq_segsum_fast_kernel<false, false>), dim3(seg_blocks), dim3(256), 0, st, g);
+            if (bf) hipLaunchKernelGGL((vq_segsum_fast_kernel<true, false>), dim3(seg_blocks, nh), dim3(256), 0, st, g);
+            else hipLaunchKernelGGL((vq_segsum_fast_kernel<false, false>), dim3(seg_blocks, nh), dim3(256), 0, st, g);
         }
         return launch_status("vq_ema_accumulate");
     }
 #endif
     if (sqerr_partial) VQ_FAIL(VQHIP_EINVAL, "ema_accumulate_sqerr: built without the fast segment-sum kernel");
-    if (bf && vec) hipLaunchKernelGGL((vq_segsum_kernel<true, true>), dim3(seg_blocks), dim3(256), 0, st, g);
-    else if (bf) hipLaunchKernelGGL((vq_segsum_kernel<true, false>), dim3(seg_blocks), dim3(256), 0, st, g);
-    else if (vec) hipLaunchKernelGGL((vq_segsum_kernel<false, true>), dim3(seg_blocks), dim3(256), 0, st, g);
-    else hipLaunchKernelGGL((vq_segsum_kernel<false, false>), dim3(seg_blocks), dim3(256), 0, st, g);
+    if (bf && vec) hipLaunchKernelGGL((vq_segsum_kernel<true, true>), dim3(seg_blocks, nh), dim3(256), 0, st, g);
+    else if (bf) hipLaunchKernelGGL((vq_segsum_kernel<true, false>), dim3(seg_blocks, nh), dim3(256), 0, st, g);
+    else if (vec) hipLaunchKernelGGL((vq_segsum_kernel<false, true>), dim3(seg_blocks, nh), dim3(256), 0, st, g);
+    else hipLaunchKernelGGL((vq_segsum_kernel<false, false>), dim3(seg_blocks, nh), dim3(256), 0, st, g);
     return launch_status("vq_ema_accumulate");
 }
 
@@ -3215,13 +3269,46 @@ extern "C" int vqhip_ema_accumulate_prezeroed(const void *x, int x_dtype, int64_
                                workspace_bytes, qsrc, sqerr_partial, stream, &f);
 }
 
+// The statistics of H heads in one set of launches (blockIdx.y = head): x [H, N, D] at x_hstride elements between heads, idx [H, N],
+// stats [H, stats_stride] = embed_sum [C, D] || count [C] per head (ACCUMULATED INTO: zero it first), workspace H x
+// vqhip_ema_batched_ws_stride(N, C) bytes, packed / embed (nullable together with sqerr_partial [H, vqhip_ema_sqerr_partials(N, C)]) the
+// codebooks as vqhip_pack_codebook_batched laid them out / [H, C, D].  Euclidean, or cosine on unit-norm rows.
+extern "C" size_t vqhip_ema_batched_ws_stride(int64_t N, int C) { return align_up(vqhip_ema_workspace_bytes(N, C), 256); }
+
+extern "C" int vqhip_ema_accumulate_batched(const void *x, int x_dtype, int H, int64_t N, int D, int64_t ldx, int64_t x_hstride,
+                                            const int64_t *idx, const uint8_t *row_mask, int C, float *stats, int64_t stats_stride,
+                                            void *workspace, size_t workspace_bytes, const float *packed, const float *embed,
+                                            double *sqerr_partial, void *stream)
+{
+    if (H < 1 || D < 1 || D > 512 || C <= 0) VQ_FAIL(VQHIP_EINVAL, "ema_accumulate_batched: bad size");
+    if (!stats || stats_stride < (int64_t)C * D + C) VQ_FAIL(VQHIP_EINVAL, "ema_accumulate_batched: stats null or stats_stride smaller than C D + C");
+    if (sqerr_partial && (!packed || !embed)) VQ_FAIL(VQHIP_EINVAL, "ema_accumulate_batched: the loss needs packed and embed");
+    const size_t wss = vqhip_ema_batched_ws_stride(N, C);
+    if (workspace_bytes < wss * (size_t)H) VQ_FAIL(VQHIP_EINVAL, "ema_accumulate_batched: workspace too small");
+    const int es = (x_dtype == VQHIP_BF16) ? 2 : 4;
+    StatsFuse f;
+    f.hist_zeroed = 0; f.cs = nullptr; f.denom = nullptr; f.omd = 0.f; f.eps = 0.f;
+    f.heads = H;
+    f.hs_x = x_hstride * es; f.hs_idx = N * 8; f.hs_ws = (int64_t)wss; f.hs_stats = stats_stride * 4;
+    f.hs_qsrc = (x_dtype == VQHIP_BF16) ? (int64_t)vq_packed_total_bytes(C, D) : (int64_t)C * D * 4;
+    f.hs_sq = seg_work_items(N, C) * (int64_t)sizeof(double);
+    const void *qsrc = !sqerr_partial ? nullptr
+                     : (x_dtype == VQHIP_BF16) ? (const void *)((const char *)packed + vq_packed_bf16_offset(C, D)) : (const void *)embed;
+    return ema_accumulate_impl(x, x_dtype, N, D, ldx, idx, 1, nullptr, VQHIP_EUCLID, row_mask, C, stats + (size_t)C * D, stats, workspace,
+                               wss, qsrc, sqerr_partial, stream, &f);
+}
+
 // ------------------------------------------------------------------------------------------------
 // EMA fold + codebook renormalisation
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) vq_ema_cs_lerp_kernel(float *cs, const float *count, const float *weight, int C, float omd)
+// (hs_*: element strides between consecutive heads of a batched launch, blockIdx.y = head; 0 for a plain one)
+__global__ void __launch_bounds__(256) vq_ema_cs_lerp_kernel(float *cs, const float *count, const float *weight, int C, float omd,
+                                                             int64_t hs_cs, int64_t hs_count)
 {
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= C) return;
+    cs += blockIdx.y * hs_cs;
+    count += blockIdx.y * hs_count;
     const float w = weight ? omd * weight[c] : omd;
     cs[c] = aten_lerp(cs[c], count[c], w);
 }
@@ -3229,6 +3316,8 @@ __global__ void __launch_bounds__(256) vq_ema_cs_lerp_kernel(float *cs, const fl
 // (the arithmetic: ema_denom_block above)
 __global__ void __launch_bounds__(256) vq_ema_denom_kernel(const float *cs_g, int C, float eps, float ceps, float *denom)
 {
+    cs_g += (size_t)blockIdx.y * C;        // (batched heads: cluster_size [H, C], denom [H, C])
+    denom += (size_t)blockIdx.y * C;
     __shared__ float part[32];
     __shared__ float total_s;
     extern __shared__ float cs_lds[];      // C floats when the launch provides them (C <= 16384), else unused
@@ -3287,9 +3376,11 @@ __device__ __forceinline__ void ema_embed_row(float *embed_avg, float *embed, co
 
 __global__ void __launch_bounds__(256) vq_ema_embed_kernel(float *embed_avg, float *embed, const float *embed_sum,
                                                            const float *weight, const float *denom, int C, int D,
-                                                           float omd, int cosine, int do_lerp, int do_update)
+                                                           float omd, int cosine, int do_lerp, int do_update, int64_t hs_sum)
 {
-    ema_embed_row(embed_avg, embed, embed_sum, weight, denom, C, D, omd, cosine, do_lerp, do_update, blockIdx.x * 4 + (threadIdx.x >> 6));
+    const size_t h = blockIdx.y;           // batched heads: embed_avg / embed [H, C, D], denom [H, C], embed_sum at hs_sum floats
+    ema_embed_row(embed_avg + h * C * D, embed + h * C * D, embed_sum ? embed_sum + h * hs_sum : nullptr, weight, denom ? denom + h * C : nullptr,
+                  C, D, omd, cosine, do_lerp, do_update, blockIdx.x * 4 + (threadIdx.x >> 6));
 }
 
 // tail of the fused train step: workgroups [0, ceil(C / 4)) fold embed_sum into embed_avg and renormalise embed (the kernel above),
@@ -3326,15 +3417,37 @@ extern "C" int vqhip_ema_finalize(float *cluster_size, float *embed_avg, float *
     if (do_update_ema && !denom_ws) VQ_FAIL(VQHIP_EINVAL, "ema_finalize: do_update_ema needs denom_ws");
     hipStream_t st = (hipStream_t)stream;
     if (do_lerp)
-        hipLaunchKernelGGL(vq_ema_cs_lerp_kernel, dim3((C + 255) / 256), dim3(256), 0, st, cluster_size, count, weight, C, one_minus_decay);
+        hipLaunchKernelGGL(vq_ema_cs_lerp_kernel, dim3((C + 255) / 256), dim3(256), 0, st, cluster_size, count, weight, C, one_minus_decay, (int64_t)0, (int64_t)0);
     if (do_update_ema) {
         const float ceps = (float)((double)C * (double)eps);
         hipLaunchKernelGGL(vq_ema_denom_kernel, dim3(1), dim3(256), (C <= 16384 ? (size_t)C * 4 : 0), st, cluster_size, C, eps, ceps, denom_ws);
     }
     if (do_lerp || do_update_ema)
         hipLaunchKernelGGL(vq_ema_embed_kernel, dim3((C + 3) / 4), dim3(256), 0, st, embed_avg, embed, embed_sum, weight,
-                           denom_ws, C, D, one_minus_decay, cosine, do_lerp, do_update_ema);
+                           denom_ws, C, D, one_minus_decay, cosine, do_lerp, do_update_ema, (int64_t)0);
     return launch_status("vq_ema_finalize");
+}
+
+// H codebooks' folds in three launches (blockIdx.y = head): cluster_size [H, C], embed_avg / embed [H, C, D] -- the module buffers of a
+// multi-head Codebook as they are -- and stats [H, stats_stride] = embed_sum [C, D] || count [C] per head (vqhip_ema_accumulate_batched).
+extern "C" int vqhip_ema_finalize_batched(float *cluster_size, float *embed_avg, float *embed, const float *stats, int64_t stats_stride,
+                                          int H, int C, int D, float one_minus_decay, float eps, int cosine, int do_update_ema,
+                                          float *denom_ws, void *stream)
+{
+    if (!cluster_size || !embed_avg || !embed || !stats || C <= 0 || H < 1) VQ_FAIL(VQHIP_EINVAL, "ema_finalize_batched: bad argument");
+    if (D < 1 || D > 512) VQ_FAIL(VQHIP_EDIM, "ema_finalize_batched: D=%d unsupported (1..512)", D);
+    if (stats_stride < (int64_t)C * D + C) VQ_FAIL(VQHIP_EINVAL, "ema_finalize_batched: stats_stride smaller than C D + C");
+    if (do_update_ema && !denom_ws) VQ_FAIL(VQHIP_EINVAL, "ema_finalize_batched: do_update_ema needs denom_ws [H, C]");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(vq_ema_cs_lerp_kernel, dim3((C + 255) / 256, H), dim3(256), 0, st, cluster_size, stats + (size_t)C * D, (const float *)nullptr, C,
+                       one_minus_decay, (int64_t)C, stats_stride);
+    if (do_update_ema) {
+        const float ceps = (float)((double)C * (double)eps);
+        hipLaunchKernelGGL(vq_ema_denom_kernel, dim3(1, H), dim3(256), (C <= 16384 ? (size_t)C * 4 : 0), st, cluster_size, C, eps, ceps, denom_ws);
+    }
+    hipLaunchKernelGGL(vq_ema_embed_kernel, dim3((C + 3) / 4, H), dim3(256), 0, st, embed_avg, embed, stats, (const float *)nullptr, denom_ws, C, D,
+                       one_minus_decay, cosine, 1, do_update_ema, stats_stride);
+    return launch_status("vq_ema_finalize_batched");
 }
 
 // Renormalisation of ONE SHARD of a codebook partitioned over ranks (parallel.ShardedVectorQuantize): the Laplace smoothing of
@@ -3358,7 +3471,7 @@ extern "C" int vqhip_ema_renormalize_shard(const float *cluster_size, float *emb
     const float ceps = (float)((double)C_total * (double)eps);
     hipLaunchKernelGGL(vq_ema_denom_ext_kernel, dim3((C + 255) / 256), dim3(256), 0, st, cluster_size, C, eps, ceps, total_cluster_size, denom_ws);
     hipLaunchKernelGGL(vq_ema_embed_kernel, dim3((C + 3) / 4), dim3(256), 0, st, embed_avg, embed, (const float *)nullptr, (const float *)nullptr,
-                       denom_ws, C, D, 0.f, cosine, 0, 1);
+                       denom_ws, C, D, 0.f, cosine, 0, 1, (int64_t)0);
     return launch_status("vq_ema_renormalize_shard");
 }
 
