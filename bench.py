@@ -403,7 +403,8 @@ def vq_cfg2(args, world, rank, dev):
         try:
             tj = json.load(open(tp))
             traffic = tj.get("assign_screened_cfg2_bytes_per_launch" if screened else "vq_assign_kernel_cfg2_bytes_per_launch")
-            traffic_src = "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, committed; not re-measured in this run)"
+            traffic_src = ("profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, committed; measured at commit "
+                           f"{(tj.get('assign_screened_cfg2') or {}).get('measured_at_commit', 'n/a')}, not re-measured in this run)")
             step_traffic = (tj.get("step_traffic", {}).get("vq_cfg2") or {}).get("bytes_per_step") if screened else None
         except Exception:
             traffic = None
