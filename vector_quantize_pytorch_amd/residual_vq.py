@@ -594,7 +594,8 @@ def _stats_stream(device, main):
         #  cfg 3 2.93 -> 4.73 / 4.43 / 4.43 ms, cfg 5 15.5 -> 27.1 ms -- a masked queue loses its concurrency with the search.
         #  Also round 4: stage q's pass held back until stage q + 1's screening kernel has finished (an event recorded by the
         #  library between that kernel and its exact passes), so that it runs in the shadow of those short kernels: cfg 3 3.01 ->
-        #  3.03 ms, cfg 5 16.0 -> 16.4 ms -- the pass outlasts that shadow and meets the next screen anyway.)
+        #  3.03 ms, cfg 5 16.0 -> 16.4 ms -- the pass outlasts that shadow and meets the next screen anyway.  And the opposite of the
+        #  round-3 experiment, the SEARCH chain on a high-priority stream: cfg 3 2.88 -> 3.06 ms, cfg 5 15.7 -> 20.7 ms.)
         _STATS_STREAMS[key] = torch.cuda.Stream(device=device)
     return _STATS_STREAMS[key]
 
