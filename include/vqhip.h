@@ -79,6 +79,11 @@ int vqhip_assign(const void *x, int x_dtype, int64_t N, int D, int64_t ldx,
  * ATen's CPU order and, for bf16 tensors, norm and quotient rounded to bf16 as the reference's bf16 ops do -- the same
  * arithmetic vqhip_assign(metric VQHIP_COSINE) applies internally.  D in {32, 64, 128, 256, 512}; rows aligned to 4 elements. */
 int vqhip_l2norm_rows(const void *x, int x_dtype, int64_t N, int D, int64_t ldx, void *out, int64_t ldo, void *stream);
+/* Its backward, the gradient autograd derives for F.normalize (the reference keeps the l2norm of :1159 in the graph when the input
+ * requires grad): out = g / n - [||x|| >= eps] x / ||x|| * sum_d(g_d x_d) / n^2 with n = max(||x||, eps), one pass over x and g instead
+ * of the quotient's, the clamp's and the norm's backward kernels.  x, g, out in x_dtype; D % 4 == 0, D <= 512; rows aligned to 4 elements. */
+int vqhip_l2norm_rows_bwd(const void *x, const void *g, int x_dtype, int64_t N, int D, int64_t ldx, int64_t ldg,
+                          void *out, int64_t ldo, void *stream);
 
 /* ---- screened assignment (D in {32, 64, 128, 256, 512}) -------------------------------------------------
  * metric: VQHIP_EUCLID, or VQHIP_COSINE_PRENORM on rows already normalised (vqhip_l2norm_rows).
@@ -252,8 +257,9 @@ int vqhip_ema_finalize_batched(float *cluster_size, float *embed_avg, float *emb
                                float *denom_ws, void *stream);
 
 /* ---- fused train step ---------------------------------------------------------------------------
- * One call = one training forward of a Euclidean EMA codebook (VectorQuantize.forward in training mode, vqp.py:1176 ->
- * EuclideanCodebook.forward :673-800): pack the codebook, nearest-code search (screened, bit-identical indices), gather q,
+ * One call = one training forward of an EMA codebook (VectorQuantize.forward in training mode, vqp.py:1176 ->
+ * Codebook.forward :673-800; use_cosine_sim: rows normalised by the caller as at :1157-1159, dot-product scores :740-741):
+ * pack the codebook, nearest-code search (screened, bit-identical indices), gather q,
  * EMA statistics (count / embed_sum, vqp.py:602-606), the commitment loss' squared error (vqp.py:1327) and -- with fold != 0 --
  * ema_inplace of cluster_size and embed_avg and update_ema (vqp.py:610-617, 576-584).  The same kernels as vqhip_pack_codebook +
  * vqhip_assign_screened + vqhip_ema_accumulate_sqerr + vqhip_ema_finalize + vqhip_reduce_partials, minus what only exists between
@@ -275,6 +281,9 @@ typedef struct {
     int64_t fold;
     void *ev_search_begin; void *ev_search_end;                           /* nullable hipEvent_t: recorded on `stream` around the search
                                                                              (screen + exact passes) -- bench.py's roofline measurement */
+    int64_t metric;                                                       /* VQHIP_EUCLID, or VQHIP_COSINE_PRENORM: x holds unit-norm rows
+                                                                             (vqhip_l2norm_rows, vqp.py:1159) of a cosine codebook -- the
+                                                                             fold then l2-normalises embed (vqp.py:581-582) */
 } vqhip_vq_step_t;
 int vqhip_vq_step_supported(int x_dtype, int64_t N, int D, int C);
 size_t vqhip_vq_step_workspace_bytes(int64_t N, int C);

@@ -856,11 +856,16 @@ def test_device_side_expiry_matches_reference_semantics(dev):
 
 @pytest.mark.parametrize("dtype,kw", [(torch.bfloat16, dict(dim=256, codebook_size=1024)), (torch.float32, dict(dim=256, codebook_size=512)),
                                       (torch.float32, dict(dim=128, codebook_size=256, heads=2, separate_codebook_per_head=True)),
-                                      (torch.float32, dict(dim=512, codebook_size=300, threshold_ema_dead_code=2))])
+                                      (torch.float32, dict(dim=512, codebook_size=300, threshold_ema_dead_code=2)),
+                                      (torch.float32, dict(dim=128, codebook_size=512, use_cosine_sim=True)),
+                                      (torch.bfloat16, dict(dim=256, codebook_size=1024, use_cosine_sim=True, threshold_ema_dead_code=2)),
+                                      (torch.float32, dict(dim=64, codebook_size=256, heads=2, separate_codebook_per_head=True,
+                                                           use_cosine_sim=True))])
 def test_commit_loss_from_the_statistics_pass_equals_the_search_kernels(dev, monkeypatch, dtype, kw):
     """Training with EMA: the squared error of the commitment loss comes from the statistics pass (Codebook.quantize,
     vqhip_ema_accumulate_sqerr) instead of the search kernel re-reading x.  Same module, same batches, VQHIP_STATS_SQERR=0
-    (search kernel sums it) vs default: indices and outputs identical, loss and codebooks equal to fp32 rounding; with a mask too."""
+    (search kernel sums it) vs default: indices and outputs identical, loss and codebooks equal to fp32 rounding; with a mask too.
+    Cosine codebooks: the pass runs on the unit-norm rows the search saw (vqp.py:1157-1159), whose squared error the loss is."""
     from vector_quantize_pytorch_amd import VectorQuantize
     torch.manual_seed(0)
     a, b = VectorQuantize(**kw).to(dev).train(), VectorQuantize(**kw).to(dev).train()
@@ -868,6 +873,8 @@ def test_commit_loss_from_the_statistics_pass_equals_the_search_kernels(dev, mon
     for step in range(3):
         x = torch.randn(4, 1500, kw["dim"], device=dev).to(dtype)
         lens = torch.tensor([1500, 900, 1, 1200], device=dev) if step == 2 else None
+        if kw.get("use_cosine_sim") and kw.get("heads", 1) > 1:
+            lens = None                    # (masked loss of multi-headed cosine modules: undefined shapes in the reference, vqp.py:1319)
         rng = torch.cuda.get_rng_state(dev)
         monkeypatch.setenv("VQHIP_STATS_SQERR", "1")
         qa, ia, la = a(x, lens=lens)
@@ -884,14 +891,19 @@ def test_commit_loss_from_the_statistics_pass_equals_the_search_kernels(dev, mon
                                             (torch.float32, dict(dim=256, codebook_size=512), (3, 2000)),
                                             (torch.float32, dict(dim=128, codebook_size=4096, decay=0.9), (2, 3000)),
                                             (torch.bfloat16, dict(dim=64, codebook_size=37, threshold_ema_dead_code=2), (5, 777)),
-                                            (torch.bfloat16, dict(dim=512, codebook_size=2048, commitment_weight=0.25), (1, 6000))])
+                                            (torch.bfloat16, dict(dim=512, codebook_size=2048, commitment_weight=0.25), (1, 6000)),
+                                            (torch.float32, dict(dim=128, codebook_size=1024, use_cosine_sim=True), (2, 3000)),
+                                            (torch.bfloat16, dict(dim=256, codebook_size=512, use_cosine_sim=True, threshold_ema_dead_code=2),
+                                             (3, 2500))])
 def test_fused_train_step_equals_the_separate_calls(dev, monkeypatch, dtype, kw, shape):
     """vqhip_vq_train_step (one call: zeroing kernel, pack, search that also counts the rows per code, statistics whose scan kernel
     folds cluster_size, one tail kernel for embed_avg / embed / loss) against the separate calls it replaces (VQHIP_FUSED_STEP=0):
     indices, q and cluster_size identical, loss / embed_avg / embed equal to the rounding of the fp32 atomics in the segmented sums;
-    several steps with an evolving codebook, with and without an input that requires grad."""
+    several steps with an evolving codebook, with and without an input that requires grad.  Cosine codebooks (rows normalised before
+    the call, embed l2-normalised by the fold, vqp.py:581-582) against the separate calls with the loss summed by the search kernel."""
     from vector_quantize_pytorch_amd import VectorQuantize, _lib
     import vector_quantize_pytorch_amd.codebook as cbmod
+    cosine = bool(kw.get("use_cosine_sim"))
     torch.manual_seed(0)
     a, b = VectorQuantize(**kw).to(dev).train(), VectorQuantize(**kw).to(dev).train()
     b.load_state_dict(a.state_dict())
@@ -903,9 +915,12 @@ def test_fused_train_step_equals_the_separate_calls(dev, monkeypatch, dtype, kw,
         xa, xb = x.clone().requires_grad_(step == 3), x.clone().requires_grad_(step == 3)
         rng = torch.cuda.get_rng_state(dev)
         monkeypatch.setenv("VQHIP_FUSED_STEP", "1")
+        monkeypatch.setenv("VQHIP_STATS_SQERR", "1")
         qa, ia, la = a(xa)
         torch.cuda.set_rng_state(rng, dev)
         monkeypatch.setenv("VQHIP_FUSED_STEP", "0")
+        if cosine:
+            monkeypatch.setenv("VQHIP_STATS_SQERR", "0")
         qb, ib, lb = b(xb)
         assert len(calls) == step + 1, "the fused step did not serve the forward"
         assert torch.equal(ia, ib) and torch.equal(qa, qb)

@@ -530,6 +530,28 @@ def test_l2norm_rows_matches_reference_arithmetic(dev, N, D, dtype):
     assert torch.equal(L.l2norm_rows(x.to(dev)).cpu(), _l2norm_ref(x))
 
 
+@pytest.mark.parametrize("N,D,dtype", [(4099, 256, torch.bfloat16), (1000, 128, torch.float32), (333, 64, torch.bfloat16),
+                                       (2048, 256, torch.float32), (700, 32, torch.float32), (515, 512, torch.float32),
+                                       (515, 512, torch.bfloat16)])
+def test_l2norm_rows_backward_is_autograds_normalize_gradient(dev, N, D, dtype):
+    """vqhip_l2norm_rows_bwd against autograd through F.normalize (vqp.py:37-38) evaluated in float64 on the same values: fp32 to
+    rounding, bf16 to one rounding of the result; a zero row and a row below the eps floor take the clamp's branch (gradient g / eps)."""
+    from vector_quantize_pytorch_amd import _lib as L
+    gen = torch.Generator().manual_seed(3)
+    x = (torch.randn(N, D, generator=gen) * torch.rand(N, 1, generator=gen) * 3).to(dtype)
+    x[5] = 0
+    x[6] = (torch.randn(D, generator=gen) * 1e-9).to(dtype)
+    g = torch.randn(N, D, generator=gen).to(dtype)
+    x64 = x.double().requires_grad_(True)
+    torch.nn.functional.normalize(x64, p=2, dim=-1, eps=1e-6).backward(g.double())
+    want = x64.grad
+    got = L.l2norm_rows_bwd(x.to(dev), g.to(dev)).cpu().double()
+    scale = want.abs().amax(dim=1, keepdim=True).clamp(min=1e-30)
+    tol = 2e-5 if dtype == torch.float32 else 1.2e-2       # bf16: the norm is the bf16-rounded one of the forward, the result rounded once
+    assert ((got - want).abs() / scale).max().item() < tol
+    assert L.l2norm_rows_supported(x.to(dev))
+
+
 @pytest.mark.parametrize("N,C,D,kind", [(4099, 1024, 256, "unit"), (5000, 1000, 128, "unit"), (3000, 37, 64, "unit"),
                                         (8192, 1024, 256, "dups"), (4000, 2048, 32, "unit"), (2000, 4096, 512, "unit")])
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])

@@ -66,6 +66,8 @@ def lib():
     L.vqhip_screen_partials.restype = i64
     L.vqhip_assign_screened.argtypes = [vp, i32, i64, i32, i64, vp, vp, i32, i32, vp, vp, i64, vp, i64, vp, vp, vp, ctypes.c_size_t, vp, vp]
     L.vqhip_l2norm_rows.argtypes = [vp, i32, i64, i32, i64, vp, i64, vp]
+    L.vqhip_l2norm_rows_bwd.argtypes = [vp, vp, i32, i64, i32, i64, i64, vp, i64, vp]
+    L.vqhip_l2norm_rows_bwd.restype = i32
     L.vqhip_screen_chain_supported.argtypes = [i32, i32]
     L.vqhip_screen_chain_supported.restype = i32
     L.vqhip_assign_screened_chain.argtypes = [vp, i32, i64, i32, i64, vp, vp, i32, i32, vp, vp, vp, ctypes.c_size_t, vp, vp]
@@ -141,7 +143,7 @@ def lib():
 
 EXPORTS = ("vqhip_version", "vqhip_last_error", "vqhip_packed_bytes", "vqhip_pack_codebook",
            "vqhip_assign_blocks", "vqhip_assign", "vqhip_screen_supported", "vqhip_screen_workspace_bytes",
-           "vqhip_screen_blocks", "vqhip_screen_partials", "vqhip_assign_screened", "vqhip_screen_chain_supported", "vqhip_assign_screened_chain", "vqhip_l2norm_rows", "vqhip_scores", "vqhip_rvq_forward", "vqhip_reduce_partials", "vqhip_reduce_partials_rows", "vqhip_ema_fold_many", "vqhip_ema_workspace_bytes", "vqhip_ema_accumulate", "vqhip_ema_sqerr_partials", "vqhip_ema_accumulate_sqerr",
+           "vqhip_screen_blocks", "vqhip_screen_partials", "vqhip_assign_screened", "vqhip_screen_chain_supported", "vqhip_assign_screened_chain", "vqhip_l2norm_rows", "vqhip_l2norm_rows_bwd", "vqhip_scores", "vqhip_rvq_forward", "vqhip_reduce_partials", "vqhip_reduce_partials_rows", "vqhip_ema_fold_many", "vqhip_ema_workspace_bytes", "vqhip_ema_accumulate", "vqhip_ema_sqerr_partials", "vqhip_ema_accumulate_sqerr",
            "vqhip_ema_finalize", "vqhip_decode_sum", "vqhip_row_sumsq", "vqhip_assign_rowwise", "vqhip_score_indices", "vqhip_topk", "vqhip_expire_scatter", "vqhip_kmeans_update", "vqhip_route_fwd", "vqhip_route_bwd", "vqhip_rvq_route", "vqhip_ema_renormalize_shard", "vqhip_scores_lse",
            "vqhip_pack_best", "vqhip_unpack_best", "vqhip_vq_step_supported", "vqhip_vq_step_workspace_bytes", "vqhip_vq_train_step", "vqhip_route_residual",
            "vqhip_pack_codebook_batched", "vqhip_screen_batched_ws_stride", "vqhip_assign_screened_batched", "vqhip_assign_batched",
@@ -436,6 +438,32 @@ def l2norm_rows(x: torch.Tensor) -> torch.Tensor:
     out = torch.empty(*x.shape, dtype=x.dtype, device=x.device)
     if N > 0:
         _check(lib().vqhip_l2norm_rows(_ptr(xk), _dtype_code(xk), N, D, ldx, _ptr(out), D, _stream()), "vqhip_l2norm_rows")
+    return out
+
+
+def l2norm_rows_supported(x: torch.Tensor) -> bool:
+    """rows l2norm_rows / l2norm_rows_bwd take: float32 / bfloat16 on the GPU, D in {32, 64, 128, 256, 512}, 4-element aligned rows"""
+    if not (x.is_cuda and x.dtype in (torch.float32, torch.bfloat16) and x.ndim >= 2 and x.shape[-1] in (32, 64, 128, 256, 512)
+            and x.numel() > 0):
+        return False
+    try:
+        xk, N, D, ldx = as_rows(x)
+    except Exception:
+        return False
+    es = xk.element_size()
+    return xk.data_ptr() % (4 * es) == 0 and (ldx * es) % (4 * es) == 0
+
+
+def l2norm_rows_bwd(x: torch.Tensor, g: torch.Tensor) -> torch.Tensor:
+    """gradient of l2norm_rows(x) with respect to x for the output gradient g (autograd's F.normalize backward, one kernel)"""
+    _need_gpu(x, g)
+    xk, N, D, ldx = as_rows(x)
+    g = g.to(x.dtype)
+    if not g.is_contiguous():
+        g = g.contiguous()
+    out = torch.empty(*x.shape, dtype=x.dtype, device=x.device)
+    if N > 0:
+        _check(lib().vqhip_l2norm_rows_bwd(_ptr(xk), _ptr(g), _dtype_code(xk), N, D, ldx, D, _ptr(out), D, _stream()), "vqhip_l2norm_rows_bwd")
     return out
 
 
@@ -795,7 +823,7 @@ class _Step(ctypes.Structure):           # vqhip_vq_step_t (include/vqhip.h)
                 ("stats", ctypes.c_void_p), ("loss_out", ctypes.c_void_p), ("loss_scale", ctypes.c_double),
                 ("packed", ctypes.c_void_p), ("workspace", ctypes.c_void_p), ("workspace_bytes", ctypes.c_size_t),
                 ("one_minus_decay", ctypes.c_double), ("eps", ctypes.c_double), ("fold", ctypes.c_int64),
-                ("ev_search_begin", ctypes.c_void_p), ("ev_search_end", ctypes.c_void_p)]
+                ("ev_search_begin", ctypes.c_void_p), ("ev_search_end", ctypes.c_void_p), ("metric", ctypes.c_int64)]
 
 
 step_event_hook = None   # bench.py: callable -> (begin, end) torch.cuda.Event pair (already recorded once, so that their handles exist),
@@ -814,8 +842,9 @@ def vq_step_supported(x: torch.Tensor, C: int) -> bool:
 
 
 @_on_device
-def vq_train_step(x: torch.Tensor, embed, embed_avg, cluster_size, *, decay, eps, want_q=True, q_out=None, loss_scale=None, fold=True):
-    """One training forward of a Euclidean EMA codebook in one library call (vqhip_vq_train_step; reference: vqp.py:673-800 under
+def vq_train_step(x: torch.Tensor, embed, embed_avg, cluster_size, *, decay, eps, want_q=True, q_out=None, loss_scale=None, fold=True,
+                  cosine=False):
+    """One training forward of an EMA codebook (Euclidean, or cosine=True on rows already unit-norm: l2norm_rows) in one library call (vqhip_vq_train_step; reference: vqp.py:673-800 under
     VectorQuantize.forward :1176).  embed / embed_avg / cluster_size: [C, D], [C, D], [C] fp32, updated in place when fold.
     -> dict(q, idx, count [C], embed_sum [C, D] (views of one [C D + C] buffer: one all-reduce), loss (0-dim fp32 or None))"""
     _need_gpu(x, embed, embed_avg, cluster_size)
@@ -838,7 +867,8 @@ def vq_train_step(x: torch.Tensor, embed, embed_avg, cluster_size, *, decay, eps
     st = _Step(x=xk.data_ptr(), x_dtype=_dtype_code(xk), N=N, D=D, ldx=ldx, embed=embed.data_ptr(), embed_avg=embed_avg.data_ptr(),
                cluster_size=cluster_size.data_ptr(), C=C, idx_out=idx.data_ptr(), q_out=None if q is None else q.data_ptr(), ldq=D,
                stats=stats.data_ptr(), loss_out=None if loss is None else loss.data_ptr(), loss_scale=float(loss_scale or 0.0),
-               packed=packed.data_ptr(), workspace=ws.data_ptr(), workspace_bytes=nws, one_minus_decay=omd, eps=float(eps), fold=int(bool(fold)))
+               packed=packed.data_ptr(), workspace=ws.data_ptr(), workspace_bytes=nws, one_minus_decay=omd, eps=float(eps), fold=int(bool(fold)),
+               metric=COSINE_PRENORM if cosine else EUCLID)
     if step_event_hook is not None:
         e0, e1 = step_event_hook()
         st.ev_search_begin, st.ev_search_end = e0.cuda_event, e1.cuda_event

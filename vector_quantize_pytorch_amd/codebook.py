@@ -403,13 +403,16 @@ class Codebook(nn.Module):
                 x_stats = ((flat - self.batch_mean) * (cstd / bstd) + self.codebook_mean).reshape(xs.shape)
         # the whole training forward of the plain case as ONE library call (vqhip_vq_train_step): pack, search, statistics, the
         # commitment loss' squared error and -- without a collective in between -- the EMA fold
-        if (H == 1 and do_update and want_sqerr and loss_scale is not None and rmask is None and ema_update and not self.use_cosine_sim
+        if (H == 1 and do_update and want_sqerr and loss_scale is not None and rmask is None and ema_update
                 and not self.affine_param and embed_override is None and ema_update_weight is None and not accum_ema_update
                 and not self.manual_ema_update and self.cluster_size.grad is None and self.embed.dtype == torch.float32
                 and L.vq_step_supported(xs[0], C)):
             cs, ea, e = self._views(0)
-            r = L.vq_train_step(xs[0], e, ea, cs, decay=self.decay, eps=self.eps, want_q=want_q, q_out=q_out, loss_scale=loss_scale,
-                                fold=not self.use_ddp)
+            x0 = xs[0]
+            if self.use_cosine_sim and not input_normalized:    # vqp.py:1157-1159 (the loss below then compares with the unit-norm rows,
+                x0 = L.l2norm_rows(x0)                          #  as the reference's does)
+            r = L.vq_train_step(x0, e, ea, cs, decay=self.decay, eps=self.eps, want_q=want_q, q_out=q_out, loss_scale=loss_scale,
+                                fold=not self.use_ddp, cosine=self.use_cosine_sim)
             if self.use_ddp:
                 dist.all_reduce(r["stats"])   # ONE collective for count || embed_sum (RCCL over xGMI), then the fold
                 self._fold_stats(0, r["count"], r["embed_sum"], None, False, ema_update)
@@ -423,7 +426,9 @@ class Codebook(nn.Module):
         rb = packed_all = None
         xs_raw = xs                     # (dead-code replacement below samples the rows as they came in, like the per-head loop)
         E_all = (self.embed if embed_override is None else embed_override).detach()
-        stats_sums_loss = want_sqerr and do_update and x_stats is xs and not self.use_cosine_sim and L.stats_sqerr_supported(xs[0])
+        # (cosine: on unit-norm rows -- handed in, or normalised below -- the loss' squared error is the Euclidean one of those rows)
+        stats_sums_loss = (want_sqerr and do_update and x_stats is xs and L.stats_sqerr_supported(xs[0])
+                           and (not self.use_cosine_sim or input_normalized or L.screen_supported(xs[0], C)))
         if H > 1 and not self.affine_param and (not want_sqerr or stats_sums_loss) and E_all.dtype == torch.float32:
             xs_b = xs
             if self.use_cosine_sim and not input_normalized and L.screen_supported(xs[0], C):
@@ -463,7 +468,7 @@ class Codebook(nn.Module):
                 prenorm = True
             # the statistics pass below reads every row next to its code: when it runs on the rows that were searched, it also
             # sums the commitment loss' squared error, and the search does not re-read x for it (csrc: vq_segsum_fast_kernel)
-            sq_in_stats = (want_sqerr and do_update and x_stats is xs and not self.use_cosine_sim and L.stats_sqerr_supported(xh))
+            sq_in_stats = (want_sqerr and do_update and x_stats is xs and (not self.use_cosine_sim or prenorm) and L.stats_sqerr_supported(xh))
             if rb is not None:
                 r = dict(idx=rb["idx"][h], q=None if rb["q"] is None else rb["q"][h], sqerr_partials=None, nblk=0,
                          rnorm=None if rb["rnorm"] is None else rb["rnorm"][h])

@@ -1497,6 +1497,108 @@ extern "C" int vqhip_l2norm_rows(const void *x, int x_dtype, int64_t N, int D, i
     return launch_status("vq_l2norm_kernel");
 }
 
+// backward of the row-wise l2norm, the gradient autograd derives for F.normalize (vqp.py:37-38: x / clamp_min(||x||, eps)):
+//     gx = g / n  -  [||x|| >= eps] * x / ||x|| * sum_d(g_d x_d) / n^2,        n = max(||x||, eps)
+// in ONE pass over x and g (autograd: the quotient's, the clamp's and the norm's backward, about ten elementwise kernels and
+// reductions over N x D tensors).  16 lanes per row, 16 rows per workgroup of 256; any D <= 512 with D % 4 == 0; fp32 arithmetic,
+// bf16 tensors: the norm rounded to bf16 as in the forward, the result rounded once.
+template <int NK, bool XBF16>
+__global__ void __launch_bounds__(256) vq_l2norm_bwd_kernel(const void *x, const void *g, int64_t N, int D, int64_t ldx, int64_t ldg,
+                                                            void *out, int64_t ldo)
+{
+    const int l16 = threadIdx.x & 15;
+    const int64_t row = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
+    const bool row_ok = row < N;
+    const int64_t rowc = row_ok ? row : (N - 1);
+    float xr[NK][4], gr[NK][4];
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
+        const int d = 64 * k + 4 * l16;
+        const bool ok = d < D;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { xr[k][r] = 0.f; gr[k][r] = 0.f; }
+        if (ok) {
+            if (XBF16) {
+                const uint2 wx = *(const uint2 *)((const unsigned short *)x + rowc * ldx + d);
+                const uint2 wg = *(const uint2 *)((const unsigned short *)g + rowc * ldg + d);
+                xr[k][0] = __uint_as_float(wx.x << 16); xr[k][1] = __uint_as_float(wx.x & 0xffff0000u);
+                xr[k][2] = __uint_as_float(wx.y << 16); xr[k][3] = __uint_as_float(wx.y & 0xffff0000u);
+                gr[k][0] = __uint_as_float(wg.x << 16); gr[k][1] = __uint_as_float(wg.x & 0xffff0000u);
+                gr[k][2] = __uint_as_float(wg.y << 16); gr[k][3] = __uint_as_float(wg.y & 0xffff0000u);
+            } else {
+                const f32x4 wx = *(const f32x4 *)((const float *)x + rowc * ldx + d);
+                const f32x4 wg = *(const f32x4 *)((const float *)g + rowc * ldg + d);
+                xr[k][0] = wx.x; xr[k][1] = wx.y; xr[k][2] = wx.z; xr[k][3] = wx.w;
+                gr[k][0] = wg.x; gr[k][1] = wg.y; gr[k][2] = wg.z; gr[k][3] = wg.w;
+            }
+        }
+    }
+    float x2 = 0.f, gx = 0.f;
+#pragma unroll
+    for (int k = 0; k < NK; ++k)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            x2 = fmaf(xr[k][r], xr[k][r], x2);
+            gx = fmaf(gr[k][r], xr[k][r], gx);
+        }
+#pragma unroll
+    for (int o = 8; o >= 1; o >>= 1) {
+        x2 += __shfl_xor(x2, o, 64);
+        gx += __shfl_xor(gx, o, 64);
+    }
+    float nrm = sqrtf(x2);
+    if (XBF16) nrm = round_to_bf16(nrm);
+    const float eps = XBF16 ? round_to_bf16(1e-6f) : 1e-6f;
+    const float n = fmaxf(nrm, eps);
+    const float inv_n = 1.f / n;
+    const float coef = (nrm >= eps && nrm > 0.f) ? (gx * inv_n * inv_n) / nrm : 0.f;
+    if (!row_ok) return;
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
+        const int d = 64 * k + 4 * l16;
+        if (d >= D) continue;
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = fmaf(-xr[k][r], coef, gr[k][r] * inv_n);
+        if (XBF16) {
+            uint2 w;
+            w.x = (__float_as_uint(round_to_bf16(v[0])) >> 16) | (__float_as_uint(round_to_bf16(v[1])) & 0xffff0000u);
+            w.y = (__float_as_uint(round_to_bf16(v[2])) >> 16) | (__float_as_uint(round_to_bf16(v[3])) & 0xffff0000u);
+            *(uint2 *)((unsigned short *)out + row * ldo + d) = w;
+        } else {
+            *(f32x4 *)((float *)out + row * ldo + d) = f32x4{v[0], v[1], v[2], v[3]};
+        }
+    }
+}
+
+extern "C" int vqhip_l2norm_rows_bwd(const void *x, const void *g, int x_dtype, int64_t N, int D, int64_t ldx, int64_t ldg,
+                                     void *out, int64_t ldo, void *stream)
+{
+    if (N < 0) VQ_FAIL(VQHIP_EINVAL, "l2norm_rows_bwd: N < 0");
+    if (N == 0) return 0;
+    if (!x || !g || !out) VQ_FAIL(VQHIP_EINVAL, "l2norm_rows_bwd: null pointer");
+    if (x_dtype != VQHIP_F32 && x_dtype != VQHIP_BF16) VQ_FAIL(VQHIP_EINVAL, "l2norm_rows_bwd: unknown dtype %d", x_dtype);
+    if (D < 4 || D > 512 || (D & 3)) VQ_FAIL(VQHIP_EDIM, "l2norm_rows_bwd: D=%d unsupported (multiples of 4 up to 512)", D);
+    const int es = (x_dtype == VQHIP_BF16) ? 2 : 4;
+    const uintptr_t al = (uintptr_t)(4 * es) - 1;
+    if ((((uintptr_t)x) & al) || (((uintptr_t)g) & al) || (((uintptr_t)out) & al) || ((ldx * es) & al) || ((ldg * es) & al) || ((ldo * es) & al))
+        VQ_FAIL(VQHIP_EALIGN, "l2norm_rows_bwd: rows must be aligned to 4 elements");
+    if (ldx < D || ldg < D || ldo < D) VQ_FAIL(VQHIP_EINVAL, "l2norm_rows_bwd: row stride smaller than D");
+    const unsigned blocks = (unsigned)((N + 15) / 16);
+    hipStream_t st = (hipStream_t)stream;
+#define VQ_L2B(NKV)                                                                                                              \
+    do {                                                                                                                         \
+        if (x_dtype == VQHIP_BF16) hipLaunchKernelGGL((vq_l2norm_bwd_kernel<NKV, true>), dim3(blocks), dim3(256), 0, st, x, g, N, D, ldx, ldg, out, ldo); \
+        else hipLaunchKernelGGL((vq_l2norm_bwd_kernel<NKV, false>), dim3(blocks), dim3(256), 0, st, x, g, N, D, ldx, ldg, out, ldo); \
+    } while (0)
+    if (D <= 64) VQ_L2B(1);
+    else if (D <= 128) VQ_L2B(2);
+    else if (D <= 256) VQ_L2B(4);
+    else VQ_L2B(8);
+#undef VQ_L2B
+    return launch_status("vq_l2norm_bwd_kernel");
+}
+
 // ------------------------------------------------------------------------------------------------
 // exact pass over a LIST of rows (the rows vq_screen.hip could not certify).  Same arithmetic as
 // vq_assign_kernel<DT, bf16, euclid> -- same device functions -- but organised for a short list: the codebook sweep
@@ -3386,11 +3488,11 @@ __global__ void __launch_bounds__(256) vq_ema_embed_kernel(float *embed_avg, flo
 // tail of the fused train step: workgroups [0, ceil(C / 4)) fold embed_sum into embed_avg and renormalise embed (the kernel above),
 // the LAST workgroup reduces the commitment loss' partials (vq_reduce_kernel's arithmetic: fp64, fixed order)
 __global__ void __launch_bounds__(256) vq_step_fold_kernel(float *embed_avg, float *embed, const float *embed_sum, const float *denom,
-                                                           int C, int D, float omd, const double *__restrict__ partials, int64_t n_partials,
-                                                           double scale, float *loss_out)
+                                                           int C, int D, float omd, int cosine, const double *__restrict__ partials,
+                                                           int64_t n_partials, double scale, float *loss_out)
 {
     if (blockIdx.x + 1 < gridDim.x) {
-        ema_embed_row(embed_avg, embed, embed_sum, nullptr, denom, C, D, omd, 0, 1, 1, blockIdx.x * 4 + (threadIdx.x >> 6));
+        ema_embed_row(embed_avg, embed, embed_sum, nullptr, denom, C, D, omd, cosine, 1, 1, blockIdx.x * 4 + (threadIdx.x >> 6));
         return;
     }
     if (!loss_out) return;
@@ -3878,6 +3980,9 @@ extern "C" int vqhip_vq_train_step(const vqhip_vq_step_t *s, void *stream)
     const int D = (int)s->D, C = (int)s->C, x_dtype = (int)s->x_dtype;
     if (!s->x || !s->embed || !s->idx_out || !s->stats || !s->packed || !s->workspace) VQ_FAIL(VQHIP_EINVAL, "vq_train_step: null pointer");
     if (s->fold && (!s->embed_avg || !s->cluster_size)) VQ_FAIL(VQHIP_EINVAL, "vq_train_step: fold needs embed_avg and cluster_size");
+    if (s->metric != VQHIP_EUCLID && s->metric != VQHIP_COSINE_PRENORM)
+        VQ_FAIL(VQHIP_EINVAL, "vq_train_step: metric %d (VQHIP_EUCLID, or VQHIP_COSINE_PRENORM on rows normalised by vqhip_l2norm_rows)", (int)s->metric);
+    const int metric = (int)s->metric;
     if (!vqhip_vq_step_supported(x_dtype, N, D, C)) VQ_FAIL(VQHIP_EDIM, "vq_train_step: N=%lld D=%d C=%d dtype=%d outside the fused step", (long long)N, D, C, x_dtype);
     if (s->workspace_bytes < vqhip_vq_step_workspace_bytes(N, C)) VQ_FAIL(VQHIP_EINVAL, "vq_train_step: workspace too small");
     if ((((uintptr_t)s->workspace) & 255) || (((uintptr_t)s->stats) & 15) || (((uintptr_t)s->packed) & 15))
@@ -3902,7 +4007,7 @@ extern "C" int vqhip_vq_train_step(const vqhip_vq_step_t *s, void *stream)
 
     if (int rc = pack_codebook_impl(s->embed, C, D, s->packed, 1, stream)) return rc;
     if (s->ev_search_begin) (void)hipEventRecord((hipEvent_t)s->ev_search_begin, st);
-    if (int rc = vq_assign_screened_impl(s->x, x_dtype, N, D, s->ldx, s->packed, s->embed, C, VQHIP_EUCLID, s->idx_out, s->q_out, s->ldq,
+    if (int rc = vq_assign_screened_impl(s->x, x_dtype, N, D, s->ldx, s->packed, s->embed, C, metric, s->idx_out, s->q_out, s->ldq,
                                          nullptr, D, nullptr, nullptr, ws_screen, step_ws_screen(N), nullptr, nullptr, 1, stream)) return rc;
     if (s->ev_search_end) (void)hipEventRecord((hipEvent_t)s->ev_search_end, st);
     StatsFuse f;
@@ -3916,7 +4021,7 @@ extern "C" int vqhip_vq_train_step(const vqhip_vq_step_t *s, void *stream)
                                      ws_stats, vqhip_ema_workspace_bytes(N, C), qsrc, partials, stream, &f)) return rc;
     if (s->fold) {
         hipLaunchKernelGGL(vq_step_fold_kernel, dim3((unsigned)((C + 3) / 4 + 1)), dim3(256), 0, st, s->embed_avg, s->embed, embed_sum, denom,
-                           C, D, (float)s->one_minus_decay, partials, n_part, s->loss_scale, s->loss_out);
+                           C, D, (float)s->one_minus_decay, metric != VQHIP_EUCLID ? 1 : 0, partials, n_part, s->loss_scale, s->loss_out);
         return launch_status("vq_step_fold_kernel");
     }
     if (s->loss_out) {

@@ -98,6 +98,29 @@ class _QuantizeFn(torch.autograd.Function):
         return gx, None, None, None, None
 
 
+class _L2NormFn(torch.autograd.Function):
+    """l2norm of the input of a cosine-similarity codebook (vqp.py:37-38 at :1159) as ONE kernel each way: forward vq_l2norm_kernel
+    (bit for bit F.normalize, bf16 rounding included), backward vq_l2norm_bwd_kernel (autograd's F.normalize gradient, recomputed from
+    x -- the normalised rows are not saved for it).  F.normalize itself: a reduction and three elementwise kernels forward, about ten
+    backward, each over the N x D tensor."""
+
+    @staticmethod
+    def forward(ctx, x):
+        ctx.save_for_backward(x)
+        return L.l2norm_rows(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        return L.l2norm_rows_bwd(x, g)
+
+
+def _l2norm_input(x):
+    if L.l2norm_rows_supported(x) and os.environ.get("VQHIP_L2NORM_FN", "1") != "0":
+        return _L2NormFn.apply(x) if (x.requires_grad and torch.is_grad_enabled()) else L.l2norm_rows(x)
+    return F.normalize(x, p=2, dim=-1, eps=1e-6)
+
+
 class _RouteFn(torch.autograd.Function):
     """routed value (straight-through / rotation trick) with gradient to x only -- the target is detached inside the
     reference's formula as well (vqp.py:292-316); HIP kernels vq_route_kernel fwd / bwd."""
@@ -704,7 +727,7 @@ class VectorQuantize(nn.Module):
         # (every branch of the autograd-glue path reads xs itself -- commit loss, update_indices, init_embed_, assign_rowwise -- so it
         #  always gets the normalised rows, input with or without grad: the reference normalises first, vqp.py:1159)
         if self.use_cosine_sim and (needs_grad or param_path or (mask is not None and self.training)):
-            xs = F.normalize(xs, p=2, dim=-1, eps=1e-6)
+            xs = _l2norm_input(xs)
             pre_normalized = True
 
         kw = dict(freeze_codebook=freeze_codebook, ema_update_weight=ema_update_weight,
@@ -799,6 +822,9 @@ class VectorQuantize(nn.Module):
                 commit_loss = sq_sum / denom
             else:
                 # reference quirk (vqp.py:1319): the masked loss compares against the ORIGINAL (un-normalised) input
+                if self.heads > 1:     # ... whose [b, n, h d] does not broadcast against the heads' [h, b, n, d]: the reference raises too
+                    raise RuntimeError("masked commitment loss of a multi-headed cosine-similarity VectorQuantize: the reference's "
+                                       "mse_loss(quantize [h, b, n, d], orig_input [b, n, h d]) (vqp.py:1319) has no defined shape")
                 diff = (quantize.detach().float() - orig_input.float()) ** 2
                 commit_loss = diff[mask].mean()
             loss = loss + (commit_loss if self.commitment_weight == 1. else commit_loss * self.commitment_weight)
