@@ -935,6 +935,70 @@ def test_fused_train_step_equals_the_separate_calls(dev, monkeypatch, dtype, kw,
         b.load_state_dict(a.state_dict())
 
 
+@pytest.mark.parametrize("dtype,kw", [(torch.float32, dict(dim=64, codebook_size=300, learnable_codebook=True, ema_update=False)),
+                                      (torch.bfloat16, dict(dim=256, codebook_size=512, learnable_codebook=True, ema_update=False)),
+                                      (torch.float32, dict(dim=128, codebook_size=256, orthogonal_reg_weight=5., ema_update=False)),
+                                      (torch.float32, dict(dim=32, codebook_size=128, learnable_codebook=True, ema_update=False,
+                                                           use_cosine_sim=False, heads=4, codebook_dim=8))])
+def test_codebook_gradient_of_the_gather_is_the_per_code_sum(dev, monkeypatch, dtype, kw):
+    """A codebook that receives gradients (vqp.py:710, 766), three ways: (A) the default -- the search as on the hot path, the codes'
+    gradient = the commitment loss' closed form from one statistics pass over x in backward (_QuantizeFn with embed_param); (B) the
+    general path with `quantize` = the search's own gather and the statistics' segmented sum as its backward (_CodesOfIndicesFn);
+    (C) F.embedding and autograd throughout (round 3).  Same indices and values; losses and gradients equal to summation order."""
+    from vector_quantize_pytorch_amd import VectorQuantize
+    torch.manual_seed(0)
+    mods = [VectorQuantize(**kw).to(dev).train() for _ in range(3)]
+    for m in mods[1:]:
+        m.load_state_dict(mods[0].state_dict())
+    x = torch.randn(3, 2000, kw["dim"], device=dev).to(dtype)
+    lens = torch.tensor([2000, 700, 1500], device=dev)
+    tol = 2e-5 if dtype == torch.float32 else 2e-2
+    for use_lens in (False, True):
+        outs = []
+        for mod, (fast, fn) in zip(mods, (("1", "1"), ("0", "1"), ("0", "0"))):
+            monkeypatch.setenv("VQHIP_LEARN_FAST", fast)
+            monkeypatch.setenv("VQHIP_GATHER_FN", fn)
+            xi = x.clone().requires_grad_(True)
+            mod.zero_grad()
+            q, ind, loss = mod(xi, **(dict(lens=lens) if use_lens else {}))
+            (q.float().square().mean() + loss.sum()).backward()
+            outs.append((q, ind, loss, xi.grad, mod._codebook.embed.grad.clone()))
+        (qa, ia, la, ga, ea), (qb, ib, lb, gb, eb), (qc, ic, lc, gc, ec) = outs
+        assert torch.equal(ib, ic) and torch.equal(qb, qc) and torch.equal(lb, lc) and torch.equal(gb, gc)
+        assert ec.abs().max() > 0
+        _close(eb, ec, tol, "codebook gradient (B)")
+        assert torch.equal(ia, ic)
+        _close(qa, qc, 1e-6 if dtype == torch.float32 else 1e-2, "quantize (A)")
+        assert torch.allclose(la, lc, rtol=1e-5 if dtype == torch.float32 else 1e-2, atol=0)
+        _close(ga, gc, tol, "input gradient (A)")
+        _close(ea, ec, tol, "codebook gradient (A)")
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.float64])
+def test_float16_and_float64_inputs_compute_in_fp32_and_come_back_in_their_dtype(dev, dtype):
+    """The reference's codebook computes in float32 whatever comes in (x.float(), vqp.py:690) and returns quantize in the input's dtype
+    (:1178); the kernels take float32 / bfloat16 rows, so the other float dtypes are cast around the forward: same indices and values
+    as the float32 call, gradients arrive in the input's dtype."""
+    from vector_quantize_pytorch_amd import VectorQuantize, ResidualVQ, GroupedResidualVQ
+    torch.manual_seed(0)
+    for make, d in ((lambda: VectorQuantize(dim=64, codebook_size=256), 64), (lambda: ResidualVQ(dim=64, num_quantizers=3, codebook_size=128), 64),
+                    (lambda: GroupedResidualVQ(dim=64, groups=2, num_quantizers=2, codebook_size=64), 64)):
+        a, b = make().to(dev).train(), make().to(dev).train()
+        b.load_state_dict(a.state_dict())
+        x = torch.randn(2, 500, d, device=dev).to(dtype)
+        xa, xb = x.clone().requires_grad_(True), x.float().requires_grad_(True)
+        qa, ia, la = a(xa)[:3]
+        qb, ib, lb = b(xb)[:3]
+        assert qa.dtype == dtype and torch.equal(ia, ib) and torch.equal(qa, qb.to(dtype)) and torch.equal(la, lb)
+        qa.float().square().sum().backward()          # (sum, not mean: a 1 / numel gradient underflows float16)
+        qb.float().square().sum().backward()
+        assert xa.grad.dtype == dtype
+        _close(xa.grad, xb.grad, 2e-3 if dtype == torch.float16 else 1e-6, "input gradient")
+    vq = make().to(dev).eval()
+    out = vq(x, return_all_codes=True)
+    assert out[0].dtype == dtype and out[3].dtype == dtype
+
+
 @pytest.mark.parametrize("kw", [dict(codebook_diversity_loss_weight=0.5, codebook_diversity_temperature=10.),
                                 dict(straight_through=True, rotation_trick=False, sample_codebook_temp=0.5),
                                 dict(stochastic_sample_codes=True, sample_codebook_temp=0., codebook_diversity_loss_weight=0.1,

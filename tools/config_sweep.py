@@ -1,0 +1,79 @@
+"""Dev tool: one training step (forward, and forward + backward with an input that requires grad) of VectorQuantize under the options
+people combine it with, at cfg-2 size (2^20 rows, D = 256, C = 1024) -- to find the options whose glue costs more than the search.
+    python tools/config_sweep.py [rows_log2]"""
+import os, sys, time, torch
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from vector_quantize_pytorch_amd import VectorQuantize, ResidualVQ
+
+LOG2 = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+B, T = 64, (1 << LOG2) // 64
+dev = torch.device("cuda:0")
+CASES = [
+    ("plain bf16", dict(dim=256, codebook_size=1024), torch.bfloat16, {}),
+    ("plain fp32", dict(dim=256, codebook_size=1024), torch.float32, {}),
+    ("fp16 rows", dict(dim=256, codebook_size=1024), torch.float16, {}),
+    ("cosine bf16", dict(dim=256, codebook_size=1024, use_cosine_sim=True), torch.bfloat16, {}),
+    ("dead-code expiry (threshold 2) bf16", dict(dim=256, codebook_size=1024, threshold_ema_dead_code=2), torch.bfloat16, {}),
+    ("eval bf16", dict(dim=256, codebook_size=1024), torch.bfloat16, dict(eval=True)),
+    ("lens mask bf16", dict(dim=256, codebook_size=1024), torch.bfloat16, dict(lens=True)),
+    ("codebook_dim 32 (projections) fp32", dict(dim=256, codebook_size=1024, codebook_dim=32), torch.float32, {}),
+    ("8 heads x 32 shared codebook fp32", dict(dim=256, codebook_size=1024, heads=8), torch.float32, {}),
+    ("8 heads x 32 separate codebooks fp32", dict(dim=256, codebook_size=1024, heads=8, separate_codebook_per_head=True), torch.float32, {}),
+    ("learnable codebook, no EMA fp32", dict(dim=256, codebook_size=1024, learnable_codebook=True, ema_update=False), torch.float32, {}),
+    ("orthogonal reg fp32", dict(dim=256, codebook_size=1024, orthogonal_reg_weight=10.), torch.float32, {}),
+    ("rotation trick off (STE) bf16", dict(dim=256, codebook_size=1024, rotation_trick=False), torch.bfloat16, {}),
+    ("image fmap fp32", dict(dim=256, codebook_size=1024, accept_image_fmap=True), torch.float32, dict(fmap=True)),
+    ("channel_last=False fp32", dict(dim=256, codebook_size=1024, channel_last=False), torch.float32, dict(chan_first=True)),
+    ("commitment_weight 0 bf16", dict(dim=256, codebook_size=1024, commitment_weight=0.), torch.bfloat16, {}),
+    ("ResidualVQ 4 stages, quantize_dropout fp32", dict(dim=256, codebook_size=1024, num_quantizers=4, quantize_dropout=True), torch.float32,
+     dict(rvq=True)),
+]
+
+
+def tm(fn, n=8):
+    for _ in range(3):
+        fn()
+    best = 1e9
+    for _ in range(3):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        best = min(best, (time.perf_counter() - t0) / n * 1e3)
+    return best
+
+
+for name, kw, dt, opt in CASES:
+    try:
+        torch.manual_seed(0)
+        mod = (ResidualVQ(**kw) if opt.get("rvq") else VectorQuantize(**kw)).to(dev)
+        mod = mod.eval() if opt.get("eval") else mod.train()
+        if opt.get("fmap"):
+            shape = (B, 256, 128, T // 128)
+        elif opt.get("chan_first"):
+            shape = (B, 256, T)
+        else:
+            shape = (B, T, 256)
+        x = torch.randn(*shape, device=dev).to(dt)
+        call_kw = {}
+        if opt.get("lens"):
+            call_kw["lens"] = torch.randint(T // 2, T + 1, (B,), device=dev)
+        res = {}
+        for grad in (False, True):
+            xi = x.clone().requires_grad_(grad)
+            gq = torch.randn_like(x)
+
+            def step():
+                out = mod(xi, **call_kw)
+                if grad:
+                    torch.autograd.backward((out[0], out[2].sum()), (gq, None))
+                    xi.grad = None
+            with torch.set_grad_enabled(grad):
+                res[grad] = tm(step)
+            if opt.get("eval"):
+                break
+        print(f"{name:48s} forward {res[False]:7.3f} ms" + (f"   forward + backward {res[True]:7.3f} ms" if True in res else ""), flush=True)
+    except Exception as e:
+        print(f"{name:48s} FAILED {type(e).__name__}: {str(e)[:200]}", flush=True)
+    del mod, x
+    torch.cuda.empty_cache()

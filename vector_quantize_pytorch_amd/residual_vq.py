@@ -18,7 +18,7 @@ import torch.distributed as dist
 from torch import Tensor, nn
 
 from . import _lib as L
-from .vector_quantize import VectorQuantize
+from .vector_quantize import VectorQuantize, other_float_dtypes_as_fp32
 
 
 def _round_up(n, m):
@@ -195,6 +195,7 @@ class ResidualVQ(nn.Module):
             summed = self.get_codes_from_indices(indices).sum(0)
         return self.project_out(summed)
 
+    @other_float_dtypes_as_fp32
     def forward(
         self,
         x,
@@ -635,6 +636,7 @@ class GroupedResidualVQ(nn.Module):
     def get_output_from_indices(self, indices):
         return torch.cat(tuple(r.get_output_from_indices(i) for r, i in zip(self.rvqs, indices)), dim=self.split_dim)
 
+    @other_float_dtypes_as_fp32
     def forward(self, x, indices=None, return_all_codes=False, sample_codebook_temp=None, freeze_codebook=False, mask=None):
         if indices is not None and len(indices) > 0:
             raise NotImplementedError("forward(indices=) is not on the MI355X hot path (SURVEY.md §8f)")

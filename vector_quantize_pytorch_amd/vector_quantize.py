@@ -45,9 +45,13 @@ class _QuantizeFn(torch.autograd.Function):
     Only x and q are saved; u, qh, w, s are recomputed in the backward kernel."""
 
     @staticmethod
-    def forward(ctx, x, vq, mask, kw, loss_scale=1.0):
+    def forward(ctx, x, vq, mask, kw, loss_scale=1.0, embed_param=None):
         """loss_scale: constant folded into the squared-error reduction (1 / numel for the unmasked commit loss), so that the
-        third output IS mean((q - x)^2) without further elementwise kernels"""
+        third output IS mean((q - x)^2) without further elementwise kernels.
+        embed_param [1, C, D]: a codebook that receives gradients (learnable_codebook / the output of vq_bridge; vqp.py:710, 766) --
+        searched as given; its gradient is that of the commitment loss mean((codes[idx] - x)^2) with `quantize` NOT detached
+        (vqp.py:1214, 1327): g_loss * 2 * loss_scale * (count_c * codes_c - sum of the rows quantized to c), i.e. the EMA statistics
+        of x (one vqhip_ema_accumulate in backward) -- the routed output itself carries no gradient to the codes (vqp.py:282-318)."""
         cb = vq._codebook
         mode = 0
         if vq.training and x.requires_grad and vq.route_gradients_to_input:
@@ -58,7 +62,10 @@ class _QuantizeFn(torch.autograd.Function):
         # cfg-2 step in each direction.
         gather = (mode != 0 and x.ndim == 3 and cb.num_codebooks == 1 and cb._is_initted() and not cb.affine_param
                   and x.is_contiguous() and x.dtype in (torch.float32, torch.bfloat16))
-        codes = cb.embed[0].detach().to(x.dtype, copy=True) if gather else None
+        src = cb.embed if embed_param is None else embed_param
+        codes = src[0].detach().to(x.dtype, copy=True) if gather else None
+        if embed_param is not None:
+            kw = dict(kw, embed_override=embed_param.detach())
         r = cb.quantize(x, mask=mask, want_sqerr=vq.training and vq.has_commitment_loss, loss_scale=float(loss_scale),
                         **(dict(kw, want_q=False) if gather else kw))
         q, idx = r["q"], r["idx"]
@@ -75,7 +82,11 @@ class _QuantizeFn(torch.autograd.Function):
         ctx.mode = mode
         ctx.gather = gather
         ctx.has_mask = mask is not None
-        ctx.save_for_backward(x, *((codes, idx) if gather else (q,)), *([mask] if mask is not None else []))
+        ctx.has_embed = embed_param is not None and embed_param.requires_grad
+        extra = []
+        if ctx.has_embed:     # (a snapshot: dead-code replacement may rewrite rows of the parameter in place before backward runs)
+            extra = [idx, embed_param[0].detach().float().clone()]
+        ctx.save_for_backward(x, *((codes, idx) if gather else (q,)), *([mask] if mask is not None else []), *extra)
         ctx.mark_non_differentiable(idx)
         if loss_sum is None:
             loss_sum = torch.zeros((), dtype=torch.float32, device=x.device)
@@ -85,17 +96,42 @@ class _QuantizeFn(torch.autograd.Function):
     def backward(ctx, g_out, g_idx, g_loss):
         tensors = ctx.saved_tensors
         x = tensors[0]
+        g_embed = None
+        if ctx.has_embed:
+            idx_e, codes_e = tensors[-2:]
+            tensors = tensors[:-2]
+            if g_loss is not None:
+                C = codes_e.shape[0]
+                count, esum = L.ema_accumulate(x, idx_e.reshape(-1), C, row_mask=tensors[-1] if ctx.has_mask else None)
+                g_embed = ((count[:, None] * codes_e - esum) * (2.0 * ctx.loss_scale * g_loss.to(torch.float32)))[None]
         mask = tensors[-1] if ctx.has_mask else None
         use_g = ctx.mode != 0 and g_out is not None
         if not use_g and g_loss is None:
-            return None, None, None, None, None
+            return None, None, None, None, None, g_embed
         if g_loss is not None and ctx.loss_scale != 1.0:
             g_loss = g_loss * ctx.loss_scale
         if ctx.gather:
             gx = L.route_bwd_gather(x, tensors[1], tensors[2], g_out.contiguous() if use_g else None, g_loss, mask, ctx.mode if use_g else 0)
         else:
             gx = L.route_bwd(x, tensors[1], g_out.contiguous() if use_g else None, g_loss, mask, ctx.mode if use_g else 0)
-        return gx, None, None, None, None
+        return gx, None, None, None, None, g_embed
+
+
+def other_float_dtypes_as_fp32(forward):
+    """The kernels take float32 and bfloat16 rows.  The reference's codebook computes in float32 whatever comes in (`x.float()`,
+    vqp.py:690) and hands `quantize` back in the input's dtype (`.type(dtype)`, :1178): float16 / float64 inputs do exactly that here,
+    around the whole forward."""
+    import functools
+
+    @functools.wraps(forward)
+    def wrapped(self, x, *args, **kwargs):
+        if torch.is_tensor(x) and x.is_floating_point() and x.dtype not in (torch.float32, torch.bfloat16):
+            out = forward(self, x.float(), *args, **kwargs)
+            # (quantize, indices, loss[, all_codes of the residual modules | LossBreakdown]): the code tensors go back to x's dtype
+            back = lambda t: t.to(x.dtype) if torch.is_tensor(t) and t.is_floating_point() and t.ndim >= 3 else t
+            return (out[0].to(x.dtype), out[1], out[2], *(back(t) for t in out[3:]))
+        return forward(self, x, *args, **kwargs)
+    return wrapped
 
 
 class _L2NormFn(torch.autograd.Function):
@@ -119,6 +155,25 @@ def _l2norm_input(x):
     if L.l2norm_rows_supported(x) and os.environ.get("VQHIP_L2NORM_FN", "1") != "0":
         return _L2NormFn.apply(x) if (x.requires_grad and torch.is_grad_enabled()) else L.l2norm_rows(x)
     return F.normalize(x, p=2, dim=-1, eps=1e-6)
+
+
+class _CodesOfIndicesFn(torch.autograd.Function):
+    """codes[idx] for a codebook that receives gradients (learnable_codebook / vq_bridge; vqp.py:710, 766).  The VALUE is the gather the
+    search already wrote (`q`, rows of the codebook as it was searched); the gradient to the codebook is the per-code sum of the
+    incoming rows -- the EMA statistics' counting sort + segmented sum (vqhip_ema_accumulate), instead of F.embedding's backward behind
+    an extra gather and two elementwise passes in forward."""
+
+    @staticmethod
+    def forward(ctx, codes, idx, q):
+        ctx.save_for_backward(idx)
+        ctx.C, ctx.dt = codes.shape[0], codes.dtype
+        return q.view_as(q)
+
+    @staticmethod
+    def backward(ctx, g):
+        (idx,) = ctx.saved_tensors
+        _, esum = L.ema_accumulate(g.contiguous(), idx.reshape(-1), ctx.C)
+        return esum.to(ctx.dt), None, None
 
 
 class _RouteFn(torch.autograd.Function):
@@ -496,9 +551,12 @@ class VectorQuantize(nn.Module):
                 r = cb.quantize(xs.detach(), mask=rmask, embed_override=embed_eff, update_usage=update_usage, **kw)
                 # value: the rows of the PRE-update codebook (the EMA fold inside quantize() runs after the gather, like
                 # vqp.py:766 vs :783); gradient: that of a gather from the parameter (vqp.py:710, 766)
+                if not (embed_eff.requires_grad and torch.is_grad_enabled()):
+                    return r["q"], r["idx"], None
+                if xs.dtype in (torch.float32, torch.bfloat16) and xs.shape[-1] <= 512 and os.environ.get("VQHIP_GATHER_FN", "1") != "0":
+                    return _CodesOfIndicesFn.apply(embed_eff[0], r["idx"], r["q"]), r["idx"], None
                 g = F.embedding(r["idx"], embed_eff[0]).to(xs.dtype)
-                q = r["q"] + (g - g.detach()) if embed_eff.requires_grad else r["q"]
-                return q, r["idx"], None
+                return r["q"] + (g - g.detach()), r["idx"], None
             if not cb._is_initted():
                 cb.init_embed_(xs.detach().reshape(1, -1, xs.shape[-1]).float(), None if rmask is None else rmask.reshape(1, -1))
             if topk_only and L.topk_supported(xs, topk, embed_eff.shape[-2]):
@@ -651,6 +709,7 @@ class VectorQuantize(nn.Module):
                     state_dict[key] = t[:, sh.lo:sh.hi]
         super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
 
+    @other_float_dtypes_as_fp32
     def forward(
         self,
         x,
@@ -722,8 +781,18 @@ class VectorQuantize(nn.Module):
         ce_only = ((return_loss or self.commitment_use_cross_entropy_loss) and not need_matrix and codebook_transform_fn is None
                    and self.in_place_codebook_optimizer is None)
         dense = need_matrix or ((return_loss or self.commitment_use_cross_entropy_loss) and not ce_only)
-        param_path = (self._codebook.learnable_codebook or self._codebook.vq_bridge is not None or self.directional_reparam or dense
-                      or ce_only or codebook_transform_fn is not None)
+        # A codebook that receives gradients, in the plain training configuration (input with grad, routed output, MSE commitment):
+        # the only gradient that reaches the codes is the commitment loss', which is a function of the EMA statistics of x -- the
+        # search runs as on the hot path and _QuantizeFn.backward adds one statistics pass (no N x D autograd glue)
+        cb_ = self._codebook
+        learn_fast = ((cb_.learnable_codebook or cb_.vq_bridge is not None) and needs_grad and self.route_gradients_to_input
+                      and not self.directional_reparam and not dense and not ce_only and codebook_transform_fn is None
+                      and self.sync_update_v == 0. and self.in_place_codebook_optimizer is None and self.has_commitment_loss
+                      and not freeze_codebook and not cb_.affine_param and not cb_.use_ddp and cb_.embed.dtype == torch.float32
+                      and xs.dtype in (torch.float32, torch.bfloat16) and xs.shape[-1] <= 512 and xs.is_cuda
+                      and os.environ.get("VQHIP_LEARN_FAST", "1") != "0")
+        param_path = not learn_fast and (self._codebook.learnable_codebook or self._codebook.vq_bridge is not None or self.directional_reparam
+                                         or dense or ce_only or codebook_transform_fn is not None)
         # (every branch of the autograd-glue path reads xs itself -- commit loss, update_indices, init_embed_, assign_rowwise -- so it
         #  always gets the normalised rows, input with or without grad: the reference normalises first, vqp.py:1159)
         if self.use_cosine_sim and (needs_grad or param_path or (mask is not None and self.training)):
@@ -749,7 +818,12 @@ class VectorQuantize(nn.Module):
                 transform_fn=codebook_transform_fn)
         else:
             fold = (mask is None and self.training and self.has_commitment_loss)     # sq_sum then already is the mean
-            quantize, embed_ind, sq_sum = _QuantizeFn.apply(xs, self, rmask, kw, 1.0 / float(max(xs.numel(), 1)) if fold else 1.0)
+            embed_param = None
+            if learn_fast:
+                embed_param = cb_.embed if cb_.vq_bridge is None else cb_.vq_bridge(cb_.embed)              # [H, C, D], requires grad
+                if not self.learnable_codebook:      # (orthogonal regularisation alone makes the CODEBOOK learnable, vqp.py:939, but the
+                    embed_param = embed_param.detach()   # commitment loss detaches `quantize` unless the module's own flag is set, :1214)
+            quantize, embed_ind, sq_sum = _QuantizeFn.apply(xs, self, rmask, kw, 1.0 / float(max(xs.numel(), 1)) if fold else 1.0, embed_param)
 
         # ---- loss (vqp.py:1282-1348) --------------------------------------------------------------
         # the reference's loss starts as a leaf that requires grad in training (vqp.py:1282).  Here: a cached CONSTANT zero per
@@ -801,18 +875,6 @@ class VectorQuantize(nn.Module):
                 else:
                     commit_loss = F.mse_loss(commit_quantize, xs)
                 loss = loss + commit_loss * self.commitment_weight
-            if self.has_codebook_orthogonal_loss:                                     # vqp.py:1331-1348, 340-345
-                codebook = self._codebook.embed
-                if self.orthogonal_reg_active_codes_only:
-                    codebook = codebook[:, torch.unique(embed_ind)]
-                ncodes = codebook.shape[-2]
-                if self.orthogonal_reg_max_codes is not None and ncodes > self.orthogonal_reg_max_codes:
-                    codebook = codebook[:, torch.randperm(ncodes, device=x.device)[:self.orthogonal_reg_max_codes]]
-                normed = F.normalize(codebook, p=2, dim=-1, eps=1e-6)
-                cos = torch.einsum('hid,hjd->hij', normed, normed)
-                h_, n_ = codebook.shape[:2]
-                orth_loss = (cos ** 2).sum() / (h_ * n_ ** 2) - (1 / n_)
-                loss = loss + orth_loss * self.orthogonal_reg_weight
         elif self.training and self.has_commitment_loss:
             d = xs.shape[-1]
             if mask is None:
@@ -828,6 +890,19 @@ class VectorQuantize(nn.Module):
                 diff = (quantize.detach().float() - orig_input.float()) ** 2
                 commit_loss = diff[mask].mean()
             loss = loss + (commit_loss if self.commitment_weight == 1. else commit_loss * self.commitment_weight)
+
+        if self.training and self.has_codebook_orthogonal_loss:                                     # vqp.py:1331-1348, 340-345
+            codebook = self._codebook.embed
+            if self.orthogonal_reg_active_codes_only:
+                codebook = codebook[:, torch.unique(embed_ind)]
+            ncodes = codebook.shape[-2]
+            if self.orthogonal_reg_max_codes is not None and ncodes > self.orthogonal_reg_max_codes:
+                codebook = codebook[:, torch.randperm(ncodes, device=x.device)[:self.orthogonal_reg_max_codes]]
+            normed = F.normalize(codebook, p=2, dim=-1, eps=1e-6)
+            cos = torch.einsum('hid,hjd->hij', normed, normed)
+            h_, n_ = codebook.shape[:2]
+            orth_loss = (cos ** 2).sum() / (h_ * n_ ** 2) - (1 / n_)
+            loss = loss + orth_loss * self.orthogonal_reg_weight
 
         if self.training:
             if loss is anchor:
