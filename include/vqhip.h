@@ -256,6 +256,13 @@ int vqhip_ema_finalize_batched(float *cluster_size, float *embed_avg, float *emb
                                int H, int C, int D, float one_minus_decay, float eps, int cosine, int do_update_ema,
                                float *denom_ws, void *stream);
 
+/* ---- channel-first layouts ------------------------------------------------------------------------
+ * `channel_last = False` / `accept_image_fmap` callers hand over [b, d, n] and the reference rearranges to [b, n, d] and back
+ * (vqp.py:1136-1147, 1375-1384).  in [B, R, S] with the batches in_bstride >= R * S elements apart (a channel group of a wider
+ * map: GroupedResidualVQ) -> out [B, S, R] contiguous, elements of 2 or 4 bytes copied as bits; 16-byte accesses on both sides when
+ * R, S and in_bstride are multiples of 16 / elem_bytes and the pointers 16-byte aligned.  B <= 65535. */
+int vqhip_transpose_batched(const void *in, void *out, int elem_bytes, int64_t B, int64_t R, int64_t S, int64_t in_bstride, void *stream);
+
 /* ---- fused train step ---------------------------------------------------------------------------
  * One call = one training forward of an EMA codebook (VectorQuantize.forward in training mode, vqp.py:1176 ->
  * Codebook.forward :673-800; use_cosine_sim: rows normalised by the caller as at :1157-1159, dot-product scores :740-741):

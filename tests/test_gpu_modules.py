@@ -974,6 +974,86 @@ def test_codebook_gradient_of_the_gather_is_the_per_code_sum(dev, monkeypatch, d
         _close(ea, ec, tol, "codebook gradient (A)")
 
 
+@pytest.mark.parametrize("kw,shape", [(dict(dim=64, codebook_size=128, channel_last=False), (3, 64, 700)),
+                                      (dict(dim=32, codebook_size=64, accept_image_fmap=True), (2, 32, 24, 20)),
+                                      (dict(dim=128, codebook_size=256, channel_last=False, use_cosine_sim=True), (2, 128, 512)),
+                                      (dict(dim=64, codebook_size=128, channel_last=False, codebook_dim=16), (2, 64, 300))])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_channel_first_inputs_through_the_transposing_copy(dev, monkeypatch, kw, shape, dtype):
+    """channel_last = False / feature maps (vqp.py:1136-1147, 1375-1384): rows come from one tiled transposing copy, the output's
+    gradient arrives through the same kernel, the input's gradient leaves as a contiguous channel-first tensor -- bit for bit what
+    ATen's strided copies give (VQHIP_TRANSPOSE=0)."""
+    from vector_quantize_pytorch_amd import VectorQuantize
+    if dtype == torch.bfloat16 and "codebook_dim" in kw:
+        pytest.skip("projection weights are float32")
+    torch.manual_seed(0)
+    a, b = VectorQuantize(**kw).to(dev).train(), VectorQuantize(**kw).to(dev).train()
+    b.load_state_dict(a.state_dict())
+    x = torch.randn(*shape, device=dev).to(dtype)
+    gq = torch.randn(*shape, device=dev).to(dtype)
+    res = []
+    for mod, flag in ((a, "1"), (b, "0")):
+        monkeypatch.setenv("VQHIP_TRANSPOSE", flag)
+        xi = x.clone().requires_grad_(True)
+        q, ind, loss = mod(xi)
+        torch.autograd.backward((q, loss.sum()), (gq, None))
+        res.append((q, ind, loss, xi.grad))
+    (qa, ia, la, ga), (qb, ib, lb, gb) = res
+    assert qa.shape == x.shape and ga.is_contiguous()
+    if "codebook_dim" in kw:       # (the projection GEMM reads a contiguous operand now: another rocBLAS kernel, other rounding)
+        assert (ia != ib).float().mean().item() < 1e-3 and torch.allclose(la, lb, rtol=1e-4)
+        _close(ga, gb, 1e-3, "input gradient")
+    else:
+        assert torch.equal(ia, ib) and torch.equal(qa, qb) and torch.equal(la, lb) and torch.equal(ga, gb)
+
+
+@pytest.mark.parametrize("grouped", [False, True])
+@pytest.mark.parametrize("kw", [dict(num_quantizers=4, codebook_size=128), dict(num_quantizers=3, codebook_size=64, shared_codebook=True),
+                                dict(num_quantizers=3, codebook_size=64, rotation_trick=False, threshold_ema_dead_code=2)])
+def test_residual_vq_on_a_feature_map_runs_the_rows_loop_once(dev, grouped, kw):
+    """ResidualVQ / GroupedResidualVQ(accept_image_fmap=True) (rvq.py: every layer rearranges the map to rows and back): the rows are
+    formed once and the fused loop runs on them -- same indices, values, losses and input gradient as the module without the flag on
+    the rows 'b d h w -> b (h w) d', indices shaped [b, h, w, q]; and as the per-stage path on the map (eval, where both are exact)."""
+    from vector_quantize_pytorch_amd import ResidualVQ, GroupedResidualVQ
+    torch.manual_seed(0)
+    cls, extra = (GroupedResidualVQ, dict(groups=2)) if grouped else (ResidualVQ, {})
+    a = cls(dim=64, accept_image_fmap=True, **extra, **kw).to(dev).train()
+    b = cls(dim=64, **extra, **kw).to(dev).train()
+    b.load_state_dict(a.state_dict())
+    for step in range(2):
+        x = torch.randn(2, 64, 12, 20, device=dev)
+        xa = x.clone().requires_grad_(step == 1)
+        xb = x.flatten(2).transpose(1, 2).contiguous().requires_grad_(step == 1)
+        rng = torch.cuda.get_rng_state(dev)
+        qa, ia, la = a(xa)
+        torch.cuda.set_rng_state(rng, dev)
+        qb, ib, lb = b(xb)
+        assert qa.shape == x.shape
+        if grouped:
+            assert ia.shape == (2, 2, 12, 20, kw["num_quantizers"]) and torch.equal(ia.reshape(2, 2, 240, -1), ib)
+        else:
+            assert ia.shape == (2, 12, 20, kw["num_quantizers"]) and torch.equal(ia.reshape(2, 240, -1), ib)
+        assert torch.equal(qa.flatten(2).transpose(1, 2), qb)
+        assert torch.allclose(la, lb, rtol=1e-5, atol=0)       # (the statistics pass sums a code's rows in the order its scatter left them)
+        if step == 1:
+            gq = torch.randn_like(x)
+            torch.autograd.backward((qa, la.sum()), (gq, None))
+            torch.autograd.backward((qb, lb.sum()), (gq.flatten(2).transpose(1, 2).contiguous(), None))
+            assert torch.equal(xa.grad.flatten(2).transpose(1, 2), xb.grad)
+        b.load_state_dict(a.state_dict())
+    a.eval()
+    x = torch.randn(2, 64, 12, 20, device=dev)
+    q1, i1, _ = a(x)
+    rvqs = a.rvqs if grouped else [a]
+    saved = [r._fused_eligible for r in rvqs]
+    for r in rvqs:
+        r._fused_eligible = lambda *ar, **k: False                 # the per-stage path: every layer rearranges the map itself
+    q2, i2, _ = a(x)
+    for r, f in zip(rvqs, saved):
+        r._fused_eligible = f
+    assert torch.equal(i1, i2) and torch.allclose(q1, q2, rtol=0, atol=1e-6)
+
+
 @pytest.mark.parametrize("dtype", [torch.float16, torch.float64])
 def test_float16_and_float64_inputs_compute_in_fp32_and_come_back_in_their_dtype(dev, dtype):
     """The reference's codebook computes in float32 whatever comes in (x.float(), vqp.py:690) and returns quantize in the input's dtype

@@ -530,6 +530,30 @@ def test_l2norm_rows_matches_reference_arithmetic(dev, N, D, dtype):
     assert torch.equal(L.l2norm_rows(x.to(dev)).cpu(), _l2norm_ref(x))
 
 
+@pytest.mark.parametrize("B,R,S,dtype", [(3, 256, 1024, torch.float32), (3, 256, 1024, torch.bfloat16), (2, 64, 128, torch.float32),
+                                         (5, 100, 333, torch.float32), (5, 100, 333, torch.bfloat16), (1, 7, 5, torch.float32),
+                                         (2, 130, 260, torch.bfloat16), (4, 32, 4096, torch.float16), (2, 512, 72, torch.float32),
+                                         (1, 2, 70000, torch.int32)])
+def test_transposing_copy_is_the_contiguous_copy_of_a_transposed_view(dev, B, R, S, dtype):
+    """vqhip_transpose_batched ([B, R, S] -> [B, S, R], channel-first callers: vqp.py:1136-1147) moves bits: equal to ATen's
+    .contiguous() of the transposed view for full tiles (16-byte accesses) and ragged / unaligned shapes (guarded element path),
+    4- and 2-byte elements, also from a view with a storage offset."""
+    from vector_quantize_pytorch_amd import _lib as L
+    g = torch.Generator().manual_seed(4)
+    base = torch.randint(-30000, 30000, (B + 1, R, S), generator=g)
+    base = base.to(dtype) if dtype == torch.int32 else (base.float() / 7).to(dtype)
+    for t in (base[:B].to(dev), base.to(dev)[1:]):
+        v = t.transpose(1, 2)
+        assert L.is_transposed_view(v)
+        out = L.transpose_rows(v)
+        assert out.is_contiguous() and out.shape == v.shape and torch.equal(out, v.contiguous())
+        assert L.rows_contiguous(v).is_contiguous() and L.rows_contiguous(out) is out
+    assert not L.is_transposed_view(base.to(dev)[:, :, ::2].transpose(1, 2))
+    if R >= 8:                                                  # a channel group of a wider map: batches further apart than R * S
+        grp = base.to(dev)[:, R // 4:R // 4 + R // 2].transpose(1, 2)
+        assert L.is_transposed_view(grp) and torch.equal(L.transpose_rows(grp), grp.contiguous())
+
+
 @pytest.mark.parametrize("N,D,dtype", [(4099, 256, torch.bfloat16), (1000, 128, torch.float32), (333, 64, torch.bfloat16),
                                        (2048, 256, torch.float32), (700, 32, torch.float32), (515, 512, torch.float32),
                                        (515, 512, torch.bfloat16)])

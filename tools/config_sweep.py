@@ -17,13 +17,17 @@ CASES = [
     ("eval bf16", dict(dim=256, codebook_size=1024), torch.bfloat16, dict(eval=True)),
     ("lens mask bf16", dict(dim=256, codebook_size=1024), torch.bfloat16, dict(lens=True)),
     ("codebook_dim 32 (projections) fp32", dict(dim=256, codebook_size=1024, codebook_dim=32), torch.float32, {}),
-    ("8 heads x 32 shared codebook fp32", dict(dim=256, codebook_size=1024, heads=8), torch.float32, {}),
-    ("8 heads x 32 separate codebooks fp32", dict(dim=256, codebook_size=1024, heads=8, separate_codebook_per_head=True), torch.float32, {}),
+    ("8 heads x 32 shared codebook fp32", dict(dim=256, codebook_size=1024, heads=8, codebook_dim=32), torch.float32, {}),
+    ("8 heads x 32 separate codebooks fp32", dict(dim=256, codebook_size=1024, heads=8, codebook_dim=32, separate_codebook_per_head=True),
+     torch.float32, {}),
     ("learnable codebook, no EMA fp32", dict(dim=256, codebook_size=1024, learnable_codebook=True, ema_update=False), torch.float32, {}),
     ("orthogonal reg fp32", dict(dim=256, codebook_size=1024, orthogonal_reg_weight=10.), torch.float32, {}),
     ("rotation trick off (STE) bf16", dict(dim=256, codebook_size=1024, rotation_trick=False), torch.bfloat16, {}),
     ("image fmap fp32", dict(dim=256, codebook_size=1024, accept_image_fmap=True), torch.float32, dict(fmap=True)),
     ("channel_last=False fp32", dict(dim=256, codebook_size=1024, channel_last=False), torch.float32, dict(chan_first=True)),
+    ("ResidualVQ 4 stages on a feature map fp32", dict(dim=256, codebook_size=1024, num_quantizers=4, accept_image_fmap=True), torch.float32,
+     dict(rvq=True, fmap=True)),
+    ("ResidualVQ 4 stages channel-last fp32", dict(dim=256, codebook_size=1024, num_quantizers=4), torch.float32, dict(rvq=True)),
     ("commitment_weight 0 bf16", dict(dim=256, codebook_size=1024, commitment_weight=0.), torch.bfloat16, {}),
     ("ResidualVQ 4 stages, quantize_dropout fp32", dict(dim=256, codebook_size=1024, num_quantizers=4, quantize_dropout=True), torch.float32,
      dict(rvq=True)),

@@ -67,6 +67,8 @@ def lib():
     L.vqhip_assign_screened.argtypes = [vp, i32, i64, i32, i64, vp, vp, i32, i32, vp, vp, i64, vp, i64, vp, vp, vp, ctypes.c_size_t, vp, vp]
     L.vqhip_l2norm_rows.argtypes = [vp, i32, i64, i32, i64, vp, i64, vp]
     L.vqhip_l2norm_rows_bwd.argtypes = [vp, vp, i32, i64, i32, i64, i64, vp, i64, vp]
+    L.vqhip_transpose_batched.argtypes = [vp, vp, i32, i64, i64, i64, i64, vp]
+    L.vqhip_transpose_batched.restype = i32
     L.vqhip_l2norm_rows_bwd.restype = i32
     L.vqhip_screen_chain_supported.argtypes = [i32, i32]
     L.vqhip_screen_chain_supported.restype = i32
@@ -143,7 +145,7 @@ def lib():
 
 EXPORTS = ("vqhip_version", "vqhip_last_error", "vqhip_packed_bytes", "vqhip_pack_codebook",
            "vqhip_assign_blocks", "vqhip_assign", "vqhip_screen_supported", "vqhip_screen_workspace_bytes",
-           "vqhip_screen_blocks", "vqhip_screen_partials", "vqhip_assign_screened", "vqhip_screen_chain_supported", "vqhip_assign_screened_chain", "vqhip_l2norm_rows", "vqhip_l2norm_rows_bwd", "vqhip_scores", "vqhip_rvq_forward", "vqhip_reduce_partials", "vqhip_reduce_partials_rows", "vqhip_ema_fold_many", "vqhip_ema_workspace_bytes", "vqhip_ema_accumulate", "vqhip_ema_sqerr_partials", "vqhip_ema_accumulate_sqerr",
+           "vqhip_screen_blocks", "vqhip_screen_partials", "vqhip_assign_screened", "vqhip_screen_chain_supported", "vqhip_assign_screened_chain", "vqhip_l2norm_rows", "vqhip_l2norm_rows_bwd", "vqhip_transpose_batched", "vqhip_scores", "vqhip_rvq_forward", "vqhip_reduce_partials", "vqhip_reduce_partials_rows", "vqhip_ema_fold_many", "vqhip_ema_workspace_bytes", "vqhip_ema_accumulate", "vqhip_ema_sqerr_partials", "vqhip_ema_accumulate_sqerr",
            "vqhip_ema_finalize", "vqhip_decode_sum", "vqhip_row_sumsq", "vqhip_assign_rowwise", "vqhip_score_indices", "vqhip_topk", "vqhip_expire_scatter", "vqhip_kmeans_update", "vqhip_route_fwd", "vqhip_route_bwd", "vqhip_rvq_route", "vqhip_ema_renormalize_shard", "vqhip_scores_lse",
            "vqhip_pack_best", "vqhip_unpack_best", "vqhip_vq_step_supported", "vqhip_vq_step_workspace_bytes", "vqhip_vq_train_step", "vqhip_route_residual",
            "vqhip_pack_codebook_batched", "vqhip_screen_batched_ws_stride", "vqhip_assign_screened_batched", "vqhip_assign_batched",
@@ -439,6 +441,33 @@ def l2norm_rows(x: torch.Tensor) -> torch.Tensor:
     if N > 0:
         _check(lib().vqhip_l2norm_rows(_ptr(xk), _dtype_code(xk), N, D, ldx, _ptr(out), D, _stream()), "vqhip_l2norm_rows")
     return out
+
+
+def is_transposed_view(t: torch.Tensor) -> bool:
+    """t [B, n, d] whose memory is a [B, d, n] tensor with contiguous [d, n] planes (x.transpose(1, 2), a flattened feature map
+    'b d (h w)' transposed, a channel group of one): the layout a channel-first caller's input, and the gradient of its output, arrive in"""
+    return (t.ndim == 3 and t.is_cuda and t.element_size() in (2, 4) and t.numel() > 0 and t.shape[0] <= 65535
+            and t.stride(1) == 1 and t.stride(2) == t.shape[1] and (t.shape[0] == 1 or t.stride(0) >= t.shape[1] * t.shape[2])
+            and t.shape[1] > 1 and t.shape[2] > 1)
+
+
+def transpose_rows(t: torch.Tensor) -> torch.Tensor:
+    """contiguous copy of a transposed view (is_transposed_view): ONE tiled transposing kernel (vqhip_transpose_batched)"""
+    _need_gpu(t)
+    B, n, d = t.shape
+    out = torch.empty(B, n, d, dtype=t.dtype, device=t.device)
+    _check(lib().vqhip_transpose_batched(_ptr(t), _ptr(out), t.element_size(), B, d, n, t.stride(0) if B > 1 else d * n, _stream()),
+           "vqhip_transpose_batched")
+    return out
+
+
+def rows_contiguous(t: torch.Tensor) -> torch.Tensor:
+    """t.contiguous(), through the transposing kernel when t is a transposed view of a channel-first tensor"""
+    if t.is_contiguous():
+        return t
+    if is_transposed_view(t) and os.environ.get("VQHIP_TRANSPOSE", "1") != "0":
+        return transpose_rows(t)
+    return t.contiguous()
 
 
 def l2norm_rows_supported(x: torch.Tensor) -> bool:

@@ -18,7 +18,7 @@ import torch.distributed as dist
 from torch import Tensor, nn
 
 from . import _lib as L
-from .vector_quantize import VectorQuantize, other_float_dtypes_as_fp32
+from .vector_quantize import VectorQuantize, _rows_of, other_float_dtypes_as_fp32
 
 
 def _round_up(n, m):
@@ -224,9 +224,20 @@ class ResidualVQ(nn.Module):
             if self.quantize_dropout_multiple_of != 1:
                 drop_at = _round_up(drop_at + 1, self.quantize_dropout_multiple_of) - 1
 
+        # Feature maps (rvq.py: every layer is built with accept_image_fmap and rearranges 'b d h w -> b (h w) d' and back, Q times
+        # each way): the residual arithmetic is row-wise, so the rows are formed ONCE (one tiled transposing copy), the stages run on
+        # them as for a channel-last input -- on the fused loop -- and output and indices go back to the map's shape as views.
+        fmap = None
+        if (self.accept_image_fmap and x.ndim >= 4 and not is_beam and not self.has_projections and mask is None
+                and self._fused_eligible(x.flatten(2).transpose(1, 2), mask, rows_of_fmap=True)):
+            fmap, x_map = x.shape[2:], x
+            x = _rows_of(x.flatten(2).transpose(1, 2))
+            if self._wants_input_grad(x) and self._route_mode() != 0 and not self._chain_eligible(x, freeze_codebook):
+                fmap, x = None, x_map                                  # (the per-stage path takes the map itself)
+
         if is_beam:
             quantized_out, all_indices, all_losses = self._forward_beam(x, mask, sample_codebook_temp, freeze_codebook, beam_size, drop_at)
-        elif self._fused_eligible(x, mask) and not (self._wants_input_grad(x) and self._route_mode() != 0
+        elif self._fused_eligible(x, mask, rows_of_fmap=fmap is not None) and not (self._wants_input_grad(x) and self._route_mode() != 0
                                                     and not self._chain_eligible(x, freeze_codebook)):
             if self._wants_input_grad(x):
                 # the same on-device loop, gradients to the input in closed form (one kernel forward, one backward).  With
@@ -245,16 +256,20 @@ class ResidualVQ(nn.Module):
             quantized_out = x + torch.nn.functional.normalize(noised, p=2, dim=-1, eps=1e-6).detach() * err.norm(dim=-1, keepdim=True)
 
         quantized_out = self.project_out(quantized_out)
+        if fmap is not None:
+            b = quantized_out.shape[0]
+            quantized_out = quantized_out.transpose(1, 2).reshape(b, -1, *fmap)
+            all_indices = all_indices.reshape(b, *fmap, all_indices.shape[-1])
         ret = (quantized_out, all_indices, all_losses)
         if return_all_codes:
             ret = (*ret, self.get_codes_from_indices(ret[1]))
         return ret
 
     # ---- fused on-device residual loop (csrc: vq_rvq_kernel) -----------------------------------------
-    def _fused_eligible(self, x, mask):
+    def _fused_eligible(self, x, mask, rows_of_fmap=False):
         vq0 = self.layers[0]
         cb0 = vq0._codebook
-        if vq0.use_cosine_sim or not self.uniform_codebook_size or self.accept_image_fmap:
+        if vq0.use_cosine_sim or not self.uniform_codebook_size or (self.accept_image_fmap and not rows_of_fmap):
             return False
         if self.codebook_dim % 32 != 0 or x.ndim != 3 or x.dtype not in (torch.float32, torch.bfloat16):
             return False
@@ -574,7 +589,7 @@ class _RvqFusedFn(torch.autograd.Function):
         use_g = ctx.mode != 0 and g_out is not None
         if not use_g and coef is None:
             return None, None, None, None, None
-        gx = L.rvq_route(x, embed, idx, ctx.Q, ctx.mode, g_out=g_out.contiguous() if use_g else None,
+        gx = L.rvq_route(x, embed, idx, ctx.Q, ctx.mode, g_out=L.rows_contiguous(g_out) if use_g else None,
                          loss_coef=coef, row_mask=mask, backward=True, resid_routed=True, loss_only=not use_g)
         return gx, None, None, None, None
 

@@ -111,9 +111,9 @@ class _QuantizeFn(torch.autograd.Function):
         if g_loss is not None and ctx.loss_scale != 1.0:
             g_loss = g_loss * ctx.loss_scale
         if ctx.gather:
-            gx = L.route_bwd_gather(x, tensors[1], tensors[2], g_out.contiguous() if use_g else None, g_loss, mask, ctx.mode if use_g else 0)
+            gx = L.route_bwd_gather(x, tensors[1], tensors[2], L.rows_contiguous(g_out) if use_g else None, g_loss, mask, ctx.mode if use_g else 0)
         else:
-            gx = L.route_bwd(x, tensors[1], g_out.contiguous() if use_g else None, g_loss, mask, ctx.mode if use_g else 0)
+            gx = L.route_bwd(x, tensors[1], L.rows_contiguous(g_out) if use_g else None, g_loss, mask, ctx.mode if use_g else 0)
         return gx, None, None, None, None, g_embed
 
 
@@ -157,6 +157,27 @@ def _l2norm_input(x):
     return F.normalize(x, p=2, dim=-1, eps=1e-6)
 
 
+class _RowsOfChannelFirstFn(torch.autograd.Function):
+    """[b, n, d] rows of a channel-first input (a transposed VIEW of [b, d, n]: channel_last = False, feature maps; vqp.py:1136-1147) as
+    one tiled transposing copy each way (vq_transpose_kernel); the gradient goes back as a view of a contiguous [b, d, n] tensor, the
+    layout the caller's tensor has."""
+
+    @staticmethod
+    def forward(ctx, xt):
+        return L.transpose_rows(xt)
+
+    @staticmethod
+    def backward(ctx, g):
+        return L.transpose_rows(g.contiguous().transpose(1, 2)).transpose(1, 2)
+
+
+def _rows_of(x):
+    """x.contiguous() for a [b, n, d] view whose last dim is strided"""
+    if L.is_transposed_view(x) and os.environ.get("VQHIP_TRANSPOSE", "1") != "0":
+        return _RowsOfChannelFirstFn.apply(x) if (x.requires_grad and torch.is_grad_enabled()) else L.transpose_rows(x)
+    return x.contiguous()
+
+
 class _CodesOfIndicesFn(torch.autograd.Function):
     """codes[idx] for a codebook that receives gradients (learnable_codebook / vq_bridge; vqp.py:710, 766).  The VALUE is the gather the
     search already wrote (`q`, rows of the codebook as it was searched); the gradient to the codebook is the per-code sum of the
@@ -172,7 +193,7 @@ class _CodesOfIndicesFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         (idx,) = ctx.saved_tensors
-        _, esum = L.ema_accumulate(g.contiguous(), idx.reshape(-1), ctx.C)
+        _, esum = L.ema_accumulate(L.rows_contiguous(g), idx.reshape(-1), ctx.C)
         return esum.to(ctx.dt), None, None
 
 
@@ -189,7 +210,7 @@ class _RouteFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         x, q = ctx.saved_tensors
-        return L.route_bwd(x, q, g.contiguous(), None, None, ctx.mode), None, None
+        return L.route_bwd(x, q, L.rows_contiguous(g), None, None, ctx.mode), None, None
 
 
 class _CrossEntropyFn(torch.autograd.Function):
@@ -759,6 +780,8 @@ class VectorQuantize(nn.Module):
 
         spatial = x.shape[2:] if (self.accept_image_fmap or self.accept_3d_fmap) else None
         x = self._to_rows_layout(x, check_mask=mask)
+        if not x.is_contiguous() and x.stride(-1) != 1:
+            x = _rows_of(x)                                                   # channel-first callers: one transposing copy
         x = self.project_in(x)
         b, n = x.shape[0], x.shape[1]
         xs = self._split_heads(x)                                             # [b,n,d] | [(b h),n,d] | [h,b,n,d]
