@@ -137,8 +137,10 @@ int vqhip_assign_batched(const void *x, int x_dtype, int H, int64_t N, int D, in
  * x - prev_embed[prev_idx] in fp32 (exactly the x - q the previous stage would have written), from the PREVIOUS stage's input x
  * and indices, and stores it to x_out, where the exact passes of this stage (and the caller's statistics pass) read it -- so no
  * stage re-reads its input to write a residual.  prev_idx == NULL: plain search of x (first stage); idx_stride lets every stage
- * write its column of an [N, Q] index tensor.  fp32 rows, D in {32, 64, 128, 256}, Euclidean (vqhip_screen_chain_supported);
- * no q / residual / squared-error outputs (the statistics pass sums the loss: vqhip_ema_accumulate_sqerr). */
+ * write its column of an [N, Q] index tensor.  A chained stage (prev_idx given): fp32 rows, D in {32, 64, 128, 256}
+ * (vqhip_screen_chain_supported); with prev_idx == NULL any rows vqhip_assign_screened takes (bf16, D = 512: the stages of a loop
+ * whose inputs vqhip_route_residual wrote).  Euclidean; no q / residual / squared-error outputs (the statistics pass sums the loss:
+ * vqhip_ema_accumulate_sqerr). */
 typedef struct {
     int64_t idx_stride;            /* idx_out[n * idx_stride] */
     const int64_t *prev_idx;       /* nullable: previous stage's indices, prev_idx[n * prev_idx_stride] */
@@ -229,10 +231,11 @@ int vqhip_route_bwd_gather(const void *x, const void *codes, const int64_t *idx,
                            int64_t N, int D, int64_t ldx, int64_t ldg, const float *loss_coef, const uint8_t *row_mask,
                            int mode, void *grad_x, int64_t ldo, void *stream);
 
-/* out[n] = x[n] - route(x[n], embed[idx[n * idx_stride]]) for fp32 rows: the input of the next ResidualVQ stage when the layer returned
- * the ROUTED value (`residual - quantized.detach()`, rvq.py:524, in a training step whose input requires grad, vqp.py:1225-1233).
- * mode 1 / 2 and arithmetic as vqhip_route_fwd (bit for bit).  embed [C, D] fp32 contiguous. */
-int vqhip_route_residual(const void *x, int64_t N, int D, int64_t ldx, const float *embed, const int64_t *idx, int64_t idx_stride,
+/* out[n] = x[n] - route(x[n], codes[idx[n * idx_stride]]): the input of the next ResidualVQ stage when the layer returned the ROUTED
+ * value (`residual - quantized.detach()`, rvq.py:524, in a training step whose input requires grad, vqp.py:1225-1233).
+ * mode 1 / 2 and arithmetic as vqhip_route_fwd (bit for bit; bf16 rows: the routed value rounded to bf16 -- the tensor the layer
+ * returned -- then the difference).  x, out, codes [C, D] contiguous: in `dtype` (for bf16 rows the bf16 copy of the code rows). */
+int vqhip_route_residual(const void *x, int dtype, int64_t N, int D, int64_t ldx, const void *codes, const int64_t *idx, int64_t idx_stride,
                          int mode, void *out, int64_t ldo, void *stream);
 
 /* sum of `n` doubles times `scale` -> one fp32 (commit loss = scale * sum of partials). */
@@ -273,7 +276,7 @@ int vqhip_transpose_batched(const void *in, void *out, int elem_bytes, int64_t B
  * separate calls: one zeroing kernel for every counter / accumulator, cluster_size folded inside the statistics' scan kernel,
  * embed_avg / embed / loss in one tail kernel (12 launches, was 19).
  * fold == 0 stops after the statistics (data parallel: all-reduce `stats`, then vqhip_ema_finalize).
- * Requirements: vqhip_vq_step_supported(); x rows 16-byte aligned; no row mask; no dead-code replacement inside (caller's). */
+ * Requirements: vqhip_vq_step_supported(); x rows 16-byte aligned; no dead-code replacement inside (caller's). */
 typedef struct {
     const void *x; int64_t x_dtype; int64_t N; int64_t D; int64_t ldx;
     float *embed; float *embed_avg; float *cluster_size; int64_t C;       /* [C, D], [C, D], [C]; updated in place when fold != 0 */
@@ -291,6 +294,9 @@ typedef struct {
     int64_t metric;                                                       /* VQHIP_EUCLID, or VQHIP_COSINE_PRENORM: x holds unit-norm rows
                                                                              (vqhip_l2norm_rows, vqp.py:1159) of a cosine codebook -- the
                                                                              fold then l2-normalises embed (vqp.py:581-582) */
+    const uint8_t *row_mask;                                              /* nullable [N]: rows with 0 (padding: `mask` / `lens`,
+                                                                             vqp.py:108-110, 599-601) are searched and gathered like the
+                                                                             others but leave the statistics and the loss alone */
 } vqhip_vq_step_t;
 int vqhip_vq_step_supported(int x_dtype, int64_t N, int D, int C);
 size_t vqhip_vq_step_workspace_bytes(int64_t N, int C);

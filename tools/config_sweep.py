@@ -5,7 +5,9 @@ import os, sys, time, torch
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from vector_quantize_pytorch_amd import VectorQuantize, ResidualVQ
 
-LOG2 = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+RVQ_SWEEP = "--rvq" in sys.argv            # the residual modules' options at cfg-3 size (2^18 rows, 8 stages) instead
+args = [a for a in sys.argv[1:] if a != "--rvq"]
+LOG2 = int(args[0]) if args else (18 if RVQ_SWEEP else 20)
 B, T = 64, (1 << LOG2) // 64
 dev = torch.device("cuda:0")
 CASES = [
@@ -32,6 +34,25 @@ CASES = [
     ("ResidualVQ 4 stages, quantize_dropout fp32", dict(dim=256, codebook_size=1024, num_quantizers=4, quantize_dropout=True), torch.float32,
      dict(rvq=True)),
 ]
+if RVQ_SWEEP:
+    R = dict(dim=256, num_quantizers=8, codebook_size=1024)
+    CASES = [
+        ("shared codebook fp32 (cfg 3)", dict(R, shared_codebook=True), torch.float32, dict(rvq=True)),
+        ("separate codebooks fp32", dict(R), torch.float32, dict(rvq=True)),
+        ("separate codebooks bf16", dict(R), torch.bfloat16, dict(rvq=True)),
+        ("dead-code expiry (threshold 2) fp32", dict(R, threshold_ema_dead_code=2), torch.float32, dict(rvq=True)),
+        ("shared codebook + dead-code expiry fp32", dict(R, shared_codebook=True, threshold_ema_dead_code=2), torch.float32, dict(rvq=True)),
+        ("cosine fp32", dict(R, use_cosine_sim=True), torch.float32, dict(rvq=True)),
+        ("cosine + expiry fp32", dict(R, use_cosine_sim=True, threshold_ema_dead_code=2), torch.float32, dict(rvq=True)),
+        ("quantize_dropout fp32", dict(R, quantize_dropout=True, quantize_dropout_cutoff_index=2), torch.float32, dict(rvq=True)),
+        ("rotation trick off (STE) fp32", dict(R, rotation_trick=False), torch.float32, dict(rvq=True)),
+        ("codebook_dim 64 (projections) fp32", dict(R, codebook_dim=64), torch.float32, dict(rvq=True)),
+        ("lens mask fp32", dict(R), torch.float32, dict(rvq=True, mask=True)),
+        ("eval fp32", dict(R), torch.float32, dict(rvq=True, eval=True)),
+        ("eval, return_all_codes fp32", dict(R), torch.float32, dict(rvq=True, eval=True, all_codes=True)),
+        ("dim 512, 4 stages fp32", dict(dim=512, num_quantizers=4, codebook_size=1024), torch.float32, dict(rvq=True, dim=512)),
+        ("feature map fp32", dict(R, accept_image_fmap=True), torch.float32, dict(rvq=True, fmap=True)),
+    ]
 
 
 def tm(fn, n=8):
@@ -52,14 +73,19 @@ for name, kw, dt, opt in CASES:
         torch.manual_seed(0)
         mod = (ResidualVQ(**kw) if opt.get("rvq") else VectorQuantize(**kw)).to(dev)
         mod = mod.eval() if opt.get("eval") else mod.train()
+        dim = opt.get("dim", 256)
         if opt.get("fmap"):
-            shape = (B, 256, 128, T // 128)
+            shape = (B, 256, 64, T // 64)
         elif opt.get("chan_first"):
             shape = (B, 256, T)
         else:
-            shape = (B, T, 256)
+            shape = (B, T, dim)
         x = torch.randn(*shape, device=dev).to(dt)
         call_kw = {}
+        if opt.get("mask"):
+            call_kw["mask"] = torch.arange(T, device=dev)[None, :] < torch.randint(T // 2, T + 1, (B,), device=dev)[:, None]
+        if opt.get("all_codes"):
+            call_kw["return_all_codes"] = True
         if opt.get("lens"):
             call_kw["lens"] = torch.randint(T // 2, T + 1, (B,), device=dev)
         res = {}

@@ -128,7 +128,7 @@ def lib():
     L.vqhip_ema_accumulate_batched.restype = i32
     L.vqhip_ema_finalize_batched.argtypes = [vp, vp, vp, vp, i64, i32, i32, i32, f32, f32, i32, i32, vp, vp]
     L.vqhip_ema_finalize_batched.restype = i32
-    L.vqhip_route_residual.argtypes = [vp, i64, i32, i64, vp, vp, i64, i32, vp, i64, vp]
+    L.vqhip_route_residual.argtypes = [vp, i32, i64, i32, i64, vp, vp, i64, i32, vp, i64, vp]
     L.vqhip_route_residual.restype = i32
     L.vqhip_vq_step_supported.argtypes = [i32, i64, i32, i32]
     L.vqhip_vq_step_supported.restype = i32
@@ -502,15 +502,19 @@ class _Chain(ctypes.Structure):          # vqhip_chain_t (include/vqhip.h)
                 ("header_zeroed", ctypes.c_int64)]
 
 
-def rvq_chain_supported(x: torch.Tensor, C: int) -> bool:
-    """can the residual loop run as a chain (every stage forms its input in its own prologue: vqhip_assign_screened_chain)?"""
-    if not (x.is_cuda and x.dtype == torch.float32 and screening_enabled() and os.environ.get("VQHIP_RVQ_CHAIN", "1") != "0"):
+def rvq_chain_supported(x: torch.Tensor, C: int, routed=False) -> bool:
+    """can the residual loop run as a chain (every stage forms its input in its own prologue: vqhip_assign_screened_chain)?
+    routed: the loop of a training step whose input requires grad -- every stage's input is written by vqhip_route_residual and
+    searched like a first stage, so bf16 rows and D = 512 qualify as well."""
+    if not (x.is_cuda and x.dtype in ((torch.float32, torch.bfloat16) if routed else (torch.float32,)) and screening_enabled()
+            and os.environ.get("VQHIP_RVQ_CHAIN", "1") != "0"):
         return False
     if os.environ.get("VQHIP_SCREEN_VERIFY", "0") == "1" or screen_debug:
         return False            # the paranoia / debug switches live in assign(): stage-by-stage loop
     xk, N, D, ldx = as_rows(x)
-    return bool(N > 0 and lib().vqhip_screen_chain_supported(_dtype_code(xk), D) and lib().vqhip_screen_supported(N, D, C)
-                and xk.data_ptr() % 16 == 0 and (ldx * 4) % 16 == 0)
+    es = xk.element_size()
+    return bool(N > 0 and (routed or lib().vqhip_screen_chain_supported(_dtype_code(xk), D)) and lib().vqhip_screen_supported(N, D, C)
+                and xk.data_ptr() % 16 == 0 and (ldx * es) % 16 == 0)
 
 
 @_on_device
@@ -529,15 +533,18 @@ def rvq_forward_chained(x: torch.Tensor, packed: torch.Tensor, embed: torch.Tens
     xk, N, D, ldx = as_rows(x)
     lead, dev = x.shape[:-1], x.device
     C = embed.shape[-2]
-    assert embed.dtype == torch.float32 and embed.is_contiguous() and xk.dtype == torch.float32
+    assert embed.dtype == torch.float32 and embed.is_contiguous()
+    assert xk.dtype == torch.float32 or (route_mode and xk.dtype == torch.bfloat16), "chained stages: float32 rows"
+    dt = _dtype_code(xk)
     idx = torch.empty(N, Q, dtype=torch.int64, device=dev)
-    bufs = torch.empty(max(Q - 1, 1), N, D, dtype=torch.float32, device=dev)
+    bufs = torch.empty(max(Q - 1, 1), N, D, dtype=xk.dtype, device=dev)
     if row_mask is not None:
         row_mask = row_mask.reshape(-1).to(torch.uint8).contiguous()
     nws = lib().vqhip_screen_workspace_bytes(N)
     nws4 = (nws + 15) // 16 * 4                       # ints per stage, 16-byte granules
     ws_all = torch.empty(Q, nws4, dtype=torch.int32, device=dev)
     ws_all[:, :4].zero_()                             # the Q list headers in ONE launch (a 16-byte memset per stage cost 13 us of gaps each)
+    codes = embed if xk.dtype == torch.float32 else embed.to(xk.dtype)      # (bf16 rows: the routing kernel gathers bf16 code rows)
     inputs, counts = [x], []
     for q in range(Q):
         ws = ws_all[q]
@@ -547,9 +554,9 @@ def rvq_forward_chained(x: torch.Tensor, packed: torch.Tensor, embed: torch.Tens
             # the previous layer returned its ROUTED value (rotation trick / straight-through on an input that requires grad) and
             # rvq.py:524 subtracted THAT: an HBM-bound kernel of its own (vqhip_route_residual) writes this stage's input, which
             # the search then reads like a first stage's
-            prev_e = embed if shared else embed[q - 1]
+            prev_c = codes if shared else codes[q - 1]
             psrc, plds = (xk, ldx) if q == 1 else (bufs[q - 2], D)
-            _check(lib().vqhip_route_residual(_ptr(psrc), N, D, plds, _ptr(prev_e), ctypes.c_void_p(idx.data_ptr() + 8 * (q - 1)), Q,
+            _check(lib().vqhip_route_residual(_ptr(psrc), dt, N, D, plds, _ptr(prev_c), ctypes.c_void_p(idx.data_ptr() + 8 * (q - 1)), Q,
                                               int(route_mode), _ptr(bufs[q - 1]), D, _stream()), "vqhip_route_residual")
             src, lds = bufs[q - 1], D
         elif q > 0:
@@ -559,7 +566,7 @@ def rvq_forward_chained(x: torch.Tensor, packed: torch.Tensor, embed: torch.Tens
             ch.x_out = bufs[q - 1].data_ptr()
             if q > 1:
                 src, lds = bufs[q - 2], D
-        _check(lib().vqhip_assign_screened_chain(_ptr(src), F32, N, D, lds, _ptr(packed if shared else packed[q]),
+        _check(lib().vqhip_assign_screened_chain(_ptr(src), dt, N, D, lds, _ptr(packed if shared else packed[q]),
                                                  _ptr(embed if shared else embed[q]), C, EUCLID,
                                                  ctypes.c_void_p(idx.data_ptr() + 8 * q), _ptr(row_mask), _ptr(ws), nws,
                                                  ctypes.byref(ch), _stream()), "vqhip_assign_screened_chain")
@@ -852,7 +859,8 @@ class _Step(ctypes.Structure):           # vqhip_vq_step_t (include/vqhip.h)
                 ("stats", ctypes.c_void_p), ("loss_out", ctypes.c_void_p), ("loss_scale", ctypes.c_double),
                 ("packed", ctypes.c_void_p), ("workspace", ctypes.c_void_p), ("workspace_bytes", ctypes.c_size_t),
                 ("one_minus_decay", ctypes.c_double), ("eps", ctypes.c_double), ("fold", ctypes.c_int64),
-                ("ev_search_begin", ctypes.c_void_p), ("ev_search_end", ctypes.c_void_p), ("metric", ctypes.c_int64)]
+                ("ev_search_begin", ctypes.c_void_p), ("ev_search_end", ctypes.c_void_p), ("metric", ctypes.c_int64),
+                ("row_mask", ctypes.c_void_p)]
 
 
 step_event_hook = None   # bench.py: callable -> (begin, end) torch.cuda.Event pair (already recorded once, so that their handles exist),
@@ -872,14 +880,17 @@ def vq_step_supported(x: torch.Tensor, C: int) -> bool:
 
 @_on_device
 def vq_train_step(x: torch.Tensor, embed, embed_avg, cluster_size, *, decay, eps, want_q=True, q_out=None, loss_scale=None, fold=True,
-                  cosine=False):
+                  cosine=False, row_mask=None):
     """One training forward of an EMA codebook (Euclidean, or cosine=True on rows already unit-norm: l2norm_rows) in one library call (vqhip_vq_train_step; reference: vqp.py:673-800 under
     VectorQuantize.forward :1176).  embed / embed_avg / cluster_size: [C, D], [C, D], [C] fp32, updated in place when fold.
     -> dict(q, idx, count [C], embed_sum [C, D] (views of one [C D + C] buffer: one all-reduce), loss (0-dim fp32 or None))"""
-    _need_gpu(x, embed, embed_avg, cluster_size)
+    _need_gpu(x, embed, embed_avg, cluster_size, row_mask)
     xk, N, D, ldx = as_rows(x)
     C = embed.shape[0]
     dev = x.device
+    if row_mask is not None:
+        row_mask = row_mask.reshape(-1).to(torch.uint8).contiguous()
+        assert row_mask.numel() == N
     for t in (embed, embed_avg, cluster_size):
         assert t.is_contiguous() and t.dtype == torch.float32
     idx = torch.empty(N, dtype=torch.int64, device=dev)
@@ -897,7 +908,7 @@ def vq_train_step(x: torch.Tensor, embed, embed_avg, cluster_size, *, decay, eps
                cluster_size=cluster_size.data_ptr(), C=C, idx_out=idx.data_ptr(), q_out=None if q is None else q.data_ptr(), ldq=D,
                stats=stats.data_ptr(), loss_out=None if loss is None else loss.data_ptr(), loss_scale=float(loss_scale or 0.0),
                packed=packed.data_ptr(), workspace=ws.data_ptr(), workspace_bytes=nws, one_minus_decay=omd, eps=float(eps), fold=int(bool(fold)),
-               metric=COSINE_PRENORM if cosine else EUCLID)
+               metric=COSINE_PRENORM if cosine else EUCLID, row_mask=None if row_mask is None else row_mask.data_ptr())
     if step_event_hook is not None:
         e0, e1 = step_event_hook()
         st.ev_search_begin, st.ev_search_end = e0.cuda_event, e1.cuda_event
@@ -1002,8 +1013,9 @@ def assign_rowwise(x: torch.Tensor, codes: torch.Tensor, cosine=False) -> torch.
 
 
 @_on_device
-def decode_sum(idx: torch.Tensor, embed: torch.Tensor, out_dtype=torch.float32) -> torch.Tensor:
-    """idx [..., Q] int64, embed [Q, C, D] or [C, D] (shared by all Q) -> [..., D] = sum_q embed_q[idx_q]."""
+def decode_sum(idx: torch.Tensor, embed: torch.Tensor, out_dtype=torch.float32, out=None) -> torch.Tensor:
+    """idx [..., Q] int64, embed [Q, C, D] or [C, D] (shared by all Q) -> [..., D] = sum_q embed_q[idx_q].
+    out (optional): a contiguous [..., D] tensor to write, e.g. one slice of a stacked [Q, ..., D] result."""
     _need_gpu(idx, embed)
     assert idx.dtype == torch.int64 and embed.dtype == torch.float32 and embed.is_contiguous()
     idx = idx.contiguous()
@@ -1016,7 +1028,11 @@ def decode_sum(idx: torch.Tensor, embed: torch.Tensor, out_dtype=torch.float32) 
         _, C, D = embed.shape
         qstride = C * D
     N = idx.numel() // Q
-    out = torch.empty(*idx.shape[:-1], D, dtype=out_dtype, device=idx.device)
+    if out is None:
+        out = torch.empty(*idx.shape[:-1], D, dtype=out_dtype, device=idx.device)
+    else:
+        out_dtype = out.dtype
+        assert out.is_contiguous() and out.numel() == N * D and out_dtype in (torch.float32, torch.bfloat16) and out.device == idx.device
     if N > 0:
         _check(lib().vqhip_decode_sum(_ptr(idx), N, Q, _ptr(embed), qstride, C, D, _ptr(out),
                                       F32 if out_dtype == torch.float32 else BF16, D, _stream()), "vqhip_decode_sum")

@@ -403,7 +403,7 @@ class Codebook(nn.Module):
                 x_stats = ((flat - self.batch_mean) * (cstd / bstd) + self.codebook_mean).reshape(xs.shape)
         # the whole training forward of the plain case as ONE library call (vqhip_vq_train_step): pack, search, statistics, the
         # commitment loss' squared error and -- without a collective in between -- the EMA fold
-        if (H == 1 and do_update and want_sqerr and loss_scale is not None and rmask is None and ema_update
+        if (H == 1 and do_update and want_sqerr and loss_scale is not None and ema_update
                 and not self.affine_param and embed_override is None and ema_update_weight is None and not accum_ema_update
                 and not self.manual_ema_update and self.cluster_size.grad is None and self.embed.dtype == torch.float32
                 and L.vq_step_supported(xs[0], C)):
@@ -412,11 +412,11 @@ class Codebook(nn.Module):
             if self.use_cosine_sim and not input_normalized:    # vqp.py:1157-1159 (the loss below then compares with the unit-norm rows,
                 x0 = L.l2norm_rows(x0)                          #  as the reference's does)
             r = L.vq_train_step(x0, e, ea, cs, decay=self.decay, eps=self.eps, want_q=want_q, q_out=q_out, loss_scale=loss_scale,
-                                fold=not self.use_ddp, cosine=self.use_cosine_sim)
+                                fold=not self.use_ddp, cosine=self.use_cosine_sim, row_mask=rmask)
             if self.use_ddp:
                 dist.all_reduce(r["stats"])   # ONE collective for count || embed_sum (RCCL over xGMI), then the fold
                 self._fold_stats(0, r["count"], r["embed_sum"], None, False, ema_update)
-            self.expire_codes_(xs.reshape(H, -1, self.dim), seq_mask=None)
+            self.expire_codes_(xs.reshape(H, -1, self.dim), seq_mask=None if rmask is None else rmask[None].bool())
             return dict(q=r["q"], idx=r["idx"], sqerr_partials=None, nblk=0, rnorm=None, loss=r["loss"], n_exact=r["n_exact"], n_pair=r["n_pair"])
         outs = []
         # Several heads with their own codebooks (vqp.py:1044-1049; the reference runs them as one batched einsum over h): ONE set of

@@ -1067,7 +1067,7 @@ __global__ void __launch_bounds__(VQS_F32_WAVES * 64, (XBF16 && NPART == 1 && DT
         const bool pair = !certified && ((b1 - b3) > thr) && code < a.C && id2 < a.C;
         flagged = !certified;
         if (row_ok && half == 0) {
-            a.idx_out[row] = (int64_t)(code < a.C ? code : 0);
+            a.idx_out[row * a.idx_stride] = (int64_t)(code < a.C ? code : 0);
             if (a.dbg) {
                 float *d = a.dbg + row * 4;
                 d[0] = b1 * iSS; d[1] = b2 * iSS; d[2] = thr * iSS; d[3] = certified ? 0.f : (pair ? 2.f : 1.f);
@@ -1306,7 +1306,10 @@ extern "C" int vqhip_assign_screened_chain(const void *x, int x_dtype, int64_t N
                                            void *workspace, size_t workspace_bytes, const vqhip_chain_t *chain, void *stream)
 {
     if (!chain) VQ_FAIL(VQHIP_EINVAL, "assign_screened_chain: chain is null");
-    if (!vqhip_screen_chain_supported(x_dtype, D)) VQ_FAIL(VQHIP_EINVAL, "assign_screened_chain: fp32 rows, D in {32, 64, 128, 256} only");
+    // (without a previous stage to subtract -- prev_idx null -- this is the plain screened search with the chain's index stride: any
+    //  rows the screen takes, e.g. the bf16 / D = 512 stages of a residual loop whose inputs vqhip_route_residual wrote)
+    if (chain->prev_idx && !vqhip_screen_chain_supported(x_dtype, D))
+        VQ_FAIL(VQHIP_EINVAL, "assign_screened_chain: a chained stage takes fp32 rows, D in {32, 64, 128, 256} only");
     if (metric != VQHIP_EUCLID) VQ_FAIL(VQHIP_EINVAL, "assign_screened_chain: Euclidean metric only");
     if (chain->idx_stride < 1) VQ_FAIL(VQHIP_EINVAL, "assign_screened_chain: idx_stride < 1");
     if (chain->prev_idx) {

@@ -2442,9 +2442,9 @@ __global__ void __launch_bounds__(256) vq_route_kernel(const RouteArgs a)
     float r[NE];
     if (!BWD) {
         vq_route_value<NE, LPR, BF16>(e, qv, a.mode, r);            // vq_route_math.h (mode 1 / 2)
-        if (!BF16 && a.sub) {
+        if (a.sub) {                                                  // the next stage's input: residual - quantized.detach() (rvq.py:524);
 #pragma unroll
-            for (int k = 0; k < NE; ++k) r[k] = e[k] - r[k];          // the next stage's input: residual - quantized.detach() (rvq.py:524)
+            for (int k = 0; k < NE; ++k) r[k] = e[k] - (BF16 ? round_to_bf16(r[k]) : r[k]);   // bf16: `quantized` is a bf16 tensor
         }
     } else if (a.mode == 2 && a.g) {
         float u[NE], qh[NE], w[NE], sc;
@@ -2498,20 +2498,23 @@ extern "C" int vqhip_route_fwd(const void *x, const void *q, int dtype, int64_t 
 
 // The residual a ResidualVQ stage hands to the next one when its layer returned the ROUTED value (training with an input that
 // requires grad: `residual = residual - quantized.detach()`, rvq.py:524 with vqp.py:1225-1233): out = x - route(x, embed[idx]),
-// the arithmetic of vqhip_route_fwd / vqhip_rvq_route bit for bit (vq_route_math.h), fp32 rows.  An HBM-bound kernel of its own at
+// the arithmetic of vqhip_route_fwd / vqhip_rvq_route bit for bit (vq_route_math.h; bf16 rows: the routed value rounded to bf16 as
+// the tensor the layer returned, then the difference); codes [C, D] in the rows' dtype.  An HBM-bound kernel of its own at
 // full occupancy: inside the screening kernel's prologue (round 4's first form) the row reductions ran on 256-register waves and
 // doubled that kernel's time (459 vs 217 us per cfg-3 stage).
-extern "C" int vqhip_route_residual(const void *x, int64_t N, int D, int64_t ldx, const float *embed, const int64_t *idx,
+extern "C" int vqhip_route_residual(const void *x, int dtype, int64_t N, int D, int64_t ldx, const void *codes, const int64_t *idx,
                                     int64_t idx_stride, int mode, void *out, int64_t ldo, void *stream)
 {
-    if (!x || !embed || !idx || !out) VQ_FAIL(VQHIP_EINVAL, "route_residual: null pointer");
+    if (!x || !codes || !idx || !out) VQ_FAIL(VQHIP_EINVAL, "route_residual: null pointer");
+    if (dtype != VQHIP_F32 && dtype != VQHIP_BF16) VQ_FAIL(VQHIP_EINVAL, "route_residual: unknown dtype");
     if (N < 0 || D < 1 || D > 512 || idx_stride < 1) VQ_FAIL(VQHIP_EINVAL, "route_residual: bad size");
     if (mode != 1 && mode != 2) VQ_FAIL(VQHIP_EINVAL, "route_residual: mode must be 1 (straight-through) or 2 (rotation trick)");
     RouteArgs a;
-    a.x = x; a.q = embed; a.g = nullptr; a.out = out; a.N = N; a.D = D; a.ldx = ldx; a.ldq = D; a.ldg = 0; a.ldo = ldo;
+    a.x = x; a.q = codes; a.g = nullptr; a.out = out; a.N = N; a.D = D; a.ldx = ldx; a.ldq = D; a.ldg = 0; a.ldo = ldo;
     a.loss_coef = nullptr; a.row_mask = nullptr; a.mode = mode; a.qidx = idx; a.qidx_stride = idx_stride; a.sub = 1;
-    a.vec = rows_vec4(x, ldx, D, 4) && rows_vec4(embed, D, D, 4) && rows_vec4(out, ldo, D, 4);
-    return route_launch(a, VQHIP_F32, false, (hipStream_t)stream);
+    const int es = dtype == VQHIP_BF16 ? 2 : 4;
+    a.vec = rows_vec4(x, ldx, D, es) && rows_vec4(codes, D, D, es) && rows_vec4(out, ldo, D, es);
+    return route_launch(a, dtype, false, (hipStream_t)stream);
 }
 
 extern "C" int vqhip_route_bwd(const void *x, const void *q, const void *g_out, int dtype, int64_t N, int D,
@@ -4099,7 +4102,7 @@ extern "C" int vqhip_vq_train_step(const vqhip_vq_step_t *s, void *stream)
     f.omd = (float)s->one_minus_decay;
     f.eps = (float)s->eps;
     const void *qsrc = (x_dtype == VQHIP_BF16) ? (const void *)((const char *)s->packed + packed_bf16_offset(C, D)) : (const void *)s->embed;
-    if (int rc = ema_accumulate_impl(s->x, x_dtype, N, D, s->ldx, s->idx_out, 1, nullptr, VQHIP_EUCLID, nullptr, C, count, embed_sum,
+    if (int rc = ema_accumulate_impl(s->x, x_dtype, N, D, s->ldx, s->idx_out, 1, nullptr, VQHIP_EUCLID, s->row_mask, C, count, embed_sum,
                                      ws_stats, vqhip_ema_workspace_bytes(N, C), qsrc, partials, stream, &f)) return rc;
     if (s->fold) {
         hipLaunchKernelGGL(vq_step_fold_kernel, dim3((unsigned)((C + 3) / 4 + 1)), dim3(256), 0, st, s->embed_avg, s->embed, embed_sum, denom,

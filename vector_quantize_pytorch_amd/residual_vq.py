@@ -180,8 +180,11 @@ class ResidualVQ(nn.Module):
                 so_far = so_far + codes                       # (the reference adds the un-masked code as well, rvq.py:364)
             allc = torch.stack(out)
             return allc.masked_fill((indices == -1).movedim(-1, 0)[..., None], 0.)
-        out = [L.decode_sum(indices[..., q:q + 1].contiguous(), cbs[q].contiguous()) for q in range(self.num_quantizers)]
-        return torch.stack(out)
+        # every stage's gather writes its slice of the stacked result (no torch.stack pass over Q x N x D floats afterwards)
+        allc = torch.empty(self.num_quantizers, *indices.shape[:-1], cbs[0].shape[-1], dtype=torch.float32, device=indices.device)
+        for q in range(self.num_quantizers):
+            L.decode_sum(indices[..., q:q + 1].contiguous(), cbs[q].contiguous(), out=allc[q])
+        return allc
 
     def get_output_from_indices(self, indices):
         qdim = indices.shape[-1]
@@ -232,13 +235,13 @@ class ResidualVQ(nn.Module):
                 and self._fused_eligible(x.flatten(2).transpose(1, 2), mask, rows_of_fmap=True)):
             fmap, x_map = x.shape[2:], x
             x = _rows_of(x.flatten(2).transpose(1, 2))
-            if self._wants_input_grad(x) and self._route_mode() != 0 and not self._chain_eligible(x, freeze_codebook):
+            if self._wants_input_grad(x) and self._route_mode() != 0 and not self._chain_eligible(x, freeze_codebook, routed=True):
                 fmap, x = None, x_map                                  # (the per-stage path takes the map itself)
 
         if is_beam:
             quantized_out, all_indices, all_losses = self._forward_beam(x, mask, sample_codebook_temp, freeze_codebook, beam_size, drop_at)
         elif self._fused_eligible(x, mask, rows_of_fmap=fmap is not None) and not (self._wants_input_grad(x) and self._route_mode() != 0
-                                                    and not self._chain_eligible(x, freeze_codebook)):
+                                                    and not self._chain_eligible(x, freeze_codebook, routed=True)):
             if self._wants_input_grad(x):
                 # the same on-device loop, gradients to the input in closed form (one kernel forward, one backward).  With
                 # routed gradients every layer RETURNS the straight-through / rotation-trick value and rvq.py:524 subtracts
@@ -311,11 +314,14 @@ class ResidualVQ(nn.Module):
             (vq0._codebook.ema_update or vq0._codebook.has_dead_code_replacement)
         return update, self.training and vq0.has_commitment_loss
 
-    def _chain_eligible(self, x, freeze_codebook):
-        """the residual chain (csrc: vqhip_assign_screened_chain): fp32 rows, D in {32, 64, 128, 256}; the per-stage commitment
-        loss comes from the statistics pass, so a loss without an EMA update has no producer there"""
+    def _chain_eligible(self, x, freeze_codebook, routed=False):
+        """the residual chain (csrc: vqhip_assign_screened_chain): fp32 rows, D in {32, 64, 128, 256}; routed (a training step whose
+        input requires grad: every stage's input comes from vqhip_route_residual and is searched like a first stage) also bf16 rows
+        and D = 512.  The per-stage commitment loss comes from the statistics pass, so a loss without an EMA update has no producer
+        there"""
         update, want_loss = self._update_and_loss(freeze_codebook)
-        return bool(L.screening_enabled() and self.codebook_dim in (32, 64, 128, 256) and L.rvq_chain_supported(x, self.codebook_size)
+        dims = (32, 64, 128, 256, 512) if routed else (32, 64, 128, 256)
+        return bool(L.screening_enabled() and self.codebook_dim in dims and L.rvq_chain_supported(x, self.codebook_size, routed=routed)
                     and (update or not want_loss))
 
     @torch.no_grad()
@@ -344,7 +350,7 @@ class ResidualVQ(nn.Module):
         # Residual chain (csrc: vqhip_assign_screened_chain): every stage forms its input x_prev - code in its own prologue, so no
         # stage re-reads its input to write a residual; the commitment loss' squared error then comes from the per-stage
         # statistics pass, which reads every row next to its code anyway (needs `update`; without a loss nothing is needed)
-        chain = self._chain_eligible(x, freeze_codebook)
+        chain = self._chain_eligible(x, freeze_codebook, routed=route_mode != 0)
         assert chain or route_mode == 0, "routed residuals need the chain (ResidualVQ.forward sends the rest to the per-stage path)"
         sq_parts = None
         if chain and want_loss:             # one [Q, P] buffer of loss partials: one batched reduction after the loop
