@@ -382,6 +382,13 @@ int vqhip_topk(const void *x, int x_dtype, int64_t N, int D, int64_t ldx, const 
  * l2-normalised for the cosine metric).  n_expired_out (nullable, device int) receives the number of replaced codes. */
 int vqhip_expire_scatter(float *cluster_size, float *embed_avg, float *embed, const float *candidates, int C, int D,
                          float threshold, float reset, int *n_expired_out, void *stream);
+/* Dead-code replacement in ONE launch, no candidate tensor (vqp.py:544-574): every code with cluster_size < threshold takes row pi(c) of
+ * the batch rows [n, D] (fp32 / bf16, row stride ldx), pi(c) = the affine permutation (a c + b) mod p of Z_p cycle-walked into [0, n) --
+ * distinct rows for distinct codes when C <= n (the reference samples without replacement, :180-188) -- l2-normalised for a cosine
+ * codebook (:545-546); embed_avg = row * reset, cluster_size = reset.  ab: device int64[2] = (a, b), both in [1, p); p: a prime with
+ * n <= p < 2^31 (the caller's: the smallest one).  Nothing on the host depends on how many codes expired. */
+int vqhip_expire_pick(float *cluster_size, float *embed_avg, float *embed, const void *rows, int x_dtype, int64_t n, int64_t ldx,
+                      const int64_t *ab, int64_t p, int C, int D, float threshold, float reset, int cosine, void *stream);
 
 /* k-means centroid update of one iteration (reference: kmeans, vector_quantize_pytorch.py:262-276): in place,
  * means[c] = embed_sum[c] / count[c] where count[c] > 0 (l2-normalised if cosine), unchanged for empty bins. */

@@ -775,8 +775,8 @@ def test_fused_residual_loop_expiry_samples_only_unmasked_rows(dev):
 
 
 def test_train_step_with_dead_code_replacement_is_graph_capturable(dev):
-    """threshold_ema_dead_code > 0 inside a HIP graph: while capturing, expiry takes the device-side path (candidates drawn every
-    step, vqhip_expire_scatter), so no host round trip is needed; replays keep replacing dead codes and every code stays alive."""
+    """threshold_ema_dead_code > 0 inside a HIP graph: while capturing, expiry takes the device-side path (a permutation drawn every
+    step, vqhip_expire_pick), so no host round trip is needed; replays keep replacing dead codes and every code stays alive."""
     from vector_quantize_pytorch_amd import VectorQuantize
     torch.manual_seed(0)
     vq = VectorQuantize(dim=64, codebook_size=256, threshold_ema_dead_code=2).to(dev).train()
@@ -852,6 +852,42 @@ def test_device_side_expiry_matches_reference_semantics(dev):
     assert torch.equal(e[40:], before[40:])
     assert torch.equal(vq._codebook.cluster_size[0, :40], torch.full((40,), 2.0, device=dev))
     assert torch.equal(vq._codebook.embed_avg[0, :40], e[:40] * 2.0)
+    # ... and they are DISTINCT rows (sample_vectors draws without replacement when the batch has enough rows, vqp.py:180-188): the
+    # kernel hands code c the row pi(c) of a random permutation of the batch (vqhip_expire_pick)
+    which = (rows[None, :, :] == e[:40, None, :]).all(-1).float().argmax(-1)
+    assert which.unique().numel() == 40
+
+
+@pytest.mark.parametrize("dtype,cosine,n", [(torch.bfloat16, False, 3000), (torch.float32, True, 777), (torch.float32, False, 50),
+                                            (torch.bfloat16, True, 1)])
+def test_expire_pick_all_codes_dead_take_a_permutation_of_the_rows(dev, dtype, cosine, n):
+    """vqhip_expire_pick with every code expired: C <= n -> C distinct rows (a bijection of the batch rows restricted to the codes);
+    fewer rows than codes -> every row used, wrapped around (the reference's with-replacement case); bf16 rows; cosine codebooks
+    store the l2-normalised row (vqp.py:545-546); two calls draw different permutations."""
+    from vector_quantize_pytorch_amd import _lib as L
+    torch.manual_seed(1)
+    C, D = 128, 64
+    rows = torch.randn(n, D, device=dev).to(dtype)
+    want = rows.float()
+    if cosine:
+        want = torch.nn.functional.normalize(want, p=2, dim=-1, eps=1e-6)
+    picks = []
+    for _ in range(2):
+        cs, ea, e = torch.zeros(C, device=dev), torch.zeros(C, D, device=dev), torch.zeros(C, D, device=dev)
+        cs[5] = 10.0                                                   # one live code stays as it is
+        L.expire_pick(cs, ea, e, rows, 2.0, 3.0, cosine=cosine)
+        d = (e[:, None, :] - want[None, :, :]).abs().amax(-1)          # [C, n]
+        src = d.argmin(-1)
+        dead = torch.arange(C, device=dev) != 5
+        assert float(d.min(-1).values[dead].max()) < 1e-6 and float(e[5].abs().max()) == 0.0 and float(cs[5]) == 10.0
+        assert torch.equal(cs[dead], torch.full((C - 1,), 3.0, device=dev)) and torch.allclose(ea[dead], e[dead] * 3.0)
+        if n >= C:
+            assert src[dead].unique().numel() == C - 1
+        else:
+            assert src[dead].unique().numel() == min(n, C - 1) or n == 1
+        picks.append(src)
+    if n >= C:
+        assert not torch.equal(picks[0], picks[1])
 
 
 @pytest.mark.parametrize("dtype,kw", [(torch.bfloat16, dict(dim=256, codebook_size=1024)), (torch.float32, dict(dim=256, codebook_size=512)),

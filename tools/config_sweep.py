@@ -16,6 +16,8 @@ CASES = [
     ("fp16 rows", dict(dim=256, codebook_size=1024), torch.float16, {}),
     ("cosine bf16", dict(dim=256, codebook_size=1024, use_cosine_sim=True), torch.bfloat16, {}),
     ("dead-code expiry (threshold 2) bf16", dict(dim=256, codebook_size=1024, threshold_ema_dead_code=2), torch.bfloat16, {}),
+    ("dead-code expiry, device-side (expire_without_host_sync) bf16", dict(dim=256, codebook_size=1024, threshold_ema_dead_code=2),
+     torch.bfloat16, dict(nosync=True)),
     ("eval bf16", dict(dim=256, codebook_size=1024), torch.bfloat16, dict(eval=True)),
     ("lens mask bf16", dict(dim=256, codebook_size=1024), torch.bfloat16, dict(lens=True)),
     ("codebook_dim 32 (projections) fp32", dict(dim=256, codebook_size=1024, codebook_dim=32), torch.float32, {}),
@@ -41,6 +43,8 @@ if RVQ_SWEEP:
         ("separate codebooks fp32", dict(R), torch.float32, dict(rvq=True)),
         ("separate codebooks bf16", dict(R), torch.bfloat16, dict(rvq=True)),
         ("dead-code expiry (threshold 2) fp32", dict(R, threshold_ema_dead_code=2), torch.float32, dict(rvq=True)),
+        ("dead-code expiry, device-side (expire_without_host_sync) fp32", dict(R, threshold_ema_dead_code=2), torch.float32,
+         dict(rvq=True, nosync=True)),
         ("shared codebook + dead-code expiry fp32", dict(R, shared_codebook=True, threshold_ema_dead_code=2), torch.float32, dict(rvq=True)),
         ("cosine fp32", dict(R, use_cosine_sim=True), torch.float32, dict(rvq=True)),
         ("cosine + expiry fp32", dict(R, use_cosine_sim=True, threshold_ema_dead_code=2), torch.float32, dict(rvq=True)),
@@ -73,6 +77,10 @@ for name, kw, dt, opt in CASES:
         torch.manual_seed(0)
         mod = (ResidualVQ(**kw) if opt.get("rvq") else VectorQuantize(**kw)).to(dev)
         mod = mod.eval() if opt.get("eval") else mod.train()
+        if opt.get("nosync"):
+            for m in mod.modules():
+                if hasattr(m, "expire_without_host_sync"):
+                    m.expire_without_host_sync = True
         dim = opt.get("dim", 256)
         if opt.get("fmap"):
             shape = (B, 256, 64, T // 64)
@@ -102,8 +110,8 @@ for name, kw, dt, opt in CASES:
                 res[grad] = tm(step)
             if opt.get("eval"):
                 break
-        print(f"{name:48s} forward {res[False]:7.3f} ms" + (f"   forward + backward {res[True]:7.3f} ms" if True in res else ""), flush=True)
+        print(f"{name:64s} forward {res[False]:7.3f} ms" + (f"   forward + backward {res[True]:7.3f} ms" if True in res else ""), flush=True)
     except Exception as e:
-        print(f"{name:48s} FAILED {type(e).__name__}: {str(e)[:200]}", flush=True)
+        print(f"{name:64s} FAILED {type(e).__name__}: {str(e)[:200]}", flush=True)
     del mod, x
     torch.cuda.empty_cache()

@@ -69,6 +69,8 @@ def lib():
     L.vqhip_l2norm_rows_bwd.argtypes = [vp, vp, i32, i64, i32, i64, i64, vp, i64, vp]
     L.vqhip_transpose_batched.argtypes = [vp, vp, i32, i64, i64, i64, i64, vp]
     L.vqhip_transpose_batched.restype = i32
+    L.vqhip_expire_pick.argtypes = [vp, vp, vp, vp, i32, i64, i64, vp, i64, i32, i32, f32, f32, i32, vp]
+    L.vqhip_expire_pick.restype = i32
     L.vqhip_l2norm_rows_bwd.restype = i32
     L.vqhip_screen_chain_supported.argtypes = [i32, i32]
     L.vqhip_screen_chain_supported.restype = i32
@@ -145,7 +147,7 @@ def lib():
 
 EXPORTS = ("vqhip_version", "vqhip_last_error", "vqhip_packed_bytes", "vqhip_pack_codebook",
            "vqhip_assign_blocks", "vqhip_assign", "vqhip_screen_supported", "vqhip_screen_workspace_bytes",
-           "vqhip_screen_blocks", "vqhip_screen_partials", "vqhip_assign_screened", "vqhip_screen_chain_supported", "vqhip_assign_screened_chain", "vqhip_l2norm_rows", "vqhip_l2norm_rows_bwd", "vqhip_transpose_batched", "vqhip_scores", "vqhip_rvq_forward", "vqhip_reduce_partials", "vqhip_reduce_partials_rows", "vqhip_ema_fold_many", "vqhip_ema_workspace_bytes", "vqhip_ema_accumulate", "vqhip_ema_sqerr_partials", "vqhip_ema_accumulate_sqerr",
+           "vqhip_screen_blocks", "vqhip_screen_partials", "vqhip_assign_screened", "vqhip_screen_chain_supported", "vqhip_assign_screened_chain", "vqhip_l2norm_rows", "vqhip_l2norm_rows_bwd", "vqhip_transpose_batched", "vqhip_expire_pick", "vqhip_scores", "vqhip_rvq_forward", "vqhip_reduce_partials", "vqhip_reduce_partials_rows", "vqhip_ema_fold_many", "vqhip_ema_workspace_bytes", "vqhip_ema_accumulate", "vqhip_ema_sqerr_partials", "vqhip_ema_accumulate_sqerr",
            "vqhip_ema_finalize", "vqhip_decode_sum", "vqhip_row_sumsq", "vqhip_assign_rowwise", "vqhip_score_indices", "vqhip_topk", "vqhip_expire_scatter", "vqhip_kmeans_update", "vqhip_route_fwd", "vqhip_route_bwd", "vqhip_rvq_route", "vqhip_ema_renormalize_shard", "vqhip_scores_lse",
            "vqhip_pack_best", "vqhip_unpack_best", "vqhip_vq_step_supported", "vqhip_vq_step_workspace_bytes", "vqhip_vq_train_step", "vqhip_route_residual",
            "vqhip_pack_codebook_batched", "vqhip_screen_batched_ws_stride", "vqhip_assign_screened_batched", "vqhip_assign_batched",
@@ -1109,6 +1111,37 @@ def expire_scatter(cluster_size: torch.Tensor, embed_avg: torch.Tensor, embed: t
         assert t.is_contiguous() and t.dtype == torch.float32
     _check(lib().vqhip_expire_scatter(_ptr(cluster_size), _ptr(embed_avg), _ptr(embed), _ptr(candidates), C, D, float(threshold),
                                       float(reset), _ptr(n_expired), _stream()), "vqhip_expire_scatter")
+
+
+_PRIMES = {}
+
+
+def _next_prime(n: int) -> int:
+    """smallest prime >= n (cached per batch size)"""
+    p = _PRIMES.get(n)
+    if p is None:
+        p = max(n, 2)
+        while any(p % d == 0 for d in range(2, int(p ** 0.5) + 1)):
+            p += 1
+        _PRIMES[n] = p
+    return p
+
+
+@_on_device
+def expire_pick(cluster_size: torch.Tensor, embed_avg: torch.Tensor, embed: torch.Tensor, rows: torch.Tensor, threshold: float, reset: float,
+                *, cosine=False):
+    """In place on one codebook: every code with cluster_size < threshold takes a row of `rows` [n, D] (float32 / bfloat16), distinct
+    rows for distinct codes when C <= n; two draws of torch's generator on the device, one kernel, no host read (vqhip_expire_pick)."""
+    _need_gpu(cluster_size, embed_avg, embed, rows)
+    C, D = embed.shape
+    rk, n, Dr, ldx = as_rows(rows)
+    assert Dr == D and n >= 1
+    for t in (cluster_size, embed_avg, embed):
+        assert t.is_contiguous() and t.dtype == torch.float32
+    p = _next_prime(n)
+    ab = torch.randint(1, p, (2,), device=rows.device, dtype=torch.int64)
+    _check(lib().vqhip_expire_pick(_ptr(cluster_size), _ptr(embed_avg), _ptr(embed), _ptr(rk), _dtype_code(rk), n, ldx, _ptr(ab), p, C, D,
+                                   float(threshold), float(reset), int(cosine), _stream()), "vqhip_expire_pick")
 
 
 @_on_device

@@ -10,6 +10,8 @@ from __future__ import annotations
 
 from typing import Callable, Optional
 
+import os
+
 import torch
 import torch.distributed as dist
 import torch.nn.functional as F
@@ -311,37 +313,50 @@ class Codebook(nn.Module):
     expire_without_host_sync = False     # class default; set True (or capture the step in a HIP graph) for the device-side path
 
     @torch.no_grad()
-    def expire_codes_(self, batch_samples: Tensor, seq_mask: Optional[Tensor] = None):
-        """vqp.py:564-574.  Default path: the reference's control flow -- `any(expired)` and the number of expired codes are read
+    def expire_codes_(self, batch_samples: Tensor, seq_mask: Optional[Tensor] = None, any_expired: Optional[bool] = None):
+        """any_expired: the caller has read `any(cluster_size < threshold)` already (ResidualVQ reads it for all its layers with ONE
+        host sync, Codebook.any_expired_many) -- skips this call's own read.
+        vqp.py:564-574.  Default path: the reference's control flow -- `any(expired)` and the number of expired codes are read
         on the host (two syncs, only when threshold_ema_dead_code > 0; 0 is VectorQuantize's default, vqp.py:818), which keeps
         torch's generator in lock-step with the reference (no draw when nothing expired).  Device-side path
-        (`expire_without_host_sync`, or automatically while the stream is being captured into a graph): candidates are drawn
-        every step and vqhip_expire_scatter hands the j-th expired code the j-th candidate -- same distribution, no host round
-        trip, but the generator advances on steps without expired codes too."""
+        (`expire_without_host_sync`, or automatically while the stream is being captured into a graph): every step draws one random
+        permutation of the batch rows (two generator draws) and vqhip_expire_pick hands every expired code its row -- rows without
+        replacement as in the reference, one launch, no host round trip, but the generator advances on steps without expired codes
+        too."""
         if not self.has_dead_code_replacement or not self.training:
             return
         H = batch_samples.shape[0]
         samples = batch_samples.reshape(H, -1, batch_samples.shape[-1])
-        nosync = (self.expire_without_host_sync or torch.cuda.is_current_stream_capturing()) and seq_mask is None \
-            and self.replace_sample_fn is batched_sample_rows
+        nosync = (self.expire_without_host_sync or os.environ.get("VQHIP_EXPIRE_DEVICE", "0") == "1"
+                  or torch.cuda.is_current_stream_capturing()) and seq_mask is None and self.replace_sample_fn is batched_sample_rows
         if nosync:
-            C = self.codebook_size
+            # ONE launch per codebook (vqhip_expire_pick): expired code c takes row pi(c) of the batch, pi an affine permutation drawn
+            # from torch's generator -- rows without replacement like sample_vectors (vqp.py:180-188), nothing sized by the count
             for h in range(H):
-                rows = samples[h]
-                n = rows.shape[0]
-                pick = torch.randperm(n, device=rows.device)[:C] if n >= C else torch.randint(0, n, (C,), device=rows.device)
-                cand = rows.index_select(0, pick).float()
-                if cand.shape[0] < C:                       # (n >= C but fewer than C rows: cannot happen; keeps shapes static)
-                    cand = torch.cat([cand, cand[: C - cand.shape[0]]], 0)
-                if self.use_cosine_sim:
-                    cand = _l2norm(cand)
+                if samples[h].shape[0] == 0:
+                    continue
                 cs, ea, e = self._views(h)
-                L.expire_scatter(cs, ea, e, cand.contiguous(), self.threshold_ema_dead_code, self.reset_cluster_size)
+                L.expire_pick(cs, ea, e, samples[h], self.threshold_ema_dead_code, self.reset_cluster_size, cosine=self.use_cosine_sim)
+            return
+        if any_expired is False:
             return
         expired = self.cluster_size < self.threshold_ema_dead_code
-        if not bool(expired.any()):
+        if any_expired is None and not bool(expired.any()):
             return
         self.replace(samples.float(), expired, seq_mask)
+
+    def expiry_reads_host(self) -> bool:
+        """does expire_codes_ take the reference's control flow (a host read of any(expired)) in this state?"""
+        return bool(self.has_dead_code_replacement and self.training
+                    and not (self.expire_without_host_sync or os.environ.get("VQHIP_EXPIRE_DEVICE", "0") == "1"
+                             or torch.cuda.is_current_stream_capturing()))
+
+    @staticmethod
+    def any_expired_many(codebooks) -> list:
+        """[any(cluster_size < threshold) for each codebook] with one device-to-host copy for all of them (the reference reads it per
+        layer, vqp.py:570: eight pipeline drains per step of an 8-stage residual VQ)"""
+        flags = torch.stack([(cb.cluster_size < cb.threshold_ema_dead_code).any() for cb in codebooks])
+        return flags.tolist()
 
     def _fold_stats(self, h, count, esum, ema_update_weight, accum_ema_update, ema_update):
         cs, ea, e = self._views(h)

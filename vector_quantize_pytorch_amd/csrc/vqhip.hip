@@ -3707,6 +3707,65 @@ extern "C" int vqhip_expire_scatter(float *cluster_size, float *embed_avg, float
     return launch_status("vq_expire_kernel");
 }
 
+// Dead-code replacement without a candidate tensor (vqp.py:544-574 with sample_vectors :180-188: expired codes take batch rows drawn
+// without replacement): code c takes row pi(c) of the batch, pi = an affine permutation t -> (a t + b) mod p of Z_p, p the
+// smallest prime >= n, cycle-walked into [0, n) (a bijection of [0, n), so distinct codes take distinct rows whenever C <= n; fewer
+// rows than codes wrap around, the reference's with-replacement case).  (a, b): two draws of the caller's generator, read from
+// device memory -- the whole replacement is this one launch, nothing depends on how many codes expired.  One wave per code.
+__global__ void __launch_bounds__(256) vq_expire_pick_kernel(float *__restrict__ cluster_size, float *__restrict__ embed_avg,
+                                                             float *__restrict__ embed, const void *__restrict__ rows, int bf16,
+                                                             int64_t n, int64_t ldx, const int64_t *__restrict__ ab, int64_t p,
+                                                             int C, int D, float threshold, float reset, int cosine)
+{
+    const int lane = threadIdx.x & 63;
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (c >= C) return;
+    if (!(cluster_size[c] < threshold)) return;
+    const unsigned long long a = (unsigned long long)ab[0], b = (unsigned long long)ab[1], pp = (unsigned long long)p;
+    unsigned long long pick = (a * ((unsigned long long)c % pp) + b) % pp;
+    for (int it = 0; it < 64 && pick >= (unsigned long long)n; ++it) pick = (a * pick + b) % pp;
+    if (pick >= (unsigned long long)n) pick %= (unsigned long long)n;       // (a short cycle of pi inside [n, p): practically never)
+    float v[8];
+    float ss = 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int k = lane + 64 * q;
+        v[q] = 0.f;
+        if (k < D) {
+            v[q] = bf16 ? bf16_bits_to_f32(((const unsigned short *)rows)[pick * ldx + k]) : ((const float *)rows)[pick * ldx + k];
+            ss += v[q] * v[q];
+        }
+    }
+    float inv = 1.f;
+    if (cosine) {                                                           // l2norm of the sampled rows (vqp.py:545-546, 37-38)
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) ss += __shfl_xor(ss, o, 64);
+        inv = fmaxf(sqrtf(ss), 1e-6f);
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int k = lane + 64 * q;
+        if (k < D) {
+            const float e = cosine ? v[q] / inv : v[q];
+            embed[(size_t)c * D + k] = e;
+            embed_avg[(size_t)c * D + k] = e * reset;
+        }
+    }
+    if (lane == 0) cluster_size[c] = reset;
+}
+
+extern "C" int vqhip_expire_pick(float *cluster_size, float *embed_avg, float *embed, const void *rows, int x_dtype, int64_t n, int64_t ldx,
+                                 const int64_t *ab, int64_t p, int C, int D, float threshold, float reset, int cosine, void *stream)
+{
+    if (!cluster_size || !embed_avg || !embed || !rows || !ab || C <= 0) VQ_FAIL(VQHIP_EINVAL, "expire_pick: bad argument");
+    if (D < 1 || D > 512) VQ_FAIL(VQHIP_EDIM, "expire_pick: D=%d unsupported (1..512)", D);
+    if (x_dtype != VQHIP_F32 && x_dtype != VQHIP_BF16) VQ_FAIL(VQHIP_EINVAL, "expire_pick: unknown dtype");
+    if (n < 1 || p < n || p < 2 || p > 0x7fffffffLL || ldx < D) VQ_FAIL(VQHIP_EINVAL, "expire_pick: need 1 <= n <= p < 2^31 (p prime), ldx >= D");
+    hipLaunchKernelGGL(vq_expire_pick_kernel, dim3((unsigned)((C + 3) / 4)), dim3(256), 0, (hipStream_t)stream, cluster_size, embed_avg, embed, rows,
+                       x_dtype == VQHIP_BF16 ? 1 : 0, n, ldx, ab, p, C, D, threshold, reset, cosine);
+    return launch_status("vq_expire_pick_kernel");
+}
+
 // k-means centroid update of one iteration (vqp.py:262-276): means[c] = embed_sum[c] / count[c] where count[c] > 0 (l2-normalised for
 // the cosine metric, eps 1e-6 as vqp.py:37-38), unchanged where the bin is empty.  In place on `means`.
 __global__ void __launch_bounds__(256) vq_kmeans_update_kernel(float *__restrict__ means, const float *__restrict__ embed_sum,

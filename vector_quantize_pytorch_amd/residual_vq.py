@@ -452,12 +452,19 @@ class ResidualVQ(nn.Module):
                 L.ema_fold_many(cs, ea, e, buf, decay=cb0.decay, eps=cb0.eps, cosine=cb0.use_cosine_sim,
                                 do_update_ema=bool(self.vq_is_ema_updating))
             else:
-                for q in range(Q):
-                    cb = self.layers[q]._codebook
+                cbs = [self.layers[q]._codebook for q in range(Q)]
+                for q, cb in enumerate(cbs):
                     cb._fold_stats(0, buf[q, C * D: C * D + C], buf[q, : C * D].view(C, D), None, False, cb.ema_update)
-                    if not self.shared_codebook:                        # vqp.py:641: expire_codes_(flatten, seq_mask = mask)
-                        cb.expire_codes_(stage_in(q).reshape(1, -1, D),
-                                         seq_mask=None if mask is None else mask.reshape(1, -1).bool())
+                if not self.shared_codebook:                            # vqp.py:641: expire_codes_(flatten, seq_mask = mask)
+                    # (after all the folds: a layer's expiry reads only its own cluster_size; replacement draws stay in layer order.
+                    #  Layers on the reference's control flow share ONE host read of their any(expired) flags.)
+                    known = {}
+                    host = [q for q, cb in enumerate(cbs) if cb.expiry_reads_host()]
+                    if len(host) > 1:
+                        known = dict(zip(host, type(cbs[0]).any_expired_many([cbs[q] for q in host])))
+                    for q, cb in enumerate(cbs):
+                        cb.expire_codes_(stage_in(q).reshape(1, -1, D), seq_mask=None if mask is None else mask.reshape(1, -1).bool(),
+                                         any_expired=known.get(q))
                 if self.shared_codebook and self.vq_is_ema_updating:    # rvq.py:593-598 (dead-code replacement never gets here:
                     vq0._codebook.update_ema()                           # _fused_eligible sends it to the per-stage path)
 
