@@ -337,7 +337,7 @@ class ResidualVQ(nn.Module):
             packed = L.pack_codebook(embed)
         else:
             embed = torch.stack([layer._codebook.embed[0] for layer in self.layers[:Q]]).contiguous()
-            packed = torch.stack([L.pack_codebook(embed[q]) for q in range(Q)])
+            packed = L.pack_codebook_batched(embed)            # the Q codebooks in two launches (was 2 Q and a torch.stack)
         update, want_loss = self._update_and_loss(freeze_codebook)
         route_mode = self._route_mode() if aux is not None else 0       # aux: called from _RvqFusedFn (the input requires grad)
         buf = side = None
