@@ -1092,6 +1092,37 @@ def test_residual_vq_on_a_feature_map_runs_the_rows_loop_once(dev, grouped, kw):
     assert torch.equal(i1, i2) and torch.allclose(q1, q2, rtol=0, atol=1e-6)
 
 
+@pytest.mark.parametrize("kw,shape", [(dict(dim=64, codebook_size=256), (3, 900, 64)),
+                                      (dict(dim=128, codebook_size=512, rotation_trick=False, input_to_quantize_commit_loss_weight=0.5,
+                                            commitment_weight=0.7), (2, 1500, 128)),
+                                      (dict(dim=32, codebook_size=128, channel_first=True), (2, 32, 700)),
+                                      (dict(dim=64, codebook_size=64, frozen_codebook_dim=16), (2, 5, 7, 64))])
+def test_sim_vq_step_with_closed_form_gradients_equals_the_autograd_graph(dev, monkeypatch, kw, shape):
+    """SimVQ (sim_vq.py:100-138) through _SimQuantizeFn -- indices + squared error from the search, routed value gathered by index,
+    backward = the routing kernel for x and one statistics pass for the codes -- against F.embedding / two F.mse_loss / autograd
+    (VQHIP_SIM_FAST=0): same indices and output, loss, input gradient and the learned map's gradient to summation order."""
+    from vector_quantize_pytorch_amd import SimVQ
+    torch.manual_seed(0)
+    a, b = SimVQ(**kw).to(dev), SimVQ(**kw).to(dev)
+    b.load_state_dict(a.state_dict())
+    x = torch.randn(*shape, device=dev)
+    gq = torch.randn_like(x)
+    res = []
+    for mod, flag in ((a, "1"), (b, "0")):
+        monkeypatch.setenv("VQHIP_SIM_FAST", flag)
+        xi = x.clone().requires_grad_(True)
+        q, ind, loss = mod(xi)
+        torch.autograd.backward((q, loss), (gq, torch.tensor(1.7, device=dev)))
+        res.append((q, ind, loss, xi.grad, [p.grad.clone() for p in mod.parameters()]))
+    (qa, ia, la, ga, pa), (qb, ib, lb, gb, pb) = res
+    assert qa.shape == x.shape and torch.equal(ia, ib)
+    _close(qa, qb, 1e-6, "quantized")
+    assert torch.allclose(la, lb, rtol=1e-5, atol=0)
+    _close(ga, gb, 2e-5, "input gradient")
+    for u, v in zip(pa, pb):
+        _close(u, v, 5e-5, "gradient of the learned map")
+
+
 @pytest.mark.parametrize("dtype", [torch.float16, torch.float64])
 def test_float16_and_float64_inputs_compute_in_fp32_and_come_back_in_their_dtype(dev, dtype):
     """The reference's codebook computes in float32 whatever comes in (x.float(), vqp.py:690) and returns quantize in the input's dtype

@@ -3,7 +3,7 @@ people combine it with, at cfg-2 size (2^20 rows, D = 256, C = 1024) -- to find 
     python tools/config_sweep.py [rows_log2]"""
 import os, sys, time, torch
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
-from vector_quantize_pytorch_amd import VectorQuantize, ResidualVQ
+from vector_quantize_pytorch_amd import VectorQuantize, ResidualVQ, SimVQ
 
 RVQ_SWEEP = "--rvq" in sys.argv            # the residual modules' options at cfg-3 size (2^18 rows, 8 stages) instead
 args = [a for a in sys.argv[1:] if a != "--rvq"]
@@ -32,6 +32,8 @@ CASES = [
     ("ResidualVQ 4 stages on a feature map fp32", dict(dim=256, codebook_size=1024, num_quantizers=4, accept_image_fmap=True), torch.float32,
      dict(rvq=True, fmap=True)),
     ("ResidualVQ 4 stages channel-last fp32", dict(dim=256, codebook_size=1024, num_quantizers=4), torch.float32, dict(rvq=True)),
+    ("SimVQ fp32", dict(dim=256, codebook_size=1024), torch.float32, dict(sim=True)),
+    ("SimVQ bf16 rows", dict(dim=256, codebook_size=1024), torch.bfloat16, dict(sim=True)),
     ("commitment_weight 0 bf16", dict(dim=256, codebook_size=1024, commitment_weight=0.), torch.bfloat16, {}),
     ("ResidualVQ 4 stages, quantize_dropout fp32", dict(dim=256, codebook_size=1024, num_quantizers=4, quantize_dropout=True), torch.float32,
      dict(rvq=True)),
@@ -75,7 +77,7 @@ def tm(fn, n=8):
 for name, kw, dt, opt in CASES:
     try:
         torch.manual_seed(0)
-        mod = (ResidualVQ(**kw) if opt.get("rvq") else VectorQuantize(**kw)).to(dev)
+        mod = (SimVQ(**kw) if opt.get("sim") else ResidualVQ(**kw) if opt.get("rvq") else VectorQuantize(**kw)).to(dev)
         mod = mod.eval() if opt.get("eval") else mod.train()
         if opt.get("nosync"):
             for m in mod.modules():

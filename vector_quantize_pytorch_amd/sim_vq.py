@@ -13,6 +13,7 @@ are closer than fp32 round-off (none in the golden fixtures).
 """
 from __future__ import annotations
 
+import os
 import random
 from typing import Callable, Optional
 
@@ -22,7 +23,49 @@ from torch import nn
 
 from . import _lib as L
 from .residual_vq import _draw_seed, _round_up
-from .vector_quantize import _RouteFn
+from .vector_quantize import _RouteFn, _rows_of
+
+
+class _SimQuantizeFn(torch.autograd.Function):
+    """SimVQ's search, gather, both commitment terms and the routed output (sim_vq.py:107-131) as the hot path runs them: the search
+    returns indices and the sum of squared errors, the routed value gathers the code rows by index, and backward is two kernels --
+    the routing kernel for x (rotation trick / straight-through Jacobian of the upstream gradient + the x-side commitment term
+    `w * 2 (x - q) / numel`) and one statistics pass for the codes (`2 (count_c q_c - sum of the rows quantized to c) / numel`, the
+    gradient of mse(x.detach(), codes[idx]); the routed output detaches the codes, sim_vq.py:126-131).  Replaces F.embedding, two
+    F.mse_loss graphs over N x D tensors and embedding's backward.  Third output: mse(x, codes[idx]); the module multiplies it by
+    (1 + w) -- both commitment terms have that value -- and this node splits the incoming gradient 1 : w between the two routes."""
+
+    @staticmethod
+    def forward(ctx, rows, implicit, mode, w):
+        searched = implicit.detach().float().contiguous()
+        numel = max(rows.numel(), 1)
+        r = L.assign(rows, L.pack_codebook(searched), searched, want_q=False, want_sqerr=True)          # sim_vq.py:111-113
+        idx = r["idx"].contiguous()
+        mse = L.reduce_partials(r["sqerr_partials"], r["nblk"], 1.0 / numel)
+        codes = searched.to(rows.dtype)
+        out = L.route_fwd_gather(rows, codes, idx, mode)
+        ctx.mode, ctx.w, ctx.scale, ctx.idt = mode, float(w), 1.0 / numel, implicit.dtype
+        ctx.save_for_backward(rows, codes, idx, searched)
+        ctx.mark_non_differentiable(idx)
+        return out, idx, mse
+
+    @staticmethod
+    def backward(ctx, g_out, g_idx, g_loss):
+        rows, codes, idx, searched = ctx.saved_tensors
+        g_codes = None
+        coef_x = None
+        if g_loss is not None:
+            g32 = g_loss.to(torch.float32)
+            share = 1.0 / (1.0 + ctx.w)
+            if ctx.needs_input_grad[1]:
+                count, esum = L.ema_accumulate(rows, idx.reshape(-1), searched.shape[0])
+                g_codes = ((count[:, None] * searched - esum) * (g32 * (2.0 * ctx.scale * share))).to(ctx.idt)
+            coef_x = g32 * (ctx.scale * ctx.w * share)
+        if not ctx.needs_input_grad[0] or (g_out is None and coef_x is None):
+            return None, g_codes, None, None
+        gx = L.route_bwd_gather(rows, codes, idx, None if g_out is None else L.rows_contiguous(g_out), coef_x, None,
+                                ctx.mode if g_out is not None else 0)
+        return gx, g_codes, None, None
 
 
 class SimVQ(nn.Module):
@@ -65,6 +108,15 @@ class SimVQ(nn.Module):
         rows = x.reshape(lead[0], -1, x.shape[-1])                               # 'b * d'
 
         implicit = self.codebook                                                # [C, D], carries grad to the learned map
+        if (rows.is_cuda and rows.dtype in (torch.float32, torch.bfloat16) and rows.shape[-1] <= 512 and rows.numel() > 0
+                and os.environ.get("VQHIP_SIM_FAST", "1") != "0"):
+            w = self.input_to_quantize_commit_loss_weight
+            mode = L.ROTATION if self.rotation_trick else L.STRAIGHT_THROUGH
+            quantized, idx, mse = _SimQuantizeFn.apply(rows if rows.is_contiguous() else _rows_of(rows), implicit, mode, w)
+            quantized = quantized.reshape(*lead, -1)
+            if self.channel_first:
+                quantized = quantized.movedim(-1, 1)
+            return quantized, idx.reshape(lead), mse * ((1.0 + w) * self.commitment_weight)
         searched = implicit.detach().float().contiguous()
         with torch.no_grad():
             idx = L.assign(rows.detach(), L.pack_codebook(searched), searched, want_q=False)["idx"]   # sim_vq.py:111-113
