@@ -1468,6 +1468,84 @@ __global__ void __launch_bounds__(256) vq_l2norm_kernel(const void *x, int64_t N
     }
 }
 
+// The same arithmetic with coalesced accesses: 16 lanes per row, every lane owns 16-byte pieces (elements 64 k + 4 l + e), so a wave
+// instruction touches four rows' contiguous 256 bytes (the kernel above: 8-byte pieces of 32 different rows per instruction -- 2.9 TB/s
+// on 2^20 x 256 bf16 rows).  ATen's summation order is kept by walking its 32 chains (elements i = res + 32 t in increasing t, res =
+// 8 (m & 3) + 4 hi + r in x2_aten_order's terms) across the two lanes that hold them: chain `res` lives on lane res / 4 (e = res & 3)
+// for even t and on lane res / 4 + 8 for odd t; then the same p / f_lo / f_hi combination.  D = 32 T, T in {1, 2, 4, 8, 16}.
+template <int NK, bool XBF16>
+__global__ void __launch_bounds__(256) vq_l2norm16_kernel(const void *x, int64_t N, int D, int64_t ldx, void *out, int64_t ldo)
+{
+    const int l16 = threadIdx.x & 15;
+    const int64_t row = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
+    const bool row_ok = row < N;
+    const int64_t rowc = row_ok ? row : (N - 1);
+    float xr[NK][4];
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
+        const int d = 64 * k + 4 * l16;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) xr[k][e] = 0.f;
+        if (d < D) {
+            if (XBF16) {
+                const uint2 w = *(const uint2 *)((const unsigned short *)x + rowc * ldx + d);
+                xr[k][0] = __uint_as_float(w.x << 16); xr[k][1] = __uint_as_float(w.x & 0xffff0000u);
+                xr[k][2] = __uint_as_float(w.y << 16); xr[k][3] = __uint_as_float(w.y & 0xffff0000u);
+            } else {
+                const f32x4 w = *(const f32x4 *)((const float *)x + rowc * ldx + d);
+                xr[k][0] = w.x; xr[k][1] = w.y; xr[k][2] = w.z; xr[k][3] = w.w;
+            }
+        }
+    }
+    const int T = D / 32;
+    float ch[4] = {0.f, 0.f, 0.f, 0.f};                     // lanes 0..7: chain (l16 >> 1, l16 & 1, e)
+#pragma unroll
+    for (int t = 0; t < 2 * NK; ++t) {
+        if (t < T) {
+            const int src = (l16 & 7) + 8 * (t & 1);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float v = __shfl(xr[t >> 1][e], src, 16);
+                ch[e] = __fadd_rn(ch[e], __fmul_rn(v, v));
+            }
+        }
+    }
+    const int hi = l16 & 1;
+    float p[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float c0 = __shfl(ch[e], hi, 16), c1 = __shfl(ch[e], 2 + hi, 16), c2 = __shfl(ch[e], 4 + hi, 16), c3 = __shfl(ch[e], 6 + hi, 16);
+        p[e] = __fadd_rn(__fadd_rn(__fadd_rn(c0, c1), c2), c3);
+    }
+    const float f_lo_own = __fadd_rn(__fadd_rn(__fadd_rn(p[0], p[1]), p[2]), p[3]);     // meaningful on even lanes (hi == 0)
+    const float f_lo = __shfl(f_lo_own, 0, 16);
+    const float f_hi_own = __fadd_rn(__fadd_rn(__fadd_rn(__fadd_rn(f_lo, p[0]), p[1]), p[2]), p[3]);   // meaningful on odd lanes
+    const float x2 = __shfl(f_hi_own, 1, 16);
+    float nrm = sqrtf(x2);
+    if (XBF16) nrm = round_to_bf16(nrm);
+    nrm = fmaxf(nrm, XBF16 ? round_to_bf16(1e-6f) : 1e-6f);
+    if (!row_ok) return;
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
+        const int d = 64 * k + 4 * l16;
+        if (d >= D) continue;
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            v[e] = xr[k][e] / nrm;
+            if (XBF16) v[e] = round_to_bf16(v[e]);
+        }
+        if (XBF16) {
+            uint2 w;
+            w.x = (__float_as_uint(v[0]) >> 16) | (__float_as_uint(v[1]) & 0xffff0000u);
+            w.y = (__float_as_uint(v[2]) >> 16) | (__float_as_uint(v[3]) & 0xffff0000u);
+            *(uint2 *)((unsigned short *)out + row * ldo + d) = w;
+        } else {
+            *(f32x4 *)((float *)out + row * ldo + d) = f32x4{v[0], v[1], v[2], v[3]};
+        }
+    }
+}
+
 extern "C" int vqhip_l2norm_rows(const void *x, int x_dtype, int64_t N, int D, int64_t ldx, void *out, int64_t ldo, void *stream)
 {
     if (N < 0) VQ_FAIL(VQHIP_EINVAL, "l2norm_rows: N < 0");
@@ -1479,8 +1557,26 @@ extern "C" int vqhip_l2norm_rows(const void *x, int x_dtype, int64_t N, int D, i
     if (ldx < D || ldo < D) VQ_FAIL(VQHIP_EINVAL, "l2norm_rows: row stride smaller than D");
     if ((((uintptr_t)x) % (4 * es)) || ((ldx * es) % (4 * es)) || (((uintptr_t)out) % (4 * es)) || ((ldo * es) % (4 * es)))
         VQ_FAIL(VQHIP_EALIGN, "l2norm_rows: rows must be aligned to 4 elements");
-    const unsigned blocks = (unsigned)((N + 127) / 128);
     hipStream_t st = (hipStream_t)stream;
+    {
+        static int old_kernel = -1;     // VQHIP_L2NORM_OLD=1: the 32-rows-per-wave kernel (A/B runs)
+        if (old_kernel < 0) { const char *e = getenv("VQHIP_L2NORM_OLD"); old_kernel = (e && e[0] == '1') ? 1 : 0; }
+        if (!old_kernel) {
+            const unsigned b16 = (unsigned)((N + 15) / 16);
+#define VQ_L2N16(NKV)                                                                                                              \
+    do {                                                                                                                           \
+        if (x_dtype == VQHIP_BF16) hipLaunchKernelGGL((vq_l2norm16_kernel<NKV, true>), dim3(b16), dim3(256), 0, st, x, N, D, ldx, out, ldo);  \
+        else hipLaunchKernelGGL((vq_l2norm16_kernel<NKV, false>), dim3(b16), dim3(256), 0, st, x, N, D, ldx, out, ldo);            \
+    } while (0)
+            if (D <= 64) VQ_L2N16(1);
+            else if (D == 128) VQ_L2N16(2);
+            else if (D == 256) VQ_L2N16(4);
+            else VQ_L2N16(8);
+#undef VQ_L2N16
+            return launch_status("vq_l2norm16_kernel");
+        }
+    }
+    const unsigned blocks = (unsigned)((N + 127) / 128);
 #define VQ_L2N(DTV)                                                                                                   \
     do {                                                                                                              \
         if (x_dtype == VQHIP_BF16) hipLaunchKernelGGL((vq_l2norm_kernel<DTV, true>), dim3(blocks), dim3(256), 0, st, x, N, ldx, out, ldo);  \

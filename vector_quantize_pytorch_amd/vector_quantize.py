@@ -124,13 +124,20 @@ def other_float_dtypes_as_fp32(forward):
     import functools
 
     @functools.wraps(forward)
-    def wrapped(self, x, *args, **kwargs):
+    def wrapped(self, *args, **kwargs):
+        x = args[0] if args else kwargs.get("x")
         if torch.is_tensor(x) and x.is_floating_point() and x.dtype not in (torch.float32, torch.bfloat16):
-            out = forward(self, x.float(), *args, **kwargs)
+            if args:
+                args = (x.float(), *args[1:])
+            else:
+                kwargs = dict(kwargs, x=x.float())
+            out = forward(self, *args, **kwargs)
+            if not isinstance(out, tuple):
+                return out
             # (quantize, indices, loss[, all_codes of the residual modules | LossBreakdown]): the code tensors go back to x's dtype
             back = lambda t: t.to(x.dtype) if torch.is_tensor(t) and t.is_floating_point() and t.ndim >= 3 else t
-            return (out[0].to(x.dtype), out[1], out[2], *(back(t) for t in out[3:]))
-        return forward(self, x, *args, **kwargs)
+            return (out[0].to(x.dtype), *out[1:3], *(back(t) for t in out[3:]))
+        return forward(self, *args, **kwargs)
     return wrapped
 
 
