@@ -199,12 +199,19 @@ int vqhip_rvq_forward(const void *x, int x_dtype, int64_t N, int D, int64_t ldx,
  *                    out = |q|/|x| (x - 2 (x.w) w + 2 (x.u) qh)   (mode 2; u, qh, w as in the reference)
  *  vqhip_route_bwd : grad_x = J^T g_out (J of the mode; mode 0 = no g_out term)
  *                             + 2 * (*loss_coef) * (x - q) on rows with row_mask != 0  (loss_coef nullable,
- *                             a DEVICE scalar = d loss / d sum_of_squares) */
+ *                             a DEVICE scalar = d loss / d sum_of_squares).
+ *                    masked_rows: what the forward left on the rows with row_mask == 0 -- 0: the routed value like any row (the mask
+ *                    only keeps them out of the loss), 1: x itself (vqhip_mask_fill_rows: grad_x = g_out there), 2: zeros (grad_x = 0).
+ *  vqhip_mask_fill_rows : the padding of a masked batch, in place (vqp.py:1386-1394: quantize = where(mask, quantize, orig_input or
+ *                    zeros), indices = where(mask, indices, -1)): rows with row_mask == 0 of q take x's row (zeros != 0: zeros), their
+ *                    idx entry -1; q or idx may be null.  Touches the padding rows only. */
 int vqhip_route_fwd(const void *x, const void *q, int dtype, int64_t N, int D, int64_t ldx, int64_t ldq,
                     void *out, int64_t ldo, int mode, void *stream);
 int vqhip_route_bwd(const void *x, const void *q, const void *g_out, int dtype, int64_t N, int D,
                     int64_t ldx, int64_t ldq, int64_t ldg, const float *loss_coef, const uint8_t *row_mask,
-                    int mode, void *grad_x, int64_t ldo, void *stream);
+                    int mode, int masked_rows, void *grad_x, int64_t ldo, void *stream);
+int vqhip_mask_fill_rows(void *q, const void *x, int dtype, int64_t N, int D, int64_t ldq, int64_t ldx, const uint8_t *row_mask,
+                         int64_t *idx, int64_t idx_stride, int zeros, void *stream);
 
 /* ---- gradient routing through the residual loop -------------------------------------------------
  * Replaces, for ResidualVQ.forward with an input that requires grad (rvq.py:469-568, quant_grad_frac = 0): per stage the
@@ -229,7 +236,7 @@ int vqhip_route_fwd_gather(const void *x, const void *codes, const int64_t *idx,
                            int64_t ldx, void *out, int64_t ldo, int mode, void *stream);
 int vqhip_route_bwd_gather(const void *x, const void *codes, const int64_t *idx, int64_t idx_stride, const void *g_out, int dtype,
                            int64_t N, int D, int64_t ldx, int64_t ldg, const float *loss_coef, const uint8_t *row_mask,
-                           int mode, void *grad_x, int64_t ldo, void *stream);
+                           int mode, int masked_rows, void *grad_x, int64_t ldo, void *stream);
 
 /* out[n] = x[n] - route(x[n], codes[idx[n * idx_stride]]): the input of the next ResidualVQ stage when the layer returned the ROUTED
  * value (`residual - quantized.detach()`, rvq.py:524, in a training step whose input requires grad, vqp.py:1225-1233).

@@ -1123,6 +1123,46 @@ def test_sim_vq_step_with_closed_form_gradients_equals_the_autograd_graph(dev, m
         _close(u, v, 5e-5, "gradient of the learned map")
 
 
+@pytest.mark.parametrize("kw", [dict(dim=64, codebook_size=256), dict(dim=256, codebook_size=512, rotation_trick=False),
+                                dict(dim=128, codebook_size=128, return_zeros_for_masked_padding=False),
+                                dict(dim=32, codebook_size=64, learnable_codebook=True, ema_update=False),
+                                dict(dim=64, codebook_size=64, threshold_ema_dead_code=2)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_padding_rows_written_by_the_node_equal_the_references_where(dev, monkeypatch, kw, dtype):
+    """A padded batch (`mask` / `lens`): output and indices of the padding rows come from vqhip_mask_fill_rows inside the autograd node
+    (padding rows only) and its gradient from the routing kernel, against the reference's torch.where(mask, quantize, orig_input |
+    zeros) / where(mask, indices, -1) at the end of forward (vqp.py:1386-1394; VQHIP_MASK_FILL=0): bit-identical outputs, indices,
+    losses, codebooks and input gradients, training with / without input gradients and eval."""
+    from vector_quantize_pytorch_amd import VectorQuantize
+    if dtype == torch.bfloat16 and kw.get("learnable_codebook"):
+        pytest.skip("one dtype is enough for the learnable path")
+    torch.manual_seed(0)
+    a, b = VectorQuantize(**kw).to(dev).train(), VectorQuantize(**kw).to(dev).train()
+    b.load_state_dict(a.state_dict())
+    for step, (grad, train) in enumerate(((False, True), (True, True), (True, True), (False, False))):
+        a.train(train); b.train(train)
+        x = torch.randn(4, 300, kw["dim"], device=dev).to(dtype)
+        lens = torch.tensor([300, 1, 170, 299], device=dev)
+        gq = torch.randn_like(x)
+        res = []
+        rng = torch.cuda.get_rng_state(dev)
+        for mod, flag in ((a, "1"), (b, "0")):
+            torch.cuda.set_rng_state(rng, dev)
+            monkeypatch.setenv("VQHIP_MASK_FILL", flag)
+            xi = x.clone().requires_grad_(grad)
+            q, ind, loss = mod(xi, lens=lens)
+            if grad:
+                torch.autograd.backward((q, loss.sum()), (gq, None))
+            res.append((q, ind, loss, xi.grad))
+        (qa, ia, la, ga), (qb, ib, lb, gb) = res
+        assert torch.equal(ia, ib) and int((ia == -1).sum()) == 4 * 300 - int(lens.sum())
+        assert torch.equal(qa, qb) and torch.allclose(la, lb, rtol=1e-6, atol=0)
+        if grad:
+            assert torch.equal(ga, gb)
+        _close(a._codebook.embed, b._codebook.embed, 1e-5, "codebook")
+        b.load_state_dict(a.state_dict())
+
+
 @pytest.mark.parametrize("dtype", [torch.float16, torch.float64])
 def test_float16_and_float64_inputs_compute_in_fp32_and_come_back_in_their_dtype(dev, dtype):
     """The reference's codebook computes in float32 whatever comes in (x.float(), vqp.py:690) and returns quantize in the input's dtype

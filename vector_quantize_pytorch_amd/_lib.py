@@ -71,6 +71,8 @@ def lib():
     L.vqhip_transpose_batched.restype = i32
     L.vqhip_expire_pick.argtypes = [vp, vp, vp, vp, i32, i64, i64, vp, i64, i32, i32, f32, f32, i32, vp]
     L.vqhip_expire_pick.restype = i32
+    L.vqhip_mask_fill_rows.argtypes = [vp, vp, i32, i64, i32, i64, i64, vp, vp, i64, i32, vp]
+    L.vqhip_mask_fill_rows.restype = i32
     L.vqhip_l2norm_rows_bwd.restype = i32
     L.vqhip_screen_chain_supported.argtypes = [i32, i32]
     L.vqhip_screen_chain_supported.restype = i32
@@ -79,7 +81,7 @@ def lib():
     L.vqhip_l2norm_rows.restype = i32
     L.vqhip_assign_screened.restype = i32
     L.vqhip_route_fwd.argtypes = [vp, vp, i32, i64, i32, i64, i64, vp, i64, i32, vp]
-    L.vqhip_route_bwd.argtypes = [vp, vp, vp, i32, i64, i32, i64, i64, i64, vp, vp, i32, vp, i64, vp]
+    L.vqhip_route_bwd.argtypes = [vp, vp, vp, i32, i64, i32, i64, i64, i64, vp, vp, i32, i32, vp, i64, vp]
     L.vqhip_route_fwd.restype = i32
     L.vqhip_ema_renormalize_shard.argtypes = [vp, vp, vp, i32, i32, f32, vp, i32, i32, vp, vp]
     L.vqhip_ema_renormalize_shard.restype = i32
@@ -122,7 +124,7 @@ def lib():
     L.vqhip_assign_batched.restype = i32
     L.vqhip_route_fwd_gather.argtypes = [vp, vp, vp, i64, i32, i64, i32, i64, vp, i64, i32, vp]
     L.vqhip_route_fwd_gather.restype = i32
-    L.vqhip_route_bwd_gather.argtypes = [vp, vp, vp, i64, vp, i32, i64, i32, i64, i64, vp, vp, i32, vp, i64, vp]
+    L.vqhip_route_bwd_gather.argtypes = [vp, vp, vp, i64, vp, i32, i64, i32, i64, i64, vp, vp, i32, i32, vp, i64, vp]
     L.vqhip_route_bwd_gather.restype = i32
     L.vqhip_ema_batched_ws_stride.argtypes = [i64, i32]
     L.vqhip_ema_batched_ws_stride.restype = ctypes.c_size_t
@@ -147,7 +149,7 @@ def lib():
 
 EXPORTS = ("vqhip_version", "vqhip_last_error", "vqhip_packed_bytes", "vqhip_pack_codebook",
            "vqhip_assign_blocks", "vqhip_assign", "vqhip_screen_supported", "vqhip_screen_workspace_bytes",
-           "vqhip_screen_blocks", "vqhip_screen_partials", "vqhip_assign_screened", "vqhip_screen_chain_supported", "vqhip_assign_screened_chain", "vqhip_l2norm_rows", "vqhip_l2norm_rows_bwd", "vqhip_transpose_batched", "vqhip_expire_pick", "vqhip_scores", "vqhip_rvq_forward", "vqhip_reduce_partials", "vqhip_reduce_partials_rows", "vqhip_ema_fold_many", "vqhip_ema_workspace_bytes", "vqhip_ema_accumulate", "vqhip_ema_sqerr_partials", "vqhip_ema_accumulate_sqerr",
+           "vqhip_screen_blocks", "vqhip_screen_partials", "vqhip_assign_screened", "vqhip_screen_chain_supported", "vqhip_assign_screened_chain", "vqhip_l2norm_rows", "vqhip_l2norm_rows_bwd", "vqhip_transpose_batched", "vqhip_expire_pick", "vqhip_mask_fill_rows", "vqhip_scores", "vqhip_rvq_forward", "vqhip_reduce_partials", "vqhip_reduce_partials_rows", "vqhip_ema_fold_many", "vqhip_ema_workspace_bytes", "vqhip_ema_accumulate", "vqhip_ema_sqerr_partials", "vqhip_ema_accumulate_sqerr",
            "vqhip_ema_finalize", "vqhip_decode_sum", "vqhip_row_sumsq", "vqhip_assign_rowwise", "vqhip_score_indices", "vqhip_topk", "vqhip_expire_scatter", "vqhip_kmeans_update", "vqhip_route_fwd", "vqhip_route_bwd", "vqhip_rvq_route", "vqhip_ema_renormalize_shard", "vqhip_scores_lse",
            "vqhip_pack_best", "vqhip_unpack_best", "vqhip_vq_step_supported", "vqhip_vq_step_workspace_bytes", "vqhip_vq_train_step", "vqhip_route_residual",
            "vqhip_pack_codebook_batched", "vqhip_screen_batched_ws_stride", "vqhip_assign_screened_batched", "vqhip_assign_batched",
@@ -678,7 +680,8 @@ def route_fwd_gather(x: torch.Tensor, codes: torch.Tensor, idx: torch.Tensor, mo
 
 
 @_on_device
-def route_bwd_gather(x: torch.Tensor, codes: torch.Tensor, idx: torch.Tensor, g_out, loss_coef, row_mask, mode: int) -> torch.Tensor:
+def route_bwd_gather(x: torch.Tensor, codes: torch.Tensor, idx: torch.Tensor, g_out, loss_coef, row_mask, mode: int,
+                     masked_rows: int = 0) -> torch.Tensor:
     """route_bwd with q = codes[idx] gathered inside the kernel"""
     _need_gpu(x, codes, idx, g_out, loss_coef, row_mask)
     xk, N, D, ldx = as_rows(x)
@@ -692,12 +695,37 @@ def route_bwd_gather(x: torch.Tensor, codes: torch.Tensor, idx: torch.Tensor, g_
     gx = torch.empty(x.shape, dtype=x.dtype, device=x.device)
     if N > 0:
         _check(lib().vqhip_route_bwd_gather(_ptr(xk), _ptr(codes), _ptr(idx), 1, _ptr(gk), _dtype_code(xk), N, D, ldx, ldg, _ptr(loss_coef),
-                                            _ptr(row_mask), mode if gk is not None else 0, _ptr(gx), D, _stream()), "vqhip_route_bwd_gather")
+                                            _ptr(row_mask), mode if gk is not None else 0, int(masked_rows), _ptr(gx), D, _stream()),
+               "vqhip_route_bwd_gather")
     return gx
 
 
 @_on_device
-def route_bwd(x: torch.Tensor, q: torch.Tensor, g_out, loss_coef, row_mask, mode: int) -> torch.Tensor:
+def mask_fill_rows(q, x, row_mask: torch.Tensor, idx=None, *, zeros=False):
+    """In place: the rows with row_mask == 0 of q [..., D] take x's rows (zeros=True: zeros) and their entries of idx [...] become -1
+    (the reference's two torch.where of a masked batch, vqp.py:1386-1394); touches the padding rows only."""
+    _need_gpu(q, x, row_mask, idx)
+    row_mask = row_mask.reshape(-1).to(torch.uint8).contiguous()
+    N = row_mask.numel()
+    qk = xk = None
+    D = ldq = ldx = 1
+    dt = F32
+    if q is not None:
+        qk, Nq, D, ldq = as_rows(q)
+        assert Nq == N and qk.data_ptr() == q.data_ptr(), "mask_fill_rows: q must be row-addressable in place"
+        dt = _dtype_code(qk)
+        if not zeros:
+            xk, Nx, Dx, ldx = as_rows(x)
+            assert Nx == N and Dx == D and xk.dtype == qk.dtype
+    if idx is not None:
+        assert idx.dtype == torch.int64 and idx.is_contiguous() and idx.numel() == N
+    if N > 0:
+        _check(lib().vqhip_mask_fill_rows(_ptr(qk), _ptr(xk), dt, N, D, ldq, ldx, _ptr(row_mask), _ptr(idx), 1, int(bool(zeros)), _stream()),
+               "vqhip_mask_fill_rows")
+
+
+@_on_device
+def route_bwd(x: torch.Tensor, q: torch.Tensor, g_out, loss_coef, row_mask, mode: int, masked_rows: int = 0) -> torch.Tensor:
     """grad wrt x of (routed output, commit-loss sum); g_out may be None (mode 0), loss_coef a 0-dim fp32 device tensor or None."""
     _need_gpu(x, q, g_out, loss_coef, row_mask)
     xk, N, D, ldx = as_rows(x)
@@ -712,7 +740,7 @@ def route_bwd(x: torch.Tensor, q: torch.Tensor, g_out, loss_coef, row_mask, mode
     gx = torch.empty(x.shape, dtype=x.dtype, device=x.device)
     if N > 0:
         _check(lib().vqhip_route_bwd(_ptr(xk), _ptr(qk), _ptr(gk), _dtype_code(xk), N, D, ldx, ldq, ldg, _ptr(loss_coef),
-                                     _ptr(row_mask), mode if gk is not None else 0, _ptr(gx), D, _stream()), "vqhip_route_bwd")
+                                     _ptr(row_mask), mode if gk is not None else 0, int(masked_rows), _ptr(gx), D, _stream()), "vqhip_route_bwd")
     return gx
 
 

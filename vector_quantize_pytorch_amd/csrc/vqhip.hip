@@ -2519,6 +2519,10 @@ struct RouteArgs {
     const int64_t *qidx;
     int64_t qidx_stride;
     int sub;
+    // backward: what the forward left on the rows with row_mask == 0 (vqhip_mask_fill_rows, the reference's torch.where(mask, quantize,
+    // orig_input | zeros) of vqp.py:1386-1394): 0 = the routed value like any row, 1 = x itself (the upstream gradient passes through),
+    // 2 = zeros (no gradient)
+    int masked_rows;
 };
 
 template <bool BF16, bool BWD, int NE, int LPR>
@@ -2532,7 +2536,7 @@ __global__ void __launch_bounds__(256) vq_route_kernel(const RouteArgs a)
     const int64_t n = valid ? n0 : a.N - 1;            // (rows share a wave: the ones past the end repeat the last row and store nothing)
     float e[NE], qv[NE], g[NE];
     row_load8<BF16, NE, LPR>(a.x, n * a.ldx, a.D, lane, a.vec != 0, e);
-    const int64_t qrow = a.qidx ? a.qidx[n * a.qidx_stride] : n;
+    const int64_t qrow = a.qidx ? max((int64_t)0, a.qidx[n * a.qidx_stride]) : n;   // (-1: a padding row, its value is not used)
     row_load8<BF16, NE, LPR>(a.q, qrow * a.ldq, a.D, lane, a.vec != 0, qv);
     if (BWD && a.g) row_load8<BF16, NE, LPR>(a.g, n * a.ldg, a.D, lane, a.vec != 0, g);
     float r[NE];
@@ -2555,6 +2559,10 @@ __global__ void __launch_bounds__(256) vq_route_kernel(const RouteArgs a)
         const float c2 = counted ? 2.f * (*a.loss_coef) : 0.f;
 #pragma unroll
         for (int k = 0; k < NE; ++k) r[k] += c2 * (e[k] - qv[k]);
+    }
+    if (BWD && a.masked_rows && a.row_mask && a.row_mask[n] == 0) {
+#pragma unroll
+        for (int k = 0; k < NE; ++k) r[k] = (a.masked_rows == 1 && a.g) ? g[k] : 0.f;
     }
     if (valid) row_store8<BF16, NE, LPR>(a.out, n * a.ldo, a.D, lane, a.vec != 0, r);
 }
@@ -2586,7 +2594,7 @@ extern "C" int vqhip_route_fwd(const void *x, const void *q, int dtype, int64_t 
     if (dtype != VQHIP_F32 && dtype != VQHIP_BF16) VQ_FAIL(VQHIP_EINVAL, "route_fwd: unknown dtype");
     RouteArgs a;
     a.x = x; a.q = q; a.g = nullptr; a.out = out; a.N = N; a.D = D; a.ldx = ldx; a.ldq = ldq; a.ldg = 0; a.ldo = ldo;
-    a.loss_coef = nullptr; a.row_mask = nullptr; a.mode = mode; a.qidx = nullptr; a.qidx_stride = 0; a.sub = 0;
+    a.loss_coef = nullptr; a.row_mask = nullptr; a.mode = mode; a.qidx = nullptr; a.qidx_stride = 0; a.sub = 0; a.masked_rows = 0;
     const int es = dtype == VQHIP_BF16 ? 2 : 4;
     a.vec = rows_vec4(x, ldx, D, es) && rows_vec4(q, ldq, D, es) && rows_vec4(out, ldo, D, es);
     return route_launch(a, dtype, false, (hipStream_t)stream);
@@ -2607,7 +2615,7 @@ extern "C" int vqhip_route_residual(const void *x, int dtype, int64_t N, int D, 
     if (mode != 1 && mode != 2) VQ_FAIL(VQHIP_EINVAL, "route_residual: mode must be 1 (straight-through) or 2 (rotation trick)");
     RouteArgs a;
     a.x = x; a.q = codes; a.g = nullptr; a.out = out; a.N = N; a.D = D; a.ldx = ldx; a.ldq = D; a.ldg = 0; a.ldo = ldo;
-    a.loss_coef = nullptr; a.row_mask = nullptr; a.mode = mode; a.qidx = idx; a.qidx_stride = idx_stride; a.sub = 1;
+    a.loss_coef = nullptr; a.row_mask = nullptr; a.mode = mode; a.qidx = idx; a.qidx_stride = idx_stride; a.sub = 1; a.masked_rows = 0;
     const int es = dtype == VQHIP_BF16 ? 2 : 4;
     a.vec = rows_vec4(x, ldx, D, es) && rows_vec4(codes, D, D, es) && rows_vec4(out, ldo, D, es);
     return route_launch(a, dtype, false, (hipStream_t)stream);
@@ -2615,8 +2623,9 @@ extern "C" int vqhip_route_residual(const void *x, int dtype, int64_t N, int D, 
 
 extern "C" int vqhip_route_bwd(const void *x, const void *q, const void *g_out, int dtype, int64_t N, int D,
                                int64_t ldx, int64_t ldq, int64_t ldg, const float *loss_coef, const uint8_t *row_mask,
-                               int mode, void *grad_x, int64_t ldo, void *stream)
+                               int mode, int masked_rows, void *grad_x, int64_t ldo, void *stream)
 {
+    if (masked_rows < 0 || masked_rows > 2) VQ_FAIL(VQHIP_EINVAL, "route_bwd: masked_rows must be 0, 1 or 2");
     if (N < 0 || !x || !q || !grad_x) VQ_FAIL(VQHIP_EINVAL, "route_bwd: bad argument");
     if (D < 1 || D > 512) VQ_FAIL(VQHIP_EDIM, "route_bwd: D=%d unsupported (1..512)", D);
     if (mode < 0 || mode > 2) VQ_FAIL(VQHIP_EINVAL, "route_bwd: mode must be 0 (loss only), 1 or 2");
@@ -2624,7 +2633,7 @@ extern "C" int vqhip_route_bwd(const void *x, const void *q, const void *g_out, 
     RouteArgs a;
     a.x = x; a.q = q; a.g = (mode == 0) ? nullptr : g_out; a.out = grad_x; a.N = N; a.D = D; a.ldx = ldx; a.ldq = ldq;
     a.ldg = ldg; a.ldo = ldo; a.loss_coef = loss_coef; a.row_mask = row_mask; a.mode = (mode == 0) ? 1 : mode;
-    a.qidx = nullptr; a.qidx_stride = 0; a.sub = 0;
+    a.qidx = nullptr; a.qidx_stride = 0; a.sub = 0; a.masked_rows = masked_rows;
     const int es = dtype == VQHIP_BF16 ? 2 : 4;
     a.vec = rows_vec4(x, ldx, D, es) && rows_vec4(q, ldq, D, es) && rows_vec4(a.g, ldg, D, es) && rows_vec4(grad_x, ldo, D, es);
     return route_launch(a, dtype, true, (hipStream_t)stream);
@@ -2642,7 +2651,7 @@ extern "C" int vqhip_route_fwd_gather(const void *x, const void *codes, const in
     if (mode != 1 && mode != 2) VQ_FAIL(VQHIP_EINVAL, "route_fwd_gather: mode must be 1 (straight-through) or 2 (rotation trick)");
     RouteArgs a;
     a.x = x; a.q = codes; a.g = nullptr; a.out = out; a.N = N; a.D = D; a.ldx = ldx; a.ldq = D; a.ldg = 0; a.ldo = ldo;
-    a.loss_coef = nullptr; a.row_mask = nullptr; a.mode = mode; a.qidx = idx; a.qidx_stride = idx_stride; a.sub = 0;
+    a.loss_coef = nullptr; a.row_mask = nullptr; a.mode = mode; a.qidx = idx; a.qidx_stride = idx_stride; a.sub = 0; a.masked_rows = 0;
     const int es = dtype == VQHIP_BF16 ? 2 : 4;
     a.vec = rows_vec4(x, ldx, D, es) && rows_vec4(codes, D, D, es) && rows_vec4(out, ldo, D, es);
     return route_launch(a, dtype, false, (hipStream_t)stream);
@@ -2650,8 +2659,9 @@ extern "C" int vqhip_route_fwd_gather(const void *x, const void *codes, const in
 
 extern "C" int vqhip_route_bwd_gather(const void *x, const void *codes, const int64_t *idx, int64_t idx_stride, const void *g_out, int dtype,
                                       int64_t N, int D, int64_t ldx, int64_t ldg, const float *loss_coef, const uint8_t *row_mask,
-                                      int mode, void *grad_x, int64_t ldo, void *stream)
+                                      int mode, int masked_rows, void *grad_x, int64_t ldo, void *stream)
 {
+    if (masked_rows < 0 || masked_rows > 2) VQ_FAIL(VQHIP_EINVAL, "route_bwd_gather: masked_rows must be 0, 1 or 2");
     if (!x || !codes || !idx || !grad_x) VQ_FAIL(VQHIP_EINVAL, "route_bwd_gather: null pointer");
     if (dtype != VQHIP_F32 && dtype != VQHIP_BF16) VQ_FAIL(VQHIP_EINVAL, "route_bwd_gather: unknown dtype");
     if (N < 0 || D < 1 || D > 512 || idx_stride < 1) VQ_FAIL(VQHIP_EINVAL, "route_bwd_gather: bad size");
@@ -2659,10 +2669,58 @@ extern "C" int vqhip_route_bwd_gather(const void *x, const void *codes, const in
     RouteArgs a;
     a.x = x; a.q = codes; a.g = (mode == 0) ? nullptr : g_out; a.out = grad_x; a.N = N; a.D = D; a.ldx = ldx; a.ldq = D;
     a.ldg = ldg; a.ldo = ldo; a.loss_coef = loss_coef; a.row_mask = row_mask; a.mode = (mode == 0) ? 1 : mode;
-    a.qidx = idx; a.qidx_stride = idx_stride; a.sub = 0;
+    a.qidx = idx; a.qidx_stride = idx_stride; a.sub = 0; a.masked_rows = masked_rows;
     const int es = dtype == VQHIP_BF16 ? 2 : 4;
     a.vec = rows_vec4(x, ldx, D, es) && rows_vec4(codes, D, D, es) && rows_vec4(a.g, ldg, D, es) && rows_vec4(grad_x, ldo, D, es);
     return route_launch(a, dtype, true, (hipStream_t)stream);
+}
+
+// Padding rows of a masked batch (vqp.py:1386-1394: quantize = where(mask, quantize, orig_input | zeros), indices = where(mask, indices,
+// -1)): in place on the rows with row_mask == 0 only -- the traffic of the padding, not three passes over N x D.  16 lanes per row.
+template <bool BF16>
+__global__ void __launch_bounds__(256) vq_mask_fill_kernel(void *q, const void *x, int64_t N, int D, int64_t ldq, int64_t ldx,
+                                                           const uint8_t *row_mask, int64_t *idx, int64_t idx_stride, int zeros, int vec)
+{
+    const int l16 = threadIdx.x & 15;
+    const int64_t row = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
+    if (row >= N || row_mask[row] != 0) return;
+    if (idx && l16 == 0) idx[row * idx_stride] = -1;
+    if (!q) return;
+    for (int d = 4 * l16; d < D; d += 64) {
+        if (vec) {
+            if (BF16) {
+                uint2 w = {0u, 0u};
+                if (!zeros) w = *(const uint2 *)((const unsigned short *)x + row * ldx + d);
+                *(uint2 *)((unsigned short *)q + row * ldq + d) = w;
+            } else {
+                f32x4 w = {0.f, 0.f, 0.f, 0.f};
+                if (!zeros) w = *(const f32x4 *)((const float *)x + row * ldx + d);
+                *(f32x4 *)((float *)q + row * ldq + d) = w;
+            }
+        } else {
+            for (int i = 0; i < 4 && d + i < D; ++i) {
+                if (BF16) ((unsigned short *)q)[row * ldq + d + i] = zeros ? (unsigned short)0 : ((const unsigned short *)x)[row * ldx + d + i];
+                else ((float *)q)[row * ldq + d + i] = zeros ? 0.f : ((const float *)x)[row * ldx + d + i];
+            }
+        }
+    }
+}
+
+extern "C" int vqhip_mask_fill_rows(void *q, const void *x, int dtype, int64_t N, int D, int64_t ldq, int64_t ldx, const uint8_t *row_mask,
+                                    int64_t *idx, int64_t idx_stride, int zeros, void *stream)
+{
+    if (N < 0 || !row_mask || (!q && !idx)) VQ_FAIL(VQHIP_EINVAL, "mask_fill_rows: bad argument");
+    if (N == 0) return 0;
+    if (dtype != VQHIP_F32 && dtype != VQHIP_BF16) VQ_FAIL(VQHIP_EINVAL, "mask_fill_rows: unknown dtype");
+    if (q && (D < 1 || ldq < D || (!zeros && (!x || ldx < D)))) VQ_FAIL(VQHIP_EINVAL, "mask_fill_rows: bad rows");
+    if (idx && idx_stride < 1) VQ_FAIL(VQHIP_EINVAL, "mask_fill_rows: idx_stride < 1");
+    const int es = dtype == VQHIP_BF16 ? 2 : 4;
+    const int vec = (q && rows_vec4(q, ldq, D, es) && (zeros || rows_vec4(x, ldx, D, es))) ? 1 : 0;
+    const unsigned blocks = (unsigned)((N + 15) / 16);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == VQHIP_BF16) hipLaunchKernelGGL(vq_mask_fill_kernel<true>, dim3(blocks), dim3(256), 0, st, q, x, N, D, ldq, ldx, row_mask, idx, idx_stride, zeros, vec);
+    else hipLaunchKernelGGL(vq_mask_fill_kernel<false>, dim3(blocks), dim3(256), 0, st, q, x, N, D, ldq, ldx, row_mask, idx, idx_stride, zeros, vec);
+    return launch_status("vq_mask_fill_kernel");
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -45,13 +45,16 @@ class _QuantizeFn(torch.autograd.Function):
     Only x and q are saved; u, qh, w, s are recomputed in the backward kernel."""
 
     @staticmethod
-    def forward(ctx, x, vq, mask, kw, loss_scale=1.0, embed_param=None):
+    def forward(ctx, x, vq, mask, kw, loss_scale=1.0, embed_param=None, fill=0):
         """loss_scale: constant folded into the squared-error reduction (1 / numel for the unmasked commit loss), so that the
         third output IS mean((q - x)^2) without further elementwise kernels.
         embed_param [1, C, D]: a codebook that receives gradients (learnable_codebook / the output of vq_bridge; vqp.py:710, 766) --
         searched as given; its gradient is that of the commitment loss mean((codes[idx] - x)^2) with `quantize` NOT detached
         (vqp.py:1214, 1327): g_loss * 2 * loss_scale * (count_c * codes_c - sum of the rows quantized to c), i.e. the EMA statistics
-        of x (one vqhip_ema_accumulate in backward) -- the routed output itself carries no gradient to the codes (vqp.py:282-318)."""
+        of x (one vqhip_ema_accumulate in backward) -- the routed output itself carries no gradient to the codes (vqp.py:282-318).
+        fill (with a mask): the padding rows of the output take x's rows (1) or zeros (2) and their indices -1 here, in place on the
+        padding only (vqhip_mask_fill_rows) -- the reference's torch.where(mask, quantize, orig_input | zeros) / where(mask, indices, -1)
+        (vqp.py:1386-1394), whose gradient the backward kernel reproduces (padding rows: the upstream gradient, or none)."""
         cb = vq._codebook
         mode = 0
         if vq.training and x.requires_grad and vq.route_gradients_to_input:
@@ -79,6 +82,10 @@ class _QuantizeFn(torch.autograd.Function):
             out = L.route_fwd_gather(x, codes, idx, mode)
         elif mode != 0:
             out = L.route_fwd(x, q, mode)
+        ctx.fill = int(fill) if mask is not None else 0
+        if ctx.fill:
+            idx = idx.contiguous()
+            L.mask_fill_rows(out, x, mask, idx, zeros=ctx.fill == 2)
         ctx.mode = mode
         ctx.gather = gather
         ctx.has_mask = mask is not None
@@ -107,14 +114,16 @@ class _QuantizeFn(torch.autograd.Function):
         mask = tensors[-1] if ctx.has_mask else None
         use_g = ctx.mode != 0 and g_out is not None
         if not use_g and g_loss is None:
-            return None, None, None, None, None, g_embed
+            return None, None, None, None, None, g_embed, None
         if g_loss is not None and ctx.loss_scale != 1.0:
             g_loss = g_loss * ctx.loss_scale
         if ctx.gather:
-            gx = L.route_bwd_gather(x, tensors[1], tensors[2], L.rows_contiguous(g_out) if use_g else None, g_loss, mask, ctx.mode if use_g else 0)
+            gx = L.route_bwd_gather(x, tensors[1], tensors[2], L.rows_contiguous(g_out) if use_g else None, g_loss, mask, ctx.mode if use_g else 0,
+                                    masked_rows=ctx.fill)
         else:
-            gx = L.route_bwd(x, tensors[1], L.rows_contiguous(g_out) if use_g else None, g_loss, mask, ctx.mode if use_g else 0)
-        return gx, None, None, None, None, g_embed
+            gx = L.route_bwd(x, tensors[1], L.rows_contiguous(g_out) if use_g else None, g_loss, mask, ctx.mode if use_g else 0,
+                             masked_rows=ctx.fill)
+        return gx, None, None, None, None, g_embed, None
 
 
 def other_float_dtypes_as_fp32(forward):
@@ -834,6 +843,7 @@ class VectorQuantize(nn.Module):
                   input_normalized=pre_normalized)
         inplace_loss = orth_loss = diversity_loss = self.zero
         distances = ce_embed = None
+        mask_filled = 0
         if param_path:
             if ce_only:     # the codebook the search is about to use, live and as a snapshot (the EMA fold inside the search rewrites
                 cb0 = self._codebook                                                  # `embed` in place; see _CrossEntropyFn)
@@ -853,7 +863,14 @@ class VectorQuantize(nn.Module):
                 embed_param = cb_.embed if cb_.vq_bridge is None else cb_.vq_bridge(cb_.embed)              # [H, C, D], requires grad
                 if not self.learnable_codebook:      # (orthogonal regularisation alone makes the CODEBOOK learnable, vqp.py:939, but the
                     embed_param = embed_param.detach()   # commitment loss detaches `quantize` unless the module's own flag is set, :1214)
-            quantize, embed_ind, sq_sum = _QuantizeFn.apply(xs, self, rmask, kw, 1.0 / float(max(xs.numel(), 1)) if fold else 1.0, embed_param)
+            # a padded batch on the plain layout (rows = the caller's tensor): the padding rows of output and indices are written by
+            # the node itself (vqhip_mask_fill_rows, padding rows only) instead of two torch.where passes over the batch at the end
+            wants = xs.requires_grad and torch.is_grad_enabled()
+            if (mask is not None and xs is orig_input and self.heads == 1 and topk is None and not only_one
+                    and (not wants or (needs_grad and self.route_gradients_to_input)) and os.environ.get("VQHIP_MASK_FILL", "1") != "0"):
+                mask_filled = 2 if self.return_zeros_for_masked_padding else 1
+            quantize, embed_ind, sq_sum = _QuantizeFn.apply(xs, self, rmask, kw, 1.0 / float(max(xs.numel(), 1)) if fold else 1.0, embed_param,
+                                                            mask_filled)
 
         # ---- loss (vqp.py:1282-1348) --------------------------------------------------------------
         # the reference's loss starts as a leaf that requires grad in training (vqp.py:1282).  Here: a cached CONSTANT zero per
@@ -961,7 +978,7 @@ class VectorQuantize(nn.Module):
         if only_one:
             quantize = quantize[:, 0]
 
-        if mask is not None:
+        if mask is not None and not mask_filled:
             fill = torch.zeros_like(orig_input) if self.return_zeros_for_masked_padding else orig_input
             if topk is not None:
                 fill = fill[..., None, :]
