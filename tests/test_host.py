@@ -185,3 +185,64 @@ def test_every_entry_point_has_a_declared_ctypes_signature():
         if sym in ("vqhip_version", "vqhip_last_error"):
             continue
         assert getattr(L, sym).argtypes is not None, f"{sym}: no argtypes declared in _lib.lib()"
+
+
+def test_expire_pick_permutation_is_a_bijection_of_the_rows():
+    """The row vqhip_expire_pick hands code c (csrc: vq_expire_pick_kernel): the affine map t -> (a t + b) mod p of Z_p, p the smallest
+    prime >= n, cycle-walked into [0, n).  Restated here in Python: for C <= n the codes take pairwise distinct rows (the reference
+    samples without replacement, vqp.py:180-188), for every (a, b) in [1, p)."""
+    import random
+    from vector_quantize_pytorch_amd._lib import _next_prime
+    assert [_next_prime(n) for n in (1, 2, 3, 4, 8, 9, 90, 1024, 8192)] == [2, 2, 3, 5, 11, 11, 97, 1031, 8209]
+
+    def pick(c, a, b, p, n):
+        v = (a * (c % p) + b) % p
+        it = 0
+        while v >= n and it < 64:
+            v = (a * v + b) % p
+            it += 1
+        return v if v < n else v % n
+
+    rng = random.Random(0)
+    for n in (1, 2, 7, 90, 1000, 4099):
+        p = _next_prime(n)
+        for _ in range(20):
+            a, b = rng.randrange(1, p), rng.randrange(1, p)
+            C = min(n, 512)
+            rows = [pick(c, a, b, p, n) for c in range(C)]
+            assert all(0 <= r < n for r in rows)
+            # distinct unless the walk was cut short by the 64-step cap (a short cycle of the map inside [n, p): not for these sizes)
+            assert len(set(rows)) == C, (n, p, a, b)
+
+
+def test_other_float_dtypes_are_computed_in_float32_and_cast_back():
+    """The decorator around the modules' forward (vector_quantize.other_float_dtypes_as_fp32; reference: x.float() ... .type(dtype),
+    vqp.py:690, 1178): float16 / float64 inputs reach the wrapped forward as float32, positional or as x=, the code tensors come back
+    in the input's dtype, indices / losses / LossBreakdown-like extras untouched; float32 and bfloat16 pass through as they are."""
+    from vector_quantize_pytorch_amd.vector_quantize import other_float_dtypes_as_fp32
+    seen = []
+
+    class M:
+        @other_float_dtypes_as_fp32
+        def forward(self, x, flag=False):
+            seen.append(x.dtype)
+            out = (x * 2, torch.zeros(x.shape[:-1], dtype=torch.long), torch.zeros(()))
+            return (*out, torch.stack([x, x])) if flag else out
+
+    m = M()
+    for dt in (torch.float16, torch.float64):
+        x = torch.randn(2, 3, 4).to(dt)
+        q, ind, loss = m.forward(x)
+        assert seen[-1] == torch.float32 and q.dtype == dt and ind.dtype == torch.long and loss.dtype == torch.float32
+        q, ind, loss, codes = m.forward(x=x, flag=True)
+        assert seen[-1] == torch.float32 and q.dtype == dt and codes.dtype == dt and codes.shape == (2, 2, 3, 4)
+    for dt in (torch.float32, torch.bfloat16):
+        q, _, _ = m.forward(torch.randn(2, 3, 4).to(dt))
+        assert seen[-1] == dt and q.dtype == dt
+
+
+def test_transposed_view_detection_is_for_gpu_tensors_only():
+    from vector_quantize_pytorch_amd import _lib
+    t = torch.randn(3, 8, 5).transpose(1, 2)
+    assert not _lib.is_transposed_view(t)                  # CPU tensor: the product has no CPU path
+    assert _lib.rows_contiguous(torch.randn(4, 4)).is_contiguous()
