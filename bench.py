@@ -135,6 +135,25 @@ def screened_vs_exact(x, vq):
 
 
 # ----------------------------------------------------------------------------------------------------------------------
+def _preheat(dev, seconds=0.25):
+    """HBM-bound copies for `seconds` right before a timed section, so that the memory clock is at its operating state when the
+    windows start.  (Two default runs of round 4 measured every forward window at 1.2 ms with the search at its usual 0.62 ms -- the
+    HBM-bound statistics pass 2.6 x slower, the MFMA-bound search unchanged.  That turned out to be one box of the pool, with or
+    without this loop, profiles/r4_final/bench_slow_box.json; the loop stays as cheap insurance against a memory clock that is
+    still ramping when the first window starts.  Untimed, the same fixed work on every rank.)"""
+    if dev.type != "cuda" or seconds <= 0:
+        return
+    a = torch.empty(64 << 20, dtype=torch.float32, device=dev)
+    b = torch.empty_like(a)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        for _ in range(8):
+            b.copy_(a)
+        torch.cuda.synchronize(dev)
+    del a, b
+
+
 def _windows(run_step, steps, windows, sync):
     """`windows` back-to-back timed windows of exactly `steps` steps, each bracketed by barrier + synchronize on both sides;
     returns the per-window wall times (the reported step time is the MEDIAN window: one 20-step window is ~20 ms at cfg 2)"""
@@ -170,6 +189,7 @@ def _time_module(mod, batches, steps, warmup, sync, windows):
 
         def step(k):
             out[0] = mod(batches[k % len(batches)])
+        _preheat(batches[0].device)
         dts = _windows(step, steps, windows, sync)
     return dts, first, out[0]
 
@@ -188,6 +208,7 @@ def _time_grad_step(mod, batches, steps, warmup, sync, windows):
         torch.autograd.backward((res[0], res[2].sum()), (gq, None))     # dL/dx = J^T gq + d(sum of the commit losses)/dx
     for i in range(max(warmup, 1)):
         step(i)
+    _preheat(batches[0].device)
     return _windows(step, steps, windows, sync)
 
 
@@ -373,6 +394,7 @@ def vq_cfg2(args, world, rank, dev):
 
         def step(k):
             last[0] = vq(batches[k % N_BATCHES])
+        _preheat(dev)
         dts = _windows(step, args.steps, args.windows, sync)
         q, idx, loss = last[0]
 
