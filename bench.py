@@ -361,11 +361,17 @@ def vq_cfg2(args, world, rank, dev):
     # the fused train step (vqhip_vq_train_step) contains the search: the library records the two events around it itself
     orig_step = _lib.vq_train_step
 
-    def event_pair():
+    pool = []                                        # event pairs made (handles created) ahead of the timed windows
+
+    def make_pair():
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(); e1.record()                     # (creates the handles; the library records them again on the same stream)
-        ev.append((e0, e1))
         return e0, e1
+
+    def event_pair():
+        pr = pool.pop() if pool else make_pair()
+        ev.append(pr)
+        return pr
 
     def counting_step(*a, **k):
         r = orig_step(*a, **k)
@@ -390,6 +396,8 @@ def vq_cfg2(args, world, rank, dev):
             vq(batches[(i + 1) % N_BATCHES])
         sync()
         ev.clear(); exact_rows.clear(); pair_rows.clear()
+        pool.extend(make_pair() for _ in range(args.steps * args.windows))      # inside the windows only the library's two records run
+        sync()
         last = [None]
 
         def step(k):
