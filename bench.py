@@ -291,8 +291,8 @@ def other_workload(args, world, rank, dev, workload=None, steps=None, warmup=Non
     if counts:
         n_last = stages if len(counts) >= stages else len(counts)
         last = counts[-n_last:]                          # the searches of the last forward, in call order (group-major, then stage)
-        per_stage = {"open_frac": [round(float(c[0].item()) / c[2], 5) for c in last],
-                     "pair_frac": [round(float(c[1].item()) / c[2], 5) for c in last]}
+        per_stage = {"open_frac": [round(float(c[0].sum().item()) / c[2], 5) for c in last],      # (.sum(): one counter per row chunk)
+                     "pair_frac": [round(float(c[1].sum().item()) / c[2], 5) for c in last]}
     tmax = torch.tensor(dts, dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)

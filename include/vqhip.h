@@ -266,6 +266,19 @@ int vqhip_ema_finalize_batched(float *cluster_size, float *embed_avg, float *emb
                                int H, int C, int D, float one_minus_decay, float eps, int cosine, int do_update_ema,
                                float *denom_ws, void *stream);
 
+/* The statistics of S consecutive stages of a residual VQ in one set of launches (grid dimension y = stage; reference: the S calls of
+ * Codebook.forward's update block, vqp.py:599-617, one per quantizer of ResidualVQ.forward's loop, rvq.py:469-568).  Stage s: input rows at
+ * x + s * x_sstride elements ([N, D] at row stride ldx: the stage inputs of a residual chain, one behind the other), codes in column s of
+ * idx [N, idx_stride], statistics ACCUMULATED INTO stats + s * stats_stride (embed_sum [C, D] || count [C]), workspace slice s of
+ * vqhip_ema_batched_ws_stride(N, C) bytes (hist_zeroed != 0: the caller zeroed the first C ints of every slice), loss partials
+ * sqerr_partial + s * sqerr_stride (nullable with packed / embed).  packed_sstride / embed_sstride: floats between the stages'
+ * codebooks (0: one shared codebook, rvq.py:302-306).  Euclidean. */
+int vqhip_ema_accumulate_stages(const void *x, int x_dtype, int S, int64_t N, int D, int64_t ldx, int64_t x_sstride,
+                                const int64_t *idx, int64_t idx_stride, const uint8_t *row_mask, int C, float *stats,
+                                int64_t stats_stride, void *workspace, size_t workspace_bytes, int hist_zeroed,
+                                const float *packed, int64_t packed_sstride, const float *embed, int64_t embed_sstride,
+                                double *sqerr_partial, int64_t sqerr_stride, void *stream);
+
 /* ---- channel-first layouts ------------------------------------------------------------------------
  * `channel_last = False` / `accept_image_fmap` callers hand over [b, d, n] and the reference rearranges to [b, n, d] and back
  * (vqp.py:1136-1147, 1375-1384).  in [B, R, S] with the batches in_bstride >= R * S elements apart (a channel group of a wider
@@ -304,9 +317,21 @@ typedef struct {
     const uint8_t *row_mask;                                              /* nullable [N]: rows with 0 (padding: `mask` / `lens`,
                                                                              vqp.py:108-110, 599-601) are searched and gathered like the
                                                                              others but leave the statistics and the loss alone */
+    /* Row pipeline (round 5).  chunks > 1 (<= 4) with side_stream given: the rows are split into `chunks` contiguous chunks of
+     * vqhip_vq_step_chunk_rows(N, chunks) rows; the statistics of chunk k (histogram, scan, scatter, segmented sum + loss: HBM-bound)
+     * run on side_stream beside the search of chunk k + 1 on `stream`; the last chunk's statistics and the fold follow on `stream`
+     * once the side stream has been joined.  Counts are integers and the sums fp32 atomics in any order already, so the results are
+     * those of one chunk up to that rounding; indices / q are identical.  events[0 .. chunks): hipEvent_t of the caller's (the
+     * library creates nothing), re-recorded by every call.  chunks <= 1 or side_stream null: everything on `stream`.
+     * Chunk k's screening workspace (header: [0] rows of its exact sweep, [1] rows decided between two codes) starts
+     * sum_{j<k} (align256(vqhip_screen_workspace_bytes(n_j)) + align256(vqhip_ema_workspace_bytes(n_j, C))) bytes into `workspace`. */
+    int64_t chunks;
+    void *side_stream;
+    void *events[4];
 } vqhip_vq_step_t;
 int vqhip_vq_step_supported(int x_dtype, int64_t N, int D, int C);
 size_t vqhip_vq_step_workspace_bytes(int64_t N, int C);
+int64_t vqhip_vq_step_chunk_rows(int64_t N, int chunks);
 int vqhip_vq_train_step(const vqhip_vq_step_t *step, void *stream);
 
 /* ---- EMA sufficient statistics ----------------------------------------------------------------

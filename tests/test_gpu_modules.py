@@ -973,6 +973,37 @@ def test_fused_train_step_equals_the_separate_calls(dev, monkeypatch, dtype, kw,
         b.load_state_dict(a.state_dict())
 
 
+@pytest.mark.parametrize("dtype,kw", [(torch.bfloat16, dict(dim=256, codebook_size=1024)), (torch.float32, dict(dim=64, codebook_size=300)),
+                                      (torch.bfloat16, dict(dim=128, codebook_size=512, use_cosine_sim=True))])
+def test_fused_train_step_row_pipeline_equals_one_chunk(dev, monkeypatch, dtype, kw):
+    """Round 5: vqhip_vq_train_step with chunks = 2 / 3 / 4 (statistics of chunk k on a side stream beside the search of chunk k + 1;
+    the last chunk's scan folds cluster_size from the accumulated counts) against chunks = 1: indices, q and cluster_size identical
+    (integer counts), loss / embed_avg / embed to the rounding of the segmented sums' fp32 atomics; ragged row count (last chunk
+    shorter, not a multiple of the screening workgroup), a padded batch, several steps of an evolving codebook."""
+    from vector_quantize_pytorch_amd import VectorQuantize
+    torch.manual_seed(0)
+    mods = [VectorQuantize(**kw).to(dev).train() for _ in range(4)]
+    for m in mods[1:]:
+        m.load_state_dict(mods[0].state_dict())
+    N = (1 << 19) + 4 * 333
+    for step in range(3):
+        x = (torch.randn(4, N // 4, kw["dim"], device=dev) * (1.0 + step)).to(dtype)
+        call_kw = dict(lens=torch.randint(1, N // 4 + 1, (4,), device=dev)) if step == 1 else {}
+        outs = []
+        for K, m in zip((1, 2, 3, 4), mods):
+            monkeypatch.setenv("VQHIP_STEP_CHUNKS", str(K))
+            with torch.no_grad():
+                outs.append(m(x, **call_kw))
+        torch.cuda.synchronize()
+        for (q, i, l), m in zip(outs[1:], mods[1:]):
+            assert torch.equal(i, outs[0][1]) and torch.equal(q, outs[0][0])
+            assert torch.allclose(l, outs[0][2], rtol=2e-6, atol=0)
+            assert torch.equal(m._codebook.cluster_size, mods[0]._codebook.cluster_size)
+            _close(m._codebook.embed_avg, mods[0]._codebook.embed_avg, 1e-5, "embed_avg")
+            _close(m._codebook.embed, mods[0]._codebook.embed, 1e-5, "embed")
+            m.load_state_dict(mods[0].state_dict())
+
+
 @pytest.mark.parametrize("dtype,kw", [(torch.float32, dict(dim=64, codebook_size=300, learnable_codebook=True, ema_update=False)),
                                       (torch.bfloat16, dict(dim=256, codebook_size=512, learnable_codebook=True, ema_update=False)),
                                       (torch.float32, dict(dim=128, codebook_size=256, orthogonal_reg_weight=5., ema_update=False)),
@@ -1358,6 +1389,42 @@ def test_residual_chain_equals_the_stage_by_stage_loop(dev, monkeypatch, kw):
         assert torch.allclose(la, lb, rtol=2e-6, atol=1e-12)
         _close(a.codebooks, b.codebooks, 1e-5, "codebooks")       # (embed_sum: fp32 atomics over a code's row chunks, in any order)
         b.load_state_dict(a.state_dict())
+
+
+@pytest.mark.parametrize("grad", [False, True])
+def test_residual_chain_in_row_chunks_equals_one_chain(dev, monkeypatch, grad):
+    """Round 5: big batches run the residual chain as K interleaved row chunks, each on its own stream (L.rvq_row_chunks; rows are
+    independent units, rvq.py:469-568 has no cross-row step before the EMA sums).  K = 1 / 2 / 3 on a ragged row count (the last
+    chunk is shorter and not a multiple of the screening workgroup): indices and outputs bit-identical, losses / codebooks to the
+    rounding of the segmented sums' fp32 atomics; with and without an input that requires grad (routed residuals), with a mask."""
+    from vector_quantize_pytorch_amd import ResidualVQ
+    kw = dict(dim=64, num_quantizers=4, codebook_size=256, shared_codebook=True)
+    torch.manual_seed(0)
+    mods = [ResidualVQ(**kw).to(dev).train() for _ in range(3)]
+    for m in mods[1:]:
+        m.load_state_dict(mods[0].state_dict())
+    N = 3 * 65536 + 777
+    for step in range(2):
+        x = torch.randn(1, N, 64, device=dev) * (1.0 + step)
+        mask = (torch.rand(1, N, device=dev) > 0.1) if step == 1 else None
+        outs = []
+        for K, m in zip((1, 2, 3), mods):
+            monkeypatch.setenv("VQHIP_RVQ_CHUNKS", str(K))
+            xi = x.clone().requires_grad_(grad)
+            with torch.set_grad_enabled(grad):
+                q, i, l = m(xi, mask=mask)
+            if grad:
+                (q.square().sum() + l.sum()).backward()
+            outs.append((q.detach(), i, l.detach(), xi.grad))
+        torch.cuda.synchronize()
+        for q, i, l, g in outs[1:]:
+            assert torch.equal(i, outs[0][1]) and torch.equal(q, outs[0][0])
+            assert torch.allclose(l, outs[0][2], rtol=2e-6, atol=1e-12)
+            if grad:
+                assert torch.equal(g, outs[0][3])
+        for m in mods[1:]:
+            _close(m.codebooks, mods[0].codebooks, 1e-5, "codebooks")
+            m.load_state_dict(mods[0].state_dict())
 
 
 def _route64(r, c, mode):

@@ -63,7 +63,7 @@ def main():
             gap = (s - last_end[q]) / 1000 if q in last_end else 0.0
             last_end[q] = e
             busy += e - s
-            if b - a <= 150:
+            if b - a <= 400:
                 lines.append(f"{(s - t0) / 1000:9.1f} {(e - s) / 1000:8.1f} {gap:7.1f}  {q:>3} {short(n)}\n")
         lines.append(f"sum of kernel durations {busy / 1000:.1f} us\n\nper kernel in this step:\n")
         per = {}

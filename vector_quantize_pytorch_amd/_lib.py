@@ -130,6 +130,9 @@ def lib():
     L.vqhip_ema_batched_ws_stride.restype = ctypes.c_size_t
     L.vqhip_ema_accumulate_batched.argtypes = [vp, i32, i32, i64, i32, i64, i64, vp, vp, i32, vp, i64, vp, ctypes.c_size_t, vp, vp, vp, vp]
     L.vqhip_ema_accumulate_batched.restype = i32
+    L.vqhip_ema_accumulate_stages.argtypes = [vp, i32, i32, i64, i32, i64, i64, vp, i64, vp, i32, vp, i64, vp, ctypes.c_size_t, i32, vp, i64, vp, i64,
+                                              vp, i64, vp]
+    L.vqhip_ema_accumulate_stages.restype = i32
     L.vqhip_ema_finalize_batched.argtypes = [vp, vp, vp, vp, i64, i32, i32, i32, f32, f32, i32, i32, vp, vp]
     L.vqhip_ema_finalize_batched.restype = i32
     L.vqhip_route_residual.argtypes = [vp, i32, i64, i32, i64, vp, vp, i64, i32, vp, i64, vp]
@@ -138,6 +141,8 @@ def lib():
     L.vqhip_vq_step_supported.restype = i32
     L.vqhip_vq_step_workspace_bytes.argtypes = [i64, i32]
     L.vqhip_vq_step_workspace_bytes.restype = ctypes.c_size_t
+    L.vqhip_vq_step_chunk_rows.argtypes = [i64, i32]
+    L.vqhip_vq_step_chunk_rows.restype = i64
     L.vqhip_vq_train_step.argtypes = [vp, vp]
     L.vqhip_vq_train_step.restype = i32
     for name in ("vqhip_pack_codebook", "vqhip_assign", "vqhip_reduce_partials", "vqhip_ema_accumulate",
@@ -151,10 +156,11 @@ EXPORTS = ("vqhip_version", "vqhip_last_error", "vqhip_packed_bytes", "vqhip_pac
            "vqhip_assign_blocks", "vqhip_assign", "vqhip_screen_supported", "vqhip_screen_workspace_bytes",
            "vqhip_screen_blocks", "vqhip_screen_partials", "vqhip_assign_screened", "vqhip_screen_chain_supported", "vqhip_assign_screened_chain", "vqhip_l2norm_rows", "vqhip_l2norm_rows_bwd", "vqhip_transpose_batched", "vqhip_expire_pick", "vqhip_mask_fill_rows", "vqhip_scores", "vqhip_rvq_forward", "vqhip_reduce_partials", "vqhip_reduce_partials_rows", "vqhip_ema_fold_many", "vqhip_ema_workspace_bytes", "vqhip_ema_accumulate", "vqhip_ema_sqerr_partials", "vqhip_ema_accumulate_sqerr",
            "vqhip_ema_finalize", "vqhip_decode_sum", "vqhip_row_sumsq", "vqhip_assign_rowwise", "vqhip_score_indices", "vqhip_topk", "vqhip_expire_scatter", "vqhip_kmeans_update", "vqhip_route_fwd", "vqhip_route_bwd", "vqhip_rvq_route", "vqhip_ema_renormalize_shard", "vqhip_scores_lse",
-           "vqhip_pack_best", "vqhip_unpack_best", "vqhip_vq_step_supported", "vqhip_vq_step_workspace_bytes", "vqhip_vq_train_step", "vqhip_route_residual",
+           "vqhip_pack_best", "vqhip_unpack_best", "vqhip_vq_step_supported", "vqhip_vq_step_workspace_bytes", "vqhip_vq_step_chunk_rows", "vqhip_vq_train_step", "vqhip_route_residual",
            "vqhip_pack_codebook_batched", "vqhip_screen_batched_ws_stride", "vqhip_assign_screened_batched", "vqhip_assign_batched",
            "vqhip_route_fwd_gather", "vqhip_route_bwd_gather", "vqhip_ema_accumulate_prezeroed",
-           "vqhip_ema_batched_ws_stride", "vqhip_ema_accumulate_batched", "vqhip_ema_finalize_batched")
+           "vqhip_ema_batched_ws_stride", "vqhip_ema_accumulate_batched", "vqhip_ema_finalize_batched",
+           "vqhip_ema_accumulate_stages")
 
 
 def _check(rc, what):
@@ -521,9 +527,33 @@ def rvq_chain_supported(x: torch.Tensor, C: int, routed=False) -> bool:
                 and xk.data_ptr() % 16 == 0 and (ldx * es) % 16 == 0)
 
 
+_CHAIN_STREAMS = {}
+
+
+def _chain_streams(device, main, n):
+    """n side streams that pair with `main` for the row chunks of a residual chain (per caller stream: concurrent groups do not share)"""
+    key = (torch.device(device).index, main.cuda_stream)
+    pool = _CHAIN_STREAMS.setdefault(key, [])
+    while len(pool) < n:
+        pool.append(torch.cuda.Stream(device=device))
+    return pool[:n]
+
+
+def rvq_row_chunks(N: int) -> int:
+    """Row chunks the residual chain is split into (each chunk runs its own chain of stages on its own stream, so that one chunk's
+    short exact passes -- refine, pair, finish: latency-bound launches every stage has to wait for -- run beside another chunk's
+    screening kernel instead of leaving the chip idle).  Measured at cfg 3 (2^18 rows x 8 stages, profiles/r5_rvq_cfg3/chunks.txt):
+    1 chunk 2.86-2.89 ms, 2 chunks 2.88, 3 chunks 2.79-2.80, 4 chunks 3.37 (chunks of 2^16 rows = 256 workgroups no longer fill the
+    chip's 512 workgroup slots) -- default: chunks of about 87 000 rows, at most 3.  VQHIP_RVQ_CHUNKS overrides; chunks are
+    multiples of 256 rows (one screening workgroup) and hold at least 65 536 rows."""
+    env = os.environ.get("VQHIP_RVQ_CHUNKS")
+    k = int(env) if env else min(3, N // 87381)
+    return max(1, min(k, N // 65536))
+
+
 @_on_device
 def rvq_forward_chained(x: torch.Tensor, packed: torch.Tensor, embed: torch.Tensor, Q: int, *, row_mask=None, stage_hook=None,
-                        fill_masked=True, route_mode=0):
+                        fill_masked=True, route_mode=0, row_chunks=1):
     """The residual loop (rvq.py:469-568) as Q chained screened searches: stage q's kernel forms its input
     inputs[q-1] - embed[idx[:, q-1]] in its prologue and stores it as inputs[q]; no stage re-reads its input to write a residual,
     and every stage writes its column of idx directly.  No q / squared-error outputs: the caller's statistics pass sums the loss
@@ -531,7 +561,11 @@ def rvq_forward_chained(x: torch.Tensor, packed: torch.Tensor, embed: torch.Tens
     fill_masked=False: the caller writes the -1 of the masked rows itself (mask_fill_indices) -- needed when stage_hook hands `idx`
     to work on ANOTHER stream, which may still be reading it when this function returns.
     route_mode (0 / STRAIGHT_THROUGH / ROTATION): what each layer returned as `quantized`, i.e. what rvq.py:524 subtracted -- the
-    code row, or the routed value of a training step whose input requires grad (the arithmetic of route_fwd, bit for bit)."""
+    code row, or the routed value of a training step whose input requires grad (the arithmetic of route_fwd, bit for bit).
+    row_chunks K > 1: the rows are split into K contiguous chunks, each running its own chain on its own stream (chunk 0 on the
+    caller's); rows are independent units, so the results are those of K = 1 bit for bit.  stage_hook then receives
+    `ready`, one event per chunk stream recorded behind stage q (its consumer waits for all of them); on return the caller's stream
+    has been joined with every chunk stream."""
     _need_gpu(x, packed, embed, row_mask)
     shared = embed.ndim == 2
     xk, N, D, ldx = as_rows(x)
@@ -540,49 +574,80 @@ def rvq_forward_chained(x: torch.Tensor, packed: torch.Tensor, embed: torch.Tens
     assert embed.dtype == torch.float32 and embed.is_contiguous()
     assert xk.dtype == torch.float32 or (route_mode and xk.dtype == torch.bfloat16), "chained stages: float32 rows"
     dt = _dtype_code(xk)
+    es = xk.element_size()
     idx = torch.empty(N, Q, dtype=torch.int64, device=dev)
     bufs = torch.empty(max(Q - 1, 1), N, D, dtype=xk.dtype, device=dev)
     if row_mask is not None:
         row_mask = row_mask.reshape(-1).to(torch.uint8).contiguous()
-    nws = lib().vqhip_screen_workspace_bytes(N)
-    nws4 = (nws + 15) // 16 * 4                       # ints per stage, 16-byte granules
-    ws_all = torch.empty(Q, nws4, dtype=torch.int32, device=dev)
-    ws_all[:, :4].zero_()                             # the Q list headers in ONE launch (a 16-byte memset per stage cost 13 us of gaps each)
+    K = max(1, int(row_chunks))
+    rpc = ((N + K - 1) // K + 255) // 256 * 256               # rows per chunk: whole screening workgroups
+    starts = [r0 for r0 in range(0, N, rpc)]
+    K = len(starts)
+    nws = lib().vqhip_screen_workspace_bytes(min(rpc, N))
+    nws4 = (nws + 15) // 16 * 4                       # ints per stage and chunk, 16-byte granules
+    ws_all = torch.empty(Q, K, nws4, dtype=torch.int32, device=dev)
+    ws_all[:, :, :4].zero_()                          # the list headers in ONE launch (a 16-byte memset per stage cost 13 us of gaps each)
     codes = embed if xk.dtype == torch.float32 else embed.to(xk.dtype)      # (bf16 rows: the routing kernel gathers bf16 code rows)
+    main = torch.cuda.current_stream(dev)
+    streams = [main]
+    if K > 1:
+        streams += _chain_streams(dev, main, K - 1)
+        fork = torch.cuda.Event()
+        fork.record(main)
+        for s in streams[1:]:
+            s.wait_event(fork)
+    x_ptr, idx_ptr, mask_ptr = xk.data_ptr(), idx.data_ptr(), (row_mask.data_ptr() if row_mask is not None else None)
     inputs, counts = [x], []
     for q in range(Q):
-        ws = ws_all[q]
-        ch = _Chain(idx_stride=Q, prev_idx=None, prev_idx_stride=Q, prev_embed=None, x_out=None, ldxo=D, route_mode=0, header_zeroed=1)
-        src, lds = xk, ldx
-        if q > 0 and route_mode:
-            # the previous layer returned its ROUTED value (rotation trick / straight-through on an input that requires grad) and
-            # rvq.py:524 subtracted THAT: an HBM-bound kernel of its own (vqhip_route_residual) writes this stage's input, which
-            # the search then reads like a first stage's
-            prev_c = codes if shared else codes[q - 1]
-            psrc, plds = (xk, ldx) if q == 1 else (bufs[q - 2], D)
-            _check(lib().vqhip_route_residual(_ptr(psrc), dt, N, D, plds, _ptr(prev_c), ctypes.c_void_p(idx.data_ptr() + 8 * (q - 1)), Q,
-                                              int(route_mode), _ptr(bufs[q - 1]), D, _stream()), "vqhip_route_residual")
-            src, lds = bufs[q - 1], D
-        elif q > 0:
-            prev_e = embed if shared else embed[q - 1]
-            ch.prev_idx = idx.data_ptr() + 8 * (q - 1)
-            ch.prev_embed = prev_e.data_ptr()
-            ch.x_out = bufs[q - 1].data_ptr()
-            if q > 1:
-                src, lds = bufs[q - 2], D
-        _check(lib().vqhip_assign_screened_chain(_ptr(src), dt, N, D, lds, _ptr(packed if shared else packed[q]),
-                                                 _ptr(embed if shared else embed[q]), C, EUCLID,
-                                                 ctypes.c_void_p(idx.data_ptr() + 8 * q), _ptr(row_mask), _ptr(ws), nws,
-                                                 ctypes.byref(ch), _stream()), "vqhip_assign_screened_chain")
+        ready = []
+        for k, r0 in enumerate(starts):
+            n_k = min(rpc, N - r0)
+            ws = ws_all[q, k]
+            with torch.cuda.stream(streams[k]):
+                ch = _Chain(idx_stride=Q, prev_idx=None, prev_idx_stride=Q, prev_embed=None, x_out=None, ldxo=D, route_mode=0, header_zeroed=1)
+                src, lds = x_ptr + r0 * ldx * es, ldx
+                if q > 0 and route_mode:
+                    # the previous layer returned its ROUTED value (rotation trick / straight-through on an input that requires grad) and
+                    # rvq.py:524 subtracted THAT: an HBM-bound kernel of its own (vqhip_route_residual) writes this stage's input, which
+                    # the search then reads like a first stage's
+                    prev_c = codes if shared else codes[q - 1]
+                    psrc, plds = (src, ldx) if q == 1 else (bufs[q - 2].data_ptr() + r0 * D * es, D)
+                    dst = bufs[q - 1].data_ptr() + r0 * D * es
+                    _check(lib().vqhip_route_residual(ctypes.c_void_p(psrc), dt, n_k, D, plds, _ptr(prev_c),
+                                                      ctypes.c_void_p(idx_ptr + 8 * (r0 * Q + q - 1)), Q, int(route_mode),
+                                                      ctypes.c_void_p(dst), D, _stream()), "vqhip_route_residual")
+                    src, lds = dst, D
+                elif q > 0:
+                    prev_e = embed if shared else embed[q - 1]
+                    ch.prev_idx = idx_ptr + 8 * (r0 * Q + q - 1)
+                    ch.prev_embed = prev_e.data_ptr()
+                    ch.x_out = bufs[q - 1].data_ptr() + r0 * D * es
+                    if q > 1:
+                        src, lds = bufs[q - 2].data_ptr() + r0 * D * es, D
+                _check(lib().vqhip_assign_screened_chain(ctypes.c_void_p(src), dt, n_k, D, lds, _ptr(packed if shared else packed[q]),
+                                                         _ptr(embed if shared else embed[q]), C, EUCLID,
+                                                         ctypes.c_void_p(idx_ptr + 8 * (r0 * Q + q)),
+                                                         ctypes.c_void_p(mask_ptr + r0) if mask_ptr is not None else None, _ptr(ws), nws,
+                                                         ctypes.byref(ch), _stream()), "vqhip_assign_screened_chain")
+                if K > 1 and (stage_hook is not None or q + 1 == Q):
+                    ev = torch.cuda.Event()
+                    ev.record(streams[k])
+                    ready.append(ev)
         if q > 0:
             inputs.append(bufs[q - 1].view(*lead, D))
-        counts.append((ws[:1], ws[1:2]))
+        counts.append((ws_all[q, :, 0], ws_all[q, :, 1]))      # per chunk: rows of the exact sweep / rows decided between two codes
         if stage_hook is not None:      # stage q's input and indices are final (in stream order): the caller's per-stage work
-            stage_hook(q, inputs[q], idx.view(*lead, Q))
+            if K > 1:
+                stage_hook(q, inputs[q], idx.view(*lead, Q), ready=ready)
+            else:
+                stage_hook(q, inputs[q], idx.view(*lead, Q))
+    if K > 1:
+        for ev in ready[1:]:
+            main.wait_event(ev)
     idx = idx.view(*lead, Q)
     if row_mask is not None and fill_masked:
         mask_fill_indices(idx, row_mask)
-    return dict(idx=idx, inputs=inputs, counts=counts)
+    return dict(idx=idx, inputs=inputs, counts=counts, bufs=bufs)
 
 
 def mask_fill_indices(idx: torch.Tensor, row_mask: torch.Tensor):
@@ -890,11 +955,37 @@ class _Step(ctypes.Structure):           # vqhip_vq_step_t (include/vqhip.h)
                 ("packed", ctypes.c_void_p), ("workspace", ctypes.c_void_p), ("workspace_bytes", ctypes.c_size_t),
                 ("one_minus_decay", ctypes.c_double), ("eps", ctypes.c_double), ("fold", ctypes.c_int64),
                 ("ev_search_begin", ctypes.c_void_p), ("ev_search_end", ctypes.c_void_p), ("metric", ctypes.c_int64),
-                ("row_mask", ctypes.c_void_p)]
+                ("row_mask", ctypes.c_void_p), ("chunks", ctypes.c_int64), ("side_stream", ctypes.c_void_p), ("events", ctypes.c_void_p * 4)]
 
 
 step_event_hook = None   # bench.py: callable -> (begin, end) torch.cuda.Event pair (already recorded once, so that their handles exist),
                          # recorded by the library around the search of the next fused step
+
+
+_STEP_SIDE = {}
+
+
+def _step_side(device, main):
+    """the side stream + events of the fused step's row pipeline that pair with `main` (created once per caller stream)"""
+    key = (torch.device(device).index, main.cuda_stream)
+    if key not in _STEP_SIDE:
+        evs = [torch.cuda.Event() for _ in range(4)]
+        for e in evs:
+            e.record(main)          # (torch creates the hipEvent_t lazily, at the first record)
+        _STEP_SIDE[key] = (torch.cuda.Stream(device=device), evs)
+    return _STEP_SIDE[key]
+
+
+def step_chunks(N: int) -> int:
+    """row chunks of the fused train step's pipeline (include/vqhip.h, vqhip_vq_step_t.chunks): VQHIP_STEP_CHUNKS, default 1 -- the
+    pipeline is built, tested and measured, and it LOSES at cfg 2 (0.845 -> 0.952 ms with 2 chunks, 1.03 with 4; DESIGN 5.1,
+    profiles/r5_step_pipeline): the screening kernels fill every SIMD's register file, so the side stream's kernels only start when a
+    screening workgroup retires (its single-workgroup scan kernel waited 226 us for a slot).  Batches of at least 2^19 rows, each
+    chunk at least 2^17 rows (the persistent screening kernel's floor); 1 while a HIP graph is being captured."""
+    k = int(os.environ.get("VQHIP_STEP_CHUNKS", "1"))
+    if N < (1 << 19) or torch.cuda.is_current_stream_capturing():
+        return 1
+    return max(1, min(k, 4, N // (1 << 17)))
 
 
 def vq_step_supported(x: torch.Tensor, C: int) -> bool:
@@ -942,8 +1033,22 @@ def vq_train_step(x: torch.Tensor, embed, embed_avg, cluster_size, *, decay, eps
     if step_event_hook is not None:
         e0, e1 = step_event_hook()
         st.ev_search_begin, st.ev_search_end = e0.cuda_event, e1.cuda_event
+    K = step_chunks(N)
+    if K > 1:       # row pipeline: the statistics of chunk k on a side stream beside the search of chunk k + 1
+        side, evs = _step_side(dev, torch.cuda.current_stream(dev))
+        st.chunks, st.side_stream = K, side.cuda_stream
+        for k in range(K):
+            st.events[k] = evs[k].cuda_event
     _check(lib().vqhip_vq_train_step(ctypes.byref(st), _stream()), "vqhip_vq_train_step")
-    hdr = ws[:16].view(torch.int32)       # [0] rows of the exact sweep, [1] rows decided between two candidates (device-side counters)
+    # per chunk: [0] rows of the exact sweep, [1] rows decided between two candidates (device-side counters at the head of the chunk's
+    # screening workspace, include/vqhip.h)
+    rpc = lib().vqhip_vq_step_chunk_rows(N, K)
+    offs, o = [], 0
+    for r0 in range(0, N, rpc):
+        n_k = min(rpc, N - r0)
+        offs.append(o)
+        o += (lib().vqhip_screen_workspace_bytes(n_k) + 255) // 256 * 256 + (lib().vqhip_ema_workspace_bytes(n_k, C) + 255) // 256 * 256
+    hdr = ws[:16].view(torch.int32) if len(offs) == 1 else torch.stack([ws[o: o + 16].view(torch.int32) for o in offs]).sum(0)
     return dict(q=None if q is None else q.reshape(x.shape), idx=idx.reshape(x.shape[:-1]), stats=stats,
                 embed_sum=stats[: C * D].view(C, D), count=stats[C * D:], loss=loss, n_exact=hdr[:1], n_pair=hdr[1:2])
 
@@ -986,6 +1091,40 @@ def ema_finalize_batched(cluster_size, embed_avg, embed, stats, *, decay, eps, c
     omd = float(torch.tensor(1.0 - decay, dtype=torch.float64).to(torch.float32))
     _check(lib().vqhip_ema_finalize_batched(_ptr(cluster_size), _ptr(embed_avg), _ptr(embed), _ptr(stats), stats.stride(0), H, C, D, omd,
                                             float(eps), int(cosine), int(do_update_ema), _ptr(denom), _stream()), "vqhip_ema_finalize_batched")
+
+
+@_on_device
+def ema_accumulate_stages(inputs: torch.Tensor, idx: torch.Tensor, stage0: int, C: int, stats: torch.Tensor, ws: torch.Tensor, *,
+                          row_mask=None, sqerr_from=None, sqerr_out=None):
+    """The statistics of the stages stage0 .. stage0 + S - 1 of a residual VQ in one set of launches (vqhip_ema_accumulate_stages):
+    inputs [S, ..., D] contiguous (the materialised stage inputs), idx [..., Q] int64 (stage s reads column stage0 + s), stats
+    [S, stride >= C D + C] zeroed by the caller, ws [S, bytes] from ema_workspaces (histograms zeroed).
+    sqerr_from = (packed, embed): shared codebook (packed 1-D, embed [C, D]) or per stage (packed [S, P], embed [S, C, D]);
+    sqerr_out [S, P'] float64 receives the loss partials."""
+    _need_gpu(inputs, idx, stats, ws, row_mask)
+    S = inputs.shape[0]
+    xk, N, D, ldx = as_rows(inputs[0])
+    Q = idx.shape[-1]
+    assert inputs.is_contiguous() and idx.dtype == torch.int64 and idx.is_contiguous() and idx.numel() == N * Q and stage0 + S <= Q
+    assert stats.dtype == torch.float32 and stats.ndim == 2 and stats.shape[0] == S and stats.stride(1) == 1
+    assert ws.dtype == torch.uint8 and ws.ndim == 2 and ws.shape[0] == S and ws.stride(1) == 1
+    assert ws.stride(0) == lib().vqhip_ema_batched_ws_stride(N, C) and ws.data_ptr() % 256 == 0
+    if row_mask is not None:
+        row_mask = row_mask.reshape(-1).to(torch.uint8).contiguous()
+    pk = em = None
+    pks = ems = sqs = 0
+    if sqerr_from is not None:
+        pk, em = sqerr_from
+        assert em.dtype == torch.float32 and em.is_contiguous() and pk.is_contiguous()
+        if em.ndim == 3:
+            assert em.shape[0] == S and pk.shape[0] == S
+            ems, pks = em.stride(0), pk.stride(0) * pk.element_size() // 4
+        assert sqerr_out.dtype == torch.float64 and sqerr_out.shape[0] == S and sqerr_out.stride(1) == 1
+        sqs = sqerr_out.stride(0)
+    _check(lib().vqhip_ema_accumulate_stages(_ptr(xk), _dtype_code(xk), S, N, D, ldx, inputs.stride(0), ctypes.c_void_p(idx.data_ptr() + 8 * stage0),
+                                             Q, _ptr(row_mask), C, _ptr(stats), stats.stride(0), _ptr(ws), S * ws.stride(0), 1,
+                                             _ptr(pk), pks, _ptr(em), ems, _ptr(sqerr_out) if sqerr_from is not None else None, sqs, _stream()),
+           "vqhip_ema_accumulate_stages")
 
 
 def ema_workspaces(Q: int, N: int, C: int, device) -> torch.Tensor:

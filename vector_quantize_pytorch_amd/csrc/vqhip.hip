@@ -3083,9 +3083,10 @@ __global__ void __launch_bounds__(1024) vq_scan_kernel(const SortArgs a0)
         a.seg_off[c] = oc;
         a.chunk_off[c] = ok;
         a.cursor[c * 16] = oc;
-        if (n) a.count[c] += (float)n;
-        if (a.cs) {                        // (count was zero before this step: the batch's count IS n)
-            const float v = aten_lerp(a.cs[c], (float)n, a.omd);
+        float tot = a.count[c];            // rows of this code seen so far this step (earlier row chunks of a pipelined step; else 0)
+        if (n) { tot += (float)n; a.count[c] = tot; }      // integers below 2^24: exact
+        if (a.cs) {                        // (the last chunk's scan: `tot` IS the batch's count)
+            const float v = aten_lerp(a.cs[c], tot, a.omd);
             a.cs[c] = v;
             s_cs[c] = v;
         }
@@ -3559,6 +3560,37 @@ extern "C" int vqhip_ema_accumulate_batched(const void *x, int x_dtype, int H, i
     const void *qsrc = !sqerr_partial ? nullptr
                      : (x_dtype == VQHIP_BF16) ? (const void *)((const char *)packed + vq_packed_bf16_offset(C, D)) : (const void *)embed;
     return ema_accumulate_impl(x, x_dtype, N, D, ldx, idx, 1, nullptr, VQHIP_EUCLID, row_mask, C, stats + (size_t)C * D, stats, workspace,
+                               wss, qsrc, sqerr_partial, stream, &f);
+}
+
+// The statistics of S consecutive stages of a residual VQ in ONE set of launches (blockIdx.y = stage): stage s reads its input rows at
+// x + s * x_sstride elements (the stage inputs a residual chain materialised one behind the other) and its codes in column s of
+// idx [N, idx_stride].  Why: issued per stage on a side stream these passes are 4 short launches each, and beside a screening kernel
+// that fills every SIMD's register file (two 256-register waves) each of them waits for a workgroup slot while slowing the search
+// down (profiles/r5_rvq_cfg3); batched they are four full-size launches behind the loop.
+extern "C" int vqhip_ema_accumulate_stages(const void *x, int x_dtype, int S, int64_t N, int D, int64_t ldx, int64_t x_sstride,
+                                           const int64_t *idx, int64_t idx_stride, const uint8_t *row_mask, int C, float *stats,
+                                           int64_t stats_stride, void *workspace, size_t workspace_bytes, int hist_zeroed,
+                                           const float *packed, int64_t packed_sstride, const float *embed, int64_t embed_sstride,
+                                           double *sqerr_partial, int64_t sqerr_stride, void *stream)
+{
+    if (S < 1 || D < 1 || D > 512 || C <= 0) VQ_FAIL(VQHIP_EINVAL, "ema_accumulate_stages: bad size");
+    if (!stats || stats_stride < (int64_t)C * D + C) VQ_FAIL(VQHIP_EINVAL, "ema_accumulate_stages: stats null or stats_stride smaller than C D + C");
+    if (idx_stride < S) VQ_FAIL(VQHIP_EINVAL, "ema_accumulate_stages: idx_stride smaller than the number of stages");
+    if (sqerr_partial && (!packed || !embed || sqerr_stride < seg_work_items(N, C))) VQ_FAIL(VQHIP_EINVAL, "ema_accumulate_stages: the loss needs packed, embed and sqerr_stride >= vqhip_ema_sqerr_partials(N, C)");
+    const size_t wss = vqhip_ema_batched_ws_stride(N, C);
+    if (workspace_bytes < wss * (size_t)S) VQ_FAIL(VQHIP_EINVAL, "ema_accumulate_stages: workspace too small");
+    const int es = (x_dtype == VQHIP_BF16) ? 2 : 4;
+    if ((x_sstride * es) & 15) VQ_FAIL(VQHIP_EALIGN, "ema_accumulate_stages: the stages' rows must stay 16-byte aligned");
+    StatsFuse f;
+    f.hist_zeroed = hist_zeroed ? 1 : 0; f.cs = nullptr; f.denom = nullptr; f.omd = 0.f; f.eps = 0.f;
+    f.heads = S;
+    f.hs_x = x_sstride * es; f.hs_idx = 8; f.hs_ws = (int64_t)wss; f.hs_stats = stats_stride * 4;
+    f.hs_qsrc = (x_dtype == VQHIP_BF16) ? packed_sstride * 4 : embed_sstride * 4;
+    f.hs_sq = sqerr_stride * (int64_t)sizeof(double);
+    const void *qsrc = !sqerr_partial ? nullptr
+                     : (x_dtype == VQHIP_BF16) ? (const void *)((const char *)packed + vq_packed_bf16_offset(C, D)) : (const void *)embed;
+    return ema_accumulate_impl(x, x_dtype, N, D, ldx, idx, idx_stride, nullptr, VQHIP_EUCLID, row_mask, C, stats + (size_t)C * D, stats, workspace,
                                wss, qsrc, sqerr_partial, stream, &f);
 }
 
@@ -4253,22 +4285,50 @@ extern "C" int vqhip_transpose_batched(const void *in, void *out, int elem_bytes
 // kernel, embed_avg / embed / loss by one tail kernel.  (Counting the rows per code inside the search -- one global atomic per
 // certified row -- was built and measured: it saves the 14 us histogram pass and costs the search 20 us; not kept.)
 // ------------------------------------------------------------------------------------------------
-struct ZeroArgs { unsigned *p[4]; unsigned n[4]; };   // up to four regions of n 32-bit words each
+#define VQ_STEP_MAX_CHUNKS 4
+#define VQ_ZERO_REGIONS (2 + 2 * VQ_STEP_MAX_CHUNKS)
+struct ZeroArgs { unsigned *p[VQ_ZERO_REGIONS]; unsigned n[VQ_ZERO_REGIONS]; };   // regions of n 32-bit words each (n = 0: unused)
 __global__ void __launch_bounds__(256) vq_zero_kernel(const ZeroArgs a)
 {
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
+    for (int r = 0; r < VQ_ZERO_REGIONS; ++r)
         for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < a.n[r]; i += gridDim.x * 256) a.p[r][i] = 0u;
 }
 
 static inline size_t step_ws_screen(int64_t N) { return align_up(vqhip_screen_workspace_bytes(N), 256); }
 
+// rows per chunk of a pipelined step: whole screening workgroups (256 rows)
+extern "C" int64_t vqhip_vq_step_chunk_rows(int64_t N, int chunks)
+{
+    if (N <= 0) return 0;
+    const int64_t K = chunks < 1 ? 1 : (chunks > VQ_STEP_MAX_CHUNKS ? VQ_STEP_MAX_CHUNKS : chunks);
+    return ((N + K - 1) / K + 255) / 256 * 256;
+}
+
+// workspace of a K-chunk step: per chunk [screening workspace | statistics workspace (histogram first)], then the denominators
+// [C], then the squared-error partials of all chunks (contiguous: one reduction).  Sized for the worst K <= VQ_STEP_MAX_CHUNKS
+// (the row-sized parts do not depend on K beyond alignment; the C-sized parts are counted once per chunk).
+static inline size_t step_ws_total(int64_t N, int C, int K)
+{
+    const int64_t rpc = vqhip_vq_step_chunk_rows(N, K);
+    size_t tot = 0, parts = 0;
+    for (int64_t r0 = 0; r0 < N; r0 += rpc) {
+        const int64_t n = N - r0 < rpc ? N - r0 : rpc;
+        tot += step_ws_screen(n) + align_up(vqhip_ema_workspace_bytes(n, C), 256);
+        parts += (size_t)seg_work_items(n, C);
+    }
+    return tot + align_up((size_t)C * 4, 256) + align_up(parts * sizeof(double), 256);
+}
+
 extern "C" size_t vqhip_vq_step_workspace_bytes(int64_t N, int C)
 {
     if (N <= 0 || C <= 0) return 0;
-    // screening workspace | statistics workspace (histogram first) | denominators [C] | squared-error partials
-    return step_ws_screen(N) + align_up(vqhip_ema_workspace_bytes(N, C), 256) + align_up((size_t)C * 4, 256) +
-           align_up((size_t)seg_work_items(N, C) * sizeof(double), 256);
+    size_t worst = 0;
+    for (int K = 1; K <= VQ_STEP_MAX_CHUNKS; ++K) {
+        const size_t t = step_ws_total(N, C, K);
+        worst = t > worst ? t : worst;
+    }
+    return worst;
 }
 
 extern "C" int vqhip_vq_step_supported(int x_dtype, int64_t N, int D, int C)
@@ -4290,38 +4350,80 @@ extern "C" int vqhip_vq_train_step(const vqhip_vq_step_t *s, void *stream)
     if (s->workspace_bytes < vqhip_vq_step_workspace_bytes(N, C)) VQ_FAIL(VQHIP_EINVAL, "vq_train_step: workspace too small");
     if ((((uintptr_t)s->workspace) & 255) || (((uintptr_t)s->stats) & 15) || (((uintptr_t)s->packed) & 15))
         VQ_FAIL(VQHIP_EALIGN, "vq_train_step: workspace must be 256-byte aligned, stats / packed 16-byte aligned");
-    hipStream_t st = (hipStream_t)stream;
+    // Row chunks (s->chunks > 1): the search of chunk k + 1 runs on `stream` while the statistics of chunk k (histogram, scan,
+    // scatter, segmented sum + loss -- HBM-bound, ~0.18 ms of a 0.84 ms cfg-2 step) run on s->side_stream; counts and sums are
+    // order-free (integer counts, fp32 atomics), so only the LAST chunk's statistics -- issued on `stream` behind the side stream's
+    // -- and the fold remain behind the search.  Needs the caller's side stream and K events; without them: one chunk.
+    int K = (int)s->chunks;
+    if (K < 1 || !s->side_stream) K = 1;
+    if (K > VQ_STEP_MAX_CHUNKS) K = VQ_STEP_MAX_CHUNKS;
+    const int64_t rpc = vqhip_vq_step_chunk_rows(N, K);
+    K = (int)((N + rpc - 1) / rpc);
+    for (int k = 0; k < K && K > 1; ++k)
+        if (!s->events[k]) VQ_FAIL(VQHIP_EINVAL, "vq_train_step: %d chunks need events[0..%d]", K, K - 1);
+    hipStream_t st = (hipStream_t)stream, side = (hipStream_t)s->side_stream;
+    const int es = (x_dtype == VQHIP_BF16) ? 2 : 4;
+
     char *ws = (char *)s->workspace;
-    void *ws_screen = ws;                          ws += step_ws_screen(N);
-    void *ws_stats = ws;                           ws += align_up(vqhip_ema_workspace_bytes(N, C), 256);
+    void *ws_screen[VQ_STEP_MAX_CHUNKS], *ws_stats[VQ_STEP_MAX_CHUNKS];
+    int64_t rows0[VQ_STEP_MAX_CHUNKS], nrows[VQ_STEP_MAX_CHUNKS], part0[VQ_STEP_MAX_CHUNKS];
+    int64_t n_part = 0;
+    for (int k = 0; k < K; ++k) {
+        rows0[k] = (int64_t)k * rpc;
+        nrows[k] = N - rows0[k] < rpc ? N - rows0[k] : rpc;
+        ws_screen[k] = ws;                         ws += step_ws_screen(nrows[k]);
+        ws_stats[k] = ws;                          ws += align_up(vqhip_ema_workspace_bytes(nrows[k], C), 256);
+        part0[k] = n_part;                         n_part += seg_work_items(nrows[k], C);
+    }
     float *denom = (float *)ws;                    ws += align_up((size_t)C * 4, 256);
     double *partials = (double *)ws;
-    const int64_t n_part = seg_work_items(N, C);
     float *embed_sum = s->stats, *count = s->stats + (size_t)C * D;
 
     ZeroArgs z;
+    for (int r = 0; r < VQ_ZERO_REGIONS; ++r) { z.p[r] = nullptr; z.n[r] = 0; }
     z.p[0] = (unsigned *)((char *)s->packed + vq_packed_scalars_offset(C, D)); z.n[0] = VQ_PACKED_SCALARS_BYTES / 4;
-    z.p[1] = (unsigned *)ws_screen;                                            z.n[1] = 4;
-    z.p[2] = (unsigned *)ws_stats;                                             z.n[2] = (unsigned)C;      // the histogram
-    z.p[3] = (unsigned *)s->stats;                                             z.n[3] = (unsigned)((size_t)C * D + C);
-    const unsigned zb = (z.n[3] + 1023) / 1024;
+    z.p[1] = (unsigned *)s->stats;                                             z.n[1] = (unsigned)((size_t)C * D + C);
+    for (int k = 0; k < K; ++k) {
+        z.p[2 + 2 * k] = (unsigned *)ws_screen[k];                             z.n[2 + 2 * k] = 4;              // list header
+        z.p[3 + 2 * k] = (unsigned *)ws_stats[k];                              z.n[3 + 2 * k] = (unsigned)C;    // the histogram
+    }
+    const unsigned zb = (z.n[1] + 1023) / 1024;
     hipLaunchKernelGGL(vq_zero_kernel, dim3(zb < 1 ? 1 : (zb > 512 ? 512 : zb)), dim3(256), 0, st, z);
     if (int rc = launch_status("vq_zero_kernel")) return rc;
 
     if (int rc = pack_codebook_impl(s->embed, C, D, s->packed, 1, stream)) return rc;
-    if (s->ev_search_begin) (void)hipEventRecord((hipEvent_t)s->ev_search_begin, st);
-    if (int rc = vq_assign_screened_impl(s->x, x_dtype, N, D, s->ldx, s->packed, s->embed, C, metric, s->idx_out, s->q_out, s->ldq,
-                                         nullptr, D, nullptr, nullptr, ws_screen, step_ws_screen(N), nullptr, nullptr, 1, stream)) return rc;
-    if (s->ev_search_end) (void)hipEventRecord((hipEvent_t)s->ev_search_end, st);
-    StatsFuse f;
-    f.hist_zeroed = 1;
-    f.cs = s->fold ? s->cluster_size : nullptr;
-    f.denom = s->fold ? denom : nullptr;
-    f.omd = (float)s->one_minus_decay;
-    f.eps = (float)s->eps;
     const void *qsrc = (x_dtype == VQHIP_BF16) ? (const void *)((const char *)s->packed + packed_bf16_offset(C, D)) : (const void *)s->embed;
-    if (int rc = ema_accumulate_impl(s->x, x_dtype, N, D, s->ldx, s->idx_out, 1, nullptr, VQHIP_EUCLID, s->row_mask, C, count, embed_sum,
-                                     ws_stats, vqhip_ema_workspace_bytes(N, C), qsrc, partials, stream, &f)) return rc;
+    if (s->ev_search_begin) (void)hipEventRecord((hipEvent_t)s->ev_search_begin, st);
+    for (int k = 0; k < K; ++k) {
+        const char *xk = (const char *)s->x + rows0[k] * s->ldx * es;
+        char *qk = s->q_out ? (char *)s->q_out + rows0[k] * s->ldq * es : nullptr;
+        if (int rc = vq_assign_screened_impl(xk, x_dtype, nrows[k], D, s->ldx, s->packed, s->embed, C, metric, s->idx_out + rows0[k], qk, s->ldq,
+                                             nullptr, D, nullptr, nullptr, ws_screen[k], step_ws_screen(nrows[k]), nullptr, nullptr, 1, stream)) return rc;
+        if (k + 1 == K && s->ev_search_end) (void)hipEventRecord((hipEvent_t)s->ev_search_end, st);
+        // statistics of this chunk: on the side stream behind its search (chunks 0 .. K - 2), on `stream` behind the side stream's
+        // work for the last one -- whose scan kernel, the one workgroup that then holds every code's total count, also folds the counts
+        // into cluster_size and forms update_ema's denominators
+        const bool last = k + 1 == K;
+        hipStream_t sk = last ? st : side;
+        if (!last) {
+            hipError_t e = hipEventRecord((hipEvent_t)s->events[k], st);
+            if (e == hipSuccess) e = hipStreamWaitEvent(side, (hipEvent_t)s->events[k], 0);
+            if (e != hipSuccess) VQ_FAIL((int)e, "vq_train_step: event record / wait: %s", hipGetErrorString(e));
+        } else if (K > 1) {
+            hipError_t e = hipEventRecord((hipEvent_t)s->events[K - 1], side);
+            if (e == hipSuccess) e = hipStreamWaitEvent(st, (hipEvent_t)s->events[K - 1], 0);
+            if (e != hipSuccess) VQ_FAIL((int)e, "vq_train_step: event record / wait: %s", hipGetErrorString(e));
+        }
+        StatsFuse f;
+        f.hist_zeroed = 1;
+        f.cs = (s->fold && last) ? s->cluster_size : nullptr;
+        f.denom = (s->fold && last) ? denom : nullptr;
+        f.omd = (float)s->one_minus_decay;
+        f.eps = (float)s->eps;
+        if (int rc = ema_accumulate_impl(xk, x_dtype, nrows[k], D, s->ldx, s->idx_out + rows0[k], 1, nullptr, VQHIP_EUCLID,
+                                         s->row_mask ? s->row_mask + rows0[k] : nullptr, C, count, embed_sum, ws_stats[k],
+                                         vqhip_ema_workspace_bytes(nrows[k], C), qsrc, partials + part0[k], (void *)sk, &f)) return rc;
+    }
     if (s->fold) {
         hipLaunchKernelGGL(vq_step_fold_kernel, dim3((unsigned)((C + 3) / 4 + 1)), dim3(256), 0, st, s->embed_avg, s->embed, embed_sum, denom,
                            C, D, (float)s->one_minus_decay, metric != VQHIP_EUCLID ? 1 : 0, partials, n_part, s->loss_scale, s->loss_out);

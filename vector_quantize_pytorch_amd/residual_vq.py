@@ -7,8 +7,8 @@ reference -- the quantize-dropout seed, rvq.py:96-102 -- is taken only when quan
 """
 from __future__ import annotations
 
+import contextlib
 import os
-
 import random
 from math import ceil
 from typing import Optional
@@ -65,6 +65,8 @@ class MLP(nn.Module):
 
 class ResidualVQ(nn.Module):
     concurrent_stats = True       # fused loop: stage statistics on a side HIP stream beside the later searches (class attribute)
+    chunk_rows = True             # fused loop: big batches run as interleaved row chunks (L.rvq_row_chunks); GroupedResidualVQ turns
+                                  # it off for its groups while they run concurrently (instance attribute there)
 
     def __init__(
         self,
@@ -372,35 +374,66 @@ class ResidualVQ(nn.Module):
             else:
                 L.ema_accumulate(stage_input, idx_all, C, **kw)
 
+        # Batched stage statistics (round 5): on the chain the inputs of stages 1 .. Q - 1 sit one behind the other, so their
+        # statistics are ONE set of launches (vqhip_ema_accumulate_stages, grid dimension y = stage) behind the loop, beside the decode,
+        # instead of Q chains of four short launches that each wait for a workgroup slot beside a screening kernel filling every
+        # register file -- and slow it down (profiles/r5_rvq_cfg3).  VQHIP_RVQ_BATCH_STATS: 0 (default) per-stage passes beside the
+        # loop, 1 stage 0 beside the loop + the rest batched, 2 everything behind the loop.  Measured at cfg 3: 2.86 / 2.93 / 2.95 ms
+        # (cfg 5: 14.7 / 15.0 / 14.9) -- the loop alone gets 0.35 ms shorter without the statistics beside it, and the batched passes
+        # (HBM-bound at 5.1 TB/s: 0.45 ms for the 1.9 GB of stages 1 .. 7) then cost more than that behind it.
+        batch_mode = int(os.environ.get("VQHIP_RVQ_BATCH_STATS", "0")) if (chain and update and Q > 1 and x.is_cuda and x.numel() > 0
+                                                                            and not vq0._codebook.use_cosine_sim) else 0
+        concurrent = bool(update and x.is_cuda and self.concurrent_stats and not torch.cuda.is_current_stream_capturing())
+        main = torch.cuda.current_stream(x.device) if x.is_cuda else None
         if L.screening_enabled() and D in (32, 64, 128, 256, 512) and x.data_ptr() % 16 == 0:
             # Q screened searches on the f16 MFMA pipe (csrc/vq_screen.hip), each writing the next stage's input; beats
             # the fused exact-fp32 kernel, which keeps the dims the screen does not cover (96, 160, ...)
             hook = None
-            if update and x.is_cuda and self.concurrent_stats and not torch.cuda.is_current_stream_capturing():
+            if concurrent:
                 # no search reads a codebook this forward changes (shared or not, embed is only rewritten after the loop), so
                 # stage q's statistics pass runs on a side stream beside the searches of the later stages.  (Not while a HIP graph
                 # is being captured: a fork nested inside GroupedResidualVQ's per-group fork crashed hipStreamEndCapture on
                 # ROCm 7.2; either fork alone captures fine, the group fork is the one kept.)
-                main = torch.cuda.current_stream(x.device)
                 side = _stats_stream(x.device, main)
                 side.wait_stream(main)
 
-                def hook(q, stage_input, idx_all):
-                    ev = torch.cuda.Event()
-                    ev.record(main)
-                    side.wait_event(ev)
+                def hook(q, stage_input, idx_all, ready=None):
+                    if batch_mode == 2 or (batch_mode == 1 and q > 0):
+                        return
+                    if ready is None:       # one chain on the caller's stream
+                        ready = [torch.cuda.Event()]
+                        ready[0].record(main)
+                    for ev in ready:        # row chunks: one event per chunk stream, recorded behind its stage q
+                        side.wait_event(ev)
                     with torch.cuda.stream(side):
                         accumulate(q, stage_input, idx_all)
             # (with a side-stream hook the -1 of the masked rows is written only after that stream has been joined below: its
             #  statistics passes read `idx`)
             if chain:
+                # (row chunks interleave two chains so that one's exact passes run beside the other's screening kernel; a grouped
+                #  module's groups already do that for each other.  Not under graph capture: nested forks, see above.)
+                capturing = x.is_cuda and torch.cuda.is_current_stream_capturing()
+                K = 1 if (capturing or not self.chunk_rows) else L.rvq_row_chunks(x.numel() // D)
                 r = L.rvq_forward_chained(x, packed, embed, Q, row_mask=mask, stage_hook=hook, fill_masked=hook is None,
-                                          route_mode=route_mode)
+                                          route_mode=route_mode, row_chunks=K)
             else:
                 r = L.rvq_forward_screened(x, packed, embed, Q, want_resid=update, want_sqerr=want_loss, row_mask=mask, stage_hook=hook,
                                            fill_masked=hook is None)
             if hook is None:
                 side = None
+            if batch_mode:
+                # stages 1 .. Q - 1 (and stage 0 unless the hook took it) in one set of launches, on the statistics stream beside the
+                # decode when there is one
+                run = contextlib.nullcontext()
+                if side is not None:
+                    side.wait_stream(main)
+                    run = torch.cuda.stream(side)
+                with run:
+                    if batch_mode == 2 or side is None:
+                        accumulate(0, x, r["idx"])
+                    L.ema_accumulate_stages(r["bufs"][: Q - 1].view(Q - 1, *x.shape), r["idx"], 1, C, buf[1:Q], stats_ws[1:Q], row_mask=mask,
+                                            sqerr_from=None if not want_loss else ((packed, embed) if self.shared_codebook else (packed[1:Q], embed[1:Q])),
+                                            sqerr_out=None if not want_loss else sq_parts[1:Q])
         else:
             r = L.rvq_forward(x, packed, embed, Q, want_resid=update, want_sqerr=want_loss, row_mask=mask)
         idx = r["idx"]
@@ -425,7 +458,7 @@ class ResidualVQ(nn.Module):
                         dist.all_reduce(buf)
                     reduced = True
                 torch.cuda.current_stream(x.device).wait_stream(side)
-            else:
+            elif not batch_mode:
                 for q in range(Q):
                     accumulate(q, stage_in(q), idx)
 
@@ -681,6 +714,8 @@ class GroupedResidualVQ(nn.Module):
             # group's search instead of leaving the chip mostly idle.  Host code order (and with it RNG consumption) is unchanged.
             cur = torch.cuda.current_stream(x.device)
             side = self._side_streams(x.device)
+            for r in self.rvqs:             # the groups interleave with each other already (VQHIP_GRVQ_CHUNK_ROWS=1: chunks on top)
+                r.chunk_rows = os.environ.get("VQHIP_GRVQ_CHUNK_ROWS", "0") == "1"
             fork = torch.cuda.Event()
             fork.record(cur)
             outs = []
