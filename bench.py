@@ -42,9 +42,9 @@ N_BATCHES = 4                        # distinct synthetic batches cycled through
 # CPU baseline + parity audit against the reference's op sequence (oracle mode "aten")
 # ----------------------------------------------------------------------------------------------------------------------
 def cpu_baseline_and_audit(nthreads, dev):
-    """Times the reference's CPU op sequence (oracle mode="aten": 3 N*C*D contractions + the N*C temporaries; proven
-    bit-identical to the live reference in the build container, tests/test_oracle.py -- /root/reference itself is not on
-    the GPU box) on a bounded sample of the cfg-2 workload (the first 131072 vectors), then audits the GPU path's indices
+    """Times the reference's CPU op sequence (oracle mode="aten", quantize_mode="onehot": the 3 N*C*D contractions of a training
+    forward -- cdist, the one-hot gather einsum, the EMA einsum -- + the N*C temporaries; proven bit-identical to the live
+    reference in the build container, tests/test_oracle.py -- /root/reference itself is not on the GPU box) on a bounded sample of the cfg-2 workload (the first 131072 vectors), then audits the GPU path's indices
     against the oracle's on ALL 2^20 rows of that batch in chunks (mismatch count with tie audit):
     for every mismatch the gap between the two candidates in the reference's own fp32 distances (ulps) and which of the two
     is closer in float64."""
@@ -63,17 +63,18 @@ def cpu_baseline_and_audit(nthreads, dev):
 
     st = fresh()
     with torch.no_grad():
-        O.vq_forward(st, cfg, xs[0])                # warm-up
+        O.vq_forward(st, cfg, xs[0], quantize_mode="onehot")                # warm-up
         ts = []
         for _ in range(3):
             t0 = time.perf_counter()
-            O.vq_forward(st, cfg, xs[0])
+            O.vq_forward(st, cfg, xs[0], quantize_mode="onehot")
             ts.append(time.perf_counter() - t0)
     t = sorted(ts)[1]
     base = dict(value=rows_b * rows_s / t, unit="vectors/s", cores=nthreads, kind="port",
-                sample=(f"oracle mode=aten = the reference's ATen op sequence (live reference not on the GPU box), "
-                        f"x=({rows_b},{rows_s},{D}) bf16 input as in cfg 2, fp32 arithmetic (the reference casts at vqp.py:692), "
-                        f"C={C}, train step, median of 3 after 1 warm-up, {t:.3f} s/forward"))
+                sample=(f"oracle mode=aten, quantize_mode=onehot = the reference's ATen op sequence of a training forward (cdist vqp.py:58-62, "
+                        f"F.one_hot(ind).type(dtype) :142 + the one-hot gather einsum :766, the EMA einsum :602-606: 3 N*C*D contractions; live "
+                        f"reference not on the GPU box), x=({rows_b},{rows_s},{D}) bf16 input as in cfg 2, fp32 arithmetic (the reference casts "
+                        f"at vqp.py:692), C={C}, median of 3 after 1 warm-up, {t:.3f} s/forward"))
 
     # ---- audit: GPU (screened + exact passes) vs the reference op sequence, same rows, same (initial) codebook ----
     ed = e[0].to(dev).contiguous()
@@ -154,6 +155,26 @@ def _preheat(dev, seconds=0.25):
     del a, b
 
 
+BENCH_ENV = {"setpriority_minus10": None, "preheat_s": 0.25,
+             "note": "round 4+: the issuing process asks for nice -10 (needs CAP_SYS_NICE: `setpriority_minus10` says whether it was granted) and "
+                     "0.25 s of untimed HBM copies precede every timed section; earlier rounds' numbers were taken without either"}
+
+
+def _dist_facts(world, dev):
+    """what a SCALE record needs to prove N ranks took part: ranks_seen = an all-reduce of ones over the process group, the RCCL
+    version torch was built against (VERDICT r4 #8)"""
+    out = {"ranks_seen": 1, "rccl_version": None}
+    try:
+        out["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+    except Exception:
+        pass
+    if world > 1:
+        one = torch.ones(1, device=dev)
+        dist.all_reduce(one)
+        out["ranks_seen"] = int(one.item())
+    return out
+
+
 def _windows(run_step, steps, windows, sync):
     """`windows` back-to-back timed windows of exactly `steps` steps, each bracketed by barrier + synchronize on both sides;
     returns the per-window wall times (the reported step time is the MEDIAN window: one 20-step window is ~20 ms at cfg 2)"""
@@ -210,6 +231,62 @@ def _time_grad_step(mod, batches, steps, warmup, sync, windows):
         step(i)
     _preheat(batches[0].device)
     return _windows(step, steps, windows, sync)
+
+
+def cpu_baseline_other(workload, nthreads):
+    """the reference's op sequence for configs 3 / 4 / 5 timed on a ROW CHUNK of the workload on the host cores and
+    scaled (throughput is flat in the row count at these sizes): oracle mode="aten" with the one-hot gather of a training forward
+    (quantize_mode="onehot") for the residual modules, eval mode for cfg 4 as BASELINE.md prescribes.  Steady state (codebooks marked
+    initialised: the k-means first forward of cfg 5 is not part of a step).  -> dict for the JSON line."""
+    from oracle import vq_oracle as O
+    g = torch.Generator().manual_seed(0)
+    if workload == "rvq_cfg3":
+        rows, Dm, Cm, Q, G = (2, 8192), 256, 1024, 8, 1
+    elif workload == "grvq_cfg5":
+        rows, Dm, Cm, Q, G = (1, 4096), 512, 4096, 8, 4
+    else:
+        rows, Dm, Cm, Q, G = (1, 4096), 512, 65536, 1, 1
+    n = rows[0] * rows[1]
+    x = torch.randn(*rows, Dm, generator=g)
+    d = Dm // G
+
+    def state(cosine=False):
+        e = (torch.rand(1, Cm, d, generator=g) * 2 - 1) * (6.0 / (Cm * d)) ** 0.5
+        if cosine:
+            e = torch.nn.functional.normalize(e, dim=-1)
+        return O.VQState(embed=e.clone(), embed_avg=e.clone(), cluster_size=torch.ones(1, Cm), initted=True)
+
+    if workload in ("rvq_cfg3", "grvq_cfg5"):
+        shared = workload == "rvq_cfg3"
+        cfg = O.VQConfig(dim=d, codebook_size=Cm, manual_ema_update=shared)
+        groups = []
+        for _ in range(G):
+            sts = [state()] * Q if shared else [state() for _ in range(Q)]
+            groups.append(sts)
+
+        def fwd():
+            for gi, sts in enumerate(groups):
+                O.rvq_forward(sts, cfg, x[..., gi * d:(gi + 1) * d], shared_codebook=shared, quantize_mode="onehot")
+        what = "train forward"
+    else:
+        cfg = O.VQConfig(dim=d, codebook_size=Cm, use_cosine_sim=True)
+        st = state(cosine=True)
+
+        def fwd():
+            O.vq_forward(st, cfg, x, training=False)
+        what = ("eval forward against ALL 65536 codes (BASELINE.md 4: cfg 4 in eval mode; the GPU line beside it is ONE of 8 ranks' share: "
+                "every row against 8192 codes)")
+    with torch.no_grad():
+        fwd()
+        ts = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            fwd()
+            ts.append(time.perf_counter() - t0)
+    t = sorted(ts)[1]
+    return dict(value=n / t, unit="vectors/s", cores=nthreads, kind="port",
+                sample=(f"oracle mode=aten (the reference's ATen op sequence; live reference not on the GPU box), {what} on a row chunk "
+                        f"x=({rows[0]},{rows[1]},{Dm}) fp32 of the workload, scaled per vector; median of 3 after 1 warm-up, {t:.3f} s/forward"))
 
 
 def other_workload(args, world, rank, dev, workload=None, steps=None, warmup=None, windows=None):
@@ -312,6 +389,9 @@ def other_workload(args, world, rank, dev, workload=None, steps=None, warmup=Non
             traffic, traffic_src = tj["bytes_per_step"], tj.get("source")
     except Exception:
         pass
+    cpu_base = None
+    if world == 1 and not args.no_cpu_baseline and args.workload in ("rvq_cfg3", "grvq_cfg5", "vq_cfg4_shard"):
+        cpu_base = cpu_baseline_other(args.workload, torch.get_num_threads())
     return ({"metric": "vectors quantized/sec", "value": n * args.steps / dt, "unit": "vectors/s", "n_gpus": world,
                       "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
                       "scaling": "strong" if strong else "weak", "vs_baseline": None,
@@ -321,8 +401,10 @@ def other_workload(args, world, rank, dev, workload=None, steps=None, warmup=Non
                           "workload": "same module and batches, x.requires_grad_() + backward (upstream gradient of `quantized` resident in HBM, + sum of the commit losses) (BASELINE.md §4, second line)",
                           "ms_per_step": _median(gdts) / args.steps * 1e3, "value": n * args.steps / _median(gdts), "unit": "vectors/s",
                           "windows_ms_per_step": [round(d / args.steps * 1e3, 4) for d in gdts]},
+                      "cpu_baseline": cpu_base,
                       "config": {"workload": name, "parallelism": par, "vector_stages_per_s": n * stages * args.steps / dt,
                                  "world_size": world, "backend": (dist.get_backend() if world > 1 else None),
+                                 **_dist_facts(world, dev), "bench_env": BENCH_ENV,
                                  "collective_bytes_per_rank_and_step": getattr(mod, "last_comm", None) or None,
                                  "first_forward_ms": first * 1e3, "uncertified_rows_per_search": per_stage},
                       "roofline": {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
@@ -418,11 +500,16 @@ def vq_cfg2(args, world, rank, dev):
     tl = tmax.tolist()
     dts, gdts = tl[: len(dts)], (tl[len(dts):] if gdts else None)
     dt = _median(dts)
+    dist_facts = _dist_facts(world, dev)            # (collective: every rank)
     if rank != 0:
         return
 
     n_vec = B * S
     k_ms = sum(a.elapsed_time(b) for a, b in ev) / max(len(ev), 1)
+    win_search = None
+    if len(ev) == args.steps * args.windows:        # one event pair per step, in step order
+        per = [a.elapsed_time(b) for a, b in ev]
+        win_search = [round(sum(per[w * args.steps:(w + 1) * args.steps]) / args.steps, 4) for w in range(args.windows)]
     flops = 2.0 * n_vec * C * D                                  # 2*C*D per vector
     alg_bytes = n_vec * 1032 + C * D * 4                         # D*2 in + D*2 out + 8 per vector (+ codebook once)
     achieved = flops / (k_ms * 1e-3) / 1e12
@@ -454,6 +541,10 @@ def vq_cfg2(args, world, rank, dev):
         "dtype": "f16+f32" if screened else "f32",
         "data": "synthetic",
         "windows_ms_per_step": [round(d / args.steps * 1e3, 4) for d in dts],   # ms_per_step / value = the median window
+        # per window: the search of a step (events recorded by the library around it) and everything else of the step (statistics, fold,
+        # pack, launch gaps) -- so that a slow window can be attributed
+        "windows_search_ms": win_search,
+        "windows_rest_ms": None if win_search is None else [round(d / args.steps * 1e3 - sm, 4) for d, sm in zip(dts, win_search)],
         "grad_step": None if gdts is None else {
             "workload": ("same module and batches, x.requires_grad_() + backward (upstream gradient of `quantized` resident in HBM, + the commit loss): rotation-trick route (the "
                          "module default, vqp.py:856) + commit-loss gradient (BASELINE.md §4, second line)"),
@@ -466,7 +557,7 @@ def vq_cfg2(args, world, rank, dev):
                    "vectors_per_gpu": n_vec,
                    "parallelism": f"dp{world} (rows sharded, one all-reduce of EMA statistics per step)" if world > 1 else "single GPU",
                    "world_size": world, "backend": (dist.get_backend() if world > 1 else None),
-                   "loss": float(loss.item())},
+                   **dist_facts, "bench_env": BENCH_ENV, "loss": float(loss.item())},
         "roofline": {"bound": "mfma",
                      "kernel": (("vq_screenc_kernel<256> + vq_compact_lists_kernel" if os.environ.get("VQHIP_SCREEN_PERSIST", "1") != "0" else "vq_screen16_kernel<256>")
                                 + " + vq_refine_kernel<256> + vq_pair_kernel<256> + vq_finish_listed_kernel" if screened
@@ -528,6 +619,8 @@ def vq_cfg2(args, world, rank, dev):
                               "first_forward_ms": round(r["config"]["first_forward_ms"], 2),
                               "open_frac_mean": _mean((r["config"]["uncertified_rows_per_search"] or {}).get("open_frac")),
                               "pair_frac_mean": _mean((r["config"]["uncertified_rows_per_search"] or {}).get("pair_frac")),
+                              "traffic_bytes_per_step": r["roofline"]["traffic"], "traffic_source": r["roofline"]["traffic_source"],
+                              "cpu_baseline": r.get("cpu_baseline"),
                               "steps": st, "windows": 3, "workload": r["config"]["workload"]}
                 except Exception as ex:      # the contract line must not die with an informational one
                     ow[wl] = {"error": f"{type(ex).__name__}: {ex}"}
@@ -559,8 +652,9 @@ def main():
     args = ap.parse_args()
     try:    # the thread that issues the launches keeps its core when other tenants load the shared host (a step is ~15 launches from
         os.setpriority(os.PRIO_PROCESS, 0, -10)     # Python; profiles/r4_final/bench_slow_box.json is what a starved issuer looks like)
+        BENCH_ENV["setpriority_minus10"] = True
     except Exception:
-        pass
+        BENCH_ENV["setpriority_minus10"] = False
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         # not under a launcher: start the N ranks ourselves (one process per GPU, RCCL), same contract as the driver's command

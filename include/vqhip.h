@@ -415,8 +415,9 @@ int vqhip_topk(const void *x, int x_dtype, int64_t N, int D, int64_t ldx, const 
 int vqhip_expire_scatter(float *cluster_size, float *embed_avg, float *embed, const float *candidates, int C, int D,
                          float threshold, float reset, int *n_expired_out, void *stream);
 /* Dead-code replacement in ONE launch, no candidate tensor (vqp.py:544-574): every code with cluster_size < threshold takes row pi(c) of
- * the batch rows [n, D] (fp32 / bf16, row stride ldx), pi(c) = the affine permutation (a c + b) mod p of Z_p cycle-walked into [0, n) --
- * distinct rows for distinct codes when C <= n (the reference samples without replacement, :180-188) -- l2-normalised for a cosine
+ * the batch rows [n, D] (fp32 / bf16, row stride ldx), pi = the affine permutation (a c + b) mod p of Z_p cycle-walked into [0, n),
+ * followed by a 4-round Feistel permutation of [0, n) keyed by (a, b) (round 5: the affine map alone hands neighbouring codes rows a
+ * fixed stride apart) -- distinct rows for distinct codes when C <= n (the reference samples without replacement, :180-188) -- l2-normalised for a cosine
  * codebook (:545-546); embed_avg = row * reset, cluster_size = reset.  ab: device int64[2] = (a, b), both in [1, p); p: a prime with
  * n <= p < 2^31 (the caller's: the smallest one).  Nothing on the host depends on how many codes expired. */
 int vqhip_expire_pick(float *cluster_size, float *embed_avg, float *embed, const void *rows, int x_dtype, int64_t n, int64_t ldx,

@@ -8,8 +8,10 @@ lucidrains/vector-quantize-pytorch v1.31.0.  Citations: "vqp.py" =
 
 Two assignment back-ends:
   mode="aten"  : distances with the same ATen/MKL ops the reference issues (bit-identical to the
-                 live reference on the same host; this is also what `cpu_baseline` times, because it
-                 is the reference's real CPU cost: 3 N*C*D contractions + the N*C temporaries).
+                 live reference on the same host; with quantize_mode="onehot" this is also what
+                 `cpu_baseline` times, because it is the reference's real CPU cost: 3 N*C*D
+                 contractions -- cdist, the one-hot gather einsum of a training forward, the EMA
+                 einsum -- + the N*C temporaries; the default quantize_mode="gather" runs 2 of them).
   mode="chain" : the deterministic C restatement (oracle/vq_oracle.c) whose x.c^T is one fp32 FMA
                  chain in ascending k -- host-independent, and bit-identical to the HIP kernel.
 
@@ -269,9 +271,13 @@ def expire_codes(st: VQState, cfg: VQConfig, batch_samples, sample_fn=batched_sa
 
 def codebook_forward(st: VQState, cfg: VQConfig, x, *, training=True, mask=None, freeze_codebook=False,
                      ema_update_weight=None, assign_mode="aten", sample_fn=batched_sample_rows,
-                     replace_sample_fn=batched_sample_rows, stats_mode="aten"):
+                     replace_sample_fn=batched_sample_rows, stats_mode="aten", quantize_mode="gather"):
     """Codebook.forward, vqp.py:673-791, for num_codebooks == 1 input [b, n, d] (or [h,b,n,d]).
-    Returns (quantize fp32, embed_ind int64).  Mutates `st` like the reference mutates its buffers."""
+    Returns (quantize fp32, embed_ind int64).  Mutates `st` like the reference mutates its buffers.
+    quantize_mode: "gather" -- embed[ind], what the reference's eval branch does (:779-781) and bit-identical to its training
+    branch; "onehot" -- the training branch AS THE REFERENCE RUNS IT: F.one_hot(ind, C).type(dtype) (:142, an N x C int64 tensor
+    cast to fp32) contracted with the codebook (:766, the second N*C*D contraction of a training forward), the same one-hot tensor
+    then feeding the EMA statistics (:602-606, the third).  bench.py's cpu_baseline times this mode."""
     needs_h = x.ndim < 4
     x = x.float()                                                   # :692
     if needs_h:
@@ -297,12 +303,17 @@ def codebook_forward(st: VQState, cfg: VQConfig, x, *, training=True, mask=None,
     ind = _assign(flat.detach(), embed, cfg.use_cosine_sim, assign_mode)      # :740-747
 
     # quantize = exact copy of the pre-update codebook row (:766 one-hot einsum / :779-781 gather)
-    quant = torch.stack([embed[h][ind[h]] for h in range(H)], 0)
+    onehot_ref = None
+    if quantize_mode == "onehot" and training:
+        onehot_ref = F.one_hot(ind, cfg.codebook_size).type(flat.dtype)                     # :142
+        quant = torch.einsum('hnc,hcd->hnd', onehot_ref, embed)                             # :766
+    else:
+        quant = torch.stack([embed[h][ind[h]] for h in range(H)], 0)
 
     if training and not freeze_codebook and (cfg.ema_update or cfg.threshold_ema_dead_code > 0):   # :783, :630
         C = cfg.codebook_size
         if stats_mode == "aten":                                    # :602-606, the reference's one-hot contraction
-            onehot = F.one_hot(ind, C).to(flat.dtype)
+            onehot = onehot_ref if onehot_ref is not None else F.one_hot(ind, C).to(flat.dtype)
             if fmask is not None:
                 onehot = onehot.masked_fill(~fmask[..., None], 0.)
             count = onehot.sum(1)

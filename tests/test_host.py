@@ -189,11 +189,13 @@ def test_every_entry_point_has_a_declared_ctypes_signature():
 
 def test_expire_pick_permutation_is_a_bijection_of_the_rows():
     """The row vqhip_expire_pick hands code c (csrc: vq_expire_pick_kernel): the affine map t -> (a t + b) mod p of Z_p, p the smallest
-    prime >= n, cycle-walked into [0, n).  Restated here in Python: for C <= n the codes take pairwise distinct rows (the reference
+    prime >= n, cycle-walked into [0, n), followed by a keyed Feistel permutation of [0, n).  Restated here in Python: for C <= n the codes take pairwise distinct rows (the reference
     samples without replacement, vqp.py:180-188), for every (a, b) in [1, p)."""
     import random
     from vector_quantize_pytorch_amd._lib import _next_prime
     assert [_next_prime(n) for n in (1, 2, 3, 4, 8, 9, 90, 1024, 8192)] == [2, 2, 3, 5, 11, 11, 97, 1031, 8209]
+
+    M32 = 0xFFFFFFFF
 
     def pick(c, a, b, p, n):
         v = (a * (c % p) + b) % p
@@ -201,7 +203,27 @@ def test_expire_pick_permutation_is_a_bijection_of_the_rows():
         while v >= n and it < 64:
             v = (a * v + b) % p
             it += 1
-        return v if v < n else v % n
+        v = v if v < n else v % n
+        if n <= 2:
+            return v
+        # round 5: a 4-round Feistel network on the smallest even-width power-of-two domain >= n, cycle-walked into [0, n), on top of
+        # the affine map (whose picks for neighbouring codes form an arithmetic progression) -- restated from the kernel
+        kb = 1
+        while (1 << kb) < n:
+            kb += 1
+        kb += kb & 1
+        hb, mask = kb >> 1, (1 << (kb >> 1)) - 1
+        w = v
+        for _ in range(64):
+            Lh, R = (w >> hb) & mask, w & mask
+            for r in range(4):
+                f = (R * 0x9E3779B1 + ((b if r & 1 else a) & M32) + 0x85EBCA6B * (r + 1) + (((a if r & 2 else b) >> 17) & M32)) & M32
+                f ^= f >> 15; f = (f * 0x2C1B3C6D) & M32; f ^= f >> 12; f = (f * 0x297A2D39) & M32; f ^= f >> 15
+                Lh, R = R, Lh ^ (f & mask)
+            w = (Lh << hb) | R
+            if w < n:
+                return w
+        return v
 
     rng = random.Random(0)
     for n in (1, 2, 7, 90, 1000, 4099):
@@ -213,6 +235,9 @@ def test_expire_pick_permutation_is_a_bijection_of_the_rows():
             assert all(0 <= r < n for r in rows)
             # distinct unless the walk was cut short by the 64-step cap (a short cycle of the map inside [n, p): not for these sizes)
             assert len(set(rows)) == C, (n, p, a, b)
+            if n >= 1000:       # neighbouring codes no longer take rows a fixed stride apart
+                steps = {(rows[c + 1] - rows[c]) % n for c in range(C - 1)}
+                assert len(steps) > C // 2, (n, a, b, len(steps))
 
 
 def test_other_float_dtypes_are_computed_in_float32_and_cast_back():

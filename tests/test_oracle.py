@@ -53,6 +53,27 @@ def test_oracle_reproduces_reference(name, mode):
             _close(v.float(), after[k].float(), tol, k)
 
 
+@pytest.mark.parametrize("cosine", [False, True])
+def test_oracle_onehot_quantize_mode_is_the_gather_bit_for_bit(cosine):
+    """quantize_mode="onehot" restates the reference's TRAINING branch literally -- F.one_hot(ind).type(dtype) contracted with the
+    codebook (vqp.py:142, 766), the same tensor feeding the EMA einsum (:602-606): the op sequence bench.py's cpu_baseline times
+    (the gather form runs 2 of the reference's 3 N*C*D contractions).  Outputs and state equal the gather form's."""
+    torch.manual_seed(0)
+    cfg = O.VQConfig(dim=32, codebook_size=64, use_cosine_sim=cosine)
+    e = torch.randn(1, 64, 32)
+    if cosine:
+        e = torch.nn.functional.normalize(e, dim=-1)
+    x = torch.randn(2, 300, 32)
+    outs = []
+    for qm in ("gather", "onehot"):
+        st = O.VQState(embed=e.clone(), embed_avg=e.clone(), cluster_size=torch.ones(1, 64))
+        with torch.no_grad():
+            q, ind, loss = O.vq_forward(st, cfg, x, quantize_mode=qm)
+        outs.append((q, ind, loss, st.embed.clone(), st.embed_avg.clone(), st.cluster_size.clone()))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize("D", [2, 8, 20, 32, 40, 64, 100, 128, 256, 384, 512])
 def test_c_sumsq_is_aten_order(D):
     x = torch.randn(2000, D, generator=torch.Generator().manual_seed(D))

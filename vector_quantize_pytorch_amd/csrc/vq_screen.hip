@@ -128,6 +128,14 @@ __global__ void __launch_bounds__(VQS_WAVES * 64, 8 / VQS_WAVES) vq_screen16_ker
     const int half = lane >> 5;
     const int64_t wrow0 = (int64_t)blockIdx.x * VQ_SCREEN_ROWS + wave * 64;
     VQ_PHASE(0);
+    if (a.stagger > 0 && (int)blockIdx.x < a.stagger_first) {
+        // the workgroup whose LDS allocation does not start at 0 is the second one on its CU (HW_REG_LDS_ALLOC, LDS_BASE field)
+        const bool second_wg = (__builtin_amdgcn_s_getreg((11 << 11) | (0 << 6) | 6) & 0xfff) != 0;
+        if (second_wg) {
+            const long long wait = 1024ll * a.stagger, t0 = __builtin_readcyclecounter();
+            while ((long long)__builtin_readcyclecounter() - t0 < wait) __builtin_amdgcn_s_sleep(8);
+        }
+    }
 
     // ---- first buffer: wave w copies the 1-KiB pieces w, w + WAVES, ... ----
     constexpr int PSTRIDE = VQS_WAVES * 1024;
@@ -258,7 +266,7 @@ __global__ void __launch_bounds__(VQS_WAVES * 64, 8 / VQS_WAVES) vq_screen16_ker
 #pragma unroll
                         for (int st = 0; st < NSTEP; ++st) {
                             g[st][i] = g[st][i] - e[st];
-                            if (r < a.N) *(f32x4 *)(a.x_out + r * a.ldxo + lc * 4 + st * CH) = g[st][i];
+                            if (r < a.N && a.x_out) *(f32x4 *)(a.x_out + r * a.ldxo + lc * 4 + st * CH) = g[st][i];
                         }
                     }
                 }
@@ -1387,6 +1395,15 @@ int vq_assign_screened_impl(const void *x, int x_dtype, int64_t N, int D, int64_
     a.prev_embed = chain ? chain->prev_embed : nullptr;
     a.x_out = chain ? (float *)chain->x_out : nullptr;
     a.ldxo = chain ? chain->ldxo : 0;
+    {   // dev switches (A/B measurements only): VQHIP_SCREEN_STAGGER=<k> start offset of every CU's second workgroup, x 1024 cycles;
+        // VQHIP_CHAIN_NOWRITE=1 a chained stage does not store its input (TIMING ONLY: the exact passes then read stale rows)
+        static int stag = -1, nowrite = -1;
+        if (stag < 0) { const char *e = getenv("VQHIP_SCREEN_STAGGER"); stag = e ? atoi(e) : 0; }
+        if (nowrite < 0) { const char *e = getenv("VQHIP_CHAIN_NOWRITE"); nowrite = (e && e[0] == '1') ? 1 : 0; }
+        a.stagger = stag;
+        a.stagger_first = 512;
+        if (nowrite) a.x_out = nullptr;
+    }
 #ifdef VQ_TRACE
     a.trace = vq_g_trace;
 #endif

@@ -45,6 +45,11 @@ struct ScreenArgs {
     const float *prev_embed;           // [C_prev, D] fp32
     float *x_out;
     int64_t ldxo;
+    // start offset (vq_screen16_kernel): the second workgroup of every CU in the launch's FIRST round (blockIdx.x < 2 x CUs) spins for
+    // stagger x 1024 cycles, so that the two workgroups of a CU alternate between their memory phase (rows, previous codes, x_out) and
+    // their sweep instead of meeting the whole chip in both
+    int stagger;
+    int stagger_first;
     // segmented lists (vq_screenc_kernel: every workgroup appends to its own segment, no global atomics; vq_compact_lists_kernel
     // packs the segments into flag_rows / flag_keys and writes flag_count)
     // several heads in one launch (vqhip_assign_screened_batched: blockIdx.y = head): byte strides between consecutive heads' rows,

@@ -3916,6 +3916,31 @@ __global__ void __launch_bounds__(256) vq_expire_pick_kernel(float *__restrict__
     unsigned long long pick = (a * ((unsigned long long)c % pp) + b) % pp;
     for (int it = 0; it < 64 && pick >= (unsigned long long)n; ++it) pick = (a * pick + b) % pp;
     if (pick >= (unsigned long long)n) pick %= (unsigned long long)n;       // (a short cycle of pi inside [n, p): practically never)
+    // The affine map alone sends neighbouring codes to rows a apart (an arithmetic progression: on a flattened [b, n, d] batch that
+    // is e.g. the same position of consecutive sequences -- ADVICE r4).  A 4-round Feistel network on the smallest even-width
+    // power-of-two domain >= n, keyed by (a, b) and cycle-walked into [0, n), permutes the rows once more: a composition of two
+    // permutations of [0, n), so distinct codes still take distinct rows; the picks no longer form a progression.
+    if (n > 2) {
+        int kb = 1;
+        while (((unsigned long long)1 << kb) < (unsigned long long)n) ++kb;
+        kb += kb & 1;
+        const int hb = kb >> 1;
+        const unsigned mask = (1u << hb) - 1u;
+        unsigned long long v = pick;
+        for (int it = 0; it < 64; ++it) {
+            unsigned L = (unsigned)(v >> hb) & mask, R = (unsigned)v & mask;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                unsigned f = R * 0x9E3779B1u + (unsigned)(r & 1 ? b : a) + 0x85EBCA6Bu * (unsigned)(r + 1) + (unsigned)((r & 2 ? a : b) >> 17);
+                f ^= f >> 15; f *= 0x2C1B3C6Du; f ^= f >> 12; f *= 0x297A2D39u; f ^= f >> 15;
+                const unsigned t = L ^ (f & mask);
+                L = R; R = t;
+            }
+            v = ((unsigned long long)L << hb) | R;
+            if (v < (unsigned long long)n) break;
+        }
+        if (v < (unsigned long long)n) pick = v;          // (64 walks without landing in [0, n) -- domain < 4 n, probability 4^-64: keep the affine pick)
+    }
     float v[8];
     float ss = 0.f;
 #pragma unroll

@@ -629,6 +629,7 @@ class VectorQuantize(nn.Module):
             # averages over the batch), consumed, and recomputed in backward (checkpoint): peak memory = one slice, not N x C.
             # Callers that want the matrix itself (top-k next to other options, the dense cross-entropy of the in-place-optimizer /
             # transform paths) keep the single call.
+            assert xs.ndim == 3, "score-row options run on [b, n, d] rows (heads == 1)"      # npos below is the position axis
             nb, npos, C_ = xs.shape[0], xs.shape[1], E.shape[0]
             pos_per = max(1, SCORE_CHUNK_BYTES() // (4 * C_ * max(nb, 1)))
             if topk is None and not need_dist and xs.ndim == 3 and npos > pos_per:
@@ -829,6 +830,9 @@ class VectorQuantize(nn.Module):
                       and self.sync_update_v == 0. and self.in_place_codebook_optimizer is None and self.has_commitment_loss
                       and not freeze_codebook and not cb_.affine_param and not cb_.use_ddp and cb_.embed.dtype == torch.float32
                       and xs.dtype in (torch.float32, torch.bfloat16) and xs.shape[-1] <= 512 and xs.is_cuda
+                      # (a masked cosine batch: the reference's loss compares the un-detached gather against the ORIGINAL input,
+                      #  vqp.py:1214, 1319 -- not the squared error the statistics pass sums, so the codes' gradient takes param_path)
+                      and not (self.use_cosine_sim and mask is not None)
                       and os.environ.get("VQHIP_LEARN_FAST", "1") != "0")
         param_path = not learn_fast and (self._codebook.learnable_codebook or self._codebook.vq_bridge is not None or self.directional_reparam
                                          or dense or ce_only or codebook_transform_fn is not None)
@@ -838,6 +842,7 @@ class VectorQuantize(nn.Module):
             xs = _l2norm_input(xs)
             pre_normalized = True
 
+        self.__dict__.pop("_diversity_from_search", None)        # (never a value left behind by a forward that raised)
         kw = dict(freeze_codebook=freeze_codebook, ema_update_weight=ema_update_weight,
                   accum_ema_update=accum_ema_update, ema_update=(ema_update if topk is None else False),
                   input_normalized=pre_normalized)
@@ -905,7 +910,10 @@ class VectorQuantize(nn.Module):
 
         if self.training and param_path:
             if self.has_codebook_diversity_loss:                                     # vqp.py:1287-1292, 67-68: computed next to the
-                diversity_loss = self.__dict__.pop("_diversity_from_search")           # scores it reads (_forward_general: rows_to_codes)
+                diversity_loss = self.__dict__.pop("_diversity_from_search", None)     # scores it reads (_forward_general: rows_to_codes)
+                if diversity_loss is None:
+                    raise NotImplementedError("codebook_diversity_loss_weight > 0 together with an option whose search does not read the "
+                                              "score rows (codebook_transform_fn): not on the MI355X path")
                 loss = loss + diversity_loss * self.codebook_diversity_loss_weight
             if self.has_commitment_loss:
                 if self.commitment_use_cross_entropy_loss:                           # vqp.py:1297-1305
@@ -941,7 +949,10 @@ class VectorQuantize(nn.Module):
         if self.training and self.has_codebook_orthogonal_loss:                                     # vqp.py:1331-1348, 340-345
             codebook = self._codebook.embed
             if self.orthogonal_reg_active_codes_only:
-                codebook = codebook[:, torch.unique(embed_ind)]
+                ids = torch.unique(embed_ind)
+                if mask_filled:             # the node has already written -1 into the padding rows (vqhip_mask_fill_rows); the reference
+                    ids = ids[ids >= 0]     # takes `unique` before its where(mask, ind, -1), vqp.py:1336 vs :1386-1394
+                codebook = codebook[:, ids]
             ncodes = codebook.shape[-2]
             if self.orthogonal_reg_max_codes is not None and ncodes > self.orthogonal_reg_max_codes:
                 codebook = codebook[:, torch.randperm(ncodes, device=x.device)[:self.orthogonal_reg_max_codes]]
