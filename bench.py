@@ -455,10 +455,13 @@ def vq_cfg2(args, world, rank, dev):
         ev.append(pr)
         return pr
 
+    counting = [True]
+
     def counting_step(*a, **k):
         r = orig_step(*a, **k)
-        exact_rows.append(r["n_exact"][0])
-        pair_rows.append(r["n_pair"][0])
+        if counting[0]:          # (views of the step's reused workspace: snapshot them -- outside the timed windows only)
+            exact_rows.append(r["n_exact"][0].clone())
+            pair_rows.append(r["n_pair"][0].clone())
         return r
 
     _lib.step_event_hook = event_pair
@@ -485,8 +488,14 @@ def vq_cfg2(args, world, rank, dev):
         def step(k):
             last[0] = vq(batches[k % N_BATCHES])
         _preheat(dev)
+        counting[0] = False
         dts = _windows(step, args.steps, args.windows, sync)
         q, idx, loss = last[0]
+        counting[0] = True          # the uncertified-row counters of one more pass over the batches (untimed, no events)
+        _lib.step_event_hook = None
+        for k in range(N_BATCHES):
+            vq(batches[k])
+        sync()
 
     cbmod.L.assign = orig_assign
     cbmod.L.vq_train_step = orig_step

@@ -999,9 +999,28 @@ def vq_step_supported(x: torch.Tensor, C: int) -> bool:
     return bool(N > 0 and lib().vqhip_vq_step_supported(_dtype_code(xk), N, D, C) and xk.data_ptr() % 16 == 0 and (ldx * es) % 16 == 0)
 
 
+_SCRATCH = {}
+
+
+def scratch(kind: str, nbytes: int, device) -> torch.Tensor:
+    """A persistent scratch buffer for a library call: one per (device, CURRENT STREAM, kind, size), so consecutive calls on a stream
+    reuse it in stream order (safe: the library only enqueues) and concurrent streams -- GroupedResidualVQ's groups -- never share
+    one.  Replaces a 26 - 31 MiB torch.empty per forward on the training hot path.  At most 16 buffers are kept
+    (least recently used first out); contents are only valid until the next call that asks for the same key."""
+    dev = torch.device(device)
+    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream, kind, int(nbytes))
+    t = _SCRATCH.pop(key, None)
+    if t is None:
+        t = torch.empty(max(int(nbytes), 1), dtype=torch.uint8, device=dev)
+        while len(_SCRATCH) >= 16:
+            _SCRATCH.pop(next(iter(_SCRATCH)))
+    _SCRATCH[key] = t                      # (re-inserted: dicts keep insertion order, so the first key is the least recently used)
+    return t
+
+
 @_on_device
 def vq_train_step(x: torch.Tensor, embed, embed_avg, cluster_size, *, decay, eps, want_q=True, q_out=None, loss_scale=None, fold=True,
-                  cosine=False, row_mask=None):
+                  cosine=False, row_mask=None, reuse_scratch=False):
     """One training forward of an EMA codebook (Euclidean, or cosine=True on rows already unit-norm: l2norm_rows) in one library call (vqhip_vq_train_step; reference: vqp.py:673-800 under
     VectorQuantize.forward :1176).  embed / embed_avg / cluster_size: [C, D], [C, D], [C] fp32, updated in place when fold.
     -> dict(q, idx, count [C], embed_sum [C, D] (views of one [C D + C] buffer: one all-reduce), loss (0-dim fp32 or None))"""
@@ -1021,9 +1040,15 @@ def vq_train_step(x: torch.Tensor, embed, embed_avg, cluster_size, *, decay, eps
         assert q.dtype == xk.dtype and q.is_contiguous() and q.numel() == N * D
     stats = torch.empty(C * D + C, dtype=torch.float32, device=dev)
     loss = torch.empty((), dtype=torch.float32, device=dev) if loss_scale is not None else None
-    packed = torch.empty(lib().vqhip_packed_bytes(C, D), dtype=torch.uint8, device=dev)
     nws = lib().vqhip_vq_step_workspace_bytes(N, C)
-    ws = torch.empty(nws, dtype=torch.uint8, device=dev)
+    if reuse_scratch and not torch.cuda.is_current_stream_capturing():
+        # the packed codebook and the workspace live only inside this call (n_exact / n_pair below are views of the workspace: read
+        # them before the next step on this stream)
+        packed = scratch("step.packed", lib().vqhip_packed_bytes(C, D), dev)
+        ws = scratch("step.ws", nws, dev)
+    else:
+        packed = torch.empty(lib().vqhip_packed_bytes(C, D), dtype=torch.uint8, device=dev)
+        ws = torch.empty(nws, dtype=torch.uint8, device=dev)
     omd = float(torch.tensor(1.0 - decay, dtype=torch.float64).to(torch.float32))
     st = _Step(x=xk.data_ptr(), x_dtype=_dtype_code(xk), N=N, D=D, ldx=ldx, embed=embed.data_ptr(), embed_avg=embed_avg.data_ptr(),
                cluster_size=cluster_size.data_ptr(), C=C, idx_out=idx.data_ptr(), q_out=None if q is None else q.data_ptr(), ldq=D,

@@ -8,9 +8,8 @@ the N x C distance / one-hot tensors the reference materialises never exist here
 """
 from __future__ import annotations
 
-from typing import Callable, Optional
-
 import os
+from typing import Callable, Optional
 
 import torch
 import torch.distributed as dist
@@ -427,7 +426,8 @@ class Codebook(nn.Module):
             if self.use_cosine_sim and not input_normalized:    # vqp.py:1157-1159 (the loss below then compares with the unit-norm rows,
                 x0 = L.l2norm_rows(x0)                          #  as the reference's does)
             r = L.vq_train_step(x0, e, ea, cs, decay=self.decay, eps=self.eps, want_q=want_q, q_out=q_out, loss_scale=loss_scale,
-                                fold=not self.use_ddp, cosine=self.use_cosine_sim, row_mask=rmask)
+                                fold=not self.use_ddp, cosine=self.use_cosine_sim, row_mask=rmask,
+                                reuse_scratch=os.environ.get("VQHIP_SCRATCH_CACHE", "1") != "0")
             if self.use_ddp:
                 dist.all_reduce(r["stats"])   # ONE collective for count || embed_sum (RCCL over xGMI), then the fold
                 self._fold_stats(0, r["count"], r["embed_sum"], None, False, ema_update)
