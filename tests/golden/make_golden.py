@@ -305,6 +305,25 @@ if __name__ == "__main__":
     # computes `dist` (vqp.py:718-720), so the loss is taken against the initialised codes, not the all-zero buffer
     run_case("vq_ce_kmeans", VectorQuantize, dict(dim=32, codebook_size=32, kmeans_init=True, kmeans_iters=3, commitment_use_cross_entropy_loss=True),
              [randn(2, 400, 32, seed=150), randn(2, 400, 32, seed=151)], grad=True, deterministic_sampling=True)
+    # several heads together with the options that read whole score rows, affine_param, learnable codebooks -- the
+    # reference carries the head axis through every einsum (vqp.py:1044-1049, 1242-1292): one shared codebook on [(b h), n, d] rows, or
+    # one codebook per head.  (topk with heads > 1 fails upstream: rearrange '1 (b h) n -> b n h' of a [1, b h, n, k] tensor.)
+    hd = dict(dim=64, codebook_size=64, heads=4, codebook_dim=16)
+    run_case("vq_heads_ce", VectorQuantize, dict(hd, commitment_use_cross_entropy_loss=True), [randn(2, 60, 64, seed=160)], grad=True, unit_codebook=True)
+    run_case("vq_heads_diversity", VectorQuantize, dict(hd, codebook_diversity_loss_weight=0.5, codebook_diversity_temperature=10.),
+             [randn(2, 60, 64, seed=161)], grad=True, unit_codebook=True)
+    run_case("vq_heads_gumbel_st", VectorQuantize, dict(dim=32, codebook_size=64, heads=2, codebook_dim=16, straight_through=True, rotation_trick=False,
+                                                        sample_codebook_temp=0.5), [randn(2, 60, 32, seed=162)], grad=True, unit_codebook=True)
+    run_case("vq_heads_affine", VectorQuantize, dict(hd, affine_param=True, affine_param_batch_decay=0.9, affine_param_codebook_decay=0.8),
+             [randn(2, 60, 64, seed=163) * 2 + 1, randn(2, 60, 64, seed=164) * 2 + 1], unit_codebook=True)
+    hs = dict(hd, separate_codebook_per_head=True)
+    run_case("vq_heads_sep_ce", VectorQuantize, dict(hs, commitment_use_cross_entropy_loss=True), [randn(2, 60, 64, seed=165)], grad=True, unit_codebook=True)
+    run_case("vq_heads_sep_diversity", VectorQuantize, dict(hs, codebook_diversity_loss_weight=0.5, codebook_diversity_temperature=10.),
+             [randn(2, 60, 64, seed=166)], grad=True, unit_codebook=True)
+    run_case("vq_heads_sep_learnable", VectorQuantize, dict(hs, learnable_codebook=True, ema_update=False),
+             [randn(2, 60, 64, seed=167)], grad=True, param_grad=True, unit_codebook=True)
+    run_case("vq_heads_sep_affine", VectorQuantize, dict(hs, affine_param=True), [randn(2, 60, 64, seed=168) * 2 + 1, randn(2, 60, 64, seed=169) * 2 + 1],
+             unit_codebook=True)
     # the same loop at a size where near-ties show up: 65 536 rows x 8 stages x 1024 shared codes, default init (cfg 3's shape, a
     # quarter of its rows) -- without an input gradient, and with one under the rotation trick (default) / straight-through, where
     # rvq.py:524 subtracts the layer's ROUTED value from the residual and the later stages' indices depend on its last bits

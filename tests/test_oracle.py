@@ -24,6 +24,8 @@ _MODULE_ONLY = ("vq_fmap", "vq_proj", "vq_heads", "vq_heads_sep", "vq_3d", "vq_c
                 "vq_learnable", "vq_learnable_sync_v", "vq_orthogonal", "vq_inplace_opt", "vq_bridge",
                 "simvq", "simvq_ste_channel_first", "residual_simvq", "rpq", "hvq", "hvq_nokmeans",
                 "vq_ce_commit", "vq_diversity", "vq_topk", "vq_topk_cos", "vq_indices_ce", "vq_stochastic_temp0", "vq_gumbel_st", "rvq_beam", "rvq_beam_shared_mask", "vq_affine",
+                "vq_heads_ce", "vq_heads_diversity", "vq_heads_gumbel_st", "vq_heads_affine", "vq_heads_sep_ce", "vq_heads_sep_diversity",
+                "vq_heads_sep_learnable", "vq_heads_sep_affine",
                 "rvq_qinco", "rvq_qinco_eval", "rvq_grad_mask", "vq_cos_transform_nograd", "rvq_dropout", "rpq_indices", "vq_ce_kmeans")
 
 

@@ -120,8 +120,6 @@ class Codebook(nn.Module):
         vq_bridge: Optional[nn.Module] = None,
     ):
         super().__init__()
-        if affine_param and num_codebooks != 1:
-            raise NotImplementedError("affine_param with several codebooks is not implemented")
         if not (1 <= dim <= 512):
             raise NotImplementedError(f"codebook dim {dim}: the HIP path supports 1 <= dim <= 512")
 

@@ -386,13 +386,9 @@ class VectorQuantize(nn.Module):
 
         if affine_param:
             assert not use_cosine_sim, 'affine param is only compatible with euclidean codebook'
-            if heads > 1:
-                raise NotImplementedError("affine_param is implemented for heads == 1 only")
-        dense_options = (commitment_use_cross_entropy_loss or codebook_diversity_loss_weight > 0. or stochastic_sample_codes
-                         or straight_through)
-        if dense_options and (heads > 1):
-            raise NotImplementedError("options that read the full distance row (cross-entropy / diversity losses, gumbel sampling) "
-                                      "are implemented for heads == 1 only")
+        # (round 5: several heads -- one shared codebook on [(b h), n, d] rows or one codebook per head, vqp.py:1044-1049 -- combine with
+        #  the options that read whole score rows, with affine_param and with learnable codebooks like the reference's einsums do;
+        #  forward(topk=) with heads > 1 fails in the reference itself and raises here)
 
         # the reference's own cross-flag checks (vqp.py:884, 898-913), for identical error behaviour
         assert not (use_cosine_sim and learnable_codebook), 'cosine sim distance codebook not compatible with learnable codebook yet'
@@ -405,8 +401,6 @@ class VectorQuantize(nn.Module):
         assert 0 <= sync_update_v <= 1.
         assert not (sync_update_v > 0. and not learnable_codebook), 'learnable codebook must be turned on'
         has_orth = orthogonal_reg_weight > 0.
-        if (learnable_codebook or has_orth) and separate_codebook_per_head:
-            raise NotImplementedError("a learnable / orthogonally regularised codebook with separate_codebook_per_head is not implemented")
 
         self.dim = dim
         self.heads = heads
@@ -590,22 +584,37 @@ class VectorQuantize(nn.Module):
                 # vqp.py:766 vs :783); gradient: that of a gather from the parameter (vqp.py:710, 766)
                 if not (embed_eff.requires_grad and torch.is_grad_enabled()):
                     return r["q"], r["idx"], None
+                if embed_eff.shape[0] > 1:      # one codebook per head (xs [h, b, n, d]): the same gather, head by head
+                    if xs.dtype in (torch.float32, torch.bfloat16) and xs.shape[-1] <= 512 and os.environ.get("VQHIP_GATHER_FN", "1") != "0":
+                        q_h = [_CodesOfIndicesFn.apply(embed_eff[h], r["idx"][h], r["q"][h]) for h in range(embed_eff.shape[0])]
+                    else:
+                        q_h = []
+                        for h in range(embed_eff.shape[0]):
+                            g = F.embedding(r["idx"][h], embed_eff[h]).to(xs.dtype)
+                            q_h.append(r["q"][h] + (g - g.detach()))
+                    return torch.stack(q_h), r["idx"], None
                 if xs.dtype in (torch.float32, torch.bfloat16) and xs.shape[-1] <= 512 and os.environ.get("VQHIP_GATHER_FN", "1") != "0":
                     return _CodesOfIndicesFn.apply(embed_eff[0], r["idx"], r["q"]), r["idx"], None
                 g = F.embedding(r["idx"], embed_eff[0]).to(xs.dtype)
                 return r["q"] + (g - g.detach()), r["idx"], None
             if not cb._is_initted():
-                cb.init_embed_(xs.detach().reshape(1, -1, xs.shape[-1]).float(), None if rmask is None else rmask.reshape(1, -1))
+                Hc = embed_eff.shape[0]
+                cb.init_embed_(xs.detach().reshape(Hc, -1, xs.shape[-1]).float(), None if rmask is None else rmask.reshape(1, -1).expand(Hc, -1))
             if topk_only and L.topk_supported(xs, topk, embed_eff.shape[-2]):
                 # top-k is the only consumer of the score row: the K best codes straight from the sweep (vqhip_topk), no N x C tensor
                 e2 = embed_eff[0].detach().float().contiguous()
                 ind = L.topk(xs.detach(), L.pack_codebook(e2), e2.shape[0], topk, cosine=cb.use_cosine_sim, skip_l2norm=True)
                 q = F.embedding(ind, embed_eff[0])
                 return q.to(xs.dtype), ind, None
-            E = embed_eff[0]
             want_div = self.training and self.has_codebook_diversity_loss
+            # one codebook per head: xs [h, b, n, d], embed_eff [h, C, D] -- every head is searched by itself; a shared codebook
+            # (heads folded into the batch axis, [(b h), n, d]) is one "head" here
+            sep = xs.ndim == 4
+            xs_h = list(xs.unbind(0)) if sep else [xs]
+            E_h = list(embed_eff.unbind(0)) if sep else [embed_eff[0]]
+            assert len(xs_h) == len(E_h)
 
-            def rows_to_codes(xc, E_search=None):                                     # xc [b, n', d] -> q, ind, dist, entropy sum
+            def rows_to_codes(xc, E, E_search=None):                                  # xc [b, n', d] -> q, ind, dist, batch-mean softmax
                 dist = _ScoresFn.apply(xc, E, cb.use_cosine_sim, E_search)            # vqp.py:740-743, [b, n', C]
                 logits = dist
                 if self.training and self.stochastic_sample_codes and temp > 0:       # vqp.py:117-119, 132-133
@@ -617,40 +626,52 @@ class VectorQuantize(nn.Module):
                     assert topk is None
                     pi = (dist / temp).softmax(dim=-1)
                     q = q + (pi - pi.detach()) @ E.detach()
-                ent = dist.new_zeros(())
+                avg = None
                 if want_div:                                                          # vqp.py:1287-1292, 67-68: softmax averaged over
                     avg = (dist * self.codebook_diversity_temperature).softmax(dim=-1).mean(dim=0)    # the batch, per position
-                    ent = (-avg * torch.log(avg.clamp(min=1e-5))).sum()              # summed over this chunk's positions
-                return q, ind, dist, ent
+                return q, ind, dist, avg
+
+            def entropy_sum(avgs):                    # the averaged distribution runs over batch AND heads ('... n l -> n l', vqp.py:1290)
+                if not want_div:
+                    return xs.new_zeros((), dtype=torch.float32)
+                avg = avgs[0] if len(avgs) == 1 else torch.stack(avgs).mean(0)
+                return (-avg * torch.log(avg.clamp(min=1e-5))).sum()                  # summed over this chunk's positions
 
             # The options that get here read whole score rows (gumbel noise, the straight-through softmax, the diversity loss'
             # batch-averaged softmax).  `dist` is N x C floats -- 4 GiB at BASELINE cfg 2 -- so beyond SCORE_CHUNK_BYTES it is
-            # produced for a slice of the positions at a time (all batch entries of a position stay together: the diversity loss
-            # averages over the batch), consumed, and recomputed in backward (checkpoint): peak memory = one slice, not N x C.
-            # Callers that want the matrix itself (top-k next to other options, the dense cross-entropy of the in-place-optimizer /
-            # transform paths) keep the single call.
-            assert xs.ndim == 3, "score-row options run on [b, n, d] rows (heads == 1)"      # npos below is the position axis
-            nb, npos, C_ = xs.shape[0], xs.shape[1], E.shape[0]
+            # produced for a slice of the positions at a time (all batch entries -- and heads -- of a position stay together: the
+            # diversity loss averages over them), consumed, and recomputed in backward (checkpoint): peak memory = one slice, not
+            # N x C.  Callers that want the matrix itself (top-k next to other options, the dense cross-entropy of the in-place-
+            # optimizer / transform paths) keep the single call.
+            nb, npos, C_ = xs_h[0].shape[0], xs_h[0].shape[1], E_h[0].shape[0]
             pos_per = max(1, SCORE_CHUNK_BYTES() // (4 * C_ * max(nb, 1)))
-            if topk is None and not need_dist and xs.ndim == 3 and npos > pos_per:
+            if topk is None and not need_dist and npos > pos_per:
                 from torch.utils.checkpoint import checkpoint
-                grad = torch.is_grad_enabled() and (xs.requires_grad or E.requires_grad)
-                E_search = E.detach().clone() if grad else None       # (the recomputation in backward runs after the EMA fold)
-                qs, inds, ent_sum = [], [], xs.new_zeros((), dtype=torch.float32)
+                grad = torch.is_grad_enabled() and (xs.requires_grad or embed_eff.requires_grad)
+                E_search = [E.detach().clone() for E in E_h] if grad else [None] * len(E_h)   # (the recomputation in backward runs after the EMA fold)
+                qs, inds, ent_sum = [[] for _ in E_h], [[] for _ in E_h], xs.new_zeros((), dtype=torch.float32)
                 for n0 in range(0, npos, pos_per):
-                    xc = xs[:, n0:n0 + pos_per].contiguous()
-                    if grad:
-                        def piece(a, e_):                                             # (e_: makes the codebook an input of the checkpoint)
-                            q_, ind_, _, ent_ = rows_to_codes(a, E_search)
-                            return q_, ind_, ent_
-                        q_, ind_, ent_ = checkpoint(piece, xc, E, use_reentrant=False)
-                    else:
-                        q_, ind_, _, ent_ = rows_to_codes(xc)
-                    qs.append(q_); inds.append(ind_)
-                    ent_sum = ent_sum + ent_
-                q, ind, dist = torch.cat(qs, 1), torch.cat(inds, 1), None
+                    avgs = []
+                    for h, (xh, E) in enumerate(zip(xs_h, E_h)):
+                        xc = xh[:, n0:n0 + pos_per].contiguous()
+                        if grad:
+                            def piece(a, e_, h=h):                                    # (e_: makes the codebook an input of the checkpoint)
+                                q_, ind_, _, avg_ = rows_to_codes(a, e_, E_search[h])
+                                return q_, ind_, (avg_ if avg_ is not None else a.new_zeros(()))
+                            q_, ind_, avg_ = checkpoint(piece, xc, E, use_reentrant=False)
+                        else:
+                            q_, ind_, _, avg_ = rows_to_codes(xc, E)
+                        qs[h].append(q_); inds[h].append(ind_); avgs.append(avg_)
+                    ent_sum = ent_sum + entropy_sum(avgs)
+                q_h, ind_h, dist_h = [torch.cat(v, 1) for v in qs], [torch.cat(v, 1) for v in inds], None
             else:
-                q, ind, dist, ent_sum = rows_to_codes(xs)
+                outs_h = [rows_to_codes(xh, E) for xh, E in zip(xs_h, E_h)]
+                q_h, ind_h = [o[0] for o in outs_h], [o[1] for o in outs_h]
+                dist_h = [o[2] for o in outs_h]
+                ent_sum = entropy_sum([o[3] for o in outs_h])
+            q = torch.stack(q_h) if sep else q_h[0]
+            ind = torch.stack(ind_h) if sep else ind_h[0]
+            dist = None if dist_h is None else (torch.stack(dist_h) if sep else dist_h[0])
             self.__dict__["_diversity_from_search"] = (-(ent_sum / npos)) if want_div else None   # -ent.mean() over the positions
             if self.training and update_usage and not freeze_codebook and topk is None:                 # vqp.py:783-784
                 cb.update_indices(xs.detach(), ind, mask=rmask, ema_update_weight=kw.get("ema_update_weight"),
@@ -833,6 +854,7 @@ class VectorQuantize(nn.Module):
                       # (a masked cosine batch: the reference's loss compares the un-detached gather against the ORIGINAL input,
                       #  vqp.py:1214, 1319 -- not the squared error the statistics pass sums, so the codes' gradient takes param_path)
                       and not (self.use_cosine_sim and mask is not None)
+                      and not (self.heads > 1 and self.separate_codebook_per_head)
                       and os.environ.get("VQHIP_LEARN_FAST", "1") != "0")
         param_path = not learn_fast and (self._codebook.learnable_codebook or self._codebook.vq_bridge is not None or self.directional_reparam
                                          or dense or ce_only or codebook_transform_fn is not None)
@@ -893,8 +915,14 @@ class VectorQuantize(nn.Module):
             loss = torch.zeros((), device=x.device, dtype=torch.float32)
         commit_loss = self.zero
         def ce_loss(codes):                                                          # vqp.py:1242-1256
-            if distances is not None:                                                # (dense path: heads == 1)
-                return F.cross_entropy(distances.permute(0, 2, 1), codes, ignore_index=-1)
+            if distances is not None:                                                # (dense path; vqp.py:1244-1254)
+                if self.heads == 1:
+                    return F.cross_entropy(distances.permute(0, 2, 1), codes, ignore_index=-1)
+                if not self.separate_codebook_per_head:                              # '1 (b h) n l -> b l n h': rows [(b h), n], codes [b, n, h]
+                    codes_bh = codes.permute(0, 2, 1).reshape(distances.shape[0], distances.shape[1])
+                    return F.cross_entropy(distances.permute(0, 2, 1), codes_bh, ignore_index=-1)
+                return F.cross_entropy(distances.permute(1, 3, 2, 0), codes, ignore_index=-1)   # 'c b n l -> b l n c'
+
             if self.heads == 1:
                 return _CrossEntropyFn.apply(xs, ce_embed[0], ce_embed_at_search[0], codes, self.use_cosine_sim)
             # multi-headed: codes [b, n, h]; the reference takes one mean over every (row, head) target
@@ -917,7 +945,12 @@ class VectorQuantize(nn.Module):
                 loss = loss + diversity_loss * self.codebook_diversity_loss_weight
             if self.has_commitment_loss:
                 if self.commitment_use_cross_entropy_loss:                           # vqp.py:1297-1305
-                    codes = embed_ind if mask is None else embed_ind.masked_fill(~mask, -1)
+                    codes = embed_ind
+                    if self.heads > 1:                                               # rows layout -> the reference's [b, n, h]
+                        codes = (embed_ind.permute(1, 2, 0) if self.separate_codebook_per_head
+                                 else embed_ind.reshape(b, self.heads, n).permute(0, 2, 1))
+                    if mask is not None:
+                        codes = codes.masked_fill(~(mask if self.heads == 1 else mask[..., None]), -1)
                     commit_loss = ce_loss(codes)
                 elif topk is not None:                                               # vqp.py:1307-1315
                     rep = orig_input[..., None, :].expand(*orig_input.shape[:-1], topk, orig_input.shape[-1])
