@@ -14,7 +14,12 @@
  *  - return value: 0 on success, a negative VQHIP_E* code on argument errors, or a positive
  *    hipError_t from the launch.  vqhip_last_error() returns a thread-local message.
  *  - dtype codes: VQHIP_F32 = 0, VQHIP_BF16 = 1.  metric: VQHIP_EUCLID / VQHIP_COSINE / VQHIP_COSINE_PRENORM.
- *  - supported shapes: 1 <= D <= 512, C >= 1, N >= 0; rows addressed as base + n * ld (elements).
+ *  - supported shapes: 1 <= D <= 2048, C >= 1, N >= 0; rows addressed as base + n * ld (elements).  D <= 512: the tuned kernels
+ *    (rows resident in VGPRs as MFMA operands).  512 < D <= 2048 (round 5, csrc/vq_wide.hip): plain exact kernels behind
+ *    vqhip_pack_codebook / vqhip_assign / vqhip_row_sumsq / vqhip_l2norm_rows / vqhip_ema_accumulate* (D % 4 == 0) / vqhip_ema_finalize /
+ *    vqhip_decode_sum / vqhip_route_* / vqhip_expire_* -- same arithmetic contract (ATen-order norms incl. the cascade level of rows
+ *    longer than 512, one ascending fp32 FMA chain per dot product); the screened search, the fused step / residual loop, score rows,
+ *    top-k and batched heads return VQHIP_EDIM there.
  */
 #ifndef VQHIP_H
 #define VQHIP_H

@@ -324,6 +324,15 @@ if __name__ == "__main__":
              [randn(2, 60, 64, seed=167)], grad=True, param_grad=True, unit_codebook=True)
     run_case("vq_heads_sep_affine", VectorQuantize, dict(hs, affine_param=True), [randn(2, 60, 64, seed=168) * 2 + 1, randn(2, 60, 64, seed=169) * 2 + 1],
              unit_codebook=True)
+    # codebook dims beyond 512 (the reference takes any dim, vqp.py:803-806): 768 and 1024 -- the ATen sum of squares
+    # of a row gets its second cascade level there -- train steps with the rotation trick, cosine, bf16 rows, a residual VQ
+    run_case("vq_dim1024", VectorQuantize, dict(dim=1024, codebook_size=512), [randn(1, 160, 1024, seed=170)])
+    run_case("vq_dim768_grad", VectorQuantize, dict(dim=768, codebook_size=64), [randn(2, 60, 768, seed=172)], grad=True, unit_codebook=True)
+    run_case("vq_dim1024_cos", VectorQuantize, dict(dim=1024, codebook_size=64, use_cosine_sim=True),
+             [randn(1, 100, 1024, seed=173), randn(1, 100, 1024, seed=174)])
+    run_case("vq_dim640_bf16", VectorQuantize, dict(dim=640, codebook_size=64), [randn(2, 100, 640, seed=175, dtype=torch.bfloat16)], unit_codebook=True)
+    run_case("rvq_dim768", ResidualVQ, dict(dim=768, num_quantizers=3, codebook_size=48), [randn(1, 100, 768, seed=176)], grad=True, unit_codebook=True)
+    run_case("vq_dim2048_eval", VectorQuantize, dict(dim=2048, codebook_size=64), [randn(1, 70, 2048, seed=177)], train=False)
     # the same loop at a size where near-ties show up: 65 536 rows x 8 stages x 1024 shared codes, default init (cfg 3's shape, a
     # quarter of its rows) -- without an input gradient, and with one under the rotation trick (default) / straight-through, where
     # rvq.py:524 subtracts the layer's ROUTED value from the residual and the later stages' indices depend on its last bits

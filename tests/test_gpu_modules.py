@@ -325,9 +325,9 @@ def test_errors_are_loud(dev):
     with pytest.raises(VQHipError):
         vq(torch.randn(1, 8, 64))                      # CPU tensor: no fallback
     with pytest.raises(NotImplementedError):
-        VectorQuantize(dim=64, codebook_size=32, affine_param=True, heads=2, codebook_dim=32)
-    with pytest.raises(NotImplementedError):
-        VectorQuantize(dim=1024, codebook_size=32)
+        VectorQuantize(dim=4096, codebook_size=32)          # (dims up to 2048 are served since round 5: csrc/vq_wide.hip)
+    with pytest.raises(NotImplementedError):                # forward(topk=) with several heads fails in the reference itself
+        VectorQuantize(dim=64, codebook_size=32, heads=2, codebook_dim=32).to(dev)(torch.randn(1, 8, 64, device=dev), topk=2)
     vq = vq.to(dev)
     q, idx, loss = vq(torch.randn(0, 8, 64, device=dev))   # empty batch
     assert q.shape == (0, 8, 64) and idx.shape == (0, 8)
@@ -336,10 +336,11 @@ def test_errors_are_loud(dev):
 # ---- gradient-routing kernels and the codebook-sharded path ----------------------------------------
 @pytest.mark.parametrize("mode", [1, 2])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-def test_route_kernels_match_autograd_of_the_reference_formula(dev, mode, dtype):
+@pytest.mark.parametrize("D", [192, 768, 2048])           # > 512: 16 / 32 elements per lane of the one-wave-per-row form
+def test_route_kernels_match_autograd_of_the_reference_formula(dev, mode, dtype, D):
     from vector_quantize_pytorch_amd import _lib as L
     g = torch.Generator().manual_seed(3)
-    N, D = 257, 192
+    N = 257
     x = torch.randn(N, D, generator=g).to(dtype)
     q = torch.randn(N, D, generator=g).to(dtype)
     go = torch.randn(N, D, generator=g).to(dtype)

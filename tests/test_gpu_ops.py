@@ -24,7 +24,8 @@ def _mk(N, C, D, dtype=torch.float32, unit=False, seed=0):
     return x, e
 
 
-@pytest.mark.parametrize("N,D", [(1000, 256), (777, 100), (64, 8), (333, 512), (5, 2), (4096, 128), (130, 40)])
+@pytest.mark.parametrize("N,D", [(1000, 256), (777, 100), (64, 8), (333, 512), (5, 2), (4096, 128), (130, 40),
+                                 (300, 520), (257, 768), (1000, 1024), (130, 1531), (64, 2048)])      # > 512: ATen's second cascade level
 def test_row_sumsq_matches_aten_order(dev, N, D):
     from vector_quantize_pytorch_amd import _lib as L
     x, _ = _mk(N, 4, D)
@@ -46,6 +47,12 @@ def test_row_sumsq_matches_aten_order(dev, N, D):
     (1000, 4096, 128, torch.float32, False),     # cfg 5 per-group shape
     (640, 2048, 512, torch.float32, False),      # cfg 4 dim
     (1, 16, 32, torch.float32, True),
+    # wide dims (csrc/vq_wide.hip, round 5): the plain exact kernel, same contract
+    (1000, 300, 768, torch.float32, False),
+    (513, 512, 1024, torch.float32, True),
+    (300, 100, 640, torch.bfloat16, True),
+    (129, 37, 2048, torch.float32, False),
+    (200, 65, 1001, torch.float32, True),        # odd wide D
 ])
 def test_assign_euclid_bitexact(dev, N, C, D, dtype, unit):
     from vector_quantize_pytorch_amd import _lib as L
@@ -68,7 +75,8 @@ def test_assign_euclid_bitexact(dev, N, C, D, dtype, unit):
 
 
 @pytest.mark.parametrize("N,C,D,dtype", [(1024, 512, 256, torch.float32), (999, 1000, 512, torch.float32),
-                                         (2048, 1024, 256, torch.bfloat16), (300, 37, 100, torch.float32)])
+                                         (2048, 1024, 256, torch.bfloat16), (300, 37, 100, torch.float32),
+                                         (400, 200, 1024, torch.float32), (300, 70, 768, torch.bfloat16)])      # wide dims
 def test_assign_cosine_bitexact(dev, N, C, D, dtype):
     from vector_quantize_pytorch_amd import _lib as L
     x, e = _mk(N, C, D, dtype, unit=True)
@@ -126,7 +134,8 @@ def test_assign_strided_rows(dev):
 
 
 @pytest.mark.parametrize("N,C,D,dtype,cos", [(5000, 1024, 256, torch.float32, False), (3000, 100, 40, torch.float32, False),
-                                             (4096, 2500, 128, torch.bfloat16, False), (2000, 512, 256, torch.float32, True)])
+                                             (4096, 2500, 128, torch.bfloat16, False), (2000, 512, 256, torch.float32, True),
+                                             (3000, 200, 768, torch.float32, False), (2000, 100, 2048, torch.bfloat16, False)])   # wide dims
 def test_ema_accumulate(dev, N, C, D, dtype, cos):
     from vector_quantize_pytorch_amd import _lib as L
     x, _ = _mk(N, C, D, dtype, unit=True)
@@ -145,7 +154,8 @@ def test_ema_accumulate(dev, N, C, D, dtype, cos):
 
 
 @pytest.mark.parametrize("N,C,D,dtype", [(20000, 1024, 256, torch.bfloat16), (20000, 512, 256, torch.float32),
-                                         (5000, 300, 512, torch.float32), (5000, 64, 32, torch.bfloat16), (777, 1000, 128, torch.bfloat16)])
+                                         (5000, 300, 512, torch.float32), (5000, 64, 32, torch.bfloat16), (777, 1000, 128, torch.bfloat16),
+                                         (3000, 100, 1024, torch.float32), (2000, 64, 640, torch.bfloat16)])      # wide dims
 def test_ema_accumulate_sqerr_equals_the_search_kernels_loss(dev, N, C, D, dtype):
     """vqhip_ema_accumulate_sqerr: the statistics pass also sums ||q - x||^2 (reference: F.mse_loss numerator, vqp.py:1327).  Against
     (a) the oracle formula on the CPU in double, (b) the sum the exact search kernel produces for the same rows and indices;
@@ -175,7 +185,8 @@ def test_ema_accumulate_sqerr_equals_the_search_kernels_loss(dev, N, C, D, dtype
     assert abs(parts2.sum().item() - want2) <= 1e-6 * want2
 
 
-@pytest.mark.parametrize("C,D,cos", [(512, 256, False), (1024, 256, False), (1000, 100, False), (4096, 128, True), (37, 2, False)])
+@pytest.mark.parametrize("C,D,cos", [(512, 256, False), (1024, 256, False), (1000, 100, False), (4096, 128, True), (37, 2, False),
+                                     (300, 768, False), (64, 2048, False), (100, 1024, True)])      # wide dims: vq_wide_embed_kernel
 def test_ema_finalize(dev, C, D, cos):
     from vector_quantize_pytorch_amd import _lib as L
     g = torch.Generator().manual_seed(1)
@@ -228,10 +239,11 @@ def test_ema_fold_many_equals_successive_folds(dev, C, D, Q, cos):
     assert torch.equal(rows, one)
 
 
-def test_decode_sum(dev):
+@pytest.mark.parametrize("D", [96, 768, 2048])          # > 512: vq_wide_decode_kernel
+def test_decode_sum(dev, D):
     from vector_quantize_pytorch_amd import _lib as L
     g = torch.Generator().manual_seed(2)
-    Q, C, D = 4, 50, 96
+    Q, C = 4, 50
     cb = torch.randn(Q, C, D, generator=g)
     idx = torch.randint(0, C, (3, 70, Q), generator=g)
     idx[0, :5, 2:] = -1

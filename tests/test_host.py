@@ -42,7 +42,10 @@ def test_host_only_entry_points():
     assert L.vqhip_screen_workspace_bytes(1000) >= 16 + 4 * 1000 + 8 * 1000
     assert L.vqhip_packed_bytes(33, 100) == (2 * (128 * 128 + 1024) + 4096 + (33 * 100 * 2 + 8) + 8192 + 64
                                              + 8 * (64 * 128 + 1024) + 8192)   # D padded to 128, C to 64 (fp16 tiles: to 8 tiles); bf16 copy 16-byte rounded
-    assert L.vqhip_packed_bytes(16, 513) == 0                              # unsupported D
+    assert L.vqhip_packed_bytes(16, 2049) == 0                             # unsupported D
+    # wide dims (csrc/vq_wide.hip, round 5): ||c||^2 [C] floats (256-byte padded) + the bf16 copy [C, D] (256-byte padded) + 256
+    assert L.vqhip_packed_bytes(16, 513) == 256 + (16 * 513 * 2 + 255) // 256 * 256 + 256
+    assert L.vqhip_screen_supported(1 << 20, 1024, 1024) == 0 and L.vqhip_vq_step_supported(0, 1 << 20, 1024, 1024) == 0
     assert L.vqhip_assign_blocks(0) == 0 and L.vqhip_assign_blocks(1) == 1 and L.vqhip_assign_blocks(129) == 2
 
 
@@ -54,7 +57,7 @@ def test_argument_validation_precedes_any_gpu_work():
     assert rc == -1 and b"null" in L.vqhip_last_error()
     buf = (ctypes.c_float * 64)()
     p = ctypes.cast(buf, ctypes.c_void_p)
-    assert L.vqhip_assign(p, 0, 16, 1024, 1024, p, p, 8, 0, p, null, 0, 64, null, null, null, null, null) == -2   # D too large
+    assert L.vqhip_assign(p, 0, 16, 4096, 4096, p, p, 8, 0, p, null, 0, 64, null, null, null, null, null) == -2   # D too large (> 2048)
     assert L.vqhip_assign(p, 7, 16, 64, 64, p, p, 8, 0, p, null, 0, 64, null, null, null, null, null) == -1      # dtype
     assert L.vqhip_assign(p, 0, 0, 64, 64, p, p, 8, 0, p, null, 0, 64, null, null, null, null, null) == 0        # N == 0: no-op
     assert L.vqhip_pack_codebook(null, 8, 64, null, null) == -1

@@ -37,6 +37,8 @@ def test_oracle_reproduces_reference(name, mode):
     tol = 1e-6 if mode == "aten" else 1e-5
     if fx.bf16:
         tol = 1e-2
+    if fx.meta["kwargs"].get("dim", 0) > 512 and fx.meta["grad"]:
+        tol = max(tol, 1e-5)        # (the rotation trick's row reductions over 768+ elements: torch's own result moves by > 1e-6 with the order)
     for s, o in enumerate(outs):
         want_idx = fx.t(f"idx{s}")
         assert torch.equal(o["idx"], want_idx), f"step {s}: {(o['idx'] != want_idx).sum().item()} index mismatches"
@@ -76,7 +78,7 @@ def test_oracle_onehot_quantize_mode_is_the_gather_bit_for_bit(cosine):
         assert torch.equal(a, b)
 
 
-@pytest.mark.parametrize("D", [2, 8, 20, 32, 40, 64, 100, 128, 256, 384, 512])
+@pytest.mark.parametrize("D", [2, 8, 20, 32, 40, 64, 100, 128, 256, 384, 512, 520, 640, 768, 1000, 1024, 1536, 2048])
 def test_c_sumsq_is_aten_order(D):
     x = torch.randn(2000, D, generator=torch.Generator().manual_seed(D))
     assert torch.equal(O.c_row_sumsq(x), (x ** 2).sum(-1))

@@ -244,7 +244,7 @@ def pack_codebook(embed2d: torch.Tensor, out: torch.Tensor | None = None) -> tor
     C, D = embed2d.shape
     nbytes = lib().vqhip_packed_bytes(C, D)
     if nbytes == 0:
-        raise VQHipError(f"codebook [{C}, {D}] unsupported: the HIP path handles 1 <= dim <= 512")
+        raise VQHipError(f"codebook [{C}, {D}] unsupported: the HIP path handles 1 <= dim <= 2048")
     if out is None or out.numel() * 4 != nbytes:
         out = torch.empty(nbytes // 4, dtype=torch.float32, device=embed2d.device)
     _check(lib().vqhip_pack_codebook(_ptr(embed2d), C, D, _ptr(out), _stream()), "vqhip_pack_codebook")
@@ -259,7 +259,7 @@ def pack_codebook_batched(embed3d: torch.Tensor) -> torch.Tensor:
     H, C, D = embed3d.shape
     nbytes = lib().vqhip_packed_bytes(C, D)
     if nbytes == 0:
-        raise VQHipError(f"codebook [{C}, {D}] unsupported: the HIP path handles 1 <= dim <= 512")
+        raise VQHipError(f"codebook [{C}, {D}] unsupported: the HIP path handles 1 <= dim <= 2048")
     out = torch.empty(H, nbytes // 4, dtype=torch.float32, device=embed3d.device)
     _check(lib().vqhip_pack_codebook_batched(_ptr(embed3d), H, C, D, _ptr(out), _stream()), "vqhip_pack_codebook_batched")
     return out
@@ -491,6 +491,15 @@ def l2norm_rows_supported(x: torch.Tensor) -> bool:
         return False
     es = xk.element_size()
     return xk.data_ptr() % (4 * es) == 0 and (ldx * es) % (4 * es) == 0
+
+
+WIDE_MAX_DIM = 2048
+
+
+def wide_dim(D: int) -> bool:
+    """512 < D <= 2048: served by the plain exact kernels of csrc/vq_wide.hip (no screened search, no score-row options, no fused
+    residual loop / fused train step; l2norm forward only)"""
+    return 512 < int(D) <= WIDE_MAX_DIM
 
 
 def l2norm_rows_bwd(x: torch.Tensor, g: torch.Tensor) -> torch.Tensor:
@@ -888,7 +897,7 @@ def stats_sqerr_supported(x: torch.Tensor, cosine=False) -> bool:
         return False
     xk, N, D, ldx = as_rows(x)
     es = xk.element_size()
-    return D % 4 == 0 and D <= 512 and xk.data_ptr() % (4 * es) == 0 and (ldx * es) % (4 * es) == 0
+    return D % 4 == 0 and D <= WIDE_MAX_DIM and xk.data_ptr() % (4 * es) == 0 and (ldx * es) % (4 * es) == 0
 
 
 @_on_device

@@ -120,8 +120,9 @@ class Codebook(nn.Module):
         vq_bridge: Optional[nn.Module] = None,
     ):
         super().__init__()
-        if not (1 <= dim <= 512):
-            raise NotImplementedError(f"codebook dim {dim}: the HIP path supports 1 <= dim <= 512")
+        if not (1 <= dim <= L.WIDE_MAX_DIM):
+            raise NotImplementedError(f"codebook dim {dim}: the HIP path supports 1 <= dim <= {L.WIDE_MAX_DIM} (the tuned kernels up to 512, "
+                                      f"plain exact ones beyond: csrc/vq_wide.hip)")
 
         self.dim = dim
         self.codebook_size = codebook_size
@@ -474,7 +475,7 @@ class Codebook(nn.Module):
             e = E_all[h].contiguous()
             packed = packed_all[h] if packed_all is not None else L.pack_codebook(e)
             xh, xst, prenorm = xs[h], x_stats[h], input_normalized
-            if self.use_cosine_sim and not prenorm and not self.affine_param and L.screen_supported(xh, C):
+            if self.use_cosine_sim and not prenorm and not self.affine_param and (L.screen_supported(xh, C) or L.wide_dim(xh.shape[-1])):
                 # cosine through the screened search (csrc/vq_screen.hip), which takes unit-norm rows: normalise once with
                 # the arithmetic the exact kernel applies internally (vqp.py:37-38 at :1159), then search / sum those rows
                 xh = xst = L.l2norm_rows(xh)

@@ -126,6 +126,7 @@ __device__ float aten_sumsq_seq(F ld, int D)
 
 extern "C" size_t vqhip_packed_bytes(int C, int D)
 {
+    if (C > 0 && vq_is_wide(D)) return vq_wide_packed_bytes(C, D);     // y2 || bf16 copy (vq_wide.hip)
     const int DT = pick_dt(D);
     if (DT == 0 || C <= 0) return 0;
     return vq_packed_total_bytes(C, D);   // layout: vqhip_internal.h
@@ -271,8 +272,9 @@ __global__ void __launch_bounds__(256) vq_pack16_kernel(const float *embed, int 
 static int pack_codebook_impl(const float *embed, int C, int D, float *packed, int scalars_zeroed, void *stream, int H = 1)
 {
     if (!embed || !packed || C <= 0 || H < 1) VQ_FAIL(VQHIP_EINVAL, "pack_codebook: null pointer, C <= 0 or H < 1");
+    if (vq_is_wide(D)) return vq_wide_pack(embed, C, D, packed, H, stream);
     const int DT = pick_dt(D);
-    if (D < 1 || DT == 0) VQ_FAIL(VQHIP_EDIM, "pack_codebook: D=%d unsupported (1..512)", D);
+    if (D < 1 || DT == 0) VQ_FAIL(VQHIP_EDIM, "pack_codebook: D=%d unsupported (1..%d)", D, VQ_WIDE_MAX_D);
     if (((uintptr_t)packed) & 15) VQ_FAIL(VQHIP_EALIGN, "pack_codebook: packed must be 16-byte aligned");
     const int tiles = (C + 31) / 32;
     char *base = (char *)packed;
@@ -1284,8 +1286,10 @@ extern "C" int vqhip_assign_rowwise(const float *x, int64_t N, int D, int64_t ld
 extern "C" int vqhip_row_sumsq(const void *x, int x_dtype, int64_t N, int D, int64_t ldx, float *out, void *stream)
 {
     if (!x || !out || N < 0) VQ_FAIL(VQHIP_EINVAL, "row_sumsq: bad argument");
-    if (D < 1 || D > 512) VQ_FAIL(VQHIP_EDIM, "row_sumsq: D=%d unsupported (1..512)", D);
+    if (D < 1 || D > VQ_WIDE_MAX_D) VQ_FAIL(VQHIP_EDIM, "row_sumsq: D=%d unsupported (1..%d)", D, VQ_WIDE_MAX_D);
     if (N == 0) return 0;
+    if (x_dtype != VQHIP_BF16 && x_dtype != VQHIP_F32) VQ_FAIL(VQHIP_EINVAL, "row_sumsq: unknown dtype %d", x_dtype);
+    if (vq_is_wide(D)) return vq_wide_row_sumsq(x, x_dtype, N, D, ldx, out, stream);
     const unsigned blocks = (unsigned)((N + 255) / 256);
     if (x_dtype == VQHIP_BF16)
         hipLaunchKernelGGL(vq_row_sumsq_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, N, D, ldx, out);
@@ -1359,9 +1363,15 @@ static int assign_impl(const void *x, int x_dtype, int64_t N, int D, int64_t ldx
     if (q_out && q_dtype != VQHIP_F32 && q_dtype != VQHIP_BF16) VQ_FAIL(VQHIP_EINVAL, "assign: unknown q dtype %d", q_dtype);
     if (metric < 0 || metric > 2) VQ_FAIL(VQHIP_EINVAL, "assign: unknown metric %d", metric);
     const int DT = pick_dt(D);
-    if (D < 1 || DT == 0) VQ_FAIL(VQHIP_EDIM, "assign: D=%d unsupported (1..512)", D);
+    if (D < 1 || (DT == 0 && !vq_is_wide(D))) VQ_FAIL(VQHIP_EDIM, "assign: D=%d unsupported (1..%d)", D, VQ_WIDE_MAX_D);
     if (ldx < D || (q_out && ldq < D)) VQ_FAIL(VQHIP_EINVAL, "assign: row stride smaller than D");
     if (((uintptr_t)packed) & 15) VQ_FAIL(VQHIP_EALIGN, "assign: packed must be 16-byte aligned");
+    if (vq_is_wide(D)) {        // 512 < D <= 2048: the plain exact kernel of vq_wide.hip (index / q / score / norm / squared-error outputs)
+        if (scores_out || lse_out || heads > 1)
+            VQ_FAIL(VQHIP_EDIM, "assign: D=%d: score rows, the streaming log-sum-exp and batched heads stop at D = 512", D);
+        return vq_wide_assign(x, x_dtype, N, D, ldx, packed, embed, C, metric, idx_out, q_out, q_dtype, ldq, best_out, rnorm_out, sqerr_partial,
+                              row_mask, stream);
+    }
     if ((D & 31) && !rnorm_out) VQ_FAIL(VQHIP_EINVAL, "assign: D %% 32 != 0 needs rnorm_out (scratch for the exact ||x||^2 pre-pass)");
 
     hipStream_t st = (hipStream_t)stream;
@@ -1552,7 +1562,11 @@ extern "C" int vqhip_l2norm_rows(const void *x, int x_dtype, int64_t N, int D, i
     if (N == 0) return 0;
     if (!x || !out) VQ_FAIL(VQHIP_EINVAL, "l2norm_rows: null pointer");
     if (x_dtype != VQHIP_F32 && x_dtype != VQHIP_BF16) VQ_FAIL(VQHIP_EINVAL, "l2norm_rows: unknown dtype %d", x_dtype);
-    if (D != 32 && D != 64 && D != 128 && D != 256 && D != 512) VQ_FAIL(VQHIP_EDIM, "l2norm_rows: D=%d unsupported (32, 64, 128, 256, 512)", D);
+    if (vq_is_wide(D)) {
+        if (ldx < D || ldo < D) VQ_FAIL(VQHIP_EINVAL, "l2norm_rows: row stride smaller than D");
+        return vq_wide_l2norm_rows(x, x_dtype, N, D, ldx, out, ldo, stream);
+    }
+    if (D != 32 && D != 64 && D != 128 && D != 256 && D != 512) VQ_FAIL(VQHIP_EDIM, "l2norm_rows: D=%d unsupported (32, 64, 128, 256, 512, or 513..2048)", D);
     const int es = (x_dtype == VQHIP_BF16) ? 2 : 4;
     if (ldx < D || ldo < D) VQ_FAIL(VQHIP_EINVAL, "l2norm_rows: row stride smaller than D");
     if ((((uintptr_t)x) % (4 * es)) || ((ldx * es) % (4 * es)) || (((uintptr_t)out) % (4 * es)) || ((ldo * es) % (4 * es)))
@@ -2575,7 +2589,9 @@ static int route_launch(const RouteArgs &a, int dtype, bool bwd, hipStream_t st)
 #define VQ_ROUTE_LAUNCH(BF, BW) do { if (a.D <= 64) hipLaunchKernelGGL((vq_route_kernel<BF, BW, 4, 16>), grid16, dim3(256), 0, st, a); \
                                      else if (a.D <= 128) hipLaunchKernelGGL((vq_route_kernel<BF, BW, 8, 16>), grid16, dim3(256), 0, st, a); \
                                      else if (a.D <= 256) hipLaunchKernelGGL((vq_route_kernel<BF, BW, 16, 16>), grid16, dim3(256), 0, st, a); \
-                                     else hipLaunchKernelGGL((vq_route_kernel<BF, BW, 8, 64>), grid, dim3(256), 0, st, a); } while (0)
+                                     else if (a.D <= 512) hipLaunchKernelGGL((vq_route_kernel<BF, BW, 8, 64>), grid, dim3(256), 0, st, a); \
+                                     else if (a.D <= 1024) hipLaunchKernelGGL((vq_route_kernel<BF, BW, 16, 64>), grid, dim3(256), 0, st, a); \
+                                     else hipLaunchKernelGGL((vq_route_kernel<BF, BW, 32, 64>), grid, dim3(256), 0, st, a); } while (0)
     if (dtype == VQHIP_BF16) {
         if (bwd) VQ_ROUTE_LAUNCH(true, true); else VQ_ROUTE_LAUNCH(true, false);
     } else {
@@ -2589,7 +2605,7 @@ extern "C" int vqhip_route_fwd(const void *x, const void *q, int dtype, int64_t 
                                void *out, int64_t ldo, int mode, void *stream)
 {
     if (N < 0 || !x || !q || !out) VQ_FAIL(VQHIP_EINVAL, "route_fwd: bad argument");
-    if (D < 1 || D > 512) VQ_FAIL(VQHIP_EDIM, "route_fwd: D=%d unsupported (1..512)", D);
+    if (D < 1 || D > VQ_WIDE_MAX_D) VQ_FAIL(VQHIP_EDIM, "route_fwd: D=%d unsupported (1..%d)", D, VQ_WIDE_MAX_D);
     if (mode != 1 && mode != 2) VQ_FAIL(VQHIP_EINVAL, "route_fwd: mode must be 1 (straight-through) or 2 (rotation trick)");
     if (dtype != VQHIP_F32 && dtype != VQHIP_BF16) VQ_FAIL(VQHIP_EINVAL, "route_fwd: unknown dtype");
     RouteArgs a;
@@ -2611,7 +2627,7 @@ extern "C" int vqhip_route_residual(const void *x, int dtype, int64_t N, int D, 
 {
     if (!x || !codes || !idx || !out) VQ_FAIL(VQHIP_EINVAL, "route_residual: null pointer");
     if (dtype != VQHIP_F32 && dtype != VQHIP_BF16) VQ_FAIL(VQHIP_EINVAL, "route_residual: unknown dtype");
-    if (N < 0 || D < 1 || D > 512 || idx_stride < 1) VQ_FAIL(VQHIP_EINVAL, "route_residual: bad size");
+    if (N < 0 || D < 1 || D > VQ_WIDE_MAX_D || idx_stride < 1) VQ_FAIL(VQHIP_EINVAL, "route_residual: bad size");
     if (mode != 1 && mode != 2) VQ_FAIL(VQHIP_EINVAL, "route_residual: mode must be 1 (straight-through) or 2 (rotation trick)");
     RouteArgs a;
     a.x = x; a.q = codes; a.g = nullptr; a.out = out; a.N = N; a.D = D; a.ldx = ldx; a.ldq = D; a.ldg = 0; a.ldo = ldo;
@@ -2627,7 +2643,7 @@ extern "C" int vqhip_route_bwd(const void *x, const void *q, const void *g_out, 
 {
     if (masked_rows < 0 || masked_rows > 2) VQ_FAIL(VQHIP_EINVAL, "route_bwd: masked_rows must be 0, 1 or 2");
     if (N < 0 || !x || !q || !grad_x) VQ_FAIL(VQHIP_EINVAL, "route_bwd: bad argument");
-    if (D < 1 || D > 512) VQ_FAIL(VQHIP_EDIM, "route_bwd: D=%d unsupported (1..512)", D);
+    if (D < 1 || D > VQ_WIDE_MAX_D) VQ_FAIL(VQHIP_EDIM, "route_bwd: D=%d unsupported (1..%d)", D, VQ_WIDE_MAX_D);
     if (mode < 0 || mode > 2) VQ_FAIL(VQHIP_EINVAL, "route_bwd: mode must be 0 (loss only), 1 or 2");
     if (dtype != VQHIP_F32 && dtype != VQHIP_BF16) VQ_FAIL(VQHIP_EINVAL, "route_bwd: unknown dtype");
     RouteArgs a;
@@ -2647,7 +2663,7 @@ extern "C" int vqhip_route_fwd_gather(const void *x, const void *codes, const in
 {
     if (!x || !codes || !idx || !out) VQ_FAIL(VQHIP_EINVAL, "route_fwd_gather: null pointer");
     if (dtype != VQHIP_F32 && dtype != VQHIP_BF16) VQ_FAIL(VQHIP_EINVAL, "route_fwd_gather: unknown dtype");
-    if (N < 0 || D < 1 || D > 512 || idx_stride < 1) VQ_FAIL(VQHIP_EINVAL, "route_fwd_gather: bad size");
+    if (N < 0 || D < 1 || D > VQ_WIDE_MAX_D || idx_stride < 1) VQ_FAIL(VQHIP_EINVAL, "route_fwd_gather: bad size");
     if (mode != 1 && mode != 2) VQ_FAIL(VQHIP_EINVAL, "route_fwd_gather: mode must be 1 (straight-through) or 2 (rotation trick)");
     RouteArgs a;
     a.x = x; a.q = codes; a.g = nullptr; a.out = out; a.N = N; a.D = D; a.ldx = ldx; a.ldq = D; a.ldg = 0; a.ldo = ldo;
@@ -2664,7 +2680,7 @@ extern "C" int vqhip_route_bwd_gather(const void *x, const void *codes, const in
     if (masked_rows < 0 || masked_rows > 2) VQ_FAIL(VQHIP_EINVAL, "route_bwd_gather: masked_rows must be 0, 1 or 2");
     if (!x || !codes || !idx || !grad_x) VQ_FAIL(VQHIP_EINVAL, "route_bwd_gather: null pointer");
     if (dtype != VQHIP_F32 && dtype != VQHIP_BF16) VQ_FAIL(VQHIP_EINVAL, "route_bwd_gather: unknown dtype");
-    if (N < 0 || D < 1 || D > 512 || idx_stride < 1) VQ_FAIL(VQHIP_EINVAL, "route_bwd_gather: bad size");
+    if (N < 0 || D < 1 || D > VQ_WIDE_MAX_D || idx_stride < 1) VQ_FAIL(VQHIP_EINVAL, "route_bwd_gather: bad size");
     if (mode < 0 || mode > 2) VQ_FAIL(VQHIP_EINVAL, "route_bwd_gather: mode must be 0, 1 or 2");
     RouteArgs a;
     a.x = x; a.q = codes; a.g = (mode == 0) ? nullptr : g_out; a.out = grad_x; a.N = N; a.D = D; a.ldx = ldx; a.ldq = D;
@@ -3416,7 +3432,7 @@ static int ema_accumulate_impl(const void *x, int x_dtype, int64_t N, int D, int
         return 0;
     }
     if (!x || !idx || !count || !embed_sum || !workspace) VQ_FAIL(VQHIP_EINVAL, "ema_accumulate: null pointer");
-    if (D > 512) VQ_FAIL(VQHIP_EDIM, "ema_accumulate: D=%d unsupported (1..512)", D);
+    if (D > VQ_WIDE_MAX_D) VQ_FAIL(VQHIP_EDIM, "ema_accumulate: D=%d unsupported (1..%d)", D, VQ_WIDE_MAX_D);
     if (N >= ((int64_t)1 << 31)) VQ_FAIL(VQHIP_EINVAL, "ema_accumulate: N must be < 2^31");
     if (metric == VQHIP_COSINE && !rnorm) VQ_FAIL(VQHIP_EINVAL, "ema_accumulate: cosine needs rnorm");
     if (x_dtype != VQHIP_F32 && x_dtype != VQHIP_BF16) VQ_FAIL(VQHIP_EINVAL, "ema_accumulate: unknown dtype");
@@ -3471,10 +3487,12 @@ static int ema_accumulate_impl(const void *x, int x_dtype, int64_t N, int D, int
     const int es = (x_dtype == VQHIP_BF16) ? 2 : 4;
     const bool vec = (D % 4 == 0) && (((uintptr_t)x) % (4 * es) == 0) && ((ldx * es) % (4 * es) == 0);
     const bool bf = (x_dtype == VQHIP_BF16);
-    if (sqerr_partial && !(vec && D <= 512 && !g.cosine && qsrc && ((uintptr_t)qsrc) % (4 * es) == 0))
-        VQ_FAIL(VQHIP_EINVAL, "ema_accumulate_sqerr: needs the Euclidean metric, D %% 4 == 0, D <= 512 and 16-byte aligned rows");
+    if (sqerr_partial && !(vec && D <= VQ_WIDE_MAX_D && !g.cosine && qsrc && ((uintptr_t)qsrc) % (4 * es) == 0))
+        VQ_FAIL(VQHIP_EINVAL, "ema_accumulate_sqerr: needs the Euclidean metric, D %% 4 == 0, D <= 2048 and 16-byte aligned rows");
+    if (D > 512 && !(vec && !g.cosine))
+        VQ_FAIL(VQHIP_EDIM, "ema_accumulate: D=%d > 512 needs D %% 4 == 0, rows aligned to 4 elements and Euclidean / unit-norm rows", D);
 #ifndef VQ_SEG_SLOW
-    if (vec && D <= 512 && !g.cosine) {
+    if (vec && D <= VQ_WIDE_MAX_D && !g.cosine) {
         if (sqerr_partial) {
             if (bf) hipLaunchKernelGGL((vq_segsum_fast_kernel<true, true>), dim3(seg_blocks, nh), dim3(256), 0, st, g);
             else hipLaunchKernelGGL((vq_segsum_fast_kernel<false, true>), dim3(seg_blocks, nh), dim3(256), 0, st, g);
@@ -3509,7 +3527,7 @@ extern "C" int vqhip_ema_accumulate_sqerr(const void *x, int x_dtype, int64_t N,
                                           const float *packed, const float *embed, double *sqerr_partial, void *stream)
 {
     if (!sqerr_partial || !packed || !embed) VQ_FAIL(VQHIP_EINVAL, "ema_accumulate_sqerr: null pointer");
-    if (D < 1 || D > 512 || C <= 0) VQ_FAIL(VQHIP_EINVAL, "ema_accumulate_sqerr: bad size");
+    if (D < 1 || D > VQ_WIDE_MAX_D || C <= 0) VQ_FAIL(VQHIP_EINVAL, "ema_accumulate_sqerr: bad size");
     // the loss' q rows: what the search writes for this dtype -- fp32 rows: embed; bf16 rows: the packed codebook's bf16 copy
     const void *qsrc = (x_dtype == VQHIP_BF16) ? (const void *)((const char *)packed + vq_packed_bf16_offset(C, D)) : (const void *)embed;
     return ema_accumulate_impl(x, x_dtype, N, D, ldx, idx, idx_stride, nullptr, VQHIP_EUCLID, row_mask, C, count, embed_sum, workspace,
@@ -3524,7 +3542,7 @@ extern "C" int vqhip_ema_accumulate_prezeroed(const void *x, int x_dtype, int64_
                                               float *count, float *embed_sum, void *workspace, size_t workspace_bytes,
                                               const float *packed, const float *embed, double *sqerr_partial, void *stream)
 {
-    if (D < 1 || D > 512 || C <= 0) VQ_FAIL(VQHIP_EINVAL, "ema_accumulate_prezeroed: bad size");
+    if (D < 1 || D > VQ_WIDE_MAX_D || C <= 0) VQ_FAIL(VQHIP_EINVAL, "ema_accumulate_prezeroed: bad size");
     if (sqerr_partial && (!packed || !embed)) VQ_FAIL(VQHIP_EINVAL, "ema_accumulate_prezeroed: the loss needs packed and embed");
     const void *qsrc = !sqerr_partial ? nullptr
                      : (x_dtype == VQHIP_BF16) ? (const void *)((const char *)packed + vq_packed_bf16_offset(C, D)) : (const void *)embed;
@@ -3708,7 +3726,7 @@ extern "C" int vqhip_ema_finalize(float *cluster_size, float *embed_avg, float *
                                   int do_lerp, int do_update_ema, float *denom_ws, void *stream)
 {
     if (!cluster_size || !embed_avg || !embed || C <= 0) VQ_FAIL(VQHIP_EINVAL, "ema_finalize: null pointer or C <= 0");
-    if (D < 1 || D > 512) VQ_FAIL(VQHIP_EDIM, "ema_finalize: D=%d unsupported (1..512)", D);
+    if (D < 1 || D > VQ_WIDE_MAX_D) VQ_FAIL(VQHIP_EDIM, "ema_finalize: D=%d unsupported (1..%d)", D, VQ_WIDE_MAX_D);
     if (do_lerp && (!count || !embed_sum)) VQ_FAIL(VQHIP_EINVAL, "ema_finalize: do_lerp needs count and embed_sum");
     if (do_update_ema && !denom_ws) VQ_FAIL(VQHIP_EINVAL, "ema_finalize: do_update_ema needs denom_ws");
     hipStream_t st = (hipStream_t)stream;
@@ -3717,6 +3735,10 @@ extern "C" int vqhip_ema_finalize(float *cluster_size, float *embed_avg, float *
     if (do_update_ema) {
         const float ceps = (float)((double)C * (double)eps);
         hipLaunchKernelGGL(vq_ema_denom_kernel, dim3(1), dim3(256), (C <= 16384 ? (size_t)C * 4 : 0), st, cluster_size, C, eps, ceps, denom_ws);
+    }
+    if (vq_is_wide(D)) {
+        if (!(do_lerp || do_update_ema)) return launch_status("vq_ema_finalize");
+        return vq_wide_ema_embed(embed_avg, embed, embed_sum, weight, denom_ws, 1, C, D, one_minus_decay, cosine, do_lerp, do_update_ema, 0, stream);
     }
     if (do_lerp || do_update_ema)
         hipLaunchKernelGGL(vq_ema_embed_kernel, dim3((C + 3) / 4), dim3(256), 0, st, embed_avg, embed, embed_sum, weight,
@@ -3941,31 +3963,20 @@ __global__ void __launch_bounds__(256) vq_expire_pick_kernel(float *__restrict__
         }
         if (v < (unsigned long long)n) pick = v;          // (64 walks without landing in [0, n) -- domain < 4 n, probability 4^-64: keep the affine pick)
     }
-    float v[8];
-    float ss = 0.f;
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-        const int k = lane + 64 * q;
-        v[q] = 0.f;
-        if (k < D) {
-            v[q] = bf16 ? bf16_bits_to_f32(((const unsigned short *)rows)[pick * ldx + k]) : ((const float *)rows)[pick * ldx + k];
-            ss += v[q] * v[q];
-        }
-    }
+    auto ld = [&](int k) { return bf16 ? bf16_bits_to_f32(((const unsigned short *)rows)[pick * ldx + k]) : ((const float *)rows)[pick * ldx + k]; };
     float inv = 1.f;
     if (cosine) {                                                           // l2norm of the sampled rows (vqp.py:545-546, 37-38)
+        float ss = 0.f;
+        for (int k = lane; k < D; k += 64) { const float v = ld(k); ss += v * v; }     // (lane l: elements l, l + 64, ... as before)
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) ss += __shfl_xor(ss, o, 64);
         inv = fmaxf(sqrtf(ss), 1e-6f);
     }
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-        const int k = lane + 64 * q;
-        if (k < D) {
-            const float e = cosine ? v[q] / inv : v[q];
-            embed[(size_t)c * D + k] = e;
-            embed_avg[(size_t)c * D + k] = e * reset;
-        }
+    for (int k = lane; k < D; k += 64) {                                    // any D (the row is re-read: at most 8 KiB)
+        const float v = ld(k);
+        const float e = cosine ? v / inv : v;
+        embed[(size_t)c * D + k] = e;
+        embed_avg[(size_t)c * D + k] = e * reset;
     }
     if (lane == 0) cluster_size[c] = reset;
 }
@@ -3974,7 +3985,7 @@ extern "C" int vqhip_expire_pick(float *cluster_size, float *embed_avg, float *e
                                  const int64_t *ab, int64_t p, int C, int D, float threshold, float reset, int cosine, void *stream)
 {
     if (!cluster_size || !embed_avg || !embed || !rows || !ab || C <= 0) VQ_FAIL(VQHIP_EINVAL, "expire_pick: bad argument");
-    if (D < 1 || D > 512) VQ_FAIL(VQHIP_EDIM, "expire_pick: D=%d unsupported (1..512)", D);
+    if (D < 1 || D > VQ_WIDE_MAX_D) VQ_FAIL(VQHIP_EDIM, "expire_pick: D=%d unsupported (1..%d)", D, VQ_WIDE_MAX_D);
     if (x_dtype != VQHIP_F32 && x_dtype != VQHIP_BF16) VQ_FAIL(VQHIP_EINVAL, "expire_pick: unknown dtype");
     if (n < 1 || p < n || p < 2 || p > 0x7fffffffLL || ldx < D) VQ_FAIL(VQHIP_EINVAL, "expire_pick: need 1 <= n <= p < 2^31 (p prime), ldx >= D");
     hipLaunchKernelGGL(vq_expire_pick_kernel, dim3((unsigned)((C + 3) / 4)), dim3(256), 0, (hipStream_t)stream, cluster_size, embed_avg, embed, rows,
@@ -4194,8 +4205,9 @@ extern "C" int vqhip_decode_sum(const int64_t *idx, int64_t N, int Q, const floa
     if (N < 0 || Q < 1 || C <= 0) VQ_FAIL(VQHIP_EINVAL, "decode_sum: bad size");
     if (N == 0) return 0;
     if (!idx || !embed || !out) VQ_FAIL(VQHIP_EINVAL, "decode_sum: null pointer");
-    if (D < 1 || D > 512) VQ_FAIL(VQHIP_EDIM, "decode_sum: D=%d unsupported (1..512)", D);
+    if (D < 1 || D > VQ_WIDE_MAX_D) VQ_FAIL(VQHIP_EDIM, "decode_sum: D=%d unsupported (1..%d)", D, VQ_WIDE_MAX_D);
     if (out_dtype != VQHIP_F32 && out_dtype != VQHIP_BF16) VQ_FAIL(VQHIP_EINVAL, "decode_sum: unknown dtype");
+    if (vq_is_wide(D)) return vq_wide_decode_sum(idx, N, Q, embed, embed_qstride, C, D, out, out_dtype, ldo, stream);
     const int oes = (out_dtype == VQHIP_BF16) ? 2 : 4;
     const bool vec = (D % 4 == 0) && (embed_qstride % 4 == 0) && ((((uintptr_t)embed) & 15) == 0) &&
                      ((((uintptr_t)out) % (4 * oes)) == 0) && ((ldo * oes) % (4 * oes) == 0);

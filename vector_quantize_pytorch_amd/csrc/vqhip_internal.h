@@ -82,6 +82,7 @@ static inline size_t vq_tiles16(int C)
 }
 static inline size_t vq_packed_bf16_offset(int C, int D)
 {
+    if (D > 512) return ((size_t)C * 4 + 255) / 256 * 256;      // wide dims (vq_wide.hip): y2 [C] floats, 256-byte padded, then the bf16 copy
     const size_t tiles = ((size_t)C + 31) / 32;
     return tiles * vq_tile_bytes(vq_pick_dt(D)) + 4096;
 }
@@ -120,3 +121,18 @@ int vq_assign_screened_impl(const void *x, int x_dtype, int64_t N, int D, int64_
                             void *resid_out, int64_t ldr, double *sqerr_partial, const uint8_t *row_mask,
                             void *workspace, size_t workspace_bytes, float *debug_out, const vqhip_chain_t *chain,
                             int header_zeroed, void *stream, const VqHeadStrides *hs = nullptr);
+
+// ---- codebook dims 512 < D <= 2048 (vq_wide.hip): plain exact kernels behind the same entry points --------------------------------
+#define VQ_WIDE_MAX_D 2048
+static inline bool vq_is_wide(int D) { return D > 512 && D <= VQ_WIDE_MAX_D; }
+size_t vq_wide_packed_bytes(int C, int D);
+int vq_wide_pack(const float *embed, int C, int D, float *packed, int H, void *stream);
+int vq_wide_row_sumsq(const void *x, int x_dtype, int64_t N, int D, int64_t ldx, float *out, void *stream);
+int vq_wide_l2norm_rows(const void *x, int x_dtype, int64_t N, int D, int64_t ldx, void *out, int64_t ldo, void *stream);
+int vq_wide_assign(const void *x, int x_dtype, int64_t N, int D, int64_t ldx, const float *packed, const float *embed, int C, int metric,
+                   int64_t *idx_out, void *q_out, int q_dtype, int64_t ldq, float *best_out, float *rnorm_out, double *sqerr_partial,
+                   const uint8_t *row_mask, void *stream);
+int vq_wide_ema_embed(float *embed_avg, float *embed, const float *embed_sum, const float *weight, const float *denom, int H, int C, int D,
+                      float omd, int cosine, int do_lerp, int do_update, int64_t hs_sum, void *stream);
+int vq_wide_decode_sum(const int64_t *idx, int64_t N, int Q, const float *embed, int64_t qstride, int C, int D, void *out, int out_dtype,
+                       int64_t ldo, void *stream);

@@ -278,6 +278,8 @@ class ResidualVQ(nn.Module):
             return False
         if self.codebook_dim % 32 != 0 or x.ndim != 3 or x.dtype not in (torch.float32, torch.bfloat16):
             return False
+        if self.codebook_dim > 512:          # (wide dims, csrc/vq_wide.hip: the layers one by one)
+            return False
         if self.quant_grad_frac > 0:
             return False
         # The fused loop searches the stored `embed` with a plain argmin under no_grad: only plain EMA / frozen codebooks

@@ -386,6 +386,8 @@ class VectorQuantize(nn.Module):
 
         if affine_param:
             assert not use_cosine_sim, 'affine param is only compatible with euclidean codebook'
+        dense_options = (commitment_use_cross_entropy_loss or codebook_diversity_loss_weight > 0. or stochastic_sample_codes
+                         or straight_through)
         # (round 5: several heads -- one shared codebook on [(b h), n, d] rows or one codebook per head, vqp.py:1044-1049 -- combine with
         #  the options that read whole score rows, with affine_param and with learnable codebooks like the reference's einsums do;
         #  forward(topk=) with heads > 1 fails in the reference itself and raises here)
