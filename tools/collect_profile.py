@@ -45,7 +45,7 @@ def main():
         shutil.copy(f[0], os.path.join(out, "kernel_stats.csv"))
 
     summary = {}
-    for i, ctrs in enumerate(PMC_PASSES):
+    for i, ctrs in enumerate([] if os.environ.get("COLLECT_NO_PMC") == "1" else PMC_PASSES):     # (COLLECT_NO_PMC=1: stats + step traffic only)
         d = os.path.join(out, f"pmc{i}")
         p = run(["rocprofv3", "--kernel-trace", "--pmc"] + ctrs + ["--output-format", "csv", "-d", d, "-o", "p", "--"] + bench,
                 env=env, cwd="/tmp")
