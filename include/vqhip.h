@@ -162,6 +162,45 @@ int vqhip_assign_screened_chain(const void *x, int x_dtype, int64_t N, int D, in
                                 const float *embed, int C, int metric, int64_t *idx_out, const uint8_t *row_mask,
                                 void *workspace, size_t workspace_bytes, const vqhip_chain_t *chain, void *stream);
 
+/* ---- the residual loop as one call (round 5) --------------------------------------------------------
+ * Everything ResidualVQ.forward's loop (residual_vq.py:469-568) launches between packing the codebooks and decoding the sum, issued from C:
+ * the Q chained screened searches (vqhip_assign_screened_chain: stage q forms x_prev - code in its prologue, residual_vq.py:524), for a
+ * training step whose input requires grad the routed residuals instead (vqhip_route_residual, vqp.py:1225-1233), and -- when `stats` is
+ * given -- every stage's EMA statistics + commitment-loss partials (vqhip_ema_accumulate_prezeroed, vqp.py:599-606, 1327).  The rows may
+ * be split into `chunks` contiguous row chunks of vqhip_rvq_chain_chunk_rows(N, chunks) rows, each running its own chain on its own
+ * stream (chunk 0 on `stream`), so that one chunk's short exact passes run beside another chunk's screening kernel; stage q's statistics
+ * are queued on stats_stream once stage q is final in every chunk.  The caller owns streams, events (re-recorded by every call; the
+ * library creates nothing) and buffers.  On return `stream` has been joined with the chunk streams; stats_stream has NOT (join it
+ * before reading `stats`).  Results are those of the per-stage entry points, bit for bit (indices) / to the rounding of the segmented
+ * sums' atomics (statistics).
+ *   inputs      [Q - 1, N, D] in x's dtype, contiguous: receives the inputs of stages 1 .. Q - 1 (stage 0's is x)
+ *   workspace   Q x K slices of vqhip_rvq_chain_ws_stride(N, chunks) bytes (K = the number of chunks actually formed), 256-byte
+ *               aligned; slice (q, k) starts with that search's counters ([0] rows of the exact sweep, [1] rows decided between two codes)
+ *   route_mode  0: `quantized` is the code row; 1 / 2: the straight-through / rotation-trick value (codes: the code rows in x's dtype,
+ *               [C, D] per stage at codes_qstride elements, 0 = shared)
+ *   stats       nullable [Q, stats_stride] floats = embed_sum [C, D] || count [C] per stage, ZEROED by the caller; stats_ws: Q slices
+ *               of stats_ws_stride >= vqhip_ema_batched_ws_stride(N, C) bytes whose first C ints the caller zeroed; sqerr_partial
+ *               nullable [Q, sqerr_stride >= vqhip_ema_sqerr_partials(N, C)]
+ *   events      at least Q x chunks + 1 hipEvent_t when chunks > 1 or stats_stream differs from `stream` */
+typedef struct {
+    const void *x; int64_t x_dtype; int64_t N; int64_t D; int64_t ldx;
+    const float *packed; int64_t packed_qstride;          /* floats between the stages' packed codebooks (0: one shared codebook) */
+    const float *embed; int64_t embed_qstride;            /* floats between the stages' codebooks [C, D] (0: shared, residual_vq.py:302-306) */
+    int64_t C; int64_t Q;
+    int64_t *idx_out;                                     /* [N, Q] */
+    void *inputs;
+    const uint8_t *row_mask;                              /* nullable [N] */
+    void *workspace; size_t workspace_bytes;
+    int64_t route_mode; const void *codes; int64_t codes_qstride;
+    float *stats; int64_t stats_stride; void *stats_ws; size_t stats_ws_stride; double *sqerr_partial; int64_t sqerr_stride;
+    int64_t chunks; void **chunk_streams;                 /* chunks - 1 streams */
+    void *stats_stream;                                   /* nullable / == stream: the statistics follow the loop on `stream` */
+    void **events; int64_t n_events;
+} vqhip_rvq_chain_t;
+int64_t vqhip_rvq_chain_chunk_rows(int64_t N, int chunks);
+size_t vqhip_rvq_chain_ws_stride(int64_t N, int chunks);
+int vqhip_rvq_chain_forward(const vqhip_rvq_chain_t *c, void *stream);
+
 /* ---- dense scores (rare options only) ------------------------------------------------------------
  * Materialises the tensor the reference calls `dist` (vqp.py:741-743): scores_out[n, c] = -cdist(x_n, c) for the
  * Euclidean metric (same rounding sequence as vqhip_assign), x^_n . c for cosine.  Needed by the options that read

@@ -1525,6 +1525,44 @@ def test_residual_chain_in_row_chunks_equals_one_chain(dev, monkeypatch, grad):
             m.load_state_dict(mods[0].state_dict())
 
 
+@pytest.mark.parametrize("kw,dtype", [(dict(dim=64, num_quantizers=4, codebook_size=256, shared_codebook=True), torch.float32),
+                                      (dict(dim=128, num_quantizers=3, codebook_size=300), torch.float32),
+                                      (dict(dim=256, num_quantizers=3, codebook_size=128, commitment_weight=0.5), torch.bfloat16)])
+def test_residual_chain_as_one_library_call_equals_the_python_loop(dev, monkeypatch, kw, dtype):
+    """Round 5: vqhip_rvq_chain_forward (searches, routed residuals and per-stage statistics of the whole loop issued from C, in row
+    chunks, statistics on their own stream) against the same launches issued from Python (VQHIP_RVQ_NATIVE=0): indices, outputs and
+    input gradients identical, losses / codebooks to the rounding of the segmented sums' atomics; no-grad steps (fp32 rows: the
+    chain prologue), gradient steps (routed residuals; bf16 rows only there), masks, eval, 1 and 3 chunks."""
+    from vector_quantize_pytorch_amd import ResidualVQ
+    torch.manual_seed(0)
+    a, b = ResidualVQ(**kw).to(dev).train(), ResidualVQ(**kw).to(dev).train()
+    b.load_state_dict(a.state_dict())
+    N = 3 * 65536 + 300
+    for step in range(4):
+        if step == 3:
+            a.eval(); b.eval()
+        grad = step in (1, 2) or (dtype == torch.bfloat16 and step == 0)
+        monkeypatch.setenv("VQHIP_RVQ_CHUNKS", "3" if step % 2 == 0 else "1")
+        x = (torch.randn(1, N, kw["dim"], device=dev) * (1.0 + step)).to(dtype)
+        mask = (torch.rand(1, N, device=dev) > 0.2) if step == 2 else None
+        outs = []
+        for m, nat in ((a, "1"), (b, "0")):
+            monkeypatch.setenv("VQHIP_RVQ_NATIVE", nat)
+            xi = x.clone().requires_grad_(grad and m.training)
+            with torch.set_grad_enabled(grad and m.training):
+                q, i, l = m(xi, mask=mask)
+            if xi.requires_grad:
+                (q.float().square().sum() + l.sum()).backward()
+            outs.append((q.detach(), i, l.detach(), xi.grad))
+        torch.cuda.synchronize()
+        (qa, ia, la, ga), (qb, ib, lb, gb) = outs
+        assert torch.equal(ia, ib) and torch.equal(qa, qb)
+        assert torch.allclose(la, lb, rtol=1e-5 if dtype == torch.float32 else 1e-2, atol=1e-12)
+        assert (ga is None) == (gb is None) and (ga is None or torch.equal(ga, gb))
+        _close(a.codebooks, b.codebooks, 5e-5, "codebooks")
+        b.load_state_dict(a.state_dict())
+
+
 def _route64(r, c, mode):
     """float64 restatement of what a layer returns for an input that requires grad (vqp.py:282-318): 1 straight-through, 2 rotation"""
     if mode == 1:

@@ -780,3 +780,52 @@ def test_pack_unpack_best_equals_the_key_algebra(dev, negate):
     assert torch.equal(best.cpu().view(torch.int32), (-s2 if negate else s2).view(torch.int32))
     mine = (i2 >= lo) & (i2 < hi)
     assert torch.equal(local.cpu(), torch.where(mine, i2 - lo, torch.full_like(i2, -1)))
+
+
+def test_routed_residuals_are_deterministic_beside_concurrent_searches(dev):
+    """Round 5 finding (csrc/Makefile, tools/route_concurrency_check.py): built with the SLP vectoriser, the routing kernels' packed
+    fp32 operations gave a wrong first element in lanes 48..63 of a wave about once per 270 launches WHEN another kernel's MFMA waves
+    ran on the same SIMD (never alone on the chip) -- one near-tie row of a gradient step continuing with the other code.  Here:
+    vqhip_route_residual (rotation trick) on three streams, each followed by a screened search as in the stages of a routed residual
+    loop (rvq.py:524 with vqp.py:1225-1233), 100 rounds: every output bit-identical to the launch that ran alone."""
+    import ctypes
+    from vector_quantize_pytorch_amd import _lib as L
+    g = torch.Generator(device=dev).manual_seed(0)
+    D, C, N, rpc = 64, 256, 3 * 65536 + 300, 65792
+    x = torch.randn(N, D, device=dev, generator=g) * 3
+    e = torch.randn(C, D, device=dev, generator=g)
+    pk = L.pack_codebook(e)
+    idx0 = L.assign(x, pk, e, want_q=False)["idx"].clone()
+    lib = L.lib()
+    nws = lib.vqhip_screen_workspace_bytes(rpc)
+
+    def route(out, r0, n):
+        L._check(lib.vqhip_route_residual(ctypes.c_void_p(x.data_ptr() + r0 * D * 4), 0, n, D, D, L._ptr(e), ctypes.c_void_p(idx0.data_ptr() + r0 * 8),
+                                          1, 2, ctypes.c_void_p(out.data_ptr() + r0 * D * 4), D, L._stream()), "route")
+
+    def search(out, idx1, ws, r0, n):
+        ch = L._Chain(idx_stride=1, prev_idx=None, prev_idx_stride=1, prev_embed=None, x_out=None, ldxo=D, route_mode=0, header_zeroed=0)
+        L._check(lib.vqhip_assign_screened_chain(ctypes.c_void_p(out.data_ptr() + r0 * D * 4), 0, n, D, D, L._ptr(pk), L._ptr(e), C, 0,
+                                                 ctypes.c_void_p(idx1.data_ptr() + r0 * 8), None, L._ptr(ws), nws, ctypes.byref(ch), L._stream()), "search")
+
+    ref = torch.empty_like(x)
+    route(ref, 0, N)
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream() for _ in range(3)]
+    wss = [torch.zeros((nws + 15) // 16 * 4, dtype=torch.int32, device=dev) for _ in range(3)]
+    outs = [torch.empty_like(x) for _ in range(4)]
+    idx1 = torch.empty(N, dtype=torch.int64, device=dev)
+    wrong = 0
+    for _ in range(100):
+        for o in outs:
+            o.fill_(float("nan"))
+        torch.cuda.synchronize()
+        for o in outs:
+            for k, s in enumerate(streams):
+                with torch.cuda.stream(s):
+                    route(o, k * rpc, min(rpc, N - k * rpc))
+                    search(o, idx1, wss[k], k * rpc, min(rpc, N - k * rpc))
+        torch.cuda.synchronize()
+        wrong += sum(int(not torch.equal(o, ref)) for o in outs)
+    assert wrong == 0, f"{wrong} of 400 routed-residual launches differ from the launch that ran alone"
+

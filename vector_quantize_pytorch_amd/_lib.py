@@ -141,6 +141,12 @@ def lib():
     L.vqhip_vq_step_supported.restype = i32
     L.vqhip_vq_step_workspace_bytes.argtypes = [i64, i32]
     L.vqhip_vq_step_workspace_bytes.restype = ctypes.c_size_t
+    L.vqhip_rvq_chain_chunk_rows.argtypes = [i64, i32]
+    L.vqhip_rvq_chain_chunk_rows.restype = i64
+    L.vqhip_rvq_chain_ws_stride.argtypes = [i64, i32]
+    L.vqhip_rvq_chain_ws_stride.restype = ctypes.c_size_t
+    L.vqhip_rvq_chain_forward.argtypes = [vp, vp]
+    L.vqhip_rvq_chain_forward.restype = i32
     L.vqhip_vq_step_chunk_rows.argtypes = [i64, i32]
     L.vqhip_vq_step_chunk_rows.restype = i64
     L.vqhip_vq_train_step.argtypes = [vp, vp]
@@ -160,7 +166,7 @@ EXPORTS = ("vqhip_version", "vqhip_last_error", "vqhip_packed_bytes", "vqhip_pac
            "vqhip_pack_codebook_batched", "vqhip_screen_batched_ws_stride", "vqhip_assign_screened_batched", "vqhip_assign_batched",
            "vqhip_route_fwd_gather", "vqhip_route_bwd_gather", "vqhip_ema_accumulate_prezeroed",
            "vqhip_ema_batched_ws_stride", "vqhip_ema_accumulate_batched", "vqhip_ema_finalize_batched",
-           "vqhip_ema_accumulate_stages")
+           "vqhip_ema_accumulate_stages", "vqhip_rvq_chain_chunk_rows", "vqhip_rvq_chain_ws_stride", "vqhip_rvq_chain_forward")
 
 
 def _check(rc, what):
@@ -657,6 +663,96 @@ def rvq_forward_chained(x: torch.Tensor, packed: torch.Tensor, embed: torch.Tens
     if row_mask is not None and fill_masked:
         mask_fill_indices(idx, row_mask)
     return dict(idx=idx, inputs=inputs, counts=counts, bufs=bufs)
+
+
+class _RvqChain(ctypes.Structure):       # vqhip_rvq_chain_t (include/vqhip.h)
+    _fields_ = [("x", ctypes.c_void_p), ("x_dtype", ctypes.c_int64), ("N", ctypes.c_int64), ("D", ctypes.c_int64), ("ldx", ctypes.c_int64),
+                ("packed", ctypes.c_void_p), ("packed_qstride", ctypes.c_int64), ("embed", ctypes.c_void_p), ("embed_qstride", ctypes.c_int64),
+                ("C", ctypes.c_int64), ("Q", ctypes.c_int64), ("idx_out", ctypes.c_void_p), ("inputs", ctypes.c_void_p),
+                ("row_mask", ctypes.c_void_p), ("workspace", ctypes.c_void_p), ("workspace_bytes", ctypes.c_size_t),
+                ("route_mode", ctypes.c_int64), ("codes", ctypes.c_void_p), ("codes_qstride", ctypes.c_int64),
+                ("stats", ctypes.c_void_p), ("stats_stride", ctypes.c_int64), ("stats_ws", ctypes.c_void_p), ("stats_ws_stride", ctypes.c_size_t),
+                ("sqerr_partial", ctypes.c_void_p), ("sqerr_stride", ctypes.c_int64),
+                ("chunks", ctypes.c_int64), ("chunk_streams", ctypes.c_void_p), ("stats_stream", ctypes.c_void_p),
+                ("events", ctypes.c_void_p), ("n_events", ctypes.c_int64)]
+
+
+_CHAIN_EVENTS = {}
+
+
+def _chain_events(device, main, n):
+    """n reusable events that pair with `main` (vqhip_rvq_chain_forward re-records them on every call); -> (events, array of handles)"""
+    key = (torch.device(device).index, main.cuda_stream)
+    evs = _CHAIN_EVENTS.setdefault(key, [])
+    while len(evs) < n:
+        e = torch.cuda.Event()
+        e.record(main)                       # (torch creates the hipEvent_t lazily, at the first record)
+        evs.append(e)
+    return evs[:n], (ctypes.c_void_p * n)(*[e.cuda_event for e in evs[:n]])
+
+
+@_on_device
+def rvq_chain_forward(x: torch.Tensor, packed: torch.Tensor, embed: torch.Tensor, Q: int, *, row_mask=None, route_mode=0, row_chunks=1,
+                      stats=None, stats_ws=None, sq_parts=None, stats_stream=None):
+    """The residual loop (rvq.py:469-568) in ONE library call (vqhip_rvq_chain_forward): the Q chained screened searches -- or, with
+    route_mode, the routed residuals + plain searches of a gradient step -- in row_chunks interleaved chunks, and every stage's EMA
+    statistics (+ loss partials into sq_parts [Q, P]) on stats_stream.  Same results as rvq_forward_chained with a stage hook that
+    calls ema_accumulate; the host enqueues one call instead of ~100 launches from Python.
+    stats [Q, stride] zeroed, stats_ws from ema_workspaces(Q, N, C) (histograms zeroed).  The statistics stream is NOT joined here.
+    -> dict(idx [..., Q], inputs (list of Q views), bufs [Q - 1, N, D], counts (per stage: per-chunk counters))"""
+    _need_gpu(x, packed, embed, row_mask, stats, stats_ws, sq_parts)
+    shared = embed.ndim == 2
+    xk, N, D, ldx = as_rows(x)
+    lead, dev = x.shape[:-1], x.device
+    C = embed.shape[-2]
+    assert embed.dtype == torch.float32 and embed.is_contiguous() and packed.is_contiguous()
+    assert xk.dtype == torch.float32 or (route_mode and xk.dtype == torch.bfloat16), "chained stages: float32 rows"
+    idx = torch.empty(N, Q, dtype=torch.int64, device=dev)
+    bufs = torch.empty(max(Q - 1, 1), N, D, dtype=xk.dtype, device=dev)
+    if row_mask is not None:
+        row_mask = row_mask.reshape(-1).to(torch.uint8).contiguous()
+    main = torch.cuda.current_stream(dev)
+    K = max(1, int(row_chunks))
+    rpc = lib().vqhip_rvq_chain_chunk_rows(N, K)
+    K = (N + rpc - 1) // rpc
+    wss = lib().vqhip_rvq_chain_ws_stride(N, K)
+    ws = torch.empty(Q * K, wss, dtype=torch.uint8, device=dev)
+    codes = None
+    if route_mode:
+        codes = embed if xk.dtype == torch.float32 else embed.to(xk.dtype)      # (bf16 rows: the routing kernel gathers bf16 code rows)
+    st = _RvqChain(x=xk.data_ptr(), x_dtype=_dtype_code(xk), N=N, D=D, ldx=ldx, packed=packed.data_ptr(),
+                   packed_qstride=0 if shared else packed.stride(0) * packed.element_size() // 4, embed=embed.data_ptr(),
+                   embed_qstride=0 if shared else embed.stride(0), C=C, Q=Q, idx_out=idx.data_ptr(), inputs=bufs.data_ptr(),
+                   row_mask=None if row_mask is None else row_mask.data_ptr(), workspace=ws.data_ptr(), workspace_bytes=ws.numel(),
+                   route_mode=int(route_mode), codes=None if codes is None else codes.data_ptr(),
+                   codes_qstride=0 if (codes is None or shared) else codes.stride(0), chunks=K)
+    keep = [codes]
+    if stats is not None:
+        assert stats.dtype == torch.float32 and stats.ndim == 2 and stats.shape[0] >= Q and stats.stride(1) == 1
+        assert stats_ws is not None and stats_ws.dtype == torch.uint8 and stats_ws.shape[0] >= Q and stats_ws.stride(1) == 1 and stats_ws.data_ptr() % 256 == 0
+        st.stats, st.stats_stride, st.stats_ws, st.stats_ws_stride = stats.data_ptr(), stats.stride(0), stats_ws.data_ptr(), stats_ws.stride(0)
+        if sq_parts is not None:
+            assert sq_parts.dtype == torch.float64 and sq_parts.shape[0] >= Q and sq_parts.stride(1) == 1
+            st.sqerr_partial, st.sqerr_stride = sq_parts.data_ptr(), sq_parts.stride(0)
+        if stats_stream is not None:
+            st.stats_stream = stats_stream.cuda_stream
+    side = stats is not None and stats_stream is not None and stats_stream.cuda_stream != main.cuda_stream
+    if K > 1 or side:
+        if K > 1:
+            cs = _chain_streams(dev, main, K - 1)
+            arr = (ctypes.c_void_p * (K - 1))(*[s_.cuda_stream for s_ in cs])
+            st.chunk_streams = ctypes.cast(arr, ctypes.c_void_p)
+            keep.append(arr)
+        evs, earr = _chain_events(dev, main, Q * K + 1)
+        st.events, st.n_events = ctypes.cast(earr, ctypes.c_void_p), Q * K + 1
+        keep += [evs, earr]
+    _check(lib().vqhip_rvq_chain_forward(ctypes.byref(st), _stream()), "vqhip_rvq_chain_forward")
+    wsi = ws.view(Q, K, wss)
+    counts = [(wsi[q, :, 0:4].view(torch.int32)[:, 0], wsi[q, :, 4:8].view(torch.int32)[:, 0]) for q in range(Q)]
+    inputs = [x] + [bufs[q].view(*lead, D) for q in range(Q - 1)]
+    # keepalive: the statistics stream is not joined here and still reads the uint8 row mask made above (allocated on the CALLER's
+    # stream: freed at return, the caching allocator would hand its memory to the caller's next allocation while those kernels run)
+    return dict(idx=idx.view(*lead, Q), inputs=inputs, counts=counts, bufs=bufs, keepalive=(row_mask, codes, ws))
 
 
 def mask_fill_indices(idx: torch.Tensor, row_mask: torch.Tensor):
@@ -1158,7 +1254,7 @@ def ema_accumulate_stages(inputs: torch.Tensor, idx: torch.Tensor, stage0: int, 
     _check(lib().vqhip_ema_accumulate_stages(_ptr(xk), _dtype_code(xk), S, N, D, ldx, inputs.stride(0), ctypes.c_void_p(idx.data_ptr() + 8 * stage0),
                                              Q, _ptr(row_mask), C, _ptr(stats), stats.stride(0), _ptr(ws), S * ws.stride(0), 1,
                                              _ptr(pk), pks, _ptr(em), ems, _ptr(sqerr_out) if sqerr_from is not None else None, sqs, _stream()),
-           "vqhip_ema_accumulate_stages")
+           "vqhip_ema_accumulate_stages", "vqhip_rvq_chain_chunk_rows", "vqhip_rvq_chain_ws_stride", "vqhip_rvq_chain_forward")
 
 
 def ema_workspaces(Q: int, N: int, C: int, device) -> torch.Tensor:

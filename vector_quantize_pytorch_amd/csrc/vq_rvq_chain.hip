@@ -1,0 +1,147 @@
+// vq_rvq_chain.hip -- the residual loop of ResidualVQ.forward (rvq.py:469-568) as ONE library call: every launch of the Q chained
+// screened searches (vq_screen.hip), of the routed residuals of a gradient step (vqhip_route_residual) and of the per-stage EMA
+// statistics (vqhip_ema_accumulate_prezeroed), issued from C on the caller's streams.  Host code only: the kernels are the ones the
+// per-stage entry points launch; what this call removes is the host work between them (a Python loop enqueued a cfg-3 forward in
+// 0.97 ms -- 1.53 ms with three row chunks -- of a 2.8 ms step, a cfg-5 forward in 5.9 ms of 14.3: tools/host_overhead.py).
+//
+// Structure (the one the Python loop had):
+//   * rows split into K contiguous chunks of whole screening workgroups, chunk k's chain of stages on its own stream (chunk 0: `stream`),
+//     so that one chunk's exact passes run beside another chunk's screening kernel;
+//   * stage q of a chunk: [routed residual of stage q - 1 -> inputs[q - 1]] , screened search that forms / reads its input and writes
+//     its column of idx;
+//   * when stage q is final in every chunk (one event per chunk stream), its statistics pass is queued on stats_stream beside the
+//     later stages' searches;
+//   * on return `stream` has been joined with the chunk streams; the statistics stream is left to the caller to join.
+#include "vqhip_internal.h"
+
+static inline size_t rc_align(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// the 16-byte list header of every (stage, chunk) workspace slice, in one launch
+__global__ void __launch_bounds__(64) vq_chain_headers_kernel(char *base, size_t stride, int n)
+{
+    const int i = blockIdx.x * 16 + (threadIdx.x >> 2);
+    if (i < n) ((unsigned *)(base + (size_t)i * stride))[threadIdx.x & 3] = 0u;
+}
+
+extern "C" int64_t vqhip_rvq_chain_chunk_rows(int64_t N, int chunks)
+{
+    if (N <= 0) return 0;
+    const int64_t K = chunks < 1 ? 1 : chunks;
+    return ((N + K - 1) / K + 255) / 256 * 256;
+}
+
+// one screening workspace per (stage, chunk): Q x K slices of this many bytes
+extern "C" size_t vqhip_rvq_chain_ws_stride(int64_t N, int chunks)
+{
+    const int64_t rpc = vqhip_rvq_chain_chunk_rows(N, chunks);
+    return rc_align(vqhip_screen_workspace_bytes(rpc < N ? rpc : N), 256);
+}
+
+extern "C" int vqhip_rvq_chain_forward(const vqhip_rvq_chain_t *c, void *stream)
+{
+    if (!c) VQ_FAIL(VQHIP_EINVAL, "rvq_chain_forward: null argument block");
+    const int64_t N = c->N, Q = c->Q;
+    const int D = (int)c->D, C = (int)c->C, dt = (int)c->x_dtype;
+    if (N < 0 || Q < 1 || C < 1) VQ_FAIL(VQHIP_EINVAL, "rvq_chain_forward: bad size");
+    if (N == 0) return 0;
+    if (!c->x || !c->packed || !c->embed || !c->idx_out || !c->workspace) VQ_FAIL(VQHIP_EINVAL, "rvq_chain_forward: null pointer");
+    if (Q > 1 && !c->inputs) VQ_FAIL(VQHIP_EINVAL, "rvq_chain_forward: Q > 1 needs the stage-input buffer");
+    if (dt != VQHIP_F32 && dt != VQHIP_BF16) VQ_FAIL(VQHIP_EINVAL, "rvq_chain_forward: unknown dtype");
+    const int routed = c->route_mode != 0;
+    if (routed && !c->codes) VQ_FAIL(VQHIP_EINVAL, "rvq_chain_forward: routed residuals need the code rows in the rows' dtype");
+    if (!routed && Q > 1 && !vqhip_screen_chain_supported(dt, D))
+        VQ_FAIL(VQHIP_EINVAL, "rvq_chain_forward: chained stages take fp32 rows, D in {32, 64, 128, 256} (routed loops: any rows of the screen)");
+    if (!vqhip_screen_supported(N, D, C)) VQ_FAIL(VQHIP_EDIM, "rvq_chain_forward: N=%lld D=%d C=%d outside the screened path", (long long)N, D, C);
+    int K = (int)c->chunks;
+    if (K < 1) K = 1;
+    const int64_t rpc = vqhip_rvq_chain_chunk_rows(N, K);
+    K = (int)((N + rpc - 1) / rpc);
+    if (K > 1 && !c->chunk_streams) VQ_FAIL(VQHIP_EINVAL, "rvq_chain_forward: %d chunks need chunk_streams[0..%d]", K, K - 2);
+    const int want_stats = c->stats != nullptr;
+    const int stats_side = want_stats && c->stats_stream && c->stats_stream != stream;
+    const int64_t need_ev = (K > 1 || stats_side) ? Q * K + 1 : 0;
+    if (need_ev > 0 && (!c->events || c->n_events < need_ev))
+        VQ_FAIL(VQHIP_EINVAL, "rvq_chain_forward: needs %lld events (Q x chunks + 1)", (long long)need_ev);
+    const size_t wss = vqhip_rvq_chain_ws_stride(N, K);
+    if (c->workspace_bytes < wss * (size_t)(Q * K)) VQ_FAIL(VQHIP_EINVAL, "rvq_chain_forward: workspace too small");
+    if (((uintptr_t)c->workspace) & 255) VQ_FAIL(VQHIP_EALIGN, "rvq_chain_forward: workspace must be 256-byte aligned");
+    if (want_stats && (!c->stats_ws || c->stats_ws_stride < vqhip_ema_batched_ws_stride(N, C) || c->stats_stride < (int64_t)C * D + C))
+        VQ_FAIL(VQHIP_EINVAL, "rvq_chain_forward: statistics need stats_ws slices of vqhip_ema_batched_ws_stride(N, C) bytes and stats_stride >= C D + C");
+    const int es = dt == VQHIP_BF16 ? 2 : 4;
+    hipStream_t main = (hipStream_t)stream;
+    hipError_t e;
+    // the Q x K list headers (16 bytes each) in one launch
+    hipLaunchKernelGGL(vq_chain_headers_kernel, dim3((unsigned)((Q * K + 15) / 16)), dim3(64), 0, main, (char *)c->workspace, wss, (int)(Q * K));
+    if (int rc = vq_launch_status("vq_chain_headers_kernel")) return rc;
+    hipEvent_t *ev = (hipEvent_t *)c->events;
+    if (K > 1) {                                                   // fork: the chunk streams start behind everything queued on `stream`
+        hipEvent_t fork = ev[Q * K];
+        if ((e = hipEventRecord(fork, main)) != hipSuccess) VQ_FAIL((int)e, "rvq_chain_forward: hipEventRecord: %s", hipGetErrorString(e));
+        for (int k = 1; k < K; ++k)
+            if ((e = hipStreamWaitEvent((hipStream_t)c->chunk_streams[k - 1], fork, 0)) != hipSuccess)
+                VQ_FAIL((int)e, "rvq_chain_forward: hipStreamWaitEvent: %s", hipGetErrorString(e));
+    }
+    const char *x0 = (const char *)c->x;
+    char *inputs = (char *)c->inputs;
+    const size_t in_stage = (size_t)N * D * es;                    // bytes between consecutive stage inputs
+    for (int64_t q = 0; q < Q; ++q) {
+        const float *packed_q = c->packed + q * c->packed_qstride;
+        const float *embed_q = c->embed + q * c->embed_qstride;
+        for (int k = 0; k < K; ++k) {
+            const int64_t r0 = (int64_t)k * rpc, n_k = N - r0 < rpc ? N - r0 : rpc;
+            hipStream_t st = k == 0 ? main : (hipStream_t)c->chunk_streams[k - 1];
+            vqhip_chain_t ch;
+            ch.idx_stride = Q; ch.prev_idx = nullptr; ch.prev_idx_stride = Q; ch.prev_embed = nullptr; ch.x_out = nullptr; ch.ldxo = D;
+            ch.route_mode = 0; ch.header_zeroed = 1;
+            const void *src = x0 + (size_t)r0 * c->ldx * es;
+            int64_t lds = c->ldx;
+            if (q > 0 && routed) {
+                // the previous layer returned its ROUTED value and rvq.py:524 subtracted that: its own HBM-bound kernel writes this
+                // stage's input, which the search then reads like a first stage's
+                const void *psrc = q == 1 ? src : (const void *)(inputs + (size_t)(q - 2) * in_stage + (size_t)r0 * D * es);
+                const int64_t plds = q == 1 ? c->ldx : D;
+                void *dst = inputs + (size_t)(q - 1) * in_stage + (size_t)r0 * D * es;
+                const void *codes = (const char *)c->codes + (size_t)(q - 1) * c->codes_qstride * es;
+                if (int rc = vqhip_route_residual(psrc, dt, n_k, D, plds, codes, c->idx_out + r0 * Q + (q - 1), Q, (int)c->route_mode, dst, D, st)) return rc;
+                src = dst; lds = D;
+            } else if (q > 0) {
+                ch.prev_idx = c->idx_out + r0 * Q + (q - 1);
+                ch.prev_embed = c->embed + (q - 1) * c->embed_qstride;
+                ch.x_out = inputs + (size_t)(q - 1) * in_stage + (size_t)r0 * D * es;
+                if (q > 1) { src = inputs + (size_t)(q - 2) * in_stage + (size_t)r0 * D * es; lds = D; }
+            }
+            void *ws = (char *)c->workspace + (size_t)(q * K + k) * wss;
+            if (int rc = vqhip_assign_screened_chain(src, dt, n_k, D, lds, packed_q, embed_q, C, VQHIP_EUCLID, c->idx_out + r0 * Q + q,
+                                                     c->row_mask ? c->row_mask + r0 : nullptr, ws, wss, &ch, st)) return rc;
+            if (need_ev > 0 && (stats_side || q + 1 == Q))
+                if ((e = hipEventRecord(ev[q * K + k], st)) != hipSuccess) VQ_FAIL((int)e, "rvq_chain_forward: hipEventRecord: %s", hipGetErrorString(e));
+        }
+        if (want_stats && stats_side) {
+            // stage q's input and indices are final in every chunk: its statistics pass beside the searches of the later stages
+            hipStream_t ss = (hipStream_t)c->stats_stream;
+            for (int k = 0; k < K; ++k)
+                if ((e = hipStreamWaitEvent(ss, ev[q * K + k], 0)) != hipSuccess) VQ_FAIL((int)e, "rvq_chain_forward: hipStreamWaitEvent: %s", hipGetErrorString(e));
+            const void *xin = q == 0 ? c->x : (const void *)(inputs + (size_t)(q - 1) * in_stage);
+            float *st_q = c->stats + q * c->stats_stride;
+            if (int rc = vqhip_ema_accumulate_prezeroed(xin, dt, N, D, q == 0 ? c->ldx : D, c->idx_out + q, Q, c->row_mask, C, st_q + (size_t)C * D, st_q,
+                                                        (char *)c->stats_ws + (size_t)q * c->stats_ws_stride, c->stats_ws_stride,
+                                                        c->sqerr_partial ? packed_q : nullptr, c->sqerr_partial ? embed_q : nullptr,
+                                                        c->sqerr_partial ? c->sqerr_partial + q * c->sqerr_stride : nullptr, ss)) return rc;
+        }
+    }
+    for (int k = 1; k < K; ++k)                                    // join: `stream` continues behind every chunk's last stage
+        if ((e = hipStreamWaitEvent(main, ev[(Q - 1) * K + k], 0)) != hipSuccess) VQ_FAIL((int)e, "rvq_chain_forward: hipStreamWaitEvent: %s", hipGetErrorString(e));
+    if (want_stats && !stats_side) {
+        for (int64_t q = 0; q < Q; ++q) {                          // no statistics stream (e.g. under graph capture): behind the loop
+            const void *xin = q == 0 ? c->x : (const void *)(inputs + (size_t)(q - 1) * in_stage);
+            float *st_q = c->stats + q * c->stats_stride;
+            const float *packed_q = c->packed + q * c->packed_qstride;
+            const float *embed_q = c->embed + q * c->embed_qstride;
+            if (int rc = vqhip_ema_accumulate_prezeroed(xin, dt, N, D, q == 0 ? c->ldx : D, c->idx_out + q, Q, c->row_mask, C, st_q + (size_t)C * D, st_q,
+                                                        (char *)c->stats_ws + (size_t)q * c->stats_ws_stride, c->stats_ws_stride,
+                                                        c->sqerr_partial ? packed_q : nullptr, c->sqerr_partial ? embed_q : nullptr,
+                                                        c->sqerr_partial ? c->sqerr_partial + q * c->sqerr_stride : nullptr, main)) return rc;
+        }
+    }
+    return 0;
+}

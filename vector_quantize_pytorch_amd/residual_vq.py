@@ -387,6 +387,7 @@ class ResidualVQ(nn.Module):
                                                                             and not vq0._codebook.use_cosine_sim) else 0
         concurrent = bool(update and x.is_cuda and self.concurrent_stats and not torch.cuda.is_current_stream_capturing())
         main = torch.cuda.current_stream(x.device) if x.is_cuda else None
+        native = False
         if L.screening_enabled() and D in (32, 64, 128, 256, 512) and x.data_ptr() % 16 == 0:
             # Q screened searches on the f16 MFMA pipe (csrc/vq_screen.hip), each writing the next stage's input; beats
             # the fused exact-fp32 kernel, which keeps the dims the screen does not cover (96, 160, ...)
@@ -416,8 +417,20 @@ class ResidualVQ(nn.Module):
                 #  module's groups already do that for each other.  Not under graph capture: nested forks, see above.)
                 capturing = x.is_cuda and torch.cuda.is_current_stream_capturing()
                 K = 1 if (capturing or not self.chunk_rows) else L.rvq_row_chunks(x.numel() // D)
-                r = L.rvq_forward_chained(x, packed, embed, Q, row_mask=mask, stage_hook=hook, fill_masked=hook is None,
-                                          route_mode=route_mode, row_chunks=K)
+                native = (batch_mode == 0 and x.numel() > 0 and not (update and vq0._codebook.use_cosine_sim)
+                          and os.environ.get("VQHIP_RVQ_NATIVE", "1") != "0")
+                if native:
+                    # the whole loop -- searches, routed residuals, per-stage statistics -- as ONE library call
+                    # (vqhip_rvq_chain_forward): the same launches on the same streams, issued from C (VQHIP_RVQ_NATIVE=0: from here)
+                    r = L.rvq_chain_forward(x, packed, embed, Q, row_mask=mask, route_mode=route_mode, row_chunks=K,
+                                            stats=buf if update else None, stats_ws=stats_ws if update else None,
+                                            sq_parts=sq_parts if (update and want_loss) else None,
+                                            stats_stream=side if (update and hook is not None) else None)
+                    if mask is not None and hook is None:
+                        L.mask_fill_indices(r["idx"], mask)
+                else:
+                    r = L.rvq_forward_chained(x, packed, embed, Q, row_mask=mask, stage_hook=hook, fill_masked=hook is None,
+                                              route_mode=route_mode, row_chunks=K)
             else:
                 r = L.rvq_forward_screened(x, packed, embed, Q, want_resid=update, want_sqerr=want_loss, row_mask=mask, stage_hook=hook,
                                            fill_masked=hook is None)
@@ -460,7 +473,7 @@ class ResidualVQ(nn.Module):
                         dist.all_reduce(buf)
                     reduced = True
                 torch.cuda.current_stream(x.device).wait_stream(side)
-            elif not batch_mode:
+            elif not batch_mode and not native:
                 for q in range(Q):
                     accumulate(q, stage_in(q), idx)
 
