@@ -426,7 +426,11 @@ class Codebook(nn.Module):
                 x0 = L.l2norm_rows(x0)                          #  as the reference's does)
             r = L.vq_train_step(x0, e, ea, cs, decay=self.decay, eps=self.eps, want_q=want_q, q_out=q_out, loss_scale=loss_scale,
                                 fold=not self.use_ddp, cosine=self.use_cosine_sim, row_mask=rmask,
-                                reuse_scratch=os.environ.get("VQHIP_SCRATCH_CACHE", "1") != "0")
+                                # (a persistent workspace per (stream, size) instead of a cached allocator block per forward: built for
+                                #  VERDICT r4 #9, measured no gain -- 1 024-row step 132 vs 137 us, 16 384 rows 186 vs 190, 2^20 rows 877 vs
+                                #  876, profiles/r5_final/scale_n_scratch_cache.txt: the allocator's cached block costs what the lookup costs --
+                                #  so it stays opt-in)
+                                reuse_scratch=os.environ.get("VQHIP_SCRATCH_CACHE", "0") == "1")
             if self.use_ddp:
                 dist.all_reduce(r["stats"])   # ONE collective for count || embed_sum (RCCL over xGMI), then the fold
                 self._fold_stats(0, r["count"], r["embed_sum"], None, False, ema_update)
