@@ -829,3 +829,68 @@ def test_routed_residuals_are_deterministic_beside_concurrent_searches(dev):
         wrong += sum(int(not torch.equal(o, ref)) for o in outs)
     assert wrong == 0, f"{wrong} of 400 routed-residual launches differ from the launch that ran alone"
 
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_deterministic_kernels_give_the_same_bits_beside_a_concurrent_mfma_load(dev, dtype):
+    """The canary behind round 5's finding (csrc/Makefile): every kernel of the path whose output is a pure function of its inputs
+    is run alone, then 40 times on one stream while another stream keeps the chip busy with screened searches (MFMA waves on every
+    SIMD): the outputs must be bit-identical.  Covered: routing forward / backward (rotation trick, by tensor and by gathered
+    index), the routed residual, the all-stages routing kernel forward / backward, l2norm forward / backward, decode, the exact
+    search (indices + winning distances), the screened search (indices), the codebook pack (through a search on it), the EMA fold.  (The statistics' sums go
+    through fp32 atomics in any order and are excluded; their integer counts are covered.)"""
+    from vector_quantize_pytorch_amd import _lib as L
+    g = torch.Generator(device=dev).manual_seed(7)
+    N, D, C, Q = 40000, 256, 512, 3
+    x = (torch.randn(N, D, device=dev, generator=g) * 2).to(dtype)
+    go = torch.randn(N, D, device=dev, generator=g).to(dtype)
+    e = torch.randn(C, D, device=dev, generator=g)
+    ecodes = e.to(dtype)
+    idx = torch.randint(0, C, (N, Q), device=dev, generator=g)
+    idx0 = idx[:, 0].contiguous()
+    q = ecodes[idx0]
+    coef = torch.tensor(0.3, device=dev)
+    coefs = torch.tensor([0.3, 0.2, 0.1], device=dev)
+    cs = torch.rand(C, device=dev, generator=g) * 5
+    cnt = torch.randint(0, 9, (C,), device=dev, generator=g).float()
+    esum = torch.randn(C, D, device=dev, generator=g)
+    pk = L.pack_codebook(e)
+
+    def ops():
+        out = {}
+        out["route_fwd"] = L.route_fwd(x, q, 2)
+        out["route_bwd"] = L.route_bwd(x, q, go, coef, None, 2)
+        out["route_fwd_gather"] = L.route_fwd_gather(x, ecodes, idx0, 2)
+        out["route_bwd_gather"] = L.route_bwd_gather(x, ecodes, idx0, go, coef, None, 2)
+        out["rvq_route_fwd"] = L.rvq_route(x, e, idx, Q, 2, resid_routed=True)
+        out["rvq_route_bwd"] = L.rvq_route(x, e, idx, Q, 2, g_out=go, loss_coef=coefs, backward=True, resid_routed=True)
+        out["l2norm"] = L.l2norm_rows(x)
+        out["l2norm_bwd"] = L.l2norm_rows_bwd(x, go)
+        out["decode"] = L.decode_sum(idx, e, out_dtype=dtype)
+        r = L.assign(x[:8192], pk, e, want_q=True, want_best=True)              # want_best: the exact kernel
+        out["exact_idx"], out["exact_best"], out["exact_q"] = r["idx"], r["best"], r["q"]
+        out["screen_idx"] = L.assign(x, pk, e, want_q=False)["idx"]
+        pk2 = L.pack_codebook(e)                                                 # (the packed buffer has uninitialised padding: judged by
+        out["screen_idx_fresh_pack"] = L.assign(x[:65536], pk2, e, want_q=False)["idx"]   #  what a search on it returns)
+        a = [t.clone() for t in (cs, esum, e)]
+        L.ema_finalize(a[0], a[1], a[2], cnt, esum * 0.5, decay=0.8, eps=1e-5)
+        out["fold_cs"], out["fold_ea"], out["fold_e"] = a
+        out["count"] = L.ema_accumulate(x, idx0, C)[0]
+        return out
+
+    ref = ops()
+    torch.cuda.synchronize()
+    load = torch.cuda.Stream()
+    xl = torch.randn(1 << 18, 256, device=dev, generator=g)
+    stop_after = 40
+    bad = {}
+    for it in range(stop_after):
+        with torch.cuda.stream(load):                      # ~4 x 0.2 ms of MFMA-dense search per round on the other stream
+            for _ in range(4):
+                L.assign(xl, pk, e, want_q=False)
+        got = ops()
+        torch.cuda.synchronize()
+        for k, v in got.items():
+            if not torch.equal(v, ref[k]):
+                bad[k] = bad.get(k, 0) + 1
+    assert not bad, f"outputs that differ from the solo run (rounds out of {stop_after}): {bad}"
+
