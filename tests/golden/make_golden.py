@@ -333,6 +333,46 @@ if __name__ == "__main__":
     run_case("vq_dim640_bf16", VectorQuantize, dict(dim=640, codebook_size=64), [randn(2, 100, 640, seed=175, dtype=torch.bfloat16)], unit_codebook=True)
     run_case("rvq_dim768", ResidualVQ, dict(dim=768, num_quantizers=3, codebook_size=48), [randn(1, 100, 768, seed=176)], grad=True, unit_codebook=True)
     run_case("vq_dim2048_eval", VectorQuantize, dict(dim=2048, codebook_size=64), [randn(1, 70, 2048, seed=177)], train=False)
+    # Regressions found by the random option combinations of make_combo.py (round 5), each reduced to a named case:
+    # * k-means init of one codebook per head next to the streamed cross-entropy, padded batch (the init got [1, (h b n), d] rows)
+    run_case("vq_heads_sep_ce_kmeans_lens", VectorQuantize, dict(dim=64, codebook_size=32, heads=2, codebook_dim=8, separate_codebook_per_head=True,
+                                                                  kmeans_init=True, kmeans_iters=3, commitment_use_cross_entropy_loss=True),
+             [randn(2, 300, 64, seed=180)], fwd_kwargs=dict(lens=[300, 210]), grad=True, deterministic_sampling=True)
+    # * affine_param together with a learnable codebook (the parameter's gradient passes through the map onto the batch's moments,
+    #   vqp.py:721-724) and with the options that read whole score rows (the scores are those of the MAPPED codebook)
+    af = dict(dim=32, codebook_size=64, affine_param=True)
+    run_case("vq_affine_learnable", VectorQuantize, dict(af, learnable_codebook=True, ema_update=False),
+             [randn(2, 80, 32, seed=181) * 2 + 1, randn(2, 80, 32, seed=182) * 2 + 1], grad=True, param_grad=True, unit_codebook=True)
+    run_case("vq_affine_ce", VectorQuantize, dict(af, commitment_use_cross_entropy_loss=True),
+             [randn(2, 80, 32, seed=183) * 2 + 1, randn(2, 80, 32, seed=184) * 2 + 1], grad=True, unit_codebook=True)
+    run_case("vq_affine_diversity", VectorQuantize, dict(af, codebook_diversity_loss_weight=0.5, codebook_diversity_temperature=10.),
+             [randn(2, 80, 32, seed=185) * 2 + 1, randn(2, 80, 32, seed=186) * 2 + 1], grad=True, unit_codebook=True)
+    run_case("vq_affine_topk", VectorQuantize, af, [randn(2, 40, 32, seed=187) * 2 + 1], fwd_kwargs=dict(topk=3), unit_codebook=True)
+    run_case("vq_affine_learnable_ce_lens", VectorQuantize, dict(af, learnable_codebook=True, ema_update=False, commitment_use_cross_entropy_loss=True),
+             [randn(2, 80, 32, seed=188) * 2 + 1], fwd_kwargs=dict(lens=[80, 31]), grad=True, param_grad=True, unit_codebook=True)
+    # * the masked commitment loss of a multi-headed module: the reference compares every head's codes with the CALLER's tensor
+    #   (`orig_input`, vqp.py:1108, 1319) -- shapes that only broadcast when codebook_dim == dim (it raises otherwise)
+    run_case("vq_heads_sep_mask_origdim", VectorQuantize, dict(dim=32, codebook_size=32, heads=2, codebook_dim=32, separate_codebook_per_head=True,
+                                                                rotation_trick=False),
+             [randn(2, 100, 32, seed=189), randn(2, 100, 32, seed=190)], fwd_kwargs=dict(lens=[100, 41]), unit_codebook=True)
+    run_case("vq_heads_mask_origdim", VectorQuantize, dict(dim=32, codebook_size=32, heads=4, codebook_dim=32, affine_param=True),
+             [randn(1, 90, 32, seed=191)], fwd_kwargs=dict(lens=[33]), unit_codebook=True)
+    # * bf16 rows that require grad: rotate_to runs on bf16 TENSORS (vqp.py:287-318), every op rounds -- ~2 % away from the fp32 formula,
+    #   and the residual loop subtracts exactly that value (rvq.py:524): later stages' indices depend on it
+    bf = torch.bfloat16
+    run_case("vq_bf16_grad_rot", VectorQuantize, dict(dim=64, codebook_size=128), [randn(2, 200, 64, seed=192, dtype=bf)], grad=True, unit_codebook=True)
+    run_case("vq_bf16_grad_rot_lens", VectorQuantize, dict(dim=32, codebook_size=64), [randn(2, 200, 32, seed=193, dtype=bf)],
+             fwd_kwargs=dict(lens=[200, 77]), grad=True, unit_codebook=True)
+    run_case("vq_bf16_grad_ste", VectorQuantize, dict(dim=64, codebook_size=128, rotation_trick=False), [randn(2, 200, 64, seed=194, dtype=bf)],
+             grad=True, unit_codebook=True)
+    run_case("vq_bf16_cos_grad_rot", VectorQuantize, dict(dim=64, codebook_size=128, use_cosine_sim=True), [randn(2, 200, 64, seed=195, dtype=bf)], grad=True)
+    run_case("rvq_bf16_grad_rot", ResidualVQ, dict(dim=64, num_quantizers=4, codebook_size=64, shared_codebook=True),
+             [randn(2, 300, 64, seed=196, dtype=bf), randn(2, 300, 64, seed=197, dtype=bf)], grad=True, unit_codebook=True)
+    run_case("rvq_bf16_grad_ste", ResidualVQ, dict(dim=64, num_quantizers=4, codebook_size=64, rotation_trick=False),
+             [randn(2, 300, 64, seed=198, dtype=bf)], grad=True, unit_codebook=True)
+    run_case("grvq_bf16_grad_rot", GroupedResidualVQ, dict(dim=128, groups=2, num_quantizers=3, codebook_size=64),
+             [randn(2, 200, 128, seed=199, dtype=bf)], grad=True, unit_codebook=True)
+    run_case("vq_bf16_grad_rot_d256", VectorQuantize, dict(dim=256, codebook_size=256), [randn(2, 150, 256, seed=201, dtype=bf)], grad=True, unit_codebook=True)
     # the same loop at a size where near-ties show up: 65 536 rows x 8 stages x 1024 shared codes, default init (cfg 3's shape, a
     # quarter of its rows) -- without an input gradient, and with one under the rotation trick (default) / straight-through, where
     # rvq.py:524 subtracts the layer's ROUTED value from the residual and the later stages' indices depend on its last bits

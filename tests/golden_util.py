@@ -167,15 +167,30 @@ def run_oracle(fx: Fixture, mode="aten"):
             final.update({p + "embed": st.embed, p + "embed_avg": st.embed_avg, p + "cluster_size": st.cluster_size})
         return res, final
 
+    def x_of(s):        # recorded with an input that requires grad: the layers then return the ROUTED value, which rvq.py:524 subtracts
+        x = fx.t(f"x{s}").clone()
+        return x.requires_grad_(True) if meta["grad"] else x
+
+    def with_grads(outs, xs):
+        for s, o in enumerate(outs):
+            if meta["grad"]:
+                (o["loss"].sum() * 3.0 + (o["q"] * fx.t(f"gw{s}")).sum()).backward()
+                o["gx"] = xs[s].grad
+            o["q"], o["loss"] = o["q"].detach(), o["loss"].detach()
+        return outs
+
     if cls == "ResidualVQ":
-        return rvq(kw, sd, "", lambda s: fx.t(f"x{s}"), meta["steps"])
+        xs = [x_of(s) for s in range(meta["steps"])]
+        res, final = rvq(kw, sd, "", lambda s: xs[s], meta["steps"])
+        return with_grads(res, xs), final
     if cls == "GroupedResidualVQ":
         G = kw["groups"]
         sub = {k: v for k, v in kw.items() if k != "groups"}
         sub["dim"] = kw["dim"] // G
         per, final = [], {}
+        xs = [x_of(s) for s in range(meta["steps"])]
         for g in range(G):
-            r, f = rvq(sub, sd, f"rvqs.{g}.", lambda s, g=g: fx.t(f"x{s}").chunk(G, -1)[g], meta["steps"])
+            r, f = rvq(sub, sd, f"rvqs.{g}.", lambda s, g=g: xs[s].chunk(G, -1)[g], meta["steps"])
             per.append(r)
             final.update(f)
         outs = []
@@ -183,7 +198,7 @@ def run_oracle(fx: Fixture, mode="aten"):
             outs.append(dict(q=torch.cat([per[g][s]["q"] for g in range(G)], -1),
                              idx=torch.stack([per[g][s]["idx"] for g in range(G)]),
                              loss=torch.stack([per[g][s]["loss"] for g in range(G)])))
-        return outs, final
+        return with_grads(outs, xs), final
     raise ValueError(cls)
 
 

@@ -41,6 +41,10 @@ def test_module_matches_reference_golden(dev, name):
     fx = G.Fixture(name)
     mod = _build(fx, dev)
     tol = 1e-2 if fx.bf16 else 1e-5
+    if name.startswith("combo_") and not fx.bf16:
+        tol = 5e-5      # (random option combinations, tests/golden/make_combo.py: losses that cancel -- commitment + a negative diversity
+                        #  term -- and gradients of order 1e-9 sit at a few 1e-5 of their scale in fp32 whatever the summation order)
+    gtol = 2e-2 if fx.bf16 else tol   # bf16 gradients: the reference's autograd chain rounds to bf16 after every op (its own noise, ~1e-2)
     for s in range(fx.meta["steps"]):
         x = fx.t(f"x{s}").to(dev)
         if fx.meta["grad"]:
@@ -75,13 +79,13 @@ def test_module_matches_reference_golden(dev, name):
                 p_.grad = None
             (loss.sum() * 3.0 + (q * fx.t(f"gw{s}").to(dev)).sum()).backward()
             if fx.meta["grad"]:
-                _close(x.grad.float(), fx.t(f"gx{s}").float(), tol, f"grad_x step {s}")
+                _close(x.grad.float(), fx.t(f"gx{s}").float(), gtol, f"grad_x step {s}")
             if fx.meta.get("param_grad"):
                 want = {k[len(f"pg{s}/"):]: fx.t(k) for k in fx.arr if k.startswith(f"pg{s}/")}
                 got = {n: p_.grad for n, p_ in mod.named_parameters() if p_.grad is not None}
                 assert set(want) == set(got), (sorted(want), sorted(got))
                 for n in want:
-                    _close(got[n].float(), want[n].float(), tol, f"grad of {n} step {s}")
+                    _close(got[n].float(), want[n].float(), gtol, f"grad of {n} step {s}")
     if fx.meta["train"]:
         after = fx.state("after")
         mine = mod.state_dict()
@@ -346,16 +350,24 @@ def test_route_kernels_match_autograd_of_the_reference_formula(dev, mode, dtype,
     go = torch.randn(N, D, generator=g).to(dtype)
     m = torch.rand(N, generator=g) < 0.7
     coef = torch.tensor(0.37)
-    xr = x.float().clone().requires_grad_(True)
-    ref = O.rotate_to(xr, q.float()) if mode == 2 else xr + (q.float() - xr).detach()
-    lsum = (((q.float() - xr) ** 2).sum(-1) * m).sum()
-    (ref * go.float()).sum().backward(retain_graph=True)
+    bf16_rot = dtype == torch.bfloat16 and mode == 2
+    # bf16 rows under the rotation trick: the reference's rotate_to runs on bf16 TENSORS, every op rounds (vqp.py:287-318) -- ~2 % away
+    # from the fp32 formula -- and the kernel applies the same roundings op by op (vq_route_math.h): compared with torch's own bf16 ops
+    xr = (x if bf16_rot else x.float()).clone().requires_grad_(True)
+    qr = q if bf16_rot else q.float()
+    ref = O.rotate_to(xr, qr) if mode == 2 else xr + (qr - xr).detach()
+    lsum = (((qr.float() - xr.float()) ** 2).sum(-1) * m).sum()
+    (ref.float() * go.float()).sum().backward(retain_graph=True)
     (lsum * coef).backward()
     out = L.route_fwd(x.to(dev), q.to(dev), mode)
     gx = L.route_bwd(x.to(dev), q.to(dev), go.to(dev), coef.to(dev), m.to(dev), mode)
     tol = 1e-5 if dtype == torch.float32 else 2e-2
-    _close(out.float(), ref.detach(), tol, "routed forward")
-    _close(gx.float(), xr.grad, tol, "grad_x")
+    if bf16_rot:      # same bits but for the rows where the order of a 192..2048-term fp32 sum moves a bf16 rounding
+        same = (out.cpu() == ref.detach()).float().mean().item()
+        assert same > 0.995, f"routed forward: {100 * same:.2f} % of the elements equal torch's bf16 rotate_to"
+        tol = 3e-2    # (gradient: against torch's bf16 autograd chain, which rounds after every op)
+    _close(out.float(), ref.detach().float(), tol, "routed forward")
+    _close(gx.float(), xr.grad.float(), tol, "grad_x")
 
 
 def _sharded_worker(rank, world, port, out_path, cosine, exchange="auto", backend="gloo", C=200):
@@ -1119,6 +1131,12 @@ def test_codebook_gradient_of_the_gather_is_the_per_code_sum(dev, monkeypatch, d
     lens = torch.tensor([2000, 700, 1500], device=dev)
     tol = 2e-5 if dtype == torch.float32 else 2e-2
     for use_lens in (False, True):
+        if use_lens and kw.get("heads", 1) > 1 and kw.get("codebook_dim", kw["dim"]) != kw["dim"]:
+            # a padded TRAINING batch of a multi-headed module: the reference's masked loss compares the heads' [1, (b h), n, d] codes
+            # with the caller's [b, n, dim] tensor (vqp.py:1108, 1319) and raises unless codebook_dim == dim -- so does this package
+            with pytest.raises(RuntimeError):
+                mods[0](x.clone().requires_grad_(True), lens=lens)
+            continue
         outs = []
         for mod, (fast, fn) in zip(mods, (("1", "1"), ("0", "1"), ("0", "0"))):
             monkeypatch.setenv("VQHIP_LEARN_FAST", fast)
@@ -1400,6 +1418,13 @@ def test_heads_with_their_own_codebooks_search_in_one_batched_launch(dev, monkey
         x = torch.randn(3, 700, kw["dim"], device=dev).to(dtype)
         lens = torch.tensor([700, 13, 512], device=dev) if step == 2 else None
         monkeypatch.setattr(cbmod.L, "assign_batched_supported", supported)
+        if lens is not None and train and kw.get("codebook_dim", kw["dim"]) != kw["dim"]:
+            # (the masked commitment loss of a multi-headed module only has a shape when codebook_dim == dim -- the reference compares
+            #  the heads' codes with the caller's tensor, vqp.py:1108, 1319, and raises here; padded batches are covered in eval mode and
+            #  by the goldens vq_heads_sep_mask_origdim / vq_heads_mask_origdim)
+            with pytest.raises(RuntimeError):
+                a(x, lens=lens)
+            break
         qa, ia, la = a(x, lens=lens)
         monkeypatch.setattr(cbmod.L, "assign_batched_supported", lambda *ar, **k: False)
         qb, ib, lb = b(x, lens=lens)

@@ -533,6 +533,11 @@ class Codebook(nn.Module):
         ind = embed_ind if embed_ind.ndim == xs.ndim - 1 else embed_ind[None]
         ind = ind.masked_fill(ind == -1, 0).reshape(H, -1).contiguous()
         rmask = None if mask is None else mask.reshape(-1)
+        xs_raw = xs
+        if self.affine_param:        # vqp.py:594-597: the statistics are taken of the rows mapped onto the codebook's moments
+            cstd = self.codebook_variance.clamp(min=1e-5).sqrt()
+            bstd = self.batch_variance.clamp(min=1e-5).sqrt()
+            xs = ((xs.reshape(H, -1, self.dim).float() - self.batch_mean) * (cstd / bstd) + self.codebook_mean).reshape(xs.shape)
         for h in range(H):
             buf = torch.zeros(C * self.dim + C, dtype=torch.float32, device=xs.device)
             esum, count = buf[: C * self.dim].view(C, self.dim), buf[C * self.dim:]
@@ -541,9 +546,16 @@ class Codebook(nn.Module):
                 fused_stats_allreduce(esum, count)    # ONE collective for count || embed_sum
             self._fold_stats(h, count, esum, ema_update_weight, accum_ema_update, ema_update)
         if not accum_ema_update:
-            self.expire_codes_(xs.reshape(H, -1, self.dim), seq_mask=None if rmask is None else rmask[None].expand(H, -1).bool())
+            self.expire_codes_(xs_raw.reshape(H, -1, self.dim), seq_mask=None if rmask is None else rmask[None].expand(H, -1).bool())
 
     update_ema_indices = update_indices
+
+    def affine_codes(self, embed: Tensor) -> Tensor:
+        """the codebook as it is searched under affine_param (vqp.py:721-724): mapped from its own running moments onto the batch's;
+        differentiable in `embed` (the moments are buffers)"""
+        cstd = self.codebook_variance.clamp(min=1e-5).sqrt()
+        bstd = self.batch_variance.clamp(min=1e-5).sqrt()
+        return (embed - self.codebook_mean) * (bstd / cstd) + self.batch_mean
 
     def forward(self, x, sample_codebook_temp=None, mask=None, freeze_codebook=False, codebook_transform_fn=None,
                 ema_update_weight=None, accum_ema_update=False, ema_update=None, topk=None, update_usage=True):

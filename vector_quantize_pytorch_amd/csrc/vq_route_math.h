@@ -52,9 +52,19 @@ __device__ __forceinline__ float vq_row_sum(float v)
     return v;
 }
 
+// bf16 rows: the reference runs rotate_to (vqp.py:287-318) on bf16 TENSORS, so every tensor op of it rounds its result to bf16
+// (the reductions accumulate in fp32 and round once) -- and the rounded norms alone move the result by ~2 % of its magnitude against
+// the fp32 formula.  With BF16 the frame and the forward value below apply those roundings op by op (the same sequence checked
+// bit for bit against the live reference on 4096 x {16..256} rows; only the order of a row's fp32 sum is this kernel's own).
+template <bool BF16>
+__device__ __forceinline__ float vq_rb(float v)
+{
+    return BF16 ? vq_bf16_bits_to_f32(vq_f32_to_bf16_rne(v)) : v;
+}
+
 // The rotation's frame for one row: u = e / |e|, qh = q / |q|, w = l2norm(u + qh), sc = |q| / |e| (all detached in the
-// reference; safe_div's clamp at 1e-6, vqp.py:40-41; one reciprocal per row, then multiplies).
-template <int NE, int LPR>
+// reference; safe_div's clamp at 1e-6, vqp.py:40-41; fp32: one reciprocal per row, then multiplies).
+template <int NE, int LPR, bool BF16 = false>
 __device__ __forceinline__ void vq_rot_frame(const float (&e)[NE], const float (&q)[NE], float (&u)[NE], float (&qh)[NE],
                                              float (&w)[NE], float &sc)
 {
@@ -64,10 +74,24 @@ __device__ __forceinline__ void vq_rot_frame(const float (&e)[NE], const float (
         se += e[k] * e[k];
         sq += q[k] * q[k];
     }
-    const float ne = sqrtf(vq_row_sum<LPR>(se)), nq = sqrtf(vq_row_sum<LPR>(sq));
-    const float de = fmaxf(ne, 1e-6f), dq = fmaxf(nq, 1e-6f);
-    const float ide = 1.f / de, idq = 1.f / dq;
+    const float ne = vq_rb<BF16>(sqrtf(vq_row_sum<LPR>(se))), nq = vq_rb<BF16>(sqrtf(vq_row_sum<LPR>(sq)));   // src.norm(), tgt.norm()
+    const float de = vq_rb<BF16>(fmaxf(ne, 1e-6f)), dq = vq_rb<BF16>(fmaxf(nq, 1e-6f));                        // .clamp(min = eps)
     float st = 0.f;
+    if (BF16) {
+#pragma unroll
+        for (int k = 0; k < NE; ++k) {
+            u[k] = vq_rb<true>(e[k] / de);                    // safe_div(src, norm_src)
+            qh[k] = vq_rb<true>(q[k] / dq);                   // safe_div(tgt, norm_tgt)
+            w[k] = vq_rb<true>(u[k] + qh[k]);                 // u + q
+            st += w[k] * w[k];
+        }
+        const float dn = vq_rb<true>(fmaxf(vq_rb<true>(sqrtf(vq_row_sum<LPR>(st))), 1e-6f));   // F.normalize: norm, clamp_min(eps)
+#pragma unroll
+        for (int k = 0; k < NE; ++k) w[k] = vq_rb<true>(w[k] / dn);
+        sc = vq_rb<true>(nq / de);                            // safe_div(norm_tgt, norm_src)
+        return;
+    }
+    const float ide = 1.f / de, idq = 1.f / dq;
 #pragma unroll
     for (int k = 0; k < NE; ++k) {
         u[k] = e[k] * ide;
@@ -82,16 +106,23 @@ __device__ __forceinline__ void vq_rot_frame(const float (&e)[NE], const float (
     sc = nq / de;
 }
 
-// forward:  out = sc (e - 2 (e.w) w + 2 (e.u) qh)
-template <int NE, int LPR>
+// forward:  out = sc (e - 2 (e.w) w + 2 (e.u) qh)      (bf16: e @ w and e @ u are bmm results, their outer products with w / qh,
+// the subtraction, the addition and the final scale each a bf16 tensor; the factor 2 is exact)
+template <int NE, int LPR, bool BF16 = false>
 __device__ __forceinline__ void vq_rot_fwd(const float (&e)[NE], const float (&u)[NE], const float (&qh)[NE], const float (&w)[NE],
                                            float sc, float (&t)[NE])
 {
     float a1 = 0.f, a2 = 0.f;
 #pragma unroll
     for (int k = 0; k < NE; ++k) { a1 += e[k] * w[k]; a2 += e[k] * u[k]; }
-    a1 = vq_row_sum<LPR>(a1);
-    a2 = vq_row_sum<LPR>(a2);
+    a1 = vq_rb<BF16>(vq_row_sum<LPR>(a1));
+    a2 = vq_rb<BF16>(vq_row_sum<LPR>(a2));
+    if (BF16) {
+#pragma unroll
+        for (int k = 0; k < NE; ++k)
+            t[k] = vq_rb<true>(vq_rb<true>(vq_rb<true>(e[k] - 2.f * vq_rb<true>(a1 * w[k])) + 2.f * vq_rb<true>(a2 * qh[k])) * sc);
+        return;
+    }
 #pragma unroll
     for (int k = 0; k < NE; ++k) t[k] = (e[k] - 2.f * a1 * w[k] + 2.f * a2 * qh[k]) * sc;
 }
@@ -117,8 +148,8 @@ __device__ __forceinline__ void vq_route_value(const float (&e)[NE], const float
 {
     if (mode == 2) {
         float u[NE], qh[NE], w[NE], sc;
-        vq_rot_frame<NE, LPR>(e, q, u, qh, w, sc);
-        vq_rot_fwd<NE, LPR>(e, u, qh, w, sc, t);
+        vq_rot_frame<NE, LPR, BF16>(e, q, u, qh, w, sc);
+        vq_rot_fwd<NE, LPR, BF16>(e, u, qh, w, sc, t);
     } else if (mode == 1) {
 #pragma unroll
         for (int k = 0; k < NE; ++k) t[k] = e[k] + (BF16 ? vq_bf16_bits_to_f32(vq_f32_to_bf16_rne(q[k] - e[k])) : (q[k] - e[k]));

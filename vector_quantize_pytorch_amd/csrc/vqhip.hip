@@ -2562,7 +2562,7 @@ __global__ void __launch_bounds__(256) vq_route_kernel(const RouteArgs a)
         }
     } else if (a.mode == 2 && a.g) {
         float u[NE], qh[NE], w[NE], sc;
-        vq_rot_frame<NE, LPR>(e, qv, u, qh, w, sc);
+        vq_rot_frame<NE, LPR, BF16>(e, qv, u, qh, w, sc);             // (bf16: the frame the reference's graph saved, rounded op by op)
         vq_rot_bwd<NE, LPR>(g, u, qh, w, sc, r);
     } else {
 #pragma unroll
@@ -2799,8 +2799,8 @@ __global__ void __launch_bounds__(256) vq_rvq_route_kernel(const RvqRouteArgs a)
         const bool need_tf = !BWD || (a.resid_routed && a.mode != 0);
         if (a.mode == 2) {                                       // rotation trick
             float u[NE], qh[NE], w[NE], sc;
-            vq_rot_frame<NE, LPR>(r, c, u, qh, w, sc);
-            if (need_tf) vq_rot_fwd<NE, LPR>(r, u, qh, w, sc, tf);
+            vq_rot_frame<NE, LPR, BF16>(r, c, u, qh, w, sc);
+            if (need_tf) vq_rot_fwd<NE, LPR, BF16>(r, u, qh, w, sc, tf);
             if (BWD) vq_rot_bwd<NE, LPR>(g, u, qh, w, sc, t);
         } else {
             if (need_tf) vq_route_value<NE, LPR, BF16>(r, c, a.mode, tf);

@@ -586,34 +586,43 @@ class VectorQuantize(nn.Module):
                 # vqp.py:766 vs :783); gradient: that of a gather from the parameter (vqp.py:710, 766)
                 if not (embed_eff.requires_grad and torch.is_grad_enabled()):
                     return r["q"], r["idx"], None
-                if embed_eff.shape[0] > 1:      # one codebook per head (xs [h, b, n, d]): the same gather, head by head
+                # (affine_param: quantize() searched and gathered the codes mapped onto the batch's moments, vqp.py:721-724; the
+                #  parameter's gradient passes through that map -- a per-dimension scale, the moments are buffers)
+                codes = cb.affine_codes(embed_eff) if cb.affine_param else embed_eff
+                if codes.shape[0] > 1:      # one codebook per head (xs [h, b, n, d]): the same gather, head by head
                     if xs.dtype in (torch.float32, torch.bfloat16) and xs.shape[-1] <= 512 and os.environ.get("VQHIP_GATHER_FN", "1") != "0":
-                        q_h = [_CodesOfIndicesFn.apply(embed_eff[h], r["idx"][h], r["q"][h]) for h in range(embed_eff.shape[0])]
+                        q_h = [_CodesOfIndicesFn.apply(codes[h], r["idx"][h], r["q"][h]) for h in range(codes.shape[0])]
                     else:
                         q_h = []
-                        for h in range(embed_eff.shape[0]):
-                            g = F.embedding(r["idx"][h], embed_eff[h]).to(xs.dtype)
+                        for h in range(codes.shape[0]):
+                            g = F.embedding(r["idx"][h], codes[h]).to(xs.dtype)
                             q_h.append(r["q"][h] + (g - g.detach()))
                     return torch.stack(q_h), r["idx"], None
                 if xs.dtype in (torch.float32, torch.bfloat16) and xs.shape[-1] <= 512 and os.environ.get("VQHIP_GATHER_FN", "1") != "0":
-                    return _CodesOfIndicesFn.apply(embed_eff[0], r["idx"], r["q"]), r["idx"], None
-                g = F.embedding(r["idx"], embed_eff[0]).to(xs.dtype)
+                    return _CodesOfIndicesFn.apply(codes[0], r["idx"], r["q"]), r["idx"], None
+                g = F.embedding(r["idx"], codes[0]).to(xs.dtype)
                 return r["q"] + (g - g.detach()), r["idx"], None
             if not cb._is_initted():
                 Hc = embed_eff.shape[0]
                 cb.init_embed_(xs.detach().reshape(Hc, -1, xs.shape[-1]).float(), None if rmask is None else rmask.reshape(1, -1).expand(Hc, -1))
+            codes_eff = embed_eff
+            if cb.affine_param:                                     # vqp.py:705-706, 721-724: moments first, then the mapped codebook
+                Hc = embed_eff.shape[0]
+                cb.update_affine(xs.detach().reshape(Hc, -1, xs.shape[-1]).float(), cb.embed,      # (every call of the codebook,
+                                 None if rmask is None else rmask.reshape(1, -1).expand(Hc, -1).bool())   # like Codebook.quantize)
+                codes_eff = cb.affine_codes(embed_eff)
             if topk_only and L.topk_supported(xs, topk, embed_eff.shape[-2]):
                 # top-k is the only consumer of the score row: the K best codes straight from the sweep (vqhip_topk), no N x C tensor
-                e2 = embed_eff[0].detach().float().contiguous()
+                e2 = codes_eff[0].detach().float().contiguous()
                 ind = L.topk(xs.detach(), L.pack_codebook(e2), e2.shape[0], topk, cosine=cb.use_cosine_sim, skip_l2norm=True)
-                q = F.embedding(ind, embed_eff[0])
+                q = F.embedding(ind, codes_eff[0])
                 return q.to(xs.dtype), ind, None
             want_div = self.training and self.has_codebook_diversity_loss
             # one codebook per head: xs [h, b, n, d], embed_eff [h, C, D] -- every head is searched by itself; a shared codebook
             # (heads folded into the batch axis, [(b h), n, d]) is one "head" here
             sep = xs.ndim == 4
             xs_h = list(xs.unbind(0)) if sep else [xs]
-            E_h = list(embed_eff.unbind(0)) if sep else [embed_eff[0]]
+            E_h = list(codes_eff.unbind(0)) if sep else [codes_eff[0]]
             assert len(xs_h) == len(E_h)
 
             def rows_to_codes(xc, E, E_search=None):                                  # xc [b, n', d] -> q, ind, dist, batch-mean softmax
@@ -712,6 +721,23 @@ class VectorQuantize(nn.Module):
             if self.sync_update_v > 0.:                                               # vqp.py:1235-1237
                 quantize = quantize + self.sync_update_v * (quantize - quantize.detach())
         return quantize, embed_ind, commit_quantize, inplace_loss, distances
+
+    def _masked_commit_loss(self, commit_quantize, orig_input, mask):
+        """The commitment loss of a padded batch as the reference computes it (vqp.py:1317-1326): the squared error against
+        `orig_input` -- the tensor the CALLER passed (vqp.py:1108), before the layout change, the projection, the head split and the
+        cosine l2norm -- broadcast against the rows' [b, n, d] / [1, (b h), n, d] / [h, b, n, d], then the mean over the valid rows.
+        For heads == 1 without a projection that is the plain masked mean.  With several heads or a projection the two shapes only
+        broadcast when codebook_dim == dim (every head is then compared with the unprojected input) and raise otherwise; both are
+        the reference's behaviour, reproduced by running its own two ops."""
+        cq = commit_quantize
+        if self.heads > 1 and not self.separate_codebook_per_head:
+            cq = cq[None]                                                   # rows [(b h), n, d]: the reference's '1 (b h) n d'
+        err = F.mse_loss(cq, orig_input, reduction='none')
+        loss_mask = mask
+        if self.heads > 1:                                                  # 'b n -> c (b h) n' (vqp.py:1323)
+            b, n = mask.shape
+            loss_mask = mask[None, :, None, :].expand(err.shape[0], b, err.shape[1] // b, n).reshape(err.shape[0], -1, n)
+        return err[loss_mask].mean()
 
     def _split_heads(self, x):
         if self.heads == 1:
@@ -841,8 +867,9 @@ class VectorQuantize(nn.Module):
         need_matrix = (topk is not None or self.has_codebook_diversity_loss or self.stochastic_sample_codes or self.gumbel_straight_through)
         # (with an in-place optimizer the second search runs on the stepped codebook and the reference recomputes `dist` from it,
         #  vqp.py:1186-1210: that case keeps the dense path, which does the same)
+        # (likewise affine_param: the scores are those of the codebook mapped onto THIS batch's moments, which the search updates)
         ce_only = ((return_loss or self.commitment_use_cross_entropy_loss) and not need_matrix and codebook_transform_fn is None
-                   and self.in_place_codebook_optimizer is None)
+                   and self.in_place_codebook_optimizer is None and not self._codebook.affine_param)
         dense = need_matrix or ((return_loss or self.commitment_use_cross_entropy_loss) and not ce_only)
         # A codebook that receives gradients, in the plain training configuration (input with grad, routed output, MSE commitment):
         # the only gradient that reaches the codes is the commitment loss', which is a function of the EMA statistics of x -- the
@@ -877,8 +904,10 @@ class VectorQuantize(nn.Module):
             if ce_only:     # the codebook the search is about to use, live and as a snapshot (the EMA fold inside the search rewrites
                 cb0 = self._codebook                                                  # `embed` in place; see _CrossEntropyFn)
                 if not cb0._is_initted():     # k-means init runs BEFORE the reference computes `dist` (vqp.py:718-720): snapshot after it
-                    cb0.init_embed_(xs.detach().reshape(1, -1, xs.shape[-1]).float(), None if rmask is None else rmask.reshape(1, -1))
-                ce_embed = cb0.embed if cb0.vq_bridge is None else cb0.vq_bridge(cb0.embed)        # [H, C, D]
+                    Hc = cb0.num_codebooks                                # (one codebook per head: xs is [h, b, n, d], the mask [b, n])
+                    cb0.init_embed_(xs.detach().reshape(Hc, -1, xs.shape[-1]).float(),
+                                    None if rmask is None else rmask.reshape(1, -1).expand(Hc, -1))
+                ce_embed =cb0.embed if cb0.vq_bridge is None else cb0.vq_bridge(cb0.embed)        # [H, C, D]
                 if not cb0.learnable_codebook:
                     ce_embed = ce_embed.detach()
                 ce_embed_at_search = ce_embed.detach().clone()
@@ -961,7 +990,7 @@ class VectorQuantize(nn.Module):
                         mk = mask.reshape(*mask.shape, *([1] * (commit_loss.ndim - mask.ndim)))
                         commit_loss = torch.where(mk, commit_loss, torch.zeros_like(commit_loss))
                 elif mask is not None:
-                    commit_loss = F.mse_loss(commit_quantize, orig_input if xs.shape == orig_input.shape else xs, reduction='none')[rmask].mean()
+                    commit_loss = self._masked_commit_loss(commit_quantize, orig_input, mask)
                 else:
                     commit_loss = F.mse_loss(commit_quantize, xs)
                 loss = loss + commit_loss * self.commitment_weight
@@ -969,16 +998,12 @@ class VectorQuantize(nn.Module):
             d = xs.shape[-1]
             if mask is None:
                 commit_loss = sq_sum                                  # mean((q - x)^2): the 1 / numel is folded into the reduction
-            elif not self.use_cosine_sim:
-                denom = (rmask.sum() * d).to(torch.float32) * (xs.shape[0] if xs.ndim == 4 else 1)
-                commit_loss = sq_sum / denom
+            elif not self.use_cosine_sim and self.heads == 1 and xs.shape == orig_input.shape:
+                commit_loss = sq_sum / (rmask.sum() * d).to(torch.float32)
             else:
-                # reference quirk (vqp.py:1319): the masked loss compares against the ORIGINAL (un-normalised) input
-                if self.heads > 1:     # ... whose [b, n, h d] does not broadcast against the heads' [h, b, n, d]: the reference raises too
-                    raise RuntimeError("masked commitment loss of a multi-headed cosine-similarity VectorQuantize: the reference's "
-                                       "mse_loss(quantize [h, b, n, d], orig_input [b, n, h d]) (vqp.py:1319) has no defined shape")
-                diff = (quantize.detach().float() - orig_input.float()) ** 2
-                commit_loss = diff[mask].mean()
+                # reference quirk (vqp.py:1319): the masked loss compares against the caller's tensor -- not l2-normalised, not
+                # projected, not split into heads (this path's codebook is not learnable: commit_quantize is detached, vqp.py:1214)
+                commit_loss = self._masked_commit_loss(quantize.detach(), orig_input, mask)
             loss = loss + (commit_loss if self.commitment_weight == 1. else commit_loss * self.commitment_weight)
 
         if self.training and self.has_codebook_orthogonal_loss:                                     # vqp.py:1331-1348, 340-345
