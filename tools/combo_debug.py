@@ -34,6 +34,8 @@ for name in sys.argv[1:]:
             if fx.meta["grad"]:
                 x.requires_grad_(True)
             res = mod(x, **fx.fwd_kwargs(dev))
+            if len(res) == 2:
+                res = (res[0], torch.zeros(1, dtype=torch.long, device=dev), res[1])
             q, idx, loss = res[:3]
             want = fx.t(f"idx{s}")
             bad = (idx.cpu() != want).nonzero()

@@ -964,7 +964,9 @@ class VectorQuantize(nn.Module):
             return sum(_CrossEntropyFn.apply(xs[h], ce_embed[h], ce_embed_at_search[h], codes[..., h].contiguous(), self.use_cosine_sim, total)
                        for h in range(self.heads))
 
-        if return_loss:                                                              # vqp.py:1260-1261
+        if return_loss:                                                              # vqp.py:1260-1261: an early return -- `quantize` still in
+            if self.heads > 1 and not self.separate_codebook_per_head:               # the codebook's layout, for a shared codebook
+                quantize = quantize[None]                                            # [1, (b h), n, d]
             return quantize, ce_loss(indices)
 
         if self.training and param_path:
@@ -993,7 +995,10 @@ class VectorQuantize(nn.Module):
                     commit_loss = self._masked_commit_loss(commit_quantize, orig_input, mask)
                 else:
                     commit_loss = F.mse_loss(commit_quantize, xs)
-                loss = loss + commit_loss * self.commitment_weight
+                term = commit_loss * self.commitment_weight
+                if term.ndim > 0:      # (top-k on bf16 rows: the reference adds this [b, n, k] bf16 tensor to its fp32 `loss` of shape [1],
+                    term = term.float()   # vqp.py:1282, 1329 -- two dimensioned tensors promote to fp32; `loss` here is 0-dim, which would not)
+                loss = loss + term
         elif self.training and self.has_commitment_loss:
             d = xs.shape[-1]
             if mask is None:
