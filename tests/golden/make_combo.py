@@ -245,6 +245,10 @@ def draw_vq2(r: random.Random, seed: int):
         sc, sh = r.choice([0.1, 3.0]), r.choice([0., 0.7])
         xs = [(x.float() * sc + sh).to(dtype) for x in xs]
     train = r.random() < 0.85
+    if kw.get("affine_param"):
+        # the codebook's moment buffers are torch.empty until the first TRAINING forward fills them (vqp.py:445-448, 501-503): a fresh
+        # module in eval mode searches a codebook mapped through uninitialised memory (seeds 1287, 1351)
+        train = True
     grad = train and r.random() < 0.5
     param_grad = grad and (learnable or "codebook_dim" in kw or kw.get("orthogonal_reg_weight", 0) > 0 or kw.get("affine_param", False))
     return VectorQuantize, kw, xs, dict(train=train, fwd_kwargs=fwd or None, grad=grad, param_grad=param_grad,
