@@ -59,15 +59,30 @@ __device__ __forceinline__ float vq_row_sum(float v)
 template <bool BF16>
 __device__ __forceinline__ float vq_rb(float v)
 {
-    return BF16 ? vq_bf16_bits_to_f32(vq_f32_to_bf16_rne(v)) : v;
+    return BF16 ? (float)(__bf16)v : v;                       // v_cvt_pk_bf16_f32 (round to nearest even) + a shift
+}
+
+// two values rounded to bf16 by ONE v_cvt_pk_bf16_f32 (gfx950), unpacked by a shift and a mask
+__device__ __forceinline__ void vq_rb2(float &a, float &b)
+{
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+    const bf16x2_t p = __builtin_convertvector((f32x2_t){a, b}, bf16x2_t);
+    const unsigned u = __builtin_bit_cast(unsigned, p);
+    a = __uint_as_float(u << 16);
+    b = __uint_as_float(u & 0xffff0000u);
 }
 
 // The rotation's frame for one row: u = e / |e|, qh = q / |q|, w = l2norm(u + qh), sc = |q| / |e| (all detached in the
 // reference; safe_div's clamp at 1e-6, vqp.py:40-41; fp32: one reciprocal per row, then multiplies).
+// BF16: every quotient below has bf16 operands (8 significant bits each).  Such a quotient is never closer than 2^-16.9 (relative)
+// to the midpoint of two neighbouring bf16 values (exhaustive over the 128 x 128 significand pairs: the closest is 233 / 241), so
+// bf16(a * rcp(b)) with v_rcp_f32's 1 ulp and the multiply's half ulp of fp32 is bit for bit bf16(fp32(a / b)): no IEEE division.
 template <int NE, int LPR, bool BF16 = false>
 __device__ __forceinline__ void vq_rot_frame(const float (&e)[NE], const float (&q)[NE], float (&u)[NE], float (&qh)[NE],
                                              float (&w)[NE], float &sc)
 {
+    static_assert(NE % 2 == 0, "elements per lane come in pairs");
     float se = 0.f, sq = 0.f;
 #pragma unroll
     for (int k = 0; k < NE; ++k) {
@@ -78,17 +93,26 @@ __device__ __forceinline__ void vq_rot_frame(const float (&e)[NE], const float (
     const float de = vq_rb<BF16>(fmaxf(ne, 1e-6f)), dq = vq_rb<BF16>(fmaxf(nq, 1e-6f));                        // .clamp(min = eps)
     float st = 0.f;
     if (BF16) {
+        const float ide = __builtin_amdgcn_rcpf(de), idq = __builtin_amdgcn_rcpf(dq);
 #pragma unroll
-        for (int k = 0; k < NE; ++k) {
-            u[k] = vq_rb<true>(e[k] / de);                    // safe_div(src, norm_src)
-            qh[k] = vq_rb<true>(q[k] / dq);                   // safe_div(tgt, norm_tgt)
-            w[k] = vq_rb<true>(u[k] + qh[k]);                 // u + q
+        for (int k = 0; k < NE; k += 2) {
+            u[k] = e[k] * ide; u[k + 1] = e[k + 1] * ide;             // safe_div(src, norm_src)
+            vq_rb2(u[k], u[k + 1]);
+            qh[k] = q[k] * idq; qh[k + 1] = q[k + 1] * idq;           // safe_div(tgt, norm_tgt)
+            vq_rb2(qh[k], qh[k + 1]);
+            w[k] = u[k] + qh[k]; w[k + 1] = u[k + 1] + qh[k + 1];     // u + q
+            vq_rb2(w[k], w[k + 1]);
             st += w[k] * w[k];
+            st += w[k + 1] * w[k + 1];
         }
         const float dn = vq_rb<true>(fmaxf(vq_rb<true>(sqrtf(vq_row_sum<LPR>(st))), 1e-6f));   // F.normalize: norm, clamp_min(eps)
+        const float idn = __builtin_amdgcn_rcpf(dn);
 #pragma unroll
-        for (int k = 0; k < NE; ++k) w[k] = vq_rb<true>(w[k] / dn);
-        sc = vq_rb<true>(nq / de);                            // safe_div(norm_tgt, norm_src)
+        for (int k = 0; k < NE; k += 2) {
+            w[k] *= idn; w[k + 1] *= idn;
+            vq_rb2(w[k], w[k + 1]);
+        }
+        sc = vq_rb<true>(nq * ide);                           // safe_div(norm_tgt, norm_src)
         return;
     }
     const float ide = 1.f / de, idq = 1.f / dq;
@@ -119,8 +143,19 @@ __device__ __forceinline__ void vq_rot_fwd(const float (&e)[NE], const float (&u
     a2 = vq_rb<BF16>(vq_row_sum<LPR>(a2));
     if (BF16) {
 #pragma unroll
-        for (int k = 0; k < NE; ++k)
-            t[k] = vq_rb<true>(vq_rb<true>(vq_rb<true>(e[k] - 2.f * vq_rb<true>(a1 * w[k])) + 2.f * vq_rb<true>(a2 * qh[k])) * sc);
+        for (int k = 0; k < NE; k += 2) {
+            float p0 = a1 * w[k], p1 = a1 * w[k + 1];
+            vq_rb2(p0, p1);
+            float s0 = __builtin_fmaf(-2.f, p0, e[k]), s1 = __builtin_fmaf(-2.f, p1, e[k + 1]);   // (2 p exact: the same value as e - 2 p)
+            vq_rb2(s0, s1);
+            float r0 = a2 * qh[k], r1 = a2 * qh[k + 1];
+            vq_rb2(r0, r1);
+            s0 = __builtin_fmaf(2.f, r0, s0); s1 = __builtin_fmaf(2.f, r1, s1);
+            vq_rb2(s0, s1);
+            s0 *= sc; s1 *= sc;
+            vq_rb2(s0, s1);
+            t[k] = s0; t[k + 1] = s1;
+        }
         return;
     }
 #pragma unroll
