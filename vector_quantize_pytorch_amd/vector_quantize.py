@@ -907,7 +907,7 @@ class VectorQuantize(nn.Module):
                     Hc = cb0.num_codebooks                                # (one codebook per head: xs is [h, b, n, d], the mask [b, n])
                     cb0.init_embed_(xs.detach().reshape(Hc, -1, xs.shape[-1]).float(),
                                     None if rmask is None else rmask.reshape(1, -1).expand(Hc, -1))
-                ce_embed =cb0.embed if cb0.vq_bridge is None else cb0.vq_bridge(cb0.embed)        # [H, C, D]
+                ce_embed = cb0.embed if cb0.vq_bridge is None else cb0.vq_bridge(cb0.embed)        # [H, C, D]
                 if not cb0.learnable_codebook:
                     ce_embed = ce_embed.detach()
                 ce_embed_at_search = ce_embed.detach().clone()
