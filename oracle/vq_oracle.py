@@ -156,6 +156,27 @@ def rotate_to(src, tgt):                       # vqp.py:287-318 (rotation trick,
     return out.reshape(shp)
 
 
+def rotate_to_bf16_ops(src, tgt):
+    """rotate_to (vqp.py:287-318) on bf16 rows, written as fp32 arithmetic with an explicit round-to-bf16 after every TENSOR OP of the
+    reference -- the sequence the routing kernels apply (csrc/vq_route_math.h, BF16 = true).  src, tgt: fp32 tensors holding bf16
+    values.  A reduction (norm, bmm) accumulates in fp32 and rounds once, like ATen's; `2 * t` is exact.  Pinned against torch's own bf16
+    tensor ops -- which is what the reference executes -- by tests/test_oracle.py (bit-identical but for rows where the order of a
+    row's fp32 sum moves a rounding)."""
+    rb = lambda t: t.to(torch.bfloat16).float()
+    e, q = src.reshape(-1, src.shape[-1]), tgt.reshape(-1, src.shape[-1])
+    ne = rb(e.pow(2).sum(-1, keepdim=True).sqrt())            # src.norm(dim = -1, keepdim = True)              :292
+    nq = rb(q.pow(2).sum(-1, keepdim=True).sqrt())            # tgt.norm(...)                                    :293
+    de, dq = rb(ne.clamp(min=1e-6)), rb(nq.clamp(min=1e-6))   # safe_div's den.clamp(min = eps)                  :40-41
+    u, qh = rb(e / de), rb(q / dq)                            # safe_div(src, norm_src), safe_div(tgt, norm_tgt) :296-297
+    s = rb(u + qh)                                            # u + q                                            :305
+    dn = rb(rb(s.pow(2).sum(-1, keepdim=True).sqrt()).clamp(min=1e-6))        # F.normalize: norm, clamp_min(eps)
+    w = rb(s / dn)
+    a1 = rb((e * w).sum(-1, keepdim=True))                    # e @ w^T  (bmm, [b, 1, d] @ [b, d, 1])            :309
+    a2 = rb((e * u).sum(-1, keepdim=True))                    # e @ u^T                                          :310
+    out = rb(rb(e - 2 * rb(a1 * w)) + 2 * rb(a2 * qh))        # e - 2 (...) + 2 (...), left to right             :307-311
+    return rb(out * rb(nq / de)).reshape(src.shape)           # rotated_tgt * safe_div(norm_tgt, norm_src)       :316
+
+
 def sample_rows(samples, num):                 # vqp.py:156-163 (consumes torch's global RNG)
     n = samples.shape[0]
     if n >= num:

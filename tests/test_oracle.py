@@ -133,3 +133,40 @@ def test_oracle_aten_reproduces_the_big_residual_golden(name):
     rows = int((idx != want).any(-1).sum())
     assert rows <= 96, f"{rows} of {idx.numel() // idx.shape[-1]} rows continue with another code than the reference's"
     _close(losses.detach(), torch.from_numpy(np.array(z["losses"])), 1e-5, "losses")
+
+
+# ---- bf16 rows under the rotation trick: the sequence of roundings the routing kernels apply ----------------------------------------
+@pytest.mark.parametrize("D", [16, 64, 128, 256])
+@pytest.mark.parametrize("scale", [1.0, 0.05, 30.0])
+def test_bf16_rotation_restated_op_by_op_equals_torchs_bf16_tensor_ops(D, scale):
+    """The reference's rotate_to runs on bf16 TENSORS when the rows are bf16 (vqp.py:1178, 287-318): every op rounds.  The oracle's
+    restatement with explicit roundings (what csrc/vq_route_math.h implements) gives the same bits as torch's bf16 ops, and the fp32
+    formula does not (~2 % of the output's magnitude): the reason the kernels round op by op."""
+    g = torch.Generator().manual_seed(D)
+    e = (torch.randn(2048, D, generator=g) * scale).bfloat16()
+    q = (torch.randn(2048, D, generator=g) * scale * 0.7).bfloat16()
+    ref = O.rotate_to(e, q).float()                               # torch's bf16 ops == the reference's graph
+    mine = O.rotate_to_bf16_ops(e.float(), q.float())
+    rows_off = (ref != mine).any(-1).sum().item()
+    assert rows_off <= 4, f"{rows_off} of 2048 rows differ"       # (only where the order of a row's fp32 sum moves a rounding)
+    plain = O.rotate_to(e.float(), q.float())
+    assert ((plain - ref).abs().max() / ref.abs().max()).item() > 5e-3
+
+
+def test_a_quotient_of_two_bf16_values_is_never_near_a_bf16_rounding_midpoint():
+    """Basis of the kernels' `a * rcp(b)` in place of an IEEE division (vq_rot_frame<..., BF16>): over all 128 x 128 pairs of 8-bit
+    significands the quotient stays >= 2^-17 (relative) away from the midpoint of two neighbouring bf16 values, far more than the
+    < 2^-22 error of v_rcp_f32 followed by one multiply -- so bf16(a * rcp(b)) == bf16(fp32(a / b)) bit for bit."""
+    from fractions import Fraction
+    best = Fraction(1)
+    for a in range(128, 256):
+        for b in range(128, 256):
+            x = Fraction(a, b)
+            while x < 1:
+                x *= 2
+            x *= 128                                              # bf16 values of this binade are the integers 128 .. 255 now
+            j = int(x)
+            d = abs(x - (Fraction(2 * j + 1, 2)))                 # distance to the midpoint between j and j + 1
+            if x != j:
+                best = min(best, d / x)
+    assert best > Fraction(1, 1 << 17), float(best)
