@@ -241,7 +241,12 @@ int vqhip_rvq_forward(const void *x, int x_dtype, int64_t N, int D, int64_t ldx,
  *  mode 1 = straight-through, mode 2 = rotation trick.  x, q, g_out, out, grad_x: [N, D] rows, one dtype.
  *  vqhip_route_fwd : out = x + (q - x)                      (mode 1)
  *                    out = |q|/|x| (x - 2 (x.w) w + 2 (x.u) qh)   (mode 2; u, qh, w as in the reference)
- *  vqhip_route_bwd : grad_x = J^T g_out (J of the mode; mode 0 = no g_out term)
+ *                    bf16 rows (VQHIP_BF16): the reference evaluates both modes on bf16 TENSORS -- every op of them rounds to bf16 (mode 1:
+ *                    x + bf16(q - x); mode 2: norms, quotients, the two dot products, their outer products, the subtraction, the
+ *                    addition and the final scale, vqp.py:287-318) -- and so do these kernels, op by op: the value equals the
+ *                    reference's bit for bit (but for the order of a row's fp32 sum inside a reduction), which the residual loop
+ *                    depends on (rvq.py:524 subtracts it).  The fp32 formula alone would be ~2 % of |out| away.
+ *  vqhip_route_bwd : grad_x = J^T g_out (J of the mode; mode 0 = no g_out term; bf16: the frame u, qh, w, |q|/|x| rounded as above)
  *                             + 2 * (*loss_coef) * (x - q) on rows with row_mask != 0  (loss_coef nullable,
  *                             a DEVICE scalar = d loss / d sum_of_squares).
  *                    masked_rows: what the forward left on the rows with row_mask == 0 -- 0: the routed value like any row (the mask
