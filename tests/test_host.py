@@ -278,3 +278,38 @@ def test_transposed_view_detection_is_for_gpu_tensors_only():
     t = torch.randn(3, 8, 5).transpose(1, 2)
     assert not _lib.is_transposed_view(t)                  # CPU tensor: the product has no CPU path
     assert _lib.rows_contiguous(torch.randn(4, 4)).is_contiguous()
+
+
+def test_committed_option_combinations_are_the_generators_draws():
+    """tests/golden/combo_<seed>.npz is what `python tests/golden/make_combo.py <seed> 1` draws: the constructor kwargs stored in every
+    committed fixture equal the generator's draw for that seed (build container only: the generator imports the live reference)."""
+    import os
+    import random
+    import sys
+    if not os.path.isdir("/root/reference/vector_quantize_pytorch"):
+        pytest.skip("the live reference is not mounted here")
+    sys.path.insert(0, os.path.join(G.GOLDEN))
+    try:
+        import make_combo as MC
+    except Exception as e:                                   # (the reference or its einx stand-in failed to import)
+        pytest.skip(f"generator not importable: {e}")
+    finally:
+        sys.path.pop(0)
+    checked = 0
+    for name in G.names():
+        if not name.startswith("combo_"):
+            continue
+        seed = int(name[len("combo_"):])
+        r = random.Random(9000 + seed)
+        if seed >= 1000:
+            draw = (MC.draw_vq2, MC.draw_vq2, MC.draw_rvq2, MC.draw_vq2, MC.draw_rvq2, MC.draw_caller)[seed % 6]
+        else:
+            draw = MC.draw_rvq if seed % 3 == 2 else MC.draw_vq
+        cls, kw, xs, opts = draw(r, 500 + seed)
+        fx = G.Fixture(name)
+        assert fx.meta["cls"] == cls.__name__, name
+        want = {k: (list(v) if isinstance(v, tuple) else v) for k, v in kw.items()}
+        assert fx.meta["kwargs"] == want, (name, fx.meta["kwargs"], want)
+        assert fx.meta["steps"] == len(xs) and fx.meta["grad"] == bool(opts.get("grad", False)), name
+        checked += 1
+    assert checked >= 60
