@@ -1588,6 +1588,34 @@ def test_residual_chain_as_one_library_call_equals_the_python_loop(dev, monkeypa
         b.load_state_dict(a.state_dict())
 
 
+@pytest.mark.parametrize("kw", [dict(dim=64, num_quantizers=4, codebook_size=256, shared_codebook=True), dict(dim=128, num_quantizers=3, codebook_size=300)])
+def test_residual_chain_batched_stage_statistics_equal_the_per_stage_passes(dev, monkeypatch, kw):
+    """VQHIP_RVQ_BATCH_STATS = 1 / 2 (vqhip_ema_accumulate_stages: the statistics of the stages in one launch set behind the loop,
+    rvq.py:469-568 + vqp.py:599-617) against mode 0 (per-stage passes beside the loop): indices and outputs identical, losses and
+    codebooks to the rounding of the segmented sums' atomics.  (the binding of that entry point raised a TypeError and
+    nothing called it.)"""
+    from vector_quantize_pytorch_amd import ResidualVQ
+    torch.manual_seed(0)
+    mods = [ResidualVQ(**kw).to(dev).train() for _ in range(3)]
+    for m in mods[1:]:
+        m.load_state_dict(mods[0].state_dict())
+    for step in range(2):
+        x = torch.randn(2, 3000, kw["dim"], device=dev) * (1.0 + step)
+        mask = (torch.rand(2, 3000, device=dev) > 0.2) if step == 1 else None
+        outs = []
+        for mode, m in zip(("0", "1", "2"), mods):
+            monkeypatch.setenv("VQHIP_RVQ_BATCH_STATS", mode)
+            with torch.no_grad():
+                outs.append(m(x, mask=mask))
+        torch.cuda.synchronize()
+        for q, i, l in outs[1:]:
+            assert torch.equal(i, outs[0][1]) and torch.equal(q, outs[0][0])
+            assert torch.allclose(l, outs[0][2], rtol=1e-5, atol=1e-12)
+        for m in mods[1:]:
+            _close(m.codebooks, mods[0].codebooks, 5e-5, "codebooks")
+            m.load_state_dict(mods[0].state_dict())
+
+
 def _route64(r, c, mode):
     """float64 restatement of what a layer returns for an input that requires grad (vqp.py:282-318): 1 straight-through, 2 rotation"""
     if mode == 1:

@@ -1254,7 +1254,7 @@ def ema_accumulate_stages(inputs: torch.Tensor, idx: torch.Tensor, stage0: int, 
     _check(lib().vqhip_ema_accumulate_stages(_ptr(xk), _dtype_code(xk), S, N, D, ldx, inputs.stride(0), ctypes.c_void_p(idx.data_ptr() + 8 * stage0),
                                              Q, _ptr(row_mask), C, _ptr(stats), stats.stride(0), _ptr(ws), S * ws.stride(0), 1,
                                              _ptr(pk), pks, _ptr(em), ems, _ptr(sqerr_out) if sqerr_from is not None else None, sqs, _stream()),
-           "vqhip_ema_accumulate_stages", "vqhip_rvq_chain_chunk_rows", "vqhip_rvq_chain_ws_stride", "vqhip_rvq_chain_forward")
+           "vqhip_ema_accumulate_stages")
 
 
 def ema_workspaces(Q: int, N: int, C: int, device) -> torch.Tensor:
