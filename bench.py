@@ -199,12 +199,14 @@ def _median(v):
     return sorted(v)[len(v) // 2]
 
 
-def _time_module(mod, batches, steps, warmup, sync, windows):
+def _time_module(mod, batches, steps, warmup, sync, windows, after_first=None):
     out = [None]
     with torch.no_grad():
         torch.cuda.synchronize(); t0 = time.perf_counter()
         mod(batches[0])                                 # first forward (k-means init for cfg 5)
         torch.cuda.synchronize(); first = time.perf_counter() - t0
+        if after_first is not None:
+            after_first()
         for i in range(warmup):
             mod(batches[i % len(batches)])
 
@@ -358,18 +360,47 @@ def other_workload(args, world, rank, dev, workload=None, steps=None, warmup=Non
     _lib.rvq_forward_chained = counting_chained
     import vector_quantize_pytorch_amd.codebook as cbmod
     cbmod.L.assign = counting_assign
-    dts, first, _ = _time_module(mod, batches, args.steps, args.warmup, sync, args.windows)
+    first_counts = []
+
+    def after_first():          # everything counted so far belongs to the FIRST forward (cfg 5: the k-means iterations, vqp.py:238-278)
+        first_counts.extend(counts)
+        counts.clear()
+
+    dts, first, _ = _time_module(mod, batches, args.steps, args.warmup, sync, args.windows, after_first=after_first)
     _lib.assign = orig_assign
     _lib.rvq_forward_chained = orig_chained
+    cbmod.L.assign = orig_assign
+    # steady state: the counters of the LAST timed forward.  The residual loops run as one native call (vqhip_rvq_chain_forward), which
+    # leaves its per-stage device counters on the module (`last_counts`: per stage (open rows, pair rows), one counter per row chunk
+    # [and group]); searches issued through L.assign (the sharded module) are in `counts`.
+    n_rows = shape[0] * shape[1]
+    per_stage = None
+    holders = [mod] if getattr(mod, "last_counts", None) is not None else [r for r in getattr(mod, "rvqs", []) if getattr(r, "last_counts", None) is not None]
+    if holders:
+        op, pr = [], []
+        for h in holders:                                # (group-major for a grouped module on side streams)
+            for c in h.last_counts:
+                o, p_ = c[0].double().reshape(c[0].shape[0], -1).sum(0), c[1].double().reshape(c[1].shape[0], -1).sum(0)    # sum over the row chunks
+                op += [round(float(v) / n_rows, 5) for v in o.tolist()]
+                pr += [round(float(v) / n_rows, 5) for v in p_.tolist()]
+        per_stage = {"open_frac": op, "pair_frac": pr, "order": "stage-major, then group" if holders == [mod] and hasattr(mod, "rvqs") else "group-major, then stage",
+                     "source": "device counters of the last timed forward (vqhip_rvq_chain_forward workspace headers)"}
+    elif counts:
+        n_last = stages if len(counts) >= stages else len(counts)
+        last = counts[-n_last:]                          # the searches of the last forward, in call order
+        per_stage = {"open_frac": [round(float(c[0].sum().item()) / c[2], 5) for c in last],      # (.sum(): one counter per row chunk)
+                     "pair_frac": [round(float(c[1].sum().item()) / c[2], 5) for c in last],
+                     "source": "device counters of the last timed forward's L.assign calls"}
+    kmeans_open = None
+    if first_counts and args.workload == "grvq_cfg5":
+        kmeans_open = {"open_frac_mean": _mean([float(c[0].sum().item()) / c[2] for c in first_counts]),
+                       "open_frac_iteration0_mean": _mean([float(c[0].sum().item()) / c[2] for c in first_counts[0::10]]),
+                       "pair_frac_mean": _mean([float(c[1].sum().item()) / c[2] for c in first_counts]),
+                       "searches": len(first_counts),
+                       "note": "the searches of the FIRST forward only: 10 k-means iterations per codebook (vqp.py:238-278); not part of a steady-state step"}
     gdts = None
     if args.workload in ("rvq_cfg3", "grvq_cfg5") and not args.no_grad_step:
         gdts = _time_grad_step(mod, batches, args.steps, args.warmup, sync, args.windows)
-    per_stage = None
-    if counts:
-        n_last = stages if len(counts) >= stages else len(counts)
-        last = counts[-n_last:]                          # the searches of the last forward, in call order (group-major, then stage)
-        per_stage = {"open_frac": [round(float(c[0].sum().item()) / c[2], 5) for c in last],      # (.sum(): one counter per row chunk)
-                     "pair_frac": [round(float(c[1].sum().item()) / c[2], 5) for c in last]}
     tmax = torch.tensor(dts, dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -389,9 +420,15 @@ def other_workload(args, world, rank, dev, workload=None, steps=None, warmup=Non
             traffic, traffic_src = tj["bytes_per_step"], tj.get("source")
     except Exception:
         pass
-    cpu_base = None
+    cpu_base = eager = None
     if world == 1 and not args.no_cpu_baseline and args.workload in ("rvq_cfg3", "grvq_cfg5", "vq_cfg4_shard"):
         cpu_base = cpu_baseline_other(args.workload, torch.get_num_threads())
+        if args.workload == "rvq_cfg3":
+            try:
+                eager = eager_rocm_rvq3(dev, batches[0])
+                eager["speedup_of_this_library"] = round(n * args.steps / dt / eager["value"], 2)
+            except Exception as ex:
+                eager = {"error": f"{type(ex).__name__}: {ex}"}
     return ({"metric": "vectors quantized/sec", "value": n * args.steps / dt, "unit": "vectors/s", "n_gpus": world,
                       "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
                       "scaling": "strong" if strong else "weak", "vs_baseline": None,
@@ -401,16 +438,195 @@ def other_workload(args, world, rank, dev, workload=None, steps=None, warmup=Non
                           "workload": "same module and batches, x.requires_grad_() + backward (upstream gradient of `quantized` resident in HBM, + sum of the commit losses) (BASELINE.md §4, second line)",
                           "ms_per_step": _median(gdts) / args.steps * 1e3, "value": n * args.steps / _median(gdts), "unit": "vectors/s",
                           "windows_ms_per_step": [round(d / args.steps * 1e3, 4) for d in gdts]},
-                      "cpu_baseline": cpu_base,
+                      "cpu_baseline": cpu_base, "eager_rocm": eager,
                       "config": {"workload": name, "parallelism": par, "vector_stages_per_s": n * stages * args.steps / dt,
                                  "world_size": world, "backend": (dist.get_backend() if world > 1 else None),
                                  **_dist_facts(world, dev), "bench_env": BENCH_ENV,
                                  "collective_bytes_per_rank_and_step": getattr(mod, "last_comm", None) or None,
-                                 "first_forward_ms": first * 1e3, "uncertified_rows_per_search": per_stage},
+                                 "first_forward_ms": first * 1e3, "uncertified_rows_per_search": per_stage, "kmeans_first_forward": kmeans_open},
                       "roofline": {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
-                                   "traffic": traffic, "traffic_source": traffic_src, "achieved_vs_fp32_mfma_peak": ach / PEAK_FP32_MFMA_TFLOPS,
+                                   "traffic": traffic, "traffic_source": traffic_src,
                                    "note": "whole step (all kernels) PER GPU, not one kernel; algorithmic flops (2*C*D per vector and stage); "
                                            "peak = dense f16 MFMA when the search runs screened (VQHIP_SCREEN != 0), fp32 MFMA otherwise"}})
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+def exact_kernel_leg(x, vq, launches=3):
+    """The exact fp32-MFMA search (vq_assign_kernel, VQHIP_SCREEN=0) on one cfg-2 batch and the current codebook, HIP-event timed on
+    the launch stream: the arithmetic the screened search defers to, priced against the fp32-MFMA peak (VERDICT r5 #2)."""
+    from vector_quantize_pytorch_amd import _lib
+    e = vq._codebook.embed[0].detach().contiguous()
+    packed = _lib.pack_codebook(e)
+    rows = x.reshape(-1, x.shape[-1])
+    old = os.environ.get("VQHIP_SCREEN")
+    ts = []
+    try:
+        os.environ["VQHIP_SCREEN"] = "0"
+        _lib.assign(rows, packed, e, want_q=True)
+        for _ in range(launches):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            _lib.assign(rows, packed, e, want_q=True)
+            e1.record()
+            torch.cuda.synchronize()
+            ts.append(e0.elapsed_time(e1))
+    finally:
+        if old is None:
+            os.environ.pop("VQHIP_SCREEN", None)
+        else:
+            os.environ["VQHIP_SCREEN"] = old
+    ms = _median(ts)
+    tf = 2.0 * rows.shape[0] * e.shape[0] * e.shape[1] / (ms * 1e-3) / 1e12
+    return {"kernel": "vq_assign_kernel<256,bf16,euclid> (VQHIP_SCREEN=0: index + q outputs)", "ms": ms, "launches": launches,
+            "achieved_tflops": tf, "frac_of_fp32_mfma_peak": tf / PEAK_FP32_MFMA_TFLOPS}
+
+
+def eager_rocm_baseline(dev, batch):
+    """BASELINE.md 4, secondary datapoint: what a user of the reference gets TODAY on this GPU -- the reference's own op sequence
+    (oracle mode "aten", quantize_mode "onehot": cdist vqp.py:58-62, argmax :140, F.one_hot + gather einsum :142 / :766, EMA einsums
+    :602-606, lerps :76-97, Laplace :152-154) run eagerly by PyTorch-ROCm on `cuda` tensors (hipBLASLt / rocBLAS contractions + the
+    N x C temporaries), at cfg 2's full size, HIP-event timed.  Same arithmetic the CPU baseline times; a baseline, not the product."""
+    from oracle import vq_oracle as O
+    g = torch.Generator().manual_seed(0)
+    bound = (6.0 / (C * D)) ** 0.5
+    e = ((torch.rand(1, C, D, generator=g) * 2 - 1) * bound).to(dev)
+    st = O.VQState(embed=e.clone(), embed_avg=e.clone(), cluster_size=torch.ones(1, C, device=dev))
+    cfg = O.VQConfig(dim=D, codebook_size=C)
+    ts = []
+    torch.cuda.reset_peak_memory_stats(dev)
+    with torch.no_grad():
+        O.vq_forward(st, cfg, batch, quantize_mode="onehot")
+        torch.cuda.synchronize()
+        for _ in range(3):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            O.vq_forward(st, cfg, batch, quantize_mode="onehot")
+            e1.record()
+            torch.cuda.synchronize()
+            ts.append(e0.elapsed_time(e1))
+    ms = _median(ts)
+    n = batch.shape[0] * batch.shape[1]
+    peak = torch.cuda.max_memory_allocated(dev)
+    torch.cuda.empty_cache()
+    return {"value": n / (ms * 1e-3), "unit": "vectors/s", "ms_per_step": ms, "kind": "port",
+            "peak_allocated_gb": round(peak / 2**30, 2),
+            "sample": (f"oracle mode=aten, quantize_mode=onehot (the reference's ATen op sequence of a training forward, proven bit-identical to the "
+                       f"live reference on CPU; live reference not on the GPU box) on cuda tensors through PyTorch-ROCm, x=({B},{S},{D}) bf16 = cfg 2 at "
+                       f"full size, C={C}, median of 3 after 1 warm-up, HIP events")}
+
+
+def eager_rocm_rvq3(dev, batch):
+    """the reference's op sequence of a cfg-3 training forward (oracle rvq_forward, mode "aten", one-hot gather) eagerly through
+    PyTorch-ROCm on cuda tensors, full size (32 x 8192 rows, 8 stages, one shared codebook), HIP-event timed"""
+    from oracle import vq_oracle as O
+    g = torch.Generator().manual_seed(0)
+    Cm, Dm, Q = 1024, 256, 8
+    e = ((torch.rand(1, Cm, Dm, generator=g) * 2 - 1) * (6.0 / (Cm * Dm)) ** 0.5).to(dev)
+    st = O.VQState(embed=e.clone(), embed_avg=e.clone(), cluster_size=torch.ones(1, Cm, device=dev), initted=True)
+    cfg = O.VQConfig(dim=Dm, codebook_size=Cm, manual_ema_update=True)
+    ts = []
+    with torch.no_grad():
+        O.rvq_forward([st] * Q, cfg, batch, shared_codebook=True, quantize_mode="onehot")
+        torch.cuda.synchronize()
+        for _ in range(3):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            O.rvq_forward([st] * Q, cfg, batch, shared_codebook=True, quantize_mode="onehot")
+            e1.record()
+            torch.cuda.synchronize()
+            ts.append(e0.elapsed_time(e1))
+    ms = _median(ts)
+    torch.cuda.empty_cache()
+    return {"value": batch.shape[0] * batch.shape[1] / (ms * 1e-3), "unit": "vectors/s", "ms_per_step": ms, "kind": "port",
+            "sample": "oracle rvq_forward mode=aten, quantize_mode=onehot on cuda tensors through PyTorch-ROCm, cfg 3 at full size, median of 3 after 1 warm-up, HIP events"}
+
+
+def screen_stress(dev, base_ms):
+    """VERDICT r5 #4: the screened train step away from its friendliest input (randn rows, default init).  Same module, shapes and
+    dtype as cfg 2; every leg reports ms per step and the uncertified fractions of its last steps.
+      all_open        every code has two identical twins: best, second and third tie for every row -> every row takes the exact fp32-MFMA
+                      sweep (vq_refine_kernel): the floor of the search
+      pair_floor      every code has ONE twin: every row is decided between two codes by two exact distances (vq_pair_kernel)
+      gmm_normspread  rows from a 64-component Gaussian mixture whose components' scales span 30 x, codebook trained on it for 50 EMA steps
+      one_code_x100   cfg 2's default codebook with ONE code scaled x 100 (its norm feeds the certificate's codebook-side terms)"""
+    from vector_quantize_pytorch_amd import VectorQuantize
+    import vector_quantize_pytorch_amd.codebook as cbmod
+    out = {}
+    gen = torch.Generator(device=dev).manual_seed(7)
+    rand_batches = [torch.randn(B, S, D, generator=gen, device=dev).bfloat16() for _ in range(2)]
+
+    def run(vq, batches, steps, prep=None, warm=1):
+        fr = []
+        orig = cbmod.L.vq_train_step
+
+        def counting(*a, **k):
+            r = orig(*a, **k)
+            fr.append((r["n_exact"][0].clone(), r["n_pair"][0].clone()))
+            return r
+        with torch.no_grad():
+            for i in range(warm):
+                if prep:
+                    prep(vq)
+                vq(batches[i % len(batches)])
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            for i in range(steps):
+                if prep:
+                    prep(vq)
+                vq(batches[i % len(batches)])
+            torch.cuda.synchronize(); ms = (time.perf_counter() - t0) / steps * 1e3
+            cbmod.L.vq_train_step = counting
+            try:
+                for i in range(2):
+                    if prep:
+                        prep(vq)
+                    vq(batches[i % len(batches)])
+            finally:
+                cbmod.L.vq_train_step = orig
+            torch.cuda.synchronize()
+        n = B * S
+        return {"ms_per_step": round(ms, 4), "vs_cfg2": None if not base_ms else round(ms / base_ms, 3),
+                "open_frac": _mean([float(a.item()) / n for a, _ in fr]), "pair_frac": _mean([float(b.item()) / n for _, b in fr]), "steps": steps}
+
+    def twins(k):
+        def prep(vq):
+            cb = vq._codebook
+            m = C // k
+            for t in range(1, k):
+                cb.embed[0, t * m:(t + 1) * m] = cb.embed[0, :m]
+        return prep
+
+    torch.manual_seed(0)
+    out["all_open"] = run(VectorQuantize(dim=D, codebook_size=C).to(dev).train(), rand_batches, 3, prep=twins(3))
+    out["all_open"]["workload"] = "cfg-2 step, every code with two identical twins (3 x 341 codes): 100 % of the rows take the exact sweep"
+    out["pair_floor"] = run(VectorQuantize(dim=D, codebook_size=C).to(dev).train(), rand_batches, 3, prep=twins(2))
+    out["pair_floor"]["workload"] = "cfg-2 step, every code with one identical twin: 100 % of the rows are decided between two codes (vq_pair_kernel)"
+    # Gaussian mixture, 64 components, scales 1 .. 30 (log-spaced): x = (mu_k + 0.5 z) s_k
+    K = 64
+    mu = torch.randn(K, D, generator=gen, device=dev)
+    sk = torch.logspace(0, torch.log10(torch.tensor(30.0)).item(), K, device=dev)
+    gmm = []
+    for _ in range(2):
+        comp = torch.randint(0, K, (B, S), generator=gen, device=dev)
+        gmm.append(((mu[comp] + 0.5 * torch.randn(B, S, D, generator=gen, device=dev)) * sk[comp][..., None]).bfloat16())
+    vq = VectorQuantize(dim=D, codebook_size=C).to(dev).train()
+    out["gmm_normspread"] = run(vq, gmm, 10, warm=50)
+    out["gmm_normspread"]["workload"] = ("cfg-2 step on rows from a 64-component Gaussian mixture, component scales 1 .. 30 (row norms span 30 x), codebook "
+                                         "trained on it for 50 EMA steps first")
+    e2 = (vq._codebook.embed[0] ** 2).sum(-1)
+    out["gmm_normspread"]["codebook_norm2_min_max"] = [float(e2.min()), float(e2.max())]
+    del gmm
+    vq = VectorQuantize(dim=D, codebook_size=C).to(dev).train()
+    with torch.no_grad():
+        vq._codebook.embed[0, 7] *= 100.0
+        vq._codebook.embed_avg[0, 7] *= 100.0
+
+    def keep_big(v):        # (the EMA keeps pulling the code towards the rows it wins: hold it at x 100 of a default code's size)
+        cb = v._codebook
+        n7 = cb.embed[0, 7].norm()
+        cb.embed[0, 7] *= (100.0 * cb.embed[0, 8].norm() / n7.clamp_min(1e-20)).clamp(max=1e6)
+    out["one_code_x100"] = run(vq, rand_batches, 10, prep=keep_big, warm=2)
+    out["one_code_x100"]["workload"] = "cfg-2 step, default codebook with code 7 held at 100 x the norm of its neighbour"
+    return out
 
 
 # ----------------------------------------------------------------------------------------------------------------------
@@ -575,7 +791,6 @@ def vq_cfg2(args, world, rank, dev):
                      "traffic": traffic, "traffic_source": traffic_src, "traffic_whole_step": step_traffic,
                      "kernel_ms": k_ms, "algorithmic_flops_per_launch": flops,
                      "algorithmic_bytes_per_launch": alg_bytes,
-                     "achieved_vs_fp32_mfma_peak": achieved / PEAK_FP32_MFMA_TFLOPS,
                      "note": ("achieved counts algorithmic flops (2*C*D per vector) over the whole search (screen + exact pass on the "
                               "uncertified rows + finish), timed with events on the launch stream") if screened else
                              "exact fp32-MFMA search (VQHIP_SCREEN=0)"},
@@ -590,6 +805,7 @@ def vq_cfg2(args, world, rank, dev):
         if screened:
             n_chk, bad = screened_vs_exact(batches[0], vq)
             parity.update(rows_checked=n_chk, mismatches_vs_exact=bad)
+            out["roofline"]["exact_kernel"] = exact_kernel_leg(batches[0], vq)
         if not args.no_adversarial and screened:
             # throughput floor: a codebook in which every code has an identical twin -- no row can be certified, every row
             # takes the screen AND the exact pass
@@ -605,12 +821,24 @@ def vq_cfg2(args, world, rank, dev):
                     cb.embed[0, C // 2:] = cb.embed[0, : C // 2]          # keep the twins identical across the EMA update
                     dup(batches[i % N_BATCHES])
                 torch.cuda.synchronize(); ta = (time.perf_counter() - t0) / k
-            out["adversarial"] = {"workload": "same step with a duplicated codebook (every code has a twin): 100 % of the rows take the exact pass",
+            out["adversarial"] = {"workload": ("PAIR-PATH floor: same step with a duplicated codebook (every code has one twin): 100 % of the rows are decided "
+                                               "between two codes by vq_pair_kernel.  The all-open floor (every row through the exact sweep) is "
+                                               "screen_stress.all_open"),
                                   "ms_per_step": ta * 1e3, "value": n_vec / ta, "unit": "vectors/s"}
+            try:
+                out["screen_stress"] = screen_stress(dev, step_s * 1e3)
+            except Exception as ex:          # informational legs must not take the contract line down
+                out["screen_stress"] = {"error": f"{type(ex).__name__}: {ex}"}
+            torch.cuda.empty_cache()
         if not args.no_cpu_baseline:
             base, audit = cpu_baseline_and_audit(torch.get_num_threads(), dev)
             out["cpu_baseline"] = base
             parity.update(audit)
+            try:
+                out["eager_rocm"] = eager_rocm_baseline(dev, batches[0])
+                out["eager_rocm"]["speedup_of_this_library"] = round(out["value"] / world / out["eager_rocm"]["value"], 2)
+            except Exception as ex:
+                out["eager_rocm"] = {"error": f"{type(ex).__name__}: {ex}"}
         out["parity"] = parity
         if not args.no_other_workloads:
             # BASELINE configs 3 / 4 (one rank's shard work) / 5 under the driver's clock as well: the same measurement as
@@ -626,10 +854,12 @@ def vq_cfg2(args, world, rank, dev):
                               "grad_ms_per_step": None if r["grad_step"] is None else round(r["grad_step"]["ms_per_step"], 4),
                               "frac_of_f16_mfma_peak_whole_step": round(r["roofline"]["frac"], 4),
                               "first_forward_ms": round(r["config"]["first_forward_ms"], 2),
-                              "open_frac_mean": _mean((r["config"]["uncertified_rows_per_search"] or {}).get("open_frac")),
-                              "pair_frac_mean": _mean((r["config"]["uncertified_rows_per_search"] or {}).get("pair_frac")),
+                              "open_frac_mean": _mean((r["config"]["uncertified_rows_per_search"] or {}).get("open_frac")),     # steady state:
+                              "pair_frac_mean": _mean((r["config"]["uncertified_rows_per_search"] or {}).get("pair_frac")),     # the last timed forward
+                              "kmeans_first_forward": r["config"].get("kmeans_first_forward"),
+                              "windows_ms_per_step": r["windows_ms_per_step"],
                               "traffic_bytes_per_step": r["roofline"]["traffic"], "traffic_source": r["roofline"]["traffic_source"],
-                              "cpu_baseline": r.get("cpu_baseline"),
+                              "cpu_baseline": r.get("cpu_baseline"), "eager_rocm": r.get("eager_rocm"),
                               "steps": st, "windows": 3, "workload": r["config"]["workload"]}
                 except Exception as ex:      # the contract line must not die with an informational one
                     ow[wl] = {"error": f"{type(ex).__name__}: {ex}"}

@@ -162,7 +162,7 @@ int vqhip_assign_screened_chain(const void *x, int x_dtype, int64_t N, int D, in
                                 const float *embed, int C, int metric, int64_t *idx_out, const uint8_t *row_mask,
                                 void *workspace, size_t workspace_bytes, const vqhip_chain_t *chain, void *stream);
 
-/* ---- the residual loop as one call (round 5) --------------------------------------------------------
+/* ---- the residual loop as one call (round 5; groups: round 6) ---------------------------------------
  * Everything ResidualVQ.forward's loop (residual_vq.py:469-568) launches between packing the codebooks and decoding the sum, issued from C:
  * the Q chained screened searches (vqhip_assign_screened_chain: stage q forms x_prev - code in its prologue, residual_vq.py:524), for a
  * training step whose input requires grad the routed residuals instead (vqhip_route_residual, vqp.py:1225-1233), and -- when `stats` is
@@ -196,6 +196,18 @@ typedef struct {
     int64_t chunks; void **chunk_streams;                 /* chunks - 1 streams */
     void *stats_stream;                                   /* nullable / == stream: the statistics follow the loop on `stream` */
     void **events; int64_t n_events;
+    /* Round 6: G independent residual loops -- the groups of GroupedResidualVQ (residual_vq.py:634-724; the reference runs them one
+     * after the other, loop at :706) -- as ONE launch set, blockIdx.y = group.  groups <= 1: one loop, the fields below are ignored.
+     * Group g reads the rows x + g * x_gstride (elements; same N, ldx: the feature chunks of one [N, G D] tensor have x_gstride = D),
+     * searches packed + g * packed_gstride / embed + g * embed_gstride (floats; stage q another q * packed_qstride / embed_qstride
+     * on top), routes through codes + g * codes_gstride (elements), accumulates into stats + g * stats_gstride (floats) with the
+     * workspace stats_ws + g * stats_ws_gstride (bytes) and the loss partials sqerr_partial + g * sqerr_gstride (doubles).
+     * Fixed layouts: idx_out [G, N, Q]; inputs [Q - 1, G, N, D]; workspace Q x K x G slices (slice ((q K + k) G + g)); row_mask is
+     * shared by the groups.  Results per group: those of a call with groups = 1, bit for bit (indices). */
+    int64_t groups;
+    int64_t x_gstride, packed_gstride, embed_gstride, codes_gstride, stats_gstride;
+    size_t stats_ws_gstride;
+    int64_t sqerr_gstride;
 } vqhip_rvq_chain_t;
 int64_t vqhip_rvq_chain_chunk_rows(int64_t N, int chunks);
 size_t vqhip_rvq_chain_ws_stride(int64_t N, int chunks);
@@ -427,6 +439,14 @@ int vqhip_ema_finalize(float *cluster_size, float *embed_avg, float *embed,
                        const float *count, const float *embed_sum, const float *weight,
                        int C, int D, float one_minus_decay, float eps, int cosine,
                        int do_lerp, int do_update_ema, float *denom_ws, void *stream);
+
+/* vqhip_ema_finalize_batched for H codebooks whose buffers are separate allocations (round 6): the layers of a residual VQ / the groups of
+ * GroupedResidualVQ keep one cluster_size / embed_avg / embed buffer set per layer (state_dict keys layers.{i}._codebook.*,
+ * residual_vq.py:124-126, 690-691), and the reference folds them one layer after the other (vqp.py:610-617 inside every layer's forward).
+ * table: H x 3 DEVICE pointers (uintptr_t) -- cluster_size [C], embed_avg [C, D], embed [C, D] of head h -- in device memory; head h's
+ * statistics at stats + h * stats_stride (embed_sum [C, D] || count [C]).  Three launches for all H folds.  denom_ws [H, C]. */
+int vqhip_ema_finalize_table(const void *table, const float *stats, int64_t stats_stride, int H, int C, int D,
+                             float one_minus_decay, float eps, int cosine, int do_update_ema, float *denom_ws, void *stream);
 
 /* update_ema (vqp.py:576-584) on ONE SHARD of a codebook partitioned over ranks: the Laplace smoothing (vqp.py:152-154) needs
  * sum(cluster_size) and the code count of the whole codebook -- total_cluster_size is a DEVICE scalar (the caller all-reduces the

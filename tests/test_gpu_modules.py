@@ -903,6 +903,46 @@ def test_train_step_with_dead_code_replacement_is_graph_capturable(dev):
     assert bool(torch.isfinite(out[2])) and int(out[1].max()) < 256
 
 
+@pytest.mark.parametrize("kw,rows", [(dict(dim=512, groups=4, num_quantizers=4, codebook_size=512), (2, 40000)),
+                                     (dict(dim=128, groups=2, num_quantizers=3, codebook_size=300, shared_codebook=True), (3, 1500)),
+                                     (dict(dim=256, groups=4, num_quantizers=2, codebook_size=64, threshold_ema_dead_code=2), (1, 777)),
+                                     (dict(dim=64, groups=2, num_quantizers=5, codebook_size=100, commitment_weight=0.3), (1, 70000))])
+def test_grouped_residual_vq_batched_chain_equals_group_streams(dev, monkeypatch, kw, rows):
+    """Round 6: the G groups of GroupedResidualVQ (rvq.py:634-724, loop at :706) as ONE launch set (vqhip_rvq_chain_t.groups: blockIdx.y =
+    group in the chained screening kernel, the exact passes and the statistics; decode into the output's feature chunks; all G x Q EMA
+    folds through vqhip_ema_finalize_table) against the groups as separate ResidualVQ forwards on side streams (VQHIP_GRVQ_BATCHED=0):
+    train steps with and without a mask, one with two row chunks, then eval -- indices and outputs identical, losses / codebooks to
+    the rounding of the segmented sums' atomics."""
+    from vector_quantize_pytorch_amd import GroupedResidualVQ
+    torch.manual_seed(0)
+    a, b = GroupedResidualVQ(**kw).to(dev).train(), GroupedResidualVQ(**kw).to(dev).train()
+    b.load_state_dict(a.state_dict())
+    for step in range(4):
+        if step == 3:
+            a.eval(); b.eval()
+        x = torch.randn(*rows, kw["dim"], device=dev) * (1.0 + step)
+        mask = (torch.rand(*rows, device=dev) > 0.2) if step == 1 else None
+        state = torch.cuda.get_rng_state(dev)
+        with torch.no_grad():
+            monkeypatch.setenv("VQHIP_GRVQ_BATCHED", "1")
+            monkeypatch.setenv("VQHIP_GRVQ_CHUNKS", "2" if step == 2 else "1")
+            assert a._batched_eligible(x, x.chunk(a.groups, -1), mask, False)
+            qa, ia, la = a(x, mask=mask)
+            torch.cuda.set_rng_state(state, dev)
+            monkeypatch.setenv("VQHIP_GRVQ_BATCHED", "0")
+            qb, ib, lb = b(x, mask=mask)
+        torch.cuda.synchronize()
+        assert ia.shape == ib.shape and torch.equal(ia, ib) and torch.equal(qa, qb)
+        assert la.shape == lb.shape and torch.allclose(la, lb, rtol=1e-5, atol=1e-12)
+        assert la.requires_grad == lb.requires_grad
+        _close(a.codebooks, b.codebooks, 5e-5, "codebooks")
+        for ra, rb in zip(a.rvqs, b.rvqs):
+            for va, vb in zip(ra.layers, rb.layers):
+                _close(va._codebook.cluster_size, vb._codebook.cluster_size, 1e-5, "cluster_size")
+                _close(va._codebook.embed_avg, vb._codebook.embed_avg, 5e-5, "embed_avg")
+        b.load_state_dict(a.state_dict())
+
+
 def test_grouped_rvq_train_step_with_side_streams_is_graph_capturable(dev):
     """GroupedResidualVQ forks one stream per group and one statistics stream per group inside forward; fork and join are events on
     the capturing stream, so the whole train step is still one HIP graph: replays match eager execution."""

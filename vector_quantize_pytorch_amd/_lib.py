@@ -135,6 +135,8 @@ def lib():
     L.vqhip_ema_accumulate_stages.restype = i32
     L.vqhip_ema_finalize_batched.argtypes = [vp, vp, vp, vp, i64, i32, i32, i32, f32, f32, i32, i32, vp, vp]
     L.vqhip_ema_finalize_batched.restype = i32
+    L.vqhip_ema_finalize_table.argtypes = [vp, vp, i64, i32, i32, i32, f32, f32, i32, i32, vp, vp]
+    L.vqhip_ema_finalize_table.restype = i32
     L.vqhip_route_residual.argtypes = [vp, i32, i64, i32, i64, vp, vp, i64, i32, vp, i64, vp]
     L.vqhip_route_residual.restype = i32
     L.vqhip_vq_step_supported.argtypes = [i32, i64, i32, i32]
@@ -166,7 +168,8 @@ EXPORTS = ("vqhip_version", "vqhip_last_error", "vqhip_packed_bytes", "vqhip_pac
            "vqhip_pack_codebook_batched", "vqhip_screen_batched_ws_stride", "vqhip_assign_screened_batched", "vqhip_assign_batched",
            "vqhip_route_fwd_gather", "vqhip_route_bwd_gather", "vqhip_ema_accumulate_prezeroed",
            "vqhip_ema_batched_ws_stride", "vqhip_ema_accumulate_batched", "vqhip_ema_finalize_batched",
-           "vqhip_ema_accumulate_stages", "vqhip_rvq_chain_chunk_rows", "vqhip_rvq_chain_ws_stride", "vqhip_rvq_chain_forward")
+           "vqhip_ema_accumulate_stages", "vqhip_rvq_chain_chunk_rows", "vqhip_rvq_chain_ws_stride", "vqhip_rvq_chain_forward",
+           "vqhip_ema_finalize_table")
 
 
 def _check(rc, what):
@@ -566,6 +569,14 @@ def rvq_row_chunks(N: int) -> int:
     return max(1, min(k, N // 65536))
 
 
+def grvq_row_chunks(N: int, G: int) -> int:
+    """Row chunks of the batched grouped chain (GroupedResidualVQ._forward_batched).  Every launch already carries the G groups'
+    workgroups (cfg 5: 4 096 per screening launch, eight rounds of the chip's 512 slots), and splitting the rows on top only adds
+    launches: cfg 5 on one box, same process conditions -- 1 chunk 14.04-14.32 ms, 2 chunks 14.22-14.57, 3 chunks 14.60-14.82
+    (gpurun_out/r6b -> profiles/r6_grvq_cfg5/chunks.txt).  VQHIP_GRVQ_CHUNKS overrides."""
+    return 1
+
+
 @_on_device
 def rvq_forward_chained(x: torch.Tensor, packed: torch.Tensor, embed: torch.Tensor, Q: int, *, row_mask=None, stage_hook=None,
                         fill_masked=True, route_mode=0, row_chunks=1):
@@ -674,7 +685,10 @@ class _RvqChain(ctypes.Structure):       # vqhip_rvq_chain_t (include/vqhip.h)
                 ("stats", ctypes.c_void_p), ("stats_stride", ctypes.c_int64), ("stats_ws", ctypes.c_void_p), ("stats_ws_stride", ctypes.c_size_t),
                 ("sqerr_partial", ctypes.c_void_p), ("sqerr_stride", ctypes.c_int64),
                 ("chunks", ctypes.c_int64), ("chunk_streams", ctypes.c_void_p), ("stats_stream", ctypes.c_void_p),
-                ("events", ctypes.c_void_p), ("n_events", ctypes.c_int64)]
+                ("events", ctypes.c_void_p), ("n_events", ctypes.c_int64),
+                ("groups", ctypes.c_int64), ("x_gstride", ctypes.c_int64), ("packed_gstride", ctypes.c_int64), ("embed_gstride", ctypes.c_int64),
+                ("codes_gstride", ctypes.c_int64), ("stats_gstride", ctypes.c_int64), ("stats_ws_gstride", ctypes.c_size_t),
+                ("sqerr_gstride", ctypes.c_int64)]
 
 
 _CHAIN_EVENTS = {}
@@ -693,22 +707,34 @@ def _chain_events(device, main, n):
 
 @_on_device
 def rvq_chain_forward(x: torch.Tensor, packed: torch.Tensor, embed: torch.Tensor, Q: int, *, row_mask=None, route_mode=0, row_chunks=1,
-                      stats=None, stats_ws=None, sq_parts=None, stats_stream=None):
+                      stats=None, stats_ws=None, sq_parts=None, stats_stream=None, groups=1):
     """The residual loop (rvq.py:469-568) in ONE library call (vqhip_rvq_chain_forward): the Q chained screened searches -- or, with
     route_mode, the routed residuals + plain searches of a gradient step -- in row_chunks interleaved chunks, and every stage's EMA
     statistics (+ loss partials into sq_parts [Q, P]) on stats_stream.  Same results as rvq_forward_chained with a stage hook that
     calls ema_accumulate; the host enqueues one call instead of ~100 launches from Python.
     stats [Q, stride] zeroed, stats_ws from ema_workspaces(Q, N, C) (histograms zeroed).  The statistics stream is NOT joined here.
-    -> dict(idx [..., Q], inputs (list of Q views), bufs [Q - 1, N, D], counts (per stage: per-chunk counters))"""
+    -> dict(idx [..., Q], inputs (list of Q views), bufs [Q - 1, N, D], counts (per stage: per-chunk counters))
+    groups = G > 1 (round 6): the G independent loops of a GroupedResidualVQ (rvq.py:634-724) as one launch set.  x [..., G D] -- group g
+    owns the feature chunk g D .. (g + 1) D --, embed [G, C, D] (every group one codebook shared by its stages) or [G, Q, C, D], packed
+    [G, P] / [G, Q, P], stats [G, Q, stride], stats_ws [G, Q, bytes], sq_parts [G, Q, P].
+    -> idx [G, ..., Q], bufs [Q - 1, G, N, D], inputs None, counts per stage: counters [K, G]"""
     _need_gpu(x, packed, embed, row_mask, stats, stats_ws, sq_parts)
-    shared = embed.ndim == 2
-    xk, N, D, ldx = as_rows(x)
+    G = int(groups)
+    if G > 1:
+        assert x.shape[-1] % G == 0
+        shared = embed.ndim == 3
+        xk, N, Dall, ldx = as_rows(x)
+        D = Dall // G
+        assert embed.shape[0] == G and packed.shape[0] == G and (shared or (embed.shape[1] >= Q and packed.shape[1] >= Q))
+    else:
+        shared = embed.ndim == 2
+        xk, N, D, ldx = as_rows(x)
     lead, dev = x.shape[:-1], x.device
     C = embed.shape[-2]
-    assert embed.dtype == torch.float32 and embed.is_contiguous() and packed.is_contiguous()
+    assert embed.dtype == torch.float32 and embed.is_contiguous() and packed.is_contiguous() and embed.shape[-1] == D
     assert xk.dtype == torch.float32 or (route_mode and xk.dtype == torch.bfloat16), "chained stages: float32 rows"
-    idx = torch.empty(N, Q, dtype=torch.int64, device=dev)
-    bufs = torch.empty(max(Q - 1, 1), N, D, dtype=xk.dtype, device=dev)
+    idx = torch.empty(*((G,) if G > 1 else ()), N, Q, dtype=torch.int64, device=dev)
+    bufs = torch.empty(max(Q - 1, 1), *((G,) if G > 1 else ()), N, D, dtype=xk.dtype, device=dev)
     if row_mask is not None:
         row_mask = row_mask.reshape(-1).to(torch.uint8).contiguous()
     main = torch.cuda.current_stream(dev)
@@ -716,24 +742,34 @@ def rvq_chain_forward(x: torch.Tensor, packed: torch.Tensor, embed: torch.Tensor
     rpc = lib().vqhip_rvq_chain_chunk_rows(N, K)
     K = (N + rpc - 1) // rpc
     wss = lib().vqhip_rvq_chain_ws_stride(N, K)
-    ws = torch.empty(Q * K, wss, dtype=torch.uint8, device=dev)
+    ws = torch.empty(Q * K * G, wss, dtype=torch.uint8, device=dev)
     codes = None
     if route_mode:
         codes = embed if xk.dtype == torch.float32 else embed.to(xk.dtype)      # (bf16 rows: the routing kernel gathers bf16 code rows)
+    pfl = packed.element_size()
     st = _RvqChain(x=xk.data_ptr(), x_dtype=_dtype_code(xk), N=N, D=D, ldx=ldx, packed=packed.data_ptr(),
-                   packed_qstride=0 if shared else packed.stride(0) * packed.element_size() // 4, embed=embed.data_ptr(),
-                   embed_qstride=0 if shared else embed.stride(0), C=C, Q=Q, idx_out=idx.data_ptr(), inputs=bufs.data_ptr(),
+                   packed_qstride=0 if shared else packed.stride(-2) * pfl // 4, embed=embed.data_ptr(),
+                   embed_qstride=0 if shared else embed.stride(-3), C=C, Q=Q, idx_out=idx.data_ptr(), inputs=bufs.data_ptr(),
                    row_mask=None if row_mask is None else row_mask.data_ptr(), workspace=ws.data_ptr(), workspace_bytes=ws.numel(),
                    route_mode=int(route_mode), codes=None if codes is None else codes.data_ptr(),
-                   codes_qstride=0 if (codes is None or shared) else codes.stride(0), chunks=K)
+                   codes_qstride=0 if (codes is None or shared) else codes.stride(-3), chunks=K)
+    if G > 1:
+        st.groups, st.x_gstride = G, D
+        st.packed_gstride, st.embed_gstride = packed.stride(0) * pfl // 4, embed.stride(0)
+        st.codes_gstride = 0 if codes is None else codes.stride(0)
     keep = [codes]
     if stats is not None:
-        assert stats.dtype == torch.float32 and stats.ndim == 2 and stats.shape[0] >= Q and stats.stride(1) == 1
-        assert stats_ws is not None and stats_ws.dtype == torch.uint8 and stats_ws.shape[0] >= Q and stats_ws.stride(1) == 1 and stats_ws.data_ptr() % 256 == 0
-        st.stats, st.stats_stride, st.stats_ws, st.stats_ws_stride = stats.data_ptr(), stats.stride(0), stats_ws.data_ptr(), stats_ws.stride(0)
+        assert stats.dtype == torch.float32 and stats.stride(-1) == 1 and stats.shape[-2] >= Q and stats.ndim == (3 if G > 1 else 2)
+        assert stats_ws is not None and stats_ws.dtype == torch.uint8 and stats_ws.shape[-2] >= Q and stats_ws.stride(-1) == 1 and stats_ws.data_ptr() % 256 == 0
+        st.stats, st.stats_stride, st.stats_ws, st.stats_ws_stride = stats.data_ptr(), stats.stride(-2), stats_ws.data_ptr(), stats_ws.stride(-2)
+        if G > 1:
+            assert stats.shape[0] == G and stats_ws.shape[0] == G and stats_ws.stride(0) % 256 == 0
+            st.stats_gstride, st.stats_ws_gstride = stats.stride(0), stats_ws.stride(0)
         if sq_parts is not None:
-            assert sq_parts.dtype == torch.float64 and sq_parts.shape[0] >= Q and sq_parts.stride(1) == 1
-            st.sqerr_partial, st.sqerr_stride = sq_parts.data_ptr(), sq_parts.stride(0)
+            assert sq_parts.dtype == torch.float64 and sq_parts.shape[-2] >= Q and sq_parts.stride(-1) == 1
+            st.sqerr_partial, st.sqerr_stride = sq_parts.data_ptr(), sq_parts.stride(-2)
+            if G > 1:
+                st.sqerr_gstride = sq_parts.stride(0)
         if stats_stream is not None:
             st.stats_stream = stats_stream.cuda_stream
     side = stats is not None and stats_stream is not None and stats_stream.cuda_stream != main.cuda_stream
@@ -747,11 +783,15 @@ def rvq_chain_forward(x: torch.Tensor, packed: torch.Tensor, embed: torch.Tensor
         st.events, st.n_events = ctypes.cast(earr, ctypes.c_void_p), Q * K + 1
         keep += [evs, earr]
     _check(lib().vqhip_rvq_chain_forward(ctypes.byref(st), _stream()), "vqhip_rvq_chain_forward")
+    # keepalive: the statistics stream is not joined here and still reads the uint8 row mask made above (allocated on the CALLER's
+    # stream: freed at return, the caching allocator would hand its memory to the caller's next allocation while those kernels run)
+    if G > 1:
+        wsi = ws.view(Q, K, G, wss)
+        counts = [(wsi[q, :, :, 0:4].view(torch.int32)[..., 0], wsi[q, :, :, 4:8].view(torch.int32)[..., 0]) for q in range(Q)]
+        return dict(idx=idx.view(G, *lead, Q), inputs=None, counts=counts, bufs=bufs, keepalive=(row_mask, codes, ws))
     wsi = ws.view(Q, K, wss)
     counts = [(wsi[q, :, 0:4].view(torch.int32)[:, 0], wsi[q, :, 4:8].view(torch.int32)[:, 0]) for q in range(Q)]
     inputs = [x] + [bufs[q].view(*lead, D) for q in range(Q - 1)]
-    # keepalive: the statistics stream is not joined here and still reads the uint8 row mask made above (allocated on the CALLER's
-    # stream: freed at return, the caching allocator would hand its memory to the caller's next allocation while those kernels run)
     return dict(idx=idx.view(*lead, Q), inputs=inputs, counts=counts, bufs=bufs, keepalive=(row_mask, codes, ws))
 
 
@@ -1223,6 +1263,27 @@ def ema_finalize_batched(cluster_size, embed_avg, embed, stats, *, decay, eps, c
                                             float(eps), int(cosine), int(do_update_ema), _ptr(denom), _stream()), "vqhip_ema_finalize_batched")
 
 
+def pointer_table(tensors) -> torch.Tensor:
+    """device int64 tensor of the tensors' data pointers (row-major over the nesting): the argument of vqhip_ema_finalize_table"""
+    flat = [t.data_ptr() for row in tensors for t in row]
+    dev = tensors[0][0].device
+    return torch.tensor(flat, dtype=torch.int64).to(dev, non_blocking=False).view(len(tensors), -1)
+
+
+@_on_device
+def ema_finalize_table(table: torch.Tensor, stats: torch.Tensor, C: int, D: int, *, decay, eps, cosine=False, do_update_ema=True):
+    """The folds of H codebooks kept in separate buffers (the layers of a grouped / residual VQ) in three launches: table [H, 3] from
+    pointer_table([(cluster_size [C], embed_avg [C, D], embed [C, D]), ...]), stats [H, stride] = embed_sum || count per head."""
+    _need_gpu(table, stats)
+    H = table.shape[0]
+    assert table.dtype == torch.int64 and table.is_contiguous() and table.shape[1] == 3
+    assert stats.dtype == torch.float32 and stats.ndim == 2 and stats.shape[0] == H and stats.stride(1) == 1 and stats.shape[1] >= C * D + C
+    denom = torch.empty(H, C, dtype=torch.float32, device=stats.device) if do_update_ema else None
+    omd = float(torch.tensor(1.0 - decay, dtype=torch.float64).to(torch.float32))
+    _check(lib().vqhip_ema_finalize_table(_ptr(table), _ptr(stats), stats.stride(0), H, C, D, omd, float(eps), int(cosine), int(do_update_ema),
+                                          _ptr(denom), _stream()), "vqhip_ema_finalize_table")
+
+
 @_on_device
 def ema_accumulate_stages(inputs: torch.Tensor, idx: torch.Tensor, stage0: int, C: int, stats: torch.Tensor, ws: torch.Tensor, *,
                           row_mask=None, sqerr_from=None, sqerr_out=None):
@@ -1314,7 +1375,8 @@ def assign_rowwise(x: torch.Tensor, codes: torch.Tensor, cosine=False) -> torch.
 @_on_device
 def decode_sum(idx: torch.Tensor, embed: torch.Tensor, out_dtype=torch.float32, out=None) -> torch.Tensor:
     """idx [..., Q] int64, embed [Q, C, D] or [C, D] (shared by all Q) -> [..., D] = sum_q embed_q[idx_q].
-    out (optional): a contiguous [..., D] tensor to write, e.g. one slice of a stacked [Q, ..., D] result."""
+    out (optional): a [..., D] tensor to write -- contiguous (one slice of a stacked [Q, ..., D] result) or a feature chunk of a wider
+    contiguous tensor (rows at a uniform stride)."""
     _need_gpu(idx, embed)
     assert idx.dtype == torch.int64 and embed.dtype == torch.float32 and embed.is_contiguous()
     idx = idx.contiguous()
@@ -1327,14 +1389,18 @@ def decode_sum(idx: torch.Tensor, embed: torch.Tensor, out_dtype=torch.float32, 
         _, C, D = embed.shape
         qstride = C * D
     N = idx.numel() // Q
+    ldo = D
     if out is None:
         out = torch.empty(*idx.shape[:-1], D, dtype=out_dtype, device=idx.device)
     else:
+        # contiguous, or a feature chunk of a wider contiguous tensor (a group's slice of GroupedResidualVQ's output: no torch.cat)
         out_dtype = out.dtype
-        assert out.is_contiguous() and out.numel() == N * D and out_dtype in (torch.float32, torch.bfloat16) and out.device == idx.device
+        ok, oN, oD, ldo = as_rows(out)
+        assert ok.data_ptr() == out.data_ptr() and oN == N and oD == D, "decode_sum: out must be row-addressable in place"
+        assert out_dtype in (torch.float32, torch.bfloat16) and out.device == idx.device
     if N > 0:
         _check(lib().vqhip_decode_sum(_ptr(idx), N, Q, _ptr(embed), qstride, C, D, _ptr(out),
-                                      F32 if out_dtype == torch.float32 else BF16, D, _stream()), "vqhip_decode_sum")
+                                      F32 if out_dtype == torch.float32 else BF16, ldo, _stream()), "vqhip_decode_sum")
     return out
 
 

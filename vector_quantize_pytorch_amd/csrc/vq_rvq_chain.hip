@@ -12,6 +12,10 @@
 //   * when stage q is final in every chunk (one event per chunk stream), its statistics pass is queued on stats_stream beside the
 //     later stages' searches;
 //   * on return `stream` has been joined with the chunk streams; the statistics stream is left to the caller to join.
+//
+// Round 6: G independent loops -- the groups of GroupedResidualVQ (rvq.py:634-724, the loop over `self.rvqs` at :706) -- as ONE launch
+// set: every launch above carries blockIdx.y = group (the batched-head forms of the screening kernel, the exact passes and the
+// statistics), so a grouped module is Q x (1 screen + 3 exact-pass + 4 statistics launches) instead of G times that on G streams.
 #include "vqhip_internal.h"
 
 static inline size_t rc_align(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -42,6 +46,7 @@ extern "C" int vqhip_rvq_chain_forward(const vqhip_rvq_chain_t *c, void *stream)
     if (!c) VQ_FAIL(VQHIP_EINVAL, "rvq_chain_forward: null argument block");
     const int64_t N = c->N, Q = c->Q;
     const int D = (int)c->D, C = (int)c->C, dt = (int)c->x_dtype;
+    const int G = c->groups > 1 ? (int)c->groups : 1;
     if (N < 0 || Q < 1 || C < 1) VQ_FAIL(VQHIP_EINVAL, "rvq_chain_forward: bad size");
     if (N == 0) return 0;
     if (!c->x || !c->packed || !c->embed || !c->idx_out || !c->workspace) VQ_FAIL(VQHIP_EINVAL, "rvq_chain_forward: null pointer");
@@ -63,15 +68,22 @@ extern "C" int vqhip_rvq_chain_forward(const vqhip_rvq_chain_t *c, void *stream)
     if (need_ev > 0 && (!c->events || c->n_events < need_ev))
         VQ_FAIL(VQHIP_EINVAL, "rvq_chain_forward: needs %lld events (Q x chunks + 1)", (long long)need_ev);
     const size_t wss = vqhip_rvq_chain_ws_stride(N, K);
-    if (c->workspace_bytes < wss * (size_t)(Q * K)) VQ_FAIL(VQHIP_EINVAL, "rvq_chain_forward: workspace too small");
+    if (c->workspace_bytes < wss * (size_t)(Q * K * G)) VQ_FAIL(VQHIP_EINVAL, "rvq_chain_forward: workspace too small");
     if (((uintptr_t)c->workspace) & 255) VQ_FAIL(VQHIP_EALIGN, "rvq_chain_forward: workspace must be 256-byte aligned");
     if (want_stats && (!c->stats_ws || c->stats_ws_stride < vqhip_ema_batched_ws_stride(N, C) || c->stats_stride < (int64_t)C * D + C))
         VQ_FAIL(VQHIP_EINVAL, "rvq_chain_forward: statistics need stats_ws slices of vqhip_ema_batched_ws_stride(N, C) bytes and stats_stride >= C D + C");
     const int es = dt == VQHIP_BF16 ? 2 : 4;
+    if (G > 1) {
+        if (c->x_gstride < D || ((c->x_gstride * es) & 15)) VQ_FAIL(VQHIP_EALIGN, "rvq_chain_forward: the groups' rows must be D or more elements apart and stay 16-byte aligned");
+        if (c->packed_gstride <= 0 || c->embed_gstride <= 0) VQ_FAIL(VQHIP_EINVAL, "rvq_chain_forward: groups need packed_gstride and embed_gstride");
+        if (want_stats && (c->stats_gstride < (int64_t)C * D + C || c->stats_ws_gstride < vqhip_ema_batched_ws_stride(N, C)))
+            VQ_FAIL(VQHIP_EINVAL, "rvq_chain_forward: groups need stats_gstride >= C D + C and stats_ws_gstride >= vqhip_ema_batched_ws_stride(N, C)");
+        if (routed && c->codes_gstride <= 0) VQ_FAIL(VQHIP_EINVAL, "rvq_chain_forward: groups with routed residuals need codes_gstride");
+    }
     hipStream_t main = (hipStream_t)stream;
     hipError_t e;
-    // the Q x K list headers (16 bytes each) in one launch
-    hipLaunchKernelGGL(vq_chain_headers_kernel, dim3((unsigned)((Q * K + 15) / 16)), dim3(64), 0, main, (char *)c->workspace, wss, (int)(Q * K));
+    // the Q x K x G list headers (16 bytes each) in one launch
+    hipLaunchKernelGGL(vq_chain_headers_kernel, dim3((unsigned)((Q * K * G + 15) / 16)), dim3(64), 0, main, (char *)c->workspace, wss, (int)(Q * K * G));
     if (int rc = vq_launch_status("vq_chain_headers_kernel")) return rc;
     hipEvent_t *ev = (hipEvent_t *)c->events;
     if (K > 1) {                                                   // fork: the chunk streams start behind everything queued on `stream`
@@ -83,7 +95,28 @@ extern "C" int vqhip_rvq_chain_forward(const vqhip_rvq_chain_t *c, void *stream)
     }
     const char *x0 = (const char *)c->x;
     char *inputs = (char *)c->inputs;
-    const size_t in_stage = (size_t)N * D * es;                    // bytes between consecutive stage inputs
+    const size_t in_group = (size_t)N * D * es;                    // bytes between the groups' blocks of one stage input
+    const size_t in_stage = in_group * (size_t)G;                  // bytes between consecutive stage inputs ([Q - 1, G, N, D])
+    const int64_t idx_g = N * Q;                                   // int64 elements between the groups' index blocks ([G, N, Q])
+    const size_t bf16_off = vq_packed_bf16_offset(C, D);
+
+    // stage q's statistics (+ loss partials) for all groups on `ss`
+    auto stage_stats = [&](int64_t q, hipStream_t ss) -> int {
+        const float *packed_q = c->packed + q * c->packed_qstride;
+        const float *embed_q = c->embed + q * c->embed_qstride;
+        const void *xin = q == 0 ? c->x : (const void *)(inputs + (size_t)(q - 1) * in_stage);
+        float *st_q = c->stats + q * c->stats_stride;
+        double *sq_q = c->sqerr_partial ? c->sqerr_partial + q * c->sqerr_stride : nullptr;
+        void *ws_q = (char *)c->stats_ws + (size_t)q * c->stats_ws_stride;
+        if (G == 1)
+            return vqhip_ema_accumulate_prezeroed(xin, dt, N, D, q == 0 ? c->ldx : D, c->idx_out + q, Q, c->row_mask, C, st_q + (size_t)C * D, st_q,
+                                                  ws_q, c->stats_ws_stride, sq_q ? packed_q : nullptr, sq_q ? embed_q : nullptr, sq_q, ss);
+        const void *qsrc = !sq_q ? nullptr : (dt == VQHIP_BF16 ? (const void *)((const char *)packed_q + bf16_off) : (const void *)embed_q);
+        return vq_ema_accumulate_heads(xin, dt, G, N, D, q == 0 ? c->ldx : D, q == 0 ? c->x_gstride * es : (int64_t)in_group, c->idx_out + q, Q,
+                                       idx_g * 8, c->row_mask, C, st_q + (size_t)C * D, st_q, c->stats_gstride * 4, ws_q, (int64_t)c->stats_ws_gstride, 1,
+                                       qsrc, dt == VQHIP_BF16 ? c->packed_gstride * 4 : c->embed_gstride * 4, sq_q, c->sqerr_gstride * 8, ss);
+    };
+
     for (int64_t q = 0; q < Q; ++q) {
         const float *packed_q = c->packed + q * c->packed_qstride;
         const float *embed_q = c->embed + q * c->embed_qstride;
@@ -95,24 +128,38 @@ extern "C" int vqhip_rvq_chain_forward(const vqhip_rvq_chain_t *c, void *stream)
             ch.route_mode = 0; ch.header_zeroed = 1;
             const void *src = x0 + (size_t)r0 * c->ldx * es;
             int64_t lds = c->ldx;
+            int64_t src_g = c->x_gstride * es;                     // bytes between the groups' rows of this stage's search input
             if (q > 0 && routed) {
                 // the previous layer returned its ROUTED value and rvq.py:524 subtracted that: its own HBM-bound kernel writes this
                 // stage's input, which the search then reads like a first stage's
                 const void *psrc = q == 1 ? src : (const void *)(inputs + (size_t)(q - 2) * in_stage + (size_t)r0 * D * es);
                 const int64_t plds = q == 1 ? c->ldx : D;
+                const int64_t psrc_g = q == 1 ? c->x_gstride * es : (int64_t)in_group;
                 void *dst = inputs + (size_t)(q - 1) * in_stage + (size_t)r0 * D * es;
                 const void *codes = (const char *)c->codes + (size_t)(q - 1) * c->codes_qstride * es;
-                if (int rc = vqhip_route_residual(psrc, dt, n_k, D, plds, codes, c->idx_out + r0 * Q + (q - 1), Q, (int)c->route_mode, dst, D, st)) return rc;
-                src = dst; lds = D;
+                for (int g = 0; g < G; ++g)
+                    if (int rc = vqhip_route_residual((const char *)psrc + (size_t)g * psrc_g, dt, n_k, D, plds, (const char *)codes + (size_t)g * c->codes_gstride * es,
+                                                      c->idx_out + (int64_t)g * idx_g + r0 * Q + (q - 1), Q, (int)c->route_mode, (char *)dst + (size_t)g * in_group, D, st)) return rc;
+                src = dst; lds = D; src_g = (int64_t)in_group;
             } else if (q > 0) {
                 ch.prev_idx = c->idx_out + r0 * Q + (q - 1);
                 ch.prev_embed = c->embed + (q - 1) * c->embed_qstride;
                 ch.x_out = inputs + (size_t)(q - 1) * in_stage + (size_t)r0 * D * es;
-                if (q > 1) { src = inputs + (size_t)(q - 2) * in_stage + (size_t)r0 * D * es; lds = D; }
+                if (q > 1) { src = inputs + (size_t)(q - 2) * in_stage + (size_t)r0 * D * es; lds = D; src_g = (int64_t)in_group; }
             }
-            void *ws = (char *)c->workspace + (size_t)(q * K + k) * wss;
-            if (int rc = vqhip_assign_screened_chain(src, dt, n_k, D, lds, packed_q, embed_q, C, VQHIP_EUCLID, c->idx_out + r0 * Q + q,
-                                                     c->row_mask ? c->row_mask + r0 : nullptr, ws, wss, &ch, st)) return rc;
+            void *ws = (char *)c->workspace + (size_t)(q * K + k) * G * wss;
+            if (G == 1) {
+                if (int rc = vqhip_assign_screened_chain(src, dt, n_k, D, lds, packed_q, embed_q, C, VQHIP_EUCLID, c->idx_out + r0 * Q + q,
+                                                         c->row_mask ? c->row_mask + r0 : nullptr, ws, wss, &ch, st)) return rc;
+            } else {
+                VqHeadStrides hs;
+                hs.heads = G;
+                hs.x = src_g; hs.packed = c->packed_gstride * 4; hs.embed = c->embed_gstride * 4;
+                hs.codes = dt == VQHIP_BF16 ? hs.packed : hs.embed;
+                hs.idx = idx_g * 8; hs.q = 0; hs.ws = (int64_t)wss; hs.xo = (int64_t)in_group;
+                if (int rc = vq_assign_screened_impl(src, dt, n_k, D, lds, packed_q, embed_q, C, VQHIP_EUCLID, c->idx_out + r0 * Q + q, nullptr, D, nullptr, D,
+                                                     nullptr, c->row_mask ? c->row_mask + r0 : nullptr, ws, wss, nullptr, &ch, 1, st, &hs)) return rc;
+            }
             if (need_ev > 0 && (stats_side || q + 1 == Q))
                 if ((e = hipEventRecord(ev[q * K + k], st)) != hipSuccess) VQ_FAIL((int)e, "rvq_chain_forward: hipEventRecord: %s", hipGetErrorString(e));
         }
@@ -121,27 +168,13 @@ extern "C" int vqhip_rvq_chain_forward(const vqhip_rvq_chain_t *c, void *stream)
             hipStream_t ss = (hipStream_t)c->stats_stream;
             for (int k = 0; k < K; ++k)
                 if ((e = hipStreamWaitEvent(ss, ev[q * K + k], 0)) != hipSuccess) VQ_FAIL((int)e, "rvq_chain_forward: hipStreamWaitEvent: %s", hipGetErrorString(e));
-            const void *xin = q == 0 ? c->x : (const void *)(inputs + (size_t)(q - 1) * in_stage);
-            float *st_q = c->stats + q * c->stats_stride;
-            if (int rc = vqhip_ema_accumulate_prezeroed(xin, dt, N, D, q == 0 ? c->ldx : D, c->idx_out + q, Q, c->row_mask, C, st_q + (size_t)C * D, st_q,
-                                                        (char *)c->stats_ws + (size_t)q * c->stats_ws_stride, c->stats_ws_stride,
-                                                        c->sqerr_partial ? packed_q : nullptr, c->sqerr_partial ? embed_q : nullptr,
-                                                        c->sqerr_partial ? c->sqerr_partial + q * c->sqerr_stride : nullptr, ss)) return rc;
+            if (int rc = stage_stats(q, ss)) return rc;
         }
     }
     for (int k = 1; k < K; ++k)                                    // join: `stream` continues behind every chunk's last stage
         if ((e = hipStreamWaitEvent(main, ev[(Q - 1) * K + k], 0)) != hipSuccess) VQ_FAIL((int)e, "rvq_chain_forward: hipStreamWaitEvent: %s", hipGetErrorString(e));
-    if (want_stats && !stats_side) {
-        for (int64_t q = 0; q < Q; ++q) {                          // no statistics stream (e.g. under graph capture): behind the loop
-            const void *xin = q == 0 ? c->x : (const void *)(inputs + (size_t)(q - 1) * in_stage);
-            float *st_q = c->stats + q * c->stats_stride;
-            const float *packed_q = c->packed + q * c->packed_qstride;
-            const float *embed_q = c->embed + q * c->embed_qstride;
-            if (int rc = vqhip_ema_accumulate_prezeroed(xin, dt, N, D, q == 0 ? c->ldx : D, c->idx_out + q, Q, c->row_mask, C, st_q + (size_t)C * D, st_q,
-                                                        (char *)c->stats_ws + (size_t)q * c->stats_ws_stride, c->stats_ws_stride,
-                                                        c->sqerr_partial ? packed_q : nullptr, c->sqerr_partial ? embed_q : nullptr,
-                                                        c->sqerr_partial ? c->sqerr_partial + q * c->sqerr_stride : nullptr, main)) return rc;
-        }
-    }
+    if (want_stats && !stats_side)
+        for (int64_t q = 0; q < Q; ++q)                            // no statistics stream (e.g. under graph capture): behind the loop
+            if (int rc = stage_stats(q, main)) return rc;
     return 0;
 }

@@ -128,6 +128,7 @@ __global__ void __launch_bounds__(VQS_WAVES * 64, 8 / VQS_WAVES) vq_screen16_ker
     const int half = lane >> 5;
     const int64_t wrow0 = (int64_t)blockIdx.x * VQ_SCREEN_ROWS + wave * 64;
     VQ_PHASE(0);
+#ifdef VQ_DEV_SWITCHES
     if (a.stagger > 0 && (int)blockIdx.x < a.stagger_first) {
         // the workgroup whose LDS allocation does not start at 0 is the second one on its CU (HW_REG_LDS_ALLOC, LDS_BASE field)
         const bool second_wg = (__builtin_amdgcn_s_getreg((11 << 11) | (0 << 6) | 6) & 0xfff) != 0;
@@ -136,6 +137,7 @@ __global__ void __launch_bounds__(VQS_WAVES * 64, 8 / VQS_WAVES) vq_screen16_ker
             while ((long long)__builtin_readcyclecounter() - t0 < wait) __builtin_amdgcn_s_sleep(8);
         }
     }
+#endif
 
     // ---- first buffer: wave w copies the 1-KiB pieces w, w + WAVES, ... ----
     constexpr int PSTRIDE = VQS_WAVES * 1024;
@@ -1340,8 +1342,8 @@ int vq_assign_screened_impl(const void *x, int x_dtype, int64_t N, int D, int64_
                             int header_zeroed, void *stream, const VqHeadStrides *hs)
 {
     const int heads = (hs && hs->heads > 1) ? hs->heads : 1;
-    if (heads > 1 && (resid_out || sqerr_partial || debug_out || chain))
-        VQ_FAIL(VQHIP_EINVAL, "assign_screened: a batched launch has index and q outputs only");
+    if (heads > 1 && (resid_out || sqerr_partial || debug_out))
+        VQ_FAIL(VQHIP_EINVAL, "assign_screened: a batched launch has index and q outputs only (and the residual chain's x_out)");
     if (N < 0 || C <= 0) VQ_FAIL(VQHIP_EINVAL, "assign_screened: N < 0 or C <= 0");
     if (N == 0) return 0;
     if (!x || !packed || !embed || !idx_out || !workspace) VQ_FAIL(VQHIP_EINVAL, "assign_screened: null pointer");
@@ -1388,22 +1390,26 @@ int vq_assign_screened_impl(const void *x, int x_dtype, int64_t N, int D, int64_
     }
     a.heads = heads;
     a.hs_x = hs ? hs->x : 0; a.hs_packed = hs ? hs->packed : 0; a.hs_embed = hs ? hs->embed : 0;
-    a.hs_idx = hs ? hs->idx : 0; a.hs_q = hs ? hs->q : 0; a.hs_ws = hs ? hs->ws : 0;
+    a.hs_idx = hs ? hs->idx : 0; a.hs_q = hs ? hs->q : 0; a.hs_ws = hs ? hs->ws : 0; a.hs_xo = hs ? hs->xo : 0;
     a.idx_stride = chain ? chain->idx_stride : 1;
     a.prev_idx = chain ? chain->prev_idx : nullptr;
     a.prev_idx_stride = chain ? chain->prev_idx_stride : 1;
     a.prev_embed = chain ? chain->prev_embed : nullptr;
     a.x_out = chain ? (float *)chain->x_out : nullptr;
     a.ldxo = chain ? chain->ldxo : 0;
-    {   // dev switches (A/B measurements only): VQHIP_SCREEN_STAGGER=<k> start offset of every CU's second workgroup, x 1024 cycles;
+    a.stagger = 0;
+    a.stagger_first = 512;
+#ifdef VQ_DEV_SWITCHES
+    {   // dev builds only (make HIPFLAGS+=-DVQ_DEV_SWITCHES; A/B measurements of round 5, tools/time_chain_stage.py):
+        // VQHIP_SCREEN_STAGGER=<k> start offset of every CU's second workgroup, x 1024 cycles;
         // VQHIP_CHAIN_NOWRITE=1 a chained stage does not store its input (TIMING ONLY: the exact passes then read stale rows)
         static int stag = -1, nowrite = -1;
         if (stag < 0) { const char *e = getenv("VQHIP_SCREEN_STAGGER"); stag = e ? atoi(e) : 0; }
         if (nowrite < 0) { const char *e = getenv("VQHIP_CHAIN_NOWRITE"); nowrite = (e && e[0] == '1') ? 1 : 0; }
         a.stagger = stag;
-        a.stagger_first = 512;
         if (nowrite) a.x_out = nullptr;
     }
+#endif
 #ifdef VQ_TRACE
     a.trace = vq_g_trace;
 #endif
@@ -1416,16 +1422,21 @@ int vq_assign_screened_impl(const void *x, int x_dtype, int64_t N, int D, int64_
         default: rc = dispatch_screen<512>(a, x_dtype, metric, st); break;
     }
     if (rc) return rc;
-    {   // VQHIP_SCREEN_ONLY=1 (dev tools that time the screening kernel by itself): leave the listed rows undecided
+#ifdef VQ_DEV_SWITCHES
+    {   // VQHIP_SCREEN_ONLY=1 (dev tools that time the screening kernel by itself; dev builds only): leave the listed rows undecided
         static int only = -1;
         if (only < 0) { const char *e = getenv("VQHIP_SCREEN_ONLY"); only = (e && e[0] == '1') ? 1 : 0; }
         if (only) return 0;
     }
+#endif
     const int with_pairs = 1;                                       // the screening kernels build the pair list as well
     // a chained stage's rows were materialised by its screening kernel: the exact passes read them there
-    const void *xl = (chain && chain->prev_idx) ? (const void *)chain->x_out : x;
-    const int64_t ldl = (chain && chain->prev_idx) ? chain->ldxo : ldx;
+    const bool chained = chain && chain->prev_idx;
+    const void *xl = chained ? (const void *)chain->x_out : x;
+    const int64_t ldl = chained ? chain->ldxo : ldx;
+    VqHeadStrides hl;
+    if (hs) { hl = *hs; if (chained) hl.x = hs->xo; }
     return vq_assign_listed(xl, x_dtype, metric, N, D, ldl, packed, embed, C, idx_out, a.idx_stride, q_out, ldq, resid_out, ldr,
                             sqerr_partial ? sqerr_partial + vqhip_screen_blocks(N, x_dtype) : nullptr, row_mask, rows, count, keys,
-                            with_pairs, st, hs);
+                            with_pairs, st, hs ? &hl : nullptr);
 }

@@ -54,9 +54,11 @@ struct ScreenArgs {
     // packs the segments into flag_rows / flag_keys and writes flag_count)
     // several heads in one launch (vqhip_assign_screened_batched: blockIdx.y = head): byte strides between consecutive heads' rows,
     // packed codebooks, fp32 codebooks, index / q outputs and workspaces.  heads <= 1: a plain launch.  (No residual / squared-error
-    // / chain outputs in a batched launch.)
+    // outputs in a batched launch.)  Round 6: the residual chain batches too -- the G groups of GroupedResidualVQ (rvq.py:634-724)
+    // are the heads: prev_idx sits in the same index block as idx_out (hs_idx), prev_embed is laid out like embed (hs_embed), x_out
+    // has its own stride (hs_xo: the stage inputs are [G, N, D] blocks, the caller's rows may be feature chunks of a wider tensor).
     int heads;
-    int64_t hs_x, hs_packed, hs_embed, hs_idx, hs_q, hs_ws;
+    int64_t hs_x, hs_packed, hs_embed, hs_idx, hs_q, hs_ws, hs_xo;
     int *seg_counts;                   // [2 * VQ_SEG_MAX]: open, pair entries per segment
     int *seg_rows;                     // [VQ_SEG_MAX * seg_cap]
     unsigned long long *seg_keys;      // [VQ_SEG_MAX * seg_cap]
@@ -83,6 +85,11 @@ __device__ __forceinline__ ScreenArgs vq_head_screen_args(const ScreenArgs &a0)
     a.flag_count = (int *)((char *)a0.flag_count + h * a0.hs_ws);
     a.flag_rows = (int *)((char *)a0.flag_rows + h * a0.hs_ws);
     a.flag_keys = (unsigned long long *)((char *)a0.flag_keys + h * a0.hs_ws);
+    if (a0.prev_idx) {
+        a.prev_idx = (const int64_t *)((const char *)a0.prev_idx + h * a0.hs_idx);
+        a.prev_embed = (const float *)((const char *)a0.prev_embed + h * a0.hs_embed);
+        if (a0.x_out) a.x_out = (float *)((char *)a0.x_out + h * a0.hs_xo);
+    }
     return a;
 }
 

@@ -3612,6 +3612,24 @@ extern "C" int vqhip_ema_accumulate_stages(const void *x, int x_dtype, int S, in
                                wss, qsrc, sqerr_partial, stream, &f);
 }
 
+// The statistics of H independent (rows, codebook) pairs in one set of launches with every stride given by the caller (bytes): the G
+// groups of a grouped residual VQ at one stage (vq_rvq_chain.hip; rvq.py:634-724 runs them one after the other).  count / embed_sum of
+// head h sit h * hs_stats behind head 0's; hist_zeroed as in vqhip_ema_accumulate_prezeroed.  Euclidean.
+int vq_ema_accumulate_heads(const void *x, int x_dtype, int H, int64_t N, int D, int64_t ldx, int64_t hs_x, const int64_t *idx,
+                            int64_t idx_stride, int64_t hs_idx, const uint8_t *row_mask, int C, float *count, float *embed_sum,
+                            int64_t hs_stats, void *workspace, int64_t hs_ws, int hist_zeroed, const void *qsrc, int64_t hs_qsrc,
+                            double *sqerr_partial, int64_t hs_sq, void *stream)
+{
+    if (H < 1 || D < 1 || D > 512 || C <= 0) VQ_FAIL(VQHIP_EINVAL, "ema_accumulate_heads: bad size");
+    if (hs_ws < (int64_t)vqhip_ema_batched_ws_stride(N, C)) VQ_FAIL(VQHIP_EINVAL, "ema_accumulate_heads: workspace slices too small");
+    StatsFuse f;
+    f.hist_zeroed = hist_zeroed ? 1 : 0; f.cs = nullptr; f.denom = nullptr; f.omd = 0.f; f.eps = 0.f;
+    f.heads = H;
+    f.hs_x = hs_x; f.hs_idx = hs_idx; f.hs_ws = hs_ws; f.hs_stats = hs_stats; f.hs_qsrc = hs_qsrc; f.hs_sq = hs_sq;
+    return ema_accumulate_impl(x, x_dtype, N, D, ldx, idx, idx_stride, nullptr, VQHIP_EUCLID, row_mask, C, count, embed_sum, workspace,
+                               (size_t)hs_ws, qsrc, sqerr_partial, stream, &f);
+}
+
 // ------------------------------------------------------------------------------------------------
 // EMA fold + codebook renormalisation
 // ------------------------------------------------------------------------------------------------
@@ -3766,6 +3784,62 @@ extern "C" int vqhip_ema_finalize_batched(float *cluster_size, float *embed_avg,
     hipLaunchKernelGGL(vq_ema_embed_kernel, dim3((C + 3) / 4, H), dim3(256), 0, st, embed_avg, embed, stats, (const float *)nullptr, denom_ws, C, D,
                        one_minus_decay, cosine, 1, do_update_ema, stats_stride);
     return launch_status("vq_ema_finalize_batched");
+}
+
+// The same three launches for H codebooks whose buffers are SEPARATE allocations -- the layers of a (grouped) residual VQ, each with its
+// own cluster_size / embed_avg / embed module buffers (state_dict keys layers.{i}._codebook.*): `table` holds H triples of device
+// pointers (cluster_size [C], embed_avg [C, D], embed [C, D]), head h's statistics sit at stats + h * stats_stride.
+__global__ void __launch_bounds__(256) vq_ema_cs_lerp_tab_kernel(const uintptr_t *table, const float *stats, int64_t stats_stride, int C, int D, float omd)
+{
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    float *cs = (float *)table[3 * blockIdx.y];
+    const float *count = stats + blockIdx.y * stats_stride + (size_t)C * D;
+    cs[c] = aten_lerp(cs[c], count[c], omd);
+}
+
+__global__ void __launch_bounds__(256) vq_ema_denom_tab_kernel(const uintptr_t *table, int C, float eps, float ceps, float *denom)
+{
+    const float *cs_g = (const float *)table[3 * blockIdx.y];
+    denom += (size_t)blockIdx.y * C;
+    __shared__ float part[32];
+    __shared__ float total_s;
+    extern __shared__ float cs_lds[];
+    const int tid = threadIdx.x;
+    const float *cs = cs_g;
+    if (C <= 16384) {
+        for (int c = tid; c < C; c += 256) cs_lds[c] = cs_g[c];
+        __syncthreads();
+        cs = cs_lds;
+    }
+    ema_denom_block<256>(cs, C, eps, ceps, denom, part, &total_s);
+}
+
+__global__ void __launch_bounds__(256) vq_ema_embed_tab_kernel(const uintptr_t *table, const float *stats, int64_t stats_stride, const float *denom,
+                                                               int C, int D, float omd, int cosine, int do_update)
+{
+    const size_t h = blockIdx.y;
+    ema_embed_row((float *)table[3 * h + 1], (float *)table[3 * h + 2], stats + h * stats_stride, nullptr, denom ? denom + h * C : nullptr,
+                  C, D, omd, cosine, 1, do_update, blockIdx.x * 4 + (threadIdx.x >> 6));
+}
+
+extern "C" int vqhip_ema_finalize_table(const void *table, const float *stats, int64_t stats_stride, int H, int C, int D,
+                                        float one_minus_decay, float eps, int cosine, int do_update_ema, float *denom_ws, void *stream)
+{
+    if (!table || !stats || C <= 0 || H < 1) VQ_FAIL(VQHIP_EINVAL, "ema_finalize_table: bad argument");
+    if (D < 1 || D > 512) VQ_FAIL(VQHIP_EDIM, "ema_finalize_table: D=%d unsupported (1..512)", D);
+    if (stats_stride < (int64_t)C * D + C) VQ_FAIL(VQHIP_EINVAL, "ema_finalize_table: stats_stride smaller than C D + C");
+    if (do_update_ema && !denom_ws) VQ_FAIL(VQHIP_EINVAL, "ema_finalize_table: do_update_ema needs denom_ws [H, C]");
+    hipStream_t st = (hipStream_t)stream;
+    const uintptr_t *tab = (const uintptr_t *)table;
+    hipLaunchKernelGGL(vq_ema_cs_lerp_tab_kernel, dim3((C + 255) / 256, H), dim3(256), 0, st, tab, stats, stats_stride, C, D, one_minus_decay);
+    if (do_update_ema) {
+        const float ceps = (float)((double)C * (double)eps);
+        hipLaunchKernelGGL(vq_ema_denom_tab_kernel, dim3(1, H), dim3(256), (C <= 16384 ? (size_t)C * 4 : 0), st, tab, C, eps, ceps, denom_ws);
+    }
+    hipLaunchKernelGGL(vq_ema_embed_tab_kernel, dim3((C + 3) / 4, H), dim3(256), 0, st, tab, stats, stats_stride, denom_ws, C, D, one_minus_decay,
+                       cosine, do_update_ema);
+    return launch_status("vq_ema_finalize_table");
 }
 
 // Renormalisation of ONE SHARD of a codebook partitioned over ranks (parallel.ShardedVectorQuantize): the Laplace smoothing of

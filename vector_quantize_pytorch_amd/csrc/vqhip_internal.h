@@ -108,6 +108,7 @@ static inline size_t vq_packed_total_bytes(int C, int D)
 struct VqHeadStrides {
     int heads;          // <= 1: a plain launch
     int64_t x, packed, embed, codes, idx, q, ws;
+    int64_t xo = 0;     // a chained stage's x_out (the exact passes read their rows there)
 };
 int vq_assign_listed(const void *x, int x_dtype, int metric, int64_t N, int D, int64_t ldx, const float *packed, const float *embed, int C,
                      int64_t *idx_out, int64_t idx_stride, void *q_out, int64_t ldq, void *resid_out, int64_t ldr, double *sqerr_partial,
@@ -121,6 +122,13 @@ int vq_assign_screened_impl(const void *x, int x_dtype, int64_t N, int D, int64_
                             void *resid_out, int64_t ldr, double *sqerr_partial, const uint8_t *row_mask,
                             void *workspace, size_t workspace_bytes, float *debug_out, const vqhip_chain_t *chain,
                             int header_zeroed, void *stream, const VqHeadStrides *hs = nullptr);
+
+// statistics of H (rows, codebook) pairs in one launch set, every head stride in bytes (vqhip.hip); qsrc: the loss' code rows in x's
+// dtype (nullable with sqerr_partial)
+int vq_ema_accumulate_heads(const void *x, int x_dtype, int H, int64_t N, int D, int64_t ldx, int64_t hs_x, const int64_t *idx,
+                            int64_t idx_stride, int64_t hs_idx, const uint8_t *row_mask, int C, float *count, float *embed_sum,
+                            int64_t hs_stats, void *workspace, int64_t hs_ws, int hist_zeroed, const void *qsrc, int64_t hs_qsrc,
+                            double *sqerr_partial, int64_t hs_sq, void *stream);
 
 // ---- codebook dims 512 < D <= 2048 (vq_wide.hip): plain exact kernels behind the same entry points --------------------------------
 #define VQ_WIDE_MAX_D 2048

@@ -63,10 +63,14 @@ class MLP(nn.Module):
         return x[0] if one_headed else x
 
 
+_GROUPS_CONCURRENT = [False]      # True while GroupedResidualVQ.forward runs its groups on side streams: the groups interleave with each
+                                  # other already, so their residual chains are not split into row chunks as well (a context, not an
+                                  # attribute written onto the child modules: a child used on its own keeps its chunking)
+
+
 class ResidualVQ(nn.Module):
     concurrent_stats = True       # fused loop: stage statistics on a side HIP stream beside the later searches (class attribute)
-    chunk_rows = True             # fused loop: big batches run as interleaved row chunks (L.rvq_row_chunks); GroupedResidualVQ turns
-                                  # it off for its groups while they run concurrently (instance attribute there)
+    chunk_rows = True             # fused loop: big batches run as interleaved row chunks (L.rvq_row_chunks)
 
     def __init__(
         self,
@@ -416,7 +420,8 @@ class ResidualVQ(nn.Module):
                 # (row chunks interleave two chains so that one's exact passes run beside the other's screening kernel; a grouped
                 #  module's groups already do that for each other.  Not under graph capture: nested forks, see above.)
                 capturing = x.is_cuda and torch.cuda.is_current_stream_capturing()
-                K = 1 if (capturing or not self.chunk_rows) else L.rvq_row_chunks(x.numel() // D)
+                no_chunks = capturing or not self.chunk_rows or (_GROUPS_CONCURRENT[0] and os.environ.get("VQHIP_GRVQ_CHUNK_ROWS", "0") != "1")
+                K = 1 if no_chunks else L.rvq_row_chunks(x.numel() // D)
                 native = (batch_mode == 0 and x.numel() > 0 and not (update and vq0._codebook.use_cosine_sim)
                           and os.environ.get("VQHIP_RVQ_NATIVE", "1") != "0")
                 if native:
@@ -426,6 +431,7 @@ class ResidualVQ(nn.Module):
                                             stats=buf if update else None, stats_ws=stats_ws if update else None,
                                             sq_parts=sq_parts if (update and want_loss) else None,
                                             stats_stream=side if (update and hook is not None) else None)
+                    self.last_counts = r["counts"]      # per stage: (open rows, pair rows) device counters, one per row chunk (diagnostic)
                     if mask is not None and hook is None:
                         L.mask_fill_indices(r["idx"], mask)
                 else:
@@ -712,6 +718,119 @@ class GroupedResidualVQ(nn.Module):
     def get_output_from_indices(self, indices):
         return torch.cat(tuple(r.get_output_from_indices(i) for r, i in zip(self.rvqs, indices)), dim=self.split_dim)
 
+    # ---- the G groups as ONE launch set (round 6; csrc/vq_rvq_chain.hip, vqhip_rvq_chain_t.groups) ----------------------------------
+    batched_groups = True         # class attribute; VQHIP_GRVQ_BATCHED=0 keeps the groups on side streams
+
+    def _batched_eligible(self, x, chunks, mask, freeze_codebook):
+        """can the groups' residual loops run as one batched chain?  The no-grad on-device loop of every group (ResidualVQ._forward_fused on
+        the native chain) with the same stage count: fp32 rows, codebook dim in {32, 64, 128, 256}, plain EMA / frozen codebooks,
+        no quantize dropout, no beam search, no projections, channel-last rows."""
+        if not (self.batched_groups and os.environ.get("VQHIP_GRVQ_BATCHED", "1") != "0" and x.is_cuda and self.groups > 1
+                and x.ndim == 3 and not self.accept_image_fmap and x.numel() > 0 and L.screening_enabled()):
+            return False
+        if os.environ.get("VQHIP_RVQ_NATIVE", "1") == "0" or int(os.environ.get("VQHIP_RVQ_BATCH_STATS", "0")) != 0:
+            return False
+        r0 = self.rvqs[0]
+        for r, c in zip(self.rvqs, chunks):
+            beam = r.beam_size if r.training else r.eval_beam_size
+            if (r.has_projections or r.diveq or (beam is not None and beam > 1) or (r.training and r.quantize_dropout)
+                    or r.training != r0.training or r._wants_input_grad(c) or not r._fused_eligible(c, mask)
+                    or not r._chain_eligible(c, freeze_codebook) or r.layers[0]._codebook.use_cosine_sim):
+                return False
+            for layer in r.layers:
+                cb = layer._codebook
+                if cb.cluster_size.grad is not None or cb.embed_avg.grad is not None:
+                    return False
+        return True
+
+    def _fold_table(self, Q):
+        """device table of the (cluster_size, embed_avg, embed) pointers of every layer, group-major -- rebuilt only when a buffer moved"""
+        bufs = [r.layers[q]._codebook._views(0) for r in self.rvqs for q in range(Q)]
+        key = tuple(t.data_ptr() for b in bufs for t in b)
+        cached = getattr(self, "_fold_table_cache", None)
+        if cached is None or cached[0] != key:
+            cached = (key, L.pointer_table(bufs))
+            self._fold_table_cache = cached
+        return cached[1]
+
+    @torch.no_grad()
+    def _forward_batched(self, x, mask, freeze_codebook):
+        """rvq.py:634-724 with the loop over the groups (:706) as grid dimension y of ONE residual chain: Q x (screen + exact passes +
+        statistics) launches for all groups, the decode of every group straight into its feature chunk of the output (no torch.cat),
+        all G x Q EMA folds in three launches."""
+        G, r0 = self.groups, self.rvqs[0]
+        Q, D, C = r0.num_quantizers, r0.codebook_dim, r0.codebook_size
+        vq0 = r0.layers[0]
+        dev = x.device
+        x = x if x.is_contiguous() else x.contiguous()
+        N = x.numel() // x.shape[-1]
+        shared = r0.shared_codebook
+        if shared:
+            embed = torch.stack([r.layers[0]._codebook.embed[0] for r in self.rvqs])                       # [G, C, D]
+            packed = L.pack_codebook_batched(embed)                                                        # [G, P]
+        else:
+            embed = torch.stack([layer._codebook.embed[0] for r in self.rvqs for layer in r.layers]).view(G, Q, C, D)
+            packed = L.pack_codebook_batched(embed.view(G * Q, C, D)).view(G, Q, -1)
+        update, want_loss = r0._update_and_loss(freeze_codebook)
+        stride = (C * D + C + 3) // 4 * 4
+        buf = torch.zeros(G, Q, stride, dtype=torch.float32, device=dev) if update else None
+        sq_parts = torch.empty(G, Q, L.lib().vqhip_ema_sqerr_partials(N, C), dtype=torch.float64, device=dev) if (update and want_loss) else None
+        stats_ws = L.ema_workspaces(G * Q, N, C, dev).view(G, Q, -1) if update else None
+        main = torch.cuda.current_stream(dev)
+        capturing = torch.cuda.is_current_stream_capturing()
+        side = None
+        if update and r0.concurrent_stats and not capturing:
+            side = _stats_stream(dev, main)
+            side.wait_stream(main)
+        env = os.environ.get("VQHIP_GRVQ_CHUNKS")
+        K = 1 if capturing else (int(env) if env else L.grvq_row_chunks(N, G))
+        r = L.rvq_chain_forward(x, packed, embed, Q, row_mask=mask, row_chunks=K, stats=buf, stats_ws=stats_ws, sq_parts=sq_parts,
+                                stats_stream=side, groups=G)
+        self.last_counts = r["counts"]                  # per stage: (open rows, pair rows) counters [chunks, G] (device, diagnostic)
+        idx = r["idx"]                                  # [G, b, n, Q]
+        if mask is not None:
+            if side is not None:
+                main.wait_stream(side)                  # the statistics passes have read idx
+            idx.masked_fill_(~mask.reshape(1, *idx.shape[1:-1], 1).bool(), -1)
+        out = torch.empty_like(x)
+        for g in range(G):
+            L.decode_sum(idx[g], embed[g], out=out[..., g * D:(g + 1) * D])
+
+        if update:
+            if side is not None:
+                if vq0._codebook.use_ddp:
+                    with torch.cuda.stream(side):       # ONE all-reduce for every group and stage, beside the decode
+                        dist.all_reduce(buf)
+                main.wait_stream(side)
+            elif vq0._codebook.use_ddp:
+                dist.all_reduce(buf)
+        losses = torch.zeros(G, Q, device=dev, dtype=torch.float32)
+        if want_loss and sq_parts is not None:
+            sums = L.reduce_partials_rows(sq_parts.view(G * Q, -1)).view(G, Q)
+            denom = float(N * D) if mask is None else (mask.sum() * D).to(torch.float32)
+            losses = sums / denom * vq0.commitment_weight
+        if self.training:
+            losses = torch.zeros(G, Q, device=dev, requires_grad=True) + losses                            # as vqp.py:1282
+
+        if update:
+            cb0 = vq0._codebook
+            if shared:
+                for g, rv in enumerate(self.rvqs):      # the Q folds of a group's one codebook in stage order + its renormalisation
+                    cs, ea, e = rv.layers[0]._codebook._views(0)
+                    L.ema_fold_many(cs, ea, e, buf[g], decay=cb0.decay, eps=cb0.eps, cosine=False, do_update_ema=bool(r0.vq_is_ema_updating))
+            else:
+                L.ema_finalize_table(self._fold_table(Q), buf.view(G * Q, stride), C, D, decay=cb0.decay, eps=cb0.eps, cosine=False,
+                                     do_update_ema=bool(cb0.ema_update and not cb0.manual_ema_update))
+                if cb0.has_dead_code_replacement:       # vqp.py:641, per layer, after all the folds (as ResidualVQ._forward_fused)
+                    cbs = [(g, q, rv.layers[q]._codebook) for g, rv in enumerate(self.rvqs) for q in range(Q)]
+                    host = [i for i, (_, _, cb) in enumerate(cbs) if cb.expiry_reads_host()]
+                    known = dict(zip(host, type(cb0).any_expired_many([cbs[i][2] for i in host]))) if len(host) > 1 else {}
+                    for i, (g, q, cb) in enumerate(cbs):
+                        stage_in = x[..., g * D:(g + 1) * D] if q == 0 else r["bufs"][q - 1, g]
+                        cb.expire_codes_(stage_in.reshape(1, -1, D), seq_mask=None if mask is None else mask.reshape(1, -1).bool(),
+                                         any_expired=known.get(i))
+        return out, idx, losses
+
     @other_float_dtypes_as_fp32
     def forward(self, x, indices=None, return_all_codes=False, sample_codebook_temp=None, freeze_codebook=False, mask=None):
         if indices is not None and len(indices) > 0:
@@ -723,24 +842,31 @@ class GroupedResidualVQ(nn.Module):
             seed = _draw_seed(x.device, need_value=any(r.quantize_dropout for r in self.rvqs))
         kw = dict(return_all_codes=return_all_codes, sample_codebook_temp=sample_codebook_temp, mask=mask,
                   freeze_codebook=freeze_codebook, rand_quantize_dropout_fixed_seed=seed)
+        if self._batched_eligible(x, chunks, mask, freeze_codebook):
+            ret = self._forward_batched(x, mask, freeze_codebook)
+            if return_all_codes:
+                ret = (*ret, self.get_codes_from_indices(ret[1]))
+            return ret
         if x.is_cuda and self.groups > 1 and self.concurrent_groups:
             # The groups share nothing (own codebooks, own feature chunk): each runs on its own HIP stream, forked from and
             # joined back into the caller's stream, so that one group's short exact-pass / statistics kernels run beside another
             # group's search instead of leaving the chip mostly idle.  Host code order (and with it RNG consumption) is unchanged.
             cur = torch.cuda.current_stream(x.device)
             side = self._side_streams(x.device)
-            for r in self.rvqs:             # the groups interleave with each other already (VQHIP_GRVQ_CHUNK_ROWS=1: chunks on top)
-                r.chunk_rows = os.environ.get("VQHIP_GRVQ_CHUNK_ROWS", "0") == "1"
             fork = torch.cuda.Event()
             fork.record(cur)
             outs = []
-            for g, (r, c) in enumerate(zip(self.rvqs, chunks)):
-                if g == 0:
-                    outs.append(r(c, **kw))
-                    continue
-                side[g - 1].wait_event(fork)
-                with torch.cuda.stream(side[g - 1]):
-                    outs.append(r(c, **kw))
+            _GROUPS_CONCURRENT[0] = True    # (the groups interleave with each other already: no row chunks inside them)
+            try:
+                for g, (r, c) in enumerate(zip(self.rvqs, chunks)):
+                    if g == 0:
+                        outs.append(r(c, **kw))
+                        continue
+                    side[g - 1].wait_event(fork)
+                    with torch.cuda.stream(side[g - 1]):
+                        outs.append(r(c, **kw))
+            finally:
+                _GROUPS_CONCURRENT[0] = False
             for g in range(1, self.groups):
                 cur.wait_stream(side[g - 1])
                 for t in outs[g]:
