@@ -85,6 +85,47 @@ def test_sharded_argmin_merge_equals_full_codebook(tmp_path, cosine):
     assert not ((idx == 70) | (idx == 99)).any()
 
 
+def _gather_worker(rank, world, port, out, chunks):
+    from vector_quantize_pytorch_amd.parallel import gathered_search, shard_bounds
+    _init(rank, world, port)
+    g = torch.Generator().manual_seed(5)
+    n, C, D = 1003, 100, 32            # 1003 rows per rank: chunks of unequal size, the last one shorter
+    x = torch.randn(world, n, D, generator=g); e = torch.randn(C, D, generator=g)
+    e[70] = e[10]                      # a duplicate across the shards: the lowest global index must win in every chunking
+    lo, hi = shard_bounds(C, world, rank)
+    shard = e[lo:hi].contiguous()
+
+    def search(rows):
+        idx, best = O.c_assign(rows, shard)
+        return best, idx
+
+    parts, gidx, local = gathered_search(x[rank].contiguous(), search, (lo, hi), euclid=True, chunks=chunks)
+    rows = torch.cat([p.reshape(world, -1, D) for p, _ in parts], dim=1)       # the gathered chunks back in row order
+    assert torch.equal(rows, x) and [o for _, o in parts] == sorted(o for _, o in parts)
+    if rank == 0:
+        torch.save(dict(gidx=gidx, local=local), out)
+    dist.destroy_process_group()
+
+
+def test_chunked_row_gather_of_the_sharded_search_returns_the_unchunked_indices(tmp_path):
+    """parallel.gathered_search (round 6): the rows of all ranks all-gathered in K chunks, chunk k + 1 travelling and chunk k - 1's
+    keys being MAX-reduced while chunk k is searched -- K = 1, 2, 4 (ragged chunks) give the same global and local indices as the
+    search of the whole batch against the full codebook."""
+    world = 2
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(world, 1003, 32, generator=g); e = torch.randn(100, 32, generator=g)
+    e[70] = e[10]
+    want, _ = O.c_assign(x.reshape(-1, 32), e)
+    for K in (1, 2, 4):
+        port, out = _free_port(), str(tmp_path / f"g{K}.pt")
+        mp.spawn(_gather_worker, args=(world, port, out, K), nprocs=world, join=True)
+        r = torch.load(out)
+        assert torch.equal(r["gidx"], want), f"chunks={K}"
+        lo, hi = 0, 50
+        assert torch.equal(r["local"], torch.where((want >= lo) & (want < hi), want - lo, torch.full_like(want, -1)))
+    assert not (want == 70).any()
+
+
 def _sample_worker(rank, world, port, out):
     from vector_quantize_pytorch_amd.codebook import sample_rows_distributed
     _init(rank, world, port)

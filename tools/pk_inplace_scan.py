@@ -3,7 +3,7 @@ pair is also a source AND whose op_sel / op_sel_hi make one half read the OTHER 
 `v_pk_mul_f32 v[0:1], v[2:3], v[0:1] op_sel_hi:[1,0]`: the high half multiplies by v0, which the low half of the same instruction
 overwrites).  Element-wise in-place forms (each half reads its own register) are not counted.
 
-    python tools/pk_inplace_scan.py file.s [file.s ...]"""
+    python tools/pk_inplace_scan.py [--fail] file.s [file.s ...]        (also reads llvm-objdump -d output; --fail: exit 1 on any hit)"""
 import re
 import sys
 
@@ -48,8 +48,13 @@ def scan(path):
     return total, inplace, cross, per
 
 
-for p in sys.argv[1:]:
+fail = "--fail" in sys.argv
+bad = 0
+for p in [a for a in sys.argv[1:] if a != "--fail"]:
     t, i, c, per = scan(p)
+    bad += c
     print(f"{p}: packed fp32 {t}, in-place {i}, in-place with a cross-half read of the destination pair {c}")
     for k, v in sorted(per.items(), key=lambda kv: -kv[1])[:8]:
         print(f"      {v:4d}  {k}")
+if fail and bad:
+    sys.exit(f"{bad} packed-fp32 instruction(s) read their own destination pair across halves")

@@ -27,7 +27,12 @@
 //            < 9 % of the model, tests/test_gpu_screen_fuzz.py::test_mfma_accumulation_error_within_model
 //   sqrt collapse: distances that differ by < 4 ulp(s) may round to the same sqrt (vqp.py:62) and tie: 8 u s
 //   index bits: the kernel stores the lane-local code number in the 4 low mantissa bits of t: 2 * 16 ulp(t)
-// A row is certified when  t_best - t_second > eps_t,  eps_t = eps_s (an s margin of 2 eps_s).  tests/test_gpu_ops.py measures the
+// Round 6: the bound is charged PER CODE.  Every term above is a bound for one code's score with Y = ||c||; the codebook-wide maxima
+// they used to be evaluated with made one large-norm (or badly rounded) code raise the threshold of every row.  Now
+//   e(c) = Rrow + Arow ||c|| + kb ||c||^2,   Rrow = 5 u x2 + X r0 + 2e-8,   Arow = X (u (10 + D + 2.002 (D + 1)) + rho) + ||x' - x_h|| + conv,
+// with ||c - c_h|| <= rho ||c|| + r0 (vq_pack16_kernel: rho measured, <= 2^-12).  The sweep ADDS Arow ||c|| + kb ||c||^2 to each code's
+// start value (||c|| per code in the tile tail), so what it tracks are upper bounds U_c >= true score - Rrow, and
+// A row is certified when  U_best - 2 (Arow ||c_best|| + kb ||c_best||^2) - U_second > 2 Rrow (+ index bits).  tests/test_gpu_ops.py measures the
 // actual |t - t_exact| against this bound and tests/test_gpu_screen_fuzz.py checks 1.6e7 adversarial rows per run bit for bit.
 
 #include <math.h>
@@ -400,27 +405,33 @@ __global__ void __launch_bounds__(VQS_WAVES * 64, 8 / VQS_WAVES) vq_screen16_ker
         iSSv[rb] = __uint_as_float((unsigned)(127 - SXv[rb] - sc) << 23);
     }
 
-    // ---- threshold (unscaled units; see the file header for the terms that did not change) ----
-    float eps[2];
+    // ---- the certificate's pieces (unscaled units; file header).  Per code c the screen's score errs against the reference's own
+    //      arithmetic by at most  e(c) = Rrow + Arow ||c|| + kb ||c||^2  (kb ||c||^2 is inside the tile's start value, vq_pack16_kernel):
+    //      the sweep adds Arow ||c|| to every start value, so the tracked scores are UPPER bounds U_c = t_c + (code part of e(c)), and
+    //      the winner is certified when  U_1 - 2 (code part of the winner) - U_2 > 2 Rrow  -- no codebook-wide maximum anywhere ----
+    float ArowS[2], Rrow[2], Arow[2];
     {
-        const float y2max = __uint_as_float(a.scalars[0]);
-        const float rmax = __uint_as_float(a.scalars[1]);
-        const float ymax = sqrtf(y2max) * 1.0001f;
+        const float rho = __uint_as_float(a.scalars[1]);
+        const float r0 = __uint_as_float(a.scalars[3]);
         const float u = 5.9604645e-8f;   // 2^-24
 #pragma unroll
         for (int rb = 0; rb < 2; ++rb) {
-            // truncated elements: |dx_k| <= 2^-24 / S each, sum_k |dx_k| |c1_k - c2_k| <= 2^-24 / S * sqrt(D) * 2 Y
-            const float conv = NPART * 2.f * 5.9604645e-8f * sqrtf((float)DT) * ymax * __uint_as_float((unsigned)(127 - SXv[rb]) << 23);
+            const float iS = __uint_as_float((unsigned)(127 - SXv[rb]) << 23);
             const float xs = xs2[rb];
             const float xn = sqrtf(xs) * 1.0001f;
-            const float xy = xn * ymax;
-            // the part of x' the operand set(s) do not carry, for both codes of the margin: one set -- the measured ||x' - x_h|| Y;
-            // two sets -- 2^-20 X Y
-            const float drop = !XF32 ? 0.f : (NPART == 1 ? 2.f * rxn[rb] * ymax : 2.f * 9.5367432e-7f * 1.01f * xy);
             const float nacc = (float)(NPART * DT + 1);
-            if (METRIC == 0) eps[rb] = u * (10.f * (xs + y2max + 2.f * xy) + 2.f * DT * xy + 4.f * nacc * 1.001f * (xy + 0.5f * y2max))
-                                       + 2.f * xn * rmax + drop + conv + 4e-8f;
-            else             eps[rb] = 2.f * (u * (DT + 2.f * NPART * DT) * 1.001f * xy + xn * rmax) + drop + conv + 1e-30f;
+            // truncated elements: |dx_k| <= 2^-24 / S each, sum_k |dx_k| |c_k| <= 2^-24 / S * sqrt(D) * ||c||   (per operand set)
+            const float conv = NPART * u * sqrtf((float)DT) * iS;
+            // the part of x' the operand set(s) do not carry: one set -- the measured ||x' - x_h|| ||c||; two sets -- 2^-20 X ||c||
+            const float drop = !XF32 ? 0.f : (NPART == 1 ? rxn[rb] : 9.5367432e-7f * 1.01f * xn);
+            if (METRIC == 0) {
+                Arow[rb] = (xn * (u * (10.f + (float)DT + 2.002f * nacc) + rho) + drop + conv) * 1.0001f;
+                Rrow[rb] = 5.f * u * xs + xn * r0 + 2e-8f;
+            } else {
+                Arow[rb] = (xn * (u * (float)(DT + 2 * NPART * DT) * 1.001f + rho) + drop + conv) * 1.0001f;
+                Rrow[rb] = xn * r0 + 1e-30f;
+            }
+            ArowS[rb] = Arow[rb] * SSv[rb];
         }
     }
 
@@ -481,30 +492,38 @@ __global__ void __launch_bounds__(VQS_WAVES * 64, 8 / VQS_WAVES) vq_screen16_ker
         for (int p = 0; p < PF2; ++p) af[p] = ap[p * 64];
         // start value -||c||^2 / 2 (scaled); register e <-> code 8 (e >> 2) + 4 half + (e & 3) of the tile.  Tiles with padding
         // codes clamp it to a finite -3e38 (see the skewed sweep).  fp32 rows: each row block has its own scale.
+        // + (row factor) x ||c|| (tile tail, floats 32 ..): the score becomes an upper bound of the code's true score (certificate above)
         f32x16 init0, init1;
-        if (METRIC == 0 || has_pad) {
+        {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 f32x4 v = *(const f32x4 *)(nh + 8 * q);
+                const f32x4 w = *(const f32x4 *)(nh + 32 + 8 * q);
                 if (METRIC != 0) { v.x = v.x < -1e38f ? v.x : 0.f; v.y = v.y < -1e38f ? v.y : 0.f;
                                    v.z = v.z < -1e38f ? v.z : 0.f; v.w = v.w < -1e38f ? v.w : 0.f; }
-                init0[4 * q + 0] = v.x * SSv[0]; init0[4 * q + 1] = v.y * SSv[0]; init0[4 * q + 2] = v.z * SSv[0]; init0[4 * q + 3] = v.w * SSv[0];
-                if (XF32) { init1[4 * q + 0] = v.x * SSv[1]; init1[4 * q + 1] = v.y * SSv[1]; init1[4 * q + 2] = v.z * SSv[1]; init1[4 * q + 3] = v.w * SSv[1]; }
+                const float vs[4] = {v.x, v.y, v.z, v.w}, ws[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if (METRIC == 0 || has_pad) {
+                        init0[4 * q + i] = __builtin_fmaf(ws[i], ArowS[0], vs[i] * SSv[0]);
+                        init1[4 * q + i] = __builtin_fmaf(ws[i], ArowS[1], vs[i] * SSv[1]);
+                    } else {
+                        init0[4 * q + i] = ws[i] * ArowS[0];
+                        init1[4 * q + i] = ws[i] * ArowS[1];
+                    }
+                }
             }
             if (has_pad) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) { init0[r] = fmaxf(init0[r], -3.0e38f); if (XF32) init1[r] = fmaxf(init1[r], -3.0e38f); }
+                for (int r = 0; r < 16; ++r) { init0[r] = fmaxf(init0[r], -3.0e38f); init1[r] = fmaxf(init1[r], -3.0e38f); }
             }
-        } else {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { init0[r] = 0.f; if (XF32) init1[r] = 0.f; }
         }
 #pragma unroll
         for (int s = 0; s < NK; ++s) {
             const f16x8 av = __builtin_bit_cast(f16x8, af[s % PF2]);
             if (s == 0) {
                 C0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, __builtin_bit_cast(f16x8, xb[0][s]), init0, 0, 0, 0);
-                C1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, __builtin_bit_cast(f16x8, xb[1][s]), XF32 ? init1 : init0, 0, 0, 0);
+                C1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, __builtin_bit_cast(f16x8, xb[1][s]), init1, 0, 0, 0);
             } else {
                 C0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, __builtin_bit_cast(f16x8, xb[0][s]), C0, 0, 0, 0);
                 C1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, __builtin_bit_cast(f16x8, xb[1][s]), C1, 0, 0, 0);
@@ -610,7 +629,16 @@ __global__ void __launch_bounds__(VQS_WAVES * 64, 8 / VQS_WAVES) vq_screen16_ker
         const int id2 = second_low ? il1 : ih2;
         const float b3 = second_low ? fmaxf(h2, l2) : fmaxf(h3, l1);
         code[rb] = ih1;
-        const float thr = eps[rb] * SSv[rb] + 8e-6f * fabsf(b1);
+        // the winner's own code part, A ||c|| + kb ||c||^2 (what the sweep added to its score, and the bound of its error): ||c|| from
+        // the tile tail of the packed codebook
+        const float kb = 5.9604645e-8f * (5.f + 1.001f * (float)(DT + 1) + 0.51f) * 1.001f;
+        auto code_part = [&](int c) {
+            const int cc = c < a.C ? c : 0;
+            const float yb = *(const float *)(a.tiles16 + (size_t)(cc >> 5) * TILE_B + 64 * DT + (32 + (cc & 31)) * 4);
+            return (Arow[rb] * yb + (METRIC == 0 ? kb * yb * yb * 1.001f : 0.f)) * 1.0001f;
+        };
+        const float cp1 = code_part(ih1);
+        const float thr = (2.f * cp1 + 2.f * Rrow[rb]) * SSv[rb] + 8e-6f * fabsf(b1);
 #ifdef VQS16_NO_SWEEP
         const bool certified = true;
 #else
@@ -621,8 +649,11 @@ __global__ void __launch_bounds__(VQS_WAVES * 64, 8 / VQS_WAVES) vq_screen16_ker
         if (row_ok[rb] && half == 0) {
             a.idx_out[rows[rb] * a.idx_stride] = (int64_t)(code[rb] < a.C ? code[rb] : 0);
             if (a.dbg) {
+                // debug view in the units of t = x.c - ||c||^2 / 2: the two best scores with the certificate's code parts taken off
+                // again, and the margin they have to exceed (certified <=> d[0] - d[1] > d[2])
                 float *d = a.dbg + rows[rb] * 4;
-                d[0] = b1 * iSSv[rb]; d[1] = b2 * iSSv[rb]; d[2] = thr * iSSv[rb]; d[3] = certified ? 0.f : (pair ? 2.f : 1.f);
+                const float cp2 = code_part(id2);
+                d[0] = b1 * iSSv[rb] - cp1; d[1] = b2 * iSSv[rb] - cp2; d[2] = thr * iSSv[rb] - cp1 + cp2; d[3] = certified ? 0.f : (pair ? 2.f : 1.f);
             }
         }
         if (code[rb] >= a.C) code[rb] = 0;
@@ -929,23 +960,27 @@ __global__ void __launch_bounds__(VQS_F32_WAVES * 64, (XBF16 && NPART == 1 && DT
         if (NPART == 1) rx2 += __shfl_xor(rx2, 32, 64);
     }
 
-    float eps;
+    // the certificate's pieces, per code (vq_screen16_kernel above): e(c) = Rrow + Arow ||c|| + kb ||c||^2
+    float Arow, Rrow, ArowS;
     {
-        const float y2max = __uint_as_float(a.scalars[0]);
-        const float rmax = __uint_as_float(a.scalars[1]);
-        const float ymax = sqrtf(y2max) * 1.0001f;
+        const float rho = __uint_as_float(a.scalars[1]);
+        const float r0 = __uint_as_float(a.scalars[3]);
         const float u = 5.9604645e-8f;   // 2^-24
-        const float conv = 2.f * NPART * 5.9604645e-8f * sqrtf((float)DT) * ymax * iS;   // truncated elements of each operand set
+        const float conv = NPART * u * sqrtf((float)DT) * iS;                                    // truncated elements of each operand set
         const float xn = sqrtf(xs2) * 1.0001f;
-        const float xy = xn * ymax;
-        // the part of x' the operand sets do not carry, for both codes of the margin
+        // the part of x' the operand sets do not carry: 2^-20 X ||c|| (two sets) / the measured ||x' - x_h|| ||c|| (one set)
         float drop = 0.f;
-        if (!XBF16 && NPART == 2) drop = 2.f * 9.5367432e-7f * 1.01f * xy;                       // 2^-20 X Y
-        if (!XBF16 && NPART == 1) drop = 2.f * sqrtf(rx2 * 1.001f) * 1.001f * iS * ymax;          // ||x' - x_h|| Y, measured
+        if (!XBF16 && NPART == 2) drop = 9.5367432e-7f * 1.01f * xn;
+        if (!XBF16 && NPART == 1) drop = sqrtf(rx2 * 1.001f) * 1.001f * iS;
         const float nacc = (float)(NPART * DT + 1);                                               // accumulated terms
-        if (METRIC == 0) eps = u * (10.f * (xs2 + y2max + 2.f * xy) + 2.f * DT * xy + 4.f * nacc * 1.001f * (xy + 0.5f * y2max))
-                               + 2.f * xn * rmax + drop + conv + 4e-8f;
-        else             eps = 2.f * (u * (DT + 2.f * NPART * DT) * 1.001f * xy + xn * rmax) + drop + conv + 1e-30f;
+        if (METRIC == 0) {
+            Arow = (xn * (u * (10.f + (float)DT + 2.002f * nacc) + rho) + drop + conv) * 1.0001f;
+            Rrow = 5.f * u * xs2 + xn * r0 + 2e-8f;
+        } else {
+            Arow = (xn * (u * (float)(DT + 2 * NPART * DT) * 1.001f + rho) + drop + conv) * 1.0001f;
+            Rrow = xn * r0 + 1e-30f;
+        }
+        ArowS = Arow * SS;
     }
 
     float m1 = -__builtin_inff(), m2 = -__builtin_inff(), m3 = -__builtin_inff();
@@ -994,22 +1029,23 @@ __global__ void __launch_bounds__(VQS_F32_WAVES * 64, (XBF16 && NPART == 1 && DT
                 const f16x8 av = __builtin_bit_cast(f16x8, af[ks % VQS16_PF]);
                 const f16x8 bv = __builtin_bit_cast(f16x8, (NPART == 2 && (s & 1)) ? xm[NPART == 2 ? ks : 0] : xh[ks]);
                 if (s == 0) {
-                    f32x16 init;
-                    if (METRIC == 0 || has_pad) {
+                    f32x16 init;        // start value + (row factor) x ||c||: an upper bound of the code's true score
+                    {
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
                             f32x4 v = *(const f32x4 *)(nh + 8 * q + 4 * half);
+                            const f32x4 w = *(const f32x4 *)(nh + 32 + 8 * q + 4 * half);
                             if (METRIC != 0) { v.x = v.x < -1e38f ? v.x : 0.f; v.y = v.y < -1e38f ? v.y : 0.f;
                                                v.z = v.z < -1e38f ? v.z : 0.f; v.w = v.w < -1e38f ? v.w : 0.f; }
-                            init[4 * q + 0] = v.x * SS; init[4 * q + 1] = v.y * SS; init[4 * q + 2] = v.z * SS; init[4 * q + 3] = v.w * SS;
+                            const float vs[4] = {v.x, v.y, v.z, v.w}, ws[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+                            for (int i = 0; i < 4; ++i)
+                                init[4 * q + i] = (METRIC == 0 || has_pad) ? __builtin_fmaf(ws[i], ArowS, vs[i] * SS) : ws[i] * ArowS;
                         }
                         if (has_pad) {
 #pragma unroll
                             for (int r = 0; r < 16; ++r) init[r] = fmaxf(init[r], -3.0e38f);
                         }
-                    } else {
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) init[r] = 0.f;
                     }
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bv, init, 0, 0, 0);
                 } else {
@@ -1072,15 +1108,23 @@ __global__ void __launch_bounds__(VQS_F32_WAVES * 64, (XBF16 && NPART == 1 && DT
         id2 = second_low ? il1 : ih2;
         const float b3 = second_low ? fmaxf(h2, l2) : fmaxf(h3, l1);
         code = ih1;
-        const float thr = eps * SS + 8e-6f * fabsf(b1);
+        const float kb = 5.9604645e-8f * (5.f + 1.001f * (float)(DT + 1) + 0.51f) * 1.001f;
+        auto code_part = [&](int c) {       // A ||c|| + kb ||c||^2 of one code (||c|| from the tile tail of the packed codebook)
+            const int cc = c < a.C ? c : 0;
+            const float yb = *(const float *)(a.tiles16 + (size_t)(cc >> 5) * TILE_B + 64 * DT + (32 + (cc & 31)) * 4);
+            return (Arow * yb + (METRIC == 0 ? kb * yb * yb * 1.001f : 0.f)) * 1.0001f;
+        };
+        const float cp1 = code_part(ih1);
+        const float thr = (2.f * cp1 + 2.f * Rrow) * SS + 8e-6f * fabsf(b1);
         const bool certified = ((b1 - b2) > thr) && code < a.C;
         const bool pair = !certified && ((b1 - b3) > thr) && code < a.C && id2 < a.C;
         flagged = !certified;
         if (row_ok && half == 0) {
             a.idx_out[row * a.idx_stride] = (int64_t)(code < a.C ? code : 0);
-            if (a.dbg) {
+            if (a.dbg) {        // (in the units of t = x.c - ||c||^2 / 2, code parts taken off again: certified <=> d[0] - d[1] > d[2])
                 float *d = a.dbg + row * 4;
-                d[0] = b1 * iSS; d[1] = b2 * iSS; d[2] = thr * iSS; d[3] = certified ? 0.f : (pair ? 2.f : 1.f);
+                const float cp2 = code_part(id2);
+                d[0] = b1 * iSS - cp1; d[1] = b2 * iSS - cp2; d[2] = thr * iSS - cp1 + cp2; d[3] = certified ? 0.f : (pair ? 2.f : 1.f);
             }
         }
         if (code >= a.C) code = 0;

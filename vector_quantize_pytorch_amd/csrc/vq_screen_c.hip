@@ -72,9 +72,8 @@ __global__ void __launch_bounds__(256, 2) vq_screenc_kernel(const ScreenArgs a, 
     const int nst = nt16 / SUB;
     const char *const tiles = a.tiles16;
     const int sc = (int)a.scalars[2];
-    const float y2max = __uint_as_float(a.scalars[0]);
-    const float rmax = __uint_as_float(a.scalars[1]);
-    const float ymax = sqrtf(y2max) * 1.0001f;
+    const float rho = __uint_as_float(a.scalars[1]);
+    const float r0 = __uint_as_float(a.scalars[3]);
     const int ldq2 = (int)(a.ldq * 2);
     const int ldx2 = (int)(a.ldx * 2);
     const int nb_mine = gid < nblk ? (nblk - gid + G2 - 1) / G2 : 0;
@@ -88,15 +87,19 @@ __global__ void __launch_bounds__(256, 2) vq_screenc_kernel(const ScreenArgs a, 
         SX = SX > sc + 90 ? sc + 90 : SX;
         return SX > 126 ? 126 : (SX < -126 ? -126 : SX);
     };
-    auto eps_of = [&](float xs, int SX) {              // certificate threshold in unscaled units (vq_screen.hip header; one operand set)
+    // the certificate's per-code pieces (vq_screen.hip header, round 6): e(c) = Rrow + Arow ||c|| + kb ||c||^2; one operand set, bf16 rows
+    auto arow_of = [&](float xs, int SX) {
         const float u = 5.9604645e-8f;
-        const float conv = 2.f * 5.9604645e-8f * sqrtf((float)DT) * ymax * __uint_as_float((unsigned)(127 - SX) << 23);
+        const float conv = u * sqrtf((float)DT) * __uint_as_float((unsigned)(127 - SX) << 23);
         const float xn = sqrtf(xs) * 1.0001f;
-        const float xy = xn * ymax;
         const float nacc = (float)(DT + 1);
-        if (METRIC == 0) return u * (10.f * (xs + y2max + 2.f * xy) + 2.f * DT * xy + 4.f * nacc * 1.001f * (xy + 0.5f * y2max))
-                                + 2.f * xn * rmax + conv + 4e-8f;
-        return 2.f * (u * (DT + 2.f * DT) * 1.001f * xy + xn * rmax) + conv + 1e-30f;
+        if (METRIC == 0) return (xn * (u * (10.f + (float)DT + 2.002f * nacc) + rho) + conv) * 1.0001f;
+        return (xn * (u * (float)(DT + 2 * DT) * 1.001f + rho) + conv) * 1.0001f;
+    };
+    auto rrow_of = [&](float xs) {
+        const float xn = sqrtf(xs) * 1.0001f;
+        if (METRIC == 0) return 5.f * 5.9604645e-8f * xs + xn * r0 + 2e-8f;
+        return xn * r0 + 1e-30f;
     };
     auto conv_word = [&](unsigned w, float S) -> unsigned {   // two bf16 -> two fp16, exact above 2^-14 (scaled), truncated below
         const float lo = __uint_as_float(w << 16) * S, hi = __uint_as_float(w & 0xffff0000u) * S;
@@ -151,7 +154,7 @@ __global__ void __launch_bounds__(256, 2) vq_screenc_kernel(const ScreenArgs a, 
     f32x16 accA[2], accB[2];                           // two accumulator sets x two row blocks
     float m1[2], m2[2], m3[2];                         // top 3 per row block
     int tix[2], tix2[2];
-    float eps_c[2], SS_c = 1.f, iSS_c = 1.f;
+    float arow_c[2], rrow_c[2], SS_c = 1.f, iSS_c = 1.f;      // Arow (unscaled), Rrow per row block
     int g = 0;                                         // interval counter of the workgroup
     int bcur = 0;                                      // LDS buffer of interval g
     int tpc = 0;                                       // g mod nst: the tile pair of interval g
@@ -233,8 +236,8 @@ __global__ void __launch_bounds__(256, 2) vq_screenc_kernel(const ScreenArgs a, 
             }
         SS_c = __uint_as_float((unsigned)(SX + sc + 127) << 23);
         iSS_c = __uint_as_float((unsigned)(127 - SX - sc) << 23);
-        eps_c[0] = eps_of(xs2[0], SX);
-        eps_c[1] = eps_of(xs2[1], SX);
+        arow_c[0] = arow_of(xs2[0], SX); arow_c[1] = arow_of(xs2[1], SX);
+        rrow_c[0] = rrow_of(xs2[0]); rrow_c[1] = rrow_of(xs2[1]);
     };
     auto reset_fold = [&]() __attribute__((always_inline)) {
 #pragma unroll
@@ -317,28 +320,39 @@ __global__ void __launch_bounds__(256, 2) vq_screenc_kernel(const ScreenArgs a, 
                 for (int p = 0; p < PF; ++p) af[p] = ap[p * 64];
                 // start value -||c||^2 / 2 (scaled); register e <-> code 8 (e >> 2) + 4 half + (e & 3) of the tile.  Tiles with padding
                 // codes clamp it to a finite -3e38.
-                f32x16 init;
-                if (METRIC == 0 || has_pad) {
+                // + (row factor) x ||c|| (tile tail, floats 32 ..): every tracked score is an upper bound of the code's true score
+                f32x16 init0, init1;
+                {
+                    const float as0 = arow_c[0] * SS_c, as1 = arow_c[1] * SS_c;
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         f32x4 v = *(const f32x4 *)(nh + 8 * q);
+                        const f32x4 w = *(const f32x4 *)(nh + 32 + 8 * q);
                         if (METRIC != 0) { v.x = v.x < -1e38f ? v.x : 0.f; v.y = v.y < -1e38f ? v.y : 0.f;
                                            v.z = v.z < -1e38f ? v.z : 0.f; v.w = v.w < -1e38f ? v.w : 0.f; }
-                        init[4 * q + 0] = v.x * SS_c; init[4 * q + 1] = v.y * SS_c; init[4 * q + 2] = v.z * SS_c; init[4 * q + 3] = v.w * SS_c;
+                        const float vs[4] = {v.x, v.y, v.z, v.w}, ws[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            if (METRIC == 0 || has_pad) {
+                                const float b = vs[i] * SS_c;
+                                init0[4 * q + i] = __builtin_fmaf(ws[i], as0, b);
+                                init1[4 * q + i] = __builtin_fmaf(ws[i], as1, b);
+                            } else {
+                                init0[4 * q + i] = ws[i] * as0;
+                                init1[4 * q + i] = ws[i] * as1;
+                            }
+                        }
                     }
                     if (has_pad) {
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) init[r] = fmaxf(init[r], -3.0e38f);
+                        for (int r = 0; r < 16; ++r) { init0[r] = fmaxf(init0[r], -3.0e38f); init1[r] = fmaxf(init1[r], -3.0e38f); }
                     }
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) init[r] = 0.f;
                 }
 #pragma unroll
                 for (int s = 0; s < NK; ++s) {
                     const f16x8 av = __builtin_bit_cast(f16x8, af[s % PF]);
-                    C[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, __builtin_bit_cast(f16x8, cur[0][s]), s == 0 ? init : C[0], 0, 0, 0);
-                    C[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, __builtin_bit_cast(f16x8, cur[1][s]), s == 0 ? init : C[1], 0, 0, 0);
+                    C[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, __builtin_bit_cast(f16x8, cur[0][s]), s == 0 ? init0 : C[0], 0, 0, 0);
+                    C[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, __builtin_bit_cast(f16x8, cur[1][s]), s == 0 ? init1 : C[1], 0, 0, 0);
                     if (s + PF < NK) af[s % PF] = ap[(s + PF) * 64];
 #ifndef VQC_NO_FOLD
                     fold(P[0], s, m1[0], m2[0], m3[0]);
@@ -384,10 +398,19 @@ __global__ void __launch_bounds__(256, 2) vq_screenc_kernel(const ScreenArgs a, 
                 float b1, b2, b3;
                 merge3(m1[t], m2[t], m3[t], ia1, ia2, xor32f(m1[t], half_b), xor32f(m2[t], half_b), xor32f(m3[t], half_b), (int)xor32((unsigned)ia1, half_b), (int)xor32((unsigned)ia2, half_b),
                        b1, b2, b3, codes[t], id2s[t]);
-                const float thr = eps_c[t] * SS_c + 8e-6f * fabsf(b1);
+                // the winner's own code part A ||c|| + kb ||c||^2 (||c|| from the tile tail of the packed codebook)
+                const float kb = 5.9604645e-8f * (5.f + 1.001f * (float)(DT + 1) + 0.51f) * 1.001f;
+                auto code_part = [&](int c) {
+                    const int cc = c < a.C ? c : 0;
+                    const float yb = *(const float *)(tiles + (size_t)(cc >> 5) * TILE_B + 64 * DT + (32 + (cc & 31)) * 4);
+                    return (arow_c[t] * yb + (METRIC == 0 ? kb * yb * yb * 1.001f : 0.f)) * 1.0001f;
+                };
+                const float cp1 = code_part(codes[t]);
+                const float thr = (2.f * cp1 + 2.f * rrow_c[t]) * SS_c + 8e-6f * fabsf(b1);
                 cert[t] = ((b1 - b2) > thr) && codes[t] < a.C;
                 pairf[t] = !cert[t] && ((b1 - b3) > thr) && codes[t] < a.C && id2s[t] < a.C;
-                dbg4[t][0] = b1 * iSS_c; dbg4[t][1] = b2 * iSS_c; dbg4[t][2] = thr * iSS_c;
+                dbg4[t][0] = b1 * iSS_c - cp1; dbg4[t][1] = b2 * iSS_c; dbg4[t][2] = thr * iSS_c - cp1;
+                if (a.dbg) { const float cp2 = code_part(id2s[t]); dbg4[t][1] -= cp2; dbg4[t][2] += cp2; }
             }
             code = half_b ? codes[1] : codes[0];
             id2 = half_b ? id2s[1] : id2s[0];

@@ -202,8 +202,8 @@ __global__ void __launch_bounds__(256) vq_pack_kernel(const float *embed, int C,
 // element then is below 2^14 and fp16 keeps 11 significant bits down to 2^-28 of the largest possible element -- and
 // rounded to fp16 (RNE); the kernel compensates the scale exactly (powers of two).  Same lane order as the bf16 tiles:
 // 16 bytes per lane and k-step; lane l = code (l & 31), k-slot 8 * (l >> 5) + e.  Tile tail: 32 floats -||c||^2 / 2
-// (-3e38 for padding codes).  scalars[1] <- max_c ||c - c_f16|| (the certificate charges X * that for the rounding),
-// scalars[2] <- sc.
+// (-3e38 for padding codes), then 32 floats ||c|| (round 6).  scalars[1] <- rho, scalars[3] <- r0 with ||c - c_f16|| <= rho ||c|| + r0
+// for every code (the certificate charges X * that for the rounding), scalars[2] <- sc.
 __global__ void __launch_bounds__(256) vq_pack16_kernel(const float *embed, int C, int D, int DT, int n_tiles,
                                                         const float *packed, char *tiles16,
                                                         unsigned *scalars, size_t head_bytes)
@@ -255,17 +255,31 @@ __global__ void __launch_bounds__(256) vq_pack16_kernel(const float *embed, int 
     }
     __syncthreads();
     {
+        // tile tail (1 KiB): floats [0, 32) the accumulator's start value, [32, 64) an upper bound of ||c|| per code -- the screening
+        // kernels add (row factor) x that to the start value, so that every score they track is an UPPER bound of the code's true
+        // score and the certificate only ever charges a row for the codes it is actually compared with (round 6: the bound used to be
+        // built from the codebook-wide max ||c||^2 and max ||c - c_h||, so ONE large-norm code raised the threshold of every row).
+        //   start value  -||c||^2 / 2 + kb ||c||^2,  kb = u (5 + 1.001 (DT + 1) + 0.51) 1.001: the code's own share of the terms that
+        //   do not depend on the row (sqrt collapse 5 u y2, MFMA accumulation of the start value, the rounding of the kernel's FMA)
         float *nh = (float *)((char *)st + (size_t)64 * DT);
         const int i = threadIdx.x;
         const bool real = (i < 32) && (t * 32 + i < C);
         // ||c||^2 of the tile's codes sits behind the fp32 tile of the exact section (written by vq_pack_kernel)
         const float y2 = (real && t < n_tiles) ? packed[(size_t)t * (32 * DT + 256) + 32 * DT + i] : 0.f;
-        nh[i] = (i < 32) ? (real ? -0.5f * y2 : -3.0e38f) : 0.f;
+        const float kb = 5.9604645e-8f * (5.f + 1.001f * (float)(DT + 1) + 0.51f) * 1.001f;
+        const float yb = sqrtf(y2) * 1.0001f;                   // (y2 is ATen's fp32 sum: off the true norm by < D u relative)
+        if (i < 32) { nh[i] = real ? __builtin_fmaf(kb, y2, -0.5f * y2) : -3.0e38f; nh[32 + i] = real ? yb : 0.f; }
+        else if (i < 224) nh[32 + i] = 0.f;
+        // the rounding of the fp16 copy, per code: every element errs by <= max(2^-12 |c_i|, 2^(-25 - sc)) (RNE; subnormal spacing below
+        // 2^-14 scaled), so ||c - c_h|| <= rho ||c|| + r0 with r0 = sqrt(DT) 2^(-25 - sc) and rho <= 2^-12: rho is MEASURED as the
+        // largest (||c - c_h|| - r0)+ / ||c|| -- a relative quantity that no single code's size can inflate
+        const float r0 = sqrtf((float)DT) * __uint_as_float((unsigned)(127 - 25 - sc) << 23) * 1.01f;
         if (real) {
             const float r = sqrtf(rsq[i]) * 1.01f + 1e-38f;     // slack for the fp32 rounding of the sum above
-            atomicMax(scalars + 1, __float_as_uint(r));
+            const float over = r - r0;
+            if (over > 0.f && y2 > 0.f) atomicMax(scalars + 1, __float_as_uint(fminf(over / sqrtf(y2) * 1.001f, 2.5e-4f)));
         }
-        if (t == 0 && i == 0) scalars[2] = (unsigned)sc;
+        if (t == 0 && i == 0) { scalars[2] = (unsigned)sc; scalars[3] = __float_as_uint(r0); }
     }
 }
 

@@ -66,11 +66,14 @@ static inline int vq_pick_dt(int D)
 //   [0)                     fp32 A-operand tiles of the exact kernel: tiles * (128*DT + 1024)
 //   [+4096)                 tail pad (the staged tile copy over-reads <= 3 KiB)
 //   [bf16_offset)           codebook rounded to bf16, [C, D] row-major (q / loss of bf16 I/O), 16-byte padded
-//   [scalars_offset)        64 bytes: [0] float bits of max_c ||c||^2, [1] float bits of max_c ||c - c_f16|| (x 1.01),
-//                           [2] int sc: the fp16 tiles hold c * 2^sc, rest reserved
+//   [scalars_offset)        64 bytes: [0] float bits of max_c ||c||^2, [1] float bits of rho, [3] of r0: ||c - c_f16|| <= rho ||c|| + r0
+//                           for every code (round 6; was the codebook-wide max_c ||c - c_f16||), [2] int sc: the fp16 tiles hold
+//                           c * 2^sc, rest reserved
 //   [f16_offset)            fp16 A-operand tiles of the single-pass screening kernel (vq_screen16_kernel):
 //                           tiles16 * (64*DT + 1024), tiles16 = tiles rounded up to a multiple of VQ_F16_TILE_GROUP
-//                           (padding tiles score -3e38), then an 8192-byte tail pad
+//                           (padding tiles score -3e38), then an 8192-byte tail pad.  Tile tail (1 KiB of floats): [0, 32) the
+//                           accumulator's start value -||c||^2/2 (+ the code's row-independent error share), [32, 64) an upper
+//                           bound of ||c|| (0 for padding codes)
 #define VQ_F16_TILE_GROUP 8
 #define VQ_PACKED_SCALARS_BYTES 64
 __host__ __device__ static inline size_t vq_tile_bytes(int DT) { return (size_t)128 * DT + 1024; }
