@@ -208,6 +208,12 @@ typedef struct {
     int64_t x_gstride, packed_gstride, embed_gstride, codes_gstride, stats_gstride;
     size_t stats_ws_gstride;
     int64_t sqerr_gstride;
+    /* Round 6: the decode (quantized_out = sum over the stages of the chosen codes, residual_vq.py:525) split around the last stage.
+     * decode_out (nullable, fp32 [N, D] rows at decode_ldo elements, group g decode_gstride elements behind group 0): the sum of the
+     * stages [0, Q - 1) is formed on stats_stream while stage Q - 1 is searched, stage Q - 1 is added on `stream` behind the loop --
+     * the same additions in the same order as vqhip_decode_sum over all stages, so bit-identical.  Requires Q >= 2, fp32 rows, no
+     * row_mask (masked rows are re-indexed to -1 only after the loop), a statistics stream, and one more event (Q x chunks + 2). */
+    void *decode_out; int64_t decode_ldo; int64_t decode_gstride;
 } vqhip_rvq_chain_t;
 int64_t vqhip_rvq_chain_chunk_rows(int64_t N, int chunks);
 size_t vqhip_rvq_chain_ws_stride(int64_t N, int chunks);
@@ -467,6 +473,12 @@ int vqhip_ema_fold_many(float *cluster_size, float *embed_avg, float *embed, con
  * embed: Q codebooks [C, D] each at stride embed_qstride floats (0 => shared codebook). */
 int vqhip_decode_sum(const int64_t *idx, int64_t N, int Q, const float *embed, int64_t embed_qstride,
                      int C, int D, void *out, int out_dtype, int64_t ldo, void *stream);
+/* The same running sum over a RANGE of stages (round 6): idx rows idx_stride elements apart (the first Q columns of a wider index
+ * tensor; pass idx + q0 and embed + q0 * embed_qstride to start at stage q0), accumulate != 0: the sum continues from what `out` holds
+ * (fp32).  Decoding stages [0, Q - 1) while the last stage is still being searched and adding stage Q - 1 afterwards performs the
+ * additions of residual_vq.py:525 in the same order -- bit-identical to one call over all stages.  D <= 512. */
+int vqhip_decode_sum_range(const int64_t *idx, int64_t idx_stride, int64_t N, int Q, const float *embed, int64_t embed_qstride,
+                           int C, int D, void *out, int out_dtype, int64_t ldo, int accumulate, void *stream);
 
 /* ---- ATen-order row sum of squares (vqp.py:59) -- exposed for tests / odd D -------------------- */
 /* The K best codes per row, K <= 8 (reference: `logits.topk(topk)` on the N x C `dist` tensor, vector_quantize_pytorch.py:137-138,

@@ -99,6 +99,9 @@ def lib():
     L.vqhip_ema_accumulate_prezeroed.restype = i32
     L.vqhip_ema_finalize.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, f32, f32, i32, i32, i32, vp, vp]
     L.vqhip_decode_sum.argtypes = [vp, i64, i32, vp, i64, i32, i32, vp, i32, i64, vp]
+    if hasattr(L, "vqhip_decode_sum_range"):          # (an A/B library of an earlier commit loaded through VQHIP_SO lacks it)
+        L.vqhip_decode_sum_range.argtypes = [vp, i64, i64, i32, vp, i64, i32, i32, vp, i32, i64, i32, vp]
+        L.vqhip_decode_sum_range.restype = i32
     L.vqhip_row_sumsq.argtypes = [vp, i32, i64, i32, i64, vp, vp]
     L.vqhip_assign_rowwise.argtypes = [vp, i64, i32, i64, vp, i32, i32, vp, vp]
     L.vqhip_assign_rowwise.restype = i32
@@ -169,7 +172,7 @@ EXPORTS = ("vqhip_version", "vqhip_last_error", "vqhip_packed_bytes", "vqhip_pac
            "vqhip_route_fwd_gather", "vqhip_route_bwd_gather", "vqhip_ema_accumulate_prezeroed",
            "vqhip_ema_batched_ws_stride", "vqhip_ema_accumulate_batched", "vqhip_ema_finalize_batched",
            "vqhip_ema_accumulate_stages", "vqhip_rvq_chain_chunk_rows", "vqhip_rvq_chain_ws_stride", "vqhip_rvq_chain_forward",
-           "vqhip_ema_finalize_table")
+           "vqhip_ema_finalize_table", "vqhip_decode_sum_range")
 
 
 def _check(rc, what):
@@ -612,7 +615,8 @@ def rvq_forward_chained(x: torch.Tensor, packed: torch.Tensor, embed: torch.Tens
     nws = lib().vqhip_screen_workspace_bytes(min(rpc, N))
     nws4 = (nws + 15) // 16 * 4                       # ints per stage and chunk, 16-byte granules
     ws_all = torch.empty(Q, K, nws4, dtype=torch.int32, device=dev)
-    ws_all[:, :, :4].zero_()                          # the list headers in ONE launch (a 16-byte memset per stage cost 13 us of gaps each)
+    n_done = ((min(rpc, N) + 127) // 128 + 1) & ~1    # arrival counters of the merged exact-pass launch (vq_tail_kernel) sit behind the header
+    ws_all[:, :, :4 + n_done].zero_()                 # the list headers (+ counters) in ONE launch (a 16-byte memset per stage cost 13 us of gaps each)
     codes = embed if xk.dtype == torch.float32 else embed.to(xk.dtype)      # (bf16 rows: the routing kernel gathers bf16 code rows)
     main = torch.cuda.current_stream(dev)
     streams = [main]
@@ -688,7 +692,7 @@ class _RvqChain(ctypes.Structure):       # vqhip_rvq_chain_t (include/vqhip.h)
                 ("events", ctypes.c_void_p), ("n_events", ctypes.c_int64),
                 ("groups", ctypes.c_int64), ("x_gstride", ctypes.c_int64), ("packed_gstride", ctypes.c_int64), ("embed_gstride", ctypes.c_int64),
                 ("codes_gstride", ctypes.c_int64), ("stats_gstride", ctypes.c_int64), ("stats_ws_gstride", ctypes.c_size_t),
-                ("sqerr_gstride", ctypes.c_int64)]
+                ("sqerr_gstride", ctypes.c_int64), ("decode_out", ctypes.c_void_p), ("decode_ldo", ctypes.c_int64), ("decode_gstride", ctypes.c_int64)]
 
 
 _CHAIN_EVENTS = {}
@@ -707,7 +711,7 @@ def _chain_events(device, main, n):
 
 @_on_device
 def rvq_chain_forward(x: torch.Tensor, packed: torch.Tensor, embed: torch.Tensor, Q: int, *, row_mask=None, route_mode=0, row_chunks=1,
-                      stats=None, stats_ws=None, sq_parts=None, stats_stream=None, groups=1):
+                      stats=None, stats_ws=None, sq_parts=None, stats_stream=None, groups=1, decode_out=None):
     """The residual loop (rvq.py:469-568) in ONE library call (vqhip_rvq_chain_forward): the Q chained screened searches -- or, with
     route_mode, the routed residuals + plain searches of a gradient step -- in row_chunks interleaved chunks, and every stage's EMA
     statistics (+ loss partials into sq_parts [Q, P]) on stats_stream.  Same results as rvq_forward_chained with a stage hook that
@@ -717,7 +721,9 @@ def rvq_chain_forward(x: torch.Tensor, packed: torch.Tensor, embed: torch.Tensor
     groups = G > 1 (round 6): the G independent loops of a GroupedResidualVQ (rvq.py:634-724) as one launch set.  x [..., G D] -- group g
     owns the feature chunk g D .. (g + 1) D --, embed [G, C, D] (every group one codebook shared by its stages) or [G, Q, C, D], packed
     [G, P] / [G, Q, P], stats [G, Q, stride], stats_ws [G, Q, bytes], sq_parts [G, Q, P].
-    -> idx [G, ..., Q], bufs [Q - 1, G, N, D], inputs None, counts per stage: counters [K, G]"""
+    -> idx [G, ..., Q], bufs [Q - 1, G, N, D], inputs None, counts per stage: counters [K, G]
+    decode_out (fp32, x's shape): receives quantized_out = the sum of the chosen codes -- stages 0 .. Q - 2 summed on the statistics stream
+    beside the last stage's search, the last stage added behind the loop (chain_decode_supported() says when this applies)."""
     _need_gpu(x, packed, embed, row_mask, stats, stats_ws, sq_parts)
     G = int(groups)
     if G > 1:
@@ -773,14 +779,21 @@ def rvq_chain_forward(x: torch.Tensor, packed: torch.Tensor, embed: torch.Tensor
         if stats_stream is not None:
             st.stats_stream = stats_stream.cuda_stream
     side = stats is not None and stats_stream is not None and stats_stream.cuda_stream != main.cuda_stream
+    n_ev = Q * K + 1
+    if decode_out is not None:
+        assert side and Q >= 2 and row_mask is None and xk.dtype == torch.float32 and decode_out.dtype == torch.float32
+        ok_, oN, oD, ldo = as_rows(decode_out)
+        assert ok_.data_ptr() == decode_out.data_ptr() and oN == N and oD == D * G
+        st.decode_out, st.decode_ldo, st.decode_gstride = decode_out.data_ptr(), ldo, D
+        n_ev += 1
     if K > 1 or side:
         if K > 1:
             cs = _chain_streams(dev, main, K - 1)
             arr = (ctypes.c_void_p * (K - 1))(*[s_.cuda_stream for s_ in cs])
             st.chunk_streams = ctypes.cast(arr, ctypes.c_void_p)
             keep.append(arr)
-        evs, earr = _chain_events(dev, main, Q * K + 1)
-        st.events, st.n_events = ctypes.cast(earr, ctypes.c_void_p), Q * K + 1
+        evs, earr = _chain_events(dev, main, n_ev)
+        st.events, st.n_events = ctypes.cast(earr, ctypes.c_void_p), n_ev
         keep += [evs, earr]
     _check(lib().vqhip_rvq_chain_forward(ctypes.byref(st), _stream()), "vqhip_rvq_chain_forward")
     # keepalive: the statistics stream is not joined here and still reads the uint8 row mask made above (allocated on the CALLER's
@@ -1373,22 +1386,27 @@ def assign_rowwise(x: torch.Tensor, codes: torch.Tensor, cosine=False) -> torch.
 
 
 @_on_device
-def decode_sum(idx: torch.Tensor, embed: torch.Tensor, out_dtype=torch.float32, out=None) -> torch.Tensor:
+def decode_sum(idx: torch.Tensor, embed: torch.Tensor, out_dtype=torch.float32, out=None, stages=None, accumulate=False) -> torch.Tensor:
     """idx [..., Q] int64, embed [Q, C, D] or [C, D] (shared by all Q) -> [..., D] = sum_q embed_q[idx_q].
     out (optional): a [..., D] tensor to write -- contiguous (one slice of a stacked [Q, ..., D] result) or a feature chunk of a wider
-    contiguous tensor (rows at a uniform stride)."""
+    contiguous tensor (rows at a uniform stride).
+    stages = (q0, q1): only the stages q0 <= q < q1; accumulate: the sum continues from what `out` holds (fp32) -- decode_sum(stages=(0, Q - 1))
+    followed by decode_sum(stages=(Q - 1, Q), accumulate=True) adds in the same order as one call (vqhip_decode_sum_range)."""
     _need_gpu(idx, embed)
     assert idx.dtype == torch.int64 and embed.dtype == torch.float32 and embed.is_contiguous()
     idx = idx.contiguous()
-    Q = idx.shape[-1]
+    Qall = idx.shape[-1]
+    q0, q1 = (0, Qall) if stages is None else stages
+    assert 0 <= q0 < q1 <= Qall
+    Q = q1 - q0
     if embed.ndim == 2:
         C, D = embed.shape
         qstride = 0
     else:
-        assert embed.shape[0] == Q
+        assert embed.shape[0] == Qall
         _, C, D = embed.shape
         qstride = C * D
-    N = idx.numel() // Q
+    N = idx.numel() // Qall
     ldo = D
     if out is None:
         out = torch.empty(*idx.shape[:-1], D, dtype=out_dtype, device=idx.device)
@@ -1399,8 +1417,14 @@ def decode_sum(idx: torch.Tensor, embed: torch.Tensor, out_dtype=torch.float32, 
         assert ok.data_ptr() == out.data_ptr() and oN == N and oD == D, "decode_sum: out must be row-addressable in place"
         assert out_dtype in (torch.float32, torch.bfloat16) and out.device == idx.device
     if N > 0:
-        _check(lib().vqhip_decode_sum(_ptr(idx), N, Q, _ptr(embed), qstride, C, D, _ptr(out),
-                                      F32 if out_dtype == torch.float32 else BF16, ldo, _stream()), "vqhip_decode_sum")
+        if stages is None and not accumulate:
+            _check(lib().vqhip_decode_sum(_ptr(idx), N, Q, _ptr(embed), qstride, C, D, _ptr(out),
+                                          F32 if out_dtype == torch.float32 else BF16, ldo, _stream()), "vqhip_decode_sum")
+        else:
+            assert not accumulate or out_dtype == torch.float32
+            _check(lib().vqhip_decode_sum_range(ctypes.c_void_p(idx.data_ptr() + 8 * q0), Qall, N, Q, ctypes.c_void_p(embed.data_ptr() + 4 * q0 * qstride),
+                                                qstride, C, D, _ptr(out), F32 if out_dtype == torch.float32 else BF16, ldo, int(bool(accumulate)),
+                                                _stream()), "vqhip_decode_sum_range")
     return out
 
 

@@ -20,11 +20,12 @@
 
 static inline size_t rc_align(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
-// the 16-byte list header of every (stage, chunk) workspace slice, in one launch
-__global__ void __launch_bounds__(64) vq_chain_headers_kernel(char *base, size_t stride, int n)
+// the 16-byte list header of every (stage, chunk, group) workspace slice and the arrival counters behind it (vq_tail_kernel), in one launch:
+// blockIdx.y = slice, the first 4 + n_done ints of each are zeroed
+__global__ void __launch_bounds__(256) vq_chain_headers_kernel(char *base, size_t stride, int n_done)
 {
-    const int i = blockIdx.x * 16 + (threadIdx.x >> 2);
-    if (i < n) ((unsigned *)(base + (size_t)i * stride))[threadIdx.x & 3] = 0u;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < 4 + n_done) ((unsigned *)(base + (size_t)blockIdx.y * stride))[i] = 0u;
 }
 
 extern "C" int64_t vqhip_rvq_chain_chunk_rows(int64_t N, int chunks)
@@ -64,9 +65,15 @@ extern "C" int vqhip_rvq_chain_forward(const vqhip_rvq_chain_t *c, void *stream)
     if (K > 1 && !c->chunk_streams) VQ_FAIL(VQHIP_EINVAL, "rvq_chain_forward: %d chunks need chunk_streams[0..%d]", K, K - 2);
     const int want_stats = c->stats != nullptr;
     const int stats_side = want_stats && c->stats_stream && c->stats_stream != stream;
-    const int64_t need_ev = (K > 1 || stats_side) ? Q * K + 1 : 0;
+    // decode split around the last stage (round 6): sum of the stages [0, Q - 1) on the statistics stream while stage Q - 1 is searched,
+    // stage Q - 1 added behind the loop -- the additions of rvq.py:525 in their order; needs the statistics stream and fp32 outputs
+    const int split_decode = c->decode_out != nullptr && stats_side && Q >= 2 && dt == VQHIP_F32 && !c->row_mask;
+    if (c->decode_out && !split_decode) VQ_FAIL(VQHIP_EINVAL, "rvq_chain_forward: decode_out needs Q >= 2, fp32 rows, no row mask and a statistics stream");
+    const int64_t need_ev = (K > 1 || stats_side) ? Q * K + 1 + (split_decode ? 1 : 0) : 0;
     if (need_ev > 0 && (!c->events || c->n_events < need_ev))
-        VQ_FAIL(VQHIP_EINVAL, "rvq_chain_forward: needs %lld events (Q x chunks + 1)", (long long)need_ev);
+        VQ_FAIL(VQHIP_EINVAL, "rvq_chain_forward: needs %lld events (Q x chunks + 1, + 1 with decode_out)", (long long)need_ev);
+    if (split_decode && (c->decode_ldo < D || (G > 1 && c->decode_gstride < D)))
+        VQ_FAIL(VQHIP_EINVAL, "rvq_chain_forward: decode_out needs decode_ldo >= D (and decode_gstride >= D for groups)");
     const size_t wss = vqhip_rvq_chain_ws_stride(N, K);
     if (c->workspace_bytes < wss * (size_t)(Q * K * G)) VQ_FAIL(VQHIP_EINVAL, "rvq_chain_forward: workspace too small");
     if (((uintptr_t)c->workspace) & 255) VQ_FAIL(VQHIP_EALIGN, "rvq_chain_forward: workspace must be 256-byte aligned");
@@ -83,7 +90,8 @@ extern "C" int vqhip_rvq_chain_forward(const vqhip_rvq_chain_t *c, void *stream)
     hipStream_t main = (hipStream_t)stream;
     hipError_t e;
     // the Q x K x G list headers (16 bytes each) in one launch
-    hipLaunchKernelGGL(vq_chain_headers_kernel, dim3((unsigned)((Q * K * G + 15) / 16)), dim3(64), 0, main, (char *)c->workspace, wss, (int)(Q * K * G));
+    const int n_done = (int)vq_screen_done_ints(rpc < N ? rpc : N);
+    hipLaunchKernelGGL(vq_chain_headers_kernel, dim3((unsigned)((4 + n_done + 255) / 256), (unsigned)(Q * K * G)), dim3(256), 0, main, (char *)c->workspace, wss, n_done);
     if (int rc = vq_launch_status("vq_chain_headers_kernel")) return rc;
     hipEvent_t *ev = (hipEvent_t *)c->events;
     if (K > 1) {                                                   // fork: the chunk streams start behind everything queued on `stream`
@@ -169,6 +177,14 @@ extern "C" int vqhip_rvq_chain_forward(const vqhip_rvq_chain_t *c, void *stream)
             for (int k = 0; k < K; ++k)
                 if ((e = hipStreamWaitEvent(ss, ev[q * K + k], 0)) != hipSuccess) VQ_FAIL((int)e, "rvq_chain_forward: hipStreamWaitEvent: %s", hipGetErrorString(e));
             if (int rc = stage_stats(q, ss)) return rc;
+            if (split_decode && q == Q - 2) {
+                // every stage but the last is final: their part of the output sum, beside the last stage's search
+                for (int g = 0; g < G; ++g)
+                    if (int rc = vqhip_decode_sum_range(c->idx_out + (int64_t)g * idx_g, Q, N, (int)(Q - 1), c->embed + (int64_t)g * c->embed_gstride,
+                                                        c->embed_qstride, C, D, (float *)c->decode_out + (int64_t)g * c->decode_gstride, VQHIP_F32,
+                                                        c->decode_ldo, 0, ss)) return rc;
+                if ((e = hipEventRecord(ev[Q * K + 1], ss)) != hipSuccess) VQ_FAIL((int)e, "rvq_chain_forward: hipEventRecord: %s", hipGetErrorString(e));
+            }
         }
     }
     for (int k = 1; k < K; ++k)                                    // join: `stream` continues behind every chunk's last stage
@@ -176,5 +192,12 @@ extern "C" int vqhip_rvq_chain_forward(const vqhip_rvq_chain_t *c, void *stream)
     if (want_stats && !stats_side)
         for (int64_t q = 0; q < Q; ++q)                            // no statistics stream (e.g. under graph capture): behind the loop
             if (int rc = stage_stats(q, main)) return rc;
+    if (split_decode) {                                            // + the last stage's codes: the output is complete on `stream`
+        if ((e = hipStreamWaitEvent(main, ev[Q * K + 1], 0)) != hipSuccess) VQ_FAIL((int)e, "rvq_chain_forward: hipStreamWaitEvent: %s", hipGetErrorString(e));
+        for (int g = 0; g < G; ++g)
+            if (int rc = vqhip_decode_sum_range(c->idx_out + (int64_t)g * idx_g + (Q - 1), Q, N, 1,
+                                                c->embed + (int64_t)g * c->embed_gstride + (Q - 1) * c->embed_qstride, c->embed_qstride, C, D,
+                                                (float *)c->decode_out + (int64_t)g * c->decode_gstride, VQHIP_F32, c->decode_ldo, 1, main)) return rc;
+    }
     return 0;
 }

@@ -156,6 +156,7 @@ __global__ void __launch_bounds__(VQS_WAVES * 64, 8 / VQS_WAVES) vq_screen16_ker
     static_assert(NPART == 1 || XF32, "only fp32 rows need a second operand set");
     bool row_ok[2];
     float xs2[2], rxn[2] = {0.f, 0.f};     // ||x||^2 (x 1.001) and, for fp32 rows, ||x' - x_h|| in unscaled units
+    [[maybe_unused]] float xs_wave = 0.f;  // bf16 rows: the largest finite ||x||^2 of the wave's 64 rows
     int SXv[2];
     const int sc = (int)a.scalars[2];
     // scale exponent from the largest FINITE squared row norm `mx` (float bits) of the rows sharing it.  Every element is <= ||x||, so
@@ -218,6 +219,7 @@ __global__ void __launch_bounds__(VQS_WAVES * 64, 8 / VQS_WAVES) vq_screen16_ker
             xs2[rb] = xs * 1.001f;
         }
         const unsigned m0 = wave_max_finite(xs2[0]), m1b = wave_max_finite(xs2[1]);
+        xs_wave = __uint_as_float(m0 > m1b ? m0 : m1b);
         SXv[0] = SXv[1] = pick_sx(m0 > m1b ? m0 : m1b);
         const float S = __uint_as_float((unsigned)(SXv[0] + 127) << 23);
 #pragma unroll
@@ -419,19 +421,26 @@ __global__ void __launch_bounds__(VQS_WAVES * 64, 8 / VQS_WAVES) vq_screen16_ker
             const float iS = __uint_as_float((unsigned)(127 - SXv[rb]) << 23);
             const float xs = xs2[rb];
             const float xn = sqrtf(xs) * 1.0001f;
+            // (per ROW: a factor built from the wave's largest row norm -- one start vector for both row blocks -- was measured: it saves
+            //  ~1 % of the cfg-2 search and sends 55 % instead of 7 % of the rows of a batch whose row norms span 30 x to the exact sweep)
+            const float xa = xn;
             const float nacc = (float)(NPART * DT + 1);
             // truncated elements: |dx_k| <= 2^-24 / S each, sum_k |dx_k| |c_k| <= 2^-24 / S * sqrt(D) * ||c||   (per operand set)
             const float conv = NPART * u * sqrtf((float)DT) * iS;
             // the part of x' the operand set(s) do not carry: one set -- the measured ||x' - x_h|| ||c||; two sets -- 2^-20 X ||c||
             const float drop = !XF32 ? 0.f : (NPART == 1 ? rxn[rb] : 9.5367432e-7f * 1.01f * xn);
             if (METRIC == 0) {
-                Arow[rb] = (xn * (u * (10.f + (float)DT + 2.002f * nacc) + rho) + drop + conv) * 1.0001f;
+                Arow[rb] = (xa * (u * (10.f + (float)DT + 2.002f * nacc) + rho) + drop + conv) * (1.0001f + 4.f * nacc * u);   // (+ the MFMA's rounding of the added part itself)
                 Rrow[rb] = 5.f * u * xs + xn * r0 + 2e-8f;
             } else {
-                Arow[rb] = (xn * (u * (float)(DT + 2 * NPART * DT) * 1.001f + rho) + drop + conv) * 1.0001f;
+                Arow[rb] = (xa * (u * (float)(DT + 2 * NPART * DT) * 1.001f + rho) + drop + conv) * (1.0001f + 4.f * nacc * u);
                 Rrow[rb] = xn * r0 + 1e-30f;
             }
             ArowS[rb] = Arow[rb] * SSv[rb];
+            // overflow guard: a row norm or a code norm beyond fp32 (or a scaled factor that left its range) -> this row is never
+            // certified (Rrow = inf) and adds nothing to the start values (no inf x 0 = NaN may enter the fold)
+            const bool y2ok = __uint_as_float(a.scalars[0]) < 1e37f;
+            if (!(Arow[rb] < 1e30f) || !(ArowS[rb] < 1e30f) || !(Rrow[rb] < 1e30f) || !y2ok) { Arow[rb] = 0.f; ArowS[rb] = 0.f; Rrow[rb] = __builtin_inff(); }
         }
     }
 
@@ -501,16 +510,20 @@ __global__ void __launch_bounds__(VQS_WAVES * 64, 8 / VQS_WAVES) vq_screen16_ker
                 const f32x4 w = *(const f32x4 *)(nh + 32 + 8 * q);
                 if (METRIC != 0) { v.x = v.x < -1e38f ? v.x : 0.f; v.y = v.y < -1e38f ? v.y : 0.f;
                                    v.z = v.z < -1e38f ? v.z : 0.f; v.w = v.w < -1e38f ? v.w : 0.f; }
-                const float vs[4] = {v.x, v.y, v.z, v.w}, ws[4] = {w.x, w.y, w.z, w.w};
+                // two scores per instruction (v_pk_mul_f32 / v_pk_fma_f32: written as 2-vectors, the SLP vectoriser is off -- csrc/Makefile)
+                const f32x2 vp[2] = {f32x2{v.x, v.y}, f32x2{v.z, v.w}}, wp[2] = {f32x2{w.x, w.y}, f32x2{w.z, w.w}};
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
+                for (int i = 0; i < 2; ++i) {
+                    f32x2 r0, r1;
                     if (METRIC == 0 || has_pad) {
-                        init0[4 * q + i] = __builtin_fmaf(ws[i], ArowS[0], vs[i] * SSv[0]);
-                        init1[4 * q + i] = __builtin_fmaf(ws[i], ArowS[1], vs[i] * SSv[1]);
+                        r0 = __builtin_elementwise_fma(wp[i], f32x2{ArowS[0], ArowS[0]}, vp[i] * f32x2{SSv[0], SSv[0]});
+                        r1 = __builtin_elementwise_fma(wp[i], f32x2{ArowS[1], ArowS[1]}, vp[i] * f32x2{SSv[1], SSv[1]});
                     } else {
-                        init0[4 * q + i] = ws[i] * ArowS[0];
-                        init1[4 * q + i] = ws[i] * ArowS[1];
+                        r0 = wp[i] * f32x2{ArowS[0], ArowS[0]};
+                        r1 = wp[i] * f32x2{ArowS[1], ArowS[1]};
                     }
+                    init0[4 * q + 2 * i] = r0.x; init0[4 * q + 2 * i + 1] = r0.y;
+                    init1[4 * q + 2 * i] = r1.x; init1[4 * q + 2 * i + 1] = r1.y;
                 }
             }
             if (has_pad) {
@@ -642,18 +655,30 @@ __global__ void __launch_bounds__(VQS_WAVES * 64, 8 / VQS_WAVES) vq_screen16_ker
 #ifdef VQS16_NO_SWEEP
         const bool certified = true;
 #else
-        const bool certified = ((b1 - b2) > thr) && code[rb] < a.C;
+        const bool certified = ((b1 - b2) > thr) && code[rb] < a.C && b1 < 3.0e38f;
 #endif
-        const bool pair = !certified && ((b1 - b3) > thr) && code[rb] < a.C && id2 < a.C;
+        const bool pair = !certified && ((b1 - b3) > thr) && code[rb] < a.C && id2 < a.C && b1 < 3.0e38f;
         flagged[rb] = !certified;
         if (row_ok[rb] && half == 0) {
             a.idx_out[rows[rb] * a.idx_stride] = (int64_t)(code[rb] < a.C ? code[rb] : 0);
             if (a.dbg) {
-                // debug view in the units of t = x.c - ||c||^2 / 2: the two best scores with the certificate's code parts taken off
-                // again, and the margin they have to exceed (certified <=> d[0] - d[1] > d[2])
+                // debug view in the units of t = x.c - ||c||^2 / 2: the two best scores with exactly what the sweep added to their start
+                // values taken off again (the start value is recomputed with the sweep's own operations; the plain -||c||^2 / 2 sits at
+                // floats 64 .. of the tile tail), and the margin they have to exceed (certified <=> d[0] - d[1] > d[2])
                 float *d = a.dbg + rows[rb] * 4;
-                const float cp2 = code_part(id2);
-                d[0] = b1 * iSSv[rb] - cp1; d[1] = b2 * iSSv[rb] - cp2; d[2] = thr * iSSv[rb] - cp1 + cp2; d[3] = certified ? 0.f : (pair ? 2.f : 1.f);
+                float add[2], sc2[2];
+                const int cs[2] = {ih1, id2};
+                const float us[2] = {b1, b2};
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const int cc = cs[k] < a.C ? cs[k] : 0;
+                    const float *tl = (const float *)(a.tiles16 + (size_t)(cc >> 5) * TILE_B + 64 * DT) + (cc & 31);
+                    const float v = METRIC == 0 ? tl[0] : 0.f, w = tl[32], pz = METRIC == 0 ? tl[64] : 0.f;
+                    const float init = METRIC == 0 ? __builtin_fmaf(w, ArowS[rb], v * SSv[rb]) : w * ArowS[rb];
+                    sc2[k] = (us[k] - init) * iSSv[rb] + pz;
+                    add[k] = init * iSSv[rb] - pz;
+                }
+                d[0] = sc2[0]; d[1] = sc2[1]; d[2] = thr * iSSv[rb] - add[0] + add[1]; d[3] = certified ? 0.f : (pair ? 2.f : 1.f);
             }
         }
         if (code[rb] >= a.C) code[rb] = 0;
@@ -974,13 +999,15 @@ __global__ void __launch_bounds__(VQS_F32_WAVES * 64, (XBF16 && NPART == 1 && DT
         if (!XBF16 && NPART == 1) drop = sqrtf(rx2 * 1.001f) * 1.001f * iS;
         const float nacc = (float)(NPART * DT + 1);                                               // accumulated terms
         if (METRIC == 0) {
-            Arow = (xn * (u * (10.f + (float)DT + 2.002f * nacc) + rho) + drop + conv) * 1.0001f;
+            Arow = (xn * (u * (10.f + (float)DT + 2.002f * nacc) + rho) + drop + conv) * (1.0001f + 4.f * nacc * u);      // (+ the MFMA's rounding of the added part)
             Rrow = 5.f * u * xs2 + xn * r0 + 2e-8f;
         } else {
-            Arow = (xn * (u * (float)(DT + 2 * NPART * DT) * 1.001f + rho) + drop + conv) * 1.0001f;
+            Arow = (xn * (u * (float)(DT + 2 * NPART * DT) * 1.001f + rho) + drop + conv) * (1.0001f + 4.f * nacc * u);
             Rrow = xn * r0 + 1e-30f;
         }
         ArowS = Arow * SS;
+        const bool y2ok = __uint_as_float(a.scalars[0]) < 1e37f;       // overflow guard, as in vq_screen16_kernel
+        if (!(Arow < 1e30f) || !(ArowS < 1e30f) || !(Rrow < 1e30f) || !y2ok) { Arow = 0.f; ArowS = 0.f; Rrow = __builtin_inff(); }
     }
 
     float m1 = -__builtin_inff(), m2 = -__builtin_inff(), m3 = -__builtin_inff();
@@ -1037,10 +1064,13 @@ __global__ void __launch_bounds__(VQS_F32_WAVES * 64, (XBF16 && NPART == 1 && DT
                             const f32x4 w = *(const f32x4 *)(nh + 32 + 8 * q + 4 * half);
                             if (METRIC != 0) { v.x = v.x < -1e38f ? v.x : 0.f; v.y = v.y < -1e38f ? v.y : 0.f;
                                                v.z = v.z < -1e38f ? v.z : 0.f; v.w = v.w < -1e38f ? v.w : 0.f; }
-                            const float vs[4] = {v.x, v.y, v.z, v.w}, ws[4] = {w.x, w.y, w.z, w.w};
+                            const f32x2 vp[2] = {f32x2{v.x, v.y}, f32x2{v.z, v.w}}, wp[2] = {f32x2{w.x, w.y}, f32x2{w.z, w.w}};
 #pragma unroll
-                            for (int i = 0; i < 4; ++i)
-                                init[4 * q + i] = (METRIC == 0 || has_pad) ? __builtin_fmaf(ws[i], ArowS, vs[i] * SS) : ws[i] * ArowS;
+                            for (int i = 0; i < 2; ++i) {
+                                const f32x2 r = (METRIC == 0 || has_pad) ? __builtin_elementwise_fma(wp[i], f32x2{ArowS, ArowS}, vp[i] * f32x2{SS, SS})
+                                                                         : wp[i] * f32x2{ArowS, ArowS};
+                                init[4 * q + 2 * i] = r.x; init[4 * q + 2 * i + 1] = r.y;
+                            }
                         }
                         if (has_pad) {
 #pragma unroll
@@ -1116,15 +1146,26 @@ __global__ void __launch_bounds__(VQS_F32_WAVES * 64, (XBF16 && NPART == 1 && DT
         };
         const float cp1 = code_part(ih1);
         const float thr = (2.f * cp1 + 2.f * Rrow) * SS + 8e-6f * fabsf(b1);
-        const bool certified = ((b1 - b2) > thr) && code < a.C;
-        const bool pair = !certified && ((b1 - b3) > thr) && code < a.C && id2 < a.C;
+        const bool certified = ((b1 - b2) > thr) && code < a.C && b1 < 3.0e38f;
+        const bool pair = !certified && ((b1 - b3) > thr) && code < a.C && id2 < a.C && b1 < 3.0e38f;
         flagged = !certified;
         if (row_ok && half == 0) {
             a.idx_out[row * a.idx_stride] = (int64_t)(code < a.C ? code : 0);
-            if (a.dbg) {        // (in the units of t = x.c - ||c||^2 / 2, code parts taken off again: certified <=> d[0] - d[1] > d[2])
+            if (a.dbg) {        // (in the units of t = x.c - ||c||^2 / 2, what the sweep added taken off again: certified <=> d[0] - d[1] > d[2])
                 float *d = a.dbg + row * 4;
-                const float cp2 = code_part(id2);
-                d[0] = b1 * iSS - cp1; d[1] = b2 * iSS - cp2; d[2] = thr * iSS - cp1 + cp2; d[3] = certified ? 0.f : (pair ? 2.f : 1.f);
+                float add[2], sc2[2];
+                const int cs[2] = {ih1, id2};
+                const float us[2] = {b1, b2};
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const int cc = cs[k] < a.C ? cs[k] : 0;
+                    const float *tl = (const float *)(a.tiles16 + (size_t)(cc >> 5) * TILE_B + 64 * DT) + (cc & 31);
+                    const float v = METRIC == 0 ? tl[0] : 0.f, w = tl[32], pz = METRIC == 0 ? tl[64] : 0.f;
+                    const float init = METRIC == 0 ? __builtin_fmaf(w, ArowS, v * SS) : w * ArowS;
+                    sc2[k] = (us[k] - init) * iSS + pz;
+                    add[k] = init * iSS - pz;
+                }
+                d[0] = sc2[0]; d[1] = sc2[1]; d[2] = thr * iSS - add[0] + add[1]; d[3] = certified ? 0.f : (pair ? 2.f : 1.f);
             }
         }
         if (code >= a.C) code = 0;
@@ -1236,11 +1277,12 @@ extern "C" int64_t vqhip_screen_partials(int64_t N, int x_dtype)
 
 extern "C" size_t vqhip_screen_workspace_bytes(int64_t N)
 {
-    // 16-byte header (count) | N ints (row list, padded to 8 bytes) | N u64 (keys of the exact pass)
+    // 16-byte header (count) | ceil(N / 128) ints (round 6: arrival counters of the exact sweep's 128-row chunks, vq_tail_kernel; zeroed
+    // with the header by the residual chain, unused otherwise) | N ints (row list, padded to 8 bytes) | N u64 (keys of the exact pass)
     // | segmented staging of the persistent screening kernel: 2 VQ_SEG_MAX counters, (N + 256 VQ_SEG_MAX) u64 keys and as many int rows
     if (N <= 0) return 0;
     const size_t nseg = (size_t)N + 256 * (size_t)VQ_SEG_MAX;
-    return 16 + (((size_t)N * sizeof(int) + 7) & ~(size_t)7) + (size_t)N * sizeof(unsigned long long)
+    return 16 + vq_screen_done_ints(N) * sizeof(int) + (((size_t)N * sizeof(int) + 7) & ~(size_t)7) + (size_t)N * sizeof(unsigned long long)
          + 2 * VQ_SEG_MAX * sizeof(int) + nseg * sizeof(unsigned long long) + nseg * sizeof(int);
 }
 
@@ -1406,7 +1448,8 @@ int vq_assign_screened_impl(const void *x, int x_dtype, int64_t N, int D, int64_
 
     hipStream_t st = (hipStream_t)stream;
     int *count = (int *)workspace;
-    int *rows = count + 4;
+    int *done = count + 4;                                           // arrival counters of the merged exact-pass launch (chain)
+    int *rows = done + vq_screen_done_ints(N);
     if (!header_zeroed) {
         hipError_t e = heads > 1 ? hipMemset2DAsync(count, (size_t)hs->ws, 0, 16, (size_t)heads, st) : hipMemsetAsync(count, 0, 16, st);
         if (e != hipSuccess) VQ_FAIL((int)e, "assign_screened: hipMemsetAsync: %s", hipGetErrorString(e));
@@ -1423,7 +1466,7 @@ int vq_assign_screened_impl(const void *x, int x_dtype, int64_t N, int D, int64_
     a.C = C;
     a.idx_out = idx_out; a.q_out = q_out; a.ldq = ldq; a.resid_out = resid_out; a.ldr = ldr;
     a.sqerr_partial = sqerr_partial; a.row_mask = row_mask;
-    unsigned long long *keys = (unsigned long long *)((char *)workspace + 16 + (((size_t)N * sizeof(int) + 7) & ~(size_t)7));
+    unsigned long long *keys = (unsigned long long *)((char *)rows + (((size_t)N * sizeof(int) + 7) & ~(size_t)7));
     a.flag_count = count; a.flag_rows = rows; a.flag_keys = keys; a.dbg = debug_out;
     {
         const size_t nseg = (size_t)N + 256 * (size_t)VQ_SEG_MAX;
@@ -1480,6 +1523,11 @@ int vq_assign_screened_impl(const void *x, int x_dtype, int64_t N, int D, int64_
     const int64_t ldl = chained ? chain->ldxo : ldx;
     VqHeadStrides hl;
     if (hs) { hl = *hs; if (chained) hl.x = hs->xo; }
+    // the residual chain (index output only, counters zeroed with the header by its caller): ONE launch for the exact sweep of the open
+    // rows and the two exact distances of the pair rows, both writing their index themselves (round 6; was refine -> pair -> finish)
+    if (chain && header_zeroed && !q_out && !resid_out && !sqerr_partial && vq_tail_enabled())
+        return vq_assign_listed_direct(xl, x_dtype, metric, N, D, ldl, packed, embed, C, idx_out, a.idx_stride, rows, count, keys, done, st,
+                                       hs ? &hl : nullptr);
     return vq_assign_listed(xl, x_dtype, metric, N, D, ldl, packed, embed, C, idx_out, a.idx_stride, q_out, ldq, resid_out, ldr,
                             sqerr_partial ? sqerr_partial + vqhip_screen_blocks(N, x_dtype) : nullptr, row_mask, rows, count, keys,
                             with_pairs, st, hs ? &hl : nullptr);

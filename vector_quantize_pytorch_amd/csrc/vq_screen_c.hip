@@ -74,6 +74,7 @@ __global__ void __launch_bounds__(256, 2) vq_screenc_kernel(const ScreenArgs a, 
     const int sc = (int)a.scalars[2];
     const float rho = __uint_as_float(a.scalars[1]);
     const float r0 = __uint_as_float(a.scalars[3]);
+    const bool y2ok = __uint_as_float(a.scalars[0]) < 1e37f;
     const int ldq2 = (int)(a.ldq * 2);
     const int ldx2 = (int)(a.ldx * 2);
     const int nb_mine = gid < nblk ? (nblk - gid + G2 - 1) / G2 : 0;
@@ -93,8 +94,9 @@ __global__ void __launch_bounds__(256, 2) vq_screenc_kernel(const ScreenArgs a, 
         const float conv = u * sqrtf((float)DT) * __uint_as_float((unsigned)(127 - SX) << 23);
         const float xn = sqrtf(xs) * 1.0001f;
         const float nacc = (float)(DT + 1);
-        if (METRIC == 0) return (xn * (u * (10.f + (float)DT + 2.002f * nacc) + rho) + conv) * 1.0001f;
-        return (xn * (u * (float)(DT + 2 * DT) * 1.001f + rho) + conv) * 1.0001f;
+        const float slack = 1.0001f + 4.f * nacc * u;      // (+ the MFMA's rounding of the added part itself)
+        if (METRIC == 0) return (xn * (u * (10.f + (float)DT + 2.002f * nacc) + rho) + conv) * slack;
+        return (xn * (u * (float)(DT + 2 * DT) * 1.001f + rho) + conv) * slack;
     };
     auto rrow_of = [&](float xs) {
         const float xn = sqrtf(xs) * 1.0001f;
@@ -236,8 +238,13 @@ __global__ void __launch_bounds__(256, 2) vq_screenc_kernel(const ScreenArgs a, 
             }
         SS_c = __uint_as_float((unsigned)(SX + sc + 127) << 23);
         iSS_c = __uint_as_float((unsigned)(127 - SX - sc) << 23);
+        // per ROW (a wave-uniform factor was measured: ~1 % of the cfg-2 search against 55 % instead of 7 % open rows when the row norms
+        // of a batch span 30 x)
         arow_c[0] = arow_of(xs2[0], SX); arow_c[1] = arow_of(xs2[1], SX);
         rrow_c[0] = rrow_of(xs2[0]); rrow_c[1] = rrow_of(xs2[1]);
+#pragma unroll
+        for (int t = 0; t < 2; ++t)     // overflow guard (vq_screen16_kernel): such a row is never certified and adds nothing to the start values
+            if (!(arow_c[t] < 1e30f) || !(arow_c[t] * SS_c < 1e30f) || !(rrow_c[t] < 1e30f) || !y2ok) { arow_c[t] = 0.f; rrow_c[t] = __builtin_inff(); }
     };
     auto reset_fold = [&]() __attribute__((always_inline)) {
 #pragma unroll
@@ -330,17 +337,21 @@ __global__ void __launch_bounds__(256, 2) vq_screenc_kernel(const ScreenArgs a, 
                         const f32x4 w = *(const f32x4 *)(nh + 32 + 8 * q);
                         if (METRIC != 0) { v.x = v.x < -1e38f ? v.x : 0.f; v.y = v.y < -1e38f ? v.y : 0.f;
                                            v.z = v.z < -1e38f ? v.z : 0.f; v.w = v.w < -1e38f ? v.w : 0.f; }
-                        const float vs[4] = {v.x, v.y, v.z, v.w}, ws[4] = {w.x, w.y, w.z, w.w};
+                        // two scores per instruction (v_pk_mul_f32 / v_pk_fma_f32, explicit 2-vectors: the SLP vectoriser is off)
+                        const f32x2 vp[2] = {f32x2{v.x, v.y}, f32x2{v.z, v.w}}, wp[2] = {f32x2{w.x, w.y}, f32x2{w.z, w.w}};
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) {
+                        for (int i = 0; i < 2; ++i) {
+                            f32x2 r0, r1;
                             if (METRIC == 0 || has_pad) {
-                                const float b = vs[i] * SS_c;
-                                init0[4 * q + i] = __builtin_fmaf(ws[i], as0, b);
-                                init1[4 * q + i] = __builtin_fmaf(ws[i], as1, b);
+                                const f32x2 b = vp[i] * f32x2{SS_c, SS_c};
+                                r0 = __builtin_elementwise_fma(wp[i], f32x2{as0, as0}, b);
+                                r1 = __builtin_elementwise_fma(wp[i], f32x2{as1, as1}, b);
                             } else {
-                                init0[4 * q + i] = ws[i] * as0;
-                                init1[4 * q + i] = ws[i] * as1;
+                                r0 = wp[i] * f32x2{as0, as0};
+                                r1 = wp[i] * f32x2{as1, as1};
                             }
+                            init0[4 * q + 2 * i] = r0.x; init0[4 * q + 2 * i + 1] = r0.y;
+                            init1[4 * q + 2 * i] = r1.x; init1[4 * q + 2 * i + 1] = r1.y;
                         }
                     }
                     if (has_pad) {
@@ -407,10 +418,24 @@ __global__ void __launch_bounds__(256, 2) vq_screenc_kernel(const ScreenArgs a, 
                 };
                 const float cp1 = code_part(codes[t]);
                 const float thr = (2.f * cp1 + 2.f * rrow_c[t]) * SS_c + 8e-6f * fabsf(b1);
-                cert[t] = ((b1 - b2) > thr) && codes[t] < a.C;
-                pairf[t] = !cert[t] && ((b1 - b3) > thr) && codes[t] < a.C && id2s[t] < a.C;
-                dbg4[t][0] = b1 * iSS_c - cp1; dbg4[t][1] = b2 * iSS_c; dbg4[t][2] = thr * iSS_c - cp1;
-                if (a.dbg) { const float cp2 = code_part(id2s[t]); dbg4[t][1] -= cp2; dbg4[t][2] += cp2; }
+                cert[t] = ((b1 - b2) > thr) && codes[t] < a.C && b1 < 3.0e38f;
+                pairf[t] = !cert[t] && ((b1 - b3) > thr) && codes[t] < a.C && id2s[t] < a.C && b1 < 3.0e38f;
+                dbg4[t][0] = dbg4[t][1] = dbg4[t][2] = 0.f;
+                if (a.dbg) {    // debug view in the units of t = x.c - ||c||^2 / 2 (vq_screen16_kernel): what the sweep added is taken off again
+                    float add[2], sc2[2];
+                    const int cs[2] = {codes[t], id2s[t]};
+                    const float us[2] = {b1, b2};
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) {
+                        const int cc = cs[k] < a.C ? cs[k] : 0;
+                        const float *tl = (const float *)(tiles + (size_t)(cc >> 5) * TILE_B + 64 * DT) + (cc & 31);
+                        const float v = METRIC == 0 ? tl[0] : 0.f, w = tl[32], pz = METRIC == 0 ? tl[64] : 0.f;
+                        const float init = METRIC == 0 ? __builtin_fmaf(w, arow_c[t] * SS_c, v * SS_c) : w * (arow_c[t] * SS_c);
+                        sc2[k] = (us[k] - init) * iSS_c + pz;
+                        add[k] = init * iSS_c - pz;
+                    }
+                    dbg4[t][0] = sc2[0]; dbg4[t][1] = sc2[1]; dbg4[t][2] = thr * iSS_c - add[0] + add[1];
+                }
             }
             code = half_b ? codes[1] : codes[0];
             id2 = half_b ? id2s[1] : id2s[0];

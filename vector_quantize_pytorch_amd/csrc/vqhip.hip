@@ -268,8 +268,14 @@ __global__ void __launch_bounds__(256) vq_pack16_kernel(const float *embed, int 
         const float y2 = (real && t < n_tiles) ? packed[(size_t)t * (32 * DT + 256) + 32 * DT + i] : 0.f;
         const float kb = 5.9604645e-8f * (5.f + 1.001f * (float)(DT + 1) + 0.51f) * 1.001f;
         const float yb = sqrtf(y2) * 1.0001f;                   // (y2 is ATen's fp32 sum: off the true norm by < D u relative)
-        if (i < 32) { nh[i] = real ? __builtin_fmaf(kb, y2, -0.5f * y2) : -3.0e38f; nh[32 + i] = real ? yb : 0.f; }
-        else if (i < 224) nh[32 + i] = 0.f;
+        // (a norm that overflowed fp32 -- y2 = inf / NaN / >= 1e37 -- gets finite placeholders: no NaN may enter the top-3 fold, which
+        //  would silently drop it; the screening kernels certify NOTHING against such a codebook, scalars[0])
+        const bool sane = y2 < 1e37f;
+        if (i < 32) {
+            nh[i] = real ? (sane ? __builtin_fmaf(kb, y2, -0.5f * y2) : -3.0e38f) : -3.0e38f;
+            nh[32 + i] = (real && sane) ? fminf(yb, 1e19f) : 0.f;
+            nh[64 + i] = (real && sane) ? -0.5f * y2 : -3.0e38f;      // the plain start value (debug view of the screening kernels only)
+        } else if (i < 192) nh[64 + i] = 0.f;
         // the rounding of the fp16 copy, per code: every element errs by <= max(2^-12 |c_i|, 2^(-25 - sc)) (RNE; subnormal spacing below
         // 2^-14 scaled), so ||c - c_h|| <= rho ||c|| + r0 with r0 = sqrt(DT) 2^(-25 - sc) and rho <= 2^-12: rho is MEASURED as the
         // largest (||c - c_h|| - r0)+ / ||c|| -- a relative quantity that no single code's size can inflate
@@ -1744,14 +1750,20 @@ struct RefineArgs {
     const int *row_count;
     unsigned long long *keys;   // [list capacity], preset to ~0
     VqHeadStrides hs;           // batched heads: blockIdx.y = head
+    // DIRECT (vq_tail_kernel): the sweep writes the index itself -- idx_out[row * idx_stride]; a split sweep counts its arrivals per
+    // 128-row chunk in done[] (zeroed by the caller) and the last one reads the chunk's keys back
+    int64_t *idx_out;
+    int64_t idx_stride;
+    int *done;
 };
 
 // (bid, nblk): this workgroup's number and the number of workgroups doing this work -- the kernel's own grid, or its share of
-// the merged launch vq_listed_kernel further down
-template <int DT, bool XBF16, int METRIC>
+// the merged launch vq_tail_kernel further down
+template <int DT, bool XBF16, int METRIC, bool DIRECT = false>
 __device__ __forceinline__ void vq_refine_body(const RefineArgs &a0, char *smem, const unsigned bid, const unsigned nblk)
 {
     RefineArgs a = a0;
+    __shared__ int s_last;
     constexpr int TILE_F = 32 * DT + 256;
     constexpr int TILE_B = TILE_F * 4;
     constexpr int NCHUNK = TILE_B / 1024;
@@ -1769,6 +1781,10 @@ __device__ __forceinline__ void vq_refine_body(const RefineArgs &a0, char *smem,
         a.row_list = (const int *)((const char *)a0.row_list + h * a0.hs.ws);
         a.row_count = (const int *)((const char *)a0.row_count + h * a0.hs.ws);
         a.keys = (unsigned long long *)((char *)a0.keys + h * a0.hs.ws);
+        if (DIRECT) {
+            a.idx_out = (int64_t *)((char *)a0.idx_out + h * a0.hs.idx);
+            a.done = (int *)((char *)a0.done + h * a0.hs.ws);
+        }
     }
     const int list_n = __builtin_amdgcn_readfirstlane(*a.row_count);
     if (list_n <= 0) return;
@@ -1850,8 +1866,27 @@ __device__ __forceinline__ void vq_refine_body(const RefineArgs &a0, char *smem,
         // similarities go through the usual sign fix (monotone map to uint) and are inverted so that larger is smaller
         unsigned hk = __float_as_uint(bd);
         if (METRIC != 0) hk = ~(hk ^ ((hk >> 31) ? 0xffffffffu : 0x80000000u));
+        if (DIRECT && splits == 1) {                      // this workgroup swept the whole codebook for the chunk: the winner is final
+            if (row_ok && hi == 0) a.idx_out[row * a.idx_stride] = (int64_t)bi;
+            continue;
+        }
         if (row_ok && hi == 0)
             atomicMin(a.keys + pos, ((unsigned long long)hk << 32) | (unsigned long long)(unsigned)bi);
+        if (DIRECT) {
+            // the chunk's last arriver (of `splits` workgroups) reads the merged keys back (device-scope atomics: L2) and writes the indices
+            __threadfence();
+            __syncthreads();
+            if (tid == 0) s_last = (atomicAdd(a.done + chunk, 1) == splits - 1) ? 1 : 0;
+            __syncthreads();
+            if (s_last) {
+                __threadfence();
+                const int64_t p2 = chunk * VQHIP_ASSIGN_ROWS_PER_BLOCK + tid;
+                if (tid < VQHIP_ASSIGN_ROWS_PER_BLOCK && p2 < list_n) {
+                    const unsigned long long k = __hip_atomic_load(a.keys + p2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    a.idx_out[(int64_t)a.row_list[p2] * a.idx_stride] = (int64_t)(unsigned)(k & 0xffffffffull);
+                }
+            }
+        }
     }
 }
 
@@ -1982,6 +2017,8 @@ struct PairArgs {
     int64_t cap;
     unsigned long long *keys;
     VqHeadStrides hs;         // batched heads: blockIdx.y = head
+    int64_t *idx_out;         // DIRECT (vq_tail_kernel): the winner goes straight to idx_out[row * idx_stride]
+    int64_t idx_stride;
 };
 
 // The 16-byte pieces a lane streams from its OWN row and its two code rows would touch 64 different cache lines per wave
@@ -1998,12 +2035,13 @@ template <bool XBF16> struct PairCfg {
     static constexpr int SMEM = VQ_PAIR_WAVES * WAVE_B;
 };
 
-template <int DT, bool XBF16, int METRIC>
+template <int DT, bool XBF16, int METRIC, bool DIRECT = false>
 __device__ __forceinline__ void vq_pair_body(const PairArgs &a0, char *smem, const unsigned bid, const unsigned nblk)
 {
     PairArgs a = a0;
     if (a0.hs.heads > 1) {
         const int64_t h = blockIdx.y;
+        if (DIRECT) a.idx_out = (int64_t *)((char *)a0.idx_out + h * a0.hs.idx);
         a.x = (const char *)a0.x + h * a0.hs.x;
         a.embed = (const float *)((const char *)a0.embed + h * a0.hs.embed);
         a.packed = (const float *)((const char *)a0.packed + h * a0.hs.packed);
@@ -2106,7 +2144,10 @@ __device__ __forceinline__ void vq_pair_body(const PairArgs &a0, char *smem, con
         } else {
             win = (xy2 > xy1 || (xy2 == xy1 && c2 < c1)) ? c2 : c1;
         }
-        if (base + lane < n) a.keys[pos] = (unsigned long long)(unsigned)win;
+        if (base + lane < n) {
+            if (DIRECT) a.idx_out[row * a.idx_stride] = (int64_t)win;
+            else a.keys[pos] = (unsigned long long)(unsigned)win;
+        }
     }
 }
 
@@ -2127,6 +2168,72 @@ static int dispatch_pair(const PairArgs &a, int x_dtype, int metric, unsigned bl
     return launch_status("vq_pair_kernel");
 }
 
+// ONE launch for the listed exact passes of a residual-chain stage (index output only): workgroups [0, gx) run the exact sweep of the
+// open rows, the others the two exact distances of the pair rows, and both write their winners to idx_out themselves -- was three
+// dependent launches (refine -> pair -> finish, ~50 us of a stage that the next stage's screening kernel waits for).
+template <int DT, bool XBF16, int METRIC>
+__global__ void __launch_bounds__(256, (DT <= 256 ? 2 : 1)) vq_tail_kernel(const RefineArgs r, const PairArgs p, const unsigned gx)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (blockIdx.x < gx) vq_refine_body<DT, XBF16, METRIC, true>(r, smem, blockIdx.x, gx);
+    else vq_pair_body<DT, XBF16, METRIC, true>(p, smem, blockIdx.x - gx, gridDim.x - gx);
+}
+
+int vq_tail_enabled()
+{
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("VQHIP_TAIL"); v = (e && e[0] == '0') ? 0 : 1; }
+    return v;
+}
+
+template <int DT, bool XBF16, int METRIC>
+static int launch_tail(const RefineArgs &r, const PairArgs &p, unsigned gx, unsigned pb, hipStream_t st)
+{
+    constexpr int SM_R = 2 * (32 * DT + 256) * 4, SM_P = PairCfg<XBF16>::SMEM, SMEM = SM_R > SM_P ? SM_R : SM_P;
+    static VqAttrOnce once;
+    if (int rc = vq_set_max_smem(once, (const void *)vq_tail_kernel<DT, XBF16, METRIC>, SMEM, "vq_tail_kernel")) return rc;
+    hipLaunchKernelGGL((vq_tail_kernel<DT, XBF16, METRIC>), dim3(gx + pb, r.hs.heads > 1 ? r.hs.heads : 1), dim3(256), SMEM, st, r, p, gx);
+    return launch_status("vq_tail_kernel");
+}
+
+template <int DT>
+static int dispatch_tail(const RefineArgs &r, const PairArgs &p, int x_dtype, int metric, unsigned gx, unsigned pb, hipStream_t st)
+{
+    if (metric == VQHIP_EUCLID)
+        return x_dtype == VQHIP_BF16 ? launch_tail<DT, true, 0>(r, p, gx, pb, st) : launch_tail<DT, false, 0>(r, p, gx, pb, st);
+    return x_dtype == VQHIP_BF16 ? launch_tail<DT, true, 1>(r, p, gx, pb, st) : launch_tail<DT, false, 1>(r, p, gx, pb, st);
+}
+
+int vq_assign_listed_direct(const void *x, int x_dtype, int metric, int64_t N, int D, int64_t ldx, const float *packed, const float *embed, int C,
+                            int64_t *idx_out, int64_t idx_stride, const int *row_list, const int *row_count, unsigned long long *keys, int *done,
+                            hipStream_t st, const VqHeadStrides *hs)
+{
+    VqHeadStrides h1;
+    h1.heads = 1; h1.x = h1.packed = h1.embed = h1.codes = h1.idx = h1.q = h1.ws = 0;
+    const VqHeadStrides &H = hs ? *hs : h1;
+    RefineArgs r;
+    r.x = x; r.ldx = ldx; r.packed = packed; r.C = C; r.n_tiles = (C + 31) / 32;
+    r.row_list = row_list; r.row_count = row_count; r.keys = keys; r.hs = H;
+    r.idx_out = idx_out; r.idx_stride = idx_stride; r.done = done;
+    const int64_t chunks = vqhip_assign_blocks(N);
+    const int64_t want = chunks * r.n_tiles;
+    const unsigned gx = (unsigned)(want < VQ_REFINE_GRID ? want : VQ_REFINE_GRID);
+    PairArgs pa;
+    pa.x = x; pa.ldx = ldx; pa.embed = embed; pa.packed = packed; pa.D = D;
+    pa.row_list = row_list; pa.row_count = row_count; pa.cap = N; pa.keys = keys; pa.hs = H;
+    pa.idx_out = idx_out; pa.idx_stride = idx_stride;
+    const int64_t pb = (N + VQ_PAIR_WAVES * 64 - 1) / (VQ_PAIR_WAVES * 64);
+    const unsigned blocks = (unsigned)(pb < 1024 ? pb : 1024);
+    switch (pick_dt(D)) {
+        case 32: return dispatch_tail<32>(r, pa, x_dtype, metric, gx, blocks, st);
+        case 64: return dispatch_tail<64>(r, pa, x_dtype, metric, gx, blocks, st);
+        case 128: return dispatch_tail<128>(r, pa, x_dtype, metric, gx, blocks, st);
+        case 256: return dispatch_tail<256>(r, pa, x_dtype, metric, gx, blocks, st);
+        case 512: return dispatch_tail<512>(r, pa, x_dtype, metric, gx, blocks, st);
+        default: VQ_FAIL(VQHIP_EDIM, "assign_listed_direct: D=%d unsupported", D);
+    }
+}
+
 int vq_assign_listed(const void *x, int x_dtype, int metric, int64_t N, int D, int64_t ldx, const float *packed, const float *embed, int C,
                      int64_t *idx_out, int64_t idx_stride, void *q_out, int64_t ldq, void *resid_out, int64_t ldr, double *sqerr_partial,
                      const uint8_t *row_mask, const int *row_list, const int *row_count, unsigned long long *keys, int with_pairs,
@@ -2141,6 +2248,7 @@ int vq_assign_listed(const void *x, int x_dtype, int metric, int64_t N, int D, i
     RefineArgs r;
     r.x = x; r.ldx = ldx; r.packed = packed; r.C = C; r.n_tiles = (C + 31) / 32;
     r.row_list = row_list; r.row_count = row_count; r.keys = keys; r.hs = H;
+    r.idx_out = nullptr; r.idx_stride = 1; r.done = nullptr;
     const int64_t chunks = vqhip_assign_blocks(N);
     const int64_t want = chunks * r.n_tiles;              // one workgroup per (chunk, tile) at most
     const unsigned gx = (unsigned)(want < VQ_REFINE_GRID ? want : VQ_REFINE_GRID);
@@ -2150,6 +2258,7 @@ int vq_assign_listed(const void *x, int x_dtype, int metric, int64_t N, int D, i
     PairArgs pa;
     pa.x = x; pa.ldx = ldx; pa.embed = embed; pa.packed = packed; pa.D = D;
     pa.row_list = row_list; pa.row_count = row_count; pa.cap = N; pa.keys = keys; pa.hs = H;
+    pa.idx_out = nullptr; pa.idx_stride = 1;
     const int64_t pb = (N + VQ_PAIR_WAVES * 64 - 1) / (VQ_PAIR_WAVES * 64);
     const unsigned blocks = (unsigned)(pb < 1024 ? pb : 1024);
     switch (pick_dt(D)) {
@@ -4172,10 +4281,12 @@ extern "C" int vqhip_unpack_best(const int64_t *key, int64_t N, int64_t own_lo, 
 // one wave per output row.  The Q indices of a row are fetched first, then the code rows of 8 stages at a time are all
 // requested before any is added (the first version chained index load -> row load -> add per stage: latency bound at
 // 1.1 TB/s of output); the adds keep the stage order, so the result is the same running sum as rvq.py:525.
+// idx_stride: elements between the rows of idx (>= Q: the first Q columns of a wider index tensor); accumulate != 0 (fp32 outputs): the
+// running sum starts from what `out` holds -- a decode split into stage ranges continues the SAME left-to-right sum of rvq.py:525
 template <bool VEC>
-__global__ void __launch_bounds__(256) vq_decode_kernel(const int64_t *__restrict__ idx, int64_t N, int Q,
+__global__ void __launch_bounds__(256) vq_decode_kernel(const int64_t *__restrict__ idx, int64_t idx_stride, int64_t N, int Q,
                                                         const float *__restrict__ embed, int64_t qstride, int C, int D,
-                                                        void *out, int out_bf16, int64_t ldo)
+                                                        void *out, int out_bf16, int64_t ldo, int accumulate)
 {
     const int lane = threadIdx.x & 63;
     const int64_t n = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -4183,10 +4294,17 @@ __global__ void __launch_bounds__(256) vq_decode_kernel(const int64_t *__restric
     constexpr int U = 8;
     if (VEC) {                      // D % 4 == 0, 16-byte aligned rows: lane owns columns 4 lane + 256 h .. +3
         f32x4 s[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+        if (accumulate) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int d = lane * 4 + 256 * h;
+                if (d < D) s[h] = *(const f32x4 *)((const float *)out + n * ldo + d);
+            }
+        }
         for (int q0 = 0; q0 < Q; q0 += U) {
             int64_t c[U];
 #pragma unroll
-            for (int u = 0; u < U; ++u) c[u] = (q0 + u < Q) ? idx[n * Q + q0 + u] : -1;
+            for (int u = 0; u < U; ++u) c[u] = (q0 + u < Q) ? idx[n * idx_stride + q0 + u] : -1;
             f32x4 v[U][2];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
@@ -4222,9 +4340,9 @@ __global__ void __launch_bounds__(256) vq_decode_kernel(const int64_t *__restric
     }
     float s[8];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) s[u] = 0.f;
+    for (int u = 0; u < 8; ++u) { const int d = lane + 64 * u; s[u] = (accumulate && d < D) ? ((const float *)out)[n * ldo + d] : 0.f; }
     for (int q = 0; q < Q; ++q) {
-        const int64_t c = idx[n * Q + q];
+        const int64_t c = idx[n * idx_stride + q];
         if (c < 0 || c >= C) continue;
         const float *r = embed + (size_t)q * qstride + (size_t)c * D;
 #pragma unroll
@@ -4290,16 +4408,24 @@ __global__ void __launch_bounds__(1024) vq_decode_lds_kernel(const int64_t *__re
 extern "C" int vqhip_decode_sum(const int64_t *idx, int64_t N, int Q, const float *embed, int64_t embed_qstride,
                                 int C, int D, void *out, int out_dtype, int64_t ldo, void *stream)
 {
-    if (N < 0 || Q < 1 || C <= 0) VQ_FAIL(VQHIP_EINVAL, "decode_sum: bad size");
+    return vqhip_decode_sum_range(idx, Q, N, Q, embed, embed_qstride, C, D, out, out_dtype, ldo, 0, stream);
+}
+
+extern "C" int vqhip_decode_sum_range(const int64_t *idx, int64_t idx_stride, int64_t N, int Q, const float *embed, int64_t embed_qstride,
+                                      int C, int D, void *out, int out_dtype, int64_t ldo, int accumulate, void *stream)
+{
+    if (N < 0 || Q < 1 || C <= 0 || idx_stride < Q) VQ_FAIL(VQHIP_EINVAL, "decode_sum: bad size");
     if (N == 0) return 0;
     if (!idx || !embed || !out) VQ_FAIL(VQHIP_EINVAL, "decode_sum: null pointer");
+    if (accumulate && out_dtype != VQHIP_F32) VQ_FAIL(VQHIP_EINVAL, "decode_sum_range: accumulate continues an fp32 running sum");
+    if ((accumulate || idx_stride != Q) && vq_is_wide(D)) VQ_FAIL(VQHIP_EDIM, "decode_sum_range: stage ranges are for D <= 512");
     if (D < 1 || D > VQ_WIDE_MAX_D) VQ_FAIL(VQHIP_EDIM, "decode_sum: D=%d unsupported (1..%d)", D, VQ_WIDE_MAX_D);
     if (out_dtype != VQHIP_F32 && out_dtype != VQHIP_BF16) VQ_FAIL(VQHIP_EINVAL, "decode_sum: unknown dtype");
     if (vq_is_wide(D)) return vq_wide_decode_sum(idx, N, Q, embed, embed_qstride, C, D, out, out_dtype, ldo, stream);
     const int oes = (out_dtype == VQHIP_BF16) ? 2 : 4;
     const bool vec = (D % 4 == 0) && (embed_qstride % 4 == 0) && ((((uintptr_t)embed) & 15) == 0) &&
                      ((((uintptr_t)out) % (4 * oes)) == 0) && ((ldo * oes) % (4 * oes) == 0);
-    if (vec && Q >= 2 && (embed_qstride == 0 || Q == 1) && C <= 1024 && D % VQ_DECODE_LDS_COLS == 0 && N >= 16384) {
+    if (vec && Q >= 2 && (embed_qstride == 0 || Q == 1) && C <= 1024 && D % VQ_DECODE_LDS_COLS == 0 && N >= 16384 && !accumulate && idx_stride == Q) {
         // shared codebook, several stages: the codes' column slices live in LDS (the gathers from L2 were the bound)
         const int smem = C * VQ_DECODE_LDS_COLS * 4;
         static VqAttrOnce once;
@@ -4314,11 +4440,11 @@ extern "C" int vqhip_decode_sum(const int64_t *idx, int64_t N, int Q, const floa
         return launch_status("vq_decode_lds_kernel");
     }
     if (vec)
-        hipLaunchKernelGGL(vq_decode_kernel<true>, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, (hipStream_t)stream, idx, N, Q, embed,
-                           embed_qstride, C, D, out, out_dtype == VQHIP_BF16, ldo);
+        hipLaunchKernelGGL(vq_decode_kernel<true>, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, (hipStream_t)stream, idx, idx_stride, N, Q, embed,
+                           embed_qstride, C, D, out, out_dtype == VQHIP_BF16, ldo, accumulate);
     else
-        hipLaunchKernelGGL(vq_decode_kernel<false>, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, (hipStream_t)stream, idx, N, Q, embed,
-                           embed_qstride, C, D, out, out_dtype == VQHIP_BF16, ldo);
+        hipLaunchKernelGGL(vq_decode_kernel<false>, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, (hipStream_t)stream, idx, idx_stride, N, Q, embed,
+                           embed_qstride, C, D, out, out_dtype == VQHIP_BF16, ldo, accumulate);
     return launch_status("vq_decode_kernel");
 }
 

@@ -427,10 +427,20 @@ class ResidualVQ(nn.Module):
                 if native:
                     # the whole loop -- searches, routed residuals, per-stage statistics -- as ONE library call
                     # (vqhip_rvq_chain_forward): the same launches on the same streams, issued from C (VQHIP_RVQ_NATIVE=0: from here)
+                    # Decode split around the last stage (round 6: stages 0 .. Q - 2 summed on the statistics stream beside the last
+                    # stage's search): for per-stage codebooks, whose decode gathers Q code rows per output row from L2; one shared
+                    # codebook of <= 1024 codes decodes from LDS in one pass (vq_decode_lds_kernel) and keeps that (VQHIP_CHAIN_DECODE=2
+                    # forces the split, 0 turns it off)
+                    dmode = os.environ.get("VQHIP_CHAIN_DECODE", "0")       # measured slower (cfg 3 2.73 -> 2.95 ms forced, cfg 5 14.07 -> 14.66): off
+                    split_out = None
+                    if (aux is None and update and hook is not None and Q >= 2 and mask is None and x.dtype == torch.float32 and route_mode == 0
+                            and (dmode == "2" or (dmode == "1" and not (self.shared_codebook and C <= 1024)))):
+                        split_out = torch.empty_like(x)
                     r = L.rvq_chain_forward(x, packed, embed, Q, row_mask=mask, route_mode=route_mode, row_chunks=K,
                                             stats=buf if update else None, stats_ws=stats_ws if update else None,
                                             sq_parts=sq_parts if (update and want_loss) else None,
-                                            stats_stream=side if (update and hook is not None) else None)
+                                            stats_stream=side if (update and hook is not None) else None, decode_out=split_out)
+                    r["decoded"] = split_out
                     self.last_counts = r["counts"]      # per stage: (open rows, pair rows) device counters, one per row chunk (diagnostic)
                     if mask is not None and hook is None:
                         L.mask_fill_indices(r["idx"], mask)
@@ -461,7 +471,9 @@ class ResidualVQ(nn.Module):
         if side is not None and mask is not None:
             torch.cuda.current_stream(x.device).wait_stream(side)       # the side stream's statistics passes have read idx
             L.mask_fill_indices(idx, mask)
-        quantized_out = L.decode_sum(idx, embed, out_dtype=x.dtype) if aux is None else None
+        quantized_out = None
+        if aux is None:
+            quantized_out = r.get("decoded") if r.get("decoded") is not None else L.decode_sum(idx, embed, out_dtype=x.dtype)
         if aux is not None:
             aux["embed"] = embed.clone() if self.shared_codebook else embed      # (torch.stack above already copied)
             aux["Q"] = Q
@@ -784,17 +796,24 @@ class GroupedResidualVQ(nn.Module):
             side.wait_stream(main)
         env = os.environ.get("VQHIP_GRVQ_CHUNKS")
         K = 1 if capturing else (int(env) if env else L.grvq_row_chunks(N, G))
+        out = torch.empty_like(x)
+        # the decode split around the last stage: stages 0 .. Q - 2 are summed on the statistics stream beside the last stage's search
+        # (cfg 5: four 0.2 ms gathers of eight code rows per output row were the tail of every step), the last stage is added behind it
+        # -- built, bit-identical (test_residual_chain_decode_split_...), and MEASURED SLOWER: cfg 5 14.07 -> 14.66 ms (the gathers of 7 x 4
+        # stages beside the last screening kernel outlast it and hold back the last stage's statistics behind them), cfg 3 2.73 -> 2.95.
+        # Off by default (VQHIP_CHAIN_DECODE=1 / 2 turn it on).
+        split = (side is not None and Q >= 2 and mask is None and x.dtype == torch.float32 and os.environ.get("VQHIP_CHAIN_DECODE", "0") != "0")
         r = L.rvq_chain_forward(x, packed, embed, Q, row_mask=mask, row_chunks=K, stats=buf, stats_ws=stats_ws, sq_parts=sq_parts,
-                                stats_stream=side, groups=G)
+                                stats_stream=side, groups=G, decode_out=out if split else None)
         self.last_counts = r["counts"]                  # per stage: (open rows, pair rows) counters [chunks, G] (device, diagnostic)
         idx = r["idx"]                                  # [G, b, n, Q]
         if mask is not None:
             if side is not None:
                 main.wait_stream(side)                  # the statistics passes have read idx
             idx.masked_fill_(~mask.reshape(1, *idx.shape[1:-1], 1).bool(), -1)
-        out = torch.empty_like(x)
-        for g in range(G):
-            L.decode_sum(idx[g], embed[g], out=out[..., g * D:(g + 1) * D])
+        if not split:
+            for g in range(G):
+                L.decode_sum(idx[g], embed[g], out=out[..., g * D:(g + 1) * D])
 
         if update:
             if side is not None:
