@@ -626,6 +626,16 @@ def screen_stress(dev, base_ms):
         cb.embed[0, 7] *= (100.0 * cb.embed[0, 8].norm() / n7.clamp_min(1e-20)).clamp(max=1e6)
     out["one_code_x100"] = run(vq, rand_batches, 10, prep=keep_big, warm=2)
     out["one_code_x100"]["workload"] = "cfg-2 step, default codebook with code 7 held at 100 x the norm of its neighbour"
+    # control: the same module and per-step rescaling launches with the code held at 1 x (what the leg above costs without the large code)
+    vq = VectorQuantize(dim=D, codebook_size=C).to(dev).train()
+
+    def keep_one(v):
+        cb = v._codebook
+        n7 = cb.embed[0, 7].norm()
+        cb.embed[0, 7] *= (1.0 * cb.embed[0, 8].norm() / n7.clamp_min(1e-20)).clamp(max=1e6)
+    ctl = run(vq, rand_batches, 10, prep=keep_one, warm=2)
+    out["one_code_x100"]["control_ms_per_step"] = ctl["ms_per_step"]
+    out["one_code_x100"]["vs_control"] = round(out["one_code_x100"]["ms_per_step"] / ctl["ms_per_step"], 3)
     return out
 
 

@@ -5,6 +5,8 @@ BASELINE.json's full sizes.  Tests read like the reference's tests/test_readme.p
 Tolerances (BASELINE.json north_star): indices bit-exact; quantized / commit_loss / state within 1e-5
 (fp32) and 1e-2 (bf16), relative to the tensor's scale.
 """
+import os
+
 import pytest
 import torch
 
@@ -1658,13 +1660,26 @@ def test_residual_chain_batched_stage_statistics_equal_the_per_stage_passes(dev,
             m.load_state_dict(mods[0].state_dict())
 
 
+@pytest.mark.parametrize("tail", ["0", "1"])
 @pytest.mark.parametrize("twins,rows", [(3, 200000), (2, 150000), (3, 1500), (2, 70000)])
-def test_residual_chain_merged_exact_passes_on_all_open_and_all_pair_batches(dev, monkeypatch, twins, rows):
-    """Round 6: a chain stage's listed exact passes are ONE launch (vq_tail_kernel: the sweep of the open rows and the two distances of the
-    pair rows write their indices themselves; a sweep split over several workgroups lets the last arriver at the chunk's counter
-    read the keys back).  Codebooks whose every code has one / two identical twins send EVERY row there -- long lists (one workgroup per
-    chunk: direct write) and short ones (split sweeps: counters) -- against the stage-by-stage loop (VQHIP_RVQ_CHAIN=0: refine, pair and
-    finish as separate launches): identical indices and outputs, the reference's lowest-index tie rule (vqp.py:140) included."""
+def test_residual_chain_exact_passes_on_all_open_and_all_pair_batches(dev, twins, rows, tail):
+    """Codebooks whose every code has one / two identical twins send EVERY row of a residual-chain stage to the listed exact passes -- long
+    lists and short ones -- with the three launches (refine, pair, finish: the default) and with the merged launch of round 6
+    (VQHIP_TAIL=1, vq_tail_kernel: the sweep of the open rows and the two distances of the pair rows write their indices themselves; a
+    sweep split over several workgroups lets the last arriver at the chunk's counter read the keys back -- measured slower, kept
+    behind the switch), against the stage-by-stage loop (VQHIP_RVQ_CHAIN=0): identical indices and outputs, the reference's
+    lowest-index tie rule (vqp.py:140) included.  A subprocess: the switch is read once per process."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r); import torch, test_gpu_modules as T; "
+            "T._chain_exact_passes_case(torch.device('cuda', 0), %d, %d); print('CASE OK')") % (root, os.path.join(root, "tests"), twins, rows)
+    p = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, VQHIP_TAIL=tail), cwd=root, stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert p.returncode == 0 and "CASE OK" in p.stdout, p.stdout[-3000:]
+
+
+def _chain_exact_passes_case(dev, twins, rows):
     from vector_quantize_pytorch_amd import ResidualVQ
     kw = dict(dim=64, num_quantizers=3, codebook_size=96 * twins)
     torch.manual_seed(0)
@@ -1677,9 +1692,9 @@ def test_residual_chain_merged_exact_passes_on_all_open_and_all_pair_batches(dev
     b.load_state_dict(a.state_dict())
     x = torch.randn(1, rows, 64, device=dev)
     with torch.no_grad():
-        monkeypatch.setenv("VQHIP_RVQ_CHAIN", "1")
+        os.environ["VQHIP_RVQ_CHAIN"] = "1"
         qa, ia, _ = a(x)
-        monkeypatch.setenv("VQHIP_RVQ_CHAIN", "0")
+        os.environ["VQHIP_RVQ_CHAIN"] = "0"
         qb, ib, _ = b(x)
     torch.cuda.synchronize()
     assert torch.equal(ia, ib) and torch.equal(qa, qb)

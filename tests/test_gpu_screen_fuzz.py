@@ -174,6 +174,19 @@ def _bf16_exact(t):
     return t.bfloat16().float()
 
 
+def _added_start_value(x, e, D):
+    """Upper bound [N, C] of what the screening kernels ADD to a code's start value -||c||^2 / 2 before the MFMAs accumulate on top of
+    it (round 6, csrc/vq_screen.hip header: Arow ||c|| + kb ||c||^2 -- every tracked score is an upper bound of the code's true score).
+    The accumulation model below has to count it among the terms the hardware rounds against.  Arow from the largest row norm of the
+    row's wave (64 rows: one operand scale per wave; the families here are per wave), rho <= 2^-12, bf16 / fp16-exact rows (no drop term)."""
+    xn = x.double().norm(dim=-1)
+    xw = xn.view(-1, 64).max(dim=1, keepdim=True).values.expand(-1, 64).reshape(-1)
+    y = e.double().norm(dim=-1)
+    arow = (xn * (U * (10.0 + D + 2.002 * (D + 1)) + 2.5e-4) + U * D ** 0.5 * xw / 4096.0) * 1.001
+    kb = U * (5.0 + 1.001 * (D + 1) + 0.51) * 1.001
+    return arow[:, None] * y[None, :] * 1.001 + kb * (y ** 2)[None, :] * 1.002
+
+
 def _adversarial_pairs(N, D, gen, big=20, spread=12):
     """rows x [N, D] and ONE code c [D], bf16-exact, products with heavy cancellation; several pattern families by row."""
     x = torch.zeros(N, D)
@@ -234,16 +247,18 @@ def test_mfma_accumulation_error_within_model(dev, D, wide):
     nh = (-0.5 * O.c_row_sumsq(e)).double()                                       # the accumulator's initial value (fp32)
     prods = x.double()[:, None, :] * ch.double()[None]                            # [N, 2, D], exact
     t_exact = prods.sum(-1) + nh[None, :]
-    a_sum = prods.abs().sum(-1) + nh.abs()[None, :]
+    add = _added_start_value(x, e, D)
+    a_sum = prods.abs().sum(-1) + nh.abs()[None, :] + add
     order = t_exact.argsort(dim=1, descending=True)
     t_sorted = t_exact.gather(1, order)
     a_sorted = a_sum.gather(1, order)
+    add_sorted = add.gather(1, order)
     n_terms = D + 1
     worst_model = worst_permfma = 0.0
     for k in range(2):
         got = dbg[:, k]
         err = (got - t_sorted[:, k]).abs()
-        idx_bits = 16.0 * got.abs() * 2.0 ** -23                                   # 4 mantissa bits overwritten by the code number
+        idx_bits = 16.0 * (got.abs() + add_sorted[:, k]) * 2.0 ** -23              # 4 mantissa bits (of score + allowance) overwritten by the code number
         model = 2.0 * U * n_terms * a_sorted[:, k]
         ok = err <= model + idx_bits
         assert bool(ok.all()), (f"D={D} wide={wide}: MFMA accumulation error exceeds the modelled 2u/term: "
@@ -280,14 +295,15 @@ def test_mfma_accumulation_error_f32_rows(dev):
     nh = (-0.5 * O.c_row_sumsq(e)).double()
     prods = x.double()[:, None, :] * e.double()[None]
     t_exact = prods.sum(-1) + nh[None, :]
-    a_sum = prods.abs().sum(-1) + nh.abs()[None, :]
+    add = _added_start_value(x, e, D)
+    a_sum = prods.abs().sum(-1) + nh.abs()[None, :] + add
     order = t_exact.argsort(dim=1, descending=True)
-    t_sorted, a_sorted = t_exact.gather(1, order), a_sum.gather(1, order)
+    t_sorted, a_sorted, add_sorted = t_exact.gather(1, order), a_sum.gather(1, order), add.gather(1, order)
     n_terms = D + 1
     for k in range(2):
         got = dbg[:, k]
         err = (got - t_sorted[:, k]).abs()
-        idx_bits = 16.0 * got.abs() * 2.0 ** -23
+        idx_bits = 16.0 * (got.abs() + add_sorted[:, k]) * 2.0 ** -23
         model = 2.0 * U * n_terms * a_sorted[:, k]
         assert bool((err <= model + idx_bits).all()), f"f32-row screen: worst ratio {(err / (model + idx_bits)).max():.3f}"
 

@@ -548,13 +548,28 @@ def rvq_chain_supported(x: torch.Tensor, C: int, routed=False) -> bool:
                 and xk.data_ptr() % 16 == 0 and (ldx * es) % 16 == 0)
 
 
+_CACHE_CAP = 32        # entries per (device, caller stream)-keyed cache below: least recently used out first
+
+
+def _lru(cache: dict, key, make):
+    """cache[key], created by make() on a miss; the caches are keyed by the caller stream's raw handle (torch's own streams come from a
+    fixed pool and are never destroyed, so a handle is a stable name; every other kind of stream -- ExternalStream -- is why the caches
+    are bounded: at most _CACHE_CAP entries, least recently used first out)."""
+    v = cache.pop(key, None)
+    if v is None:
+        v = make()
+        while len(cache) >= _CACHE_CAP:
+            cache.pop(next(iter(cache)))
+    cache[key] = v               # (re-inserted: dicts keep insertion order, the first key is the least recently used)
+    return v
+
+
 _CHAIN_STREAMS = {}
 
 
 def _chain_streams(device, main, n):
     """n side streams that pair with `main` for the row chunks of a residual chain (per caller stream: concurrent groups do not share)"""
-    key = (torch.device(device).index, main.cuda_stream)
-    pool = _CHAIN_STREAMS.setdefault(key, [])
+    pool = _lru(_CHAIN_STREAMS, (torch.device(device).index, main.cuda_stream), list)
     while len(pool) < n:
         pool.append(torch.cuda.Stream(device=device))
     return pool[:n]
@@ -700,8 +715,7 @@ _CHAIN_EVENTS = {}
 
 def _chain_events(device, main, n):
     """n reusable events that pair with `main` (vqhip_rvq_chain_forward re-records them on every call); -> (events, array of handles)"""
-    key = (torch.device(device).index, main.cuda_stream)
-    evs = _CHAIN_EVENTS.setdefault(key, [])
+    evs = _lru(_CHAIN_EVENTS, (torch.device(device).index, main.cuda_stream), list)
     while len(evs) < n:
         e = torch.cuda.Event()
         e.record(main)                       # (torch creates the hipEvent_t lazily, at the first record)
@@ -1125,13 +1139,12 @@ _STEP_SIDE = {}
 
 def _step_side(device, main):
     """the side stream + events of the fused step's row pipeline that pair with `main` (created once per caller stream)"""
-    key = (torch.device(device).index, main.cuda_stream)
-    if key not in _STEP_SIDE:
+    def make():
         evs = [torch.cuda.Event() for _ in range(4)]
         for e in evs:
             e.record(main)          # (torch creates the hipEvent_t lazily, at the first record)
-        _STEP_SIDE[key] = (torch.cuda.Stream(device=device), evs)
-    return _STEP_SIDE[key]
+        return (torch.cuda.Stream(device=device), evs)
+    return _lru(_STEP_SIDE, (torch.device(device).index, main.cuda_stream), make)
 
 
 def step_chunks(N: int) -> int:
@@ -1232,6 +1245,8 @@ def vq_train_step(x: torch.Tensor, embed, embed_avg, cluster_size, *, decay, eps
         offs.append(o)
         o += (lib().vqhip_screen_workspace_bytes(n_k) + 255) // 256 * 256 + (lib().vqhip_ema_workspace_bytes(n_k, C) + 255) // 256 * 256
     hdr = ws[:16].view(torch.int32) if len(offs) == 1 else torch.stack([ws[o: o + 16].view(torch.int32) for o in offs]).sum(0)
+    if reuse_scratch and len(offs) == 1:
+        hdr = hdr.clone()            # (the persistent workspace is overwritten by the next step on this stream: hand out a copy of the counters)
     return dict(q=None if q is None else q.reshape(x.shape), idx=idx.reshape(x.shape[:-1]), stats=stats,
                 embed_sum=stats[: C * D].view(C, D), count=stats[C * D:], loss=loss, n_exact=hdr[:1], n_pair=hdr[1:2])
 

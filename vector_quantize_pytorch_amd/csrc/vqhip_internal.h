@@ -123,7 +123,8 @@ int vq_assign_listed(const void *x, int x_dtype, int metric, int64_t N, int D, i
 static inline size_t vq_screen_done_ints(int64_t N) { return (size_t)((((N > 0 ? N : 1) + 127) / 128 + 1) & ~(int64_t)1); }
 // The listed exact passes of a residual-chain stage as ONE launch (vq_tail_kernel, vqhip.hip): workgroups [0, gx) sweep the open rows,
 // the rest decide the pair rows; both write idx_out themselves (a split sweep: the workgroup that arrives last at a chunk's counter in
-// `done` -- zeroed by the caller -- reads the chunk's keys back).  Index output only.  VQHIP_TAIL=0: the three separate launches.
+// `done` -- zeroed by the caller -- reads the chunk's keys back).  Index output only.  Measured slower than the three separate launches
+// (vqhip.hip, vq_tail_enabled): only with VQHIP_TAIL=1.
 int vq_tail_enabled();
 int vq_assign_listed_direct(const void *x, int x_dtype, int metric, int64_t N, int D, int64_t ldx, const float *packed, const float *embed, int C,
                             int64_t *idx_out, int64_t idx_stride, const int *row_list, const int *row_count, unsigned long long *keys, int *done,

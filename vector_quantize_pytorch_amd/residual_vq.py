@@ -680,6 +680,8 @@ _STATS_STREAMS = {}
 def _stats_stream(device, main):
     """The statistics stream that pairs with `main` (one per caller stream, so concurrent groups do not share one)."""
     key = (torch.device(device).index, main.cuda_stream)
+    while key not in _STATS_STREAMS and len(_STATS_STREAMS) >= L._CACHE_CAP:      # bounded (ADVICE r5): oldest caller stream out first
+        _STATS_STREAMS.pop(next(iter(_STATS_STREAMS)))
     if key not in _STATS_STREAMS:
         # (default priority.  The statistics chain is five short launches behind one another -- memset, histogram, scan, scatter,
         #  segmented sum -- and beside a search that fills every CU each of them waits for a workgroup slot: rocprofv3 shows the

@@ -732,6 +732,16 @@ class VectorQuantize(nn.Module):
         cq = commit_quantize
         if self.heads > 1 and not self.separate_codebook_per_head:
             cq = cq[None]                                                   # rows [(b h), n, d]: the reference's '1 (b h) n d'
+        try:                # the two shapes must broadcast (fail with the reason, not with an opaque broadcast error deep in ATen)
+            torch.broadcast_shapes(tuple(cq.shape), tuple(orig_input.shape))
+        except RuntimeError:
+            raise RuntimeError(
+                f"masked commitment loss: the reference compares the codes {tuple(cq.shape)} with the tensor the caller passed "
+                f"{tuple(orig_input.shape)} (vector_quantize_pytorch.py:1319: F.mse_loss(commit_quantize, orig_input)) and these do not "
+                "broadcast -- with several heads or a projection a padded training batch only has a loss when codebook_dim == dim (and, for "
+                "one codebook shared by the heads, batch size 1); the reference raises here too (INTEGRATION.md, behaviour notes)") from None
+        if tuple(cq.shape) != tuple(orig_input.shape):       # (they broadcast: exactly the reference's op, its UserWarning about it silenced)
+            cq, orig_input = torch.broadcast_tensors(cq, orig_input)
         err = F.mse_loss(cq, orig_input, reduction='none')
         loss_mask = mask
         if self.heads > 1:                                                  # 'b n -> c (b h) n' (vqp.py:1323)
