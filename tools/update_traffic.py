@@ -7,8 +7,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 R, commit = sys.argv[1], sys.argv[2]
 tp = os.path.join(ROOT, "profiles", "traffic.json")
 tj = json.load(open(tp))
-for wl, d in (("vq_cfg2", f"{R}_final"), ("rvq_cfg3", f"{R}_rvq_cfg3"), ("grvq_cfg5", f"{R}_grvq_cfg5")):
-    t = json.load(open(os.path.join(ROOT, "profiles", d, "traffic_step.json")))
+for wl, d in (("vq_cfg2", f"{R}_final"), ("rvq_cfg3", f"{R}_rvq_cfg3"), ("grvq_cfg5", f"{R}_grvq_cfg5"), ("vq_cfg4_shard", f"{R}_vq_cfg4_shard")):
+    fp = os.path.join(ROOT, "profiles", d, "traffic_step.json")
+    if not os.path.exists(fp):
+        continue
+    t = json.load(open(fp))
     tj["step_traffic"][wl] = {"bytes_per_step": t["bytes_per_step"], "fetch_bytes_per_step": t["fetch_bytes_per_step"],
                               "write_bytes_per_step": t["write_bytes_per_step"], "measured_at_commit": commit,
                               "source": f"profiles/{d}/traffic_step.json (tools/collect_profile.py: all vq_* kernels of one step, difference of two rocprofv3 "

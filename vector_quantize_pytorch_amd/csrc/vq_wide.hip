@@ -20,6 +20,7 @@
 // search and the fused residual loop are not available beyond D = 512 (they raise).
 
 #include <math.h>
+#include <stdlib.h>
 
 #include "vqhip_internal.h"
 
@@ -186,6 +187,7 @@ struct WideAssignArgs {
     double *sqerr_partial;      // one entry per workgroup (128 rows)
     const uint8_t *row_mask;
     int skip_norm;
+    int vec;                    // D % 8 == 0 and x / embed rows 16-byte aligned: the MFMA kernel's staging uses 16-byte loads
 };
 
 #define WD_ROWS 64
@@ -348,6 +350,229 @@ __global__ void __launch_bounds__(256) vq_wide_assign_kernel(const WideAssignArg
     }
 }
 
+// ---- the same search on the fp32 MFMA pipe (round 6) ---------------------------------------------------------------------------------
+// vq_wide_assign_kernel above runs every dot product as an FMA chain on the VALU: 31 algorithmic TFLOP/s.  v_mfma_f32_32x32x2_f32 fed the
+// features in ascending order computes the SAME chain (the numerics contract of the tuned exact kernel; two features per
+// instruction: lanes 0..31 carry feature 2p, lanes 32..63 feature 2p + 1, accumulated in that order), so beyond D = 512 only the operand
+// plumbing changes: the rows no longer fit a wave's registers, hence
+//   * a workgroup = 128 rows (4 waves x 32 rows, the MFMA's B operand) x WM_T code tiles of 32 codes (A operand) at a time;
+//   * the feature axis in slabs of WM_KS = 64: the slab of the 128 rows and of the WM_T x 32 codes is staged through LDS in the MFMAs'
+//     operand order (global loads of the NEXT slab are in flight in registers while this one is multiplied), a wave keeps its B slab
+//     in 32 registers for all WM_T tiles, and the accumulators run on over the slabs -- ascending k, one chain per (row, code);
+//   * after the last slab: (x2 + y2) + (-2 xy), max(., 1e-8), correctly rounded sqrt, strict < in ascending code order per lane, the two
+//     half-waves merged by (distance, index) -- the arithmetic of the kernel above, bit for bit (tests/test_gpu_ops.py: indices and
+//     winning distances equal to the chain oracle at D = 640 .. 2048).
+// Rows are re-staged once per group of WM_T tiles (from L2: C / (32 WM_T) times 128 x D x 4 bytes per workgroup).
+#define WM_T 4
+#define WM_KS 64
+typedef float f32x16w __attribute__((ext_vector_type(16)));
+
+template <bool XBF16, int METRIC>
+__global__ void __launch_bounds__(256, 2) vq_wide_mfma_kernel(const WideAssignArgs a)
+{
+    // operand images: [tile or wave][p4 = pair group of 4][hi][lane 0..31][4 pairs] floats -- a lane's ds_read_b128 returns the values of
+    // four consecutive MFMAs; consecutive lanes read consecutive 16-byte pieces (conflict-free)
+    __shared__ __attribute__((aligned(16))) float sA[WM_T * (WM_KS / 8) * 2 * 32 * 4];      // 32 KiB
+    __shared__ __attribute__((aligned(16))) float sB[4 * (WM_KS / 8) * 2 * 32 * 4];         // 32 KiB
+    __shared__ float s_x2[VQHIP_ASSIGN_ROWS_PER_BLOCK], s_nrm[VQHIP_ASSIGN_ROWS_PER_BLOCK];
+    __shared__ int s_win[VQHIP_ASSIGN_ROWS_PER_BLOCK];
+    __shared__ double s_red[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 31, hi = lane >> 5;
+    const int64_t r0 = (int64_t)blockIdx.x * VQHIP_ASSIGN_ROWS_PER_BLOCK;
+    const int n_slab = (a.D + WM_KS - 1) / WM_KS;
+    const int n_grp = (a.C + 32 * WM_T - 1) / (32 * WM_T);
+
+    // ---- row norms: ATen order, one thread per row ----
+    if (tid < VQHIP_ASSIGN_ROWS_PER_BLOCK) {
+        const int64_t r = r0 + tid < a.N ? r0 + tid : a.N - 1;
+        const float x2 = wd_aten_sumsq([&](int e) { return wd_load<XBF16>(a.x, r * a.ldx + e); }, a.D);
+        float nrm = 1.f;
+        if (METRIC == 1 && !a.skip_norm) {       // l2norm (vqp.py:37-38): bf16 tensors normalise in bf16
+            nrm = sqrtf(x2);
+            if (XBF16) nrm = wd_round_bf16(nrm);
+            nrm = fmaxf(nrm, XBF16 ? wd_round_bf16(1e-6f) : 1e-6f);
+        }
+        s_x2[tid] = x2;
+        s_nrm[tid] = nrm;
+    }
+    __syncthreads();
+
+    // staging: work item (r, g8) = 8 consecutive features g8 of row / code r of the slab -> two 16-byte LDS pieces (hi = 0: the even
+    // features, hi = 1: the odd ones); 128 x 8 items each for A and B, four per thread and operand; g8 runs fastest over the threads
+    // (eight threads read 256 contiguous bytes of one row)
+    auto fetch = [&](int slab, int grp, float (&ra)[4][8], float (&rb)[4][8]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int item = it * 256 + tid, r = item >> 3, g8 = item & 7, k = slab * WM_KS + g8 * 8;
+            const int64_t xr = r0 + r < a.N ? r0 + r : a.N - 1;
+            const int code = grp * 32 * WM_T + r;
+            const float inv = s_nrm[r];
+            if (a.vec) {        // (D % 8 == 0: a piece is inside the row or past its end as a whole)
+                const bool in = k < a.D;
+                if (XBF16) {
+                    const uint4 w = in ? *(const uint4 *)((const unsigned short *)a.x + xr * a.ldx + k) : make_uint4(0u, 0u, 0u, 0u);
+                    const unsigned ww[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { rb[it][2 * e] = __uint_as_float(ww[e] << 16); rb[it][2 * e + 1] = __uint_as_float(ww[e] & 0xffff0000u); }
+                } else {
+                    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                    const f32x4 w0 = in ? *(const f32x4 *)((const float *)a.x + xr * a.ldx + k) : z, w1 = in ? *(const f32x4 *)((const float *)a.x + xr * a.ldx + k + 4) : z;
+                    rb[it][0] = w0.x; rb[it][1] = w0.y; rb[it][2] = w0.z; rb[it][3] = w0.w; rb[it][4] = w1.x; rb[it][5] = w1.y; rb[it][6] = w1.z; rb[it][7] = w1.w;
+                }
+                const bool cin = in && code < a.C;
+                const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                const f32x4 c0 = cin ? *(const f32x4 *)(a.embed + (size_t)code * a.D + k) : z, c1 = cin ? *(const f32x4 *)(a.embed + (size_t)code * a.D + k + 4) : z;
+                ra[it][0] = c0.x; ra[it][1] = c0.y; ra[it][2] = c0.z; ra[it][3] = c0.w; ra[it][4] = c1.x; ra[it][5] = c1.y; ra[it][6] = c1.z; ra[it][7] = c1.w;
+                if (METRIC == 1 && !a.skip_norm) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { float v = rb[it][e] / inv; if (XBF16) v = wd_round_bf16(v); rb[it][e] = v; }
+                }
+                continue;
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float v = (k + e < a.D) ? wd_load<XBF16>(a.x, xr * a.ldx + k + e) : 0.f;
+                if (METRIC == 1 && !a.skip_norm) {
+                    v = v / inv;
+                    if (XBF16) v = wd_round_bf16(v);
+                }
+                rb[it][e] = v;
+                ra[it][e] = (code < a.C && k + e < a.D) ? a.embed[(size_t)code * a.D + k + e] : 0.f;
+            }
+        }
+    };
+    auto park = [&](const float (&ra)[4][8], const float (&rb)[4][8]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int item = it * 256 + tid, r = item >> 3, g8 = item & 7;
+            // pairs 4 g8 .. 4 g8 + 3 of the slab: p4 = g8; image index ((blk * 8 + p4) * 2 + hi) * 32 + (r & 31), blk = r >> 5
+            float *pa = sA + ((((r >> 5) * (WM_KS / 8) + g8) * 2) * 32 + (r & 31)) * 4;
+            float *pb = sB + ((((r >> 5) * (WM_KS / 8) + g8) * 2) * 32 + (r & 31)) * 4;
+            *(f32x4 *)pa = f32x4{ra[it][0], ra[it][2], ra[it][4], ra[it][6]};
+            *(f32x4 *)(pa + 128) = f32x4{ra[it][1], ra[it][3], ra[it][5], ra[it][7]};
+            *(f32x4 *)pb = f32x4{rb[it][0], rb[it][2], rb[it][4], rb[it][6]};
+            *(f32x4 *)(pb + 128) = f32x4{rb[it][1], rb[it][3], rb[it][5], rb[it][7]};
+        }
+    };
+
+    float bd = (METRIC == 0) ? INFINITY : -INFINITY;
+    int bi = 0;
+    const float x2r = s_x2[wave * 32 + j];
+    float ra[4][8], rb[4][8];
+    fetch(0, 0, ra, rb);
+    for (int grp = 0; grp < n_grp; ++grp) {
+        f32x16w acc[WM_T];
+#pragma unroll
+        for (int t = 0; t < WM_T; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+        for (int slab = 0; slab < n_slab; ++slab) {
+            __syncthreads();                                   // the previous slab's operands have been consumed
+            park(ra, rb);
+            __syncthreads();
+            {   // the next slab (of this group, or the first one of the next group) travels while this one is multiplied
+                int ns = slab + 1, ng = grp;
+                if (ns == n_slab) { ns = 0; ng = grp + 1; }
+                if (ng < n_grp) fetch(ns, ng, ra, rb);
+            }
+            f32x4 b[WM_KS / 8];
+#pragma unroll
+            for (int p4 = 0; p4 < WM_KS / 8; ++p4) b[p4] = *(const f32x4 *)(sB + (((wave * (WM_KS / 8) + p4) * 2 + hi) * 32 + j) * 4);
+#pragma unroll
+            for (int p4 = 0; p4 < WM_KS / 8; ++p4) {
+#pragma unroll
+                for (int t = 0; t < WM_T; ++t) {
+                    const f32x4 av = *(const f32x4 *)(sA + (((t * (WM_KS / 8) + p4) * 2 + hi) * 32 + j) * 4);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, b[p4].x, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, b[p4].y, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, b[p4].z, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, b[p4].w, acc[t], 0, 0, 0);
+                }
+            }
+        }
+        // ---- this group's codes, ascending per lane: register e of tile t <-> code 32 (grp WM_T + t) + 8 (e >> 2) + 4 hi + (e & 3) ----
+#pragma unroll
+        for (int t = 0; t < WM_T; ++t)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int code = (grp * WM_T + t) * 32 + 8 * (e >> 2) + 4 * hi + (e & 3);
+                if (code < a.C) {
+                    if (METRIC == 0) {
+                        const float tt = x2r + a.y2[code];
+                        const float d = sqrtf(fmaxf(__builtin_fmaf(-2.0f, acc[t][e], tt), 1e-8f));
+                        if (d < bd) { bd = d; bi = code; }
+                    } else {
+                        if (acc[t][e] > bd) { bd = acc[t][e]; bi = code; }
+                    }
+                }
+            }
+    }
+    {   // the two half-waves of a row: better score, then lower index
+        const float od = __shfl_xor(bd, 32, 64);
+        const int oi = __shfl_xor(bi, 32, 64);
+        const bool take = (METRIC == 0) ? ((od < bd) || (od == bd && oi < bi)) : ((od > bd) || (od == bd && oi < bi));
+        bd = take ? od : bd;
+        bi = take ? oi : bi;
+    }
+    const int lrow = wave * 32 + j;
+    if (hi == 0) {
+        s_win[lrow] = bi;
+        const int64_t r = r0 + lrow;
+        if (r < a.N) {
+            a.idx_out[r] = (int64_t)bi;
+            if (a.best_out) a.best_out[r] = bd;
+            if (a.rnorm_out) a.rnorm_out[r] = (METRIC == 0) ? s_x2[lrow] : s_nrm[lrow];
+        }
+    }
+    __syncthreads();
+    // ---- q rows and the commitment loss' squared error: one wave per row (as vq_wide_assign_kernel) ----
+    double ds = 0.0;
+    if (a.q_out || a.sqerr_partial) {
+        for (int rr = wave; rr < VQHIP_ASSIGN_ROWS_PER_BLOCK; rr += 4) {
+            const int64_t r = r0 + rr;
+            if (r >= a.N) break;
+            const int c = s_win[rr];
+            const float nr = s_nrm[rr];
+            const bool counted = !a.row_mask || a.row_mask[r] != 0;
+            float ls = 0.f;
+            for (int d = lane; d < a.D; d += 64) {
+                float g = a.embed[(size_t)c * a.D + d];
+                if (a.q_bf16) g = wd_round_bf16(g);
+                if (a.q_out) {
+                    if (a.q_bf16) ((unsigned short *)a.q_out)[r * a.ldq + d] = wd_f32_to_bf16(g);
+                    else ((float *)a.q_out)[r * a.ldq + d] = g;
+                }
+                if (a.sqerr_partial) {
+                    float xv = wd_load<XBF16>(a.x, r * a.ldx + d);
+                    if (METRIC == 1 && !a.skip_norm) {
+                        xv = xv / nr;
+                        if (XBF16) xv = wd_round_bf16(xv);
+                    }
+                    const float df = g - xv;
+                    ls += df * df;
+                }
+            }
+            if (a.sqerr_partial && counted) ds += (double)ls;
+        }
+    }
+    if (a.sqerr_partial) {
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) ds += __shfl_xor(ds, o, 64);
+        __syncthreads();
+        if (lane == 0) s_red[wave] = ds;
+        __syncthreads();
+        if (tid == 0) a.sqerr_partial[blockIdx.x] = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+    }
+}
+
+static int wd_use_mfma()
+{
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("VQHIP_WIDE_MFMA"); v = (e && e[0] == '0') ? 0 : 1; }      // =0: the VALU kernel (A/B runs)
+    return v;
+}
+
 int vq_wide_assign(const void *x, int x_dtype, int64_t N, int D, int64_t ldx, const float *packed, const float *embed, int C, int metric,
                    int64_t *idx_out, void *q_out, int q_dtype, int64_t ldq, float *best_out, float *rnorm_out, double *sqerr_partial,
                    const uint8_t *row_mask, void *stream)
@@ -356,9 +581,20 @@ int vq_wide_assign(const void *x, int x_dtype, int64_t N, int D, int64_t ldx, co
     a.x = x; a.N = N; a.D = D; a.ldx = ldx; a.y2 = packed; a.embed = embed; a.C = C; a.idx_out = idx_out; a.q_out = q_out;
     a.q_bf16 = (q_dtype == VQHIP_BF16); a.ldq = ldq; a.best_out = best_out; a.rnorm_out = rnorm_out; a.sqerr_partial = sqerr_partial;
     a.row_mask = row_mask; a.skip_norm = (metric == VQHIP_COSINE_PRENORM);
+    a.vec = (D % 8 == 0) && ((((uintptr_t)x) & 15) == 0) && ((ldx * (x_dtype == VQHIP_BF16 ? 2 : 4)) % 16 == 0) && ((((uintptr_t)embed) & 15) == 0);
     const dim3 grid((unsigned)vqhip_assign_blocks(N));
     hipStream_t st = (hipStream_t)stream;
     const bool bf = x_dtype == VQHIP_BF16;
+    if (wd_use_mfma()) {
+        if (metric == VQHIP_EUCLID) {
+            if (bf) hipLaunchKernelGGL((vq_wide_mfma_kernel<true, 0>), grid, dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((vq_wide_mfma_kernel<false, 0>), grid, dim3(256), 0, st, a);
+        } else {
+            if (bf) hipLaunchKernelGGL((vq_wide_mfma_kernel<true, 1>), grid, dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((vq_wide_mfma_kernel<false, 1>), grid, dim3(256), 0, st, a);
+        }
+        return vq_launch_status("vq_wide_mfma_kernel");
+    }
     if (metric == VQHIP_EUCLID) {
         if (bf) hipLaunchKernelGGL((vq_wide_assign_kernel<true, 0>), grid, dim3(256), 0, st, a);
         else hipLaunchKernelGGL((vq_wide_assign_kernel<false, 0>), grid, dim3(256), 0, st, a);
