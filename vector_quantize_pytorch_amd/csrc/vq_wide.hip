@@ -99,6 +99,48 @@ __device__ float wd_aten_sumsq(F ld, int D)
 }
 
 // ---- packed layout for wide dims: y2 [C] floats (256-byte padded) | bf16 copy [C, D] ------------------------------------------
+// The same sum by 32 cooperating lanes (a half-wave; c = the lane's chain, 0 .. 31): chain c of wd_aten_sumsq is exactly the elements
+// c, c + 32, c + 64, ... with the cascade fold every 16 of them, so the 32 lanes read 128 contiguous bytes per step instead of one
+// thread walking a whole row; the folds, the leftover vectors (chains 0 .. 7), the scalar tail and the final left-to-right sum keep
+// their order.  Every lane of the half-wave returns the row's sum.  `ld` as above.
+template <typename F>
+__device__ __forceinline__ float wd_aten_sumsq_coop(F ld, int D, int c)
+{
+    const int V = D >> 3;
+    const int size = V >> 2;
+    float a0 = 0.f, a1 = 0.f;
+    int i = 0;
+    for (; i + 16 <= size;) {
+        for (int j = 0; j < 16; ++j, ++i) {
+            const float v = ld(32 * i + c);
+            a0 += v * v;
+        }
+        a1 += a0; a0 = 0.f;
+    }
+    for (; i < size; ++i) {
+        const float v = ld(32 * i + c);
+        a0 += v * v;
+    }
+    a0 += a1;
+    for (int v = size * 4; v < V; ++v)
+        if (c < 8) {
+            const float t = ld(v * 8 + c);
+            a0 += t * t;
+        }
+    float fin = 0.f;
+    for (int e = V * 8; e < D; ++e) {
+        const float t = ld(e);
+        fin += t * t;
+    }
+    const int base = (int)(threadIdx.x & 32);          // first lane of this half-wave inside its wave
+#pragma unroll
+    for (int l = 0; l < 8; ++l) {
+        const float p = ((__shfl(a0, base + l, 64) + __shfl(a0, base + 8 + l, 64)) + __shfl(a0, base + 16 + l, 64)) + __shfl(a0, base + 24 + l, 64);
+        fin += p;
+    }
+    return fin;
+}
+
 static inline size_t wd_align(size_t v, size_t a) { return (v + a - 1) / a * a; }
 size_t vq_wide_packed_bytes(int C, int D) { return wd_align((size_t)C * 4, 256) + wd_align((size_t)C * D * 2, 256) + 256; }
 static inline size_t wd_bf16_offset(int C) { return wd_align((size_t)C * 4, 256); }
@@ -383,18 +425,17 @@ __global__ void __launch_bounds__(256, 2) vq_wide_mfma_kernel(const WideAssignAr
     const int n_slab = (a.D + WM_KS - 1) / WM_KS;
     const int n_grp = (a.C + 32 * WM_T - 1) / (32 * WM_T);
 
-    // ---- row norms: ATen order, one thread per row ----
-    if (tid < VQHIP_ASSIGN_ROWS_PER_BLOCK) {
-        const int64_t r = r0 + tid < a.N ? r0 + tid : a.N - 1;
-        const float x2 = wd_aten_sumsq([&](int e) { return wd_load<XBF16>(a.x, r * a.ldx + e); }, a.D);
+    // ---- row norms: ATen order, 32 lanes per row (8 rows per pass of the workgroup) ----
+    for (int rr = tid >> 5; rr < VQHIP_ASSIGN_ROWS_PER_BLOCK; rr += 8) {
+        const int64_t r = r0 + rr < a.N ? r0 + rr : a.N - 1;
+        const float x2 = wd_aten_sumsq_coop([&](int e) { return wd_load<XBF16>(a.x, r * a.ldx + e); }, a.D, tid & 31);
         float nrm = 1.f;
         if (METRIC == 1 && !a.skip_norm) {       // l2norm (vqp.py:37-38): bf16 tensors normalise in bf16
             nrm = sqrtf(x2);
             if (XBF16) nrm = wd_round_bf16(nrm);
             nrm = fmaxf(nrm, XBF16 ? wd_round_bf16(1e-6f) : 1e-6f);
         }
-        s_x2[tid] = x2;
-        s_nrm[tid] = nrm;
+        if ((tid & 31) == 0) { s_x2[rr] = x2; s_nrm[rr] = nrm; }
     }
     __syncthreads();
 
@@ -479,16 +520,26 @@ __global__ void __launch_bounds__(256, 2) vq_wide_mfma_kernel(const WideAssignAr
             f32x4 b[WM_KS / 8];
 #pragma unroll
             for (int p4 = 0; p4 < WM_KS / 8; ++p4) b[p4] = *(const f32x4 *)(sB + (((wave * (WM_KS / 8) + p4) * 2 + hi) * 32 + j) * 4);
+            f32x4 av[WM_T], an[WM_T];                       // this pair group's A pieces, and the next one's on their way from LDS
+#pragma unroll
+            for (int t = 0; t < WM_T; ++t) av[t] = *(const f32x4 *)(sA + (((t * (WM_KS / 8) + 0) * 2 + hi) * 32 + j) * 4);
 #pragma unroll
             for (int p4 = 0; p4 < WM_KS / 8; ++p4) {
+                if (p4 + 1 < WM_KS / 8) {
 #pragma unroll
-                for (int t = 0; t < WM_T; ++t) {
-                    const f32x4 av = *(const f32x4 *)(sA + (((t * (WM_KS / 8) + p4) * 2 + hi) * 32 + j) * 4);
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, b[p4].x, acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, b[p4].y, acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, b[p4].z, acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, b[p4].w, acc[t], 0, 0, 0);
+                    for (int t = 0; t < WM_T; ++t) an[t] = *(const f32x4 *)(sA + (((t * (WM_KS / 8) + p4 + 1) * 2 + hi) * 32 + j) * 4);
                 }
+                // the four tiles' accumulators take turns (independent chains: no MFMA waits for the previous one's result)
+#pragma unroll
+                for (int t = 0; t < WM_T; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t].x, b[p4].x, acc[t], 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < WM_T; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t].y, b[p4].y, acc[t], 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < WM_T; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t].z, b[p4].z, acc[t], 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < WM_T; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t].w, b[p4].w, acc[t], 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < WM_T; ++t) av[t] = an[t];
             }
         }
         // ---- this group's codes, ascending per lane: register e of tile t <-> code 32 (grp WM_T + t) + 8 (e >> 2) + 4 hi + (e & 3) ----
