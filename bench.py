@@ -805,6 +805,12 @@ def vq_cfg2(args, world, rank, dev):
                               "uncertified rows + finish), timed with events on the launch stream") if screened else
                              "exact fp32-MFMA search (VQHIP_SCREEN=0)"},
     }
+    if screened:
+        y2 = (vq._codebook.embed[0].double() ** 2).sum(-1)
+        ratio = float(y2.max() / y2.min().clamp_min(1e-300))
+        out["roofline"]["codebook_norm2_max_over_min"] = ratio
+        out["roofline"]["certificate_mode"] = ("plain scores, per-code allowances for winner and runner-up (norm spread <= 4 x)" if ratio <= 16.0
+                                               else "upper-bound scores (per-code allowance inside every start value)")
     if screened and exact_rows:
         out["roofline"]["rows_exact_pass_frac"] = float(torch.stack(exact_rows).double().mean().item()) / n_vec
         out["roofline"]["rows_exact_pass_frac_first_step"] = first_exact

@@ -440,7 +440,8 @@ __global__ void __launch_bounds__(VQS_WAVES * 64, 8 / VQS_WAVES) vq_screen16_ker
             // overflow guard: a row norm or a code norm beyond fp32 (or a scaled factor that left its range) -> this row is never
             // certified (Rrow = inf) and adds nothing to the start values (no inf x 0 = NaN may enter the fold)
             const bool y2ok = __uint_as_float(a.scalars[0]) < 1e37f;
-            if (!(Arow[rb] < 1e30f) || !(ArowS[rb] < 1e30f) || !(Rrow[rb] < 1e30f) || !y2ok) { Arow[rb] = 0.f; ArowS[rb] = 0.f; Rrow[rb] = __builtin_inff(); }
+            const bool ok = (Arow[rb] < 1e30f) & (ArowS[rb] < 1e30f) & (Rrow[rb] < 1e30f) & y2ok;      // (selects: a branch here made hipcc spill)
+            Arow[rb] = ok ? Arow[rb] : 0.f; ArowS[rb] = ok ? ArowS[rb] : 0.f; Rrow[rb] = ok ? Rrow[rb] : __builtin_inff();
         }
     }
 
@@ -1007,7 +1008,8 @@ __global__ void __launch_bounds__(VQS_F32_WAVES * 64, (XBF16 && NPART == 1 && DT
         }
         ArowS = Arow * SS;
         const bool y2ok = __uint_as_float(a.scalars[0]) < 1e37f;       // overflow guard, as in vq_screen16_kernel
-        if (!(Arow < 1e30f) || !(ArowS < 1e30f) || !(Rrow < 1e30f) || !y2ok) { Arow = 0.f; ArowS = 0.f; Rrow = __builtin_inff(); }
+        const bool ok = (Arow < 1e30f) & (ArowS < 1e30f) & (Rrow < 1e30f) & y2ok;
+        Arow = ok ? Arow : 0.f; ArowS = ok ? ArowS : 0.f; Rrow = ok ? Rrow : __builtin_inff();
     }
 
     float m1 = -__builtin_inff(), m2 = -__builtin_inff(), m3 = -__builtin_inff();

@@ -75,6 +75,15 @@ __global__ void __launch_bounds__(256, 2) vq_screenc_kernel(const ScreenArgs a, 
     const float rho = __uint_as_float(a.scalars[1]);
     const float r0 = __uint_as_float(a.scalars[3]);
     const bool y2ok = __uint_as_float(a.scalars[0]) < 1e37f;
+    // PLAIN mode (chosen per launch from the codebook alone): while the largest code norm is within 4 x of the smallest, charging every
+    // code OTHER than the two best with the largest norm costs little -- the winner / runner-up decision keeps both codes' own
+    // allowances, only the "nobody else comes close" test (best vs third) is looser, i.e. some pair rows become open rows -- and the
+    // sweep can track the plain scores: one start vector -||c||^2 / 2 for both row blocks and all lanes, 8 packed multiplies per tile
+    // instead of 8 + 16 packed FMAs (which cost the cfg-2 search 4 %).  Codebooks with a wider norm spread keep the upper-bound scores
+    // (one large code must not raise every row's threshold).
+    const float y2max_c = __uint_as_float(a.scalars[0]), y2min_c = __uint_as_float(~a.scalars[4]);
+    const bool plain = __builtin_amdgcn_readfirstlane((y2ok && y2min_c > 0.f && y2max_c <= 16.f * y2min_c) ? 1 : 0) != 0;
+    const float ymax_c = sqrtf(y2max_c) * 1.0001f;
     const int ldq2 = (int)(a.ldq * 2);
     const int ldx2 = (int)(a.ldx * 2);
     const int nb_mine = gid < nblk ? (nblk - gid + G2 - 1) / G2 : 0;
@@ -244,7 +253,11 @@ __global__ void __launch_bounds__(256, 2) vq_screenc_kernel(const ScreenArgs a, 
         rrow_c[0] = rrow_of(xs2[0]); rrow_c[1] = rrow_of(xs2[1]);
 #pragma unroll
         for (int t = 0; t < 2; ++t)     // overflow guard (vq_screen16_kernel): such a row is never certified and adds nothing to the start values
-            if (!(arow_c[t] < 1e30f) || !(arow_c[t] * SS_c < 1e30f) || !(rrow_c[t] < 1e30f) || !y2ok) { arow_c[t] = 0.f; rrow_c[t] = __builtin_inff(); }
+        {   // (selects, not a branch: as `if (...) { ... }` this guard made hipcc spill 84 registers around the sweep)
+            const bool ok = (arow_c[t] < 1e30f) & (arow_c[t] * SS_c < 1e30f) & (rrow_c[t] < 1e30f) & y2ok;
+            arow_c[t] = ok ? arow_c[t] : 0.f;
+            rrow_c[t] = ok ? rrow_c[t] : __builtin_inff();
+        }
     };
     auto reset_fold = [&]() __attribute__((always_inline)) {
 #pragma unroll
@@ -305,7 +318,9 @@ __global__ void __launch_bounds__(256, 2) vq_screenc_kernel(const ScreenArgs a, 
     }
     int ptile = 0;
     for (int ib = 0; ib < nb_mine; ++ib, blk += G2) {
-        // ---- sweep: nst intervals of two tiles, starting wherever the tile cycle stands ----
+        // ---- sweep: nst intervals of two tiles, starting wherever the tile cycle stands; one copy of the loop per certificate mode ----
+        auto sweep = [&](auto plain_c) __attribute__((always_inline)) {
+        constexpr bool PLAIN = decltype(plain_c)::value;
 #pragma unroll 1
         for (int iv = 0; iv < nst; ++iv) {
             VQC_STAMP(0);
@@ -329,7 +344,25 @@ __global__ void __launch_bounds__(256, 2) vq_screenc_kernel(const ScreenArgs a, 
                 // codes clamp it to a finite -3e38.
                 // + (row factor) x ||c|| (tile tail, floats 32 ..): every tracked score is an upper bound of the code's true score
                 f32x16 init0, init1;
-                {
+                if constexpr (PLAIN) {      // the plain start values (tile tail, floats 64 ..), shared by both row blocks
+                    if (METRIC == 0 || has_pad) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            f32x4 v = *(const f32x4 *)(nh + 64 + 8 * q);
+                            if (METRIC != 0) { v.x = v.x < -1e38f ? v.x : 0.f; v.y = v.y < -1e38f ? v.y : 0.f;
+                                               v.z = v.z < -1e38f ? v.z : 0.f; v.w = v.w < -1e38f ? v.w : 0.f; }
+                            const f32x2 r0 = f32x2{v.x, v.y} * f32x2{SS_c, SS_c}, r1 = f32x2{v.z, v.w} * f32x2{SS_c, SS_c};
+                            init0[4 * q + 0] = r0.x; init0[4 * q + 1] = r0.y; init0[4 * q + 2] = r1.x; init0[4 * q + 3] = r1.y;
+                        }
+                        if (has_pad) {
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) init0[r] = fmaxf(init0[r], -3.0e38f);
+                        }
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) init0[r] = 0.f;
+                    }
+                } else {
                     const float as0 = arow_c[0] * SS_c, as1 = arow_c[1] * SS_c;
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
@@ -363,7 +396,7 @@ __global__ void __launch_bounds__(256, 2) vq_screenc_kernel(const ScreenArgs a, 
                 for (int s = 0; s < NK; ++s) {
                     const f16x8 av = __builtin_bit_cast(f16x8, af[s % PF]);
                     C[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, __builtin_bit_cast(f16x8, cur[0][s]), s == 0 ? init0 : C[0], 0, 0, 0);
-                    C[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, __builtin_bit_cast(f16x8, cur[1][s]), s == 0 ? init1 : C[1], 0, 0, 0);
+                    C[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, __builtin_bit_cast(f16x8, cur[1][s]), s == 0 ? (PLAIN ? init0 : init1) : C[1], 0, 0, 0);
                     if (s + PF < NK) af[s % PF] = ap[(s + PF) * 64];
 #ifndef VQC_NO_FOLD
                     fold(P[0], s, m1[0], m2[0], m3[0]);
@@ -379,6 +412,8 @@ __global__ void __launch_bounds__(256, 2) vq_screenc_kernel(const ScreenArgs a, 
             tile_body(1, accB, accA);
             VQC_END_INTERVAL(0);
         }
+        };
+        if (plain) sweep(std::true_type{}); else sweep(std::false_type{});
 
         // ---- break interval 0: last tile's fold, classification, index, list slots, q rows, list entries; the next block's rows are requested ----
         VQC_STAMP(0);
@@ -417,11 +452,24 @@ __global__ void __launch_bounds__(256, 2) vq_screenc_kernel(const ScreenArgs a, 
                     return (arow_c[t] * yb + (METRIC == 0 ? kb * yb * yb * 1.001f : 0.f)) * 1.0001f;
                 };
                 const float cp1 = code_part(codes[t]);
-                const float thr = (2.f * cp1 + 2.f * rrow_c[t]) * SS_c + 8e-6f * fabsf(b1);
-                cert[t] = ((b1 - b2) > thr) && codes[t] < a.C && b1 < 3.0e38f;
-                pairf[t] = !cert[t] && ((b1 - b3) > thr) && codes[t] < a.C && id2s[t] < a.C && b1 < 3.0e38f;
+                float thr = (2.f * cp1 + 2.f * rrow_c[t]) * SS_c + 8e-6f * fabsf(b1);
+                if (plain) {
+                    // plain scores: the winner's and the runner-up's own allowances between the two, the winner's + the LARGEST code's
+                    // against everything else (third and beyond)
+                    const float cp2 = code_part(id2s[t]);
+                    const float cpm = (arow_c[t] * ymax_c + (METRIC == 0 ? kb * ymax_c * ymax_c * 1.001f : 0.f)) * 1.0001f;
+                    thr = (cp1 + cp2 + 2.f * rrow_c[t]) * SS_c + 8e-6f * fabsf(b1);
+                    const float thr3 = (cp1 + cpm + 2.f * rrow_c[t]) * SS_c + 8e-6f * fabsf(b1);
+                    const bool others_out = (b1 - b3) > thr3;
+                    cert[t] = others_out && ((b1 - b2) > thr) && codes[t] < a.C && b1 < 3.0e38f;
+                    pairf[t] = !cert[t] && others_out && codes[t] < a.C && id2s[t] < a.C && b1 < 3.0e38f;
+                } else {
+                    cert[t] = ((b1 - b2) > thr) && codes[t] < a.C && b1 < 3.0e38f;
+                    pairf[t] = !cert[t] && ((b1 - b3) > thr) && codes[t] < a.C && id2s[t] < a.C && b1 < 3.0e38f;
+                }
                 dbg4[t][0] = dbg4[t][1] = dbg4[t][2] = 0.f;
-                if (a.dbg) {    // debug view in the units of t = x.c - ||c||^2 / 2 (vq_screen16_kernel): what the sweep added is taken off again
+                if (a.dbg && plain) { dbg4[t][0] = b1 * iSS_c; dbg4[t][1] = b2 * iSS_c; dbg4[t][2] = thr * iSS_c; }
+                if (a.dbg && !plain) {    // debug view in the units of t = x.c - ||c||^2 / 2 (vq_screen16_kernel): what the sweep added is taken off again
                     float add[2], sc2[2];
                     const int cs[2] = {codes[t], id2s[t]};
                     const float us[2] = {b1, b2};

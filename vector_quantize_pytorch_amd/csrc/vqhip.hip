@@ -203,7 +203,7 @@ __global__ void __launch_bounds__(256) vq_pack_kernel(const float *embed, int C,
 // rounded to fp16 (RNE); the kernel compensates the scale exactly (powers of two).  Same lane order as the bf16 tiles:
 // 16 bytes per lane and k-step; lane l = code (l & 31), k-slot 8 * (l >> 5) + e.  Tile tail: 32 floats -||c||^2 / 2
 // (-3e38 for padding codes), then 32 floats ||c|| (round 6).  scalars[1] <- rho, scalars[3] <- r0 with ||c - c_f16|| <= rho ||c|| + r0
-// for every code (the certificate charges X * that for the rounding), scalars[2] <- sc.
+// for every code (the certificate charges X * that for the rounding), scalars[2] <- sc, scalars[4] <- ~bits(min ||c||^2).
 __global__ void __launch_bounds__(256) vq_pack16_kernel(const float *embed, int C, int D, int DT, int n_tiles,
                                                         const float *packed, char *tiles16,
                                                         unsigned *scalars, size_t head_bytes)
@@ -284,7 +284,8 @@ __global__ void __launch_bounds__(256) vq_pack16_kernel(const float *embed, int 
             const float r = sqrtf(rsq[i]) * 1.01f + 1e-38f;     // slack for the fp32 rounding of the sum above
             const float over = r - r0;
             if (over > 0.f && y2 > 0.f) atomicMax(scalars + 1, __float_as_uint(fminf(over / sqrtf(y2) * 1.001f, 2.5e-4f)));
-        }
+            atomicMax(scalars + 4, ~__float_as_uint(y2));       // ~(bits of the SMALLEST ||c||^2): the scalars start zeroed; non-negative floats
+        }                                                       // order like their bits (NaN sorts above inf: read back as "no plain mode")
         if (t == 0 && i == 0) { scalars[2] = (unsigned)sc; scalars[3] = __float_as_uint(r0); }
     }
 }

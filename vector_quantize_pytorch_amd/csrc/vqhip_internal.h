@@ -68,7 +68,7 @@ static inline int vq_pick_dt(int D)
 //   [bf16_offset)           codebook rounded to bf16, [C, D] row-major (q / loss of bf16 I/O), 16-byte padded
 //   [scalars_offset)        64 bytes: [0] float bits of max_c ||c||^2, [1] float bits of rho, [3] of r0: ||c - c_f16|| <= rho ||c|| + r0
 //                           for every code (round 6; was the codebook-wide max_c ||c - c_f16||), [2] int sc: the fp16 tiles hold
-//                           c * 2^sc, rest reserved
+//                           c * 2^sc, [4] ~(float bits of min_c ||c||^2), rest reserved
 //   [f16_offset)            fp16 A-operand tiles of the single-pass screening kernel (vq_screen16_kernel):
 //                           tiles16 * (64*DT + 1024), tiles16 = tiles rounded up to a multiple of VQ_F16_TILE_GROUP
 //                           (padding tiles score -3e38), then an 8192-byte tail pad.  Tile tail (1 KiB of floats): [0, 32) the
