@@ -4,6 +4,8 @@ Bars: indices bit-exact vs the deterministic ("chain") oracle; the winning dista
 (which pins the MFMA k-order, the ATen-order norms, the association and the sqrt rounding);
 floating-point statistics within 1e-5 relative (fp32) as BASELINE.json's north_star states.
 """
+import os
+
 import pytest
 import torch
 
@@ -931,3 +933,16 @@ def test_deterministic_kernels_give_the_same_bits_beside_a_concurrent_mfma_load(
                 bad[k] = bad.get(k, 0) + 1
     assert not bad, f"outputs that differ from the solo run (rounds out of {stop_after}): {bad}"
 
+
+
+def test_train_step_fold_inside_the_segmented_sum_matches_the_fold_kernel(dev):
+    """VQHIP_STEP_FOLD=1 (round 6, measured no faster, not the default): the wave that adds the last chunk of a code's segmented sum folds
+    embed_avg / embed for that code, the last workgroup reduces the loss -- device-scope tickets instead of a launch boundary.  Against
+    the default vq_step_fold_kernel over many steps on one reused workspace (tools/fold_stress.py --quick: two child processes, the
+    switch is read once per process): identical indices and cluster sizes, embed / embed_avg / loss equal up to the fp32 atomics' order."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "tools", "fold_stress.py"), "--quick"], cwd=root, stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, text=True, timeout=900)
+    assert p.returncode == 0 and "fold stress OK" in p.stdout, p.stdout[-3000:]

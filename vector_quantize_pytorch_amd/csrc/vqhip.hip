@@ -124,6 +124,44 @@ __device__ float aten_sumsq_seq(F ld, int D)
 #define pick_dt vq_pick_dt
 #define packed_bf16_offset vq_packed_bf16_offset
 
+// The same sum with the 32 chains on the 32 lanes of a half-wave (lane c = chain c; `ld` is called with the same element by no two lanes
+// of the chain phase, the loads of a step are one contiguous 128-byte piece of the row); the result is returned in every lane of the
+// half-wave.  All 32 lanes must call.  (vq_wide.hip holds the same routine for D > 512, with the cascade level those sizes add.)
+template <typename F>
+__device__ __forceinline__ float aten_sumsq_coop(F ld, int D, int c)
+{
+    const int V = D >> 3;
+    const int size = V >> 2;
+    float a0 = 0.f;
+    for (int i = 0; i < size; ++i) {
+        const float v = ld(32 * i + c);
+        a0 += v * v;
+    }
+    for (int v = size * 4; v < V; ++v)
+        if (c < 8) {
+            const float t = ld(v * 8 + c);
+            a0 += t * t;
+        }
+    float fin = 0.f;
+    for (int e = V * 8; e < D; ++e) {
+        const float t = ld(e);
+        fin += t * t;
+    }
+    const int base = (int)(threadIdx.x & 32);
+#pragma unroll
+    for (int l = 0; l < 8; ++l) {
+        const float p = ((__shfl(a0, base + l, 64) + __shfl(a0, base + 8 + l, 64)) + __shfl(a0, base + 16 + l, 64)) + __shfl(a0, base + 24 + l, 64);
+        fin += p;
+    }
+    return fin;
+}
+
+// regions of 32-bit words the fused train step wants zeroed before its search (statistics, histograms, list headers): zeroed by spare
+// workgroups of the pack kernel (blockIdx.y == 2) instead of a launch of their own
+#define VQ_STEP_MAX_CHUNKS 4
+#define VQ_ZERO_REGIONS (1 + 2 * VQ_STEP_MAX_CHUNKS)
+struct ZeroArgs { unsigned *p[VQ_ZERO_REGIONS]; unsigned n[VQ_ZERO_REGIONS]; };   // regions of n 32-bit words each (n = 0: unused)
+
 extern "C" size_t vqhip_packed_bytes(int C, int D)
 {
     if (C > 0 && vq_is_wide(D)) return vq_wide_packed_bytes(C, D);     // y2 || bf16 copy (vq_wide.hip)
@@ -134,10 +172,17 @@ extern "C" size_t vqhip_packed_bytes(int C, int D)
 
 __global__ void __launch_bounds__(256) vq_pack_kernel(const float *embed, int C, int D, int DT,
                                                       float *packed, unsigned short *ebf,
-                                                      unsigned *scalars, size_t head_bytes)
+                                                      unsigned *scalars, size_t head_bytes, const ZeroArgs z)
 {
     __shared__ float y2sh[32];
     const int t = blockIdx.x;
+    if (blockIdx.y == 2) {      // the fused train step's zeroing (one set of regions: head 0's workgroups only)
+        if (blockIdx.z) return;
+#pragma unroll
+        for (int r = 0; r < VQ_ZERO_REGIONS; ++r)
+            for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < z.n[r]; i += gridDim.x * 256) z.p[r][i] = 0u;
+        return;
+    }
     if (blockIdx.z) {      // batched heads (vqhip_pack_codebook_batched): head z's codebook and packed buffer
         embed += (size_t)blockIdx.z * C * D;
         packed = (float *)((char *)packed + (size_t)blockIdx.z * head_bytes);
@@ -168,33 +213,61 @@ __global__ void __launch_bounds__(256) vq_pack_kernel(const float *embed, int C,
     }
     const int tile_f = 32 * DT + 256;
     float *out = packed + (size_t)t * tile_f;
-    for (int p = threadIdx.x; p < 32 * DT; p += 256) {
-        const int jj = p & 3;
-        const int i = (p >> 2) & 31;
-        const int hi = (p >> 7) & 1;
-        const int t4 = p >> 8;
-        const int code = t * 32 + i;
-        const int k = 8 * t4 + 2 * jj + hi;
-        out[p] = (code < C && k < D) ? embed[(size_t)code * D + k] : 0.f;
-    }
-    {
-        const int i = threadIdx.x;
-        float v = 0.f;
-        if (i < 32) {
-            const int code = t * 32 + i;
-            if (code < C) {
-                const float *r = embed + (size_t)code * D;
-                v = aten_sumsq_seq([&](int e) { return r[e]; }, D);
-            } else {
-                v = INFINITY;
+    // The tile's code rows go through LDS: read from the codebook the way they lie (whole rows, 16 bytes per lane), written in the
+    // A-operand order 256 contiguous bytes per 16 codes, and the norms summed from the LDS copy.  (Reading the codebook in tile order --
+    // 4-byte loads 1 KiB apart -- and one thread per norm made this kernel 12 us of the 0.83 ms cfg-2 step.)  G codes at a time:
+    // 32 rows of <= 256 floats or 16 of <= 512, row stride D + 1 floats (the tile-order reads walk down the rows).
+    __shared__ float sh[32 * 257];
+    const int G = D <= 256 ? 32 : 16, LD = D + 1;
+    const bool vec = (D & 3) == 0 && (((uintptr_t)embed) & 15) == 0;
+#pragma unroll 1
+    for (int g0 = 0; g0 < 32; g0 += G) {
+        if (g0) __syncthreads();
+        if (vec) {
+            const int D4 = D >> 2;
+            for (int q = threadIdx.x; q < G * D4; q += 256) {
+                const int il = q / D4, k = (q - il * D4) * 4, code = t * 32 + g0 + il;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (code < C) v = *(const f32x4 *)(embed + (size_t)code * D + k);
+                float *d = sh + il * LD + k;
+                d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
             }
-            y2sh[i] = v;
+        } else {
+            for (int q = threadIdx.x; q < G * D; q += 256) {
+                const int il = q / D, k = q - il * D, code = t * 32 + g0 + il;
+                sh[il * LD + k] = code < C ? embed[(size_t)code * D + k] : 0.f;
+            }
+        }
+        __syncthreads();
+        for (int q = threadIdx.x; q < G * DT; q += 256) {
+            const int jj = q & 3, il = (q >> 2) % G, rest = q / (4 * G), hi = rest & 1, t4 = rest >> 1;
+            const int k = 8 * t4 + 2 * jj + hi;
+            out[((t4 * 2 + hi) * 32 + g0 + il) * 4 + jj] = k < D ? sh[il * LD + k] : 0.f;      // (rows past C were staged as zeros)
+        }
+        // ||c||^2 in ATen's order, a half-wave per code (eight codes at a time)
+        for (int r8 = 0; r8 < G; r8 += 8) {
+            const int il = r8 + (threadIdx.x >> 5), code = t * 32 + g0 + il;
+            const float *r = sh + il * LD;
+            float v = aten_sumsq_coop([&](int e) { return r[e]; }, D, (int)(threadIdx.x & 31));
+            if (code >= C) v = INFINITY;
+            if ((threadIdx.x & 31) == 0) y2sh[g0 + il] = v;
+        }
+    }
+    __syncthreads();
+    {
+        // tail: floats [0, 32) ||c||^2, float [32] the largest of the tile's real codes as float bits (non-negative floats order like their
+        // bit patterns; NaN sorts above inf) -- vq_pack16_kernel takes the maximum over the tiles: no atomic, nothing to zero beforehand
+        const int i = threadIdx.x;
+        float v = i < 32 ? y2sh[i] : 0.f;
+        if (i == 32) {
+            unsigned m = 0u;
+            for (int k = 0; k < 32; ++k)
+                if (t * 32 + k < C) m = max(m, __float_as_uint(y2sh[k]));
+            v = __uint_as_float(m);
         }
         out[32 * DT + i] = v;
     }
-    __syncthreads();
-    if (threadIdx.x < 32 && t * 32 + (int)threadIdx.x < C)
-        atomicMax(scalars, __float_as_uint(y2sh[threadIdx.x]));   // max ||c||^2: non-negative floats order like their bit patterns
+    if (t == 0 && threadIdx.x == 0) { scalars[1] = 0u; scalars[4] = 0u; }    // the maxima vq_pack16_kernel accumulates with atomics
 }
 
 // Second pack phase (needs max ||c||^2 of the first): fp16 A-operand tiles of the single-pass screening kernel
@@ -216,7 +289,19 @@ __global__ void __launch_bounds__(256) vq_pack16_kernel(const float *embed, int 
         tiles16 += (size_t)blockIdx.z * head_bytes;
         scalars = (unsigned *)((char *)scalars + (size_t)blockIdx.z * head_bytes);
     }
-    const unsigned y2bits = scalars[0];
+    // max ||c||^2 over the codebook: the largest of the tile maxima vq_pack_kernel left behind the fp32 tiles
+    __shared__ unsigned ymax_s;
+    if (threadIdx.x == 0) ymax_s = 0u;
+    __syncthreads();
+    {
+        unsigned m = 0u;
+        for (int tt = threadIdx.x; tt < n_tiles; tt += 256) m = max(m, __float_as_uint(packed[(size_t)tt * (32 * DT + 256) + 32 * DT + 32]));
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o, 64));
+        if ((threadIdx.x & 63) == 0 && m) atomicMax(&ymax_s, m);
+    }
+    __syncthreads();
+    const unsigned y2bits = ymax_s;
     int sc = 0;
     if (y2bits != 0u) {
         const int e2 = (int)((y2bits >> 23) & 0xffu) - 127;   // max ||c||^2 in [2^e2, 2^(e2+1))  =>  max ||c|| < 2^((e2 >> 1) + 1)
@@ -286,11 +371,11 @@ __global__ void __launch_bounds__(256) vq_pack16_kernel(const float *embed, int 
             if (over > 0.f && y2 > 0.f) atomicMax(scalars + 1, __float_as_uint(fminf(over / sqrtf(y2) * 1.001f, 2.5e-4f)));
             atomicMax(scalars + 4, ~__float_as_uint(y2));       // ~(bits of the SMALLEST ||c||^2): the scalars start zeroed; non-negative floats
         }                                                       // order like their bits (NaN sorts above inf: read back as "no plain mode")
-        if (t == 0 && i == 0) { scalars[2] = (unsigned)sc; scalars[3] = __float_as_uint(r0); }
+        if (t == 0 && i == 0) { scalars[0] = y2bits; scalars[2] = (unsigned)sc; scalars[3] = __float_as_uint(r0); }
     }
 }
 
-static int pack_codebook_impl(const float *embed, int C, int D, float *packed, int scalars_zeroed, void *stream, int H = 1)
+static int pack_codebook_impl(const float *embed, int C, int D, float *packed, void *stream, int H = 1, const ZeroArgs *zero = nullptr)
 {
     if (!embed || !packed || C <= 0 || H < 1) VQ_FAIL(VQHIP_EINVAL, "pack_codebook: null pointer, C <= 0 or H < 1");
     if (vq_is_wide(D)) return vq_wide_pack(embed, C, D, packed, H, stream);
@@ -301,12 +386,11 @@ static int pack_codebook_impl(const float *embed, int C, int D, float *packed, i
     char *base = (char *)packed;
     unsigned *scalars = (unsigned *)(base + vq_packed_scalars_offset(C, D));
     const size_t head_bytes = vq_packed_total_bytes(C, D);     // (a multiple of 16: every head's buffer keeps the alignment)
-    if (!scalars_zeroed) {
-        hipError_t e = hipMemset2DAsync(scalars, head_bytes, 0, VQ_PACKED_SCALARS_BYTES, (size_t)H, (hipStream_t)stream);
-        if (e != hipSuccess) VQ_FAIL((int)e, "pack_codebook: hipMemset2DAsync: %s", hipGetErrorString(e));
-    }
-    hipLaunchKernelGGL(vq_pack_kernel, dim3(tiles, 2, H), dim3(256), 0, (hipStream_t)stream, embed, C, D, DT, packed,
-                       (unsigned short *)(base + packed_bf16_offset(C, D)), scalars, head_bytes);
+    ZeroArgs z;
+    if (zero) z = *zero;
+    else for (int r = 0; r < VQ_ZERO_REGIONS; ++r) { z.p[r] = nullptr; z.n[r] = 0; }
+    hipLaunchKernelGGL(vq_pack_kernel, dim3(tiles, zero ? 3 : 2, H), dim3(256), 0, (hipStream_t)stream, embed, C, D, DT, packed,
+                       (unsigned short *)(base + packed_bf16_offset(C, D)), scalars, head_bytes, z);
     if (int rc = launch_status("vq_pack_kernel")) return rc;
     hipLaunchKernelGGL(vq_pack16_kernel, dim3((unsigned)vq_tiles16(C), 1, H), dim3(256), 0, (hipStream_t)stream, embed, C, D, DT, tiles,
                        (const float *)packed, base + vq_packed_f16_offset(C, D), scalars, head_bytes);
@@ -315,12 +399,12 @@ static int pack_codebook_impl(const float *embed, int C, int D, float *packed, i
 
 extern "C" int vqhip_pack_codebook(const float *embed, int C, int D, float *packed, void *stream)
 {
-    return pack_codebook_impl(embed, C, D, packed, 0, stream);
+    return pack_codebook_impl(embed, C, D, packed, stream);
 }
 
 extern "C" int vqhip_pack_codebook_batched(const float *embed, int H, int C, int D, float *packed, void *stream)
 {
-    return pack_codebook_impl(embed, C, D, packed, 0, stream, H);
+    return pack_codebook_impl(embed, C, D, packed, stream, H);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -3061,9 +3145,11 @@ extern "C" int vqhip_reduce_partials_rows(const double *partials, int R, int64_t
 #define VQ_SEG_CH 256          // rows per segmented-sum work item
 #endif
 #define VQ_HIST_LDS_MAX 16384  // codes whose histogram fits the LDS path (64 KiB)
-#ifndef VQ_SORT_ROWS_PER_BLOCK
-#define VQ_SORT_ROWS_PER_BLOCK 4096
+#ifndef VQ_SORT_THREADS
+#define VQ_SORT_THREADS 512    // threads of a counting-sort workgroup (LDS path), 16 rows each.  256 -> 512 (half the workgroups, half the
+                               // same-address atomics per code): hist 12.5 -> 11.2 us, scatter 25.4 -> 19.2 us at 2^20 rows, C = 1024; 1024: the same
 #endif
+#define VQ_SORT_ROWS_PER_BLOCK (16 * VQ_SORT_THREADS)
 
 // ATen CPU lerp (vectorised form): |w| < 0.5 ? fma(w, end - start, start) : fma(w - 1, end - start, end)
 __device__ __forceinline__ float aten_lerp(float start, float end, float w)
@@ -3137,6 +3223,9 @@ struct SortArgs {
     float *cs;     // [C] cluster_size, in place
     float *denom;  // [C] out
     float omd, eps, ceps;
+    int fold_next; // the segmented sum that follows folds every code's row itself (SegArgs.fold): every code gets at least one work item
+                   // (an empty one for a code without rows), the histogram is handed on zeroed as the codes' tickets, cursor[1] as the
+                   // workgroups' ticket
     // several heads in one launch (vqhip_ema_accumulate_batched: blockIdx.y = head): byte strides between consecutive heads' index
     // rows, workspaces (hist / cursor / seg_off / chunk_off / perm share one) and count vectors
     int heads;
@@ -3165,21 +3254,21 @@ __device__ __forceinline__ int sort_code(const SortArgs &a, int64_t row)
     return ok ? (int)ci : -1;
 }
 
-__global__ void __launch_bounds__(256) vq_hist_kernel(const SortArgs a0)
+__global__ void __launch_bounds__(VQ_SORT_THREADS) vq_hist_kernel(const SortArgs a0)
 {
     const SortArgs a = sort_head_args(a0);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int *lh = (int *)smem;
     const bool use_lds = !a.direct;
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, NT = (int)blockDim.x;     // (direct: 256 threads; LDS path: VQ_SORT_THREADS)
     if (use_lds) {
-        for (int c = tid; c < a.C; c += 256) lh[c] = 0;
+        for (int c = tid; c < a.C; c += NT) lh[c] = 0;
         __syncthreads();
     }
     const int rpb = a.direct ? 256 : VQ_SORT_ROWS_PER_BLOCK;
     const int64_t r0 = (int64_t)blockIdx.x * rpb;
     const int64_t r1 = min(a.N, r0 + rpb);
-    for (int64_t row = r0 + tid; row < r1; row += 256) {
+    for (int64_t row = r0 + tid; row < r1; row += NT) {
         const int c = sort_code(a, row);
         if (c >= 0) {
             if (use_lds) atomicAdd(&lh[c], 1);
@@ -3188,7 +3277,7 @@ __global__ void __launch_bounds__(256) vq_hist_kernel(const SortArgs a0)
     }
     if (use_lds) {
         __syncthreads();
-        for (int c = tid; c < a.C; c += 256)
+        for (int c = tid; c < a.C; c += NT)
             if (lh[c]) atomicAdd(&a.hist[c], lh[c]);
     }
 }
@@ -3208,7 +3297,7 @@ __global__ void __launch_bounds__(1024) vq_scan_kernel(const SortArgs a0)
     for (int c = c_lo; c < c_hi; ++c) {
         const int n = a.hist[c];
         sc += n;
-        sk += (n + VQ_SEG_CH - 1) / VQ_SEG_CH;
+        sk += (a.fold_next && n == 0) ? 1 : (n + VQ_SEG_CH - 1) / VQ_SEG_CH;
     }
     s_cnt[tid] = sc;
     s_chk[tid] = sk;
@@ -3235,11 +3324,16 @@ __global__ void __launch_bounds__(1024) vq_scan_kernel(const SortArgs a0)
             s_cs[c] = v;
         }
         oc += n;
-        ok += (n + VQ_SEG_CH - 1) / VQ_SEG_CH;
+        ok += (a.fold_next && n == 0) ? 1 : (n + VQ_SEG_CH - 1) / VQ_SEG_CH;
+        if (a.fold_next) a.hist[c] = 0;
     }
     if (tid == 1023) {
         a.seg_off[a.C] = s_cnt[1023];
         a.chunk_off[a.C] = s_chk[1023];
+    }
+    if (a.fold_next && tid <= 32 && tid <= a.C) {      // the workgroups' tickets: cursor[1], and cursor[16 g + 2] for the groups g < min(C, 32)
+        if (tid == 0) a.cursor[1] = 0;
+        else a.cursor[16 * (tid - 1) + 2] = 0;
     }
     if (a.cs) {
         __syncthreads();
@@ -3247,7 +3341,7 @@ __global__ void __launch_bounds__(1024) vq_scan_kernel(const SortArgs a0)
     }
 }
 
-__global__ void __launch_bounds__(256) vq_scatter_kernel(const SortArgs a0)
+__global__ void __launch_bounds__(VQ_SORT_THREADS) vq_scatter_kernel(const SortArgs a0)
 {
     const SortArgs a = sort_head_args(a0);
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -3257,7 +3351,7 @@ __global__ void __launch_bounds__(256) vq_scatter_kernel(const SortArgs a0)
     const int rpb = a.direct ? 256 : VQ_SORT_ROWS_PER_BLOCK;
     const int64_t r0 = (int64_t)blockIdx.x * rpb;
     const int64_t r1 = min(a.N, r0 + rpb);
-    constexpr int RPT = VQ_SORT_ROWS_PER_BLOCK / 256;
+    constexpr int RPT = 16, NT = VQ_SORT_THREADS;
     if (!use_lds) {
         for (int64_t row = r0 + tid; row < r1; row += 256) {
             const int c = sort_code(a, row);
@@ -3265,25 +3359,25 @@ __global__ void __launch_bounds__(256) vq_scatter_kernel(const SortArgs a0)
         }
         return;
     }
-    for (int c = tid; c < a.C; c += 256) lc[c] = 0;
+    for (int c = tid; c < a.C; c += NT) lc[c] = 0;
     __syncthreads();
     int code[RPT], rank[RPT];
 #pragma unroll
     for (int u = 0; u < RPT; ++u) {
-        const int64_t row = r0 + tid + 256 * u;
+        const int64_t row = r0 + tid + NT * u;
         code[u] = (row < r1) ? sort_code(a, row) : -1;
     }
 #pragma unroll
     for (int u = 0; u < RPT; ++u) rank[u] = (code[u] >= 0) ? atomicAdd(&lc[code[u]], 1) : 0;
     __syncthreads();
-    for (int c = tid; c < a.C; c += 256) {
+    for (int c = tid; c < a.C; c += NT) {
         const int n = lc[c];
         if (n) lc[c] = atomicAdd(&a.cursor[c * 16], n);  // reserve n slots; lc[c] becomes the base
     }
     __syncthreads();
 #pragma unroll
     for (int u = 0; u < RPT; ++u)
-        if (code[u] >= 0) a.perm[lc[code[u]] + rank[u]] = (int)(r0 + tid + 256 * u);
+        if (code[u] >= 0) a.perm[lc[code[u]] + rank[u]] = (int)(r0 + tid + NT * u);
 }
 
 struct SegArgs {
@@ -3300,6 +3394,18 @@ struct SegArgs {
     const void *qsrc;          // nullable: codebook rows in x's dtype, [C, D] -- the q of the commitment loss
     double *sqerr_partial;     // nullable: one entry per work item (n_partial of them)
     int64_t n_partial;
+    // FOLD (fused train step, one head): the wave that adds the LAST chunk of a code folds the code's sum into embed_avg and renormalises
+    // embed (ema_embed_row: what vq_step_fold_kernel did in a launch of its own); the workgroup that finishes last reduces the loss'
+    // partials [0, n_loss) (vq_reduce_kernel's order).  code_done [C] and wg_done: zeroed tickets (vq_scan_kernel, SortArgs.fold_next).
+    int *code_done, *wg_done;
+    float *embed_avg, *embed;
+    const float *denom;
+    float omd;
+    int fold_cosine;
+    const double *loss_partials;
+    int64_t n_loss;
+    double loss_scale;
+    float *loss_out;
     // several heads in one launch (blockIdx.y = head): byte strides of the rows, the workspace, embed_sum, the loss' code rows, the partials
     int heads;
     int64_t hs_x, hs_ws, hs_sum, hs_qsrc, hs_sq;
@@ -3406,23 +3512,34 @@ __global__ void __launch_bounds__(256) vq_segsum_kernel(const SegArgs a0)
         }
 }
 
+template <bool COHERENT>
+__device__ __forceinline__ void ema_embed_row(float *embed_avg, float *embed, const float *embed_sum,
+                                              const float *weight, const float *denom, int C, int D,
+                                              float omd, int cosine, int do_lerp, int do_update, int c);
+
 // Common case (D <= 256, vector-aligned rows, no per-row normalisation): the rows stay packed in their load registers
 // (2 VGPRs per bf16 row, 4 per fp32 row), so 16 rows are in flight per wave instead of 8.
 // SQ: this pass reads every (unmasked) row next to its code, which is all the commitment loss needs (F.mse_loss(quantize, x),
 // vqp.py:1327): the wave also sums ||q_c - x||^2 over its rows -- an fp32 FMA chain over the batch's elements of a lane, then in
 // double per batch of rows in flight (relative error of the total ~1e-8; the loss is held to 1e-5) -- so the search does not have to
 // re-read x for it.
-template <bool XBF16, bool SQ>
+template <bool XBF16, bool SQ, bool FOLD>
 __global__ void __launch_bounds__(256) vq_segsum_fast_kernel(const SegArgs a0)
 {
     const SegArgs a = seg_head_args(a0);
     const int lane = threadIdx.x & 63;
     const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int total = a.chunk_off[a.C];
+    // (FOLD: the partials are read by another workgroup of this launch: device-scope stores, straight to the memory side)
+    auto put_partial = [&](double v) {
+        if (FOLD) __hip_atomic_store(&a.sqerr_partial[w], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else a.sqerr_partial[w] = v;
+    };
     if (w >= total) {
-        if (SQ && lane == 0 && w < a.n_partial) a.sqerr_partial[w] = 0.0;
-        return;
+        if (SQ && lane == 0 && w < a.n_partial) put_partial(0.0);
+        if (!FOLD) return;
     }
+    if (!FOLD || w < total) {
     int lo = 0, hi = a.C;
     while (hi - lo > 1) {
         const int mid = (lo + hi) >> 1;
@@ -3510,7 +3627,48 @@ __global__ void __launch_bounds__(256) vq_segsum_fast_kernel(const SegArgs a0)
     if (SQ) {
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) sq += __shfl_xor(sq, o, 64);
-        if (lane == 0) a.sqerr_partial[w] = sq;
+        if (lane == 0) put_partial(sq);
+    }
+    if (FOLD) {
+        // This wave's adds have been performed (fp32 atomics and device-scope stores execute at the memory side, past the XCD's L2, and
+        // are acknowledged from there: vmcnt) before its ticket is drawn; the wave that draws a code's LAST ticket reads the sums with
+        // device-scope loads.  Deliberately NOT __threadfence(): on this chip that is a write-back + invalidate of the XCD's whole L2 per
+        // call -- measured: 127 -> 530 us for this kernel with one fence per wave.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        int last = 0;
+        if (lane == 0) last = atomicAdd(&a.code_done[c], 1) == (a.chunk_off[c + 1] - a.chunk_off[c]) - 1;
+        if (__builtin_amdgcn_readfirstlane(last))
+            ema_embed_row<true>(a.embed_avg, a.embed, a.embed_sum, nullptr, a.denom, a.C, a.D, a.omd, a.fold_cosine, 1, 1, c);
+    }
+    }
+    if (FOLD) {
+        // the workgroup that finishes last (every partial of the launch, and of the earlier row chunks' launches, is in memory by then)
+        // reduces the commitment loss: fp64, the fixed order of vq_reduce_kernel
+        // (two ticket levels: the workgroups of a launch finish together, and same-address atomics retire one per ~45 cycles -- 1 280
+        // tickets on one counter would be a 27 us tail; 32 counters of <= 40 and one of 32 are not)
+        __shared__ double red[256];
+        __shared__ int is_last;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const int G = a.C < 32 ? a.C : 32, nb = (int)gridDim.x, grp = (int)blockIdx.x % G;
+            const int members = nb / G + (grp < nb % G ? 1 : 0);
+            int l = 0;
+            if (atomicAdd(a.wg_done + 16 * grp + 1, 1) == members - 1) l = atomicAdd(a.wg_done, 1) == (nb < G ? nb : G) - 1;
+            is_last = l;
+        }
+        __syncthreads();
+        if (!is_last || !a.loss_out) return;
+        double sum = 0.0;
+        for (int64_t i = threadIdx.x; i < a.n_loss; i += 256)
+            sum += __hip_atomic_load(&a.loss_partials[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        red[threadIdx.x] = sum;
+        __syncthreads();
+        for (int o = 128; o >= 1; o >>= 1) {
+            if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) *a.loss_out = (float)(red[0] * a.loss_scale);
     }
 }
 
@@ -3543,6 +3701,13 @@ struct StatsFuse {
     // strides behind head 0's
     int heads = 1;
     int64_t hs_x = 0, hs_idx = 0, hs_ws = 0, hs_stats = 0, hs_qsrc = 0, hs_sq = 0;
+    // fold of embed_avg / embed and the loss' reduction inside the segmented sum (SegArgs.fold; needs cs / denom above)
+    float *fold_embed_avg = nullptr, *fold_embed = nullptr;
+    int fold_cosine = 0;
+    const double *loss_partials = nullptr;
+    int64_t n_loss = 0;
+    double loss_scale = 0.0;
+    float *loss_out = nullptr;
 };
 
 static int ema_accumulate_impl(const void *x, int x_dtype, int64_t N, int D, int64_t ldx,
@@ -3583,6 +3748,8 @@ static int ema_accumulate_impl(const void *x, int x_dtype, int64_t N, int D, int
     s.omd = fuse ? fuse->omd : 0.f;
     s.eps = fuse ? fuse->eps : 0.f;
     s.ceps = fuse ? (float)((double)C * (double)fuse->eps) : 0.f;
+    const bool fold = fuse && fuse->fold_embed_avg && fuse->fold_embed && s.cs && s.denom;
+    s.fold_next = fold ? 1 : 0;
     if (s.cs && (C > 8192 || !s.denom)) VQ_FAIL(VQHIP_EINVAL, "ema_accumulate: the fused cluster-size fold needs C <= 8192 and a denominator buffer");
     const unsigned nh = (unsigned)((fuse && fuse->heads > 1) ? fuse->heads : 1);
     s.heads = (int)nh;
@@ -3599,9 +3766,10 @@ static int ema_accumulate_impl(const void *x, int x_dtype, int64_t N, int D, int
     const int rpb = s.direct ? 256 : VQ_SORT_ROWS_PER_BLOCK;
     const unsigned sort_blocks = (unsigned)((N + rpb - 1) / rpb);
     const int lds = s.direct ? 0 : C * 4;
-    hipLaunchKernelGGL(vq_hist_kernel, dim3(sort_blocks, nh), dim3(256), lds, st, s);
+    const unsigned sort_threads = s.direct ? 256u : (unsigned)VQ_SORT_THREADS;
+    hipLaunchKernelGGL(vq_hist_kernel, dim3(sort_blocks, nh), dim3(sort_threads), lds, st, s);
     hipLaunchKernelGGL(vq_scan_kernel, dim3(1, nh), dim3(1024), s.cs ? (size_t)C * 4 : 0, st, s);
-    hipLaunchKernelGGL(vq_scatter_kernel, dim3(sort_blocks, nh), dim3(256), lds, st, s);
+    hipLaunchKernelGGL(vq_scatter_kernel, dim3(sort_blocks, nh), dim3(sort_threads), lds, st, s);
 
     SegArgs g;
     g.x = x; g.D = D; g.ldx = ldx; g.rnorm = rnorm; g.cosine = (metric == VQHIP_COSINE); g.C = C;
@@ -3610,6 +3778,11 @@ static int ema_accumulate_impl(const void *x, int x_dtype, int64_t N, int D, int
     g.heads = (int)nh;
     g.hs_x = fuse ? fuse->hs_x : 0; g.hs_ws = fuse ? fuse->hs_ws : 0; g.hs_sum = fuse ? fuse->hs_stats : 0;
     g.hs_qsrc = fuse ? fuse->hs_qsrc : 0; g.hs_sq = fuse ? fuse->hs_sq : 0;
+    g.code_done = s.hist; g.wg_done = s.cursor + 1;
+    g.embed_avg = fold ? fuse->fold_embed_avg : nullptr; g.embed = fold ? fuse->fold_embed : nullptr;
+    g.denom = s.denom; g.omd = s.omd; g.fold_cosine = fold ? fuse->fold_cosine : 0;
+    g.loss_partials = fold ? fuse->loss_partials : nullptr; g.n_loss = fold ? fuse->n_loss : 0;
+    g.loss_scale = fold ? fuse->loss_scale : 0.0; g.loss_out = fold ? fuse->loss_out : nullptr;
     if (nh > 1 && s.cs) VQ_FAIL(VQHIP_EINVAL, "ema_accumulate: the fused cluster-size fold is for one head");
     const unsigned seg_blocks = (unsigned)(seg_work_items(N, C) / 4);
     const int es = (x_dtype == VQHIP_BF16) ? 2 : 4;
@@ -3621,17 +3794,21 @@ static int ema_accumulate_impl(const void *x, int x_dtype, int64_t N, int D, int
         VQ_FAIL(VQHIP_EDIM, "ema_accumulate: D=%d > 512 needs D %% 4 == 0, rows aligned to 4 elements and Euclidean / unit-norm rows", D);
 #ifndef VQ_SEG_SLOW
     if (vec && D <= VQ_WIDE_MAX_D && !g.cosine) {
-        if (sqerr_partial) {
-            if (bf) hipLaunchKernelGGL((vq_segsum_fast_kernel<true, true>), dim3(seg_blocks, nh), dim3(256), 0, st, g);
-            else hipLaunchKernelGGL((vq_segsum_fast_kernel<false, true>), dim3(seg_blocks, nh), dim3(256), 0, st, g);
+        if (fold) {
+            if (!sqerr_partial || nh > 1 || D > 512) VQ_FAIL(VQHIP_EINVAL, "ema_accumulate: the fused fold needs the loss partials, one head and D <= 512");
+            if (bf) hipLaunchKernelGGL((vq_segsum_fast_kernel<true, true, true>), dim3(seg_blocks, nh), dim3(256), 0, st, g);
+            else hipLaunchKernelGGL((vq_segsum_fast_kernel<false, true, true>), dim3(seg_blocks, nh), dim3(256), 0, st, g);
+        } else if (sqerr_partial) {
+            if (bf) hipLaunchKernelGGL((vq_segsum_fast_kernel<true, true, false>), dim3(seg_blocks, nh), dim3(256), 0, st, g);
+            else hipLaunchKernelGGL((vq_segsum_fast_kernel<false, true, false>), dim3(seg_blocks, nh), dim3(256), 0, st, g);
         } else {
-            if (bf) hipLaunchKernelGGL((vq_segsum_fast_kernel<true, false>), dim3(seg_blocks, nh), dim3(256), 0, st, g);
-            else hipLaunchKernelGGL((vq_segsum_fast_kernel<false, false>), dim3(seg_blocks, nh), dim3(256), 0, st, g);
+            if (bf) hipLaunchKernelGGL((vq_segsum_fast_kernel<true, false, false>), dim3(seg_blocks, nh), dim3(256), 0, st, g);
+            else hipLaunchKernelGGL((vq_segsum_fast_kernel<false, false, false>), dim3(seg_blocks, nh), dim3(256), 0, st, g);
         }
         return launch_status("vq_ema_accumulate");
     }
 #endif
-    if (sqerr_partial) VQ_FAIL(VQHIP_EINVAL, "ema_accumulate_sqerr: built without the fast segment-sum kernel");
+    if (sqerr_partial || fold) VQ_FAIL(VQHIP_EINVAL, "ema_accumulate_sqerr: the loss and the fused fold need the fast segment-sum kernel's conditions");
     if (bf && vec) hipLaunchKernelGGL((vq_segsum_kernel<true, true>), dim3(seg_blocks, nh), dim3(256), 0, st, g);
     else if (bf) hipLaunchKernelGGL((vq_segsum_kernel<true, false>), dim3(seg_blocks, nh), dim3(256), 0, st, g);
     else if (vec) hipLaunchKernelGGL((vq_segsum_kernel<false, true>), dim3(seg_blocks, nh), dim3(256), 0, st, g);
@@ -3792,7 +3969,8 @@ __global__ void __launch_bounds__(256) vq_ema_denom_kernel(const float *cs_g, in
     ema_denom_block<256>(cs, C, eps, ceps, denom, part, &total_s);
 }
 
-// one wave per code row
+// one wave per code row.  COHERENT: embed_sum was accumulated by other workgroups of the SAME launch (device-scope loads)
+template <bool COHERENT>
 __device__ __forceinline__ void ema_embed_row(float *embed_avg, float *embed, const float *embed_sum,
                                               const float *weight, const float *denom, int C, int D,
                                               float omd, int cosine, int do_lerp, int do_update, int c)
@@ -3811,7 +3989,8 @@ __device__ __forceinline__ void ema_embed_row(float *embed_avg, float *embed, co
             const size_t o = (size_t)c * D + d;
             float ea = embed_avg[o];
             if (do_lerp) {
-                ea = aten_lerp(ea, embed_sum[o], w);
+                const float es = COHERENT ? __hip_atomic_load(&embed_sum[o], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : embed_sum[o];
+                ea = aten_lerp(ea, es, w);
                 embed_avg[o] = ea;
             }
             if (do_update) {
@@ -3839,7 +4018,7 @@ __global__ void __launch_bounds__(256) vq_ema_embed_kernel(float *embed_avg, flo
                                                            float omd, int cosine, int do_lerp, int do_update, int64_t hs_sum)
 {
     const size_t h = blockIdx.y;           // batched heads: embed_avg / embed [H, C, D], denom [H, C], embed_sum at hs_sum floats
-    ema_embed_row(embed_avg + h * C * D, embed + h * C * D, embed_sum ? embed_sum + h * hs_sum : nullptr, weight, denom ? denom + h * C : nullptr,
+    ema_embed_row<false>(embed_avg + h * C * D, embed + h * C * D, embed_sum ? embed_sum + h * hs_sum : nullptr, weight, denom ? denom + h * C : nullptr,
                   C, D, omd, cosine, do_lerp, do_update, blockIdx.x * 4 + (threadIdx.x >> 6));
 }
 
@@ -3850,7 +4029,7 @@ __global__ void __launch_bounds__(256) vq_step_fold_kernel(float *embed_avg, flo
                                                            int64_t n_partials, double scale, float *loss_out)
 {
     if (blockIdx.x + 1 < gridDim.x) {
-        ema_embed_row(embed_avg, embed, embed_sum, nullptr, denom, C, D, omd, cosine, 1, 1, blockIdx.x * 4 + (threadIdx.x >> 6));
+        ema_embed_row<false>(embed_avg, embed, embed_sum, nullptr, denom, C, D, omd, cosine, 1, 1, blockIdx.x * 4 + (threadIdx.x >> 6));
         return;
     }
     if (!loss_out) return;
@@ -3947,7 +4126,7 @@ __global__ void __launch_bounds__(256) vq_ema_embed_tab_kernel(const uintptr_t *
                                                                int C, int D, float omd, int cosine, int do_update)
 {
     const size_t h = blockIdx.y;
-    ema_embed_row((float *)table[3 * h + 1], (float *)table[3 * h + 2], stats + h * stats_stride, nullptr, denom ? denom + h * C : nullptr,
+    ema_embed_row<false>((float *)table[3 * h + 1], (float *)table[3 * h + 2], stats + h * stats_stride, nullptr, denom ? denom + h * C : nullptr,
                   C, D, omd, cosine, 1, do_update, blockIdx.x * 4 + (threadIdx.x >> 6));
 }
 
@@ -4541,15 +4720,6 @@ extern "C" int vqhip_transpose_batched(const void *in, void *out, int elem_bytes
 // kernel, embed_avg / embed / loss by one tail kernel.  (Counting the rows per code inside the search -- one global atomic per
 // certified row -- was built and measured: it saves the 14 us histogram pass and costs the search 20 us; not kept.)
 // ------------------------------------------------------------------------------------------------
-#define VQ_STEP_MAX_CHUNKS 4
-#define VQ_ZERO_REGIONS (2 + 2 * VQ_STEP_MAX_CHUNKS)
-struct ZeroArgs { unsigned *p[VQ_ZERO_REGIONS]; unsigned n[VQ_ZERO_REGIONS]; };   // regions of n 32-bit words each (n = 0: unused)
-__global__ void __launch_bounds__(256) vq_zero_kernel(const ZeroArgs a)
-{
-#pragma unroll
-    for (int r = 0; r < VQ_ZERO_REGIONS; ++r)
-        for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < a.n[r]; i += gridDim.x * 256) a.p[r][i] = 0u;
-}
 
 static inline size_t step_ws_screen(int64_t N) { return align_up(vqhip_screen_workspace_bytes(N), 256); }
 
@@ -4635,19 +4805,20 @@ extern "C" int vqhip_vq_train_step(const vqhip_vq_step_t *s, void *stream)
     double *partials = (double *)ws;
     float *embed_sum = s->stats, *count = s->stats + (size_t)C * D;
 
+    // VQHIP_STEP_FOLD=1: embed_avg / embed / the loss folded by the segmented sum's own waves (SegArgs FOLD) instead of the launch of
+    // vq_step_fold_kernel behind it.  Built and measured in round 6: 0.8414 vs 0.8409 ms per cfg-2 step -- the tickets, the last waves'
+    // folds and the last workgroup's reduction cost the kernel's tail what the launch cost -- so it is not the default.
+    static int fold_env = -1;
+    if (fold_env < 0) { const char *e = getenv("VQHIP_STEP_FOLD"); fold_env = (e && e[0] == '1') ? 1 : 0; }
+    const bool fold_in_sum = fold_env && D <= 512;
     ZeroArgs z;
     for (int r = 0; r < VQ_ZERO_REGIONS; ++r) { z.p[r] = nullptr; z.n[r] = 0; }
-    z.p[0] = (unsigned *)((char *)s->packed + vq_packed_scalars_offset(C, D)); z.n[0] = VQ_PACKED_SCALARS_BYTES / 4;
-    z.p[1] = (unsigned *)s->stats;                                             z.n[1] = (unsigned)((size_t)C * D + C);
+    z.p[0] = (unsigned *)s->stats;                                             z.n[0] = (unsigned)((size_t)C * D + C);
     for (int k = 0; k < K; ++k) {
-        z.p[2 + 2 * k] = (unsigned *)ws_screen[k];                             z.n[2 + 2 * k] = 4;              // list header
-        z.p[3 + 2 * k] = (unsigned *)ws_stats[k];                              z.n[3 + 2 * k] = (unsigned)C;    // the histogram
+        z.p[1 + 2 * k] = (unsigned *)ws_screen[k];                             z.n[1 + 2 * k] = 4;              // list header
+        z.p[2 + 2 * k] = (unsigned *)ws_stats[k];                              z.n[2 + 2 * k] = (unsigned)C;    // the histogram
     }
-    const unsigned zb = (z.n[1] + 1023) / 1024;
-    hipLaunchKernelGGL(vq_zero_kernel, dim3(zb < 1 ? 1 : (zb > 512 ? 512 : zb)), dim3(256), 0, st, z);
-    if (int rc = launch_status("vq_zero_kernel")) return rc;
-
-    if (int rc = pack_codebook_impl(s->embed, C, D, s->packed, 1, stream)) return rc;
+    if (int rc = pack_codebook_impl(s->embed, C, D, s->packed, stream, 1, &z)) return rc;      // (the zeroing rides in the pack kernel's grid)
     const void *qsrc = (x_dtype == VQHIP_BF16) ? (const void *)((const char *)s->packed + packed_bf16_offset(C, D)) : (const void *)s->embed;
     if (s->ev_search_begin) (void)hipEventRecord((hipEvent_t)s->ev_search_begin, st);
     for (int k = 0; k < K; ++k) {
@@ -4676,10 +4847,16 @@ extern "C" int vqhip_vq_train_step(const vqhip_vq_step_t *s, void *stream)
         f.denom = (s->fold && last) ? denom : nullptr;
         f.omd = (float)s->one_minus_decay;
         f.eps = (float)s->eps;
+        if (s->fold && last && fold_in_sum) {      // embed_avg / embed / the loss folded by the segmented sum's own waves
+            f.fold_embed_avg = s->embed_avg; f.fold_embed = s->embed;
+            f.fold_cosine = metric != VQHIP_EUCLID ? 1 : 0;
+            f.loss_partials = partials; f.n_loss = n_part; f.loss_scale = s->loss_scale; f.loss_out = s->loss_out;
+        }
         if (int rc = ema_accumulate_impl(xk, x_dtype, nrows[k], D, s->ldx, s->idx_out + rows0[k], 1, nullptr, VQHIP_EUCLID,
                                          s->row_mask ? s->row_mask + rows0[k] : nullptr, C, count, embed_sum, ws_stats[k],
                                          vqhip_ema_workspace_bytes(nrows[k], C), qsrc, partials + part0[k], (void *)sk, &f)) return rc;
     }
+    if (s->fold && fold_in_sum) return 0;
     if (s->fold) {
         hipLaunchKernelGGL(vq_step_fold_kernel, dim3((unsigned)((C + 3) / 4 + 1)), dim3(256), 0, st, s->embed_avg, s->embed, embed_sum, denom,
                            C, D, (float)s->one_minus_decay, metric != VQHIP_EUCLID ? 1 : 0, partials, n_part, s->loss_scale, s->loss_out);

@@ -1019,7 +1019,8 @@ class VectorQuantize(nn.Module):
                 # reference quirk (vqp.py:1319): the masked loss compares against the caller's tensor -- not l2-normalised, not
                 # projected, not split into heads (this path's codebook is not learnable: commit_quantize is detached, vqp.py:1214)
                 commit_loss = self._masked_commit_loss(quantize.detach(), orig_input, mask)
-            loss = loss + (commit_loss if self.commitment_weight == 1. else commit_loss * self.commitment_weight)
+            # (`loss` still is the constant zero here and 0 + v == v bit for bit: the term itself, not an add kernel per forward)
+            loss = commit_loss if self.commitment_weight == 1. else commit_loss * self.commitment_weight
 
         if self.training and self.has_codebook_orthogonal_loss:                                     # vqp.py:1331-1348, 340-345
             codebook = self._codebook.embed
