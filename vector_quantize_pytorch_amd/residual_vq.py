@@ -217,7 +217,11 @@ class ResidualVQ(nn.Module):
         rand_quantize_dropout_fixed_seed=None,
     ):
         if indices is not None:
-            raise NotImplementedError("forward(indices=) (cross-entropy to given codes) is not implemented for ResidualVQ")
+            # (the reference itself cannot run this: rvq.py:493 unpacks three values from a layer call that returns two with indices,
+            #  vqp.py:1260-1261 -- v1.31.0 raises "ValueError: not enough values to unpack (expected 3, got 2)"; checked against the live
+            #  reference, tests/golden/make_golden.py has no fixture to make)
+            raise NotImplementedError("ResidualVQ.forward(indices=): the reference (v1.31.0) raises ValueError here (rvq.py:493 unpacks three "
+                                      "values from VectorQuantize.forward(indices=), which returns two); call the layers' forward(indices=) directly")
         L._need_gpu(x)
         beam_size = (self.beam_size if self.training else self.eval_beam_size) if beam_size is None else beam_size
         is_beam = beam_size is not None and beam_size > 1
@@ -855,7 +859,8 @@ class GroupedResidualVQ(nn.Module):
     @other_float_dtypes_as_fp32
     def forward(self, x, indices=None, return_all_codes=False, sample_codebook_temp=None, freeze_codebook=False, mask=None):
         if indices is not None and len(indices) > 0:
-            raise NotImplementedError("forward(indices=) is not on the MI355X hot path (SURVEY.md §8f)")
+            raise NotImplementedError("GroupedResidualVQ.forward(indices=): every group's ResidualVQ.forward(indices=) raises in the reference "
+                                      "(v1.31.0, rvq.py:493: ValueError) -- there is no behaviour to reproduce")
         assert x.shape[self.split_dim] == self.dim
         chunks = x.chunk(self.groups, dim=self.split_dim)
         seed = None
