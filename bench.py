@@ -568,12 +568,15 @@ def screen_stress(dev, base_ms):
                 if prep:
                     prep(vq)
                 vq(batches[i % len(batches)])
-            torch.cuda.synchronize(); t0 = time.perf_counter()
-            for i in range(steps):
-                if prep:
-                    prep(vq)
-                vq(batches[i % len(batches)])
-            torch.cuda.synchronize(); ms = (time.perf_counter() - t0) / steps * 1e3
+            wins = []                               # three windows of `steps`, the median (a one-off host stall inside a short
+            for w in range(3):                      # window -- an allocator miss, a code-object load -- was 2 - 10 ms per step)
+                torch.cuda.synchronize(); t0 = time.perf_counter()
+                for i in range(steps):
+                    if prep:
+                        prep(vq)
+                    vq(batches[i % len(batches)])
+                torch.cuda.synchronize(); wins.append((time.perf_counter() - t0) / steps * 1e3)
+            ms = sorted(wins)[1]
             cbmod.L.vq_train_step = counting
             try:
                 for i in range(2):
@@ -624,18 +627,23 @@ def screen_stress(dev, base_ms):
         cb = v._codebook
         n7 = cb.embed[0, 7].norm()
         cb.embed[0, 7] *= (100.0 * cb.embed[0, 8].norm() / n7.clamp_min(1e-20)).clamp(max=1e6)
-    out["one_code_x100"] = run(vq, rand_batches, 10, prep=keep_big, warm=2)
-    out["one_code_x100"]["workload"] = "cfg-2 step, default codebook with code 7 held at 100 x the norm of its neighbour"
-    # control: the same module and per-step rescaling launches with the code held at 1 x (what the leg above costs without the large code)
-    vq = VectorQuantize(dim=D, codebook_size=C).to(dev).train()
+    # control: the same module and per-step rescaling launches with the code held at 1 x (what the leg costs without the large code).
+    # The two are timed alternately, three turns each, the median turn: a 10-step leg timed once carried its own warm-up.
+    vq_ctl = VectorQuantize(dim=D, codebook_size=C).to(dev).train()
 
     def keep_one(v):
         cb = v._codebook
         n7 = cb.embed[0, 7].norm()
         cb.embed[0, 7] *= (1.0 * cb.embed[0, 8].norm() / n7.clamp_min(1e-20)).clamp(max=1e6)
-    ctl = run(vq, rand_batches, 10, prep=keep_one, warm=2)
-    out["one_code_x100"]["control_ms_per_step"] = ctl["ms_per_step"]
-    out["one_code_x100"]["vs_control"] = round(out["one_code_x100"]["ms_per_step"] / ctl["ms_per_step"], 3)
+    big, ctl = [], []
+    for turn in range(3):
+        big.append(run(vq, rand_batches, 10, prep=keep_big, warm=2))
+        ctl.append(run(vq_ctl, rand_batches, 10, prep=keep_one, warm=2))
+    big.sort(key=lambda r: r["ms_per_step"]); ctl.sort(key=lambda r: r["ms_per_step"])
+    out["one_code_x100"] = big[1]
+    out["one_code_x100"]["workload"] = "cfg-2 step, default codebook with code 7 held at 100 x the norm of its neighbour (three turns alternating with the control, each the median of three 10-step windows; the median turn)"
+    out["one_code_x100"]["control_ms_per_step"] = ctl[1]["ms_per_step"]
+    out["one_code_x100"]["vs_control"] = round(big[1]["ms_per_step"] / ctl[1]["ms_per_step"], 3)
     return out
 
 

@@ -82,7 +82,11 @@ __global__ void __launch_bounds__(256, 2) vq_screenc_kernel(const ScreenArgs a, 
     // instead of 8 + 16 packed FMAs (which cost the cfg-2 search 4 %).  Codebooks with a wider norm spread keep the upper-bound scores
     // (one large code must not raise every row's threshold).
     const float y2max_c = __uint_as_float(a.scalars[0]), y2min_c = __uint_as_float(~a.scalars[4]);
+#ifdef VQC_FORCE_UPPER      // dev builds: the upper-bound sweep whatever the codebook (A/B runs of the two sweeps on one workload)
+    const bool plain = false;
+#else
     const bool plain = __builtin_amdgcn_readfirstlane((y2ok && y2min_c > 0.f && y2max_c <= 16.f * y2min_c) ? 1 : 0) != 0;
+#endif
     const float ymax_c = sqrtf(y2max_c) * 1.0001f;
     const int ldq2 = (int)(a.ldq * 2);
     const int ldx2 = (int)(a.ldx * 2);
