@@ -15,6 +15,19 @@ def codebook(kind, C, D, x):
     if kind == "dups":
         e = torch.randn(C, D, device=dev, generator=g); e[C // 2:] = e[: C - C // 2]; return e
     if kind == "tiny": return torch.randn(C, D, device=dev, generator=g) * 1e-3
+    # the persistent kernel picks its sweep from the codebook's norm spread (plain scores up to 4 x, upper bounds beyond): both sides of
+    # the switch, one huge code, one all-zero code (no plain mode: min ||c|| = 0), twins inside a spread codebook
+    if kind in ("ratio3.9", "ratio4.1"):
+        e = torch.nn.functional.normalize(torch.randn(C, D, device=dev, generator=g), dim=-1) * 16.0
+        s = torch.exp(torch.empty(C, 1, device=dev).uniform_(0.0, 1.0, generator=g) * torch.log(torch.tensor(float(kind[5:]))).item())
+        s[0], s[1] = 1.0, float(kind[5:])
+        e = e * s
+        e[C - 8:] = e[8:16]
+        return e
+    if kind == "x100":
+        e = torch.randn(C, D, device=dev, generator=g); e[7] *= 100.0; return e
+    if kind == "zerocode":
+        e = torch.randn(C, D, device=dev, generator=g) * 0.1; e[5] = 0.0; return e      # (small codes: the zero code wins only some rows)
     raise ValueError(kind)
 
 def rows(kind, N, D):
@@ -43,6 +56,9 @@ cases = [(1 << 17, 1024, "kaiming", "plain", False, True), (1 << 17, 1024, "kaim
          (1 << 17, 1024, "rows", "wild", False, True), (1 << 17, 1024, "randn", "big", False, True),
          (1 << 17, 1024, "randn", "small", False, True), (1 << 17, 1000, "randn", "plain", False, True),
          (1 << 17, 1024, "kaiming", "plain", True, True), (99999, 4096, "randn", "wild", True, True),
+         (1 << 17, 1024, "ratio3.9", "plain", False, True), (1 << 17, 1024, "ratio4.1", "plain", False, True),
+         (1 << 17, 1024, "ratio3.9", "wild", False, True), (1 << 17, 1024, "ratio4.1", "wild", False, False),
+         (1 << 17, 1024, "x100", "plain", False, True), (1 << 17, 1000, "zerocode", "plain", False, True),
          (1 << 20, 1024, "kaiming", "plain", False, True)]
 for (N, C, ck, rk, cosine, want_q) in cases:
     x = rows(rk, N, 256)
