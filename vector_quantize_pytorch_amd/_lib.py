@@ -591,7 +591,7 @@ def grvq_row_chunks(N: int, G: int) -> int:
     """Row chunks of the batched grouped chain (GroupedResidualVQ._forward_batched).  Every launch already carries the G groups'
     workgroups (cfg 5: 4 096 per screening launch, eight rounds of the chip's 512 slots), and splitting the rows on top only adds
     launches: cfg 5 on one box, same process conditions -- 1 chunk 14.04-14.32 ms, 2 chunks 14.22-14.57, 3 chunks 14.60-14.82
-    (gpurun_out/r6b -> profiles/r6_grvq_cfg5/chunks.txt).  VQHIP_GRVQ_CHUNKS overrides."""
+    (profiles/r6_ab/summary.md, r6b).  VQHIP_GRVQ_CHUNKS overrides."""
     return 1
 
 

@@ -2265,7 +2265,7 @@ __global__ void __launch_bounds__(256, (DT <= 256 ? 2 : 1)) vq_tail_kernel(const
 }
 
 // Built, bit-identical (test_residual_chain_merged_exact_passes_...), and MEASURED SLOWER than the three launches it replaces: cfg 3
-// 2.80 -> 2.96 ms, cfg 5 14.47 -> 14.75 ms (gpurun_out/r6g: one box, same run; round 3 had found refine + pair merged "a wash"): the
+// 2.80 -> 2.96 ms, cfg 5 14.47 -> 14.75 ms (profiles/r6_ab/summary.md, r6g: one box, same run; round 3 had found refine + pair merged "a wash"): the
 // pair rows' workgroups take the sweep's 256 registers and 34 - 68 KiB of LDS, i.e. two per CU, and every split sweep pays two barriers
 // and a device-scope counter.  OFF unless VQHIP_TAIL=1.
 int vq_tail_enabled()
