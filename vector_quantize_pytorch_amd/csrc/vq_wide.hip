@@ -110,16 +110,23 @@ __device__ __forceinline__ float wd_aten_sumsq_coop(F ld, int D, int c)
     const int size = V >> 2;
     float a0 = 0.f, a1 = 0.f;
     int i = 0;
-    for (; i + 16 <= size;) {
-        for (int j = 0; j < 16; ++j, ++i) {
-            const float v = ld(32 * i + c);
-            a0 += v * v;
-        }
+    // (the 16 loads of a block are requested together and consumed in order: as a load-then-add loop every step of the chain waited for
+    //  its own load -- 24 .. 64 round trips to L2 / HBM per row, eight rows at a time, which was a third of vq_wide_mfma_kernel's time)
+    for (; i + 16 <= size; i += 16) {
+        float v[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) v[j] = ld(32 * (i + j) + c);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) a0 += v[j] * v[j];
         a1 += a0; a0 = 0.f;
     }
-    for (; i < size; ++i) {
-        const float v = ld(32 * i + c);
-        a0 += v * v;
+    {
+        float v[16];
+#pragma unroll
+        for (int j = 0; j < 15; ++j) v[j] = (i + j < size) ? ld(32 * (i + j) + c) : 0.f;
+#pragma unroll
+        for (int j = 0; j < 15; ++j)
+            if (i + j < size) a0 += v[j] * v[j];
     }
     a0 += a1;
     for (int v = size * 4; v < V; ++v)
@@ -145,22 +152,36 @@ static inline size_t wd_align(size_t v, size_t a) { return (v + a - 1) / a * a; 
 size_t vq_wide_packed_bytes(int C, int D) { return wd_align((size_t)C * 4, 256) + wd_align((size_t)C * D * 2, 256) + 256; }
 static inline size_t wd_bf16_offset(int C) { return wd_align((size_t)C * 4, 256); }
 
+// A half-wave per code for the norm (eight codes per workgroup: C / 8 workgroups; one thread per code walked a 3 - 8 KiB row by itself
+// from 1 - 4 workgroups -- 190 - 310 us of a 0.9 - 1.6 ms step, round 6), the bf16 copy grid-strided over the same workgroups.
 __global__ void __launch_bounds__(256) vq_wide_pack_kernel(const float *embed, int C, int D, float *y2, unsigned short *ebf, size_t in_hs, size_t out_hs)
 {
     embed += blockIdx.y * in_hs;
     y2 = (float *)((char *)y2 + blockIdx.y * out_hs);
     ebf = (unsigned short *)((char *)ebf + blockIdx.y * out_hs);
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c < C) y2[c] = wd_aten_sumsq([&](int e) { return embed[(size_t)c * D + e]; }, D);
+    const int c = blockIdx.x * 8 + (int)(threadIdx.x >> 5);
+    const float *row = embed + (size_t)(c < C ? c : C - 1) * D;
+    const float v = wd_aten_sumsq_coop([&](int e) { return row[e]; }, D, (int)(threadIdx.x & 31));
+    if (c < C && (threadIdx.x & 31) == 0) y2[c] = v;
     const size_t n = (size_t)C * D;
-    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (size_t)gridDim.x * 256) ebf[e] = wd_f32_to_bf16(embed[e]);
+    if ((D & 3) == 0 && (((uintptr_t)embed) & 15) == 0 && (((uintptr_t)ebf) & 7) == 0) {
+        for (size_t e = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4; e < n; e += (size_t)gridDim.x * 1024) {
+            const f32x4 w = *(const f32x4 *)(embed + e);
+            uint2 o;
+            o.x = (unsigned)wd_f32_to_bf16(w.x) | ((unsigned)wd_f32_to_bf16(w.y) << 16);
+            o.y = (unsigned)wd_f32_to_bf16(w.z) | ((unsigned)wd_f32_to_bf16(w.w) << 16);
+            *(uint2 *)(ebf + e) = o;
+        }
+    } else {
+        for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (size_t)gridDim.x * 256) ebf[e] = wd_f32_to_bf16(embed[e]);
+    }
 }
 
 int vq_wide_pack(const float *embed, int C, int D, float *packed, int H, void *stream)
 {
     if (((uintptr_t)packed) & 15) VQ_FAIL(VQHIP_EALIGN, "pack_codebook: packed must be 16-byte aligned");
     char *base = (char *)packed;
-    hipLaunchKernelGGL(vq_wide_pack_kernel, dim3((unsigned)((C + 255) / 256), H), dim3(256), 0, (hipStream_t)stream, embed, C, D, (float *)base,
+    hipLaunchKernelGGL(vq_wide_pack_kernel, dim3((unsigned)((C + 7) / 8), H), dim3(256), 0, (hipStream_t)stream, embed, C, D, (float *)base,
                        (unsigned short *)(base + wd_bf16_offset(C)), (size_t)C * D, vq_wide_packed_bytes(C, D));
     return vq_launch_status("vq_wide_pack_kernel");
 }
@@ -442,7 +463,48 @@ __global__ void __launch_bounds__(256, 2) vq_wide_mfma_kernel(const WideAssignAr
     // staging: work item (r, g8) = 8 consecutive features g8 of row / code r of the slab -> two 16-byte LDS pieces (hi = 0: the even
     // features, hi = 1: the odd ones); 128 x 8 items each for A and B, four per thread and operand; g8 runs fastest over the threads
     // (eight threads read 256 contiguous bytes of one row)
+    // (vector path: a wave-uniform base per slab / group + a 32-bit lane offset fixed for the whole launch -- the address arithmetic of
+    //  the staging was ~200 VALU instructions per slab and wave, and on this chip VALU work is taken out of the fp32 MFMA stream)
+    constexpr int ES = XBF16 ? 2 : 4;
+    unsigned xoff[4], coff[4];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int item = it * 256 + tid, r = item >> 3, g8 = item & 7;
+        const int64_t lim = a.N - 1 - r0;                                    // rows past the end repeat the last one
+        const int rl = (int64_t)r < lim ? r : (int)(lim < 0 ? 0 : lim);
+        xoff[it] = (unsigned)((int64_t)rl * a.ldx + g8 * 8) * (unsigned)ES;
+        coff[it] = (unsigned)(r * a.D + g8 * 8) * 4u;
+    }
+    const char *const xbase = (const char *)a.x + r0 * a.ldx * ES;
+    const bool fast = a.vec && !(METRIC == 1 && !a.skip_norm) && a.ldx < ((int64_t)1 << 22);      // (the lane offsets stay below 2^32 bytes)
     auto fetch = [&](int slab, int grp, float (&ra)[4][8], float (&rb)[4][8]) __attribute__((always_inline)) {
+        if (fast) {
+            const int k0 = slab * WM_KS;
+            const char *const xs = xbase + (size_t)k0 * ES;
+            const int c0 = grp * 32 * WM_T;
+            const bool whole = k0 + WM_KS <= a.D && c0 + 32 * WM_T <= a.C;      // wave-uniform: nothing of this slab / group is padding
+            const char *const cs = (const char *)(a.embed + (size_t)c0 * a.D + k0);
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int item = it * 256 + tid, r = item >> 3, g8 = item & 7;
+                bool in = true, cin = true;
+                if (!whole) { in = k0 + g8 * 8 < a.D; cin = in && c0 + r < a.C; }
+                if (XBF16) {
+                    const uint4 w = in ? *(const uint4 *)(xs + xoff[it]) : make_uint4(0u, 0u, 0u, 0u);
+                    const unsigned ww[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { rb[it][2 * e] = __uint_as_float(ww[e] << 16); rb[it][2 * e + 1] = __uint_as_float(ww[e] & 0xffff0000u); }
+                } else {
+                    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                    const f32x4 w0 = in ? *(const f32x4 *)(xs + xoff[it]) : z, w1 = in ? *(const f32x4 *)(xs + xoff[it] + 16) : z;
+                    rb[it][0] = w0.x; rb[it][1] = w0.y; rb[it][2] = w0.z; rb[it][3] = w0.w; rb[it][4] = w1.x; rb[it][5] = w1.y; rb[it][6] = w1.z; rb[it][7] = w1.w;
+                }
+                const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                const f32x4 q0 = cin ? *(const f32x4 *)(cs + coff[it]) : z, q1 = cin ? *(const f32x4 *)(cs + coff[it] + 16) : z;
+                ra[it][0] = q0.x; ra[it][1] = q0.y; ra[it][2] = q0.z; ra[it][3] = q0.w; ra[it][4] = q1.x; ra[it][5] = q1.y; ra[it][6] = q1.z; ra[it][7] = q1.w;
+            }
+            return;
+        }
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
             const int item = it * 256 + tid, r = item >> 3, g8 = item & 7, k = slab * WM_KS + g8 * 8;
@@ -498,6 +560,7 @@ __global__ void __launch_bounds__(256, 2) vq_wide_mfma_kernel(const WideAssignAr
     };
 
     float bd = (METRIC == 0) ? INFINITY : -INFINITY;
+    float bs = INFINITY;            // Euclidean: the clamped squared distance whose root is bd
     int bi = 0;
     const float x2r = s_x2[wave * 32 + j];
     float ra[4][8], rb[4][8];
@@ -515,49 +578,75 @@ __global__ void __launch_bounds__(256, 2) vq_wide_mfma_kernel(const WideAssignAr
             {   // the next slab (of this group, or the first one of the next group) travels while this one is multiplied
                 int ns = slab + 1, ng = grp;
                 if (ns == n_slab) { ns = 0; ng = grp + 1; }
+#ifndef WM_DEV_NOFETCH          // dev builds (timing only, wrong results): the operands of the first slab are multiplied again and again
                 if (ng < n_grp) fetch(ns, ng, ra, rb);
+#endif
             }
             f32x4 b[WM_KS / 8];
 #pragma unroll
             for (int p4 = 0; p4 < WM_KS / 8; ++p4) b[p4] = *(const f32x4 *)(sB + (((wave * (WM_KS / 8) + p4) * 2 + hi) * 32 + j) * 4);
-            f32x4 av[WM_T], an[WM_T];                       // this pair group's A pieces, and the next one's on their way from LDS
+            // One tile after the other, 32 MFMAs in a row on ONE accumulator (k ascending inside it, as before).  Taking turns between the
+            // four accumulators after every MFMA -- the first version -- ran at 0.54 of the pipe's rate whatever was removed around
+            // it (staging loads, epilogue, LDS prefetch distance: tools/time_wide_kernel.py with dev builds): an MFMA whose C operand is
+            // not the previous MFMA's result moves its 16 accumulator registers through the register file, and at K = 2 that costs
+            // about as much as the product itself; a dependent chain keeps them in the pipe (the exact kernel of the tuned dims has
+            // always run one chain per wave).  A pieces: a ring of three, requested two steps ahead, pinned against the scheduler.
+            constexpr int NQ = WM_T * (WM_KS / 8);
+            f32x4 aq[3];
+            aq[0] = *(const f32x4 *)(sA + ((0 * 2 + hi) * 32 + j) * 4);
+            aq[1] = *(const f32x4 *)(sA + ((1 * 2 + hi) * 32 + j) * 4);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int t = 0; t < WM_T; ++t) av[t] = *(const f32x4 *)(sA + (((t * (WM_KS / 8) + 0) * 2 + hi) * 32 + j) * 4);
-#pragma unroll
-            for (int p4 = 0; p4 < WM_KS / 8; ++p4) {
-                if (p4 + 1 < WM_KS / 8) {
-#pragma unroll
-                    for (int t = 0; t < WM_T; ++t) an[t] = *(const f32x4 *)(sA + (((t * (WM_KS / 8) + p4 + 1) * 2 + hi) * 32 + j) * 4);
-                }
-                // the four tiles' accumulators take turns (independent chains: no MFMA waits for the previous one's result)
-#pragma unroll
-                for (int t = 0; t < WM_T; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t].x, b[p4].x, acc[t], 0, 0, 0);
-#pragma unroll
-                for (int t = 0; t < WM_T; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t].y, b[p4].y, acc[t], 0, 0, 0);
-#pragma unroll
-                for (int t = 0; t < WM_T; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t].z, b[p4].z, acc[t], 0, 0, 0);
-#pragma unroll
-                for (int t = 0; t < WM_T; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t].w, b[p4].w, acc[t], 0, 0, 0);
-#pragma unroll
-                for (int t = 0; t < WM_T; ++t) av[t] = an[t];
+            for (int q = 0; q < NQ; ++q) {
+                const int t = q / (WM_KS / 8), p4 = q % (WM_KS / 8);
+                if (q + 2 < NQ) aq[(q + 2) % 3] = *(const f32x4 *)(sA + (((q + 2) * 2 + hi) * 32 + j) * 4);
+                __builtin_amdgcn_sched_barrier(0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[q % 3].x, b[p4].x, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[q % 3].y, b[p4].y, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[q % 3].z, b[p4].z, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[q % 3].w, b[p4].w, acc[t], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
         // ---- this group's codes, ascending per lane: register e of tile t <-> code 32 (grp WM_T + t) + 8 (e >> 2) + 4 hi + (e & 3) ----
+        // Euclidean: the root is monotone, so a tile none of whose squared distances is below the best one's cannot hold a strictly
+        // smaller distance for this lane -- one fma + min per score and a wave-level skip instead of a correctly rounded sqrt per score
+        // (~25 VALU instructions each, taken out of the fp32 MFMA stream); a tile that may improve some lane runs the reference's
+        // arithmetic score by score as before.
 #pragma unroll
-        for (int t = 0; t < WM_T; ++t)
+        for (int t = 0; t < WM_T; ++t) {
+            const int cb = (grp * WM_T + t) * 32 + 4 * hi;
+#ifdef WM_DEV_NOEPI             // dev builds (timing only, wrong results)
+            if (acc[t][0] == 12345.f) bi = cb;
+            continue;
+#endif
+            if (METRIC == 0) {
+                float sv[16];
+                float smin = INFINITY;
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int code = (grp * WM_T + t) * 32 + 8 * (e >> 2) + 4 * hi + (e & 3);
-                if (code < a.C) {
-                    if (METRIC == 0) {
-                        const float tt = x2r + a.y2[code];
-                        const float d = sqrtf(fmaxf(__builtin_fmaf(-2.0f, acc[t][e], tt), 1e-8f));
-                        if (d < bd) { bd = d; bi = code; }
-                    } else {
-                        if (acc[t][e] > bd) { bd = acc[t][e]; bi = code; }
+                for (int e = 0; e < 16; ++e) {
+                    const int code = cb + 8 * (e >> 2) + (e & 3);
+                    const float tt = x2r + a.y2[code < a.C ? code : a.C - 1];
+                    sv[e] = code < a.C ? fmaxf(__builtin_fmaf(-2.0f, acc[t][e], tt), 1e-8f) : INFINITY;
+                    smin = fminf(smin, sv[e]);
+                }
+                if (!__any(smin < bs)) continue;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int code = cb + 8 * (e >> 2) + (e & 3);
+                    if (sv[e] < bs) {                 // (sv >= bs: its root is >= bd, no strict improvement)
+                        const float d = sqrtf(sv[e]);
+                        if (d < bd) { bd = d; bi = code; bs = sv[e]; }
                     }
                 }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int code = cb + 8 * (e >> 2) + (e & 3);
+                    if (code < a.C && acc[t][e] > bd) { bd = acc[t][e]; bi = code; }
+                }
             }
+        }
     }
     {   // the two half-waves of a row: better score, then lower index
         const float od = __shfl_xor(bd, 32, 64);
