@@ -11,7 +11,7 @@ if os.path.exists(notes_file):
 out = [f"# Same-box A/B runs of round {tag[1:]} (`tools/ab_summary.py {tag}`)\n",
        "Every table is ONE `gpurun` call (one box, variants interleaved); boxes differ by up to 5 %, so only rows of one table compare.\n"
        "`now` = the tree at the time of the run, other names = a library built from a variant (`VQHIP_SO`) or an environment switch.\n"]
-for d in sorted(glob.glob(os.path.join(ROOT, "gpurun_out", tag + "[a-z]"))):
+for d in sorted(glob.glob(os.path.join(ROOT, "gpurun_out", tag + "[a-z]*"))):
     name = os.path.basename(d)
     rows = []
     for f in sorted(glob.glob(os.path.join(d, "*.json"))):
@@ -48,7 +48,7 @@ for d in sorted(glob.glob(os.path.join(ROOT, "gpurun_out", tag + "[a-z]"))):
         con = sqlite3.connect(db)
         out.append(f"\n`{os.path.relpath(db, d)}` (rocprofv3 --kernel-trace, average µs per launch, vq kernels):\n")
         out.append("| kernel | launches | avg µs |\n|---|---|---|")
-        q = ("select name, count(*), avg(end-start)/1e3 from kernels where name like '%vq_%' group by name order by sum(end-start) desc limit 16")
+        q = ("select name, count(*), avg(end-start)/1e3 from kernels where name like '%vq_%' and name not like '%at::%' group by name order by sum(end-start) desc limit 16")
         for nm, n, avg in con.execute(q):
             out.append(f"| `{re.sub(r'[(].*', '', nm)[:70]}` | {n} | {avg:.2f} |")
     for t in txts:

@@ -427,16 +427,30 @@ __global__ void __launch_bounds__(256) vq_wide_assign_kernel(const WideAssignArg
 //     winning distances equal to the chain oracle at D = 640 .. 2048).
 // Rows are re-staged once per group of WM_T tiles (from L2: C / (32 WM_T) times 128 x D x 4 bytes per workgroup).
 #define WM_T 4
-#define WM_KS 64
+#ifndef WM_KS
+#define WM_KS 32            // 32: 68 KiB of LDS, two workgroups per CU (0.64 of the nominal pipe rate at dim 768 x 65 536 rows); 64: one (0.57)
+#endif
+#define WM_ITS (WM_KS / 16)                            // staging work items per thread and operand
+#define WM_G8 (WM_KS / 8)                              // 8-feature pieces (= pair groups) of a slab
 typedef float f32x16w __attribute__((ext_vector_type(16)));
 
+// A unit = the 32 lanes' 16-byte pieces of one (tile or wave, pair group, hi): 512 bytes + 16 bytes of padding, so that the staging
+// writes -- 16 lanes = 2 rows x 8 pair groups per LDS pass, a pair group every 2 units -- land 32 bytes apart per pair group and 16 per
+// row: all 64 banks.  (Unpadded, the 8 pair groups of a row hit the same banks: every staging write an 8-way conflict, ~4 000 LDS
+// cycles per slab and workgroup -- what held the kernel at 0.55 - 0.6 of the pipe through every other change.)
+#define WM_UNIT (128 + 32 / WM_G8)      // 132 at WM_KS = 64 (pair groups 32 bytes apart), 136 at WM_KS = 32 (64 bytes apart)
+#define WM_IMG (WM_T * (WM_KS / 8) * 2 * WM_UNIT)      // floats of one operand image (33 KiB)
+#define WM_SMEM (4 * WM_IMG * 4)                       // bytes: A and B images, two buffers each (128 KiB: one workgroup per CU)
 template <bool XBF16, int METRIC>
-__global__ void __launch_bounds__(256, 2) vq_wide_mfma_kernel(const WideAssignArgs a)
+__global__ void __launch_bounds__(256, WM_KS <= 32 ? 2 : 1) vq_wide_mfma_kernel(const WideAssignArgs a)
 {
     // operand images: [tile or wave][p4 = pair group of 4][hi][lane 0..31][4 pairs] floats -- a lane's ds_read_b128 returns the values of
-    // four consecutive MFMAs; consecutive lanes read consecutive 16-byte pieces (conflict-free)
-    __shared__ __attribute__((aligned(16))) float sA[WM_T * (WM_KS / 8) * 2 * 32 * 4];      // 32 KiB
-    __shared__ __attribute__((aligned(16))) float sB[4 * (WM_KS / 8) * 2 * 32 * 4];         // 32 KiB
+    // four consecutive MFMAs; consecutive lanes read consecutive 16-byte pieces (conflict-free).  TWO buffers per operand: the next
+    // slab is written into the other one from inside this slab's MFMA stream, one barrier per slab (the single-buffered first version
+    // -- barrier, write, barrier, multiply, two workgroups per CU to cover for each other -- ran at 0.66 of the pipe's rate at its
+    // actual clock; the exact kernel of the tuned dims, which stages inside its MFMA stream, at 0.95)
+    extern __shared__ __attribute__((aligned(16))) float wm_smem[];
+    float *const sA0 = wm_smem, *const sB0 = wm_smem + 2 * WM_IMG;
     __shared__ float s_x2[VQHIP_ASSIGN_ROWS_PER_BLOCK], s_nrm[VQHIP_ASSIGN_ROWS_PER_BLOCK];
     __shared__ int s_win[VQHIP_ASSIGN_ROWS_PER_BLOCK];
     __shared__ double s_red[4];
@@ -466,10 +480,10 @@ __global__ void __launch_bounds__(256, 2) vq_wide_mfma_kernel(const WideAssignAr
     // (vector path: a wave-uniform base per slab / group + a 32-bit lane offset fixed for the whole launch -- the address arithmetic of
     //  the staging was ~200 VALU instructions per slab and wave, and on this chip VALU work is taken out of the fp32 MFMA stream)
     constexpr int ES = XBF16 ? 2 : 4;
-    unsigned xoff[4], coff[4];
+    unsigned xoff[WM_ITS], coff[WM_ITS];
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
-        const int item = it * 256 + tid, r = item >> 3, g8 = item & 7;
+    for (int it = 0; it < WM_ITS; ++it) {
+        const int item = it * 256 + tid, r = item / WM_G8, g8 = item % WM_G8;
         const int64_t lim = a.N - 1 - r0;                                    // rows past the end repeat the last one
         const int rl = (int64_t)r < lim ? r : (int)(lim < 0 ? 0 : lim);
         xoff[it] = (unsigned)((int64_t)rl * a.ldx + g8 * 8) * (unsigned)ES;
@@ -477,7 +491,7 @@ __global__ void __launch_bounds__(256, 2) vq_wide_mfma_kernel(const WideAssignAr
     }
     const char *const xbase = (const char *)a.x + r0 * a.ldx * ES;
     const bool fast = a.vec && !(METRIC == 1 && !a.skip_norm) && a.ldx < ((int64_t)1 << 22);      // (the lane offsets stay below 2^32 bytes)
-    auto fetch = [&](int slab, int grp, float (&ra)[4][8], float (&rb)[4][8]) __attribute__((always_inline)) {
+    auto fetch = [&](int slab, int grp, float (&ra)[WM_ITS][8], float (&rb)[WM_ITS][8]) __attribute__((always_inline)) {
         if (fast) {
             const int k0 = slab * WM_KS;
             const char *const xs = xbase + (size_t)k0 * ES;
@@ -485,8 +499,8 @@ __global__ void __launch_bounds__(256, 2) vq_wide_mfma_kernel(const WideAssignAr
             const bool whole = k0 + WM_KS <= a.D && c0 + 32 * WM_T <= a.C;      // wave-uniform: nothing of this slab / group is padding
             const char *const cs = (const char *)(a.embed + (size_t)c0 * a.D + k0);
 #pragma unroll
-            for (int it = 0; it < 4; ++it) {
-                const int item = it * 256 + tid, r = item >> 3, g8 = item & 7;
+            for (int it = 0; it < WM_ITS; ++it) {
+                const int item = it * 256 + tid, r = item / WM_G8, g8 = item % WM_G8;
                 bool in = true, cin = true;
                 if (!whole) { in = k0 + g8 * 8 < a.D; cin = in && c0 + r < a.C; }
                 if (XBF16) {
@@ -506,8 +520,8 @@ __global__ void __launch_bounds__(256, 2) vq_wide_mfma_kernel(const WideAssignAr
             return;
         }
 #pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const int item = it * 256 + tid, r = item >> 3, g8 = item & 7, k = slab * WM_KS + g8 * 8;
+        for (int it = 0; it < WM_ITS; ++it) {
+            const int item = it * 256 + tid, r = item / WM_G8, g8 = item % WM_G8, k = slab * WM_KS + g8 * 8;
             const int64_t xr = r0 + r < a.N ? r0 + r : a.N - 1;
             const int code = grp * 32 * WM_T + r;
             const float inv = s_nrm[r];
@@ -545,26 +559,27 @@ __global__ void __launch_bounds__(256, 2) vq_wide_mfma_kernel(const WideAssignAr
             }
         }
     };
-    auto park = [&](const float (&ra)[4][8], const float (&rb)[4][8]) __attribute__((always_inline)) {
-#pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const int item = it * 256 + tid, r = item >> 3, g8 = item & 7;
-            // pairs 4 g8 .. 4 g8 + 3 of the slab: p4 = g8; image index ((blk * 8 + p4) * 2 + hi) * 32 + (r & 31), blk = r >> 5
-            float *pa = sA + ((((r >> 5) * (WM_KS / 8) + g8) * 2) * 32 + (r & 31)) * 4;
-            float *pb = sB + ((((r >> 5) * (WM_KS / 8) + g8) * 2) * 32 + (r & 31)) * 4;
-            *(f32x4 *)pa = f32x4{ra[it][0], ra[it][2], ra[it][4], ra[it][6]};
-            *(f32x4 *)(pa + 128) = f32x4{ra[it][1], ra[it][3], ra[it][5], ra[it][7]};
-            *(f32x4 *)pb = f32x4{rb[it][0], rb[it][2], rb[it][4], rb[it][6]};
-            *(f32x4 *)(pb + 128) = f32x4{rb[it][1], rb[it][3], rb[it][5], rb[it][7]};
-        }
+    auto park_one = [&](int it, int buf, const float (&ra)[WM_ITS][8], const float (&rb)[WM_ITS][8]) __attribute__((always_inline)) {
+        const int item = it * 256 + tid, r = item / WM_G8, g8 = item % WM_G8;
+        // pairs 4 g8 .. 4 g8 + 3 of the slab: p4 = g8; image index ((blk * 8 + p4) * 2 + hi) * 32 + (r & 31), blk = r >> 5
+        const int o = (((r >> 5) * (WM_KS / 8) + g8) * 2) * WM_UNIT + (r & 31) * 4 + buf * WM_IMG;
+        float *pa = sA0 + o, *pb = sB0 + o;
+        *(f32x4 *)pa = f32x4{ra[it][0], ra[it][2], ra[it][4], ra[it][6]};
+        *(f32x4 *)(pa + WM_UNIT) = f32x4{ra[it][1], ra[it][3], ra[it][5], ra[it][7]};
+        *(f32x4 *)pb = f32x4{rb[it][0], rb[it][2], rb[it][4], rb[it][6]};
+        *(f32x4 *)(pb + WM_UNIT) = f32x4{rb[it][1], rb[it][3], rb[it][5], rb[it][7]};
     };
 
     float bd = (METRIC == 0) ? INFINITY : -INFINITY;
     float bs = INFINITY;            // Euclidean: the clamped squared distance whose root is bd
     int bi = 0;
     const float x2r = s_x2[wave * 32 + j];
-    float ra[4][8], rb[4][8];
+    float ra[WM_ITS][8], rb[WM_ITS][8];
     fetch(0, 0, ra, rb);
+#pragma unroll
+    for (int it = 0; it < WM_ITS; ++it) park_one(it, 0, ra, rb);
+    __syncthreads();
+    int buf = 0;
     for (int grp = 0; grp < n_grp; ++grp) {
         f32x16w acc[WM_T];
 #pragma unroll
@@ -572,19 +587,18 @@ __global__ void __launch_bounds__(256, 2) vq_wide_mfma_kernel(const WideAssignAr
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
         for (int slab = 0; slab < n_slab; ++slab) {
-            __syncthreads();                                   // the previous slab's operands have been consumed
-            park(ra, rb);
-            __syncthreads();
-            {   // the next slab (of this group, or the first one of the next group) travels while this one is multiplied
-                int ns = slab + 1, ng = grp;
-                if (ns == n_slab) { ns = 0; ng = grp + 1; }
+            // the next slab (of this group, or the first one of the next group) is requested now, written into the other buffer from
+            // the second half of this slab's MFMAs, and published by the barrier that ends the slab
+            int ns = slab + 1, ng = grp;
+            if (ns == n_slab) { ns = 0; ng = grp + 1; }
+            const bool more = ng < n_grp;
 #ifndef WM_DEV_NOFETCH          // dev builds (timing only, wrong results): the operands of the first slab are multiplied again and again
-                if (ng < n_grp) fetch(ns, ng, ra, rb);
+            if (more) fetch(ns, ng, ra, rb);
 #endif
-            }
+            const float *const sA = sA0 + buf * WM_IMG, *const sB = sB0 + buf * WM_IMG;
             f32x4 b[WM_KS / 8];
 #pragma unroll
-            for (int p4 = 0; p4 < WM_KS / 8; ++p4) b[p4] = *(const f32x4 *)(sB + (((wave * (WM_KS / 8) + p4) * 2 + hi) * 32 + j) * 4);
+            for (int p4 = 0; p4 < WM_KS / 8; ++p4) b[p4] = *(const f32x4 *)(sB + ((wave * (WM_KS / 8) + p4) * 2 + hi) * WM_UNIT + j * 4);
             // One tile after the other, 32 MFMAs in a row on ONE accumulator (k ascending inside it, as before).  Taking turns between the
             // four accumulators after every MFMA -- the first version -- ran at 0.54 of the pipe's rate whatever was removed around
             // it (staging loads, epilogue, LDS prefetch distance: tools/time_wide_kernel.py with dev builds): an MFMA whose C operand is
@@ -593,20 +607,26 @@ __global__ void __launch_bounds__(256, 2) vq_wide_mfma_kernel(const WideAssignAr
             // always run one chain per wave).  A pieces: a ring of three, requested two steps ahead, pinned against the scheduler.
             constexpr int NQ = WM_T * (WM_KS / 8);
             f32x4 aq[3];
-            aq[0] = *(const f32x4 *)(sA + ((0 * 2 + hi) * 32 + j) * 4);
-            aq[1] = *(const f32x4 *)(sA + ((1 * 2 + hi) * 32 + j) * 4);
+            aq[0] = *(const f32x4 *)(sA + (0 * 2 + hi) * WM_UNIT + j * 4);
+            aq[1] = *(const f32x4 *)(sA + (1 * 2 + hi) * WM_UNIT + j * 4);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
                 const int t = q / (WM_KS / 8), p4 = q % (WM_KS / 8);
-                if (q + 2 < NQ) aq[(q + 2) % 3] = *(const f32x4 *)(sA + (((q + 2) * 2 + hi) * 32 + j) * 4);
+                if (q + 2 < NQ) aq[(q + 2) % 3] = *(const f32x4 *)(sA + ((q + 2) * 2 + hi) * WM_UNIT + j * 4);
                 __builtin_amdgcn_sched_barrier(0);
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[q % 3].x, b[p4].x, acc[t], 0, 0, 0);
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[q % 3].y, b[p4].y, acc[t], 0, 0, 0);
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[q % 3].z, b[p4].z, acc[t], 0, 0, 0);
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[q % 3].w, b[p4].w, acc[t], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
+                if (q >= NQ / 2 && (q - NQ / 2) % (NQ / 2 / WM_ITS) == 0) {       // WM_ITS times in the second half: a share of the next slab's operands
+                    if (more) park_one((q - NQ / 2) / (NQ / 2 / WM_ITS), buf ^ 1, ra, rb);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
+            __syncthreads();
+            buf ^= 1;
         }
         // ---- this group's codes, ascending per lane: register e of tile t <-> code 32 (grp WM_T + t) + 8 (e >> 2) + 4 hi + (e & 3) ----
         // Euclidean: the root is monotone, so a tile none of whose squared distances is below the best one's cannot hold a strictly
@@ -668,7 +688,32 @@ __global__ void __launch_bounds__(256, 2) vq_wide_mfma_kernel(const WideAssignAr
     __syncthreads();
     // ---- q rows and the commitment loss' squared error: one wave per row (as vq_wide_assign_kernel) ----
     double ds = 0.0;
-    if (a.q_out || a.sqerr_partial) {
+    // q rows alone (the training forward: the loss comes from the statistics pass), 16-byte accesses: four rows' pieces requested
+    // together -- element by element, row by row every load waited for the store in front of it (no restrict): ~0.2 ms of a 1.25 ms step
+    const bool q_fast = a.q_out && !a.sqerr_partial && (a.D & 3) == 0 && (((uintptr_t)a.embed) & 15) == 0 &&
+                        (((uintptr_t)a.q_out) & (a.q_bf16 ? 7 : 15)) == 0 && ((a.ldq * (a.q_bf16 ? 2 : 4)) & (a.q_bf16 ? 7 : 15)) == 0;
+    if (q_fast) {
+        for (int rr = wave * 4; rr < VQHIP_ASSIGN_ROWS_PER_BLOCK; rr += 16) {
+            for (int d = lane * 4; d < a.D; d += 256) {
+                f32x4 g[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) g[u] = *(const f32x4 *)(a.embed + (size_t)s_win[rr + u] * a.D + d);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int64_t r = r0 + rr + u;
+                    if (r >= a.N) continue;
+                    if (a.q_bf16) {
+                        uint2 o;
+                        o.x = (unsigned)wd_f32_to_bf16(g[u].x) | ((unsigned)wd_f32_to_bf16(g[u].y) << 16);
+                        o.y = (unsigned)wd_f32_to_bf16(g[u].z) | ((unsigned)wd_f32_to_bf16(g[u].w) << 16);
+                        *(uint2 *)((unsigned short *)a.q_out + r * a.ldq + d) = o;
+                    } else {
+                        *(f32x4 *)((float *)a.q_out + r * a.ldq + d) = g[u];
+                    }
+                }
+            }
+        }
+    } else if (a.q_out || a.sqerr_partial) {
         for (int rr = wave; rr < VQHIP_ASSIGN_ROWS_PER_BLOCK; rr += 4) {
             const int64_t r = r0 + rr;
             if (r >= a.N) break;
@@ -726,13 +771,16 @@ int vq_wide_assign(const void *x, int x_dtype, int64_t N, int D, int64_t ldx, co
     hipStream_t st = (hipStream_t)stream;
     const bool bf = x_dtype == VQHIP_BF16;
     if (wd_use_mfma()) {
+        static VqAttrOnce o00, o10, o01, o11;
+#define WM_LAUNCH(BF, M, ONCE) do { \
+            if (int rc = vq_set_max_smem(ONCE, (const void *)vq_wide_mfma_kernel<BF, M>, WM_SMEM, "vq_wide_mfma_kernel")) return rc; \
+            hipLaunchKernelGGL((vq_wide_mfma_kernel<BF, M>), grid, dim3(256), WM_SMEM, st, a); } while (0)
         if (metric == VQHIP_EUCLID) {
-            if (bf) hipLaunchKernelGGL((vq_wide_mfma_kernel<true, 0>), grid, dim3(256), 0, st, a);
-            else hipLaunchKernelGGL((vq_wide_mfma_kernel<false, 0>), grid, dim3(256), 0, st, a);
+            if (bf) WM_LAUNCH(true, 0, o10); else WM_LAUNCH(false, 0, o00);
         } else {
-            if (bf) hipLaunchKernelGGL((vq_wide_mfma_kernel<true, 1>), grid, dim3(256), 0, st, a);
-            else hipLaunchKernelGGL((vq_wide_mfma_kernel<false, 1>), grid, dim3(256), 0, st, a);
+            if (bf) WM_LAUNCH(true, 1, o11); else WM_LAUNCH(false, 1, o01);
         }
+#undef WM_LAUNCH
         return vq_launch_status("vq_wide_mfma_kernel");
     }
     if (metric == VQHIP_EUCLID) {
