@@ -29,7 +29,7 @@ for d in sorted(glob.glob(os.path.join(ROOT, "gpurun_out", tag + "[a-z]*"))):
         r = j.get("roofline") or {}
         rows.append((os.path.basename(f)[:-5], j["ms_per_step"], r.get("kernel_ms"), (j.get("config") or {}).get("workload", "")[:48],
                      r.get("rows_exact_pass_frac"), r.get("rows_pair_pass_frac"), j.get("screen_stress")))
-    dbs = sorted(glob.glob(os.path.join(d, "*", "*.db")))
+    dbs = sorted(glob.glob(os.path.join(d, "*", "*.db")) + glob.glob(os.path.join(d, "*.db")))
     txts = [t for t in sorted(glob.glob(os.path.join(d, "*.txt"))) if os.path.getsize(t) < 6000]
     if not rows and not dbs and not txts:
         continue
