@@ -190,30 +190,32 @@ int vq_wide_pack(const float *embed, int C, int D, float *packed, int H, void *s
 template <bool XBF16>
 __global__ void __launch_bounds__(256) vq_wide_sumsq_kernel(const void *x, int64_t N, int D, int64_t ldx, float *out)
 {
-    const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (n >= N) return;
-    out[n] = wd_aten_sumsq([&](int e) { return wd_load<XBF16>(x, n * ldx + e); }, D);
+    // a half-wave per row (eight rows per workgroup): the 32 chains of ATen's order on 32 lanes, 128 contiguous bytes per step
+    const int64_t n0 = (int64_t)blockIdx.x * 8 + (threadIdx.x >> 5);
+    const int64_t n = n0 < N ? n0 : N - 1;
+    const float v = wd_aten_sumsq_coop([&](int e) { return wd_load<XBF16>(x, n * ldx + e); }, D, (int)(threadIdx.x & 31));
+    if (n0 < N && (threadIdx.x & 31) == 0) out[n0] = v;
 }
 
 int vq_wide_row_sumsq(const void *x, int x_dtype, int64_t N, int D, int64_t ldx, float *out, void *stream)
 {
-    const unsigned blocks = (unsigned)((N + 255) / 256);
+    if (N <= 0) return 0;
+    const unsigned blocks = (unsigned)((N + 7) / 8);
     if (x_dtype == VQHIP_BF16) hipLaunchKernelGGL(vq_wide_sumsq_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, N, D, ldx, out);
     else hipLaunchKernelGGL(vq_wide_sumsq_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, N, D, ldx, out);
     return vq_launch_status("vq_wide_sumsq_kernel");
 }
 
 // l2norm of rows (vqp.py:37-38 at :1159): out = x / max(||x||, 1e-6), ||x||^2 in ATen order; bf16 tensors: norm and quotient rounded
-// to bf16 like the reference's bf16 ops -- the arithmetic of vqhip_l2norm_rows.  One wave per row; lane 0 sums (sequential order).
+// to bf16 like the reference's bf16 ops -- the arithmetic of vqhip_l2norm_rows.  One wave per row; both half-waves form the sum
+// cooperatively (the same value: ATen's order), instead of lane 0 walking the row alone.
 template <bool XBF16>
 __global__ void __launch_bounds__(256) vq_wide_l2norm_kernel(const void *x, int64_t N, int D, int64_t ldx, void *out, int64_t ldo)
 {
     const int lane = threadIdx.x & 63;
     const int64_t n = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (n >= N) return;
-    float x2 = 0.f;
-    if (lane == 0) x2 = wd_aten_sumsq([&](int e) { return wd_load<XBF16>(x, n * ldx + e); }, D);
-    x2 = __shfl(x2, 0, 64);
+    if (n >= N) return;         // (wave-uniform)
+    const float x2 = wd_aten_sumsq_coop([&](int e) { return wd_load<XBF16>(x, n * ldx + e); }, D, lane & 31);
     float nrm = sqrtf(x2);
     if (XBF16) nrm = wd_round_bf16(nrm);
     nrm = fmaxf(nrm, XBF16 ? wd_round_bf16(1e-6f) : 1e-6f);
