@@ -947,6 +947,38 @@ def test_grouped_residual_vq_batched_chain_equals_group_streams(dev, monkeypatch
         b.load_state_dict(a.state_dict())
 
 
+@pytest.mark.parametrize("kw,rows", [(dict(dim=512, groups=4, num_quantizers=4, codebook_size=512), (2, 20000)),
+                                     (dict(dim=128, groups=2, num_quantizers=3, codebook_size=300, shared_codebook=True, rotation_trick=False), (3, 1500)),
+                                     (dict(dim=256, groups=2, num_quantizers=3, codebook_size=128, commitment_weight=0.3), (1, 70000))])
+def test_grouped_residual_vq_batched_chain_with_input_grad_equals_group_streams(dev, monkeypatch, kw, rows):
+    """Round 6: an input that requires grad also runs the G groups as ONE chain (routed residuals, _GrvqFusedFn: every group's routed
+    output and gradient written into its feature chunk by vq_rvq_route_kernel) -- against the groups as separate ResidualVQ forwards
+    (_RvqFusedFn each, VQHIP_GRVQ_BATCHED=0): identical indices, outputs and input gradients bit for bit (the same kernels on the same
+    rows), losses / codebooks to the rounding of the segmented sums' atomics.  Rotation trick, straight-through, and a padding mask."""
+    from vector_quantize_pytorch_amd import GroupedResidualVQ
+    torch.manual_seed(0)
+    a, b = GroupedResidualVQ(**kw).to(dev).train(), GroupedResidualVQ(**kw).to(dev).train()
+    b.load_state_dict(a.state_dict())
+    for step in range(3):
+        x = torch.randn(*rows, kw["dim"], device=dev) * (1.0 + step)
+        mask = (torch.rand(*rows, device=dev) > 0.2) if step == 1 else None
+        w = torch.randn_like(x)
+        xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+        monkeypatch.setenv("VQHIP_GRVQ_BATCHED", "1")
+        assert a._batched_eligible(xa, xa.chunk(a.groups, -1), mask, False)
+        qa, ia, la = a(xa, mask=mask)
+        ((qa * w).sum() + 2.0 * la.sum()).backward()
+        monkeypatch.setenv("VQHIP_GRVQ_BATCHED", "0")
+        qb, ib, lb = b(xb, mask=mask)
+        ((qb * w).sum() + 2.0 * lb.sum()).backward()
+        torch.cuda.synchronize()
+        assert ia.shape == ib.shape and torch.equal(ia, ib) and torch.equal(qa, qb)
+        assert la.shape == lb.shape and torch.allclose(la, lb, rtol=1e-5, atol=1e-12) and la.requires_grad and lb.requires_grad
+        _close(xa.grad, xb.grad, 1e-6, "grad_x")
+        _close(a.codebooks, b.codebooks, 5e-5, "codebooks")
+        b.load_state_dict(a.state_dict())
+
+
 def test_grouped_rvq_train_step_with_side_streams_is_graph_capturable(dev):
     """GroupedResidualVQ forks one stream per group and one statistics stream per group inside forward; fork and join are events on
     the capturing stream, so the whole train step is still one HIP graph: replays match eager execution."""

@@ -983,12 +983,14 @@ def route_bwd(x: torch.Tensor, q: torch.Tensor, g_out, loss_coef, row_mask, mode
 
 @_on_device
 def rvq_route(x: torch.Tensor, embed: torch.Tensor, idx: torch.Tensor, Q: int, mode: int, *, g_out=None, loss_coef=None,
-              row_mask=None, backward=False, resid_routed=False, loss_only=False) -> torch.Tensor:
+              row_mask=None, backward=False, resid_routed=False, loss_only=False, out=None) -> torch.Tensor:
     """The residual loop's routed output (backward=False) or the gradient wrt x (backward=True) in ONE kernel that keeps the
     residual row in registers (csrc: vq_rvq_route_kernel; rvq.py:469-568 with quant_grad_frac = 0).
     x [..., D]; embed fp32 [Q', C, D] or [C, D] (shared); idx int64 [..., Q'] (first Q columns are used); mode 0 / STRAIGHT_THROUGH /
     ROTATION; loss_coef: [Q] fp32 device tensor, d loss / d (sum of squared errors of stage q).  resid_routed: the residuals are
-    re-derived as r - route(r, c) (what rvq.py:524 subtracts when the layers returned routed values) instead of r - c."""
+    re-derived as r - route(r, c) (what rvq.py:524 subtracts when the layers returned routed values) instead of r - c.
+    out: where the result goes -- x's shape and dtype, rows at a uniform stride (a feature chunk of a wider tensor: the groups of a
+    GroupedResidualVQ write their columns of one output)."""
     _need_gpu(x, embed, idx, g_out, loss_coef, row_mask)
     xk, N, D, ldx = as_rows(x)
     assert idx.dtype == torch.int64 and idx.is_contiguous() and embed.dtype == torch.float32 and embed.is_contiguous()
@@ -1009,10 +1011,15 @@ def rvq_route(x: torch.Tensor, embed: torch.Tensor, idx: torch.Tensor, Q: int, m
     if row_mask is not None:
         row_mask = row_mask.reshape(-1).to(torch.uint8).contiguous()
         assert row_mask.numel() == N
-    out = torch.empty(x.shape, dtype=x.dtype, device=x.device)
+    ldo = D
+    if out is None:
+        out = torch.empty(x.shape, dtype=x.dtype, device=x.device)
+    else:
+        ok_, oN, oD, ldo = as_rows(out)
+        assert out.shape == x.shape and out.dtype == x.dtype and ok_.data_ptr() == out.data_ptr() and oN == N and oD == D, "rvq_route: out must be rows at a uniform stride"
     if N > 0:
         _check(lib().vqhip_rvq_route(_ptr(xk), _dtype_code(xk), N, D, ldx, _ptr(embed), qstride, C, _ptr(idx), qs, Q, mode,
-                                     1 if resid_routed else 0, _ptr(gk), ldg, _ptr(loss_coef), _ptr(row_mask), 1 if backward else 0, _ptr(out), D, _stream()),
+                                     1 if resid_routed else 0, _ptr(gk), ldg, _ptr(loss_coef), _ptr(row_mask), 1 if backward else 0, _ptr(out), ldo, _stream()),
                "vqhip_rvq_route")
     return out
 

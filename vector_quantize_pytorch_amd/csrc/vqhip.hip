@@ -4551,6 +4551,10 @@ __global__ void __launch_bounds__(256) vq_decode_kernel(const int64_t *__restric
 // 8 lanes per row, 16 bytes each, the Q gathers come from LDS (conflict-free: consecutive lanes, consecutive 16-byte pieces of a
 // 128-byte row), the sums run in stage order like the reference's (rvq.py:525), and every store is a whole 128-byte line.
 #define VQ_DECODE_LDS_COLS 32
+#ifndef VQ_DECODE_LDS_PAD
+#define VQ_DECODE_LDS_PAD 0           // floats of padding behind a code's 32-column piece in LDS
+#endif
+#define VQ_DECODE_LDS_ROW (VQ_DECODE_LDS_COLS + VQ_DECODE_LDS_PAD)
 __global__ void __launch_bounds__(1024) vq_decode_lds_kernel(const int64_t *__restrict__ idx, int64_t N, int Q, const float *__restrict__ embed,
                                                              int C, int D, void *out, int out_bf16, int64_t ldo, int rows_per_block)
 {
@@ -4561,7 +4565,7 @@ __global__ void __launch_bounds__(1024) vq_decode_lds_kernel(const int64_t *__re
     const int64_t rb = blockIdx.x / nsl;                   // row chunk
     // codes: 8 lanes x 16 bytes per code row slice
     for (int i = tid; i < C * 8; i += blockDim.x)
-        *(f32x4 *)(smem + (size_t)i * 16) = *(const f32x4 *)(embed + (size_t)(i >> 3) * D + sl * VQ_DECODE_LDS_COLS + (i & 7) * 4);
+        *(f32x4 *)(smem + ((size_t)(i >> 3) * VQ_DECODE_LDS_ROW + (i & 7) * 4) * 4) = *(const f32x4 *)(embed + (size_t)(i >> 3) * D + sl * VQ_DECODE_LDS_COLS + (i & 7) * 4);
     __syncthreads();
     const int part = tid & 7;                              // which 16 bytes of the slice
     const int64_t r0 = rb * rows_per_block, r1 = (r0 + rows_per_block < N) ? r0 + rows_per_block : N;
@@ -4574,7 +4578,7 @@ __global__ void __launch_bounds__(1024) vq_decode_lds_kernel(const int64_t *__re
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int c = __shfl(lo, (threadIdx.x & 63 & ~7) + u, 64);
-                if (q0 + u < Q && c >= 0 && c < C) s += *(const f32x4 *)(smem + ((size_t)c * 8 + part) * 16);   // a skipped stage adds nothing
+                if (q0 + u < Q && c >= 0 && c < C) s += *(const f32x4 *)(smem + ((size_t)c * VQ_DECODE_LDS_ROW + part * 4) * 4);   // a skipped stage adds nothing
             }
         }
         const int d = sl * VQ_DECODE_LDS_COLS + part * 4;
@@ -4611,9 +4615,9 @@ extern "C" int vqhip_decode_sum_range(const int64_t *idx, int64_t idx_stride, in
                      ((((uintptr_t)out) % (4 * oes)) == 0) && ((ldo * oes) % (4 * oes) == 0);
     if (vec && Q >= 2 && (embed_qstride == 0 || Q == 1) && C <= 1024 && D % VQ_DECODE_LDS_COLS == 0 && N >= 16384 && !accumulate && idx_stride == Q) {
         // shared codebook, several stages: the codes' column slices live in LDS (the gathers from L2 were the bound)
-        const int smem = C * VQ_DECODE_LDS_COLS * 4;
+        const int smem = C * VQ_DECODE_LDS_ROW * 4;
         static VqAttrOnce once;
-        if (int rc = vq_set_max_smem(once, (const void *)vq_decode_lds_kernel, 1024 * VQ_DECODE_LDS_COLS * 4, "vq_decode_lds_kernel")) return rc;
+        if (int rc = vq_set_max_smem(once, (const void *)vq_decode_lds_kernel, 1024 * VQ_DECODE_LDS_ROW * 4, "vq_decode_lds_kernel")) return rc;
         const int nsl = D / VQ_DECODE_LDS_COLS;
         // about four workgroups per CU and slice-group; every workgroup re-reads its slice of the codebook (C * 128 bytes)
         int64_t chunks = (256 * 4) / nsl; if (chunks < 1) chunks = 1;

@@ -677,6 +677,48 @@ class _RvqFusedFn(torch.autograd.Function):
         return gx, None, None, None, None
 
 
+class _GrvqFusedFn(torch.autograd.Function):
+    """GroupedResidualVQ's batched chain for an input that requires grad (round 6): _RvqFusedFn for all groups at once -- ONE chain with
+    routed residuals for the G groups (GroupedResidualVQ._forward_batched), then every group's routed output / gradient written into
+    its feature chunk of one tensor by vq_rvq_route_kernel (the groups share nothing: rvq.py:706)."""
+
+    @staticmethod
+    def forward(ctx, x, grvq, mask, freeze_codebook):
+        aux = {}
+        _, idx, losses = grvq._forward_batched(x, mask, freeze_codebook, aux=aux)
+        G, D = grvq.groups, grvq.rvqs[0].codebook_dim
+        mode = grvq.rvqs[0]._route_mode()
+        xc = x if x.is_contiguous() else x.contiguous()
+        out = torch.empty_like(xc)
+        for g in range(G):
+            L.rvq_route(xc[..., g * D:(g + 1) * D], aux["embed"][g], idx[g], aux["Q"], mode, resid_routed=True, out=out[..., g * D:(g + 1) * D])
+        ctx.mode, ctx.Q, ctx.G, ctx.D, ctx.loss_scale, ctx.has_mask = mode, aux["Q"], G, D, aux.get("loss_scale"), mask is not None
+        ctx.save_for_backward(xc, idx, aux["embed"], *([mask] if mask is not None else []))
+        ctx.mark_non_differentiable(idx)
+        return out, idx, losses
+
+    @staticmethod
+    def backward(ctx, g_out, g_idx, g_losses):
+        x, idx, embed = ctx.saved_tensors[:3]
+        mask = ctx.saved_tensors[3] if ctx.has_mask else None
+        G, D, Q = ctx.G, ctx.D, ctx.Q
+        coef = None
+        if g_losses is not None and ctx.loss_scale is not None:
+            coef = (g_losses[:, :Q].to(torch.float32) * ctx.loss_scale).contiguous()          # [G, Q]
+        use_g = ctx.mode != 0 and g_out is not None
+        if not use_g and coef is None:
+            return None, None, None, None
+        if use_g:
+            g_out = L.rows_contiguous(g_out)
+        gx = torch.empty_like(x)
+        for g in range(G):
+            sl = slice(g * D, (g + 1) * D)
+            L.rvq_route(x[..., sl], embed[g], idx[g], Q, ctx.mode, g_out=g_out[..., sl] if use_g else None,
+                        loss_coef=None if coef is None else coef[g], row_mask=mask, backward=True, resid_routed=True, loss_only=not use_g,
+                        out=gx[..., sl])
+        return gx, None, None, None
+
+
 _SIDE_STREAMS = {}
 _STATS_STREAMS = {}
 
@@ -752,8 +794,11 @@ class GroupedResidualVQ(nn.Module):
         for r, c in zip(self.rvqs, chunks):
             beam = r.beam_size if r.training else r.eval_beam_size
             if (r.has_projections or r.diveq or (beam is not None and beam > 1) or (r.training and r.quantize_dropout)
-                    or r.training != r0.training or r._wants_input_grad(c) or not r._fused_eligible(c, mask)
-                    or not r._chain_eligible(c, freeze_codebook) or r.layers[0]._codebook.use_cosine_sim):
+                    or r.training != r0.training or not r._fused_eligible(c, mask) or r.layers[0]._codebook.use_cosine_sim):
+                return False
+            # an input that requires grad: the chain with routed residuals (_GrvqFusedFn below), the same mode in every group
+            grad = r._wants_input_grad(c)
+            if not r._chain_eligible(c, freeze_codebook, routed=grad and r._route_mode() != 0) or r._route_mode() != r0._route_mode():
                 return False
             for layer in r.layers:
                 cb = layer._codebook
@@ -772,10 +817,13 @@ class GroupedResidualVQ(nn.Module):
         return cached[1]
 
     @torch.no_grad()
-    def _forward_batched(self, x, mask, freeze_codebook):
+    def _forward_batched(self, x, mask, freeze_codebook, aux=None):
         """rvq.py:634-724 with the loop over the groups (:706) as grid dimension y of ONE residual chain: Q x (screen + exact passes +
         statistics) launches for all groups, the decode of every group straight into its feature chunk of the output (no torch.cat),
-        all G x Q EMA folds in three launches."""
+        all G x Q EMA folds in three launches.
+        aux (dict, filled for _GrvqFusedFn: the input requires grad): every stage's input is the previous one minus the previous layer's
+        ROUTED value (the chain's route_mode, as ResidualVQ._forward_fused), no output is decoded here (the caller routes it), and aux
+        receives the codebooks the searches used, Q and d loss / d (sum of squared errors)."""
         G, r0 = self.groups, self.rvqs[0]
         Q, D, C = r0.num_quantizers, r0.codebook_dim, r0.codebook_size
         vq0 = r0.layers[0]
@@ -808,16 +856,21 @@ class GroupedResidualVQ(nn.Module):
         # -- built, bit-identical (test_residual_chain_decode_split_...), and MEASURED SLOWER: cfg 5 14.07 -> 14.66 ms (the gathers of 7 x 4
         # stages beside the last screening kernel outlast it and hold back the last stage's statistics behind them), cfg 3 2.73 -> 2.95.
         # Off by default (VQHIP_CHAIN_DECODE=1 / 2 turn it on).
-        split = (side is not None and Q >= 2 and mask is None and x.dtype == torch.float32 and os.environ.get("VQHIP_CHAIN_DECODE", "0") != "0")
-        r = L.rvq_chain_forward(x, packed, embed, Q, row_mask=mask, row_chunks=K, stats=buf, stats_ws=stats_ws, sq_parts=sq_parts,
-                                stats_stream=side, groups=G, decode_out=out if split else None)
+        route_mode = r0._route_mode() if aux is not None else 0
+        split = (aux is None and side is not None and Q >= 2 and mask is None and x.dtype == torch.float32
+                 and os.environ.get("VQHIP_CHAIN_DECODE", "0") != "0")
+        r = L.rvq_chain_forward(x, packed, embed, Q, row_mask=mask, route_mode=route_mode, row_chunks=K, stats=buf, stats_ws=stats_ws,
+                                sq_parts=sq_parts, stats_stream=side, groups=G, decode_out=out if split else None)
         self.last_counts = r["counts"]                  # per stage: (open rows, pair rows) counters [chunks, G] (device, diagnostic)
         idx = r["idx"]                                  # [G, b, n, Q]
         if mask is not None:
             if side is not None:
                 main.wait_stream(side)                  # the statistics passes have read idx
             idx.masked_fill_(~mask.reshape(1, *idx.shape[1:-1], 1).bool(), -1)
-        if not split:
+        if aux is not None:
+            aux["embed"], aux["Q"] = embed, Q           # (torch.stack above copied: the folds below rewrite the module buffers)
+            out = None
+        elif not split:
             for g in range(G):
                 L.decode_sum(idx[g], embed[g], out=out[..., g * D:(g + 1) * D])
 
@@ -834,7 +887,9 @@ class GroupedResidualVQ(nn.Module):
             sums = L.reduce_partials_rows(sq_parts.view(G * Q, -1)).view(G, Q)
             denom = float(N * D) if mask is None else (mask.sum() * D).to(torch.float32)
             losses = sums / denom * vq0.commitment_weight
-        if self.training:
+            if aux is not None:
+                aux["loss_scale"] = vq0.commitment_weight / denom            # float, or a 0-dim device tensor under a mask
+        if self.training and aux is None:
             losses = torch.zeros(G, Q, device=dev, requires_grad=True) + losses                            # as vqp.py:1282
 
         if update:
@@ -869,7 +924,10 @@ class GroupedResidualVQ(nn.Module):
         kw = dict(return_all_codes=return_all_codes, sample_codebook_temp=sample_codebook_temp, mask=mask,
                   freeze_codebook=freeze_codebook, rand_quantize_dropout_fixed_seed=seed)
         if self._batched_eligible(x, chunks, mask, freeze_codebook):
-            ret = self._forward_batched(x, mask, freeze_codebook)
+            if self.rvqs[0]._wants_input_grad(x):
+                ret = _GrvqFusedFn.apply(x, self, mask, freeze_codebook)
+            else:
+                ret = self._forward_batched(x, mask, freeze_codebook)
             if return_all_codes:
                 ret = (*ret, self.get_codes_from_indices(ret[1]))
             return ret
