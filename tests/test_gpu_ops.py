@@ -55,6 +55,8 @@ def test_row_sumsq_matches_aten_order(dev, N, D):
     (300, 100, 640, torch.bfloat16, True),
     (129, 37, 2048, torch.float32, False),
     (200, 65, 1001, torch.float32, True),        # odd wide D
+    (1000, 260, 776, torch.float32, False),      # a partial 32-feature slab AND a partial group of 128 codes on the 16-byte staging path
+    (700, 130, 1000, torch.bfloat16, True),
 ])
 def test_assign_euclid_bitexact(dev, N, C, D, dtype, unit):
     from vector_quantize_pytorch_amd import _lib as L
@@ -74,6 +76,19 @@ def test_assign_euclid_bitexact(dev, N, C, D, dtype, unit):
     sq = r["sqerr_partials"][: r["nblk"]].sum().item()
     want_sq = ((want_q.double() - x.double()) ** 2).sum().item()
     assert abs(sq - want_sq) <= 1e-5 * max(want_sq, 1e-12)
+
+
+@pytest.mark.parametrize("N,C,D,dtype", [(1000, 300, 768, torch.float32), (333, 70, 1024, torch.bfloat16), (129, 37, 1001, torch.float32)])
+def test_wide_assign_q_rows_without_the_loss(dev, N, C, D, dtype):
+    """The training forward of a wide-dim codebook asks for indices + q rows only (the loss comes from the statistics pass): the q rows
+    are written four rows' 16-byte pieces at a time (odd D: element by element) -- the same rows as embed[idx], bit for bit."""
+    from vector_quantize_pytorch_amd import _lib as L
+    x, e = _mk(N, C, D, dtype, False)
+    xd, ed = x.to(dev), e.to(dev)
+    r = L.assign(xd, L.pack_codebook(ed), ed, want_q=True)
+    idx_o, _ = O.c_assign(x.float(), e)
+    assert torch.equal(r["idx"].cpu(), idx_o)
+    assert torch.equal(r["q"].cpu(), e[idx_o].to(dtype))
 
 
 @pytest.mark.parametrize("N,C,D,dtype", [(1024, 512, 256, torch.float32), (999, 1000, 512, torch.float32),
