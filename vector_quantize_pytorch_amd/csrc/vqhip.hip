@@ -4552,7 +4552,9 @@ __global__ void __launch_bounds__(256) vq_decode_kernel(const int64_t *__restric
 // 128-byte row), the sums run in stage order like the reference's (rvq.py:525), and every store is a whole 128-byte line.
 #define VQ_DECODE_LDS_COLS 32
 #ifndef VQ_DECODE_LDS_PAD
-#define VQ_DECODE_LDS_PAD 0           // floats of padding behind a code's 32-column piece in LDS
+#define VQ_DECODE_LDS_PAD 0           // floats of padding behind a code's 32-column piece in LDS.  rocprofv3 counts bank conflicts on 90 % of
+                                      // this kernel's LDS cycles (eight random 128-byte pieces per wave read: even codes on banks 0 .. 31, odd
+                                      // ones on 32 .. 63); 4 / 8 floats of padding measured 105 / 100 us against 104 (cfg-3 shape): not the bound
 #endif
 #define VQ_DECODE_LDS_ROW (VQ_DECODE_LDS_COLS + VQ_DECODE_LDS_PAD)
 __global__ void __launch_bounds__(1024) vq_decode_lds_kernel(const int64_t *__restrict__ idx, int64_t N, int Q, const float *__restrict__ embed,
